@@ -1,0 +1,129 @@
+"""ctypes mirror of include/dgsqp.h and the loader of the HIP library.
+
+There is deliberately no CPU fallback: if ``libdgsqp_hip.so`` is missing or
+cannot be loaded, ``load_library()`` raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import pathlib
+
+MAX_AGENTS = 4
+MAX_SEGS = 16
+MAX_NQA = 8
+NUA = 2
+
+STATUS_MSG = ['conv_abs_tol', 'conv_rel_tol', 'max_it', 'diverged', 'qp_fail', 'time_limit']
+
+dbl2 = C.c_double * NUA
+
+
+class AgentT(C.Structure):
+    _fields_ = [
+        ('model', C.c_int32), ('tire_model', C.c_int32), ('drive_wheels', C.c_int32), ('simple_slip', C.c_int32),
+        ('L_f', C.c_double), ('L_r', C.c_double), ('mass', C.c_double), ('I_z', C.c_double), ('gravity', C.c_double),
+        ('c_dr', C.c_double), ('c_da', C.c_double), ('c_s', C.c_double), ('c_r', C.c_double), ('p_r', C.c_double),
+        ('pac_Bf', C.c_double), ('pac_Br', C.c_double), ('pac_Cf', C.c_double), ('pac_Cr', C.c_double),
+        ('pac_Df', C.c_double), ('pac_Dr', C.c_double), ('lin_Bf', C.c_double), ('lin_Br', C.c_double),
+        ('w_in', dbl2), ('w_rate', dbl2), ('w_prog', C.c_double), ('w_comp', C.c_double),
+        ('comp_type', C.c_int32), ('_pad0', C.c_int32),
+        ('w_block', C.c_double), ('w_obs', C.c_double), ('obs_cost_r', C.c_double),
+        ('has_rate', C.c_int32), ('_pad1', C.c_int32),
+        ('rate_ub', dbl2), ('rate_lb', dbl2), ('in_ub', dbl2), ('in_lb', dbl2),
+        ('st_ub', C.c_double * MAX_NQA), ('st_lb', C.c_double * MAX_NQA),
+        ('radius', C.c_double),
+    ]
+
+
+class ProblemT(C.Structure):
+    _fields_ = [
+        ('M', C.c_int32), ('N', C.c_int32), ('integrator', C.c_int32), ('substeps', C.c_int32),
+        ('dt', C.c_double),
+        ('n_segs', C.c_int32), ('obstacle_rows', C.c_int32),
+        ('track_L', C.c_double),
+        ('seg_s', C.c_double * (MAX_SEGS + 1)), ('seg_curv', C.c_double * MAX_SEGS),
+        ('seg_ang', C.c_double * (MAX_SEGS + 1)),
+        ('agents', AgentT * MAX_AGENTS),
+    ]
+
+
+class ParamsT(C.Structure):
+    _fields_ = [
+        ('beta', C.c_double), ('tau', C.c_double), ('p_tol', C.c_double), ('d_tol', C.c_double), ('reg', C.c_double),
+        ('line_search_iters', C.c_int32), ('nonmono_ls', C.c_int32), ('sqp_iters', C.c_int32),
+        ('merit_function', C.c_int32), ('rel_tol_req', C.c_int32), ('lsqr_iter_lim', C.c_int32),
+        ('lsqr_atol', C.c_double), ('lsqr_btol', C.c_double),
+    ]
+
+
+class DimsT(C.Structure):
+    _fields_ = [('M', C.c_int32), ('N', C.c_int32), ('n_q', C.c_int32), ('n_u', C.c_int32), ('n', C.c_int32),
+                ('n_c', C.c_int32), ('n_dense', C.c_int32), ('lds_bytes', C.c_int32),
+                ('workspace_bytes', C.c_int64)]
+
+
+class TimingT(C.Structure):
+    _fields_ = [('h2d_ms', C.c_double), ('kernel_ms', C.c_double), ('d2h_ms', C.c_double), ('total_ms', C.c_double),
+                ('grid', C.c_int32), ('block', C.c_int32)]
+
+
+_PD = C.POINTER(C.c_double)
+_PI = C.POINTER(C.c_int32)
+_LIB = None
+
+
+def library_path() -> pathlib.Path:
+    env = os.environ.get('DGSQP_HIP_LIB')
+    if env:
+        return pathlib.Path(env)
+    return pathlib.Path(__file__).resolve().parent / 'csrc' / 'libdgsqp_hip.so'
+
+
+def load_library() -> C.CDLL:
+    """Load the HIP solver library; raise loudly if it is absent (no CPU fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not path.exists():
+        raise RuntimeError(f'HIP solver library {path} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                           f'(hipcc --offload-arch=gfx950). There is no CPU fallback.')
+    lib = C.CDLL(str(path))
+    H = C.c_void_p
+    lib.dgsqp_create.argtypes = [C.POINTER(ProblemT), C.POINTER(ParamsT), C.c_int, C.POINTER(H)]
+    lib.dgsqp_create.restype = C.c_int
+    lib.dgsqp_destroy.argtypes = [H]
+    lib.dgsqp_destroy.restype = None
+    lib.dgsqp_dims.argtypes = [H, C.POINTER(DimsT)]
+    lib.dgsqp_dims.restype = C.c_int
+    lib.dgsqp_last_error.argtypes = [H]
+    lib.dgsqp_last_error.restype = C.c_char_p
+    lib.dgsqp_backend_info.argtypes = [C.c_char_p, C.c_int]
+    lib.dgsqp_backend_info.restype = C.c_int
+    lib.dgsqp_solve_batch.argtypes = [H, C.c_int64, _PD, _PD, _PD, _PD, _PD, _PI, _PI, _PI, _PD, _PD, C.POINTER(TimingT)]
+    lib.dgsqp_solve_batch.restype = C.c_int
+    lib.dgsqp_stage_inputs.argtypes = [H, C.c_int64, _PD, _PD]
+    lib.dgsqp_stage_inputs.restype = C.c_int
+    lib.dgsqp_solve_staged.argtypes = [H, C.POINTER(TimingT)]
+    lib.dgsqp_solve_staged.restype = C.c_int
+    lib.dgsqp_fetch_results.argtypes = [H, _PD, _PD, _PD, _PI, _PI, _PI, _PD, _PD]
+    lib.dgsqp_fetch_results.restype = C.c_int
+    lib.dgsqp_evaluate_batch.argtypes = [H, C.c_int64, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD]
+    lib.dgsqp_evaluate_batch.restype = C.c_int
+    lib.dgsqp_qp_batch.argtypes = [H, C.c_int64, _PD, _PD, _PD, _PD, _PD, _PD, _PI]
+    lib.dgsqp_qp_batch.restype = C.c_int
+    _LIB = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = ['dgsqp_create', 'dgsqp_destroy', 'dgsqp_dims', 'dgsqp_last_error', 'dgsqp_backend_info',
+                    'dgsqp_solve_batch', 'dgsqp_stage_inputs', 'dgsqp_solve_staged', 'dgsqp_fetch_results',
+                    'dgsqp_evaluate_batch', 'dgsqp_qp_batch']
+
+
+def dptr(a):
+    return None if a is None else a.ctypes.data_as(_PD)
+
+
+def iptr(a):
+    return None if a is None else a.ctypes.data_as(_PI)

@@ -1,0 +1,247 @@
+"""Monte-Carlo drivers: game presets and batched scenario samplers.
+
+Counterpart of the callers of the hot path,
+scripts/DGSQP_ALGAMES_monte_carlo_{chicane,curve}.py: the same game
+definitions (bounds :80-109, cost weights :111-122, radii :126-129, solver
+parameters :161-174), the same rejection sampler for initial conditions
+(:384-404) and the same PID-rollout warm start with collision rejection
+(:411-467) -- vectorised over a batch so that B scenarios can be handed to
+``DGSQP.solve_batch`` at once.  The plant used for the warm start is a
+fixed-step RK4 of the continuous model (the reference integrates the same
+``fc`` with adaptive RK45 ``solve_ivp``, dynamics_models.py:170).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List
+
+import numpy as np
+
+from .dynamics import (CasadiDecoupledMultiAgentDynamicsModel, CasadiDynamicBicycleCombined,
+                       CasadiKinematicBicycleCombined, DynamicBicycleConfig, KinematicBicycleConfig,
+                       MultiAgentModelConfig)
+from .game import CollisionAvoidance, InputRateLimits, RacingCost
+from .solver_types import DGSQPParams
+from .tracks import ChicaneTrack, CurveTrack
+from .types import (BodyAngularVelocity, BodyLinearVelocity, OrientationEuler, ParametricPose, Position,
+                    VehicleActuation, VehicleState)
+
+
+@dataclass
+class Game:
+    """Everything ``DGSQP(...)`` takes, plus what the sampler needs."""
+    joint_model: CasadiDecoupledMultiAgentDynamicsModel
+    costs: List[RacingCost]
+    agent_constraints: list
+    shared_constraints: CollisionAvoidance
+    bounds: dict
+    params: DGSQPParams
+    track: object
+    half_width: float
+    obs_d: float
+    name: str = ''
+
+    def solver_args(self):
+        return (self.joint_model, self.costs, self.agent_constraints, self.shared_constraints, self.bounds, self.params)
+
+
+def _bounds(half_width, M, u_a=2.1, u_steer=0.436):
+    inf = np.inf
+    ub = [VehicleState(x=Position(x=inf, y=inf), p=ParametricPose(s=inf, x_tran=half_width, e_psi=inf),
+                       e=OrientationEuler(psi=inf), v=BodyLinearVelocity(v_long=inf, v_tran=inf),
+                       w=BodyAngularVelocity(w_psi=inf), u=VehicleActuation(u_a=u_a, u_steer=u_steer)) for _ in range(M)]
+    lb = [VehicleState(x=Position(x=-inf, y=-inf), p=ParametricPose(s=-inf, x_tran=-half_width, e_psi=-inf),
+                       e=OrientationEuler(psi=-inf), v=BodyLinearVelocity(v_long=-inf, v_tran=-inf),
+                       w=BodyAngularVelocity(w_psi=-inf), u=VehicleActuation(u_a=-u_a, u_steer=-u_steer)) for _ in range(M)]
+    return {'ub': ub, 'lb': lb}
+
+
+def _track(kind, theta_deg, half_width):
+    th = theta_deg * np.pi / 180
+    if kind == 'chicane':   # chicane.py:140-149
+        return ChicaneTrack(enter_straight_length=1, curve1_length=4, curve1_swept_angle=th, mid_straight_length=1,
+                            curve2_length=4, curve2_swept_angle=th, exit_straight_length=5,
+                            width=half_width * 2, slack=0.8, mirror=False)
+    if kind == 'curve':     # curve.py:140-146
+        return CurveTrack(enter_straight_length=1, curve_length=8, curve_swept_angle=th, exit_straight_length=5,
+                          width=half_width * 2, slack=0.8, ccw=True)
+    raise ValueError(kind)
+
+
+def kinematic_racing_game(track_kind='chicane', theta_deg=45, N=25, reg=1e-3, M=2, nonmono_ls=True,
+                          merit_function='stat_l1') -> Game:
+    """2-agent kinematic-bicycle race of chicane.py / curve.py (euler, dt 0.1)."""
+    dt, half_width = 0.1, 1.0
+    track = _track(track_kind, theta_deg, half_width)
+    cfg = lambda: KinematicBicycleConfig(dt=dt, model_name='kinematic_bicycle_cl', noise=False,
+                                         discretization_method='euler', wheel_dist_front=0.13, wheel_dist_rear=0.13,
+                                         drag_coefficient=0.1, slip_coefficient=0.1, code_gen=False)
+    models = [CasadiKinematicBicycleCombined(0, cfg(), track=track) for _ in range(M)]
+    joint = CasadiDecoupledMultiAgentDynamicsModel(0, models, MultiAgentModelConfig(
+        dt=dt, discretization_method='euler', use_mx=True, code_gen=False, verbose=True, compute_hessians=True))
+    chicane = track_kind == 'chicane'
+    steer_rate = np.pi if chicane else 4.5          # chicane.py:92-93 vs curve.py:94-95
+    r = 0.4 if chicane else 0.2                     # chicane.py:126-127 vs curve.py:128-129
+    params = DGSQPParams(solver_name='SQGAMES', dt=dt, N=N, reg=reg, nonmono_ls=nonmono_ls, line_search_iters=50,
+                         sqp_iters=50, p_tol=1e-3, d_tol=1e-3, beta=0.01, tau=0.5, verbose=False,
+                         merit_function=merit_function)
+    cost = lambda: RacingCost(input_weight=(1.0, 1.0), input_rate_weight=(1.0, 1.0), comp_weights=(10.0, 5.0),
+                              comp_type='atan', blocking_weight=0, obs_weight=0, obs_r=0.3)
+    return Game(joint, [cost() for _ in range(M)],
+                [InputRateLimits((10.0, steer_rate), (-10.0, -steer_rate)) for _ in range(M)],
+                CollisionAvoidance([r] * M), _bounds(half_width, M), params, track, half_width, 2 * r,
+                name=f'kb_{track_kind}_N{N}')
+
+
+def dynamic_racing_game(track_kind='curve', theta_deg=45, N=25, reg=1e-3, rk4_substeps=10) -> Game:
+    """BASELINE.json config 2: 2-agent dynamic-bicycle (Pacejka) race on the curve track.
+    Vehicle / integrator from comparison_study_barc/exact_dynamic_game_dynamic.py:26-66 and
+    globals.py:17-18 (rk4, M=10); costs / constraints / bounds of curve.py."""
+    dt, half_width, M = 0.1, 1.0, 2
+    track = _track(track_kind, theta_deg, half_width)
+    cfg = lambda: DynamicBicycleConfig(dt=dt, model_name='dynamic_bicycle', noise=False, discretization_method='rk4',
+                                       simple_slip=False, tire_model='pacejka', mass=2.2187, yaw_inertia=0.02723,
+                                       wheel_friction=0.9, pacejka_b_front=5.0, pacejka_b_rear=5.0,
+                                       pacejka_c_front=2.28, pacejka_c_rear=2.28, M=rk4_substeps)
+    models = [CasadiDynamicBicycleCombined(0, cfg(), track=track) for _ in range(M)]
+    joint = CasadiDecoupledMultiAgentDynamicsModel(0, models, MultiAgentModelConfig(
+        dt=dt, discretization_method='rk4', use_mx=False, code_gen=False, verbose=False, compute_hessians=True,
+        M=rk4_substeps))
+    r = 0.2
+    params = DGSQPParams(solver_name='DGSQP', dt=dt, N=N, reg=reg, nonmono_ls=True, line_search_iters=50,
+                         sqp_iters=50, p_tol=1e-3, d_tol=1e-3, beta=0.01, tau=0.5, verbose=False)
+    cost = lambda: RacingCost(input_weight=(1.0, 1.0), input_rate_weight=(1.0, 1.0), comp_weights=(10.0, 5.0),
+                              comp_type='atan')
+    return Game(joint, [cost() for _ in range(M)], [InputRateLimits((10.0, 4.5), (-10.0, -4.5)) for _ in range(M)],
+                CollisionAvoidance([r] * M), _bounds(half_width, M), params, track, half_width, 2 * r,
+                name=f'dyn_{track_kind}_N{N}')
+
+
+# ---------------------------------------------------------------------------------------------
+# vectorised plant for the PID warm start
+# ---------------------------------------------------------------------------------------------
+def _track_lookup(track, s):
+    L, seg_s, seg_curv, ang = track.tables()
+    sb = np.fmod(np.fmod(s, L) + L, L)
+    idx = np.clip(np.searchsorted(seg_s, sb, side='right') - 1, 0, len(seg_curv) - 1)
+    curv = seg_curv[idx]
+    slope = (ang[idx + 1] - ang[idx]) / (seg_s[idx + 1] - seg_s[idx])
+    return curv, ang[idx] + slope * (sb - seg_s[idx])
+
+
+def _fc_batch(model, q, u):
+    """Continuous dynamics for a batch: q [B, n_q], u [B, 2] (same equations as model.fc)."""
+    c = model.model_config
+    ua, us = u[:, 0], u[:, 1]
+    absv = lambda x: np.where(x > 0, x, -x)
+    if model.model_id == 0:
+        v, epsi, s, ey = q[:, 2], q[:, 3], q[:, 4], q[:, 5]
+        beta = np.arctan2(np.tan(us) * model.L_r, model.L_f + model.L_r)
+        psidot = v / model.L_r * np.sin(beta)
+        F = -model.c_da * v - model.c_dr * v * absv(v) - model.c_s * psidot ** 2
+        curv, psi_t = _track_lookup(model.track, s)
+        den = 1 - ey * curv
+        return np.stack([v * np.cos(beta + psi_t + epsi), v * np.sin(beta + psi_t + epsi), ua + F / model.m,
+                         psidot - curv * v * np.cos(beta + epsi) / den, v * np.cos(beta + epsi) / den,
+                         v * np.sin(beta + epsi)], axis=1)
+    vx, vy, w, epsi, s, ey = q[:, 2], q[:, 3], q[:, 4], q[:, 5], q[:, 6], q[:, 7]
+    curv, psi_t = _track_lookup(model.track, s)
+    a_f = -np.arctan2((vy + model.L_f * w) * np.cos(us) - vx * np.sin(us), vx * np.cos(us) + (vy + model.L_f * w) * np.sin(us))
+    a_r = -np.arctan2(vy - model.L_r * w, vx)
+    fyf = c.pacejka_d_front * np.sin(c.pacejka_c_front * np.arctan(c.pacejka_b_front * a_f))
+    fyr = c.pacejka_d_rear * np.sin(c.pacejka_c_rear * np.arctan(c.pacejka_b_rear * a_r))
+    F = -model.c_da * vx - model.c_dr * vx * absv(vx)
+    ar, af = (ua / 2, ua / 2) if c.drive_wheels == 'all' else (ua, 0 * ua)
+    ax = ar + af * np.cos(us) + (F - fyf * np.sin(us)) / model.m
+    ay = af * np.sin(us) + (fyf * np.cos(us) + fyr) / model.m
+    az = (model.L_f * fyf * np.cos(us) - model.L_r * fyr) / model.I_z
+    den = 1 - ey * curv
+    vlon = vx * np.cos(epsi) - vy * np.sin(epsi)
+    return np.stack([vx * np.cos(epsi + psi_t) - vy * np.sin(epsi + psi_t), vy * np.cos(epsi + psi_t) + vx * np.sin(epsi + psi_t),
+                     ax + w * vy, ay - w * vx, az, w - curv * vlon / den, vlon / den,
+                     vx * np.sin(epsi) + vy * np.cos(epsi)], axis=1)
+
+
+def _plant_step(model, q, u, dt, substeps=10):
+    h = dt / substeps
+    for _ in range(substeps):
+        k1 = _fc_batch(model, q, u)
+        k2 = _fc_batch(model, q + h / 2 * k1, u)
+        k3 = _fc_batch(model, q + h / 2 * k2, u)
+        k4 = _fc_batch(model, q + h * k3, u)
+        q = q + h * (k1 + 2 * k2 + 2 * k3 + k4) / 6
+    return q
+
+
+def pid_warm_start(model, q0, N, dt, u_max=(2.1, 0.436), du=(10.0, 4.5)):
+    """PID lane follower rollout (chicane.py:411-447) for a batch.  q0 [B, n_q] -> (q_ws [B,N+1,n_q], u_ws [B,N,2]).
+    Gains: speed Kp=1; steer Kp=1, Ki=0.005 on 5*(e_y - e_y0) + e_psi; du/u saturation as the script passes them."""
+    B = q0.shape[0]
+    v_idx = 2
+    epsi_idx, ey_idx = (3, 5) if model.model_id == 0 else (5, 7)
+    v_ref, lat_ref = q0[:, v_idx].copy(), q0[:, ey_idx].copy()
+    ei = np.zeros(B)
+    u_prev = np.zeros((B, 2))
+    q = q0.copy()
+    qs, us = [q0.copy()], []
+    for _ in range(N):
+        ua = -(1.0 * (q[:, v_idx] - v_ref))
+        e = 5.0 * (q[:, ey_idx] - lat_ref) + q[:, epsi_idx]
+        ei = np.clip(ei + e * dt, -100, 100)
+        ust = -(1.0 * e + 0.005 * ei)
+        u = np.stack([ua, ust], axis=1)
+        for j in range(2):                       # PID.solve saturation order: rate first, then magnitude
+            d = np.clip(u[:, j] - u_prev[:, j], -du[j], du[j])
+            u[:, j] = np.clip(d + u_prev[:, j], -u_max[j], u_max[j])
+        u_prev = u
+        q = _plant_step(model, q, u, dt)
+        qs.append(q.copy())
+        us.append(u.copy())
+    return np.stack(qs, axis=1), np.stack(us, axis=1)
+
+
+def sample_scenarios(game: Game, B: int, seed: int = 1, max_rounds: int = 200):
+    """Rejection-sample B two-agent scenarios (chicane.py:384-404, :465-467).
+    Returns x0 [B, n_q] and u_ws [B, N, n_u] (time-major, as ``set_warm_start`` expects)."""
+    if game.joint_model.n_a != 2:
+        raise NotImplementedError('sampler of the 2-agent scripts')
+    rng = np.random.default_rng(seed)
+    track, hw, obs_d = game.track, game.half_width, game.obs_d
+    N, dt = game.params.N, game.params.dt
+    first_seg_len = track.cl_segs[0, 0]
+    models = game.joint_model.dynamics_models
+    x0s, uws = [], []
+    have = 0
+    for _ in range(max_rounds):
+        if have >= B:
+            break
+        n = max(64, 2 * (B - have))
+        s1 = np.maximum(0.1, rng.random(n) * first_seg_len)
+        ey1 = rng.random(n) * hw * 2 - hw
+        v1 = rng.random(n) + 2
+        d = 2 * np.pi * rng.random(n)
+        s2 = s1 + 1.2 * obs_d * np.cos(d)
+        ey2 = ey1 + 1.2 * obs_d * np.sin(d)
+        v2 = rng.random(n) + 2
+        ok = (s2 >= 0) & (np.abs(ey2) <= hw)
+        s1, ey1, v1, s2, ey2, v2 = (a[ok] for a in (s1, ey1, v1, s2, ey2, v2))
+        q0 = []
+        for mdl, s, ey, v in ((models[0], s1, ey1, v1), (models[1], s2, ey2, v2)):
+            xy = np.array([track.local_to_global((si, ei_, 0.0))[:2] for si, ei_ in zip(s, ey)]).reshape(-1, 2)
+            q = np.zeros((len(s), mdl.n_q))
+            q[:, 0], q[:, 1], q[:, 2] = xy[:, 0], xy[:, 1], v
+            q[:, mdl.s_idx], q[:, mdl.ey_idx] = s, ey
+            q0.append(q)
+        rl = game.agent_constraints[0]
+        du = (10.0, 4.5) if rl is None else tuple(rl.rate_max)
+        q_ws, u_ws = zip(*[pid_warm_start(m, q, N, dt, du=du) for m, q in zip(models, q0)])
+        dist = np.linalg.norm(q_ws[0][:, :, :2] - q_ws[1][:, :, :2], axis=2)
+        keep = ~(dist < obs_d).any(axis=1)           # check_collision (chicane.py:38-43)
+        x0s.append(np.concatenate([q0[0][keep], q0[1][keep]], axis=1))
+        uws.append(np.concatenate([u_ws[0][keep], u_ws[1][keep]], axis=2))
+        have += int(keep.sum())
+    x0 = np.concatenate(x0s)[:B]
+    u = np.concatenate(uws)[:B]
+    if x0.shape[0] < B:
+        raise RuntimeError('sampler did not produce enough collision-free scenarios')
+    return np.ascontiguousarray(x0), np.ascontiguousarray(u)

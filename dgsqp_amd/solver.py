@@ -1,0 +1,339 @@
+"""Host-side mirror of the reference solver class for the Monte-Carlo hot path.
+
+``DGSQP`` keeps the reference surface (DGSQP/solvers/DGSQP.py:25-34 constructor,
+:268 ``initialize``, :271-281 ``set_warm_start``, :283-297 ``step``, :299
+``get_prediction``, :302-507 ``solve`` and its ``solve_info`` keys) and adds
+``solve_batch`` -- B independent ``solve()`` calls executed by the HIP kernels
+through the C-ABI of include/dgsqp.h.  All numerics run on the GPU; this file
+only lowers the game description to PODs and reshapes results.
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+import time
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from . import _ffi
+from .dynamics import CasadiDecoupledMultiAgentDynamicsModel, INTEGRATORS
+from .game import CollisionAvoidance, InputRateLimits, RacingCost
+from .solver_types import DGSQPParams
+from .types import VehiclePrediction, VehicleState
+
+
+class AbstractSolver:
+    """Reference DGSQP/solvers/abstract_solver.py:9-48 (runtime interface only)."""
+    needs_env_state = False
+
+    def initialize(self):
+        pass
+
+    def solve(self):
+        raise NotImplementedError
+
+    def step(self, estimated_state, env_state=None):
+        raise NotImplementedError
+
+    def get_prediction(self):
+        return VehiclePrediction()
+
+
+# ---------------------------------------------------------------------------------------------
+# lowering of the game to the C PODs (pure host logic, no GPU needed)
+# ---------------------------------------------------------------------------------------------
+def build_problem(joint_dynamics: CasadiDecoupledMultiAgentDynamicsModel,
+                  costs: List[RacingCost],
+                  agent_constraints: List[Optional[InputRateLimits]],
+                  shared_constraints: Optional[CollisionAvoidance],
+                  bounds: Dict[str, List[VehicleState]],
+                  params: DGSQPParams) -> _ffi.ProblemT:
+    M = joint_dynamics.n_a
+    if len(costs) != M:
+        raise ValueError('Number of agents: %i, but %i cost functions were provided' % (M, len(costs)))
+    if M > _ffi.MAX_AGENTS:
+        raise ValueError(f'at most {_ffi.MAX_AGENTS} agents are supported')
+    P = _ffi.ProblemT()
+    P.M, P.N = M, int(params.N)
+    cfg = joint_dynamics.model_config
+    P.integrator = INTEGRATORS[cfg.discretization_method]
+    P.substeps = int(cfg.M) if cfg.discretization_method != 'euler' else 1
+    P.dt = float(cfg.dt)
+    track = joint_dynamics.track
+    L, seg_s, seg_curv, seg_ang = track.tables()
+    n_segs = len(seg_curv)
+    if n_segs > _ffi.MAX_SEGS:
+        raise ValueError(f'track has {n_segs} segments, limit is {_ffi.MAX_SEGS}')
+    P.n_segs, P.track_L = n_segs, float(L)
+    for i in range(n_segs + 1):
+        P.seg_s[i] = float(seg_s[i])
+        P.seg_ang[i] = float(seg_ang[i])
+    for i in range(n_segs):
+        P.seg_curv[i] = float(seg_curv[i])
+    P.obstacle_rows = 1 if shared_constraints is not None else 0
+    if shared_constraints is not None and len(shared_constraints.radii) != M:
+        raise ValueError('CollisionAvoidance.radii must have one entry per agent')
+    for a, mdl in enumerate(joint_dynamics.dynamics_models):
+        A = P.agents[a]
+        c = mdl.model_config
+        A.model = mdl.model_id
+        A.L_f, A.L_r, A.mass = c.wheel_dist_front, c.wheel_dist_rear, c.mass
+        A.c_dr, A.c_da = c.drag_coefficient, c.damping_coefficient
+        A.c_r, A.p_r = c.rolling_resistance, c.rolling_resistance_exponent
+        if mdl.model_id == 0:
+            A.c_s = c.slip_coefficient
+            A.I_z, A.gravity = 1.0, 9.81
+        else:
+            A.I_z, A.gravity = c.yaw_inertia, c.gravity
+            A.tire_model = 0 if c.tire_model == 'pacejka' else 1
+            A.drive_wheels = 0 if c.drive_wheels == 'all' else 1
+            A.simple_slip = int(bool(c.simple_slip))
+            A.pac_Bf, A.pac_Br, A.pac_Cf, A.pac_Cr = c.pacejka_b_front, c.pacejka_b_rear, c.pacejka_c_front, c.pacejka_c_rear
+            A.pac_Df, A.pac_Dr, A.lin_Bf, A.lin_Br = c.pacejka_d_front, c.pacejka_d_rear, c.linear_bf, c.linear_br
+        cost = costs[a]
+        for j in range(2):
+            A.w_in[j] = float(cost.input_weight[j])
+            A.w_rate[j] = float(cost.input_rate_weight[j])
+        A.w_prog, A.w_comp = float(cost.comp_weights[0]), float(cost.comp_weights[1])
+        A.comp_type = {'atan': 0, 'linear': 1}[cost.comp_type]
+        A.w_block, A.w_obs, A.obs_cost_r = float(cost.blocking_weight), float(cost.obs_weight), float(cost.obs_r)
+        rate = agent_constraints[a] if agent_constraints is not None else None
+        A.has_rate = 0 if rate is None else 1
+        for j in range(2):
+            A.rate_ub[j] = 0.0 if rate is None else float(rate.rate_max[j])
+            A.rate_lb[j] = 0.0 if rate is None else float(rate.rate_min[j])
+        # box bounds -> index sets of finite entries (DGSQP.py:135-148)
+        su, iu = mdl.state2qu(bounds['ub'][a])
+        sl, il = mdl.state2qu(bounds['lb'][a])
+        for j in range(2):
+            A.in_ub[j], A.in_lb[j] = float(iu[j]), float(il[j])
+        for i in range(_ffi.MAX_NQA):
+            A.st_ub[i] = float(su[i]) if i < mdl.n_q else np.inf
+            A.st_lb[i] = float(sl[i]) if i < mdl.n_q else -np.inf
+        A.radius = float(shared_constraints.radii[a]) if shared_constraints is not None else 0.0
+    return P
+
+
+def build_params(params: DGSQPParams) -> _ffi.ParamsT:
+    if not params.conv_approx:
+        raise NotImplementedError('conv_approx=False (IPOPT Newton step, DGSQP.py:204-228) is not on the Monte-Carlo path')
+    if params.hessian_approximation != 'none':
+        raise NotImplementedError("hessian_approximation='bfgs' (DGSQP.py:535-557) is not implemented")
+    if params.merit_function not in ('stat_l1', 'stat'):
+        raise ValueError(f'Merit function option {params.merit_function} not recognized')
+    p = _ffi.ParamsT()
+    p.beta, p.tau, p.p_tol, p.d_tol, p.reg = params.beta, params.tau, params.p_tol, params.d_tol, params.reg
+    p.line_search_iters, p.nonmono_ls, p.sqp_iters = params.line_search_iters, int(params.nonmono_ls), params.sqp_iters
+    p.merit_function = 0 if params.merit_function == 'stat_l1' else 1
+    p.rel_tol_req = 3                      # DGSQP.py:56
+    p.lsqr_iter_lim = 0                    # scipy default 2*n_c
+    p.lsqr_atol = p.lsqr_btol = 1e-6       # scipy >= 1.12 defaults of sparse.linalg.lsqr
+    return p
+
+
+def problem_dims(P: _ffi.ProblemT):
+    """(n_q, n_u, n, n_c) from the constraint-assembly rules DGSQP.py:732-821."""
+    M, N = P.M, P.N
+    nqa = [8 if P.agents[a].model == 1 else 6 for a in range(M)]
+    n_q, n_u = sum(nqa), 2 * M
+    n_c = 0
+    pairs = M * (M - 1) // 2 if P.obstacle_rows else 0
+    for k in range(N + 1):
+        if k >= 1:
+            n_c += pairs
+        for a in range(M):
+            A = P.agents[a]
+            if k < N:
+                n_c += (4 if A.has_rate else 0) + sum(A.in_ub[j] < np.inf for j in range(2)) + sum(A.in_lb[j] > -np.inf for j in range(2))
+            if k > 0:
+                n_c += sum(A.st_ub[i] < np.inf for i in range(nqa[a])) + sum(A.st_lb[i] > -np.inf for i in range(nqa[a]))
+    return n_q, n_u, N * n_u, int(n_c)
+
+
+# ---------------------------------------------------------------------------------------------
+# solver
+# ---------------------------------------------------------------------------------------------
+class DGSQP(AbstractSolver):
+    def __init__(self, joint_dynamics: CasadiDecoupledMultiAgentDynamicsModel,
+                 costs: List[RacingCost],
+                 agent_constraints: List[Optional[InputRateLimits]],
+                 shared_constraints: Optional[CollisionAvoidance],
+                 bounds: Dict[str, List[VehicleState]],
+                 params: DGSQPParams = DGSQPParams(),
+                 print_method=print,
+                 xy_plot=None,
+                 use_mx: bool = False,
+                 device: int = 0):
+        self.joint_dynamics = joint_dynamics
+        self.M = joint_dynamics.n_a
+        self.print_method = (lambda s: None) if print_method is None else print_method
+        self.params = params
+        self.N = params.N
+        self.solver_name = params.solver_name
+        self.verbose = params.verbose
+        self.save_iter_data = params.save_iter_data
+        self.n_u, self.n_q = joint_dynamics.n_u, joint_dynamics.n_q
+        self.num_qa_d = [int(m.n_q) for m in joint_dynamics.dynamics_models]
+        self.num_ua_d = [int(m.n_u) for m in joint_dynamics.dynamics_models]
+        self.num_ua_el = [int(self.N * m.n_u) for m in joint_dynamics.dynamics_models]
+
+        self._problem = build_problem(joint_dynamics, costs, agent_constraints, shared_constraints, bounds, params)
+        self._cparams = build_params(params)
+        _, _, self.n, n_c = problem_dims(self._problem)
+        self.n_c_total = n_c
+
+        self._lib = _ffi.load_library()           # raises if the HIP library is missing
+        self._h = C.c_void_p()
+        rc = self._lib.dgsqp_create(C.byref(self._problem), C.byref(self._cparams), int(device), C.byref(self._h))
+        if rc != 0:
+            msg = self._lib.dgsqp_last_error(None)
+            raise RuntimeError(f'dgsqp_create failed ({rc}): {msg.decode() if msg else ""}')
+        d = _ffi.DimsT()
+        self._lib.dgsqp_dims(self._h, C.byref(d))
+        assert (d.n, d.n_c, d.n_q) == (self.n, n_c, self.n_q), 'host/device layout mismatch'
+        self.dims = d
+
+        self.state_input_predictions = [VehiclePrediction() for _ in range(self.M)]
+        self.q_pred = np.zeros((self.N + 1, self.n_q))
+        self.u_pred = np.zeros((self.N, self.n_u))
+        self.l_pred = np.zeros(n_c)
+        self.u_prev = np.zeros(self.n_u)
+        self.u_ws = np.zeros(self.N * self.n_u)
+        self.l_ws = None
+        self.initialized = True
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h is not None and h.value:
+            self._lib.dgsqp_destroy(h)
+            self._h = C.c_void_p()
+
+    # ---- layout helpers (DGSQP.py:271-281, :477-482) ------------------------------------------
+    def _to_agent_major(self, u_tm: np.ndarray) -> np.ndarray:
+        """[..., N, n_u] time-major joint inputs -> [..., n] agent-major decision vector."""
+        parts, si = [], 0
+        for nu in self.num_ua_d:
+            parts.append(u_tm[..., :, si:si + nu].reshape(*u_tm.shape[:-2], -1))
+            si += nu
+        return np.concatenate(parts, axis=-1)
+
+    def _to_time_major(self, u_am: np.ndarray) -> np.ndarray:
+        parts, si = [], 0
+        for nu, nel in zip(self.num_ua_d, self.num_ua_el):
+            parts.append(u_am[..., si:si + nel].reshape(*u_am.shape[:-1], self.N, nu))
+            si += nel
+        return np.concatenate(parts, axis=-1)
+
+    def initialize(self):
+        pass
+
+    def set_warm_start(self, u_ws: np.ndarray, l_ws: np.ndarray = None):
+        if u_ws.shape[0] != self.N or u_ws.shape[1] != self.n_u:
+            raise RuntimeError('Warm start state sequence of shape (%i,%i) is incompatible with required shape (%i,%i)'
+                               % (u_ws.shape[0], u_ws.shape[1], self.N, self.n_u))
+        self.u_ws = self._to_agent_major(np.asarray(u_ws, dtype=float))
+        self.l_ws = l_ws
+
+    # ---- batched entry point -------------------------------------------------------------------
+    def solve_batch(self, x0: np.ndarray, u_ws: np.ndarray) -> dict:
+        """B independent ``solve()`` calls.  ``x0`` [B, n_q]; ``u_ws`` [B, N, n_u] (time-major,
+        as ``set_warm_start``) or [B, n] (agent-major)."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        B = x0.shape[0]
+        u_ws = np.asarray(u_ws, dtype=np.float64)
+        if u_ws.ndim == 3:
+            if u_ws.shape[1:] != (self.N, self.n_u):
+                raise RuntimeError('Warm start state sequence of shape (%i,%i) is incompatible with required shape (%i,%i)'
+                                   % (u_ws.shape[1], u_ws.shape[2], self.N, self.n_u))
+            u_ws = self._to_agent_major(u_ws)
+        u_ws = np.ascontiguousarray(u_ws)
+        if x0.shape != (B, self.n_q) or u_ws.shape != (B, self.n):
+            raise RuntimeError(f'bad batch shapes x0 {x0.shape} u_ws {u_ws.shape}')
+        out = dict(u=np.empty((B, self.n)), l=np.empty((B, self.n_c_total)), x=np.empty((B, self.N + 1, self.n_q)),
+                   status=np.empty(B, np.int32), num_iters=np.empty(B, np.int32), qp_solves=np.empty(B, np.int32),
+                   cond=np.empty((B, 3)), cost=np.empty((B, self.M)))
+        tm = _ffi.TimingT()
+        t0 = time.time()
+        rc = self._lib.dgsqp_solve_batch(self._h, B, _ffi.dptr(x0), _ffi.dptr(u_ws), _ffi.dptr(out['u']), _ffi.dptr(out['l']),
+                                         _ffi.dptr(out['x']), _ffi.iptr(out['status']), _ffi.iptr(out['num_iters']),
+                                         _ffi.iptr(out['qp_solves']), _ffi.dptr(out['cond']), _ffi.dptr(out['cost']), C.byref(tm))
+        if rc != 0:
+            raise RuntimeError(f'dgsqp_solve_batch failed ({rc}): {self._lib.dgsqp_last_error(self._h).decode()}')
+        out['time'] = time.time() - t0
+        out['kernel_ms'] = tm.kernel_ms
+        out['msg'] = [_ffi.STATUS_MSG[s] for s in out['status']]
+        out['converged'] = out['status'] <= 1
+        out['u_pred'] = self._to_time_major(out['u'])
+        return out
+
+    # ---- test hooks ----------------------------------------------------------------------------
+    def evaluate_batch(self, x0, u, l=None):
+        """One ``_evaluate(u, l, x0, up=0, hessian=True)`` per row (DGSQP.py:509-533) + dual init."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        B = x0.shape[0]
+        l = None if l is None else np.ascontiguousarray(l, dtype=np.float64)
+        n, nc = self.n, self.n_c_total
+        out = dict(q=np.empty((B, n)), g=np.empty((B, nc)), G=np.empty((B, nc, n)), Q=np.empty((B, n, n)),
+                   x=np.empty((B, self.N + 1, self.n_q)), l0=np.empty((B, nc)))
+        rc = self._lib.dgsqp_evaluate_batch(self._h, B, _ffi.dptr(x0), _ffi.dptr(u), _ffi.dptr(l), _ffi.dptr(out['q']),
+                                            _ffi.dptr(out['g']), _ffi.dptr(out['G']), _ffi.dptr(out['Q']), _ffi.dptr(out['x']),
+                                            _ffi.dptr(out['l0']))
+        if rc != 0:
+            raise RuntimeError(f'dgsqp_evaluate_batch failed ({rc}): {self._lib.dgsqp_last_error(self._h).decode()}')
+        return out
+
+    def qp_batch(self, x0, u, l):
+        """One ``_solve_qp`` (DGSQP.py:232-266) per row at the linearisation point (u, l)."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        l = np.ascontiguousarray(l, dtype=np.float64)
+        B = x0.shape[0]
+        out = dict(du=np.empty((B, self.n)), lhat=np.empty((B, self.n_c_total)), Qpd=np.empty((B, self.n, self.n)),
+                   flag=np.empty(B, np.int32))
+        rc = self._lib.dgsqp_qp_batch(self._h, B, _ffi.dptr(x0), _ffi.dptr(u), _ffi.dptr(l), _ffi.dptr(out['du']),
+                                      _ffi.dptr(out['lhat']), _ffi.dptr(out['Qpd']), _ffi.iptr(out['flag']))
+        if rc != 0:
+            raise RuntimeError(f'dgsqp_qp_batch failed ({rc}): {self._lib.dgsqp_last_error(self._h).decode()}')
+        return out
+
+    # ---- reference single-scenario surface -----------------------------------------------------
+    def solve(self, states: List[VehicleState], parameters: np.ndarray = np.array([])) -> dict:
+        solve_start = time.time()
+        self.u_prev = np.zeros(self.n_u)
+        x0 = self.joint_dynamics.state2q(states)
+        u_init = copy.copy(self.u_ws)
+        self.print_method(self.solver_name)
+        res = self.solve_batch(x0[None, :], u_init[None, :])
+        self.q_pred = res['x'][0]
+        self.u_pred = res['u_pred'][0]
+        self.l_pred = res['l'][0]
+        msg = res['msg'][0]
+        cond = dict(p_feas=float(res['cond'][0, 0]), comp=float(res['cond'][0, 1]), stat=float(res['cond'][0, 2]))
+        solve_dur = time.time() - solve_start
+        self.print_method(f'Solve status: {msg}')
+        self.print_method(f'Solve iters: {int(res["num_iters"][0])}')
+        self.print_method(f'Solve time: {solve_dur:.2f}')
+        self.print_method(str(res['cost'][0]))
+        # iter_data is a host-debug feature of the reference (DGSQP.py:386); the batched kernels
+        # keep only the totals, so a single summary record is returned.
+        iter_data = [dict(cond=cond, u_sol=res['u'][0], l_sol=res['l'][0], qp_solves=int(res['qp_solves'][0]),
+                          it_time=solve_dur)] if self.save_iter_data else []
+        return dict(time=solve_dur, num_iters=int(res['num_iters'][0]), status=bool(res['converged'][0]),
+                    cost=[float(c) for c in res['cost'][0]], cond=cond, iter_data=iter_data, msg=msg,
+                    init=dict(u=u_init, l=None))
+
+    def step(self, states: List[VehicleState], parameters: np.ndarray = np.array([])):
+        info = self.solve(states, parameters)
+        self.joint_dynamics.qu2state(states, None, self.u_pred[0])
+        self.joint_dynamics.qu2prediction(self.state_input_predictions, self.q_pred, self.u_pred)
+        for q in self.state_input_predictions:
+            q.t = states[0].t
+        self.u_prev = self.u_pred[0]
+        if info['msg'] not in ['diverged', 'qp_fail']:
+            self.set_warm_start(np.vstack((self.u_pred[1:], self.u_pred[-1])))
+        return info
+
+    def get_prediction(self) -> List[VehiclePrediction]:
+        return self.state_input_predictions

@@ -1,0 +1,210 @@
+/*
+ * dgsqp.h -- C-ABI of the MI355X batched Dynamic-Game-SQP solver.
+ *
+ * This is the drop-in boundary for ONE hot path of zhu-edward/DGSQP: the
+ * Monte-Carlo SQP inner loop `DGSQP.solve()` (reference
+ * DGSQP/solvers/DGSQP.py:302-507) together with everything it calls per
+ * sample (`_evaluate` :509-533, `_solve_qp` :232-266, `_nearestPD`
+ * :1290-1296, `_get_mu` :559-585, `_line_search_3` :1057-1081,
+ * `_watchdog_line_search_4` :1174-1288).
+ *
+ * The reference is pure Python; its "FFI" for this path is the set of CasADi
+ * `Function.__call__`s and the `ca.conic` call made from `solve()`.  A
+ * maintainer binds this library with `ctypes.CDLL`.
+ * Only plain pointers, fixed-width integers and doubles cross the boundary.
+ *
+ * Because CasADi Function objects cannot cross a C boundary, the symbolic
+ * game (dynamics / costs / constraints built by
+ * scripts/DGSQP_*_monte_carlo_*.py) is passed as a declarative POD
+ * description, `dgsqp_problem_t`.
+ */
+#ifndef DGSQP_H
+#define DGSQP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGSQP_MAX_AGENTS 4
+#define DGSQP_MAX_SEGS 16
+#define DGSQP_MAX_NQA 8 /* largest per-agent state (dynamic bicycle) */
+#define DGSQP_NUA 2     /* every vehicle model of the path has 2 inputs */
+
+/* dynamics model ids (reference: DGSQP/dynamics/dynamics_models.py) */
+enum {
+  DGSQP_MODEL_KIN_BICYCLE = 0, /* CasadiKinematicBicycleCombined :997  */
+  DGSQP_MODEL_DYN_BICYCLE = 1, /* CasadiDynamicBicycleCombined   :1945 */
+};
+/* discretisation (dynamics_models.py:88-125, :188-219) */
+enum { DGSQP_INT_EULER = 0, DGSQP_INT_RK4 = 1, DGSQP_INT_RK3 = 2, DGSQP_INT_RK2 = 3 };
+/* terminal competition cost shape */
+enum { DGSQP_COMP_ATAN = 0, DGSQP_COMP_LINEAR = 1 };
+/* merit function (DGSQP.py:971-978) */
+enum { DGSQP_MERIT_STAT_L1 = 0, DGSQP_MERIT_STAT = 1 };
+
+/* per-scenario exit codes == reference `msg` strings (DGSQP.py:388,396,408,458,466,471) */
+enum {
+  DGSQP_CONV_ABS_TOL = 0,
+  DGSQP_CONV_REL_TOL = 1,
+  DGSQP_MAX_IT = 2,
+  DGSQP_DIVERGED = 3,
+  DGSQP_QP_FAIL = 4,
+  DGSQP_TIME_LIMIT = 5
+};
+
+/* library error codes */
+enum {
+  DGSQP_OK = 0,
+  DGSQP_E_ARG = -1,      /* bad argument / unsupported problem */
+  DGSQP_E_DEVICE = -2,   /* HIP error, no GPU, or kernel image missing */
+  DGSQP_E_NOMEM = -3,
+  DGSQP_E_TOO_LARGE = -4 /* problem exceeds the compiled LDS/workspace limits */
+};
+
+/*
+ * One agent: vehicle model (model_types.py:34-105), cost weights
+ * (scripts/DGSQP_ALGAMES_monte_carlo_chicane.py:111-122,223-277) and
+ * constraint data (:80-109,282-293).
+ */
+typedef struct {
+  int32_t model;        /* DGSQP_MODEL_* */
+  int32_t tire_model;   /* 0 pacejka, 1 linear   (dynamics_models.py:2022-2029) */
+  int32_t drive_wheels; /* 0 all, 1 rear         (dynamics_models.py:2036-2041) */
+  int32_t simple_slip;  /* dynamics_models.py:2015-2020 */
+  double L_f, L_r, mass, I_z, gravity;
+  double c_dr, c_da, c_s, c_r, p_r; /* drag, damping, slip, rolling resistance (+exponent) */
+  double pac_Bf, pac_Br, pac_Cf, pac_Cr, pac_Df, pac_Dr;
+  double lin_Bf, lin_Br;
+
+  /* stage cost 1/2 sum w_in u^2 + 1/2 sum w_rate (u-u_prev)^2 */
+  double w_in[DGSQP_NUA];
+  double w_rate[DGSQP_NUA];
+  /* terminal cost  -w_prog*s_a + w_comp * sum_{b!=a} comp(s_b - s_a) */
+  double w_prog, w_comp;
+  int32_t comp_type; /* DGSQP_COMP_* */
+  int32_t _pad0;
+  /* stage+terminal state costs (ablation script :229-230):
+     1/2 w_block sum_b (ey_a-ey_b)^2 + 1/2 w_obs sum_b max(0, d_ab-|p_a-p_b|)^2 */
+  double w_block, w_obs, obs_cost_r;
+
+  /* constraints */
+  int32_t has_rate; /* 4 rate rows per stage, order [u0 ub, u0 lb, u1 ub, u1 lb] */
+  int32_t _pad1;
+  double rate_ub[DGSQP_NUA], rate_lb[DGSQP_NUA]; /* per second; multiplied by dt inside */
+  double in_ub[DGSQP_NUA], in_lb[DGSQP_NUA];     /* +-inf = absent (DGSQP.py:145-148) */
+  double st_ub[DGSQP_MAX_NQA], st_lb[DGSQP_MAX_NQA];
+  double radius; /* obstacle row for pair (i,j): (r_i+r_j)^2 - |p_i-p_j|^2 <= 0 */
+} dgsqp_agent_t;
+
+/*
+ * The game.  Track tables follow
+ * DGSQP/tracks/radius_arclength_track.py:199-225 exactly:
+ *   curvature(s) = pw_const(sbar, seg_s[1..n_segs-1], seg_curv[0..n_segs-1])
+ *   tangent(s)   = pw_lin  (sbar, seg_s[0..n_segs],   seg_ang[0..n_segs])
+ *   sbar = fmod(fmod(s, L) + L, L)
+ */
+typedef struct {
+  int32_t M;          /* agents */
+  int32_t N;          /* horizon */
+  int32_t integrator; /* DGSQP_INT_* of the JOINT model (dynamics_models.py:2482-2530) */
+  int32_t substeps;   /* RK sub-steps per dt ("M" in DynamicsConfig) */
+  double dt;
+  int32_t n_segs;
+  int32_t obstacle_rows; /* 1: shared obstacle rows for every pair at k=1..N */
+  double track_L;
+  double seg_s[DGSQP_MAX_SEGS + 1];
+  double seg_curv[DGSQP_MAX_SEGS];
+  double seg_ang[DGSQP_MAX_SEGS + 1];
+  dgsqp_agent_t agents[DGSQP_MAX_AGENTS];
+} dgsqp_problem_t;
+
+/* DGSQPParams (solver_types.py:91-127), numeric subset used by solve() */
+typedef struct {
+  double beta, tau, p_tol, d_tol, reg;
+  int32_t line_search_iters;
+  int32_t nonmono_ls;
+  int32_t sqp_iters;
+  int32_t merit_function; /* DGSQP_MERIT_* */
+  int32_t rel_tol_req;    /* 3 (DGSQP.py:56) */
+  int32_t lsqr_iter_lim;  /* 0 => 2*n_c (scipy default, DGSQP.py:324) */
+  double lsqr_atol, lsqr_btol; /* scipy 1.15 defaults 1e-6 */
+} dgsqp_params_t;
+
+typedef struct {
+  int32_t M, N, n_q, n_u, n, n_c; /* n = N*n_u decision vars, n_c inequality rows */
+  int32_t n_dense;                /* distinct dense constraint gradients */
+  int32_t lds_bytes;              /* dynamic LDS per scenario workgroup */
+  int64_t workspace_bytes;        /* HBM scratch per resident workgroup */
+} dgsqp_dims_t;
+
+typedef struct {
+  double h2d_ms, kernel_ms, d2h_ms, total_ms; /* HIP-event times of the last call */
+  int32_t grid, block;
+} dgsqp_timing_t;
+
+typedef struct dgsqp_solver* dgsqp_handle_t;
+
+/* Build a solver for one game on one HIP device (one process per GPU).
+   Replaces DGSQP.__init__/_build_solver (DGSQP.py:26-230, :587-1030). */
+int dgsqp_create(const dgsqp_problem_t* prob, const dgsqp_params_t* par, int device,
+                 dgsqp_handle_t* out);
+void dgsqp_destroy(dgsqp_handle_t h);
+int dgsqp_dims(dgsqp_handle_t h, dgsqp_dims_t* out);
+const char* dgsqp_last_error(dgsqp_handle_t h); /* h may be NULL: last create() error */
+int dgsqp_backend_info(char* buf, int buflen);  /* device name / arch / CU count */
+
+/*
+ * Solve B independent scenarios == B calls of DGSQP.solve() (DGSQP.py:302-507).
+ * All arrays are caller-owned, C-contiguous host memory.
+ *   x0     [B][n_q]          joint initial state (state2q, dynamics_models.py:2554-2561)
+ *   u_ws   [B][n]            agent-major warm start (set_warm_start, DGSQP.py:271-281)
+ *   u_out  [B][n]            agent-major solution
+ *   l_out  [B][n_c]          multipliers (l_pred)
+ *   x_out  [B][(N+1)*n_q]    q_pred
+ *   status [B] DGSQP_* code, iters [B] num_iters, qp_solves [B]
+ *   cond   [B][3]            p_feas, comp, stat of the last iteration (DGSQP.py:376-379)
+ *   cost   [B][M]            f_J at the solution (DGSQP.py:492)
+ * Any output pointer may be NULL.
+ */
+int dgsqp_solve_batch(dgsqp_handle_t h, int64_t B, const double* x0, const double* u_ws,
+                      double* u_out, double* l_out, double* x_out, int32_t* status,
+                      int32_t* iters, int32_t* qp_solves, double* cond, double* cost,
+                      dgsqp_timing_t* timing);
+
+/*
+ * Device-resident variant used by bench.py: inputs are staged once with
+ * dgsqp_stage_inputs(); dgsqp_solve_staged() runs only the solve kernel on
+ * the handle's stream; dgsqp_fetch_results() copies results back.
+ */
+int dgsqp_stage_inputs(dgsqp_handle_t h, int64_t B, const double* x0, const double* u_ws);
+int dgsqp_solve_staged(dgsqp_handle_t h, dgsqp_timing_t* timing);
+int dgsqp_fetch_results(dgsqp_handle_t h, double* u_out, double* l_out, double* x_out,
+                        int32_t* status, int32_t* iters, int32_t* qp_solves, double* cond,
+                        double* cost);
+
+/*
+ * Test hook == one DGSQP._evaluate(u, l, x0, up=0, hessian=True) per scenario
+ * (DGSQP.py:509-533) plus the dual initialisation of DGSQP.py:320-327.
+ *   l   [B][n_c] multipliers used for Q (may be NULL => zeros)
+ *   q   [B][n], g [B][n_c], G [B][n_c][n] dense row-major, Q [B][n][n] (raw,
+ *   unsymmetrised), x [B][(N+1)*n_q], l0 [B][n_c] = max(0,-lsqr(GG^T, Gq)).
+ */
+int dgsqp_evaluate_batch(dgsqp_handle_t h, int64_t B, const double* x0, const double* u,
+                         const double* l, double* q, double* g, double* G, double* Q,
+                         double* x, double* l0);
+
+/*
+ * Test hook == DGSQP._solve_qp(Q, q, G, g) (DGSQP.py:232-266) on the game's
+ * own constraint structure: evaluates at (u, l), PSD-projects Q (+reg) and
+ * solves the QP.  du [B][n], lhat [B][n_c], Qpd [B][n][n] (projected +
+ * regularised Hessian), flag [B] (0 ok, 1 infeasible / failed).
+ */
+int dgsqp_qp_batch(dgsqp_handle_t h, int64_t B, const double* x0, const double* u,
+                   const double* l, double* du, double* lhat, double* Qpd, int32_t* flag);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGSQP_H */
