@@ -112,13 +112,17 @@ def load_library() -> C.CDLL:
     lib.dgsqp_evaluate_batch.restype = C.c_int
     lib.dgsqp_qp_batch.argtypes = [H, C.c_int64, _PD, _PD, _PD, _PD, _PD, _PD, _PI]
     lib.dgsqp_qp_batch.restype = C.c_int
+    lib.dgsqp_set_trace.argtypes = [H, C.c_int]
+    lib.dgsqp_set_trace.restype = C.c_int
+    lib.dgsqp_fetch_trace.argtypes = [H, _PD]
+    lib.dgsqp_fetch_trace.restype = C.c_int
     _LIB = lib
     return lib
 
 
 EXPORTED_SYMBOLS = ['dgsqp_create', 'dgsqp_destroy', 'dgsqp_dims', 'dgsqp_last_error', 'dgsqp_backend_info',
                     'dgsqp_solve_batch', 'dgsqp_stage_inputs', 'dgsqp_solve_staged', 'dgsqp_fetch_results',
-                    'dgsqp_evaluate_batch', 'dgsqp_qp_batch']
+                    'dgsqp_evaluate_batch', 'dgsqp_qp_batch', 'dgsqp_set_trace', 'dgsqp_fetch_trace']
 
 
 def dptr(a):

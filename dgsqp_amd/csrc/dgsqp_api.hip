@@ -1,0 +1,435 @@
+// C-ABI of the MI355X batched DG-SQP solver (include/dgsqp.h) and its kernels.
+// Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o libdgsqp_hip.so dgsqp_api.hip
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dgsqp_solve.h"
+
+extern __shared__ double dg_lds[];
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+// Persistent solve kernel: each workgroup pulls scenarios from a device-wide ticket counter, so that
+// scenarios with long SQP runs (iteration counts vary 1..50+) do not serialise a static partition.
+__global__ void __launch_bounds__(DG_BLOCK, 1)
+dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__ x0, const double* __restrict__ u_ws,
+                SolveOutPtrs O, double* __restrict__ ws_all, unsigned long long* __restrict__ ticket,
+                double* __restrict__ trace, int trace_cap) {
+  Ctx c;
+  c.D = D;
+  c.trace_cap = trace_cap;
+  c.lds = dg_lds;
+  c.ws = ws_all + (int64_t)blockIdx.x * D->ws_doubles;
+  while (true) {
+    __syncthreads();
+    if (TID == 0) dg_lds[D->L.scal + 63] = (double)atomicAdd(ticket, 1ULL);
+    __syncthreads();
+    const int64_t b = (int64_t)dg_lds[D->L.scal + 63];
+    if (b >= B) break;
+    c.x0 = x0 + b * D->nq;
+    c.trace = trace ? trace + b * (int64_t)(1 + 2 * trace_cap) : nullptr;
+    if (c.trace && TID == 0) c.trace[0] = 0.0;
+    dev_solve(c, u_ws + b * D->n, b, O);
+  }
+}
+
+// Test hook: one _evaluate(hessian=True) (+ dual init) per scenario, results expanded to dense arrays.
+__global__ void __launch_bounds__(DG_BLOCK, 1)
+dg_evaluate_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__ x0, const double* __restrict__ u,
+                   const double* __restrict__ l, double* q, double* g, double* G, double* Q, double* x, double* l0,
+                   double* __restrict__ ws_all) {
+  Ctx c;
+  c.D = D;
+  c.lds = dg_lds;
+  c.ws = ws_all + (int64_t)blockIdx.x * D->ws_doubles;
+  c.trace = nullptr; c.trace_cap = 0;
+  const DgLds& L = D->L;
+  const int n = D->n, nc = D->nc;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    c.x0 = x0 + b * D->nq;
+    __syncthreads();
+    for (int i = TID; i < n; i += NT) dg_lds[L.u + i] = u[b * n + i];
+    for (int r = TID; r < nc; r += NT) dg_lds[L.l + r] = l ? l[b * nc + r] : 0.0;
+    __syncthreads();
+    dev_evaluate(c, dg_lds + L.u, 0.0, nullptr, true);
+    if (q) for (int i = TID; i < n; i += NT) q[b * n + i] = dg_lds[L.q + i];
+    if (g) for (int r = TID; r < nc; r += NT) g[b * nc + r] = dg_lds[L.g + r];
+    if (x) for (int i = TID; i < (D->N + 1) * D->nq; i += NT) x[b * (int64_t)(D->N + 1) * D->nq + i] = dg_lds[L.e_x + i];
+    if (G)
+      for (int64_t t = TID; t < (int64_t)nc * n; t += NT)
+        G[b * (int64_t)nc * n + t] = g_row_coef(*D, dg_lds + L.gd, (int)(t / n), (int)(t % n));
+    if (Q) {
+      const double* Qg = c.ws + D->ws_q;
+      for (int t = TID; t < n * n; t += NT) Q[b * (int64_t)n * n + t] = Qg[t];
+    }
+    if (l0) {
+      dev_dual_init(c);
+      for (int r = TID; r < nc; r += NT) l0[b * nc + r] = dg_lds[L.l + r];
+    }
+    __syncthreads();
+  }
+}
+
+// Test hook: _solve_qp at the linearisation point (u, l).
+__global__ void __launch_bounds__(DG_BLOCK, 1)
+dg_qp_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__ x0, const double* __restrict__ u,
+             const double* __restrict__ l, double* du, double* lhat, double* Qpd, int32_t* flag, double* __restrict__ ws_all) {
+  Ctx c;
+  c.D = D;
+  c.lds = dg_lds;
+  c.ws = ws_all + (int64_t)blockIdx.x * D->ws_doubles;
+  c.trace = nullptr; c.trace_cap = 0;
+  const DgLds& L = D->L;
+  const int n = D->n, nc = D->nc;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    c.x0 = x0 + b * D->nq;
+    __syncthreads();
+    for (int i = TID; i < n; i += NT) dg_lds[L.u + i] = u[b * n + i];
+    for (int r = TID; r < nc; r += NT) dg_lds[L.l + r] = l[b * nc + r];
+    __syncthreads();
+    const int f = dev_linearize_and_qp(c, true, nullptr, Qpd ? Qpd + b * (int64_t)n * n : nullptr);
+    if (du) for (int i = TID; i < n; i += NT) du[b * n + i] = dg_lds[L.o_du + i];
+    if (lhat) for (int r = TID; r < nc; r += NT) lhat[b * nc + r] = dg_lds[L.o_lhat + r];
+    if (flag && TID == 0) flag[b] = f;
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct dgsqp_solver {
+  int device = 0;
+  DgProb hp;
+  DgProb* dp = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  int num_cu = 0, wg_per_cu = 1, max_grid = 0;
+  size_t lds_bytes = 0;
+  double* ws = nullptr;
+  size_t ws_groups = 0;
+  unsigned long long* ticket = nullptr;
+  // staged batch
+  int64_t cap = 0, B = 0;
+  double *d_x0 = nullptr, *d_uws = nullptr, *d_u = nullptr, *d_l = nullptr, *d_x = nullptr, *d_cond = nullptr, *d_cost = nullptr;
+  int32_t *d_status = nullptr, *d_iters = nullptr, *d_qps = nullptr;
+  double* d_trace = nullptr; int trace_cap = 0; int64_t trace_B = 0;
+  std::string err;
+};
+static thread_local std::string g_create_err;
+
+#define HIPCHK(h, call)                                                                      \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+      return DGSQP_E_DEVICE;                                                                 \
+    }                                                                                        \
+  } while (0)
+
+static void free_batch(dgsqp_solver* h) {
+  void* ptrs[] = {h->d_x0, h->d_uws, h->d_u, h->d_l, h->d_x, h->d_cond, h->d_cost, h->d_status, h->d_iters, h->d_qps};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  h->d_x0 = h->d_uws = h->d_u = h->d_l = h->d_x = h->d_cond = h->d_cost = nullptr;
+  h->d_status = h->d_iters = h->d_qps = nullptr;
+  h->cap = 0;
+}
+static int ensure_batch(dgsqp_solver* h, int64_t B) {
+  if (B <= h->cap) return DGSQP_OK;
+  free_batch(h);
+  const DgProb& D = h->hp;
+  HIPCHK(h, hipMalloc(&h->d_x0, sizeof(double) * B * D.nq));
+  HIPCHK(h, hipMalloc(&h->d_uws, sizeof(double) * B * D.n));
+  HIPCHK(h, hipMalloc(&h->d_u, sizeof(double) * B * D.n));
+  HIPCHK(h, hipMalloc(&h->d_l, sizeof(double) * B * D.nc));
+  HIPCHK(h, hipMalloc(&h->d_x, sizeof(double) * B * (D.N + 1) * D.nq));
+  HIPCHK(h, hipMalloc(&h->d_cond, sizeof(double) * B * 3));
+  HIPCHK(h, hipMalloc(&h->d_cost, sizeof(double) * B * D.M));
+  HIPCHK(h, hipMalloc(&h->d_status, sizeof(int32_t) * B));
+  HIPCHK(h, hipMalloc(&h->d_iters, sizeof(int32_t) * B));
+  HIPCHK(h, hipMalloc(&h->d_qps, sizeof(int32_t) * B));
+  h->cap = B;
+  return DGSQP_OK;
+}
+static int ensure_ws(dgsqp_solver* h, size_t groups) {
+  if (groups <= h->ws_groups) return DGSQP_OK;
+  if (h->ws) (void)hipFree(h->ws);
+  h->ws = nullptr; h->ws_groups = 0;
+  HIPCHK(h, hipMalloc(&h->ws, sizeof(double) * groups * (size_t)h->hp.ws_doubles));
+  h->ws_groups = groups;
+  return DGSQP_OK;
+}
+static int grid_for(dgsqp_solver* h, int64_t B) {
+  int64_t g = (int64_t)h->max_grid;
+  if (B < g) g = B;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// helpers for the two test hooks: temporary device buffers
+struct TmpBuf {
+  std::vector<void*> ptrs;
+  ~TmpBuf() { for (void* p : ptrs) (void)hipFree(p); }
+  template <class T> T* alloc(size_t count) { void* p = nullptr; if (hipMalloc(&p, sizeof(T) * (count ? count : 1)) != hipSuccess) return nullptr; ptrs.push_back(p); return (T*)p; }
+};
+
+extern "C" {
+
+int dgsqp_backend_info(char* buf, int buflen) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    snprintf(buf, buflen, "no HIP device");
+    return DGSQP_E_DEVICE;
+  }
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, 0) != hipSuccess) return DGSQP_E_DEVICE;
+  snprintf(buf, buflen, "%s arch=%s CUs=%d LDS/WG=%zu devices=%d", p.name, p.gcnArchName, p.multiProcessorCount, (size_t)p.sharedMemPerBlock, ndev);
+  return DGSQP_OK;
+}
+
+int dgsqp_create(const dgsqp_problem_t* prob, const dgsqp_params_t* par, int device, dgsqp_handle_t* out) {
+  if (!prob || !par || !out) { g_create_err = "null argument"; return DGSQP_E_ARG; }
+  dgsqp_solver* h = new dgsqp_solver();
+  std::string msg = dg_build(*prob, *par, h->hp);
+  if (!msg.empty()) {
+    g_create_err = msg;
+    const bool too_large = msg.find("LDS") != std::string::npos || msg.find("too many") != std::string::npos;
+    delete h;
+    return too_large ? DGSQP_E_TOO_LARGE : DGSQP_E_ARG;
+  }
+  auto fail = [&](const std::string& m) { g_create_err = m; dgsqp_destroy(h); return DGSQP_E_DEVICE; };
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device visible (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail("device index out of range");
+  h->device = device;
+  if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed");
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, device) != hipSuccess) return fail("hipGetDeviceProperties failed");
+  h->num_cu = p.multiProcessorCount;
+  h->lds_bytes = (size_t)h->hp.L.total * sizeof(double);
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+  for (auto& e : h->ev) if (hipEventCreate(&e) != hipSuccess) return fail("hipEventCreate failed");
+  if (hipMalloc(&h->dp, sizeof(DgProb)) != hipSuccess) return fail("hipMalloc(problem) failed");
+  if (hipMemcpy(h->dp, &h->hp, sizeof(DgProb), hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy(problem) failed");
+  if (hipMalloc(&h->ticket, sizeof(unsigned long long)) != hipSuccess) return fail("hipMalloc(ticket) failed");
+  const void* kernels[] = {(const void*)dg_solve_kernel, (const void*)dg_evaluate_kernel, (const void*)dg_qp_kernel};
+  for (const void* k : kernels) {
+    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+    if (e != hipSuccess) return fail(std::string("hipFuncSetAttribute(dynamic LDS): ") + hipGetErrorString(e));
+  }
+  int occ = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, dg_solve_kernel, DG_BLOCK, h->lds_bytes) != hipSuccess || occ < 1) occ = 1;
+  h->wg_per_cu = occ;
+  h->max_grid = h->num_cu * occ;
+  *out = h;
+  return DGSQP_OK;
+}
+
+void dgsqp_destroy(dgsqp_handle_t h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  free_batch(h);
+  if (h->ws) (void)hipFree(h->ws);
+  if (h->dp) (void)hipFree(h->dp);
+  if (h->ticket) (void)hipFree(h->ticket);
+  if (h->d_trace) (void)hipFree(h->d_trace);
+  for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int dgsqp_dims(dgsqp_handle_t h, dgsqp_dims_t* out) {
+  if (!h || !out) return DGSQP_E_ARG;
+  const DgProb& D = h->hp;
+  out->M = D.M; out->N = D.N; out->n_q = D.nq; out->n_u = D.nu; out->n = D.n; out->n_c = D.nc;
+  out->n_dense = D.ndense; out->lds_bytes = (int32_t)h->lds_bytes; out->workspace_bytes = D.ws_doubles * (int64_t)sizeof(double);
+  return DGSQP_OK;
+}
+
+const char* dgsqp_last_error(dgsqp_handle_t h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int dgsqp_stage_inputs(dgsqp_handle_t h, int64_t B, const double* x0, const double* u_ws) {
+  if (!h || B < 0 || (B > 0 && (!x0 || !u_ws))) { if (h) h->err = "bad argument"; return DGSQP_E_ARG; }
+  HIPCHK(h, hipSetDevice(h->device));
+  h->B = B;
+  if (B == 0) return DGSQP_OK;
+  int rc = ensure_batch(h, B);
+  if (rc) return rc;
+  rc = ensure_ws(h, (size_t)grid_for(h, B));
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpyAsync(h->d_x0, x0, sizeof(double) * B * h->hp.nq, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_uws, u_ws, sizeof(double) * B * h->hp.n, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return DGSQP_OK;
+}
+
+int dgsqp_solve_staged(dgsqp_handle_t h, dgsqp_timing_t* tm) {
+  if (!h) return DGSQP_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (tm) memset(tm, 0, sizeof(*tm));
+  if (h->B == 0) return DGSQP_OK;
+  const int grid = grid_for(h, h->B);
+  SolveOutPtrs O{h->d_u, h->d_l, h->d_x, h->d_cond, h->d_cost, h->d_status, h->d_iters, h->d_qps};
+  HIPCHK(h, hipMemsetAsync(h->ticket, 0, sizeof(unsigned long long), h->stream));
+  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+  double* trace = nullptr;
+  if (h->trace_cap > 0) {
+    if (h->trace_B < h->B) {
+      if (h->d_trace) (void)hipFree(h->d_trace);
+      h->d_trace = nullptr; h->trace_B = 0;
+      HIPCHK(h, hipMalloc(&h->d_trace, sizeof(double) * h->B * (1 + 2 * (size_t)h->trace_cap)));
+      h->trace_B = h->B;
+    }
+    trace = h->d_trace;
+  }
+  hipLaunchKernelGGL(dg_solve_kernel, dim3(grid), dim3(DG_BLOCK), h->lds_bytes, h->stream, h->dp, h->B, h->d_x0, h->d_uws, O, h->ws, h->ticket, trace, h->trace_cap);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (tm) {
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+    tm->kernel_ms = ms; tm->total_ms = ms; tm->grid = grid; tm->block = DG_BLOCK;
+  }
+  return DGSQP_OK;
+}
+
+int dgsqp_fetch_results(dgsqp_handle_t h, double* u_out, double* l_out, double* x_out, int32_t* status, int32_t* iters,
+                        int32_t* qp_solves, double* cond, double* cost) {
+  if (!h) return DGSQP_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  const DgProb& D = h->hp;
+  const int64_t B = h->B;
+  if (B == 0) return DGSQP_OK;
+  if (u_out) HIPCHK(h, hipMemcpyAsync(u_out, h->d_u, sizeof(double) * B * D.n, hipMemcpyDeviceToHost, h->stream));
+  if (l_out) HIPCHK(h, hipMemcpyAsync(l_out, h->d_l, sizeof(double) * B * D.nc, hipMemcpyDeviceToHost, h->stream));
+  if (x_out) HIPCHK(h, hipMemcpyAsync(x_out, h->d_x, sizeof(double) * B * (D.N + 1) * D.nq, hipMemcpyDeviceToHost, h->stream));
+  if (status) HIPCHK(h, hipMemcpyAsync(status, h->d_status, sizeof(int32_t) * B, hipMemcpyDeviceToHost, h->stream));
+  if (iters) HIPCHK(h, hipMemcpyAsync(iters, h->d_iters, sizeof(int32_t) * B, hipMemcpyDeviceToHost, h->stream));
+  if (qp_solves) HIPCHK(h, hipMemcpyAsync(qp_solves, h->d_qps, sizeof(int32_t) * B, hipMemcpyDeviceToHost, h->stream));
+  if (cond) HIPCHK(h, hipMemcpyAsync(cond, h->d_cond, sizeof(double) * B * 3, hipMemcpyDeviceToHost, h->stream));
+  if (cost) HIPCHK(h, hipMemcpyAsync(cost, h->d_cost, sizeof(double) * B * D.M, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return DGSQP_OK;
+}
+
+int dgsqp_solve_batch(dgsqp_handle_t h, int64_t B, const double* x0, const double* u_ws, double* u_out, double* l_out,
+                      double* x_out, int32_t* status, int32_t* iters, int32_t* qp_solves, double* cond, double* cost,
+                      dgsqp_timing_t* tm) {
+  if (!h) return DGSQP_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+  int rc = dgsqp_stage_inputs(h, B, x0, u_ws);
+  if (rc) return rc;
+  dgsqp_timing_t t2;
+  rc = dgsqp_solve_staged(h, &t2);
+  if (rc) return rc;
+  rc = dgsqp_fetch_results(h, u_out, l_out, x_out, status, iters, qp_solves, cond, cost);
+  if (rc) return rc;
+  HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (tm) {
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
+    *tm = t2;
+    tm->total_ms = ms;
+  }
+  return DGSQP_OK;
+}
+
+// Diagnostic build (-DDG_PROF) only: read and clear the per-phase cycle counters.
+int dgsqp_prof_read(unsigned long long* out, int n) {
+#ifdef DG_PROF
+  unsigned long long tmp[PH_COUNT * 2];
+  if (hipMemcpyFromSymbol(tmp, HIP_SYMBOL(dg_prof), sizeof(tmp)) != hipSuccess) return DGSQP_E_DEVICE;
+  for (int i = 0; i < n && i < PH_COUNT * 2; i++) out[i] = tmp[i];
+  memset(tmp, 0, sizeof(tmp));
+  if (hipMemcpyToSymbol(HIP_SYMBOL(dg_prof), tmp, sizeof(tmp)) != hipSuccess) return DGSQP_E_DEVICE;
+  return PH_COUNT;
+#else
+  (void)out; (void)n;
+  return 0;
+#endif
+}
+
+int dgsqp_set_trace(dgsqp_handle_t h, int pairs_per_scenario) {
+  if (!h || pairs_per_scenario < 0) return DGSQP_E_ARG;
+  h->trace_cap = pairs_per_scenario;
+  h->trace_B = 0;
+  if (h->d_trace) { (void)hipFree(h->d_trace); h->d_trace = nullptr; }
+  return DGSQP_OK;
+}
+
+int dgsqp_fetch_trace(dgsqp_handle_t h, double* out) {
+  if (!h || !out || h->trace_cap <= 0 || !h->d_trace) { if (h) h->err = "no trace recorded"; return DGSQP_E_ARG; }
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpy(out, h->d_trace, sizeof(double) * h->B * (1 + 2 * (size_t)h->trace_cap), hipMemcpyDeviceToHost));
+  return DGSQP_OK;
+}
+
+int dgsqp_evaluate_batch(dgsqp_handle_t h, int64_t B, const double* x0, const double* u, const double* l, double* q,
+                         double* g, double* G, double* Q, double* x, double* l0) {
+  if (!h || B < 0 || !x0 || !u) { if (h) h->err = "bad argument"; return DGSQP_E_ARG; }
+  if (B == 0) return DGSQP_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  const DgProb& D = h->hp;
+  const int grid = grid_for(h, B);
+  int rc = ensure_ws(h, (size_t)grid);
+  if (rc) return rc;
+  TmpBuf tb;
+  const size_t n = D.n, nc = D.nc, nx = (size_t)(D.N + 1) * D.nq;
+  double* dx0 = tb.alloc<double>(B * D.nq); double* du = tb.alloc<double>(B * n);
+  double* dl = l ? tb.alloc<double>(B * nc) : nullptr;
+  double* dq = q ? tb.alloc<double>(B * n) : nullptr; double* dg = g ? tb.alloc<double>(B * nc) : nullptr;
+  double* dG = G ? tb.alloc<double>(B * nc * n) : nullptr; double* dQ = Q ? tb.alloc<double>(B * n * n) : nullptr;
+  double* dx = x ? tb.alloc<double>(B * nx) : nullptr; double* dl0 = l0 ? tb.alloc<double>(B * nc) : nullptr;
+  if (!dx0 || !du || (l && !dl) || (q && !dq) || (g && !dg) || (G && !dG) || (Q && !dQ) || (x && !dx) || (l0 && !dl0)) { h->err = "hipMalloc failed"; return DGSQP_E_NOMEM; }
+  HIPCHK(h, hipMemcpy(dx0, x0, sizeof(double) * B * D.nq, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(du, u, sizeof(double) * B * n, hipMemcpyHostToDevice));
+  if (l) HIPCHK(h, hipMemcpy(dl, l, sizeof(double) * B * nc, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(dg_evaluate_kernel, dim3(grid), dim3(DG_BLOCK), h->lds_bytes, h->stream, h->dp, B, dx0, du, dl, dq, dg, dG, dQ, dx, dl0, h->ws);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (q) HIPCHK(h, hipMemcpy(q, dq, sizeof(double) * B * n, hipMemcpyDeviceToHost));
+  if (g) HIPCHK(h, hipMemcpy(g, dg, sizeof(double) * B * nc, hipMemcpyDeviceToHost));
+  if (G) HIPCHK(h, hipMemcpy(G, dG, sizeof(double) * B * nc * n, hipMemcpyDeviceToHost));
+  if (Q) HIPCHK(h, hipMemcpy(Q, dQ, sizeof(double) * B * n * n, hipMemcpyDeviceToHost));
+  if (x) HIPCHK(h, hipMemcpy(x, dx, sizeof(double) * B * nx, hipMemcpyDeviceToHost));
+  if (l0) HIPCHK(h, hipMemcpy(l0, dl0, sizeof(double) * B * nc, hipMemcpyDeviceToHost));
+  return DGSQP_OK;
+}
+
+int dgsqp_qp_batch(dgsqp_handle_t h, int64_t B, const double* x0, const double* u, const double* l, double* du_out,
+                   double* lhat, double* Qpd, int32_t* flag) {
+  if (!h || B < 0 || !x0 || !u || !l) { if (h) h->err = "bad argument"; return DGSQP_E_ARG; }
+  if (B == 0) return DGSQP_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  const DgProb& D = h->hp;
+  const int grid = grid_for(h, B);
+  int rc = ensure_ws(h, (size_t)grid);
+  if (rc) return rc;
+  TmpBuf tb;
+  const size_t n = D.n, nc = D.nc;
+  double* dx0 = tb.alloc<double>(B * D.nq); double* du = tb.alloc<double>(B * n); double* dl = tb.alloc<double>(B * nc);
+  double* ddu = du_out ? tb.alloc<double>(B * n) : nullptr; double* dlh = lhat ? tb.alloc<double>(B * nc) : nullptr;
+  double* dQ = Qpd ? tb.alloc<double>(B * n * n) : nullptr; int32_t* df = flag ? tb.alloc<int32_t>(B) : nullptr;
+  if (!dx0 || !du || !dl || (du_out && !ddu) || (lhat && !dlh) || (Qpd && !dQ) || (flag && !df)) { h->err = "hipMalloc failed"; return DGSQP_E_NOMEM; }
+  HIPCHK(h, hipMemcpy(dx0, x0, sizeof(double) * B * D.nq, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(du, u, sizeof(double) * B * n, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(dl, l, sizeof(double) * B * nc, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(dg_qp_kernel, dim3(grid), dim3(DG_BLOCK), h->lds_bytes, h->stream, h->dp, B, dx0, du, dl, ddu, dlh, dQ, df, h->ws);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (du_out) HIPCHK(h, hipMemcpy(du_out, ddu, sizeof(double) * B * n, hipMemcpyDeviceToHost));
+  if (lhat) HIPCHK(h, hipMemcpy(lhat, dlh, sizeof(double) * B * nc, hipMemcpyDeviceToHost));
+  if (Qpd) HIPCHK(h, hipMemcpy(Qpd, dQ, sizeof(double) * B * n * n, hipMemcpyDeviceToHost));
+  if (flag) HIPCHK(h, hipMemcpy(flag, df, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+  return DGSQP_OK;
+}
+
+}  // extern "C"

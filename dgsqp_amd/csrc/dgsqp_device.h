@@ -1,0 +1,377 @@
+// Device side of the batched DG-SQP solver for gfx950 (MI355X).
+//
+// One 256-thread workgroup (4 wavefronts) owns one Monte-Carlo scenario for
+// its whole solve (reference DGSQP.solve(), DGSQP/solvers/DGSQP.py:302-507):
+// iterates, multipliers, the packed dense constraint gradients, the packed
+// symmetric KKT Hessian, its eigenvectors and the active-set factor all live
+// in the workgroup's 160 KB of LDS; only the Taylor tensor of the dynamics, the
+// raw (unsymmetric) game Hessian and the watchdog's base-point backup go to a
+// per-workgroup HBM/L2 scratch.  All functions below are block-cooperative:
+// every thread of the workgroup calls them with identical arguments.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dgsqp_layout.h"
+
+#define NT DG_BLOCK
+#define TID ((int)threadIdx.x)
+
+struct Ctx {
+  const DgProb* D;
+  double* lds;  // dynamic LDS base
+  double* ws;   // this workgroup's global workspace
+  const double* x0;
+  double* trace;   // optional per-scenario event log: [0] = number of (code, value) pairs, then the pairs
+  int trace_cap;   // capacity in pairs
+};
+// event log compared event-by-event with the oracle's (tests/test_gpu_trace.py)
+__device__ inline void dev_tr(const Ctx& c, int code, double v) {
+  if (c.trace && threadIdx.x == 0) {
+    const int p = (int)c.trace[0];
+    if (p < c.trace_cap) { c.trace[1 + 2 * p] = (double)code; c.trace[2 + 2 * p] = v; c.trace[0] = (double)(p + 1); }
+  }
+}
+
+// Diagnostic build only (-DDG_PROF): per-phase cycle counters accumulated by thread 0 of every workgroup
+// into a global array; the production library compiles these to nothing.
+enum { PH_ROLLOUT = 0, PH_DERIV1, PH_DERIV2, PH_CHAINS, PH_DP, PH_JACOBI, PH_PFORM, PH_QP, PH_MERIT, PH_LSQR, PH_QTMUL, PH_SWEEP, PH_COUNT };
+#ifdef DG_PROF
+__device__ unsigned long long dg_prof[PH_COUNT * 2];
+#define PROF_BEGIN(v) const long long v = clock64()
+#define PROF_END(ph, v) do { if (threadIdx.x == 0) { atomicAdd(&dg_prof[2 * (ph)], (unsigned long long)(clock64() - v)); atomicAdd(&dg_prof[2 * (ph) + 1], 1ULL); } } while (0)
+#else
+#define PROF_BEGIN(v) do {} while (0)
+#define PROF_END(ph, v) do {} while (0)
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// reductions (fixed tree => bitwise reproducible)
+// ------------------------------------------------------------------------------------------------
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  return v;
+}
+__device__ inline double block_sum(double v, double* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((TID & 63) == 0) red[TID >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ inline double block_max(double v, double* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o));
+  __syncthreads();
+  if ((TID & 63) == 0) red[TID >> 6] = v;
+  __syncthreads();
+  return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+// minimum with lowest index on ties
+__device__ inline void block_argmin(double v, int idx, double* red, double& vout, int& iout) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    double v2 = __shfl_down(v, o);
+    int i2 = __shfl_down(idx, o);
+    if (v2 < v || (v2 == v && i2 < idx)) { v = v2; idx = i2; }
+  }
+  __syncthreads();
+  if ((TID & 63) == 0) { red[TID >> 6] = v; red[8 + (TID >> 6)] = (double)idx; }
+  __syncthreads();
+  vout = red[0]; iout = (int)red[8];
+  for (int w = 1; w < 4; w++) {
+    double v2 = red[w]; int i2 = (int)red[8 + w];
+    if (v2 < vout || (v2 == vout && i2 < iout)) { vout = v2; iout = i2; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// truncated univariate Taylor arithmetic, f(t) = c0 + c1 t + c2 t^2.
+// Second derivatives of the discrete dynamics are recovered from the t^2 coefficient along the
+// directions e_i and e_i+e_j (one direction per lane), first derivatives from the t coefficient.
+// Kink conventions follow CasADi (if_else differentiates the taken branch, comparisons are constant).
+// ------------------------------------------------------------------------------------------------
+template <int DEG>
+struct Ty {
+  double c[DEG + 1];
+};
+template <int DEG> __device__ inline Ty<DEG> ty_const(double v) { Ty<DEG> r; r.c[0] = v; for (int i = 1; i <= DEG; i++) r.c[i] = 0.0; return r; }
+template <int DEG> __device__ inline Ty<DEG> operator+(const Ty<DEG>& a, const Ty<DEG>& b) { Ty<DEG> r; for (int i = 0; i <= DEG; i++) r.c[i] = a.c[i] + b.c[i]; return r; }
+template <int DEG> __device__ inline Ty<DEG> operator-(const Ty<DEG>& a, const Ty<DEG>& b) { Ty<DEG> r; for (int i = 0; i <= DEG; i++) r.c[i] = a.c[i] - b.c[i]; return r; }
+template <int DEG> __device__ inline Ty<DEG> operator-(const Ty<DEG>& a) { Ty<DEG> r; for (int i = 0; i <= DEG; i++) r.c[i] = -a.c[i]; return r; }
+template <int DEG> __device__ inline Ty<DEG> operator+(const Ty<DEG>& a, double b) { Ty<DEG> r = a; r.c[0] += b; return r; }
+template <int DEG> __device__ inline Ty<DEG> operator+(double b, const Ty<DEG>& a) { return a + b; }
+template <int DEG> __device__ inline Ty<DEG> operator-(const Ty<DEG>& a, double b) { Ty<DEG> r = a; r.c[0] -= b; return r; }
+template <int DEG> __device__ inline Ty<DEG> operator-(double b, const Ty<DEG>& a) { return (-a) + b; }
+template <int DEG> __device__ inline Ty<DEG> operator*(const Ty<DEG>& a, double b) { Ty<DEG> r; for (int i = 0; i <= DEG; i++) r.c[i] = a.c[i] * b; return r; }
+template <int DEG> __device__ inline Ty<DEG> operator*(double b, const Ty<DEG>& a) { return a * b; }
+template <int DEG> __device__ inline Ty<DEG> operator/(const Ty<DEG>& a, double b) { return a * (1.0 / b); }
+template <int DEG> __device__ inline Ty<DEG> operator*(const Ty<DEG>& a, const Ty<DEG>& b) {
+  Ty<DEG> r;
+  r.c[0] = a.c[0] * b.c[0];
+  if constexpr (DEG >= 1) r.c[1] = a.c[0] * b.c[1] + a.c[1] * b.c[0];
+  if constexpr (DEG >= 2) r.c[2] = a.c[0] * b.c[2] + a.c[1] * b.c[1] + a.c[2] * b.c[0];
+  return r;
+}
+template <int DEG> __device__ inline Ty<DEG> ty_recip(const Ty<DEG>& a) {
+  Ty<DEG> r;
+  r.c[0] = 1.0 / a.c[0];
+  if constexpr (DEG >= 1) r.c[1] = -a.c[1] * r.c[0] * r.c[0];
+  if constexpr (DEG >= 2) r.c[2] = -(a.c[2] * r.c[0] + a.c[1] * r.c[1]) * r.c[0];
+  return r;
+}
+template <int DEG> __device__ inline Ty<DEG> operator/(const Ty<DEG>& a, const Ty<DEG>& b) { return a * ty_recip(b); }
+template <int DEG> __device__ inline Ty<DEG> operator/(double a, const Ty<DEG>& b) { return ty_recip(b) * a; }
+template <int DEG> __device__ inline void ty_sincos(const Ty<DEG>& a, Ty<DEG>& s, Ty<DEG>& c) {
+  double s0, c0;
+  sincos(a.c[0], &s0, &c0);
+  s.c[0] = s0; c.c[0] = c0;
+  if constexpr (DEG >= 1) { s.c[1] = c0 * a.c[1]; c.c[1] = -s0 * a.c[1]; }
+  if constexpr (DEG >= 2) { s.c[2] = 0.5 * a.c[1] * c.c[1] + a.c[2] * c0; c.c[2] = -0.5 * a.c[1] * s.c[1] - a.c[2] * s0; }
+}
+template <int DEG> __device__ inline Ty<DEG> ty_tan(const Ty<DEG>& a) {
+  Ty<DEG> r;
+  r.c[0] = tan(a.c[0]);
+  const double w0 = 1.0 + r.c[0] * r.c[0];
+  if constexpr (DEG >= 1) r.c[1] = w0 * a.c[1];
+  if constexpr (DEG >= 2) r.c[2] = w0 * a.c[2] + r.c[0] * r.c[1] * a.c[1];
+  return r;
+}
+template <int DEG> __device__ inline Ty<DEG> ty_atan(const Ty<DEG>& a) {
+  Ty<DEG> r;
+  r.c[0] = atan(a.c[0]);
+  const double w0 = 1.0 + a.c[0] * a.c[0];
+  if constexpr (DEG >= 1) r.c[1] = a.c[1] / w0;
+  if constexpr (DEG >= 2) r.c[2] = (2.0 * a.c[2] - 2.0 * a.c[0] * a.c[1] * r.c[1]) / (2.0 * w0);
+  return r;
+}
+template <int DEG> __device__ inline Ty<DEG> ty_atan2(const Ty<DEG>& y, const Ty<DEG>& x) {
+  Ty<DEG> r;
+  r.c[0] = atan2(y.c[0], x.c[0]);
+  const double w0 = x.c[0] * x.c[0] + y.c[0] * y.c[0];
+  if constexpr (DEG >= 1) r.c[1] = (x.c[0] * y.c[1] - y.c[0] * x.c[1]) / w0;
+  if constexpr (DEG >= 2) {
+    const double w1 = 2.0 * (x.c[0] * x.c[1] + y.c[0] * y.c[1]);
+    const double n1 = 2.0 * (x.c[0] * y.c[2] - y.c[0] * x.c[2]);
+    r.c[2] = (n1 - r.c[1] * w1) / (2.0 * w0);
+  }
+  return r;
+}
+template <int DEG> __device__ inline Ty<DEG> ty_sqrt(const Ty<DEG>& a) {
+  Ty<DEG> r;
+  r.c[0] = sqrt(a.c[0]);
+  if constexpr (DEG >= 1) r.c[1] = a.c[1] / (2.0 * r.c[0]);
+  if constexpr (DEG >= 2) r.c[2] = (a.c[2] - r.c[1] * r.c[1]) / (2.0 * r.c[0]);
+  return r;
+}
+template <int DEG> __device__ inline Ty<DEG> ty_pow(const Ty<DEG>& a, double p) {
+  Ty<DEG> r;
+  r.c[0] = pow(a.c[0], p);
+  if constexpr (DEG >= 1) r.c[1] = p * r.c[0] * a.c[1] / a.c[0];
+  if constexpr (DEG >= 2) r.c[2] = (p * (2.0 * r.c[0] * a.c[2] + r.c[1] * a.c[1]) - a.c[1] * r.c[1]) / (2.0 * a.c[0]);
+  return r;
+}
+template <int DEG> __device__ inline Ty<DEG> ty_abs(const Ty<DEG>& a) { return a.c[0] > 0 ? a : -a; }  // ca_abs, dynamics_models.py:228-234
+
+// ------------------------------------------------------------------------------------------------
+// track tables (radius_arclength_track.py:199-225): curvature piecewise constant, tangent piecewise linear
+// ------------------------------------------------------------------------------------------------
+template <int DEG>
+__device__ inline void dev_track(const dgsqp_problem_t& P, const Ty<DEG>& s, double& curv, Ty<DEG>& psi) {
+  const double L = P.track_L;
+  const double sbar = fmod(fmod(s.c[0], L) + L, L);
+  int seg = 0;
+  for (int i = 1; i < P.n_segs; i++) seg += (sbar >= P.seg_s[i]) ? 1 : 0;
+  curv = P.seg_curv[seg];
+  const double slope = (P.seg_ang[seg + 1] - P.seg_ang[seg]) / (P.seg_s[seg + 1] - P.seg_s[seg]);
+  psi = (s + (sbar - s.c[0] - P.seg_s[seg])) * slope + P.seg_ang[seg];
+}
+
+// kinematic bicycle in the Frenet frame (dynamics_models.py:1046-1070); q = [x,y,v,e_psi,s,e_y], u = [a, delta]
+template <int DEG>
+__device__ inline void dev_fc_kin(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const Ty<DEG>* q, const Ty<DEG>* u, Ty<DEG>* dq) {
+  typedef Ty<DEG> T;
+  const T beta = ty_atan2(ty_tan(u[1]) * ag.L_r, ty_const<DEG>(ag.L_f + ag.L_r));
+  T sb, cb;
+  ty_sincos(beta, sb, cb);
+  const T psidot = q[2] * sb * (1.0 / ag.L_r);
+  T F = q[2] * (-ag.c_da) - q[2] * ty_abs(q[2]) * ag.c_dr - psidot * psidot * ag.c_s;
+  if (ag.c_r != 0.0) F = F - ty_pow(ty_abs(q[2]), ag.p_r) * (q[2] / ty_sqrt(q[2] * q[2] + 1e-6)) * ag.c_r;
+  double c;
+  T psit;
+  dev_track(P, q[4], c, psit);
+  T s1, c1, s2, c2;
+  ty_sincos(beta + psit + q[3], s1, c1);
+  ty_sincos(beta + q[3], s2, c2);
+  const T inv = ty_recip(1.0 - q[5] * c);
+  const T vlon = q[2] * c2 * inv;
+  dq[0] = q[2] * c1;
+  dq[1] = q[2] * s1;
+  dq[2] = u[0] + F * (1.0 / ag.mass);
+  dq[3] = psidot - vlon * c;
+  dq[4] = vlon;
+  dq[5] = q[2] * s2;
+}
+
+// dynamic bicycle, Pacejka / linear tyres (dynamics_models.py:2008-2062); q = [x,y,vx,vy,w,e_psi,s,e_y]
+template <int DEG>
+__device__ inline void dev_fc_dyn(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const Ty<DEG>* q, const Ty<DEG>* u, Ty<DEG>* dq) {
+  typedef Ty<DEG> T;
+  const T &vx = q[2], &vy = q[3], &w = q[4];
+  double c;
+  T psit;
+  dev_track(P, q[6], c, psit);
+  T sd, cd;
+  ty_sincos(u[1], sd, cd);
+  const T vyf = vy + w * ag.L_f;
+  T af;
+  if (ag.simple_slip) af = u[1] - ty_atan2(vyf, vx);
+  else af = -ty_atan2(vyf * cd - vx * sd, vx * cd + vyf * sd);
+  const T ar = -ty_atan2(vy - w * ag.L_r, vx);
+  T fyf, fyr;
+  if (ag.tire_model == 0) {
+    T s_, c_;
+    ty_sincos(ty_atan(af * ag.pac_Bf) * ag.pac_Cf, s_, c_);
+    fyf = s_ * ag.pac_Df;
+    ty_sincos(ty_atan(ar * ag.pac_Br) * ag.pac_Cr, s_, c_);
+    fyr = s_ * ag.pac_Dr;
+  } else {
+    fyf = af * (ag.lin_Bf * ag.mass * ag.gravity * ag.L_r / (ag.L_f + ag.L_r));
+    fyr = ar * (ag.lin_Br * ag.mass * ag.gravity * ag.L_f / (ag.L_f + ag.L_r));
+  }
+  T F = vx * (-ag.c_da) - vx * ty_abs(vx) * ag.c_dr;
+  if (ag.c_r != 0.0) F = F - ty_pow(ty_abs(vx), ag.p_r) * (vx / ty_sqrt(vx * vx + 1e-6)) * ag.c_r;
+  T a_r, a_f;
+  if (ag.drive_wheels == 0) { a_r = u[0] * 0.5; a_f = u[0] * 0.5; } else { a_r = u[0]; a_f = ty_const<DEG>(0.0); }
+  const T ax = a_r + a_f * cd + (F - fyf * sd) * (1.0 / ag.mass);
+  const T ay = a_f * sd + (fyf * cd + fyr) * (1.0 / ag.mass);
+  T se, ce, st, ct;
+  ty_sincos(q[5], se, ce);
+  ty_sincos(q[5] + psit, st, ct);
+  const T vlon = (vx * ce - vy * se) * ty_recip(1.0 - q[7] * c);
+  dq[0] = vx * ct - vy * st;
+  dq[1] = vy * ct + vx * st;
+  dq[2] = ax + w * vy;
+  dq[3] = ay - w * vx;
+  dq[4] = (fyf * cd * ag.L_f - fyr * ag.L_r) * (1.0 / ag.I_z);
+  dq[5] = w - vlon * c;
+  dq[6] = vlon;
+  dq[7] = vx * se + vy * ce;
+}
+
+template <int DEG, int NQA>
+__device__ inline void dev_fc(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const Ty<DEG>* q, const Ty<DEG>* u, Ty<DEG>* dq) {
+  if constexpr (NQA == 8) dev_fc_dyn<DEG>(P, ag, q, u, dq); else dev_fc_kin<DEG>(P, ag, q, u, dq);
+}
+
+// one discrete step of the joint model's integrator (dynamics_models.py:88-99, :188-219)
+template <int DEG, int NQA>
+__device__ inline void dev_fd(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const Ty<DEG>* q, const Ty<DEG>* u, Ty<DEG>* qn) {
+  typedef Ty<DEG> T;
+  T x[NQA], k1[NQA], k2[NQA], k3[NQA], t[NQA];
+  for (int i = 0; i < NQA; i++) x[i] = q[i];
+  if (P.integrator == DGSQP_INT_EULER) {
+    dev_fc<DEG, NQA>(P, ag, x, u, k1);
+    for (int i = 0; i < NQA; i++) qn[i] = x[i] + k1[i] * P.dt;
+    return;
+  }
+  const double h = P.dt / P.substeps;
+  for (int m = 0; m < P.substeps; m++) {
+    if (P.integrator == DGSQP_INT_RK4) {
+      dev_fc<DEG, NQA>(P, ag, x, u, k1);
+      for (int i = 0; i < NQA; i++) t[i] = x[i] + k1[i] * (h / 2);
+      dev_fc<DEG, NQA>(P, ag, t, u, k2);
+      for (int i = 0; i < NQA; i++) { t[i] = x[i] + k2[i] * (h / 2); k1[i] = k1[i] + k2[i] * 2.0; }
+      dev_fc<DEG, NQA>(P, ag, t, u, k3);
+      for (int i = 0; i < NQA; i++) { t[i] = x[i] + k3[i] * h; k1[i] = k1[i] + k3[i] * 2.0; }
+      dev_fc<DEG, NQA>(P, ag, t, u, k2);
+      for (int i = 0; i < NQA; i++) x[i] = x[i] + (k1[i] + k2[i]) * h / 6.0;
+    } else if (P.integrator == DGSQP_INT_RK3) {
+      dev_fc<DEG, NQA>(P, ag, x, u, k1);
+      for (int i = 0; i < NQA; i++) { k1[i] = k1[i] * h; t[i] = x[i] + k1[i] * 0.5; }
+      dev_fc<DEG, NQA>(P, ag, t, u, k2);
+      for (int i = 0; i < NQA; i++) { k2[i] = k2[i] * h; t[i] = x[i] - k1[i] + k2[i] * 2.0; }
+      dev_fc<DEG, NQA>(P, ag, t, u, k3);
+      for (int i = 0; i < NQA; i++) x[i] = x[i] + (k1[i] + k2[i] * 4.0 + k3[i] * h) / 6.0;
+    } else {
+      dev_fc<DEG, NQA>(P, ag, x, u, k1);
+      for (int i = 0; i < NQA; i++) t[i] = x[i] + k1[i] * h;
+      dev_fc<DEG, NQA>(P, ag, t, u, k2);
+      for (int i = 0; i < NQA; i++) x[i] = x[i] + (k1[i] + k2[i]) * (h / 2);
+    }
+  }
+  for (int i = 0; i < NQA; i++) qn[i] = x[i];
+}
+
+__device__ inline int am_col(const DgProb& D, int a, int k, int j) { return a * D.N * DGSQP_NUA + k * DGSQP_NUA + j; }
+
+// ------------------------------------------------------------------------------------------------
+// structured products with the constraint Jacobian G (n_c x n), never formed densely
+// ------------------------------------------------------------------------------------------------
+// y[r] = (G x)[r] for one row
+__device__ inline double g_row_dot(const DgProb& D, const double* gd, int r, const double* x) {
+  const DgRow R = D.rows[r];
+  switch (R.type) {
+    case DG_R_IN_UB: return x[am_col(D, R.a, R.k, R.idx)];
+    case DG_R_IN_LB: return -x[am_col(D, R.a, R.k, R.idx)];
+    case DG_R_RATE_UB:
+    case DG_R_RATE_LB: {
+      double t = x[am_col(D, R.a, R.k, R.idx)];
+      if (R.k > 0) t -= x[am_col(D, R.a, R.k - 1, R.idx)];
+      return R.type == DG_R_RATE_UB ? t : -t;
+    }
+    default: {
+      const DgDense dd = D.dense[R.dense];
+      const double* p = gd + dd.off;
+      const int len = 2 * dd.k;
+      double s = 0;
+      const double* xa = x + dd.a * D.N * DGSQP_NUA;
+      for (int i = 0; i < len; i++) s += p[i] * xa[i];
+      if (dd.kind == 1) {
+        const double* xb = x + dd.b * D.N * DGSQP_NUA;
+        for (int i = 0; i < len; i++) s += p[len + i] * xb[i];
+      }
+      return R.sgn * s;
+    }
+  }
+}
+// out[n] = G^T y.  yd is an LDS scratch of ndense doubles.  Contains barriers.
+__device__ inline void gt_mul(const Ctx& c, const double* y, double* out) {
+  const DgProb& D = *c.D;
+  double* yd = c.lds + D.L.yd;
+  const double* gd = c.lds + D.L.gd;
+  __syncthreads();
+  for (int d = TID; d < D.ndense; d += NT) yd[d] = 0.0;
+  __syncthreads();
+  for (int r = TID; r < D.nc; r += NT) {
+    const DgRow R = D.rows[r];
+    if (R.dense >= 0 && R.sgn > 0) yd[R.dense] = y[r];  // ub / obstacle row first ...
+  }
+  __syncthreads();
+  for (int r = TID; r < D.nc; r += NT) {
+    const DgRow R = D.rows[r];
+    if (R.dense >= 0 && R.sgn < 0) yd[R.dense] -= y[r];  // ... then the lb row sharing the gradient
+  }
+  __syncthreads();
+  for (int col = TID; col < D.n; col += NT) {
+    const int a = col / (D.N * DGSQP_NUA), rem = col % (D.N * DGSQP_NUA), t = rem / DGSQP_NUA, j = rem % DGSQP_NUA;
+    double s = 0;
+    int r;
+    if ((r = D.r_in_ub[a][t][j]) >= 0) s += y[r];
+    if ((r = D.r_in_lb[a][t][j]) >= 0) s -= y[r];
+    if ((r = D.r_rate_ub[a][t][j]) >= 0) s += y[r];
+    if ((r = D.r_rate_lb[a][t][j]) >= 0) s -= y[r];
+    if (t + 1 < D.N) {
+      if ((r = D.r_rate_ub[a][t + 1][j]) >= 0) s -= y[r];
+      if ((r = D.r_rate_lb[a][t + 1][j]) >= 0) s += y[r];
+    }
+    for (int d = 0; d < D.ndense; d++) {
+      const DgDense dd = D.dense[d];
+      if (dd.k <= t) continue;
+      if (dd.a == a) s += yd[d] * gd[dd.off + t * DGSQP_NUA + j];
+      else if (dd.kind == 1 && dd.b == a) s += yd[d] * gd[dd.off + 2 * dd.k + t * DGSQP_NUA + j];
+    }
+    out[col] = s;
+  }
+  __syncthreads();
+}

@@ -1,0 +1,206 @@
+// Host+device description of one game as the HIP kernels see it: dimensions,
+// the constraint-row table (reference row order, DGSQP/solvers/DGSQP.py:732-821),
+// the packed storage of the distinct dense constraint gradients
+//  and the LDS arena of one scenario workgroup.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/dgsqp.h"
+
+#define DG_NMAX 64        // horizon limit
+#define DG_NCMAX 2048     // inequality rows limit
+#define DG_NDMAX 512      // distinct dense gradients limit
+#define DG_MAXEFF 8       // effective variables of one agent's dynamics (dyn bicycle: 6 states + 2 inputs)
+#define DG_MAXDIR 36      // MAXEFF*(MAXEFF+1)/2 Taylor directions
+#define DG_BLOCK 256      // threads per scenario workgroup (4 wavefronts)
+#define DG_LDS_LIMIT 163840
+
+enum { DG_R_OBS = 0, DG_R_RATE_UB, DG_R_RATE_LB, DG_R_IN_UB, DG_R_IN_LB, DG_R_ST_UB, DG_R_ST_LB };
+
+struct DgRow {      // one inequality row
+  int8_t type, a, b, idx, sgn;  // sgn: coefficient of the shared dense gradient (+1 / -1)
+  int8_t k;
+  int16_t dense;    // index of the dense gradient backing this row, or -1
+};
+
+struct DgDense {    // one distinct dense gradient: d x^a_k[idx] / du   or the obstacle gradient of pair (a,b) at stage k
+  int8_t kind;      // 0 state row, 1 obstacle
+  int8_t a, b, idx, k;
+  int32_t off;      // offset in the packed Gd array; kind 0: 2k entries [t][j]; kind 1: 4k entries, agent a then agent b
+};
+
+// LDS arena, offsets in doubles
+struct DgLds {
+  // persistent
+  int u, l, q, g, d, v, gd, yd, red, scal;
+  int scr;  // start of phase scratch
+  // EVAL scratch (absolute offsets)
+  int e_x, e_ue, e_A[DGSQP_MAX_AGENTS], e_B[DGSQP_MAX_AGENTS], e_dJ, e_Dx, e_Dxx, e_nDxx, e_tQA, e_tQB, e_A1, e_A2, e_Dxu, e_Hc, e_cv, e_inj;
+  // EIG scratch
+  int g_Bp, g_V, g_rot;
+  // QP scratch (P shares g_Bp)
+  int p_R, p_lam, p_c, p_w, p_r, p_y, p_z, p_t, p_alist, p_act;
+  // QP outputs that must survive trial evaluations
+  int o_du, o_lhat;
+  // LSQR scratch
+  int s_u, s_v, s_w, s_x, s_t;
+  int total;  // doubles
+};
+
+struct DgProb {
+  dgsqp_problem_t P;
+  dgsqp_params_t par;
+  int M, N, nq, nu, n, nc, npairs, ndense, ngd;
+  int nqa[DGSQP_MAX_AGENTS], qoff[DGSQP_MAX_AGENTS], sidx[DGSQP_MAX_AGENTS], eyidx[DGSQP_MAX_AGENTS];
+  int neff[DGSQP_MAX_AGENTS], ndir[DGSQP_MAX_AGENTS];
+  int effvar[DGSQP_MAX_AGENTS][DG_MAXEFF];  // effective variable -> index into z = (q_0..q_{nqa-1}, u_0, u_1)
+  int t2off[DGSQP_MAX_AGENTS];              // offset (doubles) of agent block in the Taylor tensor workspace
+  int t2k[DGSQP_MAX_AGENTS];                // per-stage stride of that block = nqa*ndir
+  int64_t ws_t2, ws_q, ws_base, ws_doubles; // global workspace layout (doubles): Taylor tensor, raw Q, watchdog backups
+  DgRow rows[DG_NCMAX];
+  DgDense dense[DG_NDMAX];
+  int16_t r_in_ub[DGSQP_MAX_AGENTS][DG_NMAX][DGSQP_NUA], r_in_lb[DGSQP_MAX_AGENTS][DG_NMAX][DGSQP_NUA];
+  int16_t r_rate_ub[DGSQP_MAX_AGENTS][DG_NMAX][DGSQP_NUA], r_rate_lb[DGSQP_MAX_AGENTS][DG_NMAX][DGSQP_NUA];
+  int16_t stage_row0[DG_NMAX + 2];   // first row of each stage (rows are ordered by stage)
+  int16_t stage_dense0[DG_NMAX + 2]; // first dense gradient of each stage
+  DgLds L;
+};
+
+#include <cmath>
+#include <cstring>
+#include <string>
+
+// Build the device-side problem description. Returns empty string on success, else an error message.
+static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_t& par, DgProb& D) {
+  memset(&D, 0, sizeof(D));
+  D.P = P; D.par = par;
+  if (P.M < 1 || P.M > DGSQP_MAX_AGENTS) return "unsupported number of agents";
+  if (P.N < 1 || P.N > DG_NMAX) return "unsupported horizon";
+  if (P.n_segs < 1 || P.n_segs > DGSQP_MAX_SEGS) return "bad track table";
+  D.M = P.M; D.N = P.N; D.nq = 0; D.nu = P.M * DGSQP_NUA;
+  int t2 = 0;
+  for (int a = 0; a < P.M; a++) {
+    const bool dyn = P.agents[a].model == DGSQP_MODEL_DYN_BICYCLE;
+    if (P.agents[a].model != DGSQP_MODEL_KIN_BICYCLE && !dyn) return "unsupported vehicle model";
+    D.nqa[a] = dyn ? 8 : 6;
+    D.qoff[a] = D.nq; D.nq += D.nqa[a];
+    D.sidx[a] = dyn ? 6 : 4; D.eyidx[a] = dyn ? 7 : 5;
+    // x, y (state 0,1) never enter fc: effective variables are the remaining states and the two inputs
+    D.neff[a] = D.nqa[a];  // (nqa-2) states + 2 inputs
+    for (int e = 0; e < D.nqa[a] - 2; e++) D.effvar[a][e] = e + 2;
+    D.effvar[a][D.nqa[a] - 2] = D.nqa[a]; D.effvar[a][D.nqa[a] - 1] = D.nqa[a] + 1;
+    D.ndir[a] = D.neff[a] * (D.neff[a] + 1) / 2;
+    D.t2off[a] = t2; D.t2k[a] = D.nqa[a] * D.ndir[a];
+    t2 += P.N * D.t2k[a];
+  }
+  D.n = P.N * D.nu;
+  D.npairs = P.obstacle_rows ? P.M * (P.M - 1) / 2 : 0;
+  for (int a = 0; a < DGSQP_MAX_AGENTS; a++)
+    for (int k = 0; k < DG_NMAX; k++)
+      for (int j = 0; j < DGSQP_NUA; j++) D.r_in_ub[a][k][j] = D.r_in_lb[a][k][j] = D.r_rate_ub[a][k][j] = D.r_rate_lb[a][k][j] = -1;
+  // ---- rows in reference order, dense gradients in (stage, [pairs], agent, state idx) order
+  int nc = 0, nd = 0, off = 0;
+  auto add_row = [&](int type, int k, int a, int b, int idx, int sgn, int dense) -> bool {
+    if (nc >= DG_NCMAX) return false;
+    D.rows[nc] = DgRow{(int8_t)type, (int8_t)a, (int8_t)b, (int8_t)idx, (int8_t)sgn, (int8_t)k, (int16_t)dense};
+    nc++;
+    return true;
+  };
+  for (int k = 0; k <= P.N; k++) {
+    D.stage_row0[k] = (int16_t)nc; D.stage_dense0[k] = (int16_t)nd;
+    if (P.obstacle_rows && k >= 1)
+      for (int i = 0; i < P.M; i++)
+        for (int j = i + 1; j < P.M; j++) {
+          if (nd >= DG_NDMAX) return "too many dense rows";
+          D.dense[nd] = DgDense{1, (int8_t)i, (int8_t)j, 0, (int8_t)k, off};
+          off += 4 * k;
+          if (!add_row(DG_R_OBS, k, i, j, 0, 1, nd)) return "too many rows";
+          nd++;
+        }
+    for (int a = 0; a < P.M; a++) {
+      const dgsqp_agent_t& ag = P.agents[a];
+      if (k < P.N) {
+        if (ag.has_rate)
+          for (int j = 0; j < DGSQP_NUA; j++) {
+            D.r_rate_ub[a][k][j] = (int16_t)nc; if (!add_row(DG_R_RATE_UB, k, a, -1, j, 1, -1)) return "too many rows";
+            D.r_rate_lb[a][k][j] = (int16_t)nc; if (!add_row(DG_R_RATE_LB, k, a, -1, j, -1, -1)) return "too many rows";
+          }
+        for (int j = 0; j < DGSQP_NUA; j++)
+          if (ag.in_ub[j] < INFINITY) { D.r_in_ub[a][k][j] = (int16_t)nc; if (!add_row(DG_R_IN_UB, k, a, -1, j, 1, -1)) return "too many rows"; }
+        for (int j = 0; j < DGSQP_NUA; j++)
+          if (ag.in_lb[j] > -INFINITY) { D.r_in_lb[a][k][j] = (int16_t)nc; if (!add_row(DG_R_IN_LB, k, a, -1, j, -1, -1)) return "too many rows"; }
+      }
+      if (k > 0) {
+        // one dense gradient per constrained state, shared by its ub and lb rows
+        int dense_of[DGSQP_MAX_NQA];
+        for (int i = 0; i < D.nqa[a]; i++) {
+          dense_of[i] = -1;
+          if (ag.st_ub[i] < INFINITY || ag.st_lb[i] > -INFINITY) {
+            if (nd >= DG_NDMAX) return "too many dense rows";
+            D.dense[nd] = DgDense{0, (int8_t)a, -1, (int8_t)i, (int8_t)k, off};
+            off += 2 * k;
+            dense_of[i] = nd++;
+          }
+        }
+        for (int i = 0; i < D.nqa[a]; i++)
+          if (ag.st_ub[i] < INFINITY) if (!add_row(DG_R_ST_UB, k, a, -1, i, 1, dense_of[i])) return "too many rows";
+        for (int i = 0; i < D.nqa[a]; i++)
+          if (ag.st_lb[i] > -INFINITY) if (!add_row(DG_R_ST_LB, k, a, -1, i, -1, dense_of[i])) return "too many rows";
+      }
+    }
+  }
+  D.stage_row0[P.N + 1] = (int16_t)nc; D.stage_dense0[P.N + 1] = (int16_t)nd;
+  D.nc = nc; D.ndense = nd; D.ngd = off;
+  // ---- global workspace (doubles)
+  D.ws_t2 = 0;
+  D.ws_q = D.ws_t2 + t2;
+  D.ws_base = D.ws_q + (int64_t)D.n * D.n;
+  D.ws_doubles = D.ws_base + 2 * D.n + 2 * D.nc + 16;
+  D.ws_doubles = (D.ws_doubles + 31) / 32 * 32;
+  // ---- LDS arena
+  DgLds& L = D.L;
+  const int n = D.n, nq = D.nq, nu = D.nu, N = D.N;
+  int o = 0;
+  auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
+  L.u = take(n); L.l = take(nc); L.q = take(n); L.g = take(nc); L.d = take(n); L.v = take(n);
+  L.gd = take(D.ngd); L.yd = take(nd); L.red = take(64); L.scal = take(64);
+  L.scr = o;
+  // EVAL
+  o = L.scr;
+  L.e_x = take((N + 1) * nq); L.e_ue = take(n);
+  for (int a = 0; a < D.M; a++) { L.e_A[a] = take(N * D.nqa[a] * D.nqa[a]); L.e_B[a] = take(N * D.nqa[a] * DGSQP_NUA); }
+  L.e_dJ = take((N + 1) * nq);
+  L.e_Dx = take(2 * nq); L.e_Dxx = take(nq * nq); L.e_nDxx = take(nq * nq); L.e_tQA = take(nq * nq); L.e_tQB = take(nq * nu);
+  L.e_A1 = take(nu * nu); L.e_A2 = take(nu * nq); L.e_Dxu = take(2 * n * nq);
+  L.e_Hc = take(D.M * (DG_MAXEFF * DG_MAXEFF)); L.e_cv = take(D.M * DG_MAXDIR); L.e_inj = take(nq + nq * nq);
+  const int eval_end = o;
+  // EIG
+  o = L.scr;
+  const int npk = n * (n + 1) / 2;
+  L.g_Bp = take(npk); L.g_V = take(n * n); L.g_rot = take(4 * ((n + 1) / 2 + 1) + 2 * n + 4);
+  const int eig_end = o;
+  // QP (P aliases Bp)
+  o = L.scr + ((npk + 1) & ~1);
+  L.p_R = take(npk); L.p_lam = take(n + 1); L.p_c = take(n + 1); L.p_w = take(n + 1); L.p_r = take(n + 1);
+  L.p_y = take(n); L.p_z = take(n); L.p_t = take(n); L.p_alist = take((n + 2) / 2 + 1); L.p_act = take(nc / 8 + 2);
+  const int qp_end = o;
+  // QP outputs live past the end of both the QP and EVAL scratch
+  o = qp_end > eval_end ? qp_end : eval_end;
+  L.o_du = take(n); L.o_lhat = take(nc);
+  const int out_end = o;
+  // LSQR
+  o = L.scr;
+  L.s_u = take(nc); L.s_v = take(nc); L.s_w = take(nc); L.s_x = take(nc); L.s_t = take(nc > n ? nc : n);
+  const int lsqr_end = o;
+  int tot = eval_end;
+  if (eig_end > tot) tot = eig_end;
+  if (out_end > tot) tot = out_end;
+  if (lsqr_end > tot) tot = lsqr_end;
+  L.total = tot;
+  if ((long)tot * 8 > DG_LDS_LIMIT) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "problem needs %ld B of LDS per scenario (limit %d): n=%d n_c=%d", (long)tot * 8, DG_LDS_LIMIT, n, nc);
+    return buf;
+  }
+  return "";
+}

@@ -267,6 +267,20 @@ class DGSQP(AbstractSolver):
         out['u_pred'] = self._to_time_major(out['u'])
         return out
 
+    def set_trace(self, pairs_per_scenario: int):
+        """Test hook: record the SQP event log of subsequent solves (0 disables)."""
+        self._trace_cap = int(pairs_per_scenario)
+        self._lib.dgsqp_set_trace(self._h, self._trace_cap)
+
+    def fetch_trace(self, B: int):
+        """List of [(code, value)] arrays, one per scenario of the last solve_batch."""
+        cap = getattr(self, '_trace_cap', 0)
+        raw = np.zeros((B, 1 + 2 * cap))
+        rc = self._lib.dgsqp_fetch_trace(self._h, _ffi.dptr(raw))
+        if rc != 0:
+            raise RuntimeError(self._lib.dgsqp_last_error(self._h).decode())
+        return [raw[b, 1:1 + 2 * int(raw[b, 0])].reshape(-1, 2) for b in range(B)]
+
     # ---- test hooks ----------------------------------------------------------------------------
     def evaluate_batch(self, x0, u, l=None):
         """One ``_evaluate(u, l, x0, up=0, hessian=True)`` per row (DGSQP.py:509-533) + dual init."""

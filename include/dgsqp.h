@@ -204,6 +204,14 @@ int dgsqp_evaluate_batch(dgsqp_handle_t h, int64_t B, const double* x0, const do
 int dgsqp_qp_batch(dgsqp_handle_t h, int64_t B, const double* x0, const double* u,
                    const double* l, double* du, double* lhat, double* Qpd, int32_t* flag);
 
+/*
+ * Test hook: event log of the SQP state machine (convergence measures, merit values, step lengths,
+ * watchdog branches) of every scenario of the next solve calls; compared event-by-event with the
+ * oracle's log.  Layout per scenario: [count, (code, value) x pairs_per_scenario].  0 disables.
+ */
+int dgsqp_set_trace(dgsqp_handle_t h, int pairs_per_scenario);
+int dgsqp_fetch_trace(dgsqp_handle_t h, double* out);
+
 #ifdef __cplusplus
 }
 #endif

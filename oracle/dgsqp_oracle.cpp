@@ -993,7 +993,9 @@ struct Ctx {
   const Layout& L;
   const double* x0;
   int literal;
+  vec* trace;  // optional event log (code, value) pairs, compared event-by-event with the device trace
 };
+static inline void tr(const Ctx& c, int code, double v) { if (c.trace) { c.trace->push_back((double)code); c.trace->push_back(v); } }
 static void eval_lin(const Ctx& c, const vec& u, const vec& l, bool hessian, Lin& out, vec* xout = nullptr) {
   Eval ev;
   evaluate(c.P, c.L, u.data(), l.data(), c.x0, hessian, c.literal, ev);
@@ -1032,6 +1034,7 @@ static void line_search_3(const Ctx& c, double mu, const vec& u, const vec& du, 
     Lin tr;
     eval_lin(c, ut, lt, false, tr);
     phit = f_phi(c.L, c.par, lt, st, tr.q, tr.G, tr.g, mu);
+    ::tr(c, 30, alpha); ::tr(c, 31, phit);
     if (phit <= phi + c.par.beta * alpha * dphi) break;
     alpha *= c.par.tau;
   }
@@ -1050,6 +1053,7 @@ static void watchdog_4(const Ctx& c, double mu, const vec& u_k, const vec& du_k,
   Lin tr;
   eval_lin(c, u1, l1, false, tr);
   const double phi1 = f_phi(c.L, c.par, l1, s1, tr.q, tr.G, tr.g, mu);
+  ::tr(c, 20, phi1);
   if (phi1 <= phi_k + c.par.beta * dphi_k) { u_out = u1; l_out = l1; return; }
   bool fail = false;
   vec u_t = u1, l_t = l1, du, lhat, dl, s, ds, u_n, l_n;
@@ -1064,6 +1068,7 @@ static void watchdog_4(const Ctx& c, double mu, const vec& u_k, const vec& du_k,
     u_n = axpy(u_t, 1.0, du); l_n = lhat; vec s_n = axpy(s, 1.0, ds);
     eval_lin(c, u_n, l_n, false, tr);
     phi_n = f_phi(c.L, c.par, l_n, s_n, tr.q, tr.G, tr.g, mu);
+    ::tr(c, 21, phi_n);
     if (phi_n > merit_max) break;
     if (phi_n <= phi_k + c.par.beta * dphi_k) { u_out = u_n; l_out = l_n; return; }
     u_t = u_n; l_t = l_n;
@@ -1076,6 +1081,7 @@ static void watchdog_4(const Ctx& c, double mu, const vec& u_k, const vec& du_k,
   else {
     step_vectors(c.L, lt, du, l_t, lhat, dl, s, ds);
     line_search_3(c, mu, u_t, du, l_t, dl, s, ds, lt, u_n, l_n, phi_n);
+    ::tr(c, 22, phi_n);
   }
   if (!fail) {
     if (phi_n <= phi_k + c.par.beta * dphi_k) { u_out = u_n; l_out = l_n; return; }
@@ -1108,8 +1114,8 @@ struct SolveOut {
   double cond[3];
   double cost[DGSQP_MAX_AGENTS];
 };
-static void solve_one(const dgsqp_problem_t& P, const dgsqp_params_t& par, const Layout& L, const double* x0, const double* u_ws, int literal, SolveOut& out) {
-  Ctx c{P, par, L, x0, literal};
+static void solve_one(const dgsqp_problem_t& P, const dgsqp_params_t& par, const Layout& L, const double* x0, const double* u_ws, int literal, SolveOut& out, vec* trace = nullptr) {
+  Ctx c{P, par, L, x0, literal, trace};
   vec u(u_ws, u_ws + L.n), l;
   {
     Eval ev;
@@ -1130,6 +1136,7 @@ static void solve_one(const dgsqp_problem_t& P, const dgsqp_params_t& par, const
     for (int r = 0; r < L.nc; r++) { gmax = std::max(gmax, k.g[r]); comp = std::max(comp, std::fabs(k.g[r] * l[r])); }
     p_feas = std::max(0.0, gmax);
     for (int cc = 0; cc < L.n; cc++) { double d = k.q[cc]; for (int r = 0; r < L.nc; r++) d += k.G[(size_t)r * L.n + cc] * l[r]; stat = std::max(stat, std::fabs(d)); }
+    tr(c, 1, stat); tr(c, 2, p_feas); tr(c, 3, comp);
     if (stat > 1e5) { status = DGSQP_DIVERGED; break; }
     if (p_feas < par.p_tol && comp < par.d_tol && stat < par.d_tol) { status = DGSQP_CONV_ABS_TOL; break; }
     vec du, lhat;
@@ -1139,6 +1146,10 @@ static void solve_one(const dgsqp_problem_t& P, const dgsqp_params_t& par, const
     vec dl, s, ds;
     step_vectors(L, k, du, l, lhat, dl, s, ds);
     const double mu = get_mu(L, par, du, l, dl, s, k);
+    { double d2 = 0; for (double e : du) d2 += e * e; tr(c, 10, d2); }
+    tr(c, 11, mu);
+    tr(c, 12, f_phi(L, par, l, s, k.q, k.G, k.g, mu));
+    tr(c, 13, f_dphi(L, par, du, l, dl, s, k, mu));
     if (par.nonmono_ls) {
       int nqp = 0; vec un, ln;
       watchdog_4(c, mu, u, du, l, dl, s, ds, k, un, ln, nqp);
@@ -1276,6 +1287,19 @@ int oracle_merit(const dgsqp_problem_t* P, const dgsqp_params_t* par, const doub
   if (mu_out) { *mu_out = get_mu(L, *par, duv, lv, dlv, sv, k); }
   if (phi) *phi = f_phi(L, *par, lv, sv, k.q, k.G, k.g, mu);
   if (dphi) *dphi = f_dphi(L, *par, duv, lv, dlv, sv, k, mu);
+  return 0;
+}
+
+// DGSQP.solve() of one scenario with the event log used by the trace-parity tests
+int oracle_solve_trace(const dgsqp_problem_t* P, const dgsqp_params_t* par, const double* x0, const double* u_ws, double* trace_out, int32_t max_pairs, int32_t* n_pairs) {
+  Layout L = make_layout(*P);
+  SolveOut o;
+  vec t;
+  solve_one(*P, *par, L, x0, u_ws, 0, o, &t);
+  int np = (int)t.size() / 2;
+  if (np > max_pairs) np = max_pairs;
+  for (int i = 0; i < 2 * np; i++) trace_out[i] = t[i];
+  *n_pairs = np;
   return 0;
 }
 

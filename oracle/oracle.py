@@ -147,3 +147,13 @@ def solve_batch(P, par, x0, u_ws, literal=0, nthreads=1):
                              _i(out['status']), _i(out['num_iters']), _i(out['qp_solves']), _d(out['cond']), _d(out['cost']),
                              _d(out['l_init']), C.c_int(literal), C.c_int(nthreads))
     return out
+
+
+def solve_trace(P, par, x0, u_ws, max_pairs=20000):
+    """Event log [(code, value)] of one solve (see tr() in dgsqp_oracle.cpp)."""
+    x0 = np.ascontiguousarray(x0, float)
+    u_ws = np.ascontiguousarray(u_ws, float)
+    out = np.zeros((max_pairs, 2))
+    npairs = C.c_int32()
+    lib().oracle_solve_trace(C.byref(P), C.byref(par), _d(x0), _d(u_ws), _d(out), C.c_int32(max_pairs), C.byref(npairs))
+    return out[:npairs.value]

@@ -1,0 +1,25 @@
+"""Development aid: time solve_batch for a config on the GPU box."""
+import sys, time, pathlib
+import numpy as np
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+from dgsqp_amd.montecarlo import kinematic_racing_game, dynamic_racing_game, sample_scenarios
+from dgsqp_amd.solver import DGSQP
+which, N, B = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+M = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+game = kinematic_racing_game('curve' if which == 'kbcurve' else 'chicane', N=N) if which.startswith('kb') else dynamic_racing_game(N=N, rk4_substeps=M)
+s = DGSQP(*game.solver_args(), print_method=None)
+t = time.time(); x0, uws = sample_scenarios(game, B, seed=1); print('sample', time.time() - t)
+for rep in range(2):
+    t = time.time(); res = s.solve_batch(x0, uws); dt = time.time() - t
+    st = res['status']
+    print(f'{which} N={N} B={B} wall {dt:.3f}s kernel {res["kernel_ms"]:.1f} ms -> {B/dt:.1f} scen/s | conv {np.mean(st<=1):.3f} abs {np.mean(st==0):.3f} maxit {np.mean(st==2):.3f} qpfail {np.mean(st==4):.3f} div {np.mean(st==3):.3f} | mean iters {res["num_iters"].mean():.2f} (conv {res["num_iters"][st<=1].mean():.2f}) qps {res["qp_solves"].mean():.2f}')
+import ctypes, os
+lib = s._lib
+if hasattr(lib, 'dgsqp_prof_read'):
+    buf = (ctypes.c_ulonglong * 32)()
+    nph = lib.dgsqp_prof_read(buf, 32)
+    names = ['rollout', 'deriv1', 'deriv2', 'chains', 'dp', 'jacobi', 'pform', 'qp', 'merit', 'lsqr', 'qtmul', 'sweep']
+    tot = sum(buf[2 * i] for i in range(nph))
+    for i in range(nph):
+        if buf[2 * i + 1]:
+            print(f'  {names[i]:8s} cycles {buf[2*i]:>16d} calls {buf[2*i+1]:>9d} per call {buf[2*i]/buf[2*i+1]:>12.0f} share {buf[2*i]/max(tot,1):.3f}')
