@@ -38,6 +38,7 @@ __device__ inline void dev_psd_inverse(const Ctx& c, double* Qpd) {
   }
   for (int t = TID; t < n * n; t += NT) Vt[t] = (t / n == t % n) ? 1.0 : 0.0;
   __syncthreads();
+  bool final_sweep = false;
   for (int sweep = 0; sweep < 40; sweep++) {
     double off = 0, dg = 0;
     for (int t = TID; t < npk; t += NT) {
@@ -49,7 +50,9 @@ __device__ inline void dev_psd_inverse(const Ctx& c, double* Qpd) {
     }
     off = block_sum(off, red);
     dg = block_sum(dg, red);
-    if (off <= 1e-26 * dg || off < 1e-300) break;  // |off| <= 1e-13 |B|_F; Jacobi converges quadratically
+    if (final_sweep || off <= 1e-31 * dg || off < 1e-300) break;
+    // Jacobi converges quadratically: once |off| <= 1e-9 |B|_F one more sweep reaches the rounding floor
+    if (off <= 1e-18 * dg) final_sweep = true;
     PROF_BEGIN(pt_s);
     for (int rd = 0; rd < np - 1; rd++) {
       // rotation angles of the m disjoint pairs of this round

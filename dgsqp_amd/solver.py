@@ -214,7 +214,7 @@ class DGSQP(AbstractSolver):
         """[..., N, n_u] time-major joint inputs -> [..., n] agent-major decision vector."""
         parts, si = [], 0
         for nu in self.num_ua_d:
-            parts.append(u_tm[..., :, si:si + nu].reshape(*u_tm.shape[:-2], -1))
+            parts.append(u_tm[..., :, si:si + nu].reshape(*u_tm.shape[:-2], self.N * nu))
             si += nu
         return np.concatenate(parts, axis=-1)
 

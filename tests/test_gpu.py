@@ -1,0 +1,204 @@
+"""Parity of the HIP path (through the C-ABI) with the CPU oracle, on a real MI355X.
+
+Bars: integer outputs (status, iteration counts, QP-solve counts) identical; floating-point iterates within
+1e-5 relative (north_star), stage-level quantities far tighter (stated per test).  Full solves are compared
+with a converged LSQR dual start (conftest.tight_lsqr) because scipy's default 1e-6 LSQR tolerance leaves a
+~1e-4 spread between any two correct implementations (tests/test_oracle.py::test_lsqr_matches_scipy)."""
+import pathlib
+
+import numpy as np
+import pytest
+
+from conftest import agent_major, tight_lsqr
+
+pytestmark = pytest.mark.gpu
+GOLD = pathlib.Path(__file__).parent / 'golden'
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(1e-300, np.abs(b).max())
+
+
+@pytest.fixture(scope='module')
+def solvers(games):
+    from dgsqp_amd.solver import DGSQP
+    import dgsqp_amd.solver as sv
+    out = {}
+    orig = sv.build_params
+    sv.build_params = lambda p: tight_lsqr(orig(p))
+    try:
+        for name, (g, P, par) in games.items():
+            out[name] = DGSQP(*g.solver_args(), print_method=None)
+    finally:
+        sv.build_params = orig
+    return out
+
+
+def test_native_library_is_loaded(solvers):
+    """The product path is the HIP library (in-tree .so), on a gfx950 device."""
+    import ctypes
+    from dgsqp_amd import _ffi
+    buf = ctypes.create_string_buffer(256)
+    assert _ffi.load_library().dgsqp_backend_info(buf, 256) == 0
+    assert b'gfx950' in buf.value
+    assert _ffi.library_path().name == 'libdgsqp_hip.so' and _ffi.library_path().exists()
+    s = solvers['kb_chicane_N25']
+    assert s.dims.lds_bytes <= 163840 and s.dims.n == 100 and s.dims.n_c == 525 and s.dims.n_dense == 75
+
+
+@pytest.mark.parametrize('name', ['kb_chicane_N15', 'kb_chicane_N25', 'kb_curve_N10', 'dyn_curve_N15'])
+def test_evaluate_parity(oracle, games, solvers, name):
+    """_evaluate (DGSQP.py:509-533): rollout, q, g, G, raw Q.  Tolerance 1e-12 relative (fp64, different
+    derivative techniques: Taylor directions on device vs dense jets in the oracle)."""
+    from dgsqp_amd.montecarlo import sample_scenarios
+    g, P, par = games[name]
+    s = solvers[name]
+    B = 6
+    x0, u_tm = sample_scenarios(g, B, seed=21)
+    rng = np.random.default_rng(0)
+    u = agent_major(u_tm) + 0.01 * rng.standard_normal((B, s.n))
+    l = np.maximum(0, rng.standard_normal((B, s.n_c_total)))
+    ev = s.evaluate_batch(x0, u, l)
+    for b in range(B):
+        o = oracle.evaluate(P, x0[b], u[b], l[b], 1)
+        for key in ('x', 'q', 'g', 'G', 'Q'):
+            assert rel(ev[key][b], o[key]) < 1e-12, (key, b)
+        l0 = oracle.dual_init(P, tight_lsqr(par), x0[b], u[b])
+        assert rel(ev['l0'][b], l0) < 1e-6, b          # LSQR run to 1e-13: both reach the min-norm solution
+
+
+@pytest.mark.parametrize('name', ['kb_chicane_N15', 'kb_chicane_N25', 'dyn_curve_N15'])
+def test_qp_parity_and_kkt(oracle, games, solvers, name):
+    """_nearestPD + _solve_qp (DGSQP.py:232-266, 1290-1296): projected Hessian to 1e-11, primal step to 1e-8,
+    multipliers to 1e-6 relative, identical active sets, KKT residuals of the device answer itself."""
+    from dgsqp_amd.montecarlo import sample_scenarios
+    g, P, par = games[name]
+    s = solvers[name]
+    B = 6
+    x0, u_tm = sample_scenarios(g, B, seed=22)
+    u = agent_major(u_tm)
+    l = np.array([oracle.dual_init(P, tight_lsqr(par), x0[b], u[b]) for b in range(B)])
+    qp = s.qp_batch(x0, u, l)
+    for b in range(B):
+        o = oracle.evaluate(P, x0[b], u[b], l[b], 1)
+        Qpd = oracle.nearest_pd(o['Q'], par.reg)
+        du, lam, flag = oracle.qp(Qpd, o['q'], o['G'], o['g'])
+        assert qp['flag'][b] == flag
+        # absolute error of the projection scales with the RAW Hessian (its large negative part is projected away)
+        assert np.abs(qp['Qpd'][b] - Qpd).max() < 1e-11 * max(1.0, np.abs(o['Q']).max())
+        if flag != 0:
+            continue
+        cond_scale = max(1.0, np.abs(o['Q']).max() / max(1e-300, np.abs(Qpd).max()))
+        assert rel(qp['du'][b], du) < 1e-8 * cond_scale and rel(qp['lhat'][b], lam) < 1e-6 * cond_scale
+        assert np.array_equal(qp['lhat'][b] > 0, lam > 0)
+        d, lh = qp['du'][b], qp['lhat'][b]
+        scale = max(1.0, np.abs(o['q']).max())
+        assert np.abs(Qpd @ d + o['q'] + o['G'].T @ lh).max() < 1e-7 * scale
+        assert (o['G'] @ d + o['g']).max() < 1e-12 and lh.min() >= 0
+        assert np.abs(lh * (o['G'] @ d + o['g'])).max() < 1e-10 * scale
+
+
+@pytest.mark.parametrize('name', ['kb_chicane_N15', 'kb_curve_N10', 'dyn_curve_N15'])
+def test_solve_matches_golden_fixtures(solvers, name):
+    """Committed oracle solutions (tools/make_golden.py): identical flags / iteration / QP counts and iterates
+    within 1e-5 relative on every scenario whose control flow is well conditioned; at most 10 % of the
+    scenarios (50-iteration chaotic runs) may take a different path."""
+    gold = np.load(GOLD / f'{name}.npz')
+    s = solvers[name]
+    res = s.solve_batch(gold['x0'], gold['u_ws'])
+    same = (res['status'] == gold['status']) & (res['num_iters'] == gold['num_iters']) & (res['qp_solves'] == gold['qp_solves'])
+    assert same.mean() >= 0.9, (res['status'], gold['status'], res['num_iters'], gold['num_iters'])
+    easy = gold['num_iters'] < 30
+    assert same[easy].all()
+    for b in np.where(same)[0]:
+        assert rel(res['u'][b], gold['u'][b]) < 1e-5, b
+        if gold['status'][b] == 0:
+            assert rel(res['l'][b], gold['l'][b]) < 1e-5, b
+            assert rel(res['cost'][b], gold['cost'][b]) < 1e-8, b
+
+
+def test_event_trace_parity(oracle, games, solvers):
+    """Event-by-event comparison of the SQP state machine (convergence measures, mu, merit values, every
+    watchdog / line-search trial): same event codes in the same order, values within 1e-5 relative."""
+    from dgsqp_amd.montecarlo import sample_scenarios
+    name = 'kb_chicane_N15'
+    g, P, par = games[name]
+    s = solvers[name]
+    B = 12
+    x0, u_tm = sample_scenarios(g, B, seed=23)
+    s.set_trace(6000)
+    try:
+        res = s.solve_batch(x0, u_tm)
+        traces = s.fetch_trace(B)
+    finally:
+        s.set_trace(0)
+    identical = 0
+    for b in range(B):
+        to = oracle.solve_trace(P, tight_lsqr(par), x0[b], agent_major(u_tm)[b])
+        tg = traces[b]
+        if len(to) == len(tg) and np.array_equal(to[:, 0], tg[:, 0]):
+            big = np.abs(to[:, 1]) > 1e-6
+            if np.all(np.abs(tg[big, 1] - to[big, 1]) <= 1e-5 * np.abs(to[big, 1])):
+                identical += 1
+    assert identical >= B - 1, identical
+
+
+def test_full_size_properties(games):
+    """BASELINE config sizes (2-agent N=25, B=1024): size-independent properties.
+    * conv_abs_tol  =>  optimality measures recomputed from (u, l) by an independent kernel are below tolerance
+    * multipliers non-negative, iteration counts within [0, sqp_iters]
+    * bitwise determinism of a repeated run and invariance to the order of the scenarios in the batch."""
+    from dgsqp_amd.montecarlo import sample_scenarios
+    from dgsqp_amd.solver import DGSQP
+    g, P, par = games['kb_chicane_N25']
+    s = DGSQP(*g.solver_args(), print_method=None)
+    B = 1024
+    x0, u_tm = sample_scenarios(g, B, seed=1)
+    res = s.solve_batch(x0, u_tm)
+    st = res['status']
+    assert set(np.unique(st)).issubset({0, 1, 2, 3, 4}) and (res['num_iters'] <= 50).all() and (res['num_iters'] >= 0).all()
+    assert (st <= 1).mean() > 0.5
+    ok = np.where(st == 0)[0]
+    ev = s.evaluate_batch(x0[ok[:64]], res['u'][ok[:64]], res['l'][ok[:64]])
+    for i, b in enumerate(ok[:64]):
+        assert max(0.0, ev['g'][i].max()) < par.p_tol
+        assert np.abs(ev['g'][i] * res['l'][b]).max() < par.d_tol
+        assert np.abs(ev['q'][i] + ev['G'][i].T @ res['l'][b]).max() < par.d_tol
+        assert (res['l'][b] >= 0).all()
+        np.testing.assert_allclose(ev['x'][i], res['x'][b], rtol=0, atol=1e-12)
+    res2 = s.solve_batch(x0, u_tm)
+    for k in ('u', 'l', 'status', 'num_iters', 'qp_solves', 'cond', 'cost'):
+        assert np.array_equal(res[k], res2[k], equal_nan=True), k
+    perm = np.random.default_rng(0).permutation(B)
+    res3 = s.solve_batch(x0[perm], u_tm[perm])
+    assert np.array_equal(res3['status'], st[perm]) and np.array_equal(res3['u'], res['u'][perm], equal_nan=True)
+
+
+def test_edge_cases_and_reference_surface(games, oracle):
+    """Empty and ragged batches, wrong shapes, the single-scenario reference surface (solve / step / set_warm_start)."""
+    from dgsqp_amd.montecarlo import sample_scenarios
+    from dgsqp_amd.solver import DGSQP
+    from dgsqp_amd.types import VehicleState
+    g, P, par = games['kb_curve_N10']
+    s = DGSQP(*g.solver_args(), print_method=None)
+    x0, u_tm = sample_scenarios(g, 3, seed=6)
+    empty = s.solve_batch(x0[:0], u_tm[:0])
+    assert empty['u'].shape == (0, s.n) and empty['status'].shape == (0,)
+    one = s.solve_batch(x0[:1], u_tm[:1])
+    three = s.solve_batch(x0, u_tm)                                  # B=3 < grid: ragged last wave of work
+    assert np.array_equal(one['u'][0], three['u'][0])
+    with pytest.raises(RuntimeError):
+        s.set_warm_start(np.zeros((s.N + 1, s.n_u)))                  # DGSQP.py:272-273
+    with pytest.raises(RuntimeError):
+        s.solve_batch(x0, u_tm[:, :-1])
+    states = [VehicleState(t=0.0), VehicleState(t=0.0)]
+    g.joint_model.qu2state(states, x0[0], None)
+    s.set_warm_start(u_tm[0])
+    info = s.solve(states)
+    assert set(info) == {'time', 'num_iters', 'status', 'cost', 'cond', 'iter_data', 'msg', 'init'}     # DGSQP.py:495-502
+    assert info['msg'] in ('conv_abs_tol', 'conv_rel_tol', 'max_it', 'diverged', 'qp_fail')
+    assert info['num_iters'] == int(three['num_iters'][0]) and s.q_pred.shape == (s.N + 1, s.n_q) and s.u_pred.shape == (s.N, s.n_u)
+    np.testing.assert_allclose(s.u_pred, three['u_pred'][0])
+    info2 = s.step(states)
+    assert states[0].u.u_a == pytest.approx(s.u_pred[0, 0]) and len(s.get_prediction()) == 2
+    assert s.get_prediction()[0].x is not None and info2['msg'] in ('conv_abs_tol', 'conv_rel_tol', 'max_it', 'diverged', 'qp_fail')
