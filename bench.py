@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Monte-Carlo scenarios/s (= DG-SQP solves/s) of the 2-agent N=25 game.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the hot path (DGSQP.solve(), reference DGSQP/solvers/DGSQP.py:302-507) over one batch
+of synthetic random-initial-condition scenarios that is already resident in HBM (dgsqp_stage_inputs).  Every rank
+owns its own batch of the same size (weak scaling, no data-path collective); the only exchange is ONE all_gather of
+the per-scenario convergence record (RCCL over xGMI with the nccl backend).  Rank 0 prints ONE JSON line.
+
+torch is plumbing here (process group, barrier, gather); the solver itself is the ctypes/HIP library.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]
+    'dyn_curve_N25': dict(desc='2-agent dynamic-bicycle (Pacejka, rk4 M=10) curve track, N=25, fp64', kind='dyn', track='curve', N=25),
+    # the reference's own Monte-Carlo experiment (scripts/DGSQP_ALGAMES_monte_carlo_curve.py), kinematic bicycle
+    'kb_curve_N25': dict(desc='2-agent kinematic-bicycle (euler) curve track, N=25, fp64', kind='kb', track='curve', N=25),
+    'kb_chicane_N25': dict(desc='2-agent kinematic-bicycle (euler) chicane track, N=25, fp64', kind='kb', track='chicane', N=25),
+}
+
+
+def make_game(name):
+    from dgsqp_amd.montecarlo import dynamic_racing_game, kinematic_racing_game
+    w = WORKLOADS[name]
+    if w['kind'] == 'dyn':
+        return dynamic_racing_game(w['track'], N=w['N'], rk4_substeps=10)
+    return kinematic_racing_game(w['track'], N=w['N'])
+
+
+def algorithmic_bytes_per_solve(d):
+    """inputs x0[n_q] + u_ws[n]; outputs u[n] + l[n_c] + x[(N+1) n_q] + cond[3] + cost[M] (fp64)
+    + three int32 (status, iterations, QP solves)."""
+    return 8 * (d.n_q + d.n + d.n + d.n_c + (d.N + 1) * d.n_q + 3 + d.M) + 12
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=1024, help='scenarios per GPU per step')
+    ap.add_argument('--workload', default='dyn_curve_N25', choices=sorted(WORKLOADS))
+    ap.add_argument('--cpu-sample', type=int, default=16, help='scenarios timed on the host for cpu_baseline (0 disables)')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    import torch
+    import torch.distributed as dist
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    dev = torch.device('cuda', local_rank)
+
+    from dgsqp_amd import _ffi
+    from dgsqp_amd.montecarlo import sample_scenarios
+    from dgsqp_amd.sharding import gather_stats, pack_stats, summarize
+    from dgsqp_amd.solver import DGSQP
+    import ctypes as C
+
+    game = make_game(args.workload)
+    solver = DGSQP(*game.solver_args(), print_method=None, device=local_rank)
+    d = solver.dims
+    B = args.batch
+    x0, u_tm = sample_scenarios(game, B, seed=1 + rank)          # rejection sampling happens before any timing
+    u_am = np.ascontiguousarray(solver._to_agent_major(u_tm))
+    lib, h = solver._lib, solver._h
+    assert lib.dgsqp_stage_inputs(h, B, _ffi.dptr(x0), _ffi.dptr(u_am)) == 0, lib.dgsqp_last_error(h)
+
+    tm = _ffi.TimingT()
+    for _ in range(args.warmup):
+        assert lib.dgsqp_solve_staged(h, C.byref(tm)) == 0, lib.dgsqp_last_error(h)
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    kernel_ms = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        assert lib.dgsqp_solve_staged(h, C.byref(tm)) == 0, lib.dgsqp_last_error(h)   # launches + waits on the solver's stream
+        kernel_ms.append(tm.kernel_ms)                                               # HIP events around the kernel on that stream
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # results of the last step + the single stats gather
+    out = dict(status=np.empty(B, np.int32), num_iters=np.empty(B, np.int32), qp_solves=np.empty(B, np.int32), cond=np.empty((B, 3)))
+    assert lib.dgsqp_fetch_results(h, None, None, None, _ffi.iptr(out['status']), _ffi.iptr(out['num_iters']),
+                                   _ffi.iptr(out['qp_solves']), _ffi.dptr(out['cond']), None) == 0
+    stats = gather_stats(pack_stats(out), device=dev)
+    kms = float(np.mean(kernel_ms))
+    if distributed:
+        t = torch.tensor([kms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        kms = float(t.item())
+
+    if rank == 0:
+        total = B * world * args.steps
+        value = total / elapsed
+        bytes_per_launch = algorithmic_bytes_per_solve(d) * B
+        achieved = bytes_per_launch / (kms * 1e-3) / 1e9
+        summ = summarize(stats)
+        line = {
+            'metric': 'Monte-Carlo scenarios/sec (SQP solves/sec), 2-agent N=25', 'value': value, 'unit': 'scenarios/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': args.workload, 'description': WORKLOADS[args.workload]['desc'], 'batch_per_gpu': B,
+                       'n': int(d.n), 'n_c': int(d.n_c), 'parallelism': f'scenario-sharded x{world}',
+                       'sampler': 'scripts/DGSQP_ALGAMES_monte_carlo_curve.py:384-467 (seed 1+rank), PID warm start'},
+            'mean_iters': summ['mean_iters_converged'], 'mean_iters_all': summ['mean_iters_all'],
+            'mean_qp_solves': summ['mean_qp_solves_all'], 'converged_fraction': summ['converged'],
+            'status_fractions': {k: summ[k] for k in ('conv_abs_tol', 'conv_rel_tol', 'max_it', 'diverged', 'qp_fail')},
+            # The path is ALU/LDS-bound (state lives in LDS for the whole solve); the HBM figure is reported as the
+            # contract asks and is expected to be a tiny fraction of peak.
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
+                         'traffic': None, 'kernel': 'dg_solve_kernel', 'kernel_ms': kms,
+                         'algorithmic_bytes_per_solve': algorithmic_bytes_per_solve(d)},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            from oracle import oracle            # checker/baseline only: the CPU restatement, NOT CasADi+OSQP
+            oracle.build()
+            ns = min(args.cpu_sample, B)
+            cores = os.cpu_count() or 1
+            t1 = time.perf_counter()
+            oracle.solve_batch(solver._problem, solver._cparams, x0[:ns], u_am[:ns], nthreads=min(cores, ns))
+            dt = time.perf_counter() - t1
+            line['cpu_baseline'] = {'value': ns / dt, 'unit': 'scenarios/s', 'cores': min(cores, ns), 'kind': 'port',
+                                    'sample': f'first {ns} scenarios of the same batch, oracle/dgsqp_oracle.cpp, {dt:.1f} s'}
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
