@@ -9,7 +9,6 @@
 
 #include "dgsqp_solve.h"
 
-extern __shared__ double dg_lds[];
 
 // ------------------------------------------------------------------------------------------------
 // kernels
@@ -21,21 +20,32 @@ dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restric
                 SolveOutPtrs O, double* __restrict__ ws_all, unsigned long long* __restrict__ ticket,
                 double* __restrict__ trace, int trace_cap) {
   Ctx c;
-  c.D = D;
   c.trace_cap = trace_cap;
-  c.lds = dg_lds;
-  c.ws = ws_all + (int64_t)blockIdx.x * D->ws_doubles;
+  c.ws = (gptr)ws_all + (int64_t)blockIdx.x * dg_prob.ws_doubles;
+#ifdef DG_PROF
+  const long long wg_t0 = clock64();
+  const unsigned long long wall0 = wall_clock64();
+#endif
+  dev_load_tables();
   while (true) {
     __syncthreads();
-    if (TID == 0) dg_lds[D->L.scal + 63] = (double)atomicAdd(ticket, 1ULL);
+    if (TID == 0) dg_lds[dg_prob.L.scal + 63] = (double)atomicAdd(ticket, 1ULL);
     __syncthreads();
-    const int64_t b = (int64_t)dg_lds[D->L.scal + 63];
+    const int64_t b = (int64_t)dg_lds[dg_prob.L.scal + 63];
     if (b >= B) break;
-    c.x0 = x0 + b * D->nq;
-    c.trace = trace ? trace + b * (int64_t)(1 + 2 * trace_cap) : nullptr;
+    c.x0 = (cgptr)x0 + b * dg_prob.nq;
+    c.trace = trace ? (gptr)trace + b * (int64_t)(1 + 2 * trace_cap) : nullptr;
     if (c.trace && TID == 0) c.trace[0] = 0.0;
-    dev_solve(c, u_ws + b * D->n, b, O);
+    dev_solve(c, (cgptr)u_ws + b * dg_prob.n, b, O);
   }
+#ifdef DG_PROF
+  if (TID == 0) {
+    atomicAdd(&dg_prof[2 * PH_WGTOTAL], (unsigned long long)(clock64() - wg_t0));
+    atomicAdd(&dg_prof[2 * PH_WGTOTAL + 1], 1ULL);
+    atomicMax(&dg_prof[2 * PH_WGMAX], (unsigned long long)(clock64() - wg_t0));
+    atomicMax(&dg_prof[2 * PH_WGMAX + 1], (unsigned long long)(wall_clock64() - wall0));
+  }
+#endif
 }
 
 // Test hook: one _evaluate(hessian=True) (+ dual init) per scenario, results expanded to dense arrays.
@@ -44,27 +54,26 @@ dg_evaluate_kernel(const DgProb* __restrict__ D, int64_t B, const double* __rest
                    const double* __restrict__ l, double* q, double* g, double* G, double* Q, double* x, double* l0,
                    double* __restrict__ ws_all) {
   Ctx c;
-  c.D = D;
-  c.lds = dg_lds;
-  c.ws = ws_all + (int64_t)blockIdx.x * D->ws_doubles;
+  c.ws = (gptr)ws_all + (int64_t)blockIdx.x * dg_prob.ws_doubles;
   c.trace = nullptr; c.trace_cap = 0;
-  const DgLds& L = D->L;
-  const int n = D->n, nc = D->nc;
+  const DgLds& L = dg_prob.L;
+  const int n = dg_prob.n, nc = dg_prob.nc;
+  dev_load_tables();
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
-    c.x0 = x0 + b * D->nq;
+    c.x0 = (cgptr)x0 + b * dg_prob.nq;
     __syncthreads();
     for (int i = TID; i < n; i += NT) dg_lds[L.u + i] = u[b * n + i];
     for (int r = TID; r < nc; r += NT) dg_lds[L.l + r] = l ? l[b * nc + r] : 0.0;
     __syncthreads();
-    dev_evaluate(c, dg_lds + L.u, 0.0, nullptr, true);
+    dev_evaluate(c, LP(L.u), 0.0, nullptr, true);
     if (q) for (int i = TID; i < n; i += NT) q[b * n + i] = dg_lds[L.q + i];
     if (g) for (int r = TID; r < nc; r += NT) g[b * nc + r] = dg_lds[L.g + r];
-    if (x) for (int i = TID; i < (D->N + 1) * D->nq; i += NT) x[b * (int64_t)(D->N + 1) * D->nq + i] = dg_lds[L.e_x + i];
+    if (x) for (int i = TID; i < (dg_prob.N + 1) * dg_prob.nq; i += NT) x[b * (int64_t)(dg_prob.N + 1) * dg_prob.nq + i] = dg_lds[L.e_x + i];
     if (G)
       for (int64_t t = TID; t < (int64_t)nc * n; t += NT)
-        G[b * (int64_t)nc * n + t] = g_row_coef(*D, dg_lds + L.gd, (int)(t / n), (int)(t % n));
+        G[b * (int64_t)nc * n + t] = g_row_coef(dg_prob, LP(L.gd), (int)(t / n), (int)(t % n));
     if (Q) {
-      const double* Qg = c.ws + D->ws_q;
+      cgptr Qg = c.ws + dg_prob.ws_q;
       for (int t = TID; t < n * n; t += NT) Q[b * (int64_t)n * n + t] = Qg[t];
     }
     if (l0) {
@@ -80,19 +89,18 @@ __global__ void __launch_bounds__(DG_BLOCK, 1)
 dg_qp_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__ x0, const double* __restrict__ u,
              const double* __restrict__ l, double* du, double* lhat, double* Qpd, int32_t* flag, double* __restrict__ ws_all) {
   Ctx c;
-  c.D = D;
-  c.lds = dg_lds;
-  c.ws = ws_all + (int64_t)blockIdx.x * D->ws_doubles;
+  c.ws = (gptr)ws_all + (int64_t)blockIdx.x * dg_prob.ws_doubles;
   c.trace = nullptr; c.trace_cap = 0;
-  const DgLds& L = D->L;
-  const int n = D->n, nc = D->nc;
+  const DgLds& L = dg_prob.L;
+  const int n = dg_prob.n, nc = dg_prob.nc;
+  dev_load_tables();
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
-    c.x0 = x0 + b * D->nq;
+    c.x0 = (cgptr)x0 + b * dg_prob.nq;
     __syncthreads();
     for (int i = TID; i < n; i += NT) dg_lds[L.u + i] = u[b * n + i];
     for (int r = TID; r < nc; r += NT) dg_lds[L.l + r] = l[b * nc + r];
     __syncthreads();
-    const int f = dev_linearize_and_qp(c, true, nullptr, Qpd ? Qpd + b * (int64_t)n * n : nullptr);
+    const int f = dev_linearize_and_qp(c, true, nullptr, Qpd ? (gptr)Qpd + b * (int64_t)n * n : nullptr);
     if (du) for (int i = TID; i < n; i += NT) du[b * n + i] = dg_lds[L.o_du + i];
     if (lhat) for (int r = TID; r < nc; r += NT) lhat[b * nc + r] = dg_lds[L.o_lhat + r];
     if (flag && TID == 0) flag[b] = f;
@@ -162,6 +170,11 @@ static int ensure_ws(dgsqp_solver* h, size_t groups) {
   h->ws = nullptr; h->ws_groups = 0;
   HIPCHK(h, hipMalloc(&h->ws, sizeof(double) * groups * (size_t)h->hp.ws_doubles));
   h->ws_groups = groups;
+  return DGSQP_OK;
+}
+// The kernels read the game from the __constant__ symbol dg_prob; (re)upload it on the handle's stream before a launch.
+static int upload_problem(dgsqp_solver* h) {
+  HIPCHK(h, hipMemcpyToSymbolAsync(HIP_SYMBOL(dg_prob), &h->hp, sizeof(DgProb), 0, hipMemcpyHostToDevice, h->stream));
   return DGSQP_OK;
 }
 static int grid_for(dgsqp_solver* h, int64_t B) {
@@ -275,6 +288,7 @@ int dgsqp_solve_staged(dgsqp_handle_t h, dgsqp_timing_t* tm) {
   if (h->B == 0) return DGSQP_OK;
   const int grid = grid_for(h, h->B);
   SolveOutPtrs O{h->d_u, h->d_l, h->d_x, h->d_cond, h->d_cost, h->d_status, h->d_iters, h->d_qps};
+  { int rcu = upload_problem(h); if (rcu) return rcu; }
   HIPCHK(h, hipMemsetAsync(h->ticket, 0, sizeof(unsigned long long), h->stream));
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
   double* trace = nullptr;
@@ -392,6 +406,7 @@ int dgsqp_evaluate_batch(dgsqp_handle_t h, int64_t B, const double* x0, const do
   HIPCHK(h, hipMemcpy(dx0, x0, sizeof(double) * B * D.nq, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(du, u, sizeof(double) * B * n, hipMemcpyHostToDevice));
   if (l) HIPCHK(h, hipMemcpy(dl, l, sizeof(double) * B * nc, hipMemcpyHostToDevice));
+  { int rcu = upload_problem(h); if (rcu) return rcu; }
   hipLaunchKernelGGL(dg_evaluate_kernel, dim3(grid), dim3(DG_BLOCK), h->lds_bytes, h->stream, h->dp, B, dx0, du, dl, dq, dg, dG, dQ, dx, dl0, h->ws);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -422,6 +437,7 @@ int dgsqp_qp_batch(dgsqp_handle_t h, int64_t B, const double* x0, const double* 
   HIPCHK(h, hipMemcpy(dx0, x0, sizeof(double) * B * D.nq, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(du, u, sizeof(double) * B * n, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(dl, l, sizeof(double) * B * nc, hipMemcpyHostToDevice));
+  { int rcu = upload_problem(h); if (rcu) return rcu; }
   hipLaunchKernelGGL(dg_qp_kernel, dim3(grid), dim3(DG_BLOCK), h->lds_bytes, h->stream, h->dp, B, dx0, du, dl, ddu, dlh, dQ, df, h->ws);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -16,15 +16,54 @@
 #define NT DG_BLOCK
 #define TID ((int)threadIdx.x)
 
+// Explicit address spaces: every LDS access must compile to ds_read/ds_write and every workspace access to
+// global_load/global_store.  (With plain `double*` the LDS base travels through a struct and hipcc falls back to
+// flat_load/flat_store for all of them.)
+typedef __attribute__((address_space(3))) double lds_d;
+typedef lds_d* lptr;
+typedef const lds_d* clptr;
+typedef __attribute__((address_space(1))) double glb_d;
+typedef glb_d* gptr;
+typedef const glb_d* cgptr;
+extern __shared__ double dg_lds[];
+#define LP(off) ((lptr)dg_lds + (off))
+// The game description lives in constant memory: wave-uniform reads become scalar loads in every function.
+__constant__ DgProb dg_prob;
+// row / dense-gradient tables are copied to LDS once per workgroup (dev_load_tables): they are indexed per lane
+// inside sequential loops, where a constant-memory vector load would cost a global-memory round trip each time.
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+static_assert(sizeof(DgRow) == 8 && sizeof(DgDense) == 16, "table entries are moved as 64-bit words");
+__device__ inline DgRow ld_row(int r) {
+  const unsigned long long w = ((const lds_u64*)LP(dg_prob.L.t_rows))[r];
+  DgRow R;
+  __builtin_memcpy(&R, &w, 8);
+  return R;
+}
+__device__ inline DgDense ld_dense(int d) {
+  const lds_u64* p = (const lds_u64*)LP(dg_prob.L.t_dense) + 2 * d;
+  const unsigned long long w[2] = {p[0], p[1]};
+  DgDense R;
+  __builtin_memcpy(&R, w, 16);
+  return R;
+}
+__device__ inline void dev_load_tables() {
+  const DgProb& D = dg_prob;
+  lds_u64* tr = (lds_u64*)LP(D.L.t_rows);
+  lds_u64* td = (lds_u64*)LP(D.L.t_dense);
+  const unsigned long long* sr = (const unsigned long long*)D.rows;
+  const unsigned long long* sd = (const unsigned long long*)D.dense;
+  for (int r = threadIdx.x; r < D.nc; r += DG_BLOCK) tr[r] = sr[r];
+  for (int d = threadIdx.x; d < 2 * D.ndense; d += DG_BLOCK) td[d] = sd[d];
+  __syncthreads();
+}
+
 struct Ctx {
-  const DgProb* D;
-  double* lds;  // dynamic LDS base
-  double* ws;   // this workgroup's global workspace
-  const double* x0;
-  double* trace;   // optional per-scenario event log: [0] = number of (code, value) pairs, then the pairs
+  gptr ws;      // this workgroup's global workspace
+  cgptr x0;
+  gptr trace;   // optional per-scenario event log: [0] = number of (code, value) pairs, then the pairs
   int trace_cap;   // capacity in pairs
 };
-// event log compared event-by-event with the oracle's (tests/test_gpu_trace.py)
+// event log compared event-by-event with the oracle's (tests/test_gpu.py::test_event_trace_parity)
 __device__ inline void dev_tr(const Ctx& c, int code, double v) {
   if (c.trace && threadIdx.x == 0) {
     const int p = (int)c.trace[0];
@@ -34,7 +73,7 @@ __device__ inline void dev_tr(const Ctx& c, int code, double v) {
 
 // Diagnostic build only (-DDG_PROF): per-phase cycle counters accumulated by thread 0 of every workgroup
 // into a global array; the production library compiles these to nothing.
-enum { PH_ROLLOUT = 0, PH_DERIV1, PH_DERIV2, PH_CHAINS, PH_DP, PH_JACOBI, PH_PFORM, PH_QP, PH_MERIT, PH_LSQR, PH_QTMUL, PH_SWEEP, PH_COUNT };
+enum { PH_ROLLOUT = 0, PH_DERIV1, PH_DERIV2, PH_CHAINS, PH_DP, PH_JACOBI, PH_PFORM, PH_QP, PH_MERIT, PH_LSQR, PH_QTMUL, PH_SWEEP, PH_WGTOTAL, PH_WGMAX, PH_COUNT };
 #ifdef DG_PROF
 __device__ unsigned long long dg_prof[PH_COUNT * 2];
 #define PROF_BEGIN(v) const long long v = clock64()
@@ -52,14 +91,14 @@ __device__ inline double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
   return v;
 }
-__device__ inline double block_sum(double v, double* red) {
+__device__ inline double block_sum(double v, lptr red) {
   v = wave_sum(v);
   __syncthreads();
   if ((TID & 63) == 0) red[TID >> 6] = v;
   __syncthreads();
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
-__device__ inline double block_max(double v, double* red) {
+__device__ inline double block_max(double v, lptr red) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o));
   __syncthreads();
@@ -68,7 +107,7 @@ __device__ inline double block_max(double v, double* red) {
   return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
 // minimum with lowest index on ties
-__device__ inline void block_argmin(double v, int idx, double* red, double& vout, int& iout) {
+__device__ inline void block_argmin(double v, int idx, lptr red, double& vout, int& iout) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     double v2 = __shfl_down(v, o);
@@ -309,8 +348,8 @@ __device__ inline int am_col(const DgProb& D, int a, int k, int j) { return a * 
 // structured products with the constraint Jacobian G (n_c x n), never formed densely
 // ------------------------------------------------------------------------------------------------
 // y[r] = (G x)[r] for one row
-__device__ inline double g_row_dot(const DgProb& D, const double* gd, int r, const double* x) {
-  const DgRow R = D.rows[r];
+__device__ inline double g_row_dot(const DgProb& D, clptr gd, int r, clptr x) {
+  const DgRow R = ld_row(r);
   switch (R.type) {
     case DG_R_IN_UB: return x[am_col(D, R.a, R.k, R.idx)];
     case DG_R_IN_LB: return -x[am_col(D, R.a, R.k, R.idx)];
@@ -321,14 +360,14 @@ __device__ inline double g_row_dot(const DgProb& D, const double* gd, int r, con
       return R.type == DG_R_RATE_UB ? t : -t;
     }
     default: {
-      const DgDense dd = D.dense[R.dense];
-      const double* p = gd + dd.off;
+      const DgDense dd = ld_dense(R.dense);
+      clptr p = gd + dd.off;
       const int len = 2 * dd.k;
       double s = 0;
-      const double* xa = x + dd.a * D.N * DGSQP_NUA;
+      clptr xa = x + dd.a * D.N * DGSQP_NUA;
       for (int i = 0; i < len; i++) s += p[i] * xa[i];
       if (dd.kind == 1) {
-        const double* xb = x + dd.b * D.N * DGSQP_NUA;
+        clptr xb = x + dd.b * D.N * DGSQP_NUA;
         for (int i = 0; i < len; i++) s += p[len + i] * xb[i];
       }
       return R.sgn * s;
@@ -336,21 +375,14 @@ __device__ inline double g_row_dot(const DgProb& D, const double* gd, int r, con
   }
 }
 // out[n] = G^T y.  yd is an LDS scratch of ndense doubles.  Contains barriers.
-__device__ inline void gt_mul(const Ctx& c, const double* y, double* out) {
-  const DgProb& D = *c.D;
-  double* yd = c.lds + D.L.yd;
-  const double* gd = c.lds + D.L.gd;
+__device__ __noinline__ void gt_mul(const Ctx& c, clptr y, lptr out) {
+  const DgProb& D = dg_prob;
+  lptr yd = LP(D.L.yd);
+  clptr gd = LP(D.L.gd);
   __syncthreads();
-  for (int d = TID; d < D.ndense; d += NT) yd[d] = 0.0;
-  __syncthreads();
-  for (int r = TID; r < D.nc; r += NT) {
-    const DgRow R = D.rows[r];
-    if (R.dense >= 0 && R.sgn > 0) yd[R.dense] = y[r];  // ub / obstacle row first ...
-  }
-  __syncthreads();
-  for (int r = TID; r < D.nc; r += NT) {
-    const DgRow R = D.rows[r];
-    if (R.dense >= 0 && R.sgn < 0) yd[R.dense] -= y[r];  // ... then the lb row sharing the gradient
+  for (int d = TID; d < D.ndense; d += NT) {
+    const DgDense dd = ld_dense(d);
+    yd[d] = (dd.r_pos >= 0 ? y[dd.r_pos] : 0.0) - (dd.r_neg >= 0 ? y[dd.r_neg] : 0.0);
   }
   __syncthreads();
   for (int col = TID; col < D.n; col += NT) {
@@ -365,9 +397,8 @@ __device__ inline void gt_mul(const Ctx& c, const double* y, double* out) {
       if ((r = D.r_rate_ub[a][t + 1][j]) >= 0) s -= y[r];
       if ((r = D.r_rate_lb[a][t + 1][j]) >= 0) s += y[r];
     }
-    for (int d = 0; d < D.ndense; d++) {
-      const DgDense dd = D.dense[d];
-      if (dd.k <= t) continue;
+    for (int d = D.stage_dense0[t + 1]; d < D.ndense; d++) {   // only gradients of later stages reach column (a,t,j)
+      const DgDense dd = ld_dense(d);
       if (dd.a == a) s += yd[d] * gd[dd.off + t * DGSQP_NUA + j];
       else if (dd.kind == 1 && dd.b == a) s += yd[d] * gd[dd.off + 2 * dd.k + t * DGSQP_NUA + j];
     }

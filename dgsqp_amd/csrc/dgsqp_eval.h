@@ -7,7 +7,8 @@
 // state-dependent part of agent a's cost (chicane.py:239-256, ablation.py:229-262): value and
 // analytic joint gradient / Hessian.  Executed by ONE thread; Dx/Dxx are accumulated into.
 // ------------------------------------------------------------------------------------------------
-__device__ inline double dev_state_cost(const DgProb& D, int a, const double* xk, bool terminal, double* Dx, double* Dxx) {
+template <class XP, class DP>
+__device__ inline double dev_state_cost(const DgProb& D, int a, XP xk, bool terminal, DP Dx, DP Dxx) {
   const dgsqp_agent_t& ag = D.P.agents[a];
   const int nq = D.nq, ia = D.qoff[a];
   double J = 0;
@@ -74,7 +75,7 @@ __device__ inline double dev_state_cost(const DgProb& D, int a, const double* xk
 // rollout x_{k+1} = f_d(x_k, u_k)   (evaluate_dynamics, DGSQP.py:597-601): one lane per agent
 // ------------------------------------------------------------------------------------------------
 template <int NQA>
-__device__ inline void dev_rollout_agent(const DgProb& D, int a, const double* ue, double* x) {
+__device__ inline void dev_rollout_agent(const DgProb& D, int a, clptr ue, lptr x) {
   typedef Ty<0> T;
   const int nq = D.nq, qo = D.qoff[a];
   T q[NQA], u[2], qn[NQA];
@@ -86,8 +87,8 @@ __device__ inline void dev_rollout_agent(const DgProb& D, int a, const double* u
     for (int i = 0; i < NQA; i++) { q[i] = qn[i]; x[(k + 1) * nq + qo + i] = qn[i].c[0]; }
   }
 }
-__device__ inline void dev_rollout(const Ctx& c, const double* ue, double* x) {
-  const DgProb& D = *c.D;
+__device__ __noinline__ void dev_rollout(const Ctx& c, clptr ue, lptr x) {
+  const DgProb& D = dg_prob;
   __syncthreads();
   for (int i = TID; i < D.nq; i += NT) x[i] = c.x0[i];
   __syncthreads();
@@ -109,11 +110,11 @@ __device__ inline void dir_pair(int neff, int dir, int& i, int& j) {
   j = i + 1 + p;
 }
 template <int DEG, int NQA>
-__device__ inline void dev_taylor_item(const Ctx& c, int a, int k, int dir, const double* ue) {
-  const DgProb& D = *c.D;
+__device__ inline void dev_taylor_item(const Ctx& c, int a, int k, int dir, clptr ue) {
+  const DgProb& D = dg_prob;
   const DgLds& L = D.L;
   typedef Ty<DEG> T;
-  const double* x = c.lds + L.e_x + k * D.nq + D.qoff[a];
+  clptr x = LP(L.e_x + k * D.nq + D.qoff[a]);
   T q[NQA], u[2], out[NQA];
   for (int i = 0; i < NQA; i++) q[i] = ty_const<DEG>(x[i]);
   u[0] = ty_const<DEG>(ue[am_col(D, a, k, 0)]);
@@ -132,29 +133,29 @@ __device__ inline void dev_taylor_item(const Ctx& c, int a, int k, int dir, cons
   if (dir < D.neff[a]) {
     const int z = D.effvar[a][dir];
     if (z < NQA) {
-      double* A = c.lds + L.e_A[a] + k * NQA * NQA;
+      lptr A = LP(L.e_A[a] + k * NQA * NQA);
       for (int o = 0; o < NQA; o++) A[o * NQA + z] = out[o].c[1];
     } else {
-      double* B = c.lds + L.e_B[a] + k * NQA * 2;
+      lptr B = LP(L.e_B[a] + k * NQA * 2);
       for (int o = 0; o < NQA; o++) B[o * 2 + (z - NQA)] = out[o].c[1];
     }
   }
   if constexpr (DEG >= 2) {
-    double* T2 = c.ws + D.ws_t2 + D.t2off[a] + (int64_t)k * D.t2k[a];
+    gptr T2 = c.ws + D.ws_t2 + D.t2off[a] + (int64_t)k * D.t2k[a];
     const int nd = D.ndir[a];
     for (int o = 0; o < NQA; o++) T2[o * nd + dir] = out[o].c[2];
   }
 }
 template <int DEG>
-__device__ inline void dev_dyn_derivs(const Ctx& c, const double* ue) {
-  const DgProb& D = *c.D;
+__device__ __noinline__ void dev_dyn_derivs(const Ctx& c, clptr ue) {
+  const DgProb& D = dg_prob;
   const DgLds& L = D.L;
   for (int a = 0; a < D.M; a++) {
     const int nqa = D.nqa[a];
     // columns of x, y: identity (they never enter fc)
     for (int it = TID; it < D.N * nqa; it += NT) {
       const int k = it / nqa, o = it % nqa;
-      double* A = c.lds + L.e_A[a] + k * nqa * nqa;
+      lptr A = LP(L.e_A[a] + k * nqa * nqa);
       A[o * nqa + 0] = (o == 0) ? 1.0 : 0.0;
       A[o * nqa + 1] = (o == 1) ? 1.0 : 0.0;
     }
@@ -172,18 +173,18 @@ __device__ inline void dev_dyn_derivs(const Ctx& c, const double* ue) {
 // consumed on the fly into the packed dense gradients (f_Du_C :823-826) and q (f_q :672-676, 898-899)
 // ------------------------------------------------------------------------------------------------
 template <int NQA>
-__device__ inline void dev_chain_item(const Ctx& c, const double* ue, int it);
-__device__ inline void dev_chains(const Ctx& c, const double* ue) {
-  const DgProb& D = *c.D;
+__device__ inline void dev_chain_item(const Ctx& c, clptr ue, int it);
+__device__ __noinline__ void dev_chains(const Ctx& c, clptr ue) {
+  const DgProb& D = dg_prob;
   const DgLds& L = D.L;
-  double* lds = c.lds;
-  const double* x = lds + L.e_x;
+  lptr lds = LP(0);
+  clptr x = lds + L.e_x;
   // own-state gradient of each agent's cost at every stage
   for (int it = TID; it < D.M * (D.N + 1); it += NT) {
     const int a = it / (D.N + 1), k = it % (D.N + 1);
     double Dx[DGSQP_MAX_AGENTS * DGSQP_MAX_NQA];
     for (int i = 0; i < D.nq; i++) Dx[i] = 0;
-    dev_state_cost(D, a, x + k * D.nq, k == D.N, Dx, nullptr);
+    dev_state_cost(D, a, x + k * D.nq, k == D.N, (double*)Dx, (double*)nullptr);
     for (int i = 0; i < D.nqa[a]; i++) lds[L.e_dJ + k * D.nq + D.qoff[a] + i] = Dx[D.qoff[a] + i];
   }
   __syncthreads();
@@ -194,18 +195,18 @@ __device__ inline void dev_chains(const Ctx& c, const double* ue) {
   __syncthreads();
 }
 template <int NQA>
-__device__ inline void dev_chain_item(const Ctx& c, const double* ue, int it) {
-  const DgProb& D = *c.D;
+__device__ inline void dev_chain_item(const Ctx& c, clptr ue, int it) {
+  const DgProb& D = dg_prob;
   const DgLds& L = D.L;
-  double* lds = c.lds;
-  const double* x = lds + L.e_x;
+  lptr lds = LP(0);
+  clptr x = lds + L.e_x;
   {
     const int a = it / (D.N * DGSQP_NUA), rem = it % (D.N * DGSQP_NUA), t0 = rem / DGSQP_NUA, j = rem % DGSQP_NUA;
     constexpr int nqa = NQA;
     const int qo = D.qoff[a];
     const dgsqp_agent_t& ag = D.P.agents[a];
     double v[NQA], w[NQA];
-    const double* B = lds + L.e_B[a] + t0 * nqa * 2;
+    clptr B = lds + L.e_B[a] + t0 * nqa * 2;
 #pragma unroll
     for (int i = 0; i < nqa; i++) v[i] = B[i * 2 + j];
     // direct part of dJ^a/du^a_{t0,j}
@@ -214,9 +215,9 @@ __device__ inline void dev_chain_item(const Ctx& c, const double* ue, int it) {
     if (t0 + 1 < D.N) qacc -= ag.w_rate[j] * (ue[it + DGSQP_NUA] - uk);
     int d = D.stage_dense0[t0 + 1];  // dense gradients are ordered by stage
     for (int k = t0 + 1; k <= D.N; k++) {
-      const double* xk = x + k * D.nq;
-      for (; d < D.ndense && D.dense[d].k == k; d++) {
-        const DgDense dd = D.dense[d];
+      clptr xk = x + k * D.nq;
+      for (; d < D.stage_dense0[k + 1]; d++) {
+        const DgDense dd = ld_dense(d);
         if (dd.kind == 0) {
           if (dd.a == a) {
             double val = 0.0;
@@ -232,11 +233,11 @@ __device__ inline void dev_chain_item(const Ctx& c, const double* ue, int it) {
           else lds[L.gd + dd.off + 2 * k + t0 * DGSQP_NUA + j] = s;
         }
       }
-      const double* dJ = lds + L.e_dJ + k * D.nq + qo;
+      clptr dJ = lds + L.e_dJ + k * D.nq + qo;
 #pragma unroll
       for (int i = 0; i < nqa; i++) qacc += dJ[i] * v[i];
       if (k < D.N) {
-        const double* A = lds + L.e_A[a] + k * nqa * nqa;
+        clptr A = lds + L.e_A[a] + k * nqa * nqa;
 #pragma unroll
         for (int i = 0; i < nqa; i++) {
           double s = 0;
@@ -253,14 +254,14 @@ __device__ inline void dev_chain_item(const Ctx& c, const double* ue, int it) {
 }
 
 // constraint values (f_Cxu, DGSQP.py:729-821, 911)
-__device__ inline void dev_constraint_values(const Ctx& c, const double* ue) {
-  const DgProb& D = *c.D;
+__device__ __noinline__ void dev_constraint_values(const Ctx& c, clptr ue) {
+  const DgProb& D = dg_prob;
   const DgLds& L = D.L;
-  const double* x = c.lds + L.e_x;
+  clptr x = LP(L.e_x);
   for (int r = TID; r < D.nc; r += NT) {
-    const DgRow R = D.rows[r];
+    const DgRow R = ld_row(r);
     const dgsqp_agent_t& ag = D.P.agents[R.a];
-    const double* xk = x + R.k * D.nq;
+    clptr xk = x + R.k * D.nq;
     double g;
     switch (R.type) {
       case DG_R_OBS: {
@@ -279,7 +280,7 @@ __device__ inline void dev_constraint_values(const Ctx& c, const double* ue) {
       case DG_R_ST_UB: g = xk[D.qoff[R.a] + R.idx] - ag.st_ub[R.idx]; break;
       default: g = ag.st_lb[R.idx] - xk[D.qoff[R.a] + R.idx]; break;
     }
-    c.lds[L.g + r] = g;
+    LP(L.g)[r] = g;
   }
   __syncthreads();
 }
@@ -290,20 +291,20 @@ __device__ inline void dev_constraint_values(const Ctx& c, const double* ue) {
 // linearity, identical to the reference's own f_Duu_L :937-941).  Rows of agent a go to raw Q.
 // ------------------------------------------------------------------------------------------------
 // stage injection: d/dx_k and d2/dx_k^2 of [J^a_k + sum_r l_r c_r] for rows r of stage k
-__device__ inline void dev_stage_injection(const Ctx& c, int a, int k, double* inj) {
-  const DgProb& D = *c.D;
+__device__ inline void dev_stage_injection(const Ctx& c, int a, int k, lptr inj) {
+  const DgProb& D = dg_prob;
   const DgLds& L = D.L;
   const int nq = D.nq;
   for (int i = TID; i < nq + nq * nq; i += NT) inj[i] = 0.0;
   __syncthreads();
   if (TID == 0) {
-    const double* xk = c.lds + L.e_x + k * nq;
-    const double* l = c.lds + L.l;
-    double* Dx = inj;
-    double* Dxx = inj + nq;
+    clptr xk = LP(L.e_x + k * nq);
+    clptr l = LP(L.l);
+    lptr Dx = inj;
+    lptr Dxx = inj + nq;
     dev_state_cost(D, a, xk, k == D.N, Dx, Dxx);
     for (int r = D.stage_row0[k]; r < D.stage_row0[k + 1]; r++) {
-      const DgRow R = D.rows[r];
+      const DgRow R = ld_row(r);
       if (R.dense < 0) continue;  // rate / input-box rows are affine in u: no state derivatives
       const double lr = l[r];
       if (R.type == DG_R_OBS) {
@@ -327,16 +328,16 @@ __device__ inline int dev_block_of(const DgProb& D, int xi) {
   return b;
 }
 
-__device__ inline void dev_hessian_dp(const Ctx& c, int a) {
-  const DgProb& D = *c.D;
+__device__ __noinline__ void dev_hessian_dp(const Ctx& c, int a) {
+  const DgProb& D = dg_prob;
   const DgLds& L = D.L;
-  double* lds = c.lds;
+  lptr lds = LP(0);
   const int nq = D.nq, nu = D.nu, n = D.n, N = D.N;
-  double *Dx = lds + L.e_Dx, *Dxn = lds + L.e_Dx + nq, *Dxx = lds + L.e_Dxx, *nDxx = lds + L.e_nDxx;
-  double *tQA = lds + L.e_tQA, *tQB = lds + L.e_tQB, *A1 = lds + L.e_A1, *A2 = lds + L.e_A2;
-  double *Dxu = lds + L.e_Dxu, *Dxu2 = lds + L.e_Dxu + n * nq;  // double-buffered rows d2/du_t dx_k
-  double *Hc = lds + L.e_Hc, *cv = lds + L.e_cv, *inj = lds + L.e_inj;
-  double* Qg = c.ws + D.ws_q;
+  lds_d *Dx = lds + L.e_Dx, *Dxn = lds + L.e_Dx + nq, *Dxx = lds + L.e_Dxx, *nDxx = lds + L.e_nDxx;
+  lds_d *tQA = lds + L.e_tQA, *tQB = lds + L.e_tQB, *A1 = lds + L.e_A1, *A2 = lds + L.e_A2;
+  lds_d *Dxu = lds + L.e_Dxu, *Dxu2 = lds + L.e_Dxu + n * nq;  // double-buffered rows d2/du_t dx_k
+  lds_d *Hc = lds + L.e_Hc, *cv = lds + L.e_cv, *inj = lds + L.e_inj;
+  gptr Qg = c.ws + D.ws_q;
   const dgsqp_agent_t& ag = D.P.agents[a];
 
   dev_stage_injection(c, a, N, inj);
@@ -349,7 +350,7 @@ __device__ inline void dev_hessian_dp(const Ctx& c, int a) {
     for (int it = TID; it < D.M * DG_MAXDIR; it += NT) {
       const int b = it / DG_MAXDIR, dir = it % DG_MAXDIR;
       if (dir < D.ndir[b]) {
-        const double* T2 = c.ws + D.ws_t2 + D.t2off[b] + (int64_t)k * D.t2k[b];
+        cgptr T2 = c.ws + D.ws_t2 + D.t2off[b] + (int64_t)k * D.t2k[b];
         double s = 0;
         for (int o = 0; o < D.nqa[b]; o++) s += Dx[D.qoff[b] + o] * T2[o * D.ndir[b] + dir];
         cv[b * DG_MAXDIR + dir] = s;
@@ -359,14 +360,14 @@ __device__ inline void dev_hessian_dp(const Ctx& c, int a) {
       const int i = it / (nq + nu), jj = it % (nq + nu);
       if (jj < nq) {  // tQA[i][jj] = sum_l Dxx[i][l] A[l][jj], A block diagonal
         const int b = dev_block_of(D, jj), nqa = D.nqa[b], qo = D.qoff[b];
-        const double* A = lds + L.e_A[b] + k * nqa * nqa;
+        clptr A = lds + L.e_A[b] + k * nqa * nqa;
         double s = 0;
         for (int m = 0; m < nqa; m++) s += Dxx[i * nq + qo + m] * A[m * nqa + (jj - qo)];
         tQA[i * nq + jj] = s;
       } else {
         const int cu = jj - nq, b = cu / DGSQP_NUA, j = cu % DGSQP_NUA;
         const int nqa = D.nqa[b], qo = D.qoff[b];
-        const double* B = lds + L.e_B[b] + k * nqa * 2;
+        clptr B = lds + L.e_B[b] + k * nqa * 2;
         double s = 0;
         for (int m = 0; m < nqa; m++) s += Dxx[i * nq + qo + m] * B[m * 2 + j];
         tQB[i * nu + cu] = s;
@@ -378,7 +379,7 @@ __device__ inline void dev_hessian_dp(const Ctx& c, int a) {
       const int b = it / (DG_MAXEFF * DG_MAXEFF), i = (it / DG_MAXEFF) % DG_MAXEFF, j = it % DG_MAXEFF;
       const int ne = D.neff[b];
       if (i < ne && j < ne) {
-        const double* cb = cv + b * DG_MAXDIR;
+        clptr cb = cv + b * DG_MAXDIR;
         double h;
         if (i == j) h = 2.0 * cb[i];
         else {
@@ -394,7 +395,7 @@ __device__ inline void dev_hessian_dp(const Ctx& c, int a) {
     for (int it = TID; it < nu * (nu + nq); it += NT) {
       const int c1 = it / (nu + nq), jj = it % (nu + nq);
       const int b1 = c1 / DGSQP_NUA, j1 = c1 % DGSQP_NUA, nqa1 = D.nqa[b1], qo1 = D.qoff[b1];
-      const double* B = lds + L.e_B[b1] + k * nqa1 * 2;
+      clptr B = lds + L.e_B[b1] + k * nqa1 * 2;
       if (jj < nu) {  // A1[c1][c2] = Duu_J + B^T Dxx B + sum_i Dx_i F_i      (DGSQP.py:698-700)
         const int c2 = jj, b2 = c2 / DGSQP_NUA, j2 = c2 % DGSQP_NUA;
         double s = 0;
@@ -415,11 +416,11 @@ __device__ inline void dev_hessian_dp(const Ctx& c, int a) {
       const int nrows = (N - 1 - k) * nu, row0 = (k + 1) * nu, per = nu + nq;
       for (int it = TID; it < nrows * per; it += NT) {
         const int row = row0 + it / per, jj = it % per;
-        const double* old = Dxu + row * nq;
+        clptr old = Dxu + row * nq;
         if (jj < nu) {   // B1 = Dxu_Q[-1] @ B_k (+ d2J/du_{k+1}du_k)                 (DGSQP.py:704-706)
           const int t = row / nu, ju = row % nu, ar = ju / DGSQP_NUA;
           const int cu = jj, b = cu / DGSQP_NUA, j = cu % DGSQP_NUA, nqa = D.nqa[b], qo = D.qoff[b];
-          const double* B = lds + L.e_B[b] + k * nqa * 2;
+          clptr B = lds + L.e_B[b] + k * nqa * 2;
           double s = 0;
           for (int m = 0; m < nqa; m++) s += old[qo + m] * B[m * 2 + j];
           if (t == k + 1 && cu == ju && b == a) s -= ag.w_rate[j];
@@ -428,7 +429,7 @@ __device__ inline void dev_hessian_dp(const Ctx& c, int a) {
           if (b == a) Qg[(int64_t)ci * n + ri] = s;
         } else {         // Dxu_Q[-1] @ A_k                                            (DGSQP.py:714)
           const int jx = jj - nu, b = dev_block_of(D, jx), nqa = D.nqa[b], qo = D.qoff[b];
-          const double* A = lds + L.e_A[b] + k * nqa * nqa;
+          clptr A = lds + L.e_A[b] + k * nqa * nqa;
           double s = 0;
           for (int m = 0; m < nqa; m++) s += old[qo + m] * A[m * nqa + (jx - qo)];
           Dxu2[row * nq + jx] = s;
@@ -447,7 +448,7 @@ __device__ inline void dev_hessian_dp(const Ctx& c, int a) {
       for (int it = TID; it < nq * nq; it += NT) {
         const int i = it / nq, jx = it % nq;
         const int b = dev_block_of(D, i), nqa = D.nqa[b], qo = D.qoff[b];
-        const double* A = lds + L.e_A[b] + k * nqa * nqa;
+        clptr A = lds + L.e_A[b] + k * nqa * nqa;
         double s = inj[nq + it];
         for (int m = 0; m < nqa; m++) s += A[m * nqa + (i - qo)] * tQA[(qo + m) * nq + jx];
         const int li = i - qo, lj = jx - qo;
@@ -456,7 +457,7 @@ __device__ inline void dev_hessian_dp(const Ctx& c, int a) {
       }
       for (int jx = TID; jx < nq; jx += NT) {
         const int b = dev_block_of(D, jx), nqa = D.nqa[b], qo = D.qoff[b];
-        const double* A = lds + L.e_A[b] + k * nqa * nqa;
+        clptr A = lds + L.e_A[b] + k * nqa * nqa;
         double s = inj[jx];
         for (int m = 0; m < nqa; m++) s += Dx[qo + m] * A[m * nqa + (jx - qo)];
         Dxn[jx] = s;
@@ -467,7 +468,7 @@ __device__ inline void dev_hessian_dp(const Ctx& c, int a) {
       for (int it = TID; it < nq * nq; it += NT) Dxx[it] = nDxx[it];
       for (int it = TID; it < nq; it += NT) Dx[it] = Dxn[it];
     }
-    { double* t = Dxu; Dxu = Dxu2; Dxu2 = t; }
+    { lptr t = Dxu; Dxu = Dxu2; Dxu2 = t; }
     __syncthreads();
   }
 }
@@ -476,13 +477,13 @@ __device__ inline void dev_hessian_dp(const Ctx& c, int a) {
 // _evaluate(u, l, x0, up=0, hessian)   (DGSQP.py:509-533).  `usrc` is copied into the EVAL scratch.
 // Produces q, g, packed G (LDS) and, if hessian, raw Q in the global workspace.
 // ------------------------------------------------------------------------------------------------
-__device__ inline void dev_evaluate(const Ctx& c, const double* usrc, double alpha, const double* dusrc, bool hessian) {
-  const DgProb& D = *c.D;
+__device__ inline void dev_evaluate(const Ctx& c, clptr usrc, double alpha, clptr dusrc, bool hessian) {
+  const DgProb& D = dg_prob;
   const DgLds& L = D.L;
-  double* ue = c.lds + L.e_ue;
+  lptr ue = LP(L.e_ue);
   __syncthreads();
   for (int i = TID; i < D.n; i += NT) ue[i] = dusrc ? usrc[i] + alpha * dusrc[i] : usrc[i];
-  { PROF_BEGIN(pt_); dev_rollout(c, ue, c.lds + L.e_x); PROF_END(PH_ROLLOUT, pt_); }
+  { PROF_BEGIN(pt_); dev_rollout(c, ue, LP(L.e_x)); PROF_END(PH_ROLLOUT, pt_); }
   if (hessian) { PROF_BEGIN(pt_); dev_dyn_derivs<2>(c, ue); PROF_END(PH_DERIV2, pt_); }
   else { PROF_BEGIN(pt_); dev_dyn_derivs<1>(c, ue); PROF_END(PH_DERIV1, pt_); }
   { PROF_BEGIN(pt_); dev_chains(c, ue); dev_constraint_values(c, ue); PROF_END(PH_CHAINS, pt_); }
@@ -495,9 +496,9 @@ __device__ inline void dev_evaluate(const Ctx& c, const double* usrc, double alp
 }
 
 // f_J (DGSQP.py:889-893): per-agent cost along the current rollout in the EVAL scratch
-__device__ inline void dev_costs(const Ctx& c, const double* ue, double* Jout) {
-  const DgProb& D = *c.D;
-  const double* x = c.lds + D.L.e_x;
+__device__ inline void dev_costs(const Ctx& c, clptr ue, double* Jout) {
+  const DgProb& D = dg_prob;
+  clptr x = LP(D.L.e_x);
   if (TID < D.M) {
     const int a = TID;
     const dgsqp_agent_t& ag = D.P.agents[a];
@@ -507,9 +508,9 @@ __device__ inline void dev_costs(const Ctx& c, const double* ue, double* Jout) {
         const double uk = ue[am_col(D, a, k, j)], um = k > 0 ? ue[am_col(D, a, k - 1, j)] : 0.0;
         s += 0.5 * ag.w_in[j] * uk * uk + 0.5 * ag.w_rate[j] * (uk - um) * (uk - um);
       }
-      s += dev_state_cost(D, a, x + k * D.nq, false, nullptr, nullptr);
+      s += dev_state_cost(D, a, x + k * D.nq, false, (double*)nullptr, (double*)nullptr);
     }
-    s += dev_state_cost(D, a, x + D.N * D.nq, true, nullptr, nullptr);
+    s += dev_state_cost(D, a, x + D.N * D.nq, true, (double*)nullptr, (double*)nullptr);
     Jout[a] = s;
   }
 }

@@ -26,18 +26,21 @@ struct DgRow {      // one inequality row
 struct DgDense {    // one distinct dense gradient: d x^a_k[idx] / du   or the obstacle gradient of pair (a,b) at stage k
   int8_t kind;      // 0 state row, 1 obstacle
   int8_t a, b, idx, k;
+  int8_t pad_[3];
   int32_t off;      // offset in the packed Gd array; kind 0: 2k entries [t][j]; kind 1: 4k entries, agent a then agent b
+  int16_t r_pos, r_neg;  // rows using this gradient with coefficient +1 / -1 (-1: none)
 };
 
 // LDS arena, offsets in doubles
 struct DgLds {
   // persistent
   int u, l, q, g, d, v, gd, yd, red, scal;
+  int t_rows, t_dense;  // LDS copies of the row / dense-gradient tables (8 and 16 bytes per entry)
   int scr;  // start of phase scratch
   // EVAL scratch (absolute offsets)
   int e_x, e_ue, e_A[DGSQP_MAX_AGENTS], e_B[DGSQP_MAX_AGENTS], e_dJ, e_Dx, e_Dxx, e_nDxx, e_tQA, e_tQB, e_A1, e_A2, e_Dxu, e_Hc, e_cv, e_inj;
   // EIG scratch
-  int g_Bp, g_V, g_rot;
+  int g_Bp, g_V, g_tw;  // packed P / packed Householder reflectors / tridiagonal workspace
   // QP scratch (P shares g_Bp)
   int p_R, p_lam, p_c, p_w, p_r, p_y, p_z, p_t, p_alist, p_act;
   // QP outputs that must survive trial evaluations
@@ -76,6 +79,7 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   D.P = P; D.par = par;
   if (P.M < 1 || P.M > DGSQP_MAX_AGENTS) return "unsupported number of agents";
   if (P.N < 1 || P.N > DG_NMAX) return "unsupported horizon";
+  if (P.N * P.M * DGSQP_NUA > 128) return "more than 128 decision variables are not supported yet";
   if (P.n_segs < 1 || P.n_segs > DGSQP_MAX_SEGS) return "bad track table";
   D.M = P.M; D.N = P.N; D.nq = 0; D.nu = P.M * DGSQP_NUA;
   int t2 = 0;
@@ -112,7 +116,7 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
       for (int i = 0; i < P.M; i++)
         for (int j = i + 1; j < P.M; j++) {
           if (nd >= DG_NDMAX) return "too many dense rows";
-          D.dense[nd] = DgDense{1, (int8_t)i, (int8_t)j, 0, (int8_t)k, off};
+          D.dense[nd] = DgDense{1, (int8_t)i, (int8_t)j, 0, (int8_t)k, {0, 0, 0}, off, (int16_t)nc, -1};
           off += 4 * k;
           if (!add_row(DG_R_OBS, k, i, j, 0, 1, nd)) return "too many rows";
           nd++;
@@ -137,15 +141,15 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
           dense_of[i] = -1;
           if (ag.st_ub[i] < INFINITY || ag.st_lb[i] > -INFINITY) {
             if (nd >= DG_NDMAX) return "too many dense rows";
-            D.dense[nd] = DgDense{0, (int8_t)a, -1, (int8_t)i, (int8_t)k, off};
+            D.dense[nd] = DgDense{0, (int8_t)a, -1, (int8_t)i, (int8_t)k, {0, 0, 0}, off, -1, -1};
             off += 2 * k;
             dense_of[i] = nd++;
           }
         }
         for (int i = 0; i < D.nqa[a]; i++)
-          if (ag.st_ub[i] < INFINITY) if (!add_row(DG_R_ST_UB, k, a, -1, i, 1, dense_of[i])) return "too many rows";
+          if (ag.st_ub[i] < INFINITY) { D.dense[dense_of[i]].r_pos = (int16_t)nc; if (!add_row(DG_R_ST_UB, k, a, -1, i, 1, dense_of[i])) return "too many rows"; }
         for (int i = 0; i < D.nqa[a]; i++)
-          if (ag.st_lb[i] > -INFINITY) if (!add_row(DG_R_ST_LB, k, a, -1, i, -1, dense_of[i])) return "too many rows";
+          if (ag.st_lb[i] > -INFINITY) { D.dense[dense_of[i]].r_neg = (int16_t)nc; if (!add_row(DG_R_ST_LB, k, a, -1, i, -1, dense_of[i])) return "too many rows"; }
       }
     }
   }
@@ -164,6 +168,7 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
   L.u = take(n); L.l = take(nc); L.q = take(n); L.g = take(nc); L.d = take(n); L.v = take(n);
   L.gd = take(D.ngd); L.yd = take(nd); L.red = take(64); L.scal = take(64);
+  L.t_rows = take(nc); L.t_dense = take(2 * nd);
   L.scr = o;
   // EVAL
   o = L.scr;
@@ -174,10 +179,12 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   L.e_A1 = take(nu * nu); L.e_A2 = take(nu * nq); L.e_Dxu = take(2 * n * nq);
   L.e_Hc = take(D.M * (DG_MAXEFF * DG_MAXEFF)); L.e_cv = take(D.M * DG_MAXDIR); L.e_inj = take(nq + nq * nq);
   const int eval_end = o;
-  // EIG
+  // EIG: packed P, packed Householder reflectors, tridiagonal workspace
   o = L.scr;
   const int npk = n * (n + 1) / 2;
-  L.g_Bp = take(npk); L.g_V = take(n * n); L.g_rot = take(4 * ((n + 1) / 2 + 1) + 2 * n + 4);
+  const int rpt = n <= 32 ? 16 : (n <= 64 ? 32 : (n <= 100 ? 50 : 64));
+  L.g_Bp = take(npk); L.g_V = take(npk);
+  L.g_tw = take(7 * n + 16 + 10 * n /* Z */ + (10 * 3 * n > 3 * (2 * rpt + 4) ? 10 * 3 * n : 3 * (2 * rpt + 4)));
   const int eig_end = o;
   // QP (P aliases Bp)
   o = L.scr + ((npk + 1) & ~1);

@@ -6,155 +6,344 @@
 __device__ inline int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
 // ------------------------------------------------------------------------------------------------
-// _nearestPD + reg (DGSQP.py:1290-1296, :238-239) by parallel-order cyclic Jacobi in LDS.
-// In : raw Q (global workspace).  Out: P = (nearestPD(Q) + reg I)^-1 packed in L.g_Bp.
-// The projected matrix itself is never needed by the QP below, only its inverse.
-// If Qpd != nullptr the projected+regularised matrix is also written there (test hook).
+// Fast path of _nearestPD + reg + inverse.  The symmetrised game Hessian has only a handful of negative
+// eigenvalues (1-8 in the racing games), so instead of a full eigendecomposition:
+//   1. Householder tridiagonalisation  B = Q T Q^T  in LDS (full storage, reflectors kept in place),
+//   2. Sturm count at 0 -> number of negative eigenvalues; each one by 64-way multisection (one wavefront
+//      evaluates 64 Sturm sequences per step),
+//   3. eigenvectors of T by inverse iteration (tridiagonal LU with partial pivoting, one lane each),
+//      modified Gram-Schmidt, back-transformation through the reflectors (one wavefront per vector),
+//   4. M = B + sum_j (1e-10 - lambda_j) v_j v_j^T + reg I   (== U diag(s') U^T + reg I of DGSQP.py:1290-1296),
+//   5. P = M^-1 by the symmetric Gauss-Jordan sweep (SPD => no pivoting), packed into L.g_Bp.
+// Returns false (nothing written) when there are more than PSD_KMAX negative eigenvalues: caller falls back
+// to the Jacobi route.
 // ------------------------------------------------------------------------------------------------
-__device__ inline void dev_psd_inverse(const Ctx& c, double* Qpd) {
-  const DgProb& D = *c.D;
+#define PSD_KMAX 10
+// Number of eigenvalues of the symmetric tridiagonal (d, e) below sigma = number of sign changes of the
+// Sturm sequence p_0 = 1, p_1 = d_0 - s, p_{i+1} = (d_i - s) p_i - e_{i-1}^2 p_{i-1}  (division-free, rescaled).
+__device__ inline int sturm_count(clptr d, clptr e2, int n, double sigma, double pivmin) {
+  (void)pivmin;
+  double pp = 1.0, pc = d[0] - sigma;
+  int cnt = pc < 0.0 || pc == 0.0;  // a zero is counted as a sign change (same convention as q = -pivmin)
+  if (pc == 0.0) pc = -1e-300;
+  for (int i = 1; i < n; i++) {
+    double pn = (d[i] - sigma) * pc - e2[i - 1] * pp;
+    if (pn == 0.0) pn = pc > 0.0 ? -1e-300 * fabs(pc) - 1e-320 : 1e-300 * fabs(pc) + 1e-320;
+    cnt += (pn < 0.0) != (pc < 0.0);
+    pp = pc; pc = pn;
+    const double a = fabs(pc);
+    if (a > 1e120) { pc *= 1e-120; pp *= 1e-120; }
+    else if (a < 1e-120) { pc *= 1e120; pp *= 1e120; }
+  }
+  return cnt;
+}
+// Register-resident layout: thread (jc = TID & 127, hf = TID >> 7) owns column jc, rows hf, hf+2, hf+4, ...
+// (RPT of them) of the symmetric matrix for the whole Householder reduction AND the Gauss-Jordan sweep; LDS
+// only carries the broadcast vectors (reflector v, w, pivot column) and the stored reflectors.
+template <int RPT>
+__device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
+  const DgProb& D = dg_prob;
   const DgLds& L = D.L;
-  double* lds = c.lds;
-  const int n = D.n, npk = n * (n + 1) / 2;
-  const int np = (n + 1) & ~1, m = np / 2;
-  double* Bp = lds + L.g_Bp;
-  double* Vt = lds + L.g_V;  // Vt[k*n + i] = component i of eigenvector k
-  double* rc = lds + L.g_rot;
-  double* rs = rc + m + 1;
-  int* rp = (int*)(rs + m + 1);
-  int* rq = rp + m + 1;
-  double* wts = lds + L.g_rot + 4 * ((n + 1) / 2 + 1);
-  double* sev = wts + n + 2;
-  double* red = lds + L.red;
-  const double* Qg = c.ws + D.ws_q;
+  lptr lds = LP(0);
+  const int n = D.n;
+  if (n > 2 * RPT || n > 128 || n < 4) return false;
+  lds_d* Rf = lds + L.g_V;   // Householder reflectors, strict lower triangle packed by columns
+#define RFOFF(k) ((k) * (2 * n - (k) - 1) / 2)
+  lds_d* Wk = lds + L.g_tw;  // workspace (aliases the packed slot when LDS is tight: P is written there last)
+  lds_d *dv = Wk, *ev = Wk + n, *tau = Wk + 2 * n, *vv = Wk + 3 * n, *pp = Wk + 4 * n /* 2n */, *ww = Wk + 6 * n;
+  lptr lamv = Wk + 7 * n;             // PSD_KMAX (+ pad)
+  lptr Z = Wk + 7 * n + 16;           // PSD_KMAX x n eigenvectors
+  lptr tws = Z + PSD_KMAX * n;        // PSD_KMAX x 3n tridiagonal-solve workspace
+  lds_d* red = lds + L.red;
+  lds_d* scal = lds + L.scal;
+  cgptr Qg = c.ws + D.ws_q;
+  const int lane = TID & 63, wave = TID >> 6;
+  const int jc = TID & 127, hf = TID >> 7;
+  const bool colok = jc < n;
   __syncthreads();
-  PROF_BEGIN(pt_j);
-  for (int t = TID; t < npk; t += NT) {
-    int i = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-    while ((i + 1) * (i + 2) / 2 <= t) i++;
-    while (i * (i + 1) / 2 > t) i--;
-    const int j = t - i * (i + 1) / 2;
-    Bp[t] = 0.5 * (Qg[(int64_t)i * n + j] + Qg[(int64_t)j * n + i]);  // B = (A + A^T)/2
+  PROF_BEGIN(pt_t);
+  // ---- 1. B = (Q + Q^T)/2, this thread's slice
+  double Br[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; r++) {
+    const int i = hf + 2 * r;
+    Br[r] = (colok && i < n) ? 0.5 * (Qg[(int64_t)i * n + jc] + Qg[(int64_t)jc * n + i]) : 0.0;
   }
-  for (int t = TID; t < n * n; t += NT) Vt[t] = (t / n == t % n) ? 1.0 : 0.0;
+  // ---- 2. Householder tridiagonalisation.  vf / wf hold v and w at FULL row index (zero for rows <= k and for the
+  //         padding rows >= n), so the per-thread loops below are branch-free and their LDS reads can be batched.
+  lptr vf = tws;                 // 2*RPT + 2 entries each, carved from the tridiagonal-solve workspace (unused until 3b)
+  lptr wf = tws + 2 * RPT + 4;
+  lptr cb = tws + 2 * (2 * RPT + 4);  // published column
+  for (int i = TID; i < 2 * RPT + 2; i += NT) { vf[i] = 0.0; wf[i] = 0.0; }
   __syncthreads();
-  bool final_sweep = false;
-  for (int sweep = 0; sweep < 40; sweep++) {
-    double off = 0, dg = 0;
-    for (int t = TID; t < npk; t += NT) {
-      int i = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-      while ((i + 1) * (i + 2) / 2 <= t) i++;
-      while (i * (i + 1) / 2 > t) i--;
-      const double v = Bp[t];
-      if (t - i * (i + 1) / 2 == i) dg += v * v; else off += v * v;
+  for (int k = 0; k < n - 2; k++) {
+    const int m = n - k - 1;
+    if (jc == k) {  // the two owners of column k publish their whole slice (straight-line stores, no per-row predicates)
+#pragma unroll
+      for (int r = 0; r < RPT; r++) cb[hf + 2 * r] = Br[r];
     }
-    off = block_sum(off, red);
-    dg = block_sum(dg, red);
-    if (final_sweep || off <= 1e-31 * dg || off < 1e-300) break;
-    // Jacobi converges quadratically: once |off| <= 1e-9 |B|_F one more sweep reaches the rounding floor
-    if (off <= 1e-18 * dg) final_sweep = true;
-    PROF_BEGIN(pt_s);
-    for (int rd = 0; rd < np - 1; rd++) {
-      // rotation angles of the m disjoint pairs of this round
-      if (TID < m) {
-        int a, b;
-        if (TID == 0) { a = np - 1; b = rd; }
-        else { a = (rd + TID) % (np - 1); b = (rd - TID + (np - 1)) % (np - 1); }
-        const int p = a < b ? a : b, q = a < b ? b : a;
-        double cs = 1.0, sn = 0.0;
-        if (q < n) {
-          const double apq = Bp[tri(q, p)];
-          if (apq != 0.0) {
-            const double app = Bp[tri(p, p)], aqq = Bp[tri(q, q)];
-            const double theta = (aqq - app) / (2.0 * apq);
-            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-            cs = 1.0 / sqrt(t * t + 1.0);
-            sn = t * cs;
-          }
-        }
-        rc[TID] = cs; rs[TID] = sn; rp[TID] = p; rq[TID] = q;
+    __syncthreads();
+    if (wave == 0) {
+      const double xa = lane < m ? cb[k + 1 + lane] : 0.0, xb = lane + 64 < m ? cb[k + 1 + lane + 64] : 0.0;
+      if (lane == 0) dv[k] = cb[k];
+      const double x0 = __shfl(xa, 0);
+      double nrm2 = xa * xa + xb * xb;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) nrm2 += __shfl_xor(nrm2, o);
+      const double tail2 = nrm2 - x0 * x0;
+      double alpha, beta;
+      if (!(tail2 > 0.0)) { alpha = x0; beta = 0.0; }
+      else {
+        alpha = x0 >= 0 ? -sqrt(nrm2) : sqrt(nrm2);
+        const double v0 = x0 - alpha;
+        beta = 2.0 / (tail2 + v0 * v0);
+      }
+      const double va = (lane == 0 && beta != 0.0) ? xa - alpha : xa;
+      if (lane < m) { vf[k + 1 + lane] = va; Rf[RFOFF(k) + lane] = va; }
+      if (lane + 64 < m) { vf[k + 1 + lane + 64] = xb; Rf[RFOFF(k) + lane + 64] = xb; }
+      if (lane == 0) { vf[k] = 0.0; wf[k] = 0.0; ev[k] = alpha; tau[k] = beta; scal[8] = beta; }
+    }
+    __syncthreads();
+    const double beta = scal[8];
+    if (beta != 0.0) {
+      // p_j = sum_i B[i][j] v_i over this thread's rows (B symmetric => column sums give the matvec)
+      double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+      for (int r = 0; r + 3 < RPT; r += 4) {
+        s0 += Br[r] * vf[hf + 2 * r];
+        s1 += Br[r + 1] * vf[hf + 2 * r + 2];
+        s2 += Br[r + 2] * vf[hf + 2 * r + 4];
+        s3 += Br[r + 3] * vf[hf + 2 * r + 6];
+      }
+#pragma unroll
+      for (int r = RPT & ~3; r < RPT; r++) s0 += Br[r] * vf[hf + 2 * r];
+      if (colok) pp[hf * n + jc] = (s0 + s1) + (s2 + s3);
+      __syncthreads();
+      if (wave == 0) {
+        const double pa = lane < m ? beta * (pp[k + 1 + lane] + pp[n + k + 1 + lane]) : 0.0;
+        const double pb = lane + 64 < m ? beta * (pp[k + 1 + lane + 64] + pp[n + k + 1 + lane + 64]) : 0.0;
+        const double va = lane < m ? vf[k + 1 + lane] : 0.0, vb = lane + 64 < m ? vf[k + 1 + lane + 64] : 0.0;
+        double pv = pa * va + pb * vb;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pv += __shfl_xor(pv, o);
+        const double K = 0.5 * beta * pv;
+        if (lane < m) wf[k + 1 + lane] = pa - K * va;
+        if (lane + 64 < m) wf[k + 1 + lane + 64] = pb - K * vb;
       }
       __syncthreads();
-      // B <- J^T B J, one 2x2 block per task
-      for (int t = TID; t < m * (m + 1) / 2; t += NT) {
-        int r2 = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-        while ((r2 + 1) * (r2 + 2) / 2 <= t) r2++;
-        while (r2 * (r2 + 1) / 2 > t) r2--;
-        const int r1 = t - r2 * (r2 + 1) / 2;
-        const int p1 = rp[r1], q1 = rq[r1], p2 = rp[r2], q2 = rq[r2];
-        if (q1 >= n || q2 >= n) continue;
-        const double c1 = rc[r1], s1 = rs[r1], c2 = rc[r2], s2 = rs[r2];
-        if (r1 == r2) {
-          const int ipp = tri(p1, p1), iqq = tri(q1, q1), ipq = tri(q1, p1);
-          const double apq = Bp[ipq];
-          if (s1 != 0.0) {
-            const double t2 = s1 / c1;
-            Bp[ipp] -= t2 * apq; Bp[iqq] += t2 * apq; Bp[ipq] = 0.0;
-          }
-        } else {
-          const int i00 = tri(p1, p2), i01 = tri(p1, q2), i10 = tri(q1, p2), i11 = tri(q1, q2);
-          const double x00 = Bp[i00], x01 = Bp[i01], x10 = Bp[i10], x11 = Bp[i11];
-          const double y00 = c2 * x00 - s2 * x01, y01 = s2 * x00 + c2 * x01;
-          const double y10 = c2 * x10 - s2 * x11, y11 = s2 * x10 + c2 * x11;
-          Bp[i00] = c1 * y00 - s1 * y10; Bp[i01] = c1 * y01 - s1 * y11;
-          Bp[i10] = s1 * y00 + c1 * y10; Bp[i11] = s1 * y01 + c1 * y11;
-        }
+      {
+        const double vj = colok ? vf[jc] : 0.0, wj = colok ? wf[jc] : 0.0;   // zero for columns <= k
+#pragma unroll
+        for (int r = 0; r < RPT; r++) Br[r] -= vf[hf + 2 * r] * wj + wf[hf + 2 * r] * vj;
       }
-      // V <- V J (rows of Vt)
-      for (int t = TID; t < m * n; t += NT) {
-        const int r = t / n, i = t % n;
-        const int p = rp[r], q = rq[r];
-        if (q >= n) continue;
-        const double cs = rc[r], sn = rs[r];
-        const double vp = Vt[p * n + i], vq = Vt[q * n + i];
-        Vt[p * n + i] = cs * vp - sn * vq;
-        Vt[q * n + i] = sn * vp + cs * vq;
-      }
-      __syncthreads();
     }
-    PROF_END(PH_SWEEP, pt_s);
+    __syncthreads();
   }
-  PROF_END(PH_JACOBI, pt_j);
-  PROF_BEGIN(pt_p);
-  // eigenvalues: negative -> 1e-10 (DGSQP.py:1294), then + reg; P = V diag(1/.) V^T
-  for (int i = TID; i < n; i += NT) {
-    double s = Bp[tri(i, i)];
-    if (s < 0) s = 1e-10;
-    sev[i] = s;
-    wts[i] = 1.0 / (s + (D.par.reg > 0 ? D.par.reg : 0.0));
+#pragma unroll
+  for (int r = 0; r < RPT; r++) {
+    const int i = hf + 2 * r;
+    if (jc == n - 2 && i == n - 2) dv[n - 2] = Br[r];
+    if (jc == n - 1 && i == n - 1) { dv[n - 1] = Br[r]; ev[n - 1] = 0.0; }
+    if (jc == n - 2 && i == n - 1) ev[n - 2] = Br[r];
   }
   __syncthreads();
+  // ---- 3. negative eigenvalues of T by Sturm counts.  pp <- e^2
+  double tn = 0;
+  for (int i = TID; i < n; i += NT) { pp[i] = ev[i] * ev[i]; tn = fmax(tn, fabs(dv[i]) + fabs(ev[i]) + (i > 0 ? fabs(ev[i - 1]) : 0.0)); }
+  const double tnorm = block_max(tn, red);
+  const double pivmin = fmax(1e-300, 2.3e-308 * 4.0 * tnorm * tnorm);
+  const int kneg = sturm_count(dv, pp, n, 0.0, pivmin);
+  // ---- 4a. M = B + reg I (this thread's slice, back into Br); the negative part is corrected batch by batch
+  const double reg = D.par.reg > 0 ? D.par.reg : 0.0;
+#pragma unroll
+  for (int r = 0; r < RPT; r++) {
+    const int i = hf + 2 * r;
+    double a = 0.0;
+    if (colok && i < n) {
+      a = 0.5 * (Qg[(int64_t)i * n + jc] + Qg[(int64_t)jc * n + i]);
+      if (i == jc) a += reg;
+    }
+    Br[r] = a;
+  }
+  for (int j0 = 0; j0 < kneg; j0 += PSD_KMAX) {
+    const int kb = kneg - j0 < PSD_KMAX ? kneg - j0 : PSD_KMAX;
+    __syncthreads();
+    for (int jj = wave; jj < kb; jj += 4) {
+      const int j = j0 + jj;
+      // eigenvalue j (ascending) lies in [lo, hi) with count(lo) <= j < count(hi): 64-way multisection
+      double lo = -tnorm * 1.0000001 - 1e-300, hi = 0.0;
+      for (int it = 0; it < 16; it++) {
+        const double wdt = hi - lo;
+        const double sg = lo + wdt * (double)(lane + 1) * (1.0 / 65.0);
+        const int cnt = sturm_count(dv, pp, n, sg, pivmin);
+        const unsigned long long above = __ballot(cnt > j);
+        const int first = above ? __ffsll((long long)above) - 1 : 64;
+        const double nlo = first == 0 ? lo : __shfl(sg, first - 1);
+        const double nhi = first == 64 ? hi : __shfl(sg, first);
+        lo = nlo; hi = nhi;
+        if (hi - lo <= 4.5e-16 * fmax(fabs(lo), fabs(hi)) + 1e-300) break;
+      }
+      if (lane == 0) lamv[jj] = 0.5 * (lo + hi);
+    }
+    __syncthreads();
+    // ---- 3b. eigenvectors of T: inverse iteration, one lane per eigenvalue
+    if (TID < kb) {
+      const int j = TID;
+      const double lam = lamv[j];
+      lptr z = Z + j * n;
+      lds_d *dd = tws + j * 3 * n, *du = dd + n, *du2 = du + n;
+      const double tiny = 2.3e-16 * tnorm + 1e-300;
+      for (int i = 0; i < n; i++) z[i] = 1.0 + 0.37 * (double)((i * 7 + j * 3) % 5);
+      for (int iter = 0; iter < 2; iter++) {
+        for (int i = 0; i < n; i++) { dd[i] = dv[i] - lam; du[i] = ev[i]; du2[i] = 0.0; }
+        for (int i = 0; i < n - 1; i++) {   // elimination with partial pivoting (LAPACK dgtsv)
+          const double dl = ev[i];
+          if (fabs(dd[i]) >= fabs(dl)) {
+            if (dd[i] == 0.0) dd[i] = tiny;
+            const double f = dl / dd[i];
+            dd[i + 1] -= f * du[i];
+            z[i + 1] -= f * z[i];
+          } else {
+            const double f = dd[i] / dl;
+            dd[i] = dl;
+            const double t = dd[i + 1];
+            dd[i + 1] = du[i] - f * t;
+            if (i < n - 2) { du2[i] = du[i + 1]; du[i + 1] = -f * du2[i]; }
+            du[i] = t;
+            const double zt = z[i];
+            z[i] = z[i + 1];
+            z[i + 1] = zt - f * z[i + 1];
+          }
+        }
+        if (fabs(dd[n - 1]) < tiny) dd[n - 1] = tiny;
+        z[n - 1] /= dd[n - 1];
+        z[n - 2] = (z[n - 2] - du[n - 2] * z[n - 1]) / dd[n - 2];
+        for (int i = n - 3; i >= 0; i--) z[i] = (z[i] - du[i] * z[i + 1] - du2[i] * z[i + 2]) / dd[i];
+        double nr = 0;
+        for (int i = 0; i < n; i++) nr = fmax(nr, fabs(z[i]));
+        nr = 1.0 / nr;
+        for (int i = 0; i < n; i++) z[i] *= nr;
+      }
+    }
+    __syncthreads();
+    // ---- 3c. modified Gram-Schmidt (wavefront 0), then back-transformation v = H_0 ... H_{n-3} z (one wavefront per vector)
+    if (wave == 0) {
+      for (int j = 0; j < kb; j++) {
+        double za = lane < n ? Z[j * n + lane] : 0.0, zb = lane + 64 < n ? Z[j * n + lane + 64] : 0.0;
+        for (int i = 0; i < j; i++) {
+          const double ya = lane < n ? Z[i * n + lane] : 0.0, yb = lane + 64 < n ? Z[i * n + lane + 64] : 0.0;
+          double dt = za * ya + zb * yb;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) dt += __shfl_xor(dt, o);
+          za -= dt * ya; zb -= dt * yb;
+        }
+        double nr = za * za + zb * zb;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nr += __shfl_xor(nr, o);
+        nr = 1.0 / sqrt(nr);
+        za *= nr; zb *= nr;
+        if (lane < n) Z[j * n + lane] = za;
+        if (lane + 64 < n) Z[j * n + lane + 64] = zb;
+      }
+    }
+    __syncthreads();
+    for (int j = wave; j < kb; j += 4) {
+      double za = lane < n ? Z[j * n + lane] : 0.0, zb = lane + 64 < n ? Z[j * n + lane + 64] : 0.0;
+      for (int k = n - 3; k >= 0; k--) {
+        const double beta = tau[k];
+        if (beta == 0.0) continue;
+        const double va = (lane > k && lane < n) ? Rf[RFOFF(k) + lane - k - 1] : 0.0;
+        const double vb = (lane + 64 > k && lane + 64 < n) ? Rf[RFOFF(k) + lane + 64 - k - 1] : 0.0;
+        double dt = va * za + vb * zb;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dt += __shfl_xor(dt, o);
+        dt *= beta;
+        za -= dt * va; zb -= dt * vb;
+      }
+      if (lane < n) Z[j * n + lane] = za;
+      if (lane + 64 < n) Z[j * n + lane + 64] = zb;
+    }
+    __syncthreads();
+    // ---- 4b. M += sum_j (1e-10 - lam_j) v_j v_j^T   (== U diag(s') U^T of DGSQP.py:1290-1296 on the negative part)
+#pragma unroll
+    for (int r = 0; r < RPT; r++) {
+      const int i = hf + 2 * r;
+      if (colok && i < n) {
+        double a = Br[r];
+        for (int j = 0; j < kb; j++) a += (1e-10 - lamv[j]) * Z[j * n + i] * Z[j * n + jc];
+        Br[r] = a;
+      }
+    }
+  }
   if (Qpd) {
-    for (int t = TID; t < n * n; t += NT) {
-      const int i = t / n, j = t % n;
-      double a = 0;
-      for (int k = 0; k < n; k++) a += Vt[k * n + i] * sev[k] * Vt[k * n + j];
-      if (i == j && D.par.reg > 0) a += D.par.reg;
-      Qpd[t] = a;
+#pragma unroll
+    for (int r = 0; r < RPT; r++) {
+      const int i = hf + 2 * r;
+      if (colok && i < n) Qpd[i * n + jc] = Br[r];
     }
   }
-  for (int t = TID; t < npk; t += NT) {
-    int i = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-    while ((i + 1) * (i + 2) / 2 <= t) i++;
-    while (i * (i + 1) / 2 > t) i--;
-    const int j = t - i * (i + 1) / 2;
-    double a = 0;
-    for (int k = 0; k < n; k++) a += Vt[k * n + i] * wts[k] * Vt[k * n + j];
-    Bp[t] = a;
+  __syncthreads();
+  PROF_END(PH_JACOBI, pt_t);
+  PROF_BEGIN(pt_s);
+  // ---- 5. symmetric Gauss-Jordan sweep in registers: after all pivots the slice holds -M^-1
+  lptr colk = tws;  // 2*RPT + 2 entries; padding rows stay zero
+  for (int i = TID; i < 2 * RPT + 2; i += NT) colk[i] = 0.0;
+  __syncthreads();
+  for (int k = 0; k < n; k++) {
+    if (jc == k) {
+#pragma unroll
+      for (int r = 0; r < RPT; r++) colk[hf + 2 * r] = Br[r];   // padding rows hold exact zeros
+    }
+    __syncthreads();
+    const double dinv = 1.0 / colk[k];
+    const double rj = colok ? colk[jc] * dinv : 0.0;
+    const bool pc = jc == k;
+    const double rowv = pc ? -dinv : rj;   // new row k:  a_kj/d, pivot -1/d
+    // Straight-line update (selects on registers only, every LDS read unconditional so they can be batched):
+    //   general  a_ij - a_ik a_kj/d ;  column k  a_ik/d ;  row k  a_kj/d ;  pivot -1/d
+    double ci[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; r++) ci[r] = colk[hf + 2 * r];
+#pragma unroll
+    for (int r = 0; r < RPT; r++) {
+      const bool onrow = (hf + 2 * r) == k;
+      double base = pc ? ci[r] * dinv : Br[r];
+      base = onrow ? rowv : base;
+      const double mult = (pc || onrow) ? 0.0 : ci[r];
+      Br[r] = fma(-mult, rj, base);
+    }
+    __syncthreads();
+  }
+  lds_d* Pp = lds + L.g_Bp;
+#pragma unroll
+  for (int r = 0; r < RPT; r++) {
+    const int i = hf + 2 * r;
+    if (colok && i < n && i >= jc) Pp[i * (i + 1) / 2 + jc] = -Br[r];
   }
   __syncthreads();
-  PROF_END(PH_PFORM, pt_p);
+  PROF_END(PH_PFORM, pt_s);
+  return true;
+}
+
+__device__ inline void dev_psd_inverse(const Ctx& c, gptr Qpd) {
+  const int n = dg_prob.n;
+  bool ok;
+  if (n <= 32) ok = dev_psd_inverse_tridiag<16>(c, Qpd);
+  else if (n <= 64) ok = dev_psd_inverse_tridiag<32>(c, Qpd);
+  else if (n <= 100) ok = dev_psd_inverse_tridiag<50>(c, Qpd);
+  else ok = dev_psd_inverse_tridiag<64>(c, Qpd);
+  (void)ok;  // n <= 128 is enforced by dgsqp_create
 }
 
 // out = P t  (P packed symmetric in LDS)
-__device__ inline void dev_p_mul(const Ctx& c, const double* t, double* out, double scale) {
-  const DgProb& D = *c.D;
-  const double* Pp = c.lds + D.L.g_Bp;
+__device__ inline void dev_p_mul(const Ctx& c, clptr t, lptr out, double scale) {
+  const DgProb& D = dg_prob;
+  const lds_d* Pp = LP(0) + D.L.g_Bp;
   const int n = D.n;
   __syncthreads();
   for (int i = TID; i < n; i += NT) {
     double s = 0;
-    const double* row = Pp + i * (i + 1) / 2;
+    clptr row = Pp + i * (i + 1) / 2;
     for (int j = 0; j <= i; j++) s += row[j] * t[j];
     for (int j = i + 1; j < n; j++) s += Pp[j * (j + 1) / 2 + i] * t[j];
     out[i] = scale * s;
@@ -163,8 +352,8 @@ __device__ inline void dev_p_mul(const Ctx& c, const double* t, double* out, dou
 }
 
 // coefficient of constraint row r at column col
-__device__ inline double g_row_coef(const DgProb& D, const double* gd, int r, int col) {
-  const DgRow R = D.rows[r];
+__device__ inline double g_row_coef(const DgProb& D, clptr gd, int r, int col) {
+  const DgRow R = ld_row(r);
   const int a = col / (D.N * DGSQP_NUA), rem = col % (D.N * DGSQP_NUA), t = rem / DGSQP_NUA, j = rem % DGSQP_NUA;
   switch (R.type) {
     case DG_R_IN_UB: return (a == R.a && t == R.k && j == R.idx) ? 1.0 : 0.0;
@@ -177,7 +366,7 @@ __device__ inline double g_row_coef(const DgProb& D, const double* gd, int r, in
       return R.type == DG_R_RATE_UB ? v : -v;
     }
     default: {
-      const DgDense dd = D.dense[R.dense];
+      const DgDense dd = ld_dense(R.dense);
       if (t >= dd.k) return 0.0;
       if (a == dd.a) return R.sgn * gd[dd.off + t * DGSQP_NUA + j];
       if (dd.kind == 1 && a == dd.b) return R.sgn * gd[dd.off + 2 * dd.k + t * DGSQP_NUA + j];
@@ -189,7 +378,7 @@ __device__ inline double g_row_coef(const DgProb& D, const double* gd, int r, in
 // wavefront-0 helper: solve (R^T R) r = c for the packed upper-triangular factor R of order m (<= 128).
 // Lane j keeps entries j and j+64 in registers; pivots are broadcast with shuffles, so there is no LDS
 // hazard inside the substitution loops.  Writes w = R^-T c to wv, r to rv and returns |w|^2 to every lane.
-__device__ inline double qp_wave_solve(const double* R, int m, int lane, const double* cvec, double* wv, double* rv,
+__device__ inline double qp_wave_solve(clptr R, int m, int lane, clptr cvec, lptr wv, lptr rv,
                                        double& r0_out, double& r1_out) {
   double c0 = lane < m ? cvec[lane] : 0.0, c1 = lane + 64 < m ? cvec[lane + 64] : 0.0;
   double w0 = 0, w1 = 0;
@@ -226,21 +415,23 @@ __device__ inline double qp_wave_solve(const double* R, int m, int lane, const d
 // This is the KKT point OSQP(polish=True) returns when its polish succeeds.
 // Out: du (L.o_du), lhat (L.o_lhat).  Returns 0 ok, 1 infeasible, 2 iteration limit.
 // ------------------------------------------------------------------------------------------------
-__device__ inline int dev_qp(const Ctx& c) {
-  const DgProb& D = *c.D;
+__device__ __noinline__ int dev_qp(const Ctx& c) {
+  const DgProb& D = dg_prob;
   const DgLds& L = D.L;
-  double* lds = c.lds;
+  lptr lds = LP(0);
   const int n = D.n, nc = D.nc;
-  double *x = lds + L.o_du, *lhat = lds + L.o_lhat;
-  double *R = lds + L.p_R, *lam = lds + L.p_lam, *cvec = lds + L.p_c, *wv = lds + L.p_w, *rv = lds + L.p_r;
-  double *y = lds + L.p_y, *z = lds + L.p_z, *tv = lds + L.p_t;
-  int* alist = (int*)(lds + L.p_alist);
-  unsigned char* act = (unsigned char*)(lds + L.p_act);
-  double* red = lds + L.red;
-  double* scal = lds + L.scal;
-  const double* gd = lds + L.gd;
-  const double* g = lds + L.g;
-  const double* q = lds + L.q;
+  lds_d *x = lds + L.o_du, *lhat = lds + L.o_lhat;
+  lds_d *R = lds + L.p_R, *lam = lds + L.p_lam, *cvec = lds + L.p_c, *wv = lds + L.p_w, *rv = lds + L.p_r;
+  lds_d *y = lds + L.p_y, *z = lds + L.p_z, *tv = lds + L.p_t;
+  typedef __attribute__((address_space(3))) int lds_i;
+  typedef __attribute__((address_space(3))) unsigned char lds_b;
+  lds_i* alist = (lds_i*)(lds + L.p_alist);
+  lds_b* act = (lds_b*)(lds + L.p_act);
+  lds_d* red = lds + L.red;
+  lds_d* scal = lds + L.scal;
+  const lds_d* gd = lds + L.gd;
+  const lds_d* g = lds + L.g;
+  const lds_d* q = lds + L.q;
   const double TOL = 1e-10;
   const int lane = TID & 63;
   const int NONE = 0x7fffffff;
@@ -413,10 +604,10 @@ __device__ inline int dev_qp(const Ctx& c) {
 // its defaults damp=0, atol=btol=1e-6, conlim=1e8, iter_lim=2*n_c; the operator G G^T is applied as
 // G (G^T v) through the packed constraint gradients instead of being assembled.
 // ------------------------------------------------------------------------------------------------
-__device__ inline void dev_ggt_mul(const Ctx& c, const double* vin, double* vout, double* tmpn) {
-  const DgProb& D = *c.D;
+__device__ inline void dev_ggt_mul(const Ctx& c, clptr vin, lptr vout, lptr tmpn) {
+  const DgProb& D = dg_prob;
   gt_mul(c, vin, tmpn);
-  for (int r = TID; r < D.nc; r += NT) vout[r] = g_row_dot(D, c.lds + D.L.gd, r, tmpn);
+  for (int r = TID; r < D.nc; r += NT) vout[r] = g_row_dot(D, LP(0) + D.L.gd, r, tmpn);
   __syncthreads();
 }
 __device__ inline void dev_sym_ortho(double a, double b, double& cs, double& sn, double& r) {
@@ -425,15 +616,15 @@ __device__ inline void dev_sym_ortho(double a, double b, double& cs, double& sn,
   else if (fabs(b) > fabs(a)) { const double tau = a / b; sn = ((b > 0) - (b < 0)) / sqrt(1 + tau * tau); cs = sn * tau; r = b / sn; }
   else { const double tau = b / a; cs = ((a > 0) - (a < 0)) / sqrt(1 + tau * tau); sn = cs * tau; r = a / cs; }
 }
-__device__ inline void dev_dual_init(const Ctx& c) {
-  const DgProb& D = *c.D;
+__device__ __noinline__ void dev_dual_init(const Ctx& c) {
+  const DgProb& D = dg_prob;
   const DgLds& L = D.L;
-  double* lds = c.lds;
+  lptr lds = LP(0);
   const int nc = D.nc;
-  double *u = lds + L.s_u, *v = lds + L.s_v, *w = lds + L.s_w, *x = lds + L.s_x, *tmp = lds + L.s_t;
-  double* tn = lds + L.d;  // n-vector scratch (d is recomputed afterwards)
-  double* red = lds + L.red;
-  double* l = lds + L.l;
+  lds_d *u = lds + L.s_u, *v = lds + L.s_v, *w = lds + L.s_w, *x = lds + L.s_x, *tmp = lds + L.s_t;
+  lds_d* tn = lds + L.d;  // n-vector scratch (d is recomputed afterwards)
+  lds_d* red = lds + L.red;
+  lds_d* l = lds + L.l;
   PROF_BEGIN(pt_l);
   const double eps = 2.220446049250313e-16;
   const double atol = D.par.lsqr_atol, btol = D.par.lsqr_btol, ctol = 1e-8;
@@ -529,36 +720,36 @@ struct LinScal {
 };
 
 // d = q + G^T l  (also the stationarity vector of the convergence test, DGSQP.py:368)
-__device__ inline void dev_stat_vector(const Ctx& c, const double* lvec, double* dout) {
-  const DgProb& D = *c.D;
+__device__ inline void dev_stat_vector(const Ctx& c, clptr lvec, lptr dout) {
+  const DgProb& D = dg_prob;
   gt_mul(c, lvec, dout);
-  for (int i = TID; i < D.n; i += NT) dout[i] += c.lds[D.L.q + i];
+  for (int i = TID; i < D.n; i += NT) dout[i] += LP(0)[D.L.q + i];
   __syncthreads();
 }
 // v = Qraw^T d
 __device__ inline void dev_qt_mul(const Ctx& c) {
-  const DgProb& D = *c.D;
-  const double* Qg = c.ws + D.ws_q;
-  const double* d = c.lds + D.L.d;
+  const DgProb& D = dg_prob;
+  cgptr Qg = c.ws + D.ws_q;
+  const lds_d* d = LP(0) + D.L.d;
   __syncthreads();
   PROF_BEGIN(pt_q);
   for (int j = TID; j < D.n; j += NT) {
     double s = 0;
     for (int i = 0; i < D.n; i++) s += Qg[(int64_t)i * D.n + j] * d[i];
-    c.lds[D.L.v + j] = s;
+    LP(0)[D.L.v + j] = s;
   }
   __syncthreads();
   PROF_END(PH_QTMUL, pt_q);
 }
 // after a QP solve at the current linearisation: everything phi / dphi / mu need
-__device__ inline void dev_step_scalars(const Ctx& c, LinScal& S) {
-  const DgProb& D = *c.D;
+__device__ __noinline__ void dev_step_scalars(const Ctx& c, LinScal& S) {
+  const DgProb& D = dg_prob;
   const DgLds& L = D.L;
-  double* lds = c.lds;
-  const double *q = lds + L.q, *g = lds + L.g, *l = lds + L.l, *d = lds + L.d, *v = lds + L.v;
-  const double *du = lds + L.o_du, *lhat = lds + L.o_lhat;
-  double* t = lds + L.p_t;  // G^T lhat
-  double* red = lds + L.red;
+  lptr lds = LP(0);
+  const lds_d *q = lds + L.q, *g = lds + L.g, *l = lds + L.l, *d = lds + L.d, *v = lds + L.v;
+  const lds_d *du = lds + L.o_du, *lhat = lds + L.o_lhat;
+  lds_d* t = lds + L.p_t;  // G^T lhat
+  lds_d* red = lds + L.red;
   PROF_BEGIN(pt_m);
   gt_mul(c, lhat, t);
   double a1 = 0, a2 = 0, lGdu = 0, dd = 0;
@@ -588,14 +779,14 @@ __device__ inline void dev_step_scalars(const Ctx& c, LinScal& S) {
   PROF_END(PH_MERIT, pt_m);
 }
 // merit of a trial point: current (q, g, G) in LDS belong to the trial u; multipliers l + alpha (lhat - l)
-__device__ inline double dev_phi_trial(const Ctx& c, double alpha, double sum_s, double mu) {
-  const DgProb& D = *c.D;
+__device__ __noinline__ double dev_phi_trial(const Ctx& c, double alpha, double sum_s, double mu) {
+  const DgProb& D = dg_prob;
   const DgLds& L = D.L;
-  double* lds = c.lds;
-  double* lt = lds + L.s_x;
-  double* dt = lds + L.s_t;
-  double* red = lds + L.red;
-  const double *l = lds + L.l, *lhat = lds + L.o_lhat, *g = lds + L.g;
+  lptr lds = LP(0);
+  lds_d* lt = lds + L.s_x;
+  lds_d* dt = lds + L.s_t;
+  lds_d* red = lds + L.red;
+  const lds_d *l = lds + L.l, *lhat = lds + L.o_lhat, *g = lds + L.g;
   __syncthreads();
   PROF_BEGIN(pt_m);
   double lg = 0, sg = 0;
@@ -618,9 +809,9 @@ __device__ inline double dev_phi_trial(const Ctx& c, double alpha, double sum_s,
 // _line_search_3 (DGSQP.py:1057-1081) from the base (u, du, l, lhat) held in LDS.  On return u and l hold
 // the LAST trial point; returns its merit.
 __device__ inline double dev_line_search(const Ctx& c, double mu, double phi, double dphi, double S0, double S1) {
-  const DgProb& D = *c.D;
+  const DgProb& D = dg_prob;
   const DgLds& L = D.L;
-  double* lds = c.lds;
+  lptr lds = LP(0);
   double alpha = 1.0, phit = 0.0;
   for (int i = 0; i < D.par.line_search_iters; i++) {
     dev_evaluate(c, lds + L.u, alpha, lds + L.o_du, false);
@@ -638,10 +829,10 @@ __device__ inline double dev_line_search(const Ctx& c, double mu, double phi, do
 
 // full linearisation + QP at the current (u, l): _evaluate(hessian=True) followed by _solve_qp.
 // Returns the QP flag (0 ok).  Leaves d, v, du, lhat and P in LDS.
-__device__ inline int dev_linearize_and_qp(const Ctx& c, bool do_qp, double* cond3, double* Qpd) {
-  const DgProb& D = *c.D;
+__device__ inline int dev_linearize_and_qp(const Ctx& c, bool do_qp, double* cond3, gptr Qpd) {
+  const DgProb& D = dg_prob;
   const DgLds& L = D.L;
-  double* lds = c.lds;
+  lptr lds = LP(0);
   dev_evaluate(c, lds + L.u, 0.0, nullptr, true);
   dev_stat_vector(c, lds + L.l, lds + L.d);
   if (cond3) {  // convergence measures (DGSQP.py:376-378)
@@ -659,37 +850,37 @@ __device__ inline int dev_linearize_and_qp(const Ctx& c, bool do_qp, double* con
 }
 
 __device__ inline void dev_save_base(const Ctx& c) {
-  const DgProb& D = *c.D;
+  const DgProb& D = dg_prob;
   const DgLds& L = D.L;
-  double* b = c.ws + D.ws_base;
-  for (int i = TID; i < D.n; i += NT) { b[i] = c.lds[L.u + i]; b[D.n + i] = c.lds[L.o_du + i]; }
-  for (int r = TID; r < D.nc; r += NT) { b[2 * D.n + r] = c.lds[L.l + r]; b[2 * D.n + D.nc + r] = c.lds[L.o_lhat + r]; }
+  gptr b = c.ws + D.ws_base;
+  for (int i = TID; i < D.n; i += NT) { b[i] = LP(0)[L.u + i]; b[D.n + i] = LP(0)[L.o_du + i]; }
+  for (int r = TID; r < D.nc; r += NT) { b[2 * D.n + r] = LP(0)[L.l + r]; b[2 * D.n + D.nc + r] = LP(0)[L.o_lhat + r]; }
   __syncthreads();
 }
 __device__ inline void dev_restore_base(const Ctx& c) {
-  const DgProb& D = *c.D;
+  const DgProb& D = dg_prob;
   const DgLds& L = D.L;
-  const double* b = c.ws + D.ws_base;
+  cgptr b = c.ws + D.ws_base;
   __syncthreads();
-  for (int i = TID; i < D.n; i += NT) { c.lds[L.u + i] = b[i]; c.lds[L.o_du + i] = b[D.n + i]; }
-  for (int r = TID; r < D.nc; r += NT) { c.lds[L.l + r] = b[2 * D.n + r]; c.lds[L.o_lhat + r] = b[2 * D.n + D.nc + r]; }
+  for (int i = TID; i < D.n; i += NT) { LP(0)[L.u + i] = b[i]; LP(0)[L.o_du + i] = b[D.n + i]; }
+  for (int r = TID; r < D.nc; r += NT) { LP(0)[L.l + r] = b[2 * D.n + r]; LP(0)[L.o_lhat + r] = b[2 * D.n + D.nc + r]; }
   __syncthreads();
 }
 __device__ inline void dev_take_full_step(const Ctx& c) {  // u += du ; l = lhat
-  const DgProb& D = *c.D;
+  const DgProb& D = dg_prob;
   const DgLds& L = D.L;
   __syncthreads();
-  for (int i = TID; i < D.n; i += NT) c.lds[L.u + i] += c.lds[L.o_du + i];
-  for (int r = TID; r < D.nc; r += NT) c.lds[L.l + r] = c.lds[L.o_lhat + r];
+  for (int i = TID; i < D.n; i += NT) LP(0)[L.u + i] += LP(0)[L.o_du + i];
+  for (int r = TID; r < D.nc; r += NT) LP(0)[L.l + r] = LP(0)[L.o_lhat + r];
   __syncthreads();
 }
 
 // _watchdog_line_search_4 (DGSQP.py:1174-1288; branch order of SURVEY.md A.7).  Base point and step
 // (u_k, du_k, l_k, lhat_k) are in LDS on entry; returns the number of extra QP solves.
 __device__ inline int dev_watchdog(const Ctx& c, double mu, const LinScal& Sk) {
-  const DgProb& D = *c.D;
+  const DgProb& D = dg_prob;
   const DgLds& L = D.L;
-  double* lds = c.lds;
+  lptr lds = LP(0);
   const double beta = D.par.beta;
   const double phi_k = Sk.phi, dphi_k = Sk.dphi;
   int nqp = 0;
@@ -758,10 +949,10 @@ struct SolveOutPtrs {
   double *u, *l, *x, *cond, *cost;
   int32_t *status, *iters, *qp_solves;
 };
-__device__ inline void dev_solve(const Ctx& c, const double* u_ws, int64_t b, const SolveOutPtrs& O) {
-  const DgProb& D = *c.D;
+__device__ inline void dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const SolveOutPtrs& O) {
+  const DgProb& D = dg_prob;
   const DgLds& L = D.L;
-  double* lds = c.lds;
+  lptr lds = LP(0);
   const int n = D.n, nc = D.nc;
   __syncthreads();
   for (int i = TID; i < n; i += NT) lds[L.u + i] = u_ws[i];
@@ -809,7 +1000,7 @@ __device__ inline void dev_solve(const Ctx& c, const double* u_ws, int64_t b, co
     else dev_line_search(c, mu, S.phi, S.dphi, S.S0, S.S1);
     // relative-tolerance exit (DGSQP.py:454-462)
     double du2 = 0, dl2 = 0;
-    const double* bk = c.ws + D.ws_base;
+    cgptr bk = c.ws + D.ws_base;
     for (int i = TID; i < n; i += NT) { const double t = lds[L.u + i] - bk[i]; du2 += t * t; }
     for (int r = TID; r < nc; r += NT) { const double t = lds[L.l + r] - bk[2 * n + r]; dl2 += t * t; }
     du2 = block_sum(du2, lds + L.red);
@@ -823,7 +1014,7 @@ __device__ inline void dev_solve(const Ctx& c, const double* u_ws, int64_t b, co
   }
   // outputs: q_pred = evaluate_dynamics(u, x0) (DGSQP.py:476), cost = f_J (:492)
   __syncthreads();
-  double* ue = lds + L.e_ue;
+  lds_d* ue = lds + L.e_ue;
   for (int i = TID; i < n; i += NT) ue[i] = lds[L.u + i];
   dev_rollout(c, ue, lds + L.e_x);
   if (O.cost) dev_costs(c, ue, O.cost + b * D.M);

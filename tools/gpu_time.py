@@ -18,7 +18,7 @@ lib = s._lib
 if hasattr(lib, 'dgsqp_prof_read'):
     buf = (ctypes.c_ulonglong * 32)()
     nph = lib.dgsqp_prof_read(buf, 32)
-    names = ['rollout', 'deriv1', 'deriv2', 'chains', 'dp', 'jacobi', 'pform', 'qp', 'merit', 'lsqr', 'qtmul', 'sweep']
+    names = ['rollout', 'deriv1', 'deriv2', 'chains', 'dp', 'jacobi', 'pform', 'qp', 'merit', 'lsqr', 'qtmul', 'sweep', 'wgtotal', 'wgmax(clk,wall100MHz)']
     tot = sum(buf[2 * i] for i in range(nph))
     for i in range(nph):
         if buf[2 * i + 1]:
