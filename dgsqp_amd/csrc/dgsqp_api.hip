@@ -15,7 +15,7 @@
 // ------------------------------------------------------------------------------------------------
 // Persistent solve kernel: each workgroup pulls scenarios from a device-wide ticket counter, so that
 // scenarios with long SQP runs (iteration counts vary 1..50+) do not serialise a static partition.
-__global__ void __launch_bounds__(DG_BLOCK, 1)
+__global__ void __launch_bounds__(DG_BLOCK)
 dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__ x0, const double* __restrict__ u_ws,
                 SolveOutPtrs O, double* __restrict__ ws_all, unsigned long long* __restrict__ ticket,
                 double* __restrict__ trace, int trace_cap) {
@@ -49,7 +49,7 @@ dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restric
 }
 
 // Test hook: one _evaluate(hessian=True) (+ dual init) per scenario, results expanded to dense arrays.
-__global__ void __launch_bounds__(DG_BLOCK, 1)
+__global__ void __launch_bounds__(DG_BLOCK)
 dg_evaluate_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__ x0, const double* __restrict__ u,
                    const double* __restrict__ l, double* q, double* g, double* G, double* Q, double* x, double* l0,
                    double* __restrict__ ws_all) {
@@ -85,7 +85,7 @@ dg_evaluate_kernel(const DgProb* __restrict__ D, int64_t B, const double* __rest
 }
 
 // Test hook: _solve_qp at the linearisation point (u, l).
-__global__ void __launch_bounds__(DG_BLOCK, 1)
+__global__ void __launch_bounds__(DG_BLOCK)
 dg_qp_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__ x0, const double* __restrict__ u,
              const double* __restrict__ l, double* du, double* lhat, double* Qpd, int32_t* flag, double* __restrict__ ws_all) {
   Ctx c;

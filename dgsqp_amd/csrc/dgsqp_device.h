@@ -73,7 +73,7 @@ __device__ inline void dev_tr(const Ctx& c, int code, double v) {
 
 // Diagnostic build only (-DDG_PROF): per-phase cycle counters accumulated by thread 0 of every workgroup
 // into a global array; the production library compiles these to nothing.
-enum { PH_ROLLOUT = 0, PH_DERIV1, PH_DERIV2, PH_CHAINS, PH_DP, PH_JACOBI, PH_PFORM, PH_QP, PH_MERIT, PH_LSQR, PH_QTMUL, PH_SWEEP, PH_WGTOTAL, PH_WGMAX, PH_COUNT };
+enum { PH_ROLLOUT = 0, PH_DERIV1, PH_DERIV2, PH_CHAINS, PH_DP, PH_JACOBI, PH_PFORM, PH_QP, PH_MERIT, PH_LSQR, PH_QTMUL, PH_SWEEP, PH_WGTOTAL, PH_WGMAX, PH_Q_SCAN, PH_Q_Y, PH_Q_DIR, PH_Q_STEP, PH_Q_UPD, PH_Q_REFINE, PH_COUNT };
 #ifdef DG_PROF
 __device__ unsigned long long dg_prof[PH_COUNT * 2];
 #define PROF_BEGIN(v) const long long v = clock64()
@@ -86,40 +86,81 @@ __device__ unsigned long long dg_prof[PH_COUNT * 2];
 // ------------------------------------------------------------------------------------------------
 // reductions (fixed tree => bitwise reproducible)
 // ------------------------------------------------------------------------------------------------
+// Cross-lane data movement uses DPP (row-local, a few cycles) and v_readlane (scalar broadcast) instead of
+// ds_bpermute-based __shfl, whose LDS round trip dominated the many small reductions of this solver.
+template <int CTRL>
+__device__ inline double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ inline int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+__device__ inline double lane_bcast(double v, int src_lane) {  // src_lane must be wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 64 lanes, returned to every lane (wave-uniform)
 __device__ inline double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-  return v;
+  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);  // row_half_mirror
+  v += dpp_f64<0x140>(v);  // row_mirror: every lane now holds the sum of its 16-lane row
+  return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+}
+__device__ inline double wave_max(double v) {
+  v = fmax(v, dpp_f64<0xB1>(v));
+  v = fmax(v, dpp_f64<0x4E>(v));
+  v = fmax(v, dpp_f64<0x141>(v));
+  v = fmax(v, dpp_f64<0x140>(v));
+  return fmax(fmax(lane_bcast(v, 0), lane_bcast(v, 16)), fmax(lane_bcast(v, 32), lane_bcast(v, 48)));
 }
 __device__ inline double block_sum(double v, lptr red) {
   v = wave_sum(v);
   __syncthreads();
   if ((TID & 63) == 0) red[TID >> 6] = v;
   __syncthreads();
-  return (red[0] + red[1]) + (red[2] + red[3]);
+  double t = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; w++) t += red[w];
+  return t;
 }
 __device__ inline double block_max(double v, lptr red) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o));
+  v = wave_max(v);
   __syncthreads();
   if ((TID & 63) == 0) red[TID >> 6] = v;
   __syncthreads();
-  return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  double t = red[0];
+#pragma unroll
+  for (int w = 1; w < NT / 64; w++) t = fmax(t, red[w]);
+  return t;
 }
 // minimum with lowest index on ties
+__device__ inline void argmin_pick(double& v, int& idx, double v2, int i2) {
+  if (v2 < v || (v2 == v && i2 < idx)) { v = v2; idx = i2; }
+}
+// (value, index) minimum over the wave, lowest index on ties, result wave-uniform
+__device__ inline void wave_argmin(double& v, int& idx) {
+  argmin_pick(v, idx, dpp_f64<0xB1>(v), dpp_i32<0xB1>(idx));
+  argmin_pick(v, idx, dpp_f64<0x4E>(v), dpp_i32<0x4E>(idx));
+  argmin_pick(v, idx, dpp_f64<0x141>(v), dpp_i32<0x141>(idx));
+  argmin_pick(v, idx, dpp_f64<0x140>(v), dpp_i32<0x140>(idx));
+  double vr = lane_bcast(v, 0); int ir = __builtin_amdgcn_readlane(idx, 0);
+  argmin_pick(vr, ir, lane_bcast(v, 16), __builtin_amdgcn_readlane(idx, 16));
+  argmin_pick(vr, ir, lane_bcast(v, 32), __builtin_amdgcn_readlane(idx, 32));
+  argmin_pick(vr, ir, lane_bcast(v, 48), __builtin_amdgcn_readlane(idx, 48));
+  v = vr; idx = ir;
+}
 __device__ inline void block_argmin(double v, int idx, lptr red, double& vout, int& iout) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    double v2 = __shfl_down(v, o);
-    int i2 = __shfl_down(idx, o);
-    if (v2 < v || (v2 == v && i2 < idx)) { v = v2; idx = i2; }
-  }
+  wave_argmin(v, idx);
   __syncthreads();
-  if ((TID & 63) == 0) { red[TID >> 6] = v; red[8 + (TID >> 6)] = (double)idx; }
+  if ((TID & 63) == 0) { red[TID >> 6] = v; red[32 + (TID >> 6)] = (double)idx; }
   __syncthreads();
-  vout = red[0]; iout = (int)red[8];
-  for (int w = 1; w < 4; w++) {
-    double v2 = red[w]; int i2 = (int)red[8 + w];
+  vout = red[0]; iout = (int)red[32];
+  for (int w = 1; w < NT / 64; w++) {
+    double v2 = red[w]; int i2 = (int)red[32 + w];
     if (v2 < vout || (v2 == vout && i2 < iout)) { vout = v2; iout = i2; }
   }
 }
@@ -363,14 +404,18 @@ __device__ inline double g_row_dot(const DgProb& D, clptr gd, int r, clptr x) {
       const DgDense dd = ld_dense(R.dense);
       clptr p = gd + dd.off;
       const int len = 2 * dd.k;
-      double s = 0;
+      double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
       clptr xa = x + dd.a * D.N * DGSQP_NUA;
-      for (int i = 0; i < len; i++) s += p[i] * xa[i];
+      int i = 0;
+      for (; i + 3 < len; i += 4) { s0 += p[i] * xa[i]; s1 += p[i + 1] * xa[i + 1]; s2 += p[i + 2] * xa[i + 2]; s3 += p[i + 3] * xa[i + 3]; }
+      for (; i < len; i++) s0 += p[i] * xa[i];
       if (dd.kind == 1) {
         clptr xb = x + dd.b * D.N * DGSQP_NUA;
-        for (int i = 0; i < len; i++) s += p[len + i] * xb[i];
+        clptr pb = p + len;
+        for (i = 0; i + 3 < len; i += 4) { s0 += pb[i] * xb[i]; s1 += pb[i + 1] * xb[i + 1]; s2 += pb[i + 2] * xb[i + 2]; s3 += pb[i + 3] * xb[i + 3]; }
+        for (; i < len; i++) s0 += pb[i] * xb[i];
       }
-      return R.sgn * s;
+      return R.sgn * ((s0 + s1) + (s2 + s3));
     }
   }
 }

@@ -12,7 +12,10 @@
 #define DG_NDMAX 512      // distinct dense gradients limit
 #define DG_MAXEFF 8       // effective variables of one agent's dynamics (dyn bicycle: 6 states + 2 inputs)
 #define DG_MAXDIR 36      // MAXEFF*(MAXEFF+1)/2 Taylor directions
-#define DG_BLOCK 256      // threads per scenario workgroup (4 wavefronts)
+#ifndef DG_BLOCK
+#define DG_BLOCK 512      // threads per scenario workgroup (8 wavefronts = 2 per SIMD, to hide LDS latency)
+#endif
+#define DG_NH (DG_BLOCK / 128)  // row-groups of the register-resident matrix slices (thread = column x row-group)
 #define DG_LDS_LIMIT 163840
 
 enum { DG_R_OBS = 0, DG_R_RATE_UB, DG_R_RATE_LB, DG_R_IN_UB, DG_R_IN_LB, DG_R_ST_UB, DG_R_ST_LB };
@@ -42,7 +45,7 @@ struct DgLds {
   // EIG scratch
   int g_Bp, g_V, g_tw;  // packed P / packed Householder reflectors / tridiagonal workspace
   // QP scratch (P shares g_Bp)
-  int p_R, p_lam, p_c, p_w, p_r, p_y, p_z, p_t, p_alist, p_act;
+  int p_R, p_lam, p_c, p_w, p_r, p_y, p_z, p_t, p_alist, p_act, p_part;
   // QP outputs that must survive trial evaluations
   int o_du, o_lhat;
   // LSQR scratch
@@ -182,14 +185,14 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   // EIG: packed P, packed Householder reflectors, tridiagonal workspace
   o = L.scr;
   const int npk = n * (n + 1) / 2;
-  const int rpt = n <= 32 ? 16 : (n <= 64 ? 32 : (n <= 100 ? 50 : 64));
+  const int rpt = (n <= 32 ? 32 : (n <= 64 ? 64 : (n <= 100 ? 100 : 128))) / DG_NH;
   L.g_Bp = take(npk); L.g_V = take(npk);
-  L.g_tw = take(7 * n + 16 + 10 * n /* Z */ + (10 * 3 * n > 3 * (2 * rpt + 4) ? 10 * 3 * n : 3 * (2 * rpt + 4)));
+  L.g_tw = take((5 + DG_NH) * n + 16 + 10 * n /* Z */ + (10 * 3 * n > 3 * (DG_NH * rpt + 4) ? 10 * 3 * n : 3 * (DG_NH * rpt + 4)));
   const int eig_end = o;
   // QP (P aliases Bp)
   o = L.scr + ((npk + 1) & ~1);
   L.p_R = take(npk); L.p_lam = take(n + 1); L.p_c = take(n + 1); L.p_w = take(n + 1); L.p_r = take(n + 1);
-  L.p_y = take(n); L.p_z = take(n); L.p_t = take(n); L.p_alist = take((n + 2) / 2 + 1); L.p_act = take(nc / 8 + 2);
+  L.p_y = take(n); L.p_z = take(n); L.p_t = take(n); L.p_alist = take((n + 2) / 2 + 1); L.p_act = take(nc / 8 + 2); L.p_part = take(DG_NH * n);
   const int qp_end = o;
   // QP outputs live past the end of both the QP and EVAL scratch
   o = qp_end > eval_end ? qp_end : eval_end;

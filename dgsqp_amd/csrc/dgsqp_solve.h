@@ -46,13 +46,14 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
   const DgLds& L = D.L;
   lptr lds = LP(0);
   const int n = D.n;
-  if (n > 2 * RPT || n > 128 || n < 4) return false;
+  if (n > DG_NH * RPT || n > 128 || n < 4) return false;
   lds_d* Rf = lds + L.g_V;   // Householder reflectors, strict lower triangle packed by columns
 #define RFOFF(k) ((k) * (2 * n - (k) - 1) / 2)
   lds_d* Wk = lds + L.g_tw;  // workspace (aliases the packed slot when LDS is tight: P is written there last)
-  lds_d *dv = Wk, *ev = Wk + n, *tau = Wk + 2 * n, *vv = Wk + 3 * n, *pp = Wk + 4 * n /* 2n */, *ww = Wk + 6 * n;
-  lptr lamv = Wk + 7 * n;             // PSD_KMAX (+ pad)
-  lptr Z = Wk + 7 * n + 16;           // PSD_KMAX x n eigenvectors
+  constexpr int NH = DG_NH;
+  lds_d *dv = Wk, *ev = Wk + n, *tau = Wk + 2 * n, *vv = Wk + 3 * n, *pp = Wk + 4 * n /* NH*n */;
+  lptr lamv = Wk + (4 + NH) * n;       // PSD_KMAX (+ pad)
+  lptr Z = Wk + (4 + NH) * n + 16;     // PSD_KMAX x n eigenvectors
   lptr tws = Z + PSD_KMAX * n;        // PSD_KMAX x 3n tridiagonal-solve workspace
   lds_d* red = lds + L.red;
   lds_d* scal = lds + L.scal;
@@ -66,30 +67,28 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
   double Br[RPT];
 #pragma unroll
   for (int r = 0; r < RPT; r++) {
-    const int i = hf + 2 * r;
+    const int i = hf + NH * r;
     Br[r] = (colok && i < n) ? 0.5 * (Qg[(int64_t)i * n + jc] + Qg[(int64_t)jc * n + i]) : 0.0;
   }
   // ---- 2. Householder tridiagonalisation.  vf / wf hold v and w at FULL row index (zero for rows <= k and for the
   //         padding rows >= n), so the per-thread loops below are branch-free and their LDS reads can be batched.
   lptr vf = tws;                 // 2*RPT + 2 entries each, carved from the tridiagonal-solve workspace (unused until 3b)
-  lptr wf = tws + 2 * RPT + 4;
-  lptr cb = tws + 2 * (2 * RPT + 4);  // published column
-  for (int i = TID; i < 2 * RPT + 2; i += NT) { vf[i] = 0.0; wf[i] = 0.0; }
+  lptr wf = tws + NH * RPT + 4;
+  lptr cb = tws + 2 * (NH * RPT + 4);  // published column
+  for (int i = TID; i < NH * RPT + 2; i += NT) { vf[i] = 0.0; wf[i] = 0.0; }
   __syncthreads();
   for (int k = 0; k < n - 2; k++) {
     const int m = n - k - 1;
     if (jc == k) {  // the two owners of column k publish their whole slice (straight-line stores, no per-row predicates)
 #pragma unroll
-      for (int r = 0; r < RPT; r++) cb[hf + 2 * r] = Br[r];
+      for (int r = 0; r < RPT; r++) cb[hf + NH * r] = Br[r];
     }
     __syncthreads();
     if (wave == 0) {
       const double xa = lane < m ? cb[k + 1 + lane] : 0.0, xb = lane + 64 < m ? cb[k + 1 + lane + 64] : 0.0;
       if (lane == 0) dv[k] = cb[k];
-      const double x0 = __shfl(xa, 0);
-      double nrm2 = xa * xa + xb * xb;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) nrm2 += __shfl_xor(nrm2, o);
+      const double x0 = lane_bcast(xa, 0);
+      double nrm2 = wave_sum(xa * xa + xb * xb);
       const double tail2 = nrm2 - x0 * x0;
       double alpha, beta;
       if (!(tail2 > 0.0)) { alpha = x0; beta = 0.0; }
@@ -110,22 +109,25 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
       double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
       for (int r = 0; r + 3 < RPT; r += 4) {
-        s0 += Br[r] * vf[hf + 2 * r];
-        s1 += Br[r + 1] * vf[hf + 2 * r + 2];
-        s2 += Br[r + 2] * vf[hf + 2 * r + 4];
-        s3 += Br[r + 3] * vf[hf + 2 * r + 6];
+        s0 += Br[r] * vf[hf + NH * r];
+        s1 += Br[r + 1] * vf[hf + NH * (r + 1)];
+        s2 += Br[r + 2] * vf[hf + NH * (r + 2)];
+        s3 += Br[r + 3] * vf[hf + NH * (r + 3)];
       }
 #pragma unroll
-      for (int r = RPT & ~3; r < RPT; r++) s0 += Br[r] * vf[hf + 2 * r];
+      for (int r = RPT & ~3; r < RPT; r++) s0 += Br[r] * vf[hf + NH * r];
       if (colok) pp[hf * n + jc] = (s0 + s1) + (s2 + s3);
       __syncthreads();
       if (wave == 0) {
-        const double pa = lane < m ? beta * (pp[k + 1 + lane] + pp[n + k + 1 + lane]) : 0.0;
-        const double pb = lane + 64 < m ? beta * (pp[k + 1 + lane + 64] + pp[n + k + 1 + lane + 64]) : 0.0;
-        const double va = lane < m ? vf[k + 1 + lane] : 0.0, vb = lane + 64 < m ? vf[k + 1 + lane + 64] : 0.0;
-        double pv = pa * va + pb * vb;
+        double pa = 0.0, pb = 0.0;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) pv += __shfl_xor(pv, o);
+        for (int h = 0; h < NH; h++) {
+          if (lane < m) pa += pp[h * n + k + 1 + lane];
+          if (lane + 64 < m) pb += pp[h * n + k + 1 + lane + 64];
+        }
+        pa *= beta; pb *= beta;
+        const double va = lane < m ? vf[k + 1 + lane] : 0.0, vb = lane + 64 < m ? vf[k + 1 + lane + 64] : 0.0;
+        double pv = wave_sum(pa * va + pb * vb);
         const double K = 0.5 * beta * pv;
         if (lane < m) wf[k + 1 + lane] = pa - K * va;
         if (lane + 64 < m) wf[k + 1 + lane + 64] = pb - K * vb;
@@ -134,14 +136,14 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
       {
         const double vj = colok ? vf[jc] : 0.0, wj = colok ? wf[jc] : 0.0;   // zero for columns <= k
 #pragma unroll
-        for (int r = 0; r < RPT; r++) Br[r] -= vf[hf + 2 * r] * wj + wf[hf + 2 * r] * vj;
+        for (int r = 0; r < RPT; r++) Br[r] -= vf[hf + NH * r] * wj + wf[hf + NH * r] * vj;
       }
     }
     __syncthreads();
   }
 #pragma unroll
   for (int r = 0; r < RPT; r++) {
-    const int i = hf + 2 * r;
+    const int i = hf + NH * r;
     if (jc == n - 2 && i == n - 2) dv[n - 2] = Br[r];
     if (jc == n - 1 && i == n - 1) { dv[n - 1] = Br[r]; ev[n - 1] = 0.0; }
     if (jc == n - 2 && i == n - 1) ev[n - 2] = Br[r];
@@ -157,7 +159,7 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
   const double reg = D.par.reg > 0 ? D.par.reg : 0.0;
 #pragma unroll
   for (int r = 0; r < RPT; r++) {
-    const int i = hf + 2 * r;
+    const int i = hf + NH * r;
     double a = 0.0;
     if (colok && i < n) {
       a = 0.5 * (Qg[(int64_t)i * n + jc] + Qg[(int64_t)jc * n + i]);
@@ -168,7 +170,7 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
   for (int j0 = 0; j0 < kneg; j0 += PSD_KMAX) {
     const int kb = kneg - j0 < PSD_KMAX ? kneg - j0 : PSD_KMAX;
     __syncthreads();
-    for (int jj = wave; jj < kb; jj += 4) {
+    for (int jj = wave; jj < kb; jj += NT / 64) {
       const int j = j0 + jj;
       // eigenvalue j (ascending) lies in [lo, hi) with count(lo) <= j < count(hi): 64-way multisection
       double lo = -tnorm * 1.0000001 - 1e-300, hi = 0.0;
@@ -178,8 +180,8 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
         const int cnt = sturm_count(dv, pp, n, sg, pivmin);
         const unsigned long long above = __ballot(cnt > j);
         const int first = above ? __ffsll((long long)above) - 1 : 64;
-        const double nlo = first == 0 ? lo : __shfl(sg, first - 1);
-        const double nhi = first == 64 ? hi : __shfl(sg, first);
+        const double nlo = first == 0 ? lo : lane_bcast(sg, first - 1);
+        const double nhi = first == 64 ? hi : lane_bcast(sg, first);
         lo = nlo; hi = nhi;
         if (hi - lo <= 4.5e-16 * fmax(fabs(lo), fabs(hi)) + 1e-300) break;
       }
@@ -232,14 +234,10 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
         double za = lane < n ? Z[j * n + lane] : 0.0, zb = lane + 64 < n ? Z[j * n + lane + 64] : 0.0;
         for (int i = 0; i < j; i++) {
           const double ya = lane < n ? Z[i * n + lane] : 0.0, yb = lane + 64 < n ? Z[i * n + lane + 64] : 0.0;
-          double dt = za * ya + zb * yb;
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) dt += __shfl_xor(dt, o);
+          double dt = wave_sum(za * ya + zb * yb);
           za -= dt * ya; zb -= dt * yb;
         }
-        double nr = za * za + zb * zb;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) nr += __shfl_xor(nr, o);
+        double nr = wave_sum(za * za + zb * zb);
         nr = 1.0 / sqrt(nr);
         za *= nr; zb *= nr;
         if (lane < n) Z[j * n + lane] = za;
@@ -247,16 +245,14 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
       }
     }
     __syncthreads();
-    for (int j = wave; j < kb; j += 4) {
+    for (int j = wave; j < kb; j += NT / 64) {
       double za = lane < n ? Z[j * n + lane] : 0.0, zb = lane + 64 < n ? Z[j * n + lane + 64] : 0.0;
       for (int k = n - 3; k >= 0; k--) {
         const double beta = tau[k];
         if (beta == 0.0) continue;
         const double va = (lane > k && lane < n) ? Rf[RFOFF(k) + lane - k - 1] : 0.0;
         const double vb = (lane + 64 > k && lane + 64 < n) ? Rf[RFOFF(k) + lane + 64 - k - 1] : 0.0;
-        double dt = va * za + vb * zb;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) dt += __shfl_xor(dt, o);
+        double dt = wave_sum(va * za + vb * zb);
         dt *= beta;
         za -= dt * va; zb -= dt * vb;
       }
@@ -267,7 +263,7 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
     // ---- 4b. M += sum_j (1e-10 - lam_j) v_j v_j^T   (== U diag(s') U^T of DGSQP.py:1290-1296 on the negative part)
 #pragma unroll
     for (int r = 0; r < RPT; r++) {
-      const int i = hf + 2 * r;
+      const int i = hf + NH * r;
       if (colok && i < n) {
         double a = Br[r];
         for (int j = 0; j < kb; j++) a += (1e-10 - lamv[j]) * Z[j * n + i] * Z[j * n + jc];
@@ -278,7 +274,7 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
   if (Qpd) {
 #pragma unroll
     for (int r = 0; r < RPT; r++) {
-      const int i = hf + 2 * r;
+      const int i = hf + NH * r;
       if (colok && i < n) Qpd[i * n + jc] = Br[r];
     }
   }
@@ -286,13 +282,13 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
   PROF_END(PH_JACOBI, pt_t);
   PROF_BEGIN(pt_s);
   // ---- 5. symmetric Gauss-Jordan sweep in registers: after all pivots the slice holds -M^-1
-  lptr colk = tws;  // 2*RPT + 2 entries; padding rows stay zero
-  for (int i = TID; i < 2 * RPT + 2; i += NT) colk[i] = 0.0;
+  lptr colk = tws;  // NH*RPT + 2 entries; padding rows stay zero
+  for (int i = TID; i < NH * RPT + 2; i += NT) colk[i] = 0.0;
   __syncthreads();
   for (int k = 0; k < n; k++) {
     if (jc == k) {
 #pragma unroll
-      for (int r = 0; r < RPT; r++) colk[hf + 2 * r] = Br[r];   // padding rows hold exact zeros
+      for (int r = 0; r < RPT; r++) colk[hf + NH * r] = Br[r];   // padding rows hold exact zeros
     }
     __syncthreads();
     const double dinv = 1.0 / colk[k];
@@ -303,10 +299,10 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
     //   general  a_ij - a_ik a_kj/d ;  column k  a_ik/d ;  row k  a_kj/d ;  pivot -1/d
     double ci[RPT];
 #pragma unroll
-    for (int r = 0; r < RPT; r++) ci[r] = colk[hf + 2 * r];
+    for (int r = 0; r < RPT; r++) ci[r] = colk[hf + NH * r];
 #pragma unroll
     for (int r = 0; r < RPT; r++) {
-      const bool onrow = (hf + 2 * r) == k;
+      const bool onrow = (hf + NH * r) == k;
       double base = pc ? ci[r] * dinv : Br[r];
       base = onrow ? rowv : base;
       const double mult = (pc || onrow) ? 0.0 : ci[r];
@@ -317,7 +313,7 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
   lds_d* Pp = lds + L.g_Bp;
 #pragma unroll
   for (int r = 0; r < RPT; r++) {
-    const int i = hf + 2 * r;
+    const int i = hf + NH * r;
     if (colok && i < n && i >= jc) Pp[i * (i + 1) / 2 + jc] = -Br[r];
   }
   __syncthreads();
@@ -328,25 +324,50 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
 __device__ inline void dev_psd_inverse(const Ctx& c, gptr Qpd) {
   const int n = dg_prob.n;
   bool ok;
-  if (n <= 32) ok = dev_psd_inverse_tridiag<16>(c, Qpd);
-  else if (n <= 64) ok = dev_psd_inverse_tridiag<32>(c, Qpd);
-  else if (n <= 100) ok = dev_psd_inverse_tridiag<50>(c, Qpd);
-  else ok = dev_psd_inverse_tridiag<64>(c, Qpd);
+  if (n <= 32) ok = dev_psd_inverse_tridiag<32 / DG_NH>(c, Qpd);
+  else if (n <= 64) ok = dev_psd_inverse_tridiag<64 / DG_NH>(c, Qpd);
+  else if (n <= 100) ok = dev_psd_inverse_tridiag<100 / DG_NH>(c, Qpd);
+  else ok = dev_psd_inverse_tridiag<128 / DG_NH>(c, Qpd);
   (void)ok;  // n <= 128 is enforced by dgsqp_create
 }
 
-// out = P t  (P packed symmetric in LDS)
+// out = scale * P t  (P packed symmetric in LDS).  Every row is split over NSEG threads, each with four independent
+// accumulators so that the LDS reads of a segment are in flight together; the partial sums meet in LDS.
 __device__ inline void dev_p_mul(const Ctx& c, clptr t, lptr out, double scale) {
   const DgProb& D = dg_prob;
-  const lds_d* Pp = LP(0) + D.L.g_Bp;
+  clptr Pp = LP(D.L.g_Bp);
+  lptr part = LP(D.L.p_part);  // NSEG x n partial sums
   const int n = D.n;
+  constexpr int NSEG = NT / 128;
+  const int i = TID & 127, sg = TID >> 7;
   __syncthreads();
-  for (int i = TID; i < n; i += NT) {
-    double s = 0;
+  if (i < n) {
+    const int len = (n + NSEG - 1) / NSEG;
+    const int j0 = sg * len, j1 = (j0 + len < n) ? j0 + len : n;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    // columns j <= i come from row i of the packed lower triangle (contiguous), j > i from column i (stride j)
+    const int split = (i + 1 < j1) ? ((i + 1 > j0) ? i + 1 : j0) : j1;
     clptr row = Pp + i * (i + 1) / 2;
-    for (int j = 0; j <= i; j++) s += row[j] * t[j];
-    for (int j = i + 1; j < n; j++) s += Pp[j * (j + 1) / 2 + i] * t[j];
-    out[i] = scale * s;
+    int j = j0;
+    for (; j + 3 < split; j += 4) {
+      a0 += row[j] * t[j]; a1 += row[j + 1] * t[j + 1]; a2 += row[j + 2] * t[j + 2]; a3 += row[j + 3] * t[j + 3];
+    }
+    for (; j < split; j++) a0 += row[j] * t[j];
+    for (; j + 3 < j1; j += 4) {
+      a0 += Pp[j * (j + 1) / 2 + i] * t[j];
+      a1 += Pp[(j + 1) * (j + 2) / 2 + i] * t[j + 1];
+      a2 += Pp[(j + 2) * (j + 3) / 2 + i] * t[j + 2];
+      a3 += Pp[(j + 3) * (j + 4) / 2 + i] * t[j + 3];
+    }
+    for (; j < j1; j++) a0 += Pp[j * (j + 1) / 2 + i] * t[j];
+    part[sg * n + i] = (a0 + a1) + (a2 + a3);
+  }
+  __syncthreads();
+  if (TID < n) {
+    double s = 0;
+#pragma unroll
+    for (int g = 0; g < NSEG; g++) s += part[g * n + TID];
+    out[TID] = scale * s;
   }
   __syncthreads();
 }
@@ -383,20 +404,18 @@ __device__ inline double qp_wave_solve(clptr R, int m, int lane, clptr cvec, lpt
   double c0 = lane < m ? cvec[lane] : 0.0, c1 = lane + 64 < m ? cvec[lane + 64] : 0.0;
   double w0 = 0, w1 = 0;
   for (int i = 0; i < m; i++) {
-    const double ci = __shfl(i < 64 ? c0 : c1, i & 63);
+    const double ci = lane_bcast(i < 64 ? c0 : c1, i & 63);
     const double wi = ci / R[tri(i, i)];
     if (lane == (i & 63)) { if (i < 64) w0 = wi; else w1 = wi; }
     if (lane > i && lane < m) c0 -= R[tri(lane, i)] * wi;
     if (lane + 64 > i && lane + 64 < m) c1 -= R[tri(lane + 64, i)] * wi;
   }
-  double ww = w0 * w0 + w1 * w1;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) ww += __shfl_xor(ww, o);
+  const double ww = wave_sum(w0 * w0 + w1 * w1);
   if (lane < m) wv[lane] = w0;
   if (lane + 64 < m) wv[lane + 64] = w1;
   double r0 = 0, r1 = 0;
   for (int j = m - 1; j >= 0; j--) {
-    const double wj = __shfl(j < 64 ? w0 : w1, j & 63);
+    const double wj = lane_bcast(j < 64 ? w0 : w1, j & 63);
     const double rj = wj / R[tri(j, j)];
     if (lane == (j & 63)) { if (j < 64) r0 = rj; else r1 = rj; }
     if (lane < j) w0 -= R[tri(j, lane)] * rj;
@@ -445,6 +464,7 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
   const int max_outer = 4 * (n + nc);
   for (int iter = 0; iter < max_outer; iter++) {
     // ---- step 1: most violated inactive constraint (lowest index on ties)
+    PROF_BEGIN(pq1);
     double best = -TOL;
     int bi = NONE;
     for (int r = TID; r < nc; r += NT) {
@@ -454,17 +474,24 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
     }
     double bv; int p;
     block_argmin(best, bi, red, bv, p);
+    PROF_END(PH_Q_SCAN, pq1);
     if (p == NONE) { ret = 0; break; }
+    PROF_BEGIN(pq2);
+#ifdef DG_PROF
+    if (TID == 0) { atomicAdd(&dg_prof[2 * PH_SWEEP], 1ULL); }
+#endif
     for (int col = TID; col < n; col += NT) tv[col] = g_row_coef(D, gd, p, col);
     dev_p_mul(c, tv, y, 1.0);  // y = P a_p
     double part = 0, part2 = 0;
     for (int i = TID; i < n; i += NT) { part += tv[i] * y[i]; part2 += tv[i] * tv[i]; }
     const double app = block_sum(part, red);
     const double apap = block_sum(part2, red);
+    PROF_END(PH_Q_Y, pq2);
     double lp = 0.0;
     bool infeasible = false;
     for (int inner = 0; inner < 4 * (n + nc); inner++) {
       // ---- step 2a: directions.  c = A_A y ; R^T w = c ; r = R^-1 w
+      PROF_BEGIN(pq3);
       for (int j = TID; j < m; j += NT) cvec[j] = g_row_dot(D, gd, alist[j], y);
       double pv = 0;
       for (int i = TID; i < n; i += NT) pv += tv[i] * x[i];
@@ -476,11 +503,7 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
         double t1 = INFINITY; int jd = NONE;
         if (lane < m && r0 > 0) { t1 = lam[lane] / r0; jd = lane; }
         if (lane + 64 < m && r1 > 0) { const double tt = lam[lane + 64] / r1; if (tt < t1) { t1 = tt; jd = lane + 64; } }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const double t2 = __shfl_xor(t1, o); const int j2 = __shfl_xor(jd, o);
-          if (t2 < t1 || (t2 == t1 && j2 < jd)) { t1 = t2; jd = j2; }
-        }
+        wave_argmin(t1, jd);
         if (lane == 0) {
           const double delta = app - ww;  // a_p^T (P - P A^T S^-1 A P) a_p >= 0
           const bool indep = delta > 1e-11 * app && delta > 1e-18 * apap;
@@ -493,6 +516,8 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
         }
       }
       __syncthreads();
+      PROF_END(PH_Q_DIR, pq3);
+      PROF_BEGIN(pq4);
       const double t = scal[0];
       const int jd = (int)scal[1];
       const double delta = scal[2];
@@ -512,15 +537,21 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
       for (int j = TID; j < m; j += NT) lam[j] -= t * rv[j];
       lp += t;
       __syncthreads();
+      PROF_END(PH_Q_STEP, pq4);
+      PROF_BEGIN(pq5);
       if (!dual_only && !partial) {
         // ---- full step: constraint p becomes active, append column [w ; sqrt(delta)] to R
         for (int i = TID; i < m; i += NT) R[tri(m, i)] = wv[i];
         if (TID == 0) { R[tri(m, m)] = sqrt(delta); alist[m] = p; lam[m] = lp; act[p] = 1; }
         m++;
         __syncthreads();
+        PROF_END(PH_Q_UPD, pq5);
         break;
       }
       // ---- partial / dual-only step: drop blocking constraint jd (column deletion + Givens)
+#ifdef DG_PROF
+      if (TID == 0) { atomicAdd(&dg_prof[2 * PH_SWEEP + 1], 1ULL); }
+#endif
       if (TID < 64) {
         const int mn = m - 1;
         const int ca = lane, cb = lane + 64;
@@ -543,8 +574,8 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
         for (int k = jd; k < mn; k++) {
           double dk = 0;
           if (lane == (k & 63)) dk = R[tri(k, k)];
-          dk = __shfl(dk, k & 63);
-          const double sub = __shfl(k < 64 ? suba : subb, k & 63);
+          dk = lane_bcast(dk, k & 63);
+          const double sub = lane_bcast(k < 64 ? suba : subb, k & 63);
           const double h = hypot(dk, sub);
           const double cs = h > 0 ? dk / h : 1.0, sn = h > 0 ? sub / h : 0.0;
           if (lane == (k & 63)) R[tri(k, k)] = h;
@@ -564,6 +595,7 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
       }
       m--;
       __syncthreads();
+      PROF_END(PH_Q_UPD, pq5);
     }
     if (infeasible) { ret = 1; break; }
   }
@@ -572,6 +604,7 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
   // P is an explicit inverse, so the active rows hold to ~1e-12 only; two projection steps
   //   x <- x - P A^T S^-1 (A x - b),  lam <- lam + S^-1 (A x - b)
   // bring them to rounding level.
+  PROF_BEGIN(pq6);
   if (ret == 0 && m > 0) {
     for (int pass = 0; pass < 2; pass++) {
       for (int j = TID; j < m; j += NT) cvec[j] = g[alist[j]] + g_row_dot(D, gd, alist[j], x);
@@ -589,6 +622,7 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
       __syncthreads();
     }
   }
+  PROF_END(PH_Q_REFINE, pq6);
   for (int r = TID; r < nc; r += NT) lhat[r] = 0.0;
   __syncthreads();
   if (ret == 0)

@@ -16,9 +16,9 @@ for rep in range(2):
 import ctypes, os
 lib = s._lib
 if hasattr(lib, 'dgsqp_prof_read'):
-    buf = (ctypes.c_ulonglong * 32)()
-    nph = lib.dgsqp_prof_read(buf, 32)
-    names = ['rollout', 'deriv1', 'deriv2', 'chains', 'dp', 'jacobi', 'pform', 'qp', 'merit', 'lsqr', 'qtmul', 'sweep', 'wgtotal', 'wgmax(clk,wall100MHz)']
+    buf = (ctypes.c_ulonglong * 64)()
+    nph = lib.dgsqp_prof_read(buf, 64)
+    names = ['rollout', 'deriv1', 'deriv2', 'chains', 'dp', 'jacobi', 'pform', 'qp', 'merit', 'lsqr', 'qtmul', 'gi_adds/drops', 'wgtotal', 'wgmax(clk,wall100MHz)', 'q_scan', 'q_y', 'q_dir', 'q_step', 'q_upd', 'q_refine']
     tot = sum(buf[2 * i] for i in range(nph))
     for i in range(nph):
         if buf[2 * i + 1]:
