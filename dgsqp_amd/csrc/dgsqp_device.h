@@ -54,6 +54,14 @@ __device__ inline void dev_load_tables() {
   const unsigned long long* sd = (const unsigned long long*)D.dense;
   for (int r = threadIdx.x; r < D.nc; r += DG_BLOCK) tr[r] = sr[r];
   for (int d = threadIdx.x; d < 2 * D.ndense; d += DG_BLOCK) td[d] = sd[d];
+  lptr tt = LP(D.L.t_track);
+  constexpr int S1 = DGSQP_MAX_SEGS + 1;
+  for (int i = threadIdx.x; i < S1; i += DG_BLOCK) {
+    tt[i] = i <= D.P.n_segs ? D.P.seg_s[i] : 1e300;
+    tt[S1 + i] = i < D.P.n_segs ? D.P.seg_curv[i] : 0.0;
+    tt[2 * S1 + i] = i <= D.P.n_segs ? D.P.seg_ang[i] : 0.0;
+    tt[3 * S1 + i] = i < D.P.n_segs ? (D.P.seg_ang[i + 1] - D.P.seg_ang[i]) / (D.P.seg_s[i + 1] - D.P.seg_s[i]) : 0.0;
+  }
   __syncthreads();
 }
 
@@ -256,15 +264,25 @@ template <int DEG> __device__ inline Ty<DEG> ty_abs(const Ty<DEG>& a) { return a
 // ------------------------------------------------------------------------------------------------
 // track tables (radius_arclength_track.py:199-225): curvature piecewise constant, tangent piecewise linear
 // ------------------------------------------------------------------------------------------------
+// sbar = fmod(fmod(s, L) + L, L) for |s| < 2^40 L: one exact remainder step per fmod (s - L*trunc(s/L) is exact in fp64
+// when the quotient is small), cheaper than the generic OCML loop.
+__device__ inline double wrap_s(double s, double L) {
+  double r = s - L * trunc(s / L);      // fmod(s, L): sign of s, |r| < L (up to one ulp of the quotient)
+  if (r >= L) r -= L; else if (r <= -L) r += L;
+  r += L;
+  r = r - L * trunc(r / L);
+  if (r >= L) r -= L;
+  return r;
+}
 template <int DEG>
 __device__ inline void dev_track(const dgsqp_problem_t& P, const Ty<DEG>& s, double& curv, Ty<DEG>& psi) {
-  const double L = P.track_L;
-  const double sbar = fmod(fmod(s.c[0], L) + L, L);
+  constexpr int S1 = DGSQP_MAX_SEGS + 1;
+  clptr tt = LP(dg_prob.L.t_track);
+  const double sbar = wrap_s(s.c[0], P.track_L);
   int seg = 0;
-  for (int i = 1; i < P.n_segs; i++) seg += (sbar >= P.seg_s[i]) ? 1 : 0;
-  curv = P.seg_curv[seg];
-  const double slope = (P.seg_ang[seg + 1] - P.seg_ang[seg]) / (P.seg_s[seg + 1] - P.seg_s[seg]);
-  psi = (s + (sbar - s.c[0] - P.seg_s[seg])) * slope + P.seg_ang[seg];
+  for (int i = 1; i < P.n_segs; i++) seg += (sbar >= tt[i]) ? 1 : 0;
+  curv = tt[S1 + seg];
+  psi = (s + (sbar - s.c[0] - tt[seg])) * tt[3 * S1 + seg] + tt[2 * S1 + seg];
 }
 
 // kinematic bicycle in the Frenet frame (dynamics_models.py:1046-1070); q = [x,y,v,e_psi,s,e_y], u = [a, delta]

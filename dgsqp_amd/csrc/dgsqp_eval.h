@@ -87,12 +87,109 @@ __device__ inline void dev_rollout_agent(const DgProb& D, int a, clptr ue, lptr 
     for (int i = 0; i < NQA; i++) { q[i] = qn[i]; x[(k + 1) * nq + qo + i] = qn[i].c[0]; }
   }
 }
+// Dynamic-bicycle rollout on TWO lanes per agent.  The 40 f_c evaluations of one rk4 step (M = 10) are sequential and
+// each costs ~9 fp64 transcendental calls; the front / rear tyre chains (atan2 -> atan -> sin) and the two angle sincos
+// are the same instruction stream on different data, so lane 2a handles (front axle, e_psi) and lane 2a+1 (rear axle,
+// e_psi + psi_t); results are exchanged inside the quad with DPP.  sincos(delta) is constant over the step and hoisted.
+// Same arithmetic as dev_fc_dyn<0> (dynamics_models.py:2008-2062), evaluated redundantly on both lanes otherwise.
+__device__ inline void dyn_fc_pair(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, int role, const double* q, double ua, double us,
+                                   double sd, double cd, double* dq) {
+  const double vx = q[2], vy = q[3], w = q[4];
+  constexpr int S1 = DGSQP_MAX_SEGS + 1;
+  clptr tt = LP(dg_prob.L.t_track);
+  const double sbar = wrap_s(q[6], P.track_L);
+  int seg = 0;
+  for (int i = 1; i < P.n_segs; i++) seg += (sbar >= tt[i]) ? 1 : 0;
+  const double c = tt[S1 + seg];
+  const double psit = (q[6] + (sbar - q[6] - tt[seg])) * tt[3 * S1 + seg] + tt[2 * S1 + seg];
+  const double vyf = vy + w * ag.L_f;
+  // role 0: front axle and e_psi ; role 1: rear axle and e_psi + psi_t
+  double ay_, ax_, add;
+  if (role == 0) {
+    if (ag.simple_slip) { ay_ = vyf; ax_ = vx; add = us; } else { ay_ = vyf * cd - vx * sd; ax_ = vx * cd + vyf * sd; add = 0.0; }
+  } else { ay_ = vy - w * ag.L_r; ax_ = vx; add = 0.0; }
+  const double alpha = add - atan2(ay_, ax_);
+  double F;
+  if (ag.tire_model == 0) {
+    const double Bc = role == 0 ? ag.pac_Bf : ag.pac_Br, Cc = role == 0 ? ag.pac_Cf : ag.pac_Cr, Dc = role == 0 ? ag.pac_Df : ag.pac_Dr;
+    F = Dc * sin(Cc * atan(Bc * alpha));
+  } else {
+    F = alpha * (role == 0 ? ag.lin_Bf * ag.mass * ag.gravity * ag.L_r / (ag.L_f + ag.L_r) : ag.lin_Br * ag.mass * ag.gravity * ag.L_f / (ag.L_f + ag.L_r));
+  }
+  double sa, ca;
+  sincos(role == 0 ? q[5] : q[5] + psit, &sa, &ca);
+  // exchange inside the pair: quad_perm [0,0,2,2] takes the even lane's value, [1,1,3,3] the odd lane's
+  const double fyf = dpp_f64<0xA0>(F), fyr = dpp_f64<0xF5>(F);
+  const double se = dpp_f64<0xA0>(sa), ce = dpp_f64<0xA0>(ca), st = dpp_f64<0xF5>(sa), ct = dpp_f64<0xF5>(ca);
+  double Fx = vx * (-ag.c_da) - vx * (vx > 0 ? vx : -vx) * ag.c_dr;
+  if (ag.c_r != 0.0) Fx = Fx - pow(vx > 0 ? vx : -vx, ag.p_r) * (vx / sqrt(vx * vx + 1e-6)) * ag.c_r;
+  const double a_r = ag.drive_wheels == 0 ? ua * 0.5 : ua, a_f = ag.drive_wheels == 0 ? ua * 0.5 : 0.0;
+  const double ax = a_r + a_f * cd + (Fx - fyf * sd) * (1.0 / ag.mass);
+  const double ay = a_f * sd + (fyf * cd + fyr) * (1.0 / ag.mass);
+  const double vlon = (vx * ce - vy * se) * (1.0 / (1.0 - q[7] * c));
+  dq[0] = vx * ct - vy * st;
+  dq[1] = vy * ct + vx * st;
+  dq[2] = ax + w * vy;
+  dq[3] = ay - w * vx;
+  dq[4] = (fyf * cd * ag.L_f - fyr * ag.L_r) * (1.0 / ag.I_z);
+  dq[5] = w - vlon * c;
+  dq[6] = vlon;
+  dq[7] = vx * se + vy * ce;
+}
+__device__ inline void dev_rollout_dyn_pair(const DgProb& D, int a, int role, clptr ue, lptr x) {
+  const dgsqp_problem_t& P = D.P;
+  const dgsqp_agent_t& ag = P.agents[a];
+  const int nq = D.nq, qo = D.qoff[a];
+  double q[8], k1[8], k2[8], k3[8], t[8];
+  for (int i = 0; i < 8; i++) q[i] = x[qo + i];
+  const double h = P.dt / P.substeps;
+  for (int k = 0; k < D.N; k++) {
+    const double ua = ue[am_col(D, a, k, 0)], us = ue[am_col(D, a, k, 1)];
+    double sd, cd;
+    sincos(us, &sd, &cd);
+    if (P.integrator == DGSQP_INT_EULER) {
+      dyn_fc_pair(P, ag, role, q, ua, us, sd, cd, k1);
+      for (int i = 0; i < 8; i++) q[i] = q[i] + k1[i] * P.dt;
+    } else {
+      for (int m = 0; m < P.substeps; m++) {
+        if (P.integrator == DGSQP_INT_RK4) {
+          dyn_fc_pair(P, ag, role, q, ua, us, sd, cd, k1);
+          for (int i = 0; i < 8; i++) t[i] = q[i] + k1[i] * (h / 2);
+          dyn_fc_pair(P, ag, role, t, ua, us, sd, cd, k2);
+          for (int i = 0; i < 8; i++) { t[i] = q[i] + k2[i] * (h / 2); k1[i] = k1[i] + k2[i] * 2.0; }
+          dyn_fc_pair(P, ag, role, t, ua, us, sd, cd, k3);
+          for (int i = 0; i < 8; i++) { t[i] = q[i] + k3[i] * h; k1[i] = k1[i] + k3[i] * 2.0; }
+          dyn_fc_pair(P, ag, role, t, ua, us, sd, cd, k2);
+          for (int i = 0; i < 8; i++) q[i] = q[i] + (k1[i] + k2[i]) * h / 6.0;
+        } else if (P.integrator == DGSQP_INT_RK3) {
+          dyn_fc_pair(P, ag, role, q, ua, us, sd, cd, k1);
+          for (int i = 0; i < 8; i++) { k1[i] = k1[i] * h; t[i] = q[i] + k1[i] * 0.5; }
+          dyn_fc_pair(P, ag, role, t, ua, us, sd, cd, k2);
+          for (int i = 0; i < 8; i++) { k2[i] = k2[i] * h; t[i] = q[i] - k1[i] + k2[i] * 2.0; }
+          dyn_fc_pair(P, ag, role, t, ua, us, sd, cd, k3);
+          for (int i = 0; i < 8; i++) q[i] = q[i] + (k1[i] + k2[i] * 4.0 + k3[i] * h) / 6.0;
+        } else {
+          dyn_fc_pair(P, ag, role, q, ua, us, sd, cd, k1);
+          for (int i = 0; i < 8; i++) t[i] = q[i] + k1[i] * h;
+          dyn_fc_pair(P, ag, role, t, ua, us, sd, cd, k2);
+          for (int i = 0; i < 8; i++) q[i] = q[i] + (k1[i] + k2[i]) * (h / 2);
+        }
+      }
+    }
+    if (role == 0)
+      for (int i = 0; i < 8; i++) x[(k + 1) * nq + qo + i] = q[i];
+  }
+}
 __device__ __noinline__ void dev_rollout(const Ctx& c, clptr ue, lptr x) {
   const DgProb& D = dg_prob;
   __syncthreads();
   for (int i = TID; i < D.nq; i += NT) x[i] = c.x0[i];
   __syncthreads();
-  if (TID < D.M) {
+  bool all_dyn = true;
+  for (int a = 0; a < D.M; a++) all_dyn = all_dyn && D.nqa[a] == 8;
+  if (all_dyn) {
+    if (TID < 2 * D.M) dev_rollout_dyn_pair(D, TID >> 1, TID & 1, ue, x);
+  } else if (TID < D.M) {
     if (D.nqa[TID] == 8) dev_rollout_agent<8>(D, TID, ue, x); else dev_rollout_agent<6>(D, TID, ue, x);
   }
   __syncthreads();

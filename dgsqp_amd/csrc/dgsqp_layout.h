@@ -39,6 +39,7 @@ struct DgLds {
   // persistent
   int u, l, q, g, d, v, gd, yd, red, scal;
   int t_rows, t_dense;  // LDS copies of the row / dense-gradient tables (8 and 16 bytes per entry)
+  int t_track;          // LDS copy of the track tables: seg_s[17], seg_curv[16], seg_ang[17], slope[16]
   int scr;  // start of phase scratch
   // EVAL scratch (absolute offsets)
   int e_x, e_ue, e_A[DGSQP_MAX_AGENTS], e_B[DGSQP_MAX_AGENTS], e_dJ, e_Dx, e_Dxx, e_nDxx, e_tQA, e_tQB, e_A1, e_A2, e_Dxu, e_Hc, e_cv, e_inj;
@@ -171,7 +172,7 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
   L.u = take(n); L.l = take(nc); L.q = take(n); L.g = take(nc); L.d = take(n); L.v = take(n);
   L.gd = take(D.ngd); L.yd = take(nd); L.red = take(64); L.scal = take(64);
-  L.t_rows = take(nc); L.t_dense = take(2 * nd);
+  L.t_rows = take(nc); L.t_dense = take(2 * nd); L.t_track = take(4 * (DGSQP_MAX_SEGS + 1));
   L.scr = o;
   // EVAL
   o = L.scr;
