@@ -70,76 +70,92 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
     const int i = hf + NH * r;
     Br[r] = (colok && i < n) ? 0.5 * (Qg[(int64_t)i * n + jc] + Qg[(int64_t)jc * n + i]) : 0.0;
   }
-  // ---- 2. Householder tridiagonalisation.  vf / wf hold v and w at FULL row index (zero for rows <= k and for the
-  //         padding rows >= n), so the per-thread loops below are branch-free and their LDS reads can be batched.
-  lptr vf = tws;                 // 2*RPT + 2 entries each, carved from the tridiagonal-solve workspace (unused until 3b)
-  lptr wf = tws + NH * RPT + 4;
-  lptr cb = tws + 2 * (NH * RPT + 4);  // published column
-  for (int i = TID; i < NH * RPT + 2; i += NT) { vf[i] = 0.0; wf[i] = 0.0; }
+  // ---- 2. Householder tridiagonalisation, three barriers per step.  Every wavefront derives alpha / beta / K
+  //         redundantly from the published column (no serial wave-0 sections); v is the published column masked to
+  //         rows > k (with v_{k+1} = x_{k+1} - alpha), w is shared through wf at FULL row index (zero for rows <= k
+  //         and the padding rows), so the per-thread loops are branch-free and their LDS reads are batched.
+  lptr wf = tws;                        // NH*RPT + 4
+  lptr cb0 = tws + (NH * RPT + 4);      // published column, double buffered
+  lptr cb1 = tws + 2 * (NH * RPT + 4);
+  for (int i = TID; i < NH * RPT + 4; i += NT) { wf[i] = 0.0; cb0[i] = 0.0; cb1[i] = 0.0; }
+  __syncthreads();
+  if (jc == 0) {
+#pragma unroll
+    for (int r = 0; r < RPT; r++) cb0[hf + NH * r] = Br[r];
+  }
   __syncthreads();
   for (int k = 0; k < n - 2; k++) {
     const int m = n - k - 1;
-    if (jc == k) {  // the two owners of column k publish their whole slice (straight-line stores, no per-row predicates)
-#pragma unroll
-      for (int r = 0; r < RPT; r++) cb[hf + NH * r] = Br[r];
+    clptr cb = (k & 1) ? cb1 : cb0;
+    lptr cbn = (k & 1) ? cb0 : cb1;
+    // -- every wave: x = cb[k+1..n-1]; alpha = -sign(x0)|x|; v = x - alpha e1; beta = 2 / v^T v
+    const double xa = lane < m ? cb[k + 1 + lane] : 0.0, xb = lane + 64 < m ? cb[k + 1 + lane + 64] : 0.0;
+    const double x0 = lane_bcast(xa, 0);
+    const double nrm2 = wave_sum(xa * xa + xb * xb);
+    const double tail2 = nrm2 - x0 * x0;
+    double alpha, beta;
+    if (!(tail2 > 0.0)) { alpha = x0; beta = 0.0; }
+    else {
+      alpha = x0 >= 0 ? -sqrt(nrm2) : sqrt(nrm2);
+      const double v0 = x0 - alpha;
+      beta = 2.0 / (tail2 + v0 * v0);
     }
-    __syncthreads();
+    const double dshift = beta != 0.0 ? alpha : 0.0;   // v_{k+1} = x_{k+1} - dshift
     if (wave == 0) {
-      const double xa = lane < m ? cb[k + 1 + lane] : 0.0, xb = lane + 64 < m ? cb[k + 1 + lane + 64] : 0.0;
-      if (lane == 0) dv[k] = cb[k];
-      const double x0 = lane_bcast(xa, 0);
-      double nrm2 = wave_sum(xa * xa + xb * xb);
-      const double tail2 = nrm2 - x0 * x0;
-      double alpha, beta;
-      if (!(tail2 > 0.0)) { alpha = x0; beta = 0.0; }
-      else {
-        alpha = x0 >= 0 ? -sqrt(nrm2) : sqrt(nrm2);
-        const double v0 = x0 - alpha;
-        beta = 2.0 / (tail2 + v0 * v0);
-      }
-      const double va = (lane == 0 && beta != 0.0) ? xa - alpha : xa;
-      if (lane < m) { vf[k + 1 + lane] = va; Rf[RFOFF(k) + lane] = va; }
-      if (lane + 64 < m) { vf[k + 1 + lane + 64] = xb; Rf[RFOFF(k) + lane + 64] = xb; }
-      if (lane == 0) { vf[k] = 0.0; wf[k] = 0.0; ev[k] = alpha; tau[k] = beta; scal[8] = beta; }
+      const double va = lane == 0 ? xa - dshift : xa;
+      if (lane < m) Rf[RFOFF(k) + lane] = va;
+      if (lane + 64 < m) Rf[RFOFF(k) + lane + 64] = xb;
+      if (lane == 0) { dv[k] = cb[k]; ev[k] = alpha; tau[k] = beta; }
     }
-    __syncthreads();
-    const double beta = scal[8];
-    if (beta != 0.0) {
+    if (beta != 0.0) {   // wave-uniform (all waves computed the same beta)
       // p_j = sum_i B[i][j] v_i over this thread's rows (B symmetric => column sums give the matvec)
       double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
-      for (int r = 0; r + 3 < RPT; r += 4) {
-        s0 += Br[r] * vf[hf + NH * r];
-        s1 += Br[r + 1] * vf[hf + NH * (r + 1)];
-        s2 += Br[r + 2] * vf[hf + NH * (r + 2)];
-        s3 += Br[r + 3] * vf[hf + NH * (r + 3)];
+      for (int r = 0; r < RPT; r++) {
+        const int i = hf + NH * r;
+        double vi = cb[i];
+        vi = (i == k + 1) ? vi - dshift : vi;
+        vi = (i > k) ? vi : 0.0;
+        if ((r & 3) == 0) s0 += Br[r] * vi; else if ((r & 3) == 1) s1 += Br[r] * vi; else if ((r & 3) == 2) s2 += Br[r] * vi; else s3 += Br[r] * vi;
       }
-#pragma unroll
-      for (int r = RPT & ~3; r < RPT; r++) s0 += Br[r] * vf[hf + NH * r];
       if (colok) pp[hf * n + jc] = (s0 + s1) + (s2 + s3);
-      __syncthreads();
-      if (wave == 0) {
-        double pa = 0.0, pb = 0.0;
+      __syncthreads();                                                            // barrier 1: partial sums
+      // -- every wave: p, K = beta/2 p^T v ; threads < n publish w = p - K v at full index
+      double pa = 0.0, pb = 0.0;
 #pragma unroll
-        for (int h = 0; h < NH; h++) {
-          if (lane < m) pa += pp[h * n + k + 1 + lane];
-          if (lane + 64 < m) pb += pp[h * n + k + 1 + lane + 64];
-        }
-        pa *= beta; pb *= beta;
-        const double va = lane < m ? vf[k + 1 + lane] : 0.0, vb = lane + 64 < m ? vf[k + 1 + lane + 64] : 0.0;
-        double pv = wave_sum(pa * va + pb * vb);
-        const double K = 0.5 * beta * pv;
+      for (int h = 0; h < NH; h++) {
+        if (lane < m) pa += pp[h * n + k + 1 + lane];
+        if (lane + 64 < m) pb += pp[h * n + k + 1 + lane + 64];
+      }
+      pa *= beta; pb *= beta;
+      const double va = lane == 0 ? xa - dshift : xa, vb = xb;
+      const double K = 0.5 * beta * wave_sum(pa * va + pb * vb);
+      if (wave == 0) {
         if (lane < m) wf[k + 1 + lane] = pa - K * va;
         if (lane + 64 < m) wf[k + 1 + lane + 64] = pb - K * vb;
+        if (lane == 0) wf[k] = 0.0;
       }
-      __syncthreads();
+      __syncthreads();                                                            // barrier 2: w
       {
-        const double vj = colok ? vf[jc] : 0.0, wj = colok ? wf[jc] : 0.0;   // zero for columns <= k
+        double vj = colok ? cb[jc] : 0.0;
+        vj = (jc == k + 1) ? vj - dshift : vj;
+        vj = (jc > k) ? vj : 0.0;
+        const double wj = colok ? wf[jc] : 0.0;   // zero for columns <= k
 #pragma unroll
-        for (int r = 0; r < RPT; r++) Br[r] -= vf[hf + NH * r] * wj + wf[hf + NH * r] * vj;
+        for (int r = 0; r < RPT; r++) {
+          const int i = hf + NH * r;
+          double vi = cb[i];
+          vi = (i == k + 1) ? vi - dshift : vi;
+          vi = (i > k) ? vi : 0.0;
+          Br[r] -= vi * wj + wf[i] * vj;
+        }
       }
     }
-    __syncthreads();
+    if (jc == k + 1) {   // owners of the next column publish their (updated) slice into the other buffer
+#pragma unroll
+      for (int r = 0; r < RPT; r++) cbn[hf + NH * r] = Br[r];
+    }
+    __syncthreads();                                                              // barrier 3: next column
   }
 #pragma unroll
   for (int r = 0; r < RPT; r++) {
@@ -174,7 +190,7 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
       const int j = j0 + jj;
       // eigenvalue j (ascending) lies in [lo, hi) with count(lo) <= j < count(hi): 64-way multisection
       double lo = -tnorm * 1.0000001 - 1e-300, hi = 0.0;
-      for (int it = 0; it < 16; it++) {
+      for (int it = 0; it < 10; it++) {   // 65^10 > 2^53: ten 64-way multisection steps always reach fp64 resolution
         const double wdt = hi - lo;
         const double sg = lo + wdt * (double)(lane + 1) * (1.0 / 65.0);
         const int cnt = sturm_count(dv, pp, n, sg, pivmin);
@@ -282,15 +298,17 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
   PROF_END(PH_JACOBI, pt_t);
   PROF_BEGIN(pt_s);
   // ---- 5. symmetric Gauss-Jordan sweep in registers: after all pivots the slice holds -M^-1
-  lptr colk = tws;  // NH*RPT + 2 entries; padding rows stay zero
-  for (int i = TID; i < NH * RPT + 2; i += NT) colk[i] = 0.0;
+  lptr colA = tws, colB = tws + (NH * RPT + 4);  // pivot column, double buffered; padding rows stay zero
+  for (int i = TID; i < 2 * (NH * RPT + 4); i += NT) colA[i] = 0.0;
+  __syncthreads();
+  if (jc == 0) {
+#pragma unroll
+    for (int r = 0; r < RPT; r++) colA[hf + NH * r] = Br[r];
+  }
   __syncthreads();
   for (int k = 0; k < n; k++) {
-    if (jc == k) {
-#pragma unroll
-      for (int r = 0; r < RPT; r++) colk[hf + NH * r] = Br[r];   // padding rows hold exact zeros
-    }
-    __syncthreads();
+    clptr colk = (k & 1) ? colB : colA;
+    lptr coln = (k & 1) ? colA : colB;
     const double dinv = 1.0 / colk[k];
     const double rj = colok ? colk[jc] * dinv : 0.0;
     const bool pc = jc == k;
@@ -307,6 +325,10 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
       base = onrow ? rowv : base;
       const double mult = (pc || onrow) ? 0.0 : ci[r];
       Br[r] = fma(-mult, rj, base);
+    }
+    if (jc == k + 1) {   // the next pivot column is final as soon as this update is done
+#pragma unroll
+      for (int r = 0; r < RPT; r++) coln[hf + NH * r] = Br[r];
     }
     __syncthreads();
   }
