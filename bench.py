@@ -118,6 +118,16 @@ def main():
         kms = float(t.item())
 
     if rank == 0:
+        # HBM traffic from PMC counters is collected offline in separate rocprofv3 --pmc passes (gpurun refuses mixed runs)
+        traffic = None
+        try:
+            import glob
+            for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_*.json'))):
+                pm = json.load(open(f))
+                if pm.get('workload') == args.workload and pm.get('batch_per_gpu') == B:
+                    traffic = pm['traffic_bytes_per_launch']
+        except Exception:
+            traffic = None
         total = B * world * args.steps
         value = total / elapsed
         bytes_per_launch = algorithmic_bytes_per_solve(d) * B
@@ -136,7 +146,7 @@ def main():
             # The path is ALU/LDS-bound (state lives in LDS for the whole solve); the HBM figure is reported as the
             # contract asks and is expected to be a tiny fraction of peak.
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
-                         'traffic': None, 'kernel': 'dg_solve_kernel', 'kernel_ms': kms,
+                         'traffic': traffic, 'kernel': 'dg_solve_kernel', 'kernel_ms': kms,
                          'algorithmic_bytes_per_solve': algorithmic_bytes_per_solve(d)},
         }
         if world == 1 and args.cpu_sample > 0:
