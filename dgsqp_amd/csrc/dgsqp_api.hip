@@ -36,7 +36,13 @@ dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restric
     c.x0 = (cgptr)x0 + b * dg_prob.nq;
     c.trace = trace ? (gptr)trace + b * (int64_t)(1 + 2 * trace_cap) : nullptr;
     if (c.trace && TID == 0) c.trace[0] = 0.0;
+#ifdef DG_PROF
+    const long long sc_t0 = clock64();
+#endif
     dev_solve(c, (cgptr)u_ws + b * dg_prob.n, b, O);
+#ifdef DG_PROF
+    if (TID == 0 && b < 16384) dg_prof_scn[b] = (unsigned long long)(clock64() - sc_t0);
+#endif
   }
 #ifdef DG_PROF
   if (TID == 0) {
@@ -62,6 +68,7 @@ dg_evaluate_kernel(const DgProb* __restrict__ D, int64_t B, const double* __rest
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     c.x0 = (cgptr)x0 + b * dg_prob.nq;
     __syncthreads();
+    if (TID == 0) dg_lds[L.scal + DG_XVALID] = 0.0;
     for (int i = TID; i < n; i += NT) dg_lds[L.u + i] = u[b * n + i];
     for (int r = TID; r < nc; r += NT) dg_lds[L.l + r] = l ? l[b * nc + r] : 0.0;
     __syncthreads();
@@ -97,6 +104,7 @@ dg_qp_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     c.x0 = (cgptr)x0 + b * dg_prob.nq;
     __syncthreads();
+    if (TID == 0) dg_lds[L.scal + DG_XVALID] = 0.0;
     for (int i = TID; i < n; i += NT) dg_lds[L.u + i] = u[b * n + i];
     for (int r = TID; r < nc; r += NT) dg_lds[L.l + r] = l[b * nc + r];
     __syncthreads();
@@ -354,6 +362,17 @@ int dgsqp_solve_batch(dgsqp_handle_t h, int64_t B, const double* x0, const doubl
     tm->total_ms = ms;
   }
   return DGSQP_OK;
+}
+
+// Diagnostic build (-DDG_PROF) only: cycles spent on each scenario of the last launch.
+int dgsqp_prof_scn(unsigned long long* out, int n) {
+#ifdef DG_PROF
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dg_prof_scn), sizeof(unsigned long long) * (n < 16384 ? n : 16384)) != hipSuccess) return DGSQP_E_DEVICE;
+  return 0;
+#else
+  (void)out; (void)n;
+  return -1;
+#endif
 }
 
 // Diagnostic build (-DDG_PROF) only: read and clear the per-phase cycle counters.

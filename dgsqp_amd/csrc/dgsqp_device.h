@@ -84,6 +84,7 @@ __device__ inline void dev_tr(const Ctx& c, int code, double v) {
 enum { PH_ROLLOUT = 0, PH_DERIV1, PH_DERIV2, PH_CHAINS, PH_DP, PH_JACOBI, PH_PFORM, PH_QP, PH_MERIT, PH_LSQR, PH_QTMUL, PH_SWEEP, PH_WGTOTAL, PH_WGMAX, PH_Q_SCAN, PH_Q_Y, PH_Q_DIR, PH_Q_STEP, PH_Q_UPD, PH_Q_REFINE, PH_COUNT };
 #ifdef DG_PROF
 __device__ unsigned long long dg_prof[PH_COUNT * 2];
+__device__ unsigned long long dg_prof_scn[16384];
 #define PROF_BEGIN(v) const long long v = clock64()
 #define PROF_END(ph, v) do { if (threadIdx.x == 0) { atomicAdd(&dg_prof[2 * (ph)], (unsigned long long)(clock64() - v)); atomicAdd(&dg_prof[2 * (ph) + 1], 1ULL); } } while (0)
 #else
@@ -174,6 +175,73 @@ __device__ inline void block_argmin(double v, int idx, lptr red, double& vout, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// Lean fp64 elementary functions (<= 1 ulp on the arguments that occur here: angles and slip ratios, |x| < 2^20).
+// The OCML versions carry large-argument reduction and full IEEE division (sincos ~200, atan2 ~125, tan ~220 ISA
+// instructions); f_c is evaluated ~10^3 times per rollout on a handful of lanes, so the instruction count of these
+// is the latency of the whole rollout.  Kernels are the classical fdlibm minimax polynomials.
+// ------------------------------------------------------------------------------------------------
+__device__ inline double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);          // v_rcp_f64: ~2^-23 relative
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+__device__ inline void dev_sincos(double x, double& so, double& co) {
+  const double k = __builtin_rint(x * 0.63661977236758138);
+  double r = __builtin_fma(-k, 1.5707963267948966, x);
+  r = __builtin_fma(-k, 6.123233995736766e-17, r);
+  const double z = r * r;
+  double ps = 1.58969099521155010221e-10;
+  ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
+  ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+  ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+  ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+  ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+  double pc = -1.13596475577881948265e-11;
+  pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+  pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+  pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+  pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+  pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+  const double sn = __builtin_fma(r * z, ps, r);
+  const double cs = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
+  const int q = (int)k;
+  double s1 = (q & 1) ? cs : sn, c1 = (q & 1) ? sn : cs;
+  so = (q & 2) ? -s1 : s1;
+  co = ((q + 1) & 2) ? -c1 : c1;
+}
+__device__ inline double dev_atan2(double y, double x) {
+  const double ay = __builtin_fabs(y), ax = __builtin_fabs(x);
+  const double y16 = 16.0 * ay;
+  // argument reduction atan(t) = atan(k) + atan((t - k)/(1 + k t)), k in {0, 1/2, 1, 3/2, inf}, folded into ONE division
+  double num = ay, den = ax, hi = 0.0, lo = 0.0;
+  if (y16 >= 7.0 * ax) { num = 2.0 * ay - ax; den = __builtin_fma(2.0, ax, ay); hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17; }
+  if (y16 >= 11.0 * ax) { num = ay - ax; den = ax + ay; hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17; }
+  if (y16 >= 19.0 * ax) { num = __builtin_fma(-1.5, ax, ay); den = __builtin_fma(1.5, ay, ax); hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17; }
+  if (y16 >= 39.0 * ax) { num = -ax; den = ay; hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17; }
+  den = den == 0.0 ? 1.0 : den;                 // atan2(0, 0) = 0
+  const double t = num * fast_rcp(den);
+  const double z = t * t;
+  double p = 1.62858201153657823623e-02;
+  p = __builtin_fma(p, z, -3.65315727442169155270e-02);
+  p = __builtin_fma(p, z, 4.97687799461593236017e-02);
+  p = __builtin_fma(p, z, -5.83357013379057348645e-02);
+  p = __builtin_fma(p, z, 6.66107313738753120669e-02);
+  p = __builtin_fma(p, z, -7.69187620504482999495e-02);
+  p = __builtin_fma(p, z, 9.09088713343650656196e-02);
+  p = __builtin_fma(p, z, -1.11111104054623557880e-01);
+  p = __builtin_fma(p, z, 1.42857142725034663711e-01);
+  p = __builtin_fma(p, z, -1.99999999998764832476e-01);
+  p = __builtin_fma(p, z, 3.33333333333329318027e-01);
+  double r = hi + ((lo - t * z * p) + t);
+  r = x < 0.0 ? (3.141592653589793 - r) + 1.2246467991473532e-16 : r;
+  return y < 0.0 ? -r : r;
+}
+__device__ inline double dev_atan(double x) { return dev_atan2(x, 1.0); }
+__device__ inline double dev_tan(double x) { double s, c; dev_sincos(x, s, c); return s * fast_rcp(c); }
+
+// ------------------------------------------------------------------------------------------------
 // truncated univariate Taylor arithmetic, f(t) = c0 + c1 t + c2 t^2.
 // Second derivatives of the discrete dynamics are recovered from the t^2 coefficient along the
 // directions e_i and e_i+e_j (one direction per lane), first derivatives from the t coefficient.
@@ -203,7 +271,7 @@ template <int DEG> __device__ inline Ty<DEG> operator*(const Ty<DEG>& a, const T
 }
 template <int DEG> __device__ inline Ty<DEG> ty_recip(const Ty<DEG>& a) {
   Ty<DEG> r;
-  r.c[0] = 1.0 / a.c[0];
+  r.c[0] = fast_rcp(a.c[0]);
   if constexpr (DEG >= 1) r.c[1] = -a.c[1] * r.c[0] * r.c[0];
   if constexpr (DEG >= 2) r.c[2] = -(a.c[2] * r.c[0] + a.c[1] * r.c[1]) * r.c[0];
   return r;
@@ -212,14 +280,14 @@ template <int DEG> __device__ inline Ty<DEG> operator/(const Ty<DEG>& a, const T
 template <int DEG> __device__ inline Ty<DEG> operator/(double a, const Ty<DEG>& b) { return ty_recip(b) * a; }
 template <int DEG> __device__ inline void ty_sincos(const Ty<DEG>& a, Ty<DEG>& s, Ty<DEG>& c) {
   double s0, c0;
-  sincos(a.c[0], &s0, &c0);
+  dev_sincos(a.c[0], s0, c0);
   s.c[0] = s0; c.c[0] = c0;
   if constexpr (DEG >= 1) { s.c[1] = c0 * a.c[1]; c.c[1] = -s0 * a.c[1]; }
   if constexpr (DEG >= 2) { s.c[2] = 0.5 * a.c[1] * c.c[1] + a.c[2] * c0; c.c[2] = -0.5 * a.c[1] * s.c[1] - a.c[2] * s0; }
 }
 template <int DEG> __device__ inline Ty<DEG> ty_tan(const Ty<DEG>& a) {
   Ty<DEG> r;
-  r.c[0] = tan(a.c[0]);
+  r.c[0] = dev_tan(a.c[0]);
   const double w0 = 1.0 + r.c[0] * r.c[0];
   if constexpr (DEG >= 1) r.c[1] = w0 * a.c[1];
   if constexpr (DEG >= 2) r.c[2] = w0 * a.c[2] + r.c[0] * r.c[1] * a.c[1];
@@ -227,36 +295,39 @@ template <int DEG> __device__ inline Ty<DEG> ty_tan(const Ty<DEG>& a) {
 }
 template <int DEG> __device__ inline Ty<DEG> ty_atan(const Ty<DEG>& a) {
   Ty<DEG> r;
-  r.c[0] = atan(a.c[0]);
-  const double w0 = 1.0 + a.c[0] * a.c[0];
-  if constexpr (DEG >= 1) r.c[1] = a.c[1] / w0;
-  if constexpr (DEG >= 2) r.c[2] = (2.0 * a.c[2] - 2.0 * a.c[0] * a.c[1] * r.c[1]) / (2.0 * w0);
+  r.c[0] = dev_atan(a.c[0]);
+  const double iw0 = fast_rcp(1.0 + a.c[0] * a.c[0]);
+  if constexpr (DEG >= 1) r.c[1] = a.c[1] * iw0;
+  if constexpr (DEG >= 2) r.c[2] = (a.c[2] - a.c[0] * a.c[1] * r.c[1]) * iw0;
   return r;
 }
 template <int DEG> __device__ inline Ty<DEG> ty_atan2(const Ty<DEG>& y, const Ty<DEG>& x) {
   Ty<DEG> r;
-  r.c[0] = atan2(y.c[0], x.c[0]);
+  r.c[0] = dev_atan2(y.c[0], x.c[0]);
   const double w0 = x.c[0] * x.c[0] + y.c[0] * y.c[0];
-  if constexpr (DEG >= 1) r.c[1] = (x.c[0] * y.c[1] - y.c[0] * x.c[1]) / w0;
+  const double iw0 = DEG >= 1 ? fast_rcp(w0) : 0.0;
+  if constexpr (DEG >= 1) r.c[1] = (x.c[0] * y.c[1] - y.c[0] * x.c[1]) * iw0;
   if constexpr (DEG >= 2) {
     const double w1 = 2.0 * (x.c[0] * x.c[1] + y.c[0] * y.c[1]);
     const double n1 = 2.0 * (x.c[0] * y.c[2] - y.c[0] * x.c[2]);
-    r.c[2] = (n1 - r.c[1] * w1) / (2.0 * w0);
+    r.c[2] = (n1 - r.c[1] * w1) * (0.5 * iw0);
   }
   return r;
 }
 template <int DEG> __device__ inline Ty<DEG> ty_sqrt(const Ty<DEG>& a) {
   Ty<DEG> r;
   r.c[0] = sqrt(a.c[0]);
-  if constexpr (DEG >= 1) r.c[1] = a.c[1] / (2.0 * r.c[0]);
-  if constexpr (DEG >= 2) r.c[2] = (a.c[2] - r.c[1] * r.c[1]) / (2.0 * r.c[0]);
+  const double ih = DEG >= 1 ? 0.5 * fast_rcp(r.c[0]) : 0.0;
+  if constexpr (DEG >= 1) r.c[1] = a.c[1] * ih;
+  if constexpr (DEG >= 2) r.c[2] = (a.c[2] - r.c[1] * r.c[1]) * ih;
   return r;
 }
 template <int DEG> __device__ inline Ty<DEG> ty_pow(const Ty<DEG>& a, double p) {
   Ty<DEG> r;
   r.c[0] = pow(a.c[0], p);
-  if constexpr (DEG >= 1) r.c[1] = p * r.c[0] * a.c[1] / a.c[0];
-  if constexpr (DEG >= 2) r.c[2] = (p * (2.0 * r.c[0] * a.c[2] + r.c[1] * a.c[1]) - a.c[1] * r.c[1]) / (2.0 * a.c[0]);
+  const double ia = DEG >= 1 ? fast_rcp(a.c[0]) : 0.0;
+  if constexpr (DEG >= 1) r.c[1] = p * r.c[0] * a.c[1] * ia;
+  if constexpr (DEG >= 2) r.c[2] = (p * (2.0 * r.c[0] * a.c[2] + r.c[1] * a.c[1]) - a.c[1] * r.c[1]) * (0.5 * ia);
   return r;
 }
 template <int DEG> __device__ inline Ty<DEG> ty_abs(const Ty<DEG>& a) { return a.c[0] > 0 ? a : -a; }  // ca_abs, dynamics_models.py:228-234
@@ -266,11 +337,9 @@ template <int DEG> __device__ inline Ty<DEG> ty_abs(const Ty<DEG>& a) { return a
 // ------------------------------------------------------------------------------------------------
 // sbar = fmod(fmod(s, L) + L, L) for |s| < 2^40 L: one exact remainder step per fmod (s - L*trunc(s/L) is exact in fp64
 // when the quotient is small), cheaper than the generic OCML loop.
-__device__ inline double wrap_s(double s, double L) {
-  double r = s - L * trunc(s / L);      // fmod(s, L): sign of s, |r| < L (up to one ulp of the quotient)
-  if (r >= L) r -= L; else if (r <= -L) r += L;
-  r += L;
-  r = r - L * trunc(r / L);
+__device__ inline double wrap_s(double s, double L, double invL) {
+  double r = __builtin_fma(-L, __builtin_floor(s * invL), s);   // s mod L; the quotient may be one ulp off at the seam
+  if (r < 0.0) r += L;
   if (r >= L) r -= L;
   return r;
 }
@@ -278,7 +347,7 @@ template <int DEG>
 __device__ inline void dev_track(const dgsqp_problem_t& P, const Ty<DEG>& s, double& curv, Ty<DEG>& psi) {
   constexpr int S1 = DGSQP_MAX_SEGS + 1;
   clptr tt = LP(dg_prob.L.t_track);
-  const double sbar = wrap_s(s.c[0], P.track_L);
+  const double sbar = wrap_s(s.c[0], P.track_L, dg_prob.inv_track_L);
   int seg = 0;
   for (int i = 1; i < P.n_segs; i++) seg += (sbar >= tt[i]) ? 1 : 0;
   curv = tt[S1 + seg];
@@ -286,13 +355,26 @@ __device__ inline void dev_track(const dgsqp_problem_t& P, const Ty<DEG>& s, dou
 }
 
 // kinematic bicycle in the Frenet frame (dynamics_models.py:1046-1070); q = [x,y,v,e_psi,s,e_y], u = [a, delta]
+// terms of f_c that depend on the (zero-order-hold) input only: evaluated once per stage, not once per rk sub-stage
 template <int DEG>
-__device__ inline void dev_fc_kin(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const Ty<DEG>* q, const Ty<DEG>* u, Ty<DEG>* dq) {
+struct FcPre { Ty<DEG> a0, s0, c0; double im, iz, ilr; };   // kin: beta, sin beta, cos beta ; dyn: -, sin delta, cos delta
+template <int DEG>
+__device__ inline void dev_fc_pre_kin(const dgsqp_agent_t& ag, const Ty<DEG>* u, FcPre<DEG>& pre) {
+  pre.im = 1.0 / ag.mass; pre.ilr = 1.0 / ag.L_r; pre.iz = 0.0;
+  pre.a0 = ty_atan2(ty_tan(u[1]) * ag.L_r, ty_const<DEG>(ag.L_f + ag.L_r));
+  ty_sincos(pre.a0, pre.s0, pre.c0);
+}
+template <int DEG>
+__device__ inline void dev_fc_pre_dyn(const dgsqp_agent_t& ag, const Ty<DEG>* u, FcPre<DEG>& pre) {
+  pre.im = 1.0 / ag.mass; pre.iz = 1.0 / ag.I_z; pre.ilr = 0.0;
+  pre.a0 = u[1];
+  ty_sincos(u[1], pre.s0, pre.c0);
+}
+template <int DEG>
+__device__ inline void dev_fc_kin(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const Ty<DEG>* q, const Ty<DEG>* u, const FcPre<DEG>& pre, Ty<DEG>* dq) {
   typedef Ty<DEG> T;
-  const T beta = ty_atan2(ty_tan(u[1]) * ag.L_r, ty_const<DEG>(ag.L_f + ag.L_r));
-  T sb, cb;
-  ty_sincos(beta, sb, cb);
-  const T psidot = q[2] * sb * (1.0 / ag.L_r);
+  const T &beta = pre.a0, &sb = pre.s0, &cb = pre.c0;
+  const T psidot = q[2] * sb * pre.ilr;
   T F = q[2] * (-ag.c_da) - q[2] * ty_abs(q[2]) * ag.c_dr - psidot * psidot * ag.c_s;
   if (ag.c_r != 0.0) F = F - ty_pow(ty_abs(q[2]), ag.p_r) * (q[2] / ty_sqrt(q[2] * q[2] + 1e-6)) * ag.c_r;
   double c;
@@ -305,7 +387,7 @@ __device__ inline void dev_fc_kin(const dgsqp_problem_t& P, const dgsqp_agent_t&
   const T vlon = q[2] * c2 * inv;
   dq[0] = q[2] * c1;
   dq[1] = q[2] * s1;
-  dq[2] = u[0] + F * (1.0 / ag.mass);
+  dq[2] = u[0] + F * pre.im;
   dq[3] = psidot - vlon * c;
   dq[4] = vlon;
   dq[5] = q[2] * s2;
@@ -313,14 +395,13 @@ __device__ inline void dev_fc_kin(const dgsqp_problem_t& P, const dgsqp_agent_t&
 
 // dynamic bicycle, Pacejka / linear tyres (dynamics_models.py:2008-2062); q = [x,y,vx,vy,w,e_psi,s,e_y]
 template <int DEG>
-__device__ inline void dev_fc_dyn(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const Ty<DEG>* q, const Ty<DEG>* u, Ty<DEG>* dq) {
+__device__ inline void dev_fc_dyn(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const Ty<DEG>* q, const Ty<DEG>* u, const FcPre<DEG>& pre, Ty<DEG>* dq) {
   typedef Ty<DEG> T;
   const T &vx = q[2], &vy = q[3], &w = q[4];
   double c;
   T psit;
   dev_track(P, q[6], c, psit);
-  T sd, cd;
-  ty_sincos(u[1], sd, cd);
+  const T &sd = pre.s0, &cd = pre.c0;
   const T vyf = vy + w * ag.L_f;
   T af;
   if (ag.simple_slip) af = u[1] - ty_atan2(vyf, vx);
@@ -341,8 +422,8 @@ __device__ inline void dev_fc_dyn(const dgsqp_problem_t& P, const dgsqp_agent_t&
   if (ag.c_r != 0.0) F = F - ty_pow(ty_abs(vx), ag.p_r) * (vx / ty_sqrt(vx * vx + 1e-6)) * ag.c_r;
   T a_r, a_f;
   if (ag.drive_wheels == 0) { a_r = u[0] * 0.5; a_f = u[0] * 0.5; } else { a_r = u[0]; a_f = ty_const<DEG>(0.0); }
-  const T ax = a_r + a_f * cd + (F - fyf * sd) * (1.0 / ag.mass);
-  const T ay = a_f * sd + (fyf * cd + fyr) * (1.0 / ag.mass);
+  const T ax = a_r + a_f * cd + (F - fyf * sd) * pre.im;
+  const T ay = a_f * sd + (fyf * cd + fyr) * pre.im;
   T se, ce, st, ct;
   ty_sincos(q[5], se, ce);
   ty_sincos(q[5] + psit, st, ct);
@@ -351,15 +432,15 @@ __device__ inline void dev_fc_dyn(const dgsqp_problem_t& P, const dgsqp_agent_t&
   dq[1] = vy * ct + vx * st;
   dq[2] = ax + w * vy;
   dq[3] = ay - w * vx;
-  dq[4] = (fyf * cd * ag.L_f - fyr * ag.L_r) * (1.0 / ag.I_z);
+  dq[4] = (fyf * cd * ag.L_f - fyr * ag.L_r) * pre.iz;
   dq[5] = w - vlon * c;
   dq[6] = vlon;
   dq[7] = vx * se + vy * ce;
 }
 
 template <int DEG, int NQA>
-__device__ inline void dev_fc(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const Ty<DEG>* q, const Ty<DEG>* u, Ty<DEG>* dq) {
-  if constexpr (NQA == 8) dev_fc_dyn<DEG>(P, ag, q, u, dq); else dev_fc_kin<DEG>(P, ag, q, u, dq);
+__device__ inline void dev_fc(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const Ty<DEG>* q, const Ty<DEG>* u, const FcPre<DEG>& pre, Ty<DEG>* dq) {
+  if constexpr (NQA == 8) dev_fc_dyn<DEG>(P, ag, q, u, pre, dq); else dev_fc_kin<DEG>(P, ag, q, u, pre, dq);
 }
 
 // one discrete step of the joint model's integrator (dynamics_models.py:88-99, :188-219)
@@ -367,34 +448,36 @@ template <int DEG, int NQA>
 __device__ inline void dev_fd(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const Ty<DEG>* q, const Ty<DEG>* u, Ty<DEG>* qn) {
   typedef Ty<DEG> T;
   T x[NQA], k1[NQA], k2[NQA], k3[NQA], t[NQA];
+  FcPre<DEG> pre;
+  if constexpr (NQA == 8) dev_fc_pre_dyn<DEG>(ag, u, pre); else dev_fc_pre_kin<DEG>(ag, u, pre);
   for (int i = 0; i < NQA; i++) x[i] = q[i];
   if (P.integrator == DGSQP_INT_EULER) {
-    dev_fc<DEG, NQA>(P, ag, x, u, k1);
+    dev_fc<DEG, NQA>(P, ag, x, u, pre, k1);
     for (int i = 0; i < NQA; i++) qn[i] = x[i] + k1[i] * P.dt;
     return;
   }
   const double h = P.dt / P.substeps;
   for (int m = 0; m < P.substeps; m++) {
     if (P.integrator == DGSQP_INT_RK4) {
-      dev_fc<DEG, NQA>(P, ag, x, u, k1);
+      dev_fc<DEG, NQA>(P, ag, x, u, pre, k1);
       for (int i = 0; i < NQA; i++) t[i] = x[i] + k1[i] * (h / 2);
-      dev_fc<DEG, NQA>(P, ag, t, u, k2);
+      dev_fc<DEG, NQA>(P, ag, t, u, pre, k2);
       for (int i = 0; i < NQA; i++) { t[i] = x[i] + k2[i] * (h / 2); k1[i] = k1[i] + k2[i] * 2.0; }
-      dev_fc<DEG, NQA>(P, ag, t, u, k3);
+      dev_fc<DEG, NQA>(P, ag, t, u, pre, k3);
       for (int i = 0; i < NQA; i++) { t[i] = x[i] + k3[i] * h; k1[i] = k1[i] + k3[i] * 2.0; }
-      dev_fc<DEG, NQA>(P, ag, t, u, k2);
-      for (int i = 0; i < NQA; i++) x[i] = x[i] + (k1[i] + k2[i]) * h / 6.0;
+      dev_fc<DEG, NQA>(P, ag, t, u, pre, k2);
+      for (int i = 0; i < NQA; i++) x[i] = x[i] + (k1[i] + k2[i]) * (h / 6.0);
     } else if (P.integrator == DGSQP_INT_RK3) {
-      dev_fc<DEG, NQA>(P, ag, x, u, k1);
+      dev_fc<DEG, NQA>(P, ag, x, u, pre, k1);
       for (int i = 0; i < NQA; i++) { k1[i] = k1[i] * h; t[i] = x[i] + k1[i] * 0.5; }
-      dev_fc<DEG, NQA>(P, ag, t, u, k2);
+      dev_fc<DEG, NQA>(P, ag, t, u, pre, k2);
       for (int i = 0; i < NQA; i++) { k2[i] = k2[i] * h; t[i] = x[i] - k1[i] + k2[i] * 2.0; }
-      dev_fc<DEG, NQA>(P, ag, t, u, k3);
+      dev_fc<DEG, NQA>(P, ag, t, u, pre, k3);
       for (int i = 0; i < NQA; i++) x[i] = x[i] + (k1[i] + k2[i] * 4.0 + k3[i] * h) / 6.0;
     } else {
-      dev_fc<DEG, NQA>(P, ag, x, u, k1);
+      dev_fc<DEG, NQA>(P, ag, x, u, pre, k1);
       for (int i = 0; i < NQA; i++) t[i] = x[i] + k1[i] * h;
-      dev_fc<DEG, NQA>(P, ag, t, u, k2);
+      dev_fc<DEG, NQA>(P, ag, t, u, pre, k2);
       for (int i = 0; i < NQA; i++) x[i] = x[i] + (k1[i] + k2[i]) * (h / 2);
     }
   }

@@ -74,15 +74,18 @@ __device__ inline double dev_state_cost(const DgProb& D, int a, XP xk, bool term
 // ------------------------------------------------------------------------------------------------
 // rollout x_{k+1} = f_d(x_k, u_k)   (evaluate_dynamics, DGSQP.py:597-601): one lane per agent
 // ------------------------------------------------------------------------------------------------
+// trial input u + alpha du, written the same way everywhere so that equal points give bit-identical trajectories
+__device__ inline double step_u(double u, double alpha, double du) { return __builtin_fma(alpha, du, u); }
 template <int NQA>
-__device__ inline void dev_rollout_agent(const DgProb& D, int a, clptr ue, lptr x) {
+__device__ inline void dev_rollout_agent(const DgProb& D, int a, clptr ub, clptr du, double alpha, lptr x) {
   typedef Ty<0> T;
   const int nq = D.nq, qo = D.qoff[a];
   T q[NQA], u[2], qn[NQA];
   for (int i = 0; i < NQA; i++) q[i].c[0] = x[qo + i];
   for (int k = 0; k < D.N; k++) {
-    u[0].c[0] = ue[am_col(D, a, k, 0)];
-    u[1].c[0] = ue[am_col(D, a, k, 1)];
+    const int i0 = am_col(D, a, k, 0);
+    u[0].c[0] = du ? step_u(ub[i0], alpha, du[i0]) : ub[i0];
+    u[1].c[0] = du ? step_u(ub[i0 + 1], alpha, du[i0 + 1]) : ub[i0 + 1];
     dev_fd<0, NQA>(D.P, D.P.agents[a], q, u, qn);
     for (int i = 0; i < NQA; i++) { q[i] = qn[i]; x[(k + 1) * nq + qo + i] = qn[i].c[0]; }
   }
@@ -92,108 +95,140 @@ __device__ inline void dev_rollout_agent(const DgProb& D, int a, clptr ue, lptr 
 // are the same instruction stream on different data, so lane 2a handles (front axle, e_psi) and lane 2a+1 (rear axle,
 // e_psi + psi_t); results are exchanged inside the quad with DPP.  sincos(delta) is constant over the step and hoisted.
 // Same arithmetic as dev_fc_dyn<0> (dynamics_models.py:2008-2062), evaluated redundantly on both lanes otherwise.
-__device__ inline void dyn_fc_pair(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, int role, const double* q, double ua, double us,
-                                   double sd, double cd, double* dq) {
-  const double vx = q[2], vy = q[3], w = q[4];
+struct DynLane {
+  // per-lane constants of the pair rollout, loaded once (agent parameters are lane-dependent, i.e. vector loads otherwise)
+  double L_f, L_r, Bc, Cc, Dc, lin, c_da, c_dr, c_r, p_r, inv_mass, inv_Iz, fr, ff, L, invL;
+  int role, simple_slip, pacejka, nsegs;
+  // track segment currently containing s: [lo, hi), curvature, tangent angle at lo and its slope
+  double lo, hi, curv, ang0, slope;
+};
+__device__ inline void dyn_lane_seek(DynLane& Z, double sbar) {
   constexpr int S1 = DGSQP_MAX_SEGS + 1;
   clptr tt = LP(dg_prob.L.t_track);
-  const double sbar = wrap_s(q[6], P.track_L);
   int seg = 0;
-  for (int i = 1; i < P.n_segs; i++) seg += (sbar >= tt[i]) ? 1 : 0;
-  const double c = tt[S1 + seg];
-  const double psit = (q[6] + (sbar - q[6] - tt[seg])) * tt[3 * S1 + seg] + tt[2 * S1 + seg];
-  const double vyf = vy + w * ag.L_f;
+  for (int i = 1; i < Z.nsegs; i++) seg += (sbar >= tt[i]) ? 1 : 0;
+  Z.lo = tt[seg]; Z.hi = seg + 1 < Z.nsegs ? tt[seg + 1] : 1e300;
+  Z.curv = tt[S1 + seg]; Z.ang0 = tt[2 * S1 + seg]; Z.slope = tt[3 * S1 + seg];
+}
+__device__ inline void dyn_fc_pair(DynLane& Z, const double* q, double ua, double us, double sd, double cd, double* dq) {
+  const double vx = q[2], vy = q[3], w = q[4];
+  const double sbar = wrap_s(q[6], Z.L, Z.invL);
+  if (!(sbar >= Z.lo && sbar < Z.hi)) dyn_lane_seek(Z, sbar);     // rare: s crossed a segment boundary
+  const double c = Z.curv;
+  const double psit = (q[6] + (sbar - q[6] - Z.lo)) * Z.slope + Z.ang0;
+  const double vyf = __builtin_fma(w, Z.L_f, vy);
   // role 0: front axle and e_psi ; role 1: rear axle and e_psi + psi_t
   double ay_, ax_, add;
-  if (role == 0) {
-    if (ag.simple_slip) { ay_ = vyf; ax_ = vx; add = us; } else { ay_ = vyf * cd - vx * sd; ax_ = vx * cd + vyf * sd; add = 0.0; }
-  } else { ay_ = vy - w * ag.L_r; ax_ = vx; add = 0.0; }
-  const double alpha = add - atan2(ay_, ax_);
+  if (Z.role == 0) {
+    if (Z.simple_slip) { ay_ = vyf; ax_ = vx; add = us; } else { ay_ = vyf * cd - vx * sd; ax_ = vx * cd + vyf * sd; add = 0.0; }
+  } else { ay_ = __builtin_fma(-w, Z.L_r, vy); ax_ = vx; add = 0.0; }
+  const double alpha = add - dev_atan2(ay_, ax_);
   double F;
-  if (ag.tire_model == 0) {
-    const double Bc = role == 0 ? ag.pac_Bf : ag.pac_Br, Cc = role == 0 ? ag.pac_Cf : ag.pac_Cr, Dc = role == 0 ? ag.pac_Df : ag.pac_Dr;
-    F = Dc * sin(Cc * atan(Bc * alpha));
+  if (Z.pacejka) {
+    double sF, cF;
+    dev_sincos(Z.Cc * dev_atan(Z.Bc * alpha), sF, cF);
+    F = Z.Dc * sF;
   } else {
-    F = alpha * (role == 0 ? ag.lin_Bf * ag.mass * ag.gravity * ag.L_r / (ag.L_f + ag.L_r) : ag.lin_Br * ag.mass * ag.gravity * ag.L_f / (ag.L_f + ag.L_r));
+    F = alpha * Z.lin;
   }
   double sa, ca;
-  sincos(role == 0 ? q[5] : q[5] + psit, &sa, &ca);
+  dev_sincos(Z.role == 0 ? q[5] : q[5] + psit, sa, ca);
   // exchange inside the pair: quad_perm [0,0,2,2] takes the even lane's value, [1,1,3,3] the odd lane's
   const double fyf = dpp_f64<0xA0>(F), fyr = dpp_f64<0xF5>(F);
   const double se = dpp_f64<0xA0>(sa), ce = dpp_f64<0xA0>(ca), st = dpp_f64<0xF5>(sa), ct = dpp_f64<0xF5>(ca);
-  double Fx = vx * (-ag.c_da) - vx * (vx > 0 ? vx : -vx) * ag.c_dr;
-  if (ag.c_r != 0.0) Fx = Fx - pow(vx > 0 ? vx : -vx, ag.p_r) * (vx / sqrt(vx * vx + 1e-6)) * ag.c_r;
-  const double a_r = ag.drive_wheels == 0 ? ua * 0.5 : ua, a_f = ag.drive_wheels == 0 ? ua * 0.5 : 0.0;
-  const double ax = a_r + a_f * cd + (Fx - fyf * sd) * (1.0 / ag.mass);
-  const double ay = a_f * sd + (fyf * cd + fyr) * (1.0 / ag.mass);
-  const double vlon = (vx * ce - vy * se) * (1.0 / (1.0 - q[7] * c));
+  const double avx = __builtin_fabs(vx);
+  double Fx = vx * (-Z.c_da) - vx * avx * Z.c_dr;
+  if (Z.c_r != 0.0) Fx = Fx - pow(avx, Z.p_r) * (vx / sqrt(vx * vx + 1e-6)) * Z.c_r;
+  const double a_r = ua * Z.fr, a_f = ua * Z.ff;
+  const double ax = a_r + a_f * cd + (Fx - fyf * sd) * Z.inv_mass;
+  const double ay = a_f * sd + (fyf * cd + fyr) * Z.inv_mass;
+  const double vlon = (vx * ce - vy * se) * fast_rcp(1.0 - q[7] * c);
   dq[0] = vx * ct - vy * st;
   dq[1] = vy * ct + vx * st;
   dq[2] = ax + w * vy;
   dq[3] = ay - w * vx;
-  dq[4] = (fyf * cd * ag.L_f - fyr * ag.L_r) * (1.0 / ag.I_z);
+  dq[4] = (fyf * cd * Z.L_f - fyr * Z.L_r) * Z.inv_Iz;
   dq[5] = w - vlon * c;
   dq[6] = vlon;
   dq[7] = vx * se + vy * ce;
 }
-__device__ inline void dev_rollout_dyn_pair(const DgProb& D, int a, int role, clptr ue, lptr x) {
+__device__ inline void dev_rollout_dyn_pair(const DgProb& D, int a, int role, clptr ub, clptr du, double alpha, lptr x) {
   const dgsqp_problem_t& P = D.P;
   const dgsqp_agent_t& ag = P.agents[a];
   const int nq = D.nq, qo = D.qoff[a];
-  double q[8], k1[8], k2[8], k3[8], t[8];
+  DynLane Z;
+  Z.role = role; Z.simple_slip = ag.simple_slip; Z.pacejka = ag.tire_model == 0; Z.nsegs = P.n_segs;
+  Z.L_f = ag.L_f; Z.L_r = ag.L_r;
+  Z.Bc = role == 0 ? ag.pac_Bf : ag.pac_Br; Z.Cc = role == 0 ? ag.pac_Cf : ag.pac_Cr; Z.Dc = role == 0 ? ag.pac_Df : ag.pac_Dr;
+  Z.lin = role == 0 ? ag.lin_Bf * ag.mass * ag.gravity * ag.L_r / (ag.L_f + ag.L_r) : ag.lin_Br * ag.mass * ag.gravity * ag.L_f / (ag.L_f + ag.L_r);
+  Z.c_da = ag.c_da; Z.c_dr = ag.c_dr; Z.c_r = ag.c_r; Z.p_r = ag.p_r;
+  Z.inv_mass = 1.0 / ag.mass; Z.inv_Iz = 1.0 / ag.I_z;
+  Z.fr = ag.drive_wheels == 0 ? 0.5 : 1.0; Z.ff = ag.drive_wheels == 0 ? 0.5 : 0.0;
+  Z.L = P.track_L; Z.invL = D.inv_track_L;
+  Z.lo = 1.0; Z.hi = 0.0;   // empty interval: first use seeks
+  double q[8], k1[8], k2[8], t[8];
   for (int i = 0; i < 8; i++) q[i] = x[qo + i];
-  const double h = P.dt / P.substeps;
+  const double h = P.dt / P.substeps, h2 = 0.5 * h, h6 = h / 6.0;
+  const int integ = P.integrator, nsub = integ == DGSQP_INT_EULER ? 1 : P.substeps;
   for (int k = 0; k < D.N; k++) {
-    const double ua = ue[am_col(D, a, k, 0)], us = ue[am_col(D, a, k, 1)];
+    const int i0 = am_col(D, a, k, 0);
+    const double ua = du ? step_u(ub[i0], alpha, du[i0]) : ub[i0], us = du ? step_u(ub[i0 + 1], alpha, du[i0 + 1]) : ub[i0 + 1];
     double sd, cd;
-    sincos(us, &sd, &cd);
-    if (P.integrator == DGSQP_INT_EULER) {
-      dyn_fc_pair(P, ag, role, q, ua, us, sd, cd, k1);
-      for (int i = 0; i < 8; i++) q[i] = q[i] + k1[i] * P.dt;
-    } else {
-      for (int m = 0; m < P.substeps; m++) {
-        if (P.integrator == DGSQP_INT_RK4) {
-          dyn_fc_pair(P, ag, role, q, ua, us, sd, cd, k1);
-          for (int i = 0; i < 8; i++) t[i] = q[i] + k1[i] * (h / 2);
-          dyn_fc_pair(P, ag, role, t, ua, us, sd, cd, k2);
-          for (int i = 0; i < 8; i++) { t[i] = q[i] + k2[i] * (h / 2); k1[i] = k1[i] + k2[i] * 2.0; }
-          dyn_fc_pair(P, ag, role, t, ua, us, sd, cd, k3);
-          for (int i = 0; i < 8; i++) { t[i] = q[i] + k3[i] * h; k1[i] = k1[i] + k3[i] * 2.0; }
-          dyn_fc_pair(P, ag, role, t, ua, us, sd, cd, k2);
-          for (int i = 0; i < 8; i++) q[i] = q[i] + (k1[i] + k2[i]) * h / 6.0;
-        } else if (P.integrator == DGSQP_INT_RK3) {
-          dyn_fc_pair(P, ag, role, q, ua, us, sd, cd, k1);
-          for (int i = 0; i < 8; i++) { k1[i] = k1[i] * h; t[i] = q[i] + k1[i] * 0.5; }
-          dyn_fc_pair(P, ag, role, t, ua, us, sd, cd, k2);
-          for (int i = 0; i < 8; i++) { k2[i] = k2[i] * h; t[i] = q[i] - k1[i] + k2[i] * 2.0; }
-          dyn_fc_pair(P, ag, role, t, ua, us, sd, cd, k3);
-          for (int i = 0; i < 8; i++) q[i] = q[i] + (k1[i] + k2[i] * 4.0 + k3[i] * h) / 6.0;
-        } else {
-          dyn_fc_pair(P, ag, role, q, ua, us, sd, cd, k1);
-          for (int i = 0; i < 8; i++) t[i] = q[i] + k1[i] * h;
-          dyn_fc_pair(P, ag, role, t, ua, us, sd, cd, k2);
-          for (int i = 0; i < 8; i++) q[i] = q[i] + (k1[i] + k2[i]) * (h / 2);
-        }
+    dev_sincos(us, sd, cd);
+    for (int m = 0; m < nsub; m++) {
+      if (integ == DGSQP_INT_RK4) {
+        dyn_fc_pair(Z, q, ua, us, sd, cd, k1);
+        for (int i = 0; i < 8; i++) t[i] = __builtin_fma(k1[i], h2, q[i]);
+        dyn_fc_pair(Z, t, ua, us, sd, cd, k2);
+        for (int i = 0; i < 8; i++) { t[i] = __builtin_fma(k2[i], h2, q[i]); k1[i] = __builtin_fma(k2[i], 2.0, k1[i]); }
+        dyn_fc_pair(Z, t, ua, us, sd, cd, k2);
+        for (int i = 0; i < 8; i++) { t[i] = __builtin_fma(k2[i], h, q[i]); k1[i] = __builtin_fma(k2[i], 2.0, k1[i]); }
+        dyn_fc_pair(Z, t, ua, us, sd, cd, k2);
+        for (int i = 0; i < 8; i++) q[i] = __builtin_fma(k1[i] + k2[i], h6, q[i]);
+      } else if (integ == DGSQP_INT_RK3) {
+        double k3[8];
+        dyn_fc_pair(Z, q, ua, us, sd, cd, k1);
+        for (int i = 0; i < 8; i++) { k1[i] = k1[i] * h; t[i] = q[i] + k1[i] * 0.5; }
+        dyn_fc_pair(Z, t, ua, us, sd, cd, k2);
+        for (int i = 0; i < 8; i++) { k2[i] = k2[i] * h; t[i] = q[i] - k1[i] + k2[i] * 2.0; }
+        dyn_fc_pair(Z, t, ua, us, sd, cd, k3);
+        for (int i = 0; i < 8; i++) q[i] = q[i] + (k1[i] + k2[i] * 4.0 + k3[i] * h) / 6.0;
+      } else if (integ == DGSQP_INT_RK2) {
+        dyn_fc_pair(Z, q, ua, us, sd, cd, k1);
+        for (int i = 0; i < 8; i++) t[i] = q[i] + k1[i] * h;
+        dyn_fc_pair(Z, t, ua, us, sd, cd, k2);
+        for (int i = 0; i < 8; i++) q[i] = q[i] + (k1[i] + k2[i]) * h2;
+      } else {
+        dyn_fc_pair(Z, q, ua, us, sd, cd, k1);
+        for (int i = 0; i < 8; i++) q[i] = q[i] + k1[i] * P.dt;
       }
     }
     if (role == 0)
       for (int i = 0; i < 8; i++) x[(k + 1) * nq + qo + i] = q[i];
   }
 }
-__device__ __noinline__ void dev_rollout(const Ctx& c, clptr ue, lptr x) {
+// K trajectories x^(j) = rollout(ub + alpha_j du), alpha_j = alpha0 tau^j, j < K, on K * (lanes per trajectory) lanes of
+// wavefront 0 (one instruction stream: K trajectories cost the latency of one).  xs[j] has stride xstride doubles.
+__device__ __noinline__ void dev_rollout_multi(const Ctx& c, clptr ub, clptr du, double alpha0, double tau, int K, lptr xs, int xstride) {
   const DgProb& D = dg_prob;
   __syncthreads();
-  for (int i = TID; i < D.nq; i += NT) x[i] = c.x0[i];
+  for (int i = TID; i < K * D.nq; i += NT) xs[(i / D.nq) * xstride + i % D.nq] = c.x0[i % D.nq];
   __syncthreads();
   bool all_dyn = true;
   for (int a = 0; a < D.M; a++) all_dyn = all_dyn && D.nqa[a] == 8;
-  if (all_dyn) {
-    if (TID < 2 * D.M) dev_rollout_dyn_pair(D, TID >> 1, TID & 1, ue, x);
-  } else if (TID < D.M) {
-    if (D.nqa[TID] == 8) dev_rollout_agent<8>(D, TID, ue, x); else dev_rollout_agent<6>(D, TID, ue, x);
+  const int per = all_dyn ? 2 * D.M : D.M;
+  if (TID < K * per) {
+    const int j = TID / per, w = TID % per;
+    double alpha = alpha0;
+    for (int t = 0; t < j; t++) alpha *= tau;           // same products as the sequential alpha *= tau
+    lptr x = xs + j * xstride;
+    if (all_dyn) dev_rollout_dyn_pair(D, w >> 1, w & 1, ub, du, alpha, x);
+    else if (D.nqa[w] == 8) dev_rollout_agent<8>(D, w, ub, du, alpha, x);
+    else dev_rollout_agent<6>(D, w, ub, du, alpha, x);
   }
   __syncthreads();
 }
+__device__ inline void dev_rollout(const Ctx& c, clptr ue, lptr x) { dev_rollout_multi(c, ue, nullptr, 0.0, 1.0, 1, x, 0); }
 
 // ------------------------------------------------------------------------------------------------
 // derivatives of f_d at (x_k, u_k) by truncated Taylor propagation, one (agent, stage, direction)
@@ -382,211 +417,440 @@ __device__ __noinline__ void dev_constraint_values(const Ctx& c, clptr ue) {
   __syncthreads();
 }
 
-// ------------------------------------------------------------------------------------------------
-// Hessian of agent a's Lagrangian L^a = J^a + l^T C w.r.t. the input sequence by ONE backward
-// dynamic-programming sweep (same recursion as DGSQP.py:679-727 / :828-877, summed over rows by
-// linearity, identical to the reference's own f_Duu_L :937-941).  Rows of agent a go to raw Q.
-// ------------------------------------------------------------------------------------------------
-// stage injection: d/dx_k and d2/dx_k^2 of [J^a_k + sum_r l_r c_r] for rows r of stage k
-__device__ inline void dev_stage_injection(const Ctx& c, int a, int k, lptr inj) {
-  const DgProb& D = dg_prob;
-  const DgLds& L = D.L;
-  const int nq = D.nq;
-  for (int i = TID; i < nq + nq * nq; i += NT) inj[i] = 0.0;
-  __syncthreads();
-  if (TID == 0) {
-    clptr xk = LP(L.e_x + k * nq);
-    clptr l = LP(L.l);
-    lptr Dx = inj;
-    lptr Dxx = inj + nq;
-    dev_state_cost(D, a, xk, k == D.N, Dx, Dxx);
-    for (int r = D.stage_row0[k]; r < D.stage_row0[k + 1]; r++) {
-      const DgRow R = ld_row(r);
-      if (R.dense < 0) continue;  // rate / input-box rows are affine in u: no state derivatives
-      const double lr = l[r];
-      if (R.type == DG_R_OBS) {
-        const int ia = D.qoff[R.a], ib = D.qoff[R.b];
-        const double dx = xk[ia] - xk[ib], dy = xk[ia + 1] - xk[ib + 1];
-        Dx[ia] -= 2 * lr * dx; Dx[ia + 1] -= 2 * lr * dy; Dx[ib] += 2 * lr * dx; Dx[ib + 1] += 2 * lr * dy;
-        for (int p = 0; p < 2; p++) {
-          Dxx[(ia + p) * nq + ia + p] -= 2 * lr; Dxx[(ib + p) * nq + ib + p] -= 2 * lr;
-          Dxx[(ia + p) * nq + ib + p] += 2 * lr; Dxx[(ib + p) * nq + ia + p] += 2 * lr;
-        }
-      } else if (R.type == DG_R_ST_UB) Dx[D.qoff[R.a] + R.idx] += lr;
-      else if (R.type == DG_R_ST_LB) Dx[D.qoff[R.a] + R.idx] -= lr;
-    }
-  }
-  __syncthreads();
-}
-
 __device__ inline int dev_block_of(const DgProb& D, int xi) {
   int b = 0;
   while (b + 1 < D.M && xi >= D.qoff[b + 1]) b++;
   return b;
 }
 
-__device__ __noinline__ void dev_hessian_dp(const Ctx& c, int a) {
+// generic (mixed-model) variant: run-time block offsets, arrays end up in scratch memory
+template <int NQA>
+__device__ __noinline__ void dev_hessian_row_generic(const Ctx& c, int row, int a, int k0, int j0) {
   const DgProb& D = dg_prob;
   const DgLds& L = D.L;
   lptr lds = LP(0);
-  const int nq = D.nq, nu = D.nu, n = D.n, N = D.N;
-  lds_d *Dx = lds + L.e_Dx, *Dxn = lds + L.e_Dx + nq, *Dxx = lds + L.e_Dxx, *nDxx = lds + L.e_nDxx;
-  lds_d *tQA = lds + L.e_tQA, *tQB = lds + L.e_tQB, *A1 = lds + L.e_A1, *A2 = lds + L.e_A2;
-  lds_d *Dxu = lds + L.e_Dxu, *Dxu2 = lds + L.e_Dxu + n * nq;  // double-buffered rows d2/du_t dx_k
-  lds_d *Hc = lds + L.e_Hc, *cv = lds + L.e_cv, *inj = lds + L.e_inj;
-  gptr Qg = c.ws + D.ws_q;
+  const int nq = D.nq, n = D.n, N = D.N, M = D.M;
+  clptr Kc = lds + L.e_K;
+  cgptr Hg = c.ws + D.ws_H;
+  gptr tang = c.ws + D.ws_tang;
+  gptr Qrow = c.ws + D.ws_q + (int64_t)row * n;
   const dgsqp_agent_t& ag = D.P.agents[a];
-
-  dev_stage_injection(c, a, N, inj);
-  for (int i = TID; i < nq; i += NT) Dx[i] = inj[i];
-  for (int i = TID; i < nq * nq; i += NT) Dxx[i] = inj[nq + i];
-  __syncthreads();
-
-  for (int k = N - 1; k >= 0; k--) {
-    // ---- phase 1: contraction of the Taylor tensor with the costate, Dxx*A, Dxx*B, stage injection
-    for (int it = TID; it < D.M * DG_MAXDIR; it += NT) {
-      const int b = it / DG_MAXDIR, dir = it % DG_MAXDIR;
-      if (dir < D.ndir[b]) {
-        cgptr T2 = c.ws + D.ws_t2 + D.t2off[b] + (int64_t)k * D.t2k[b];
-        double s = 0;
-        for (int o = 0; o < D.nqa[b]; o++) s += Dx[D.qoff[b] + o] * T2[o * D.ndir[b] + dir];
-        cv[b * DG_MAXDIR + dir] = s;
-      }
-    }
-    for (int it = TID; it < nq * (nq + nu); it += NT) {
-      const int i = it / (nq + nu), jj = it % (nq + nu);
-      if (jj < nq) {  // tQA[i][jj] = sum_l Dxx[i][l] A[l][jj], A block diagonal
-        const int b = dev_block_of(D, jj), nqa = D.nqa[b], qo = D.qoff[b];
-        clptr A = lds + L.e_A[b] + k * nqa * nqa;
-        double s = 0;
-        for (int m = 0; m < nqa; m++) s += Dxx[i * nq + qo + m] * A[m * nqa + (jj - qo)];
-        tQA[i * nq + jj] = s;
-      } else {
-        const int cu = jj - nq, b = cu / DGSQP_NUA, j = cu % DGSQP_NUA;
-        const int nqa = D.nqa[b], qo = D.qoff[b];
-        clptr B = lds + L.e_B[b] + k * nqa * 2;
-        double s = 0;
-        for (int m = 0; m < nqa; m++) s += Dxx[i * nq + qo + m] * B[m * 2 + j];
-        tQB[i * nu + cu] = s;
-      }
-    }
-    if (k > 0) dev_stage_injection(c, a, k, inj); else __syncthreads();
-    // Hc[b][i][j]: Hessian (in effective variables) of  costate . f_d  for agent block b
-    for (int it = TID; it < D.M * DG_MAXEFF * DG_MAXEFF; it += NT) {
-      const int b = it / (DG_MAXEFF * DG_MAXEFF), i = (it / DG_MAXEFF) % DG_MAXEFF, j = it % DG_MAXEFF;
-      const int ne = D.neff[b];
-      if (i < ne && j < ne) {
-        clptr cb = cv + b * DG_MAXDIR;
-        double h;
-        if (i == j) h = 2.0 * cb[i];
-        else {
-          const int lo = i < j ? i : j, hi = i < j ? j : i;
-          const int dir = ne + lo * (ne - 1) - lo * (lo - 1) / 2 + (hi - lo - 1);
-          h = cb[dir] - cb[lo] - cb[hi];
-        }
-        Hc[it] = h;
-      }
-    }
-    __syncthreads();
-    // ---- phase 2: A1, A2, and the rows t>k of Dxu (emit B1, propagate into the other buffer)
-    for (int it = TID; it < nu * (nu + nq); it += NT) {
-      const int c1 = it / (nu + nq), jj = it % (nu + nq);
-      const int b1 = c1 / DGSQP_NUA, j1 = c1 % DGSQP_NUA, nqa1 = D.nqa[b1], qo1 = D.qoff[b1];
-      clptr B = lds + L.e_B[b1] + k * nqa1 * 2;
-      if (jj < nu) {  // A1[c1][c2] = Duu_J + B^T Dxx B + sum_i Dx_i F_i      (DGSQP.py:698-700)
-        const int c2 = jj, b2 = c2 / DGSQP_NUA, j2 = c2 % DGSQP_NUA;
-        double s = 0;
-        for (int m = 0; m < nqa1; m++) s += B[m * 2 + j1] * tQB[(qo1 + m) * nu + c2];
-        if (b1 == b2) s += Hc[(b1 * DG_MAXEFF + (D.neff[b1] - 2 + j1)) * DG_MAXEFF + (D.neff[b1] - 2 + j2)];
-        if (c1 == c2 && b1 == a) s += ag.w_in[j1] + ag.w_rate[j1] + (k + 1 < N ? ag.w_rate[j1] : 0.0);
-        A1[c1 * nu + c2] = s;
-      } else {        // A2[c1][x] = B^T Dxx A + sum_i Dx_i G_i                 (DGSQP.py:708-710)
-        const int xi = jj - nu;
-        double s = 0;
-        for (int m = 0; m < nqa1; m++) s += B[m * 2 + j1] * tQA[(qo1 + m) * nq + xi];
-        const int li = xi - qo1;
-        if (li >= 2 && li < nqa1) s += Hc[(b1 * DG_MAXEFF + (D.neff[b1] - 2 + j1)) * DG_MAXEFF + (li - 2)];
-        A2[c1 * nq + xi] = s;
-      }
-    }
-    {
-      const int nrows = (N - 1 - k) * nu, row0 = (k + 1) * nu, per = nu + nq;
-      for (int it = TID; it < nrows * per; it += NT) {
-        const int row = row0 + it / per, jj = it % per;
-        clptr old = Dxu + row * nq;
-        if (jj < nu) {   // B1 = Dxu_Q[-1] @ B_k (+ d2J/du_{k+1}du_k)                 (DGSQP.py:704-706)
-          const int t = row / nu, ju = row % nu, ar = ju / DGSQP_NUA;
-          const int cu = jj, b = cu / DGSQP_NUA, j = cu % DGSQP_NUA, nqa = D.nqa[b], qo = D.qoff[b];
-          clptr B = lds + L.e_B[b] + k * nqa * 2;
+  constexpr int EE = DG_MAXEFF * DG_MAXEFF;
+  constexpr int NE = NQA;            // effective variables: states 2..NQA-1, then the two inputs
+  const int qa = D.qoff[a];
+  // forward tangent dx_t (block a only), t = k0+1 .. N, stored to the per-workgroup scratch (coalesced over lanes)
+  double v[NQA], w[NQA];
+  {
+    clptr B = lds + L.e_B[a] + k0 * NQA * 2;
+#pragma unroll
+    for (int i = 0; i < NQA; i++) v[i] = B[i * 2 + j0];
+    for (int t = k0 + 1; t <= N; t++) {
+#pragma unroll
+      for (int i = 0; i < NQA; i++) tang[((int64_t)t * DGSQP_MAX_NQA + i) * n + row] = v[i];
+      if (t < N) {
+        clptr A = lds + L.e_A[a] + t * NQA * NQA;
+#pragma unroll
+        for (int i = 0; i < NQA; i++) {
           double s = 0;
-          for (int m = 0; m < nqa; m++) s += old[qo + m] * B[m * 2 + j];
-          if (t == k + 1 && cu == ju && b == a) s -= ag.w_rate[j];
-          const int ri = am_col(D, ar, t, ju % DGSQP_NUA), ci = am_col(D, b, k, j);
-          if (ar == a) Qg[(int64_t)ri * n + ci] = s;
-          if (b == a) Qg[(int64_t)ci * n + ri] = s;
-        } else {         // Dxu_Q[-1] @ A_k                                            (DGSQP.py:714)
-          const int jx = jj - nu, b = dev_block_of(D, jx), nqa = D.nqa[b], qo = D.qoff[b];
-          clptr A = lds + L.e_A[b] + k * nqa * nqa;
-          double s = 0;
-          for (int m = 0; m < nqa; m++) s += old[qo + m] * A[m * nqa + (jx - qo)];
-          Dxu2[row * nq + jx] = s;
+#pragma unroll
+          for (int m = 0; m < NQA; m++) s += A[i * NQA + m] * v[m];
+          w[i] = s;
         }
+#pragma unroll
+        for (int i = 0; i < NQA; i++) v[i] = w[i];
       }
     }
-    __syncthreads();
-    // ---- phase 3: emit A1, store A2 as rows of stage k, update Dxx / Dx  (DGSQP.py:696, 717-719)
-    for (int it = TID; it < nu * nu; it += NT) {
-      const int c1 = it / nu, c2 = it % nu;
-      if (c1 / DGSQP_NUA == a)
-        Qg[(int64_t)am_col(D, a, k, c1 % DGSQP_NUA) * n + am_col(D, c2 / DGSQP_NUA, k, c2 % DGSQP_NUA)] = A1[it];
-    }
-    for (int it = TID; it < nu * nq; it += NT) Dxu2[k * nu * nq + it] = A2[it];
-    if (k > 0) {
-      for (int it = TID; it < nq * nq; it += NT) {
-        const int i = it / nq, jx = it % nq;
-        const int b = dev_block_of(D, i), nqa = D.nqa[b], qo = D.qoff[b];
-        clptr A = lds + L.e_A[b] + k * nqa * nqa;
-        double s = inj[nq + it];
-        for (int m = 0; m < nqa; m++) s += A[m * nqa + (i - qo)] * tQA[(qo + m) * nq + jx];
-        const int li = i - qo, lj = jx - qo;
-        if (li >= 2 && lj >= 2 && lj < nqa) s += Hc[(b * DG_MAXEFF + (li - 2)) * DG_MAXEFF + (lj - 2)];
-        nDxx[it] = s;
-      }
-      for (int jx = TID; jx < nq; jx += NT) {
-        const int b = dev_block_of(D, jx), nqa = D.nqa[b], qo = D.qoff[b];
-        clptr A = lds + L.e_A[b] + k * nqa * nqa;
-        double s = inj[jx];
-        for (int m = 0; m < nqa; m++) s += Dx[qo + m] * A[m * nqa + (jx - qo)];
-        Dxn[jx] = s;
-      }
-    }
-    __syncthreads();
-    if (k > 0) {
-      for (int it = TID; it < nq * nq; it += NT) Dxx[it] = nDxx[it];
-      for (int it = TID; it < nq; it += NT) Dx[it] = Dxn[it];
-    }
-    { lptr t = Dxu; Dxu = Dxu2; Dxu2 = t; }
-    __syncthreads();
   }
+  // backward second-order adjoint; mu is joint (n_q) because the state Hessian couples the agents
+  double mu[DGSQP_MAX_AGENTS * DGSQP_MAX_NQA];
+  // mu_N = L_xx,N dx_N  (v holds dx_N)
+  for (int i = 0; i < nq; i++) mu[i] = 0.0;
+  {
+    clptr K = Kc + (a * (N + 1) + N) * M * 5;
+    for (int b = 0; b < M; b++) {
+      const int qb = D.qoff[b];
+      mu[qb + 0] += K[b * 5 + 0] * v[0] + K[b * 5 + 1] * v[1];
+      mu[qb + 1] += K[b * 5 + 1] * v[0] + K[b * 5 + 2] * v[1];
+      mu[qb + D.eyidx[b]] += K[b * 5 + 3] * v[NQA - 1];
+      mu[qb + D.sidx[b]] += K[b * 5 + 4] * v[NQA - 2];
+    }
+  }
+  for (int t = N - 1; t >= 0; t--) {
+    // dx_t (zero for t <= k0)
+    if (t > k0) {
+#pragma unroll
+      for (int i = 0; i < NQA; i++) v[i] = tang[((int64_t)t * DGSQP_MAX_NQA + i) * n + row];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NQA; i++) v[i] = 0.0;
+    }
+    const double du = (t == k0) ? 1.0 : 0.0;
+    // z = (dx_t effective part, du): effective variable e <-> state e+2 for e < NQA-2, inputs after
+    cgptr Ha = Hg + (((int64_t)a * N + t) * M + a) * EE;
+    double hz[NE];
+#pragma unroll
+    for (int e = 0; e < NE; e++) {
+      double s = 0;
+#pragma unroll
+      for (int f = 0; f < NQA - 2; f++) s += Ha[e * DG_MAXEFF + f] * v[f + 2];
+      s += Ha[e * DG_MAXEFF + (NQA - 2 + j0)] * du;
+      hz[e] = s;
+    }
+    // row entries of stage t: B_t^T mu_{t+1} (+ H_u. z + L_uu du for agent a's own inputs)
+    for (int b = 0; b < M; b++) {
+      const int nqb = D.nqa[b], qb = D.qoff[b];
+      clptr B = lds + L.e_B[b] + t * nqb * 2;
+      for (int j = 0; j < DGSQP_NUA; j++) {
+        double s = 0;
+        for (int m = 0; m < nqb; m++) s += B[m * 2 + j] * mu[qb + m];
+        if (b == a) {
+          s += hz[NQA - 2 + j];
+          if (j == j0) {
+            if (t == k0) s += ag.w_in[j] + ag.w_rate[j] + (t + 1 < N ? ag.w_rate[j] : 0.0);
+            else if (t == k0 + 1 || t == k0 - 1) s -= ag.w_rate[j];
+          }
+        }
+        Qrow[am_col(D, b, t, j)] = s;
+      }
+    }
+    if (t > 0) {
+      // mu_t = A_t^T mu_{t+1} + L_xx,t dx_t + (H_xx dx_t + H_xu du) on block a
+      double nm[DGSQP_MAX_AGENTS * DGSQP_MAX_NQA];
+      for (int b = 0; b < M; b++) {
+        const int nqb = D.nqa[b], qb = D.qoff[b];
+        clptr A = lds + L.e_A[b] + t * nqb * nqb;
+        for (int i = 0; i < nqb; i++) {
+          double s = 0;
+          for (int m = 0; m < nqb; m++) s += A[m * nqb + i] * mu[qb + m];
+          nm[qb + i] = s;
+        }
+      }
+      if (t > k0) {
+        clptr K = Kc + (a * (N + 1) + t) * M * 5;
+        for (int b = 0; b < M; b++) {
+          const int qb = D.qoff[b];
+          nm[qb + 0] += K[b * 5 + 0] * v[0] + K[b * 5 + 1] * v[1];
+          nm[qb + 1] += K[b * 5 + 1] * v[0] + K[b * 5 + 2] * v[1];
+          nm[qb + D.eyidx[b]] += K[b * 5 + 3] * v[NQA - 1];
+          nm[qb + D.sidx[b]] += K[b * 5 + 4] * v[NQA - 2];
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < NQA - 2; f++) nm[qa + f + 2] += hz[f];
+      for (int i = 0; i < nq; i++) mu[i] = nm[i];
+    }
+  }
+}
+
+// uniform-model variant (every agent has NQA states): all register arrays are statically indexed
+template <int NQA, int MM>
+__device__ __noinline__ void dev_hessian_row(const Ctx& c, int row, int a, int k0, int j0) {
+  const DgProb& D = dg_prob;
+  const DgLds& L = D.L;
+  lptr lds = LP(0);
+  const int n = D.n, N = D.N;
+  clptr Kc = lds + L.e_K;
+  cgptr Hg = c.ws + D.ws_H;
+  gptr tang = c.ws + D.ws_tang;
+  gptr Qrow = c.ws + D.ws_q + (int64_t)row * n;
+  const dgsqp_agent_t& ag = D.P.agents[a];
+  constexpr int EE = DG_MAXEFF * DG_MAXEFF;
+  constexpr int NU = DGSQP_NUA;
+  const double wr = ag.w_rate[j0], win = ag.w_in[j0];
+  double v[NQA], w[NQA];
+  {
+    clptr B = lds + L.e_B[a] + k0 * NQA * NU;
+#pragma unroll
+    for (int i = 0; i < NQA; i++) v[i] = B[i * NU + j0];
+    for (int t = k0 + 1; t <= N; t++) {
+#pragma unroll
+      for (int i = 0; i < NQA; i++) tang[((int64_t)t * DGSQP_MAX_NQA + i) * n + row] = v[i];
+      if (t < N) {
+        clptr A = lds + L.e_A[a] + t * NQA * NQA;
+#pragma unroll
+        for (int i = 0; i < NQA; i++) {
+          double s = 0;
+#pragma unroll
+          for (int m = 0; m < NQA; m++) s += A[i * NQA + m] * v[m];
+          w[i] = s;
+        }
+#pragma unroll
+        for (int i = 0; i < NQA; i++) v[i] = w[i];
+      }
+    }
+  }
+  double mu[MM][NQA];
+  {
+    clptr K = Kc + (a * (N + 1) + N) * MM * 5;
+#pragma unroll
+    for (int b = 0; b < MM; b++) {
+#pragma unroll
+      for (int i = 0; i < NQA; i++) mu[b][i] = 0.0;
+      mu[b][0] = K[b * 5 + 0] * v[0] + K[b * 5 + 1] * v[1];
+      mu[b][1] = K[b * 5 + 1] * v[0] + K[b * 5 + 2] * v[1];
+      mu[b][NQA - 1] = K[b * 5 + 3] * v[NQA - 1];
+      mu[b][NQA - 2] = K[b * 5 + 4] * v[NQA - 2];
+    }
+  }
+  // own-block offset in the agent-major column order
+  for (int t = N - 1; t >= 0; t--) {
+    const bool live = t > k0;
+#pragma unroll
+    for (int i = 0; i < NQA; i++) v[i] = live ? tang[((int64_t)t * DGSQP_MAX_NQA + i) * n + row] : 0.0;
+    const double du = (t == k0) ? 1.0 : 0.0;
+    cgptr Ha = Hg + (((int64_t)a * N + t) * MM + a) * EE;
+    double hz[NQA];
+#pragma unroll
+    for (int e = 0; e < NQA; e++) {
+      double s = 0;
+#pragma unroll
+      for (int f = 0; f < NQA - 2; f++) s += Ha[e * DG_MAXEFF + f] * v[f + 2];
+      s += Ha[e * DG_MAXEFF + (NQA - 2 + j0)] * du;
+      hz[e] = s;
+    }
+    double dir0 = 0.0;   // agent a's own L_uu entry on input j0 at this stage
+    if (t == k0) dir0 = win + wr + (t + 1 < N ? wr : 0.0);
+    else if (t == k0 + 1 || t == k0 - 1) dir0 = -wr;
+#pragma unroll
+    for (int b = 0; b < MM; b++) {
+      clptr B = lds + L.e_B[b] + t * NQA * NU;
+#pragma unroll
+      for (int j = 0; j < NU; j++) {
+        double s = 0;
+#pragma unroll
+        for (int m = 0; m < NQA; m++) s += B[m * NU + j] * mu[b][m];
+        if (b == a) s += (j == 0 ? hz[NQA - 2] : hz[NQA - 1]) + (j == j0 ? dir0 : 0.0);
+        Qrow[(b * N + t) * NU + j] = s;
+      }
+    }
+    if (t > 0) {
+      clptr K = Kc + (a * (N + 1) + t) * MM * 5;
+#pragma unroll
+      for (int b = 0; b < MM; b++) {
+        clptr A = lds + L.e_A[b] + t * NQA * NQA;
+        double nm[NQA];
+#pragma unroll
+        for (int i = 0; i < NQA; i++) {
+          double s = 0;
+#pragma unroll
+          for (int m = 0; m < NQA; m++) s += A[m * NQA + i] * mu[b][m];
+          nm[i] = s;
+        }
+        // state-Hessian columns (v is zero when t <= k0, so no branch is needed)
+        nm[0] += K[b * 5 + 0] * v[0] + K[b * 5 + 1] * v[1];
+        nm[1] += K[b * 5 + 1] * v[0] + K[b * 5 + 2] * v[1];
+        nm[NQA - 1] += K[b * 5 + 3] * v[NQA - 1];
+        nm[NQA - 2] += K[b * 5 + 4] * v[NQA - 2];
+        const double own = b == a ? 1.0 : 0.0;
+#pragma unroll
+        for (int f = 0; f < NQA - 2; f++) nm[f + 2] += own * hz[f];
+#pragma unroll
+        for (int i = 0; i < NQA; i++) mu[b][i] = nm[i];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Game Hessian by second-order adjoints.  Row i of Q (i an input of agent a) is the gradient of
+// dL^a/du_i, i.e. one Hessian-vector product of agent a's Lagrangian L^a = J^a + l^T C with e_i:
+//   costates      lam_k  = L_x,k + A_k^T lam_{k+1}                                    (once per agent)
+//   H_k^b         = sum_o lam_{k+1}[b,o] grad^2 f^b_{k,o}   (Taylor tensor contracted with the costate, all (a,k,b) in parallel)
+//   tangent       dx_{t+1} = A_t dx_t + B_t e_i                                        (one lane per i)
+//   2nd adjoint   mu_t   = A_t^T mu_{t+1} + (L_xx,t + H_xx,t) dx_t + H_xu,t du_t
+//   row entries   Q[i, (b,t,j)] = B_t^T mu_{t+1} + H_ux,t dx_t + (H_uu,t + L_uu) du_t
+// Mathematically identical to the reference's backward DP (DGSQP.py:679-727, :828-877, f_Q :920-934) and to its
+// own f_Duu_L (:937-941); here all N*n_u rows are independent lanes with 25 uniform steps each.
+// ------------------------------------------------------------------------------------------------
+__device__ __noinline__ void dev_hessian_adjoint(const Ctx& c) {
+  const DgProb& D = dg_prob;
+  const DgLds& L = D.L;
+  lptr lds = LP(0);
+  const int nq = D.nq, n = D.n, N = D.N, M = D.M;
+  clptr x = lds + L.e_x;
+  clptr lm = lds + L.l;
+  lptr lam = lds + L.e_lam;   // [a][k][nq]
+  lptr Dxs = lds + L.e_Dxs;   // [a][k][nq]   d/dx_k of (stage cost a + sum_r l_r c_r)
+  lptr Kc = lds + L.e_K;      // [a][k][b][5] columns (block a) of the state Hessian: Kxx, Kxy, Kyy on positions, k_ey, k_s
+  gptr Hg = c.ws + D.ws_H;    // [a][k][b][MAXEFF*MAXEFF]
+  gptr tang = c.ws + D.ws_tang;  // [t][i][lane]
+  gptr Qg = c.ws + D.ws_q;
+  const gptr T2base = c.ws + D.ws_t2;
+  constexpr int EE = DG_MAXEFF * DG_MAXEFF;
+  // ---- 0. first / second state derivatives of every agent's stage Lagrangian
+  for (int it = TID; it < M * (N + 1); it += NT) {
+    const int a = it / (N + 1), k = it % (N + 1);
+    double Dx[DGSQP_MAX_AGENTS * DGSQP_MAX_NQA];
+    double Kl[DGSQP_MAX_AGENTS * 5];
+    for (int i = 0; i < nq; i++) Dx[i] = 0.0;
+    for (int i = 0; i < M * 5; i++) Kl[i] = 0.0;
+    clptr xk = x + k * nq;
+    const dgsqp_agent_t& ag = D.P.agents[a];
+    const int ia = D.qoff[a];
+    // cost part (same terms as dev_state_cost, kept in the compact column form)
+    for (int b = 0; b < M; b++) {
+      if (b == a) continue;
+      const int ib = D.qoff[b];
+      if (ag.w_block != 0.0) {
+        const int ea = ia + D.eyidx[a], eb = ib + D.eyidx[b];
+        const double dd = xk[ea] - xk[eb];
+        Dx[ea] += ag.w_block * dd; Dx[eb] -= ag.w_block * dd;
+        Kl[a * 5 + 3] += ag.w_block; Kl[b * 5 + 3] -= ag.w_block;
+      }
+      if (ag.w_obs != 0.0) {
+        const double dx = xk[ia] - xk[ib], dy = xk[ia + 1] - xk[ib + 1];
+        const double r = sqrt(dx * dx + dy * dy);
+        const double z = (ag.obs_cost_r + D.P.agents[b].obs_cost_r) - r;
+        if (z > 0) {
+          const double ex = dx / r, ey = dy / r;
+          Dx[ia] -= ag.w_obs * z * ex; Dx[ia + 1] -= ag.w_obs * z * ey; Dx[ib] += ag.w_obs * z * ex; Dx[ib + 1] += ag.w_obs * z * ey;
+          const double hxx = ag.w_obs * (ex * ex - z * (1 - ex * ex) / r), hxy = ag.w_obs * (ex * ey + z * ex * ey / r), hyy = ag.w_obs * (ey * ey - z * (1 - ey * ey) / r);
+          Kl[a * 5 + 0] += hxx; Kl[a * 5 + 1] += hxy; Kl[a * 5 + 2] += hyy;
+          Kl[b * 5 + 0] -= hxx; Kl[b * 5 + 1] -= hxy; Kl[b * 5 + 2] -= hyy;
+        }
+      }
+    }
+    if (k == N) {
+      const int sa = ia + D.sidx[a];
+      Dx[sa] -= ag.w_prog;
+      for (int b = 0; b < M; b++) {
+        if (b == a) continue;
+        const int sb = D.qoff[b] + D.sidx[b];
+        const double dl = xk[sb] - xk[sa];
+        if (ag.comp_type == DGSQP_COMP_ATAN) {
+          const double w = 1.0 + dl * dl;
+          Dx[sb] += ag.w_comp / w; Dx[sa] -= ag.w_comp / w;
+          const double f2 = -2.0 * ag.w_comp * dl / (w * w);
+          Kl[a * 5 + 4] += f2; Kl[b * 5 + 4] -= f2;
+        } else { Dx[sb] += ag.w_comp; Dx[sa] -= ag.w_comp; }
+      }
+    }
+    // constraint part: rows of stage k (obstacle and state rows only)
+    for (int r = D.stage_row0[k]; r < D.stage_row0[k + 1]; r++) {
+      const DgRow R = ld_row(r);
+      if (R.dense < 0) continue;
+      const double lr = lm[r];
+      if (R.type == DG_R_OBS) {
+        const int ip = D.qoff[R.a], iq = D.qoff[R.b];
+        const double dx = xk[ip] - xk[iq], dy = xk[ip + 1] - xk[iq + 1];
+        Dx[ip] -= 2 * lr * dx; Dx[ip + 1] -= 2 * lr * dy; Dx[iq] += 2 * lr * dx; Dx[iq + 1] += 2 * lr * dy;
+        if (R.a == a || R.b == a) {
+          const int other = R.a == a ? R.b : R.a;
+          Kl[a * 5 + 0] -= 2 * lr; Kl[a * 5 + 2] -= 2 * lr;
+          Kl[other * 5 + 0] += 2 * lr; Kl[other * 5 + 2] += 2 * lr;
+        }
+      } else if (R.type == DG_R_ST_UB) Dx[D.qoff[R.a] + R.idx] += lr;
+      else Dx[D.qoff[R.a] + R.idx] -= lr;
+    }
+    for (int i = 0; i < nq; i++) Dxs[(a * (N + 1) + k) * nq + i] = Dx[i];
+    for (int i = 0; i < M * 5; i++) Kc[(a * (N + 1) + k) * M * 5 + i] = Kl[i];
+  }
+  __syncthreads();
+  // ---- 1. costates: one wavefront per agent, lane = state component
+  {
+    const int a = TID >> 6, i = TID & 63;
+    if (a < M) {
+      int b = 0;
+      if (i < nq) b = dev_block_of(D, i);
+      const int nqa = D.nqa[b], qo = D.qoff[b];
+      double cur = i < nq ? Dxs[(a * (N + 1) + N) * nq + i] : 0.0;
+      if (i < nq) lam[(a * (N + 1) + N) * nq + i] = cur;
+      for (int k = N - 1; k >= 1; k--) {
+        // lam_k[i] = Dx_k[i] + sum_m A_k[m][i] lam_{k+1}[m]   (A block diagonal: m in the block of i)
+        double s = i < nq ? Dxs[(a * (N + 1) + k) * nq + i] : 0.0;
+        if (i < nq) {
+          clptr A = lds + L.e_A[b] + k * nqa * nqa;
+          clptr ln = lam + (a * (N + 1) + k + 1) * nq + qo;
+          for (int m = 0; m < nqa; m++) s += A[m * nqa + (i - qo)] * ln[m];
+          lam[(a * (N + 1) + k) * nq + i] = s;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 2. H[a][k][b] = sum_o lam^a_{k+1}[b,o] * Hessian of f^b_{k,o} in effective variables (interpolated from the
+  //         e_i / e_i+e_j Taylor coefficients: H_ii = 2 c_i, H_ij = c_ij - c_i - c_j)
+  for (int it = TID; it < M * N * M * EE; it += NT) {
+    const int e = it % EE, b = (it / EE) % M, k = (it / (EE * M)) % N, a = it / (EE * M * N);
+    const int i = e / DG_MAXEFF, j = e % DG_MAXEFF, ne = D.neff[b];
+    double h = 0.0;
+    if (i < ne && j < ne) {
+      cgptr T2 = T2base + D.t2off[b] + (int64_t)k * D.t2k[b];
+      clptr lk = lam + (a * (N + 1) + k + 1) * nq + D.qoff[b];
+      const int nd = D.ndir[b];
+      if (i == j) {
+        double s = 0;
+        for (int o = 0; o < D.nqa[b]; o++) s += lk[o] * T2[o * nd + i];
+        h = 2.0 * s;
+      } else {
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        const int dir = ne + lo * (ne - 1) - lo * (lo - 1) / 2 + (hi - lo - 1);
+        double s = 0;
+        for (int o = 0; o < D.nqa[b]; o++) s += lk[o] * (T2[o * nd + dir] - T2[o * nd + lo] - T2[o * nd + hi]);
+        h = s;
+      }
+    }
+    Hg[it] = h;
+  }
+  __syncthreads();
+  // ---- 3. one lane per row of Q
+  for (int row = TID; row < n; row += NT) {
+    const int a = row / (N * DGSQP_NUA), rem = row % (N * DGSQP_NUA), k0 = rem / DGSQP_NUA, j0 = rem % DGSQP_NUA;
+    if (!D.uniform_nqa) {
+      if (D.nqa[a] == 8) dev_hessian_row_generic<8>(c, row, a, k0, j0); else dev_hessian_row_generic<6>(c, row, a, k0, j0);
+    } else if (D.nqa[0] == 8) {
+      switch (M) {
+        case 1: dev_hessian_row<8, 1>(c, row, a, k0, j0); break;
+        case 2: dev_hessian_row<8, 2>(c, row, a, k0, j0); break;
+        case 3: dev_hessian_row<8, 3>(c, row, a, k0, j0); break;
+        default: dev_hessian_row<8, 4>(c, row, a, k0, j0); break;
+      }
+    } else {
+      switch (M) {
+        case 1: dev_hessian_row<6, 1>(c, row, a, k0, j0); break;
+        case 2: dev_hessian_row<6, 2>(c, row, a, k0, j0); break;
+        case 3: dev_hessian_row<6, 3>(c, row, a, k0, j0); break;
+        default: dev_hessian_row<6, 4>(c, row, a, k0, j0); break;
+      }
+    }
+  }
+  __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------
 // _evaluate(u, l, x0, up=0, hessian)   (DGSQP.py:509-533).  `usrc` is copied into the EVAL scratch.
 // Produces q, g, packed G (LDS) and, if hessian, raw Q in the global workspace.
 // ------------------------------------------------------------------------------------------------
-__device__ inline void dev_evaluate(const Ctx& c, clptr usrc, double alpha, clptr dusrc, bool hessian) {
+// The trajectory is reused when it is already known: `xsrc` (a speculative line-search rollout of exactly this point), or
+// the EVAL scratch still holding the rollout of a bit-identical input (tag in scal[60], cleared by the phases that
+// overwrite the scratch) -- e.g. the full evaluation that follows an accepted trial point.
+#define DG_XVALID 60
+__device__ inline void dev_evaluate(const Ctx& c, clptr usrc, double alpha, clptr dusrc, bool hessian, clptr xsrc = nullptr) {
   const DgProb& D = dg_prob;
   const DgLds& L = D.L;
   lptr ue = LP(L.e_ue);
   __syncthreads();
-  for (int i = TID; i < D.n; i += NT) ue[i] = dusrc ? usrc[i] + alpha * dusrc[i] : usrc[i];
-  { PROF_BEGIN(pt_); dev_rollout(c, ue, LP(L.e_x)); PROF_END(PH_ROLLOUT, pt_); }
+  const bool tagged = LP(L.scal)[DG_XVALID] != 0.0;
+  int differs = 0;
+  for (int i = TID; i < D.n; i += NT) {
+    const double v = dusrc ? step_u(usrc[i], alpha, dusrc[i]) : usrc[i];
+    if (tagged && !xsrc) differs |= (__double_as_longlong(v) != __double_as_longlong(ue[i]));
+    ue[i] = v;
+  }
+  if (xsrc) {
+    for (int i = TID; i < (D.N + 1) * D.nq; i += NT) LP(L.e_x)[i] = xsrc[i];
+    __syncthreads();
+  } else if (!tagged || __syncthreads_or(differs)) {
+    PROF_BEGIN(pt_); dev_rollout(c, ue, LP(L.e_x)); PROF_END(PH_ROLLOUT, pt_);
+  }
+  if (TID == 0) LP(L.scal)[DG_XVALID] = 1.0;
   if (hessian) { PROF_BEGIN(pt_); dev_dyn_derivs<2>(c, ue); PROF_END(PH_DERIV2, pt_); }
   else { PROF_BEGIN(pt_); dev_dyn_derivs<1>(c, ue); PROF_END(PH_DERIV1, pt_); }
   { PROF_BEGIN(pt_); dev_chains(c, ue); dev_constraint_values(c, ue); PROF_END(PH_CHAINS, pt_); }
   if (hessian) {
     PROF_BEGIN(pt_);
-    for (int a = 0; a < D.M; a++) dev_hessian_dp(c, a);
+    dev_hessian_adjoint(c);
     PROF_END(PH_DP, pt_);
   }
   __syncthreads();

@@ -42,7 +42,7 @@ struct DgLds {
   int t_track;          // LDS copy of the track tables: seg_s[17], seg_curv[16], seg_ang[17], slope[16]
   int scr;  // start of phase scratch
   // EVAL scratch (absolute offsets)
-  int e_x, e_ue, e_A[DGSQP_MAX_AGENTS], e_B[DGSQP_MAX_AGENTS], e_dJ, e_Dx, e_Dxx, e_nDxx, e_tQA, e_tQB, e_A1, e_A2, e_Dxu, e_Hc, e_cv, e_inj;
+  int e_x, e_ue, e_A[DGSQP_MAX_AGENTS], e_B[DGSQP_MAX_AGENTS], e_dJ, e_lam, e_Dxs, e_K, e_xs;
   // EIG scratch
   int g_Bp, g_V, g_tw;  // packed P / packed Householder reflectors / tridiagonal workspace
   // QP scratch (P shares g_Bp)
@@ -59,11 +59,15 @@ struct DgProb {
   dgsqp_params_t par;
   int M, N, nq, nu, n, nc, npairs, ndense, ngd;
   int nqa[DGSQP_MAX_AGENTS], qoff[DGSQP_MAX_AGENTS], sidx[DGSQP_MAX_AGENTS], eyidx[DGSQP_MAX_AGENTS];
+  double inv_track_L;
+  int uniform_nqa;
+  int ls_spec;      // trial step sizes of _line_search_3 rolled out concurrently (speculation width)  // every agent uses the same vehicle model (statically indexed fast paths)
   int neff[DGSQP_MAX_AGENTS], ndir[DGSQP_MAX_AGENTS];
   int effvar[DGSQP_MAX_AGENTS][DG_MAXEFF];  // effective variable -> index into z = (q_0..q_{nqa-1}, u_0, u_1)
   int t2off[DGSQP_MAX_AGENTS];              // offset (doubles) of agent block in the Taylor tensor workspace
   int t2k[DGSQP_MAX_AGENTS];                // per-stage stride of that block = nqa*ndir
-  int64_t ws_t2, ws_q, ws_base, ws_doubles; // global workspace layout (doubles): Taylor tensor, raw Q, watchdog backups
+  int64_t ws_t2, ws_q, ws_base, ws_H, ws_tang, ws_doubles; // global workspace layout (doubles): Taylor tensor, raw Q, watchdog backups,
+                                                             // costate-contracted dynamics Hessians, tangent trajectories
   DgRow rows[DG_NCMAX];
   DgDense dense[DG_NDMAX];
   int16_t r_in_ub[DGSQP_MAX_AGENTS][DG_NMAX][DGSQP_NUA], r_in_lb[DGSQP_MAX_AGENTS][DG_NMAX][DGSQP_NUA];
@@ -87,7 +91,10 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   if (P.n_segs < 1 || P.n_segs > DGSQP_MAX_SEGS) return "bad track table";
   D.M = P.M; D.N = P.N; D.nq = 0; D.nu = P.M * DGSQP_NUA;
   int t2 = 0;
+  D.uniform_nqa = 1;
+  D.inv_track_L = 1.0 / P.track_L;
   for (int a = 0; a < P.M; a++) {
+    if (P.agents[a].model != P.agents[0].model) D.uniform_nqa = 0;
     const bool dyn = P.agents[a].model == DGSQP_MODEL_DYN_BICYCLE;
     if (P.agents[a].model != DGSQP_MODEL_KIN_BICYCLE && !dyn) return "unsupported vehicle model";
     D.nqa[a] = dyn ? 8 : 6;
@@ -163,7 +170,9 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   D.ws_t2 = 0;
   D.ws_q = D.ws_t2 + t2;
   D.ws_base = D.ws_q + (int64_t)D.n * D.n;
-  D.ws_doubles = D.ws_base + 2 * D.n + 2 * D.nc + 16;
+  D.ws_H = D.ws_base + 2 * D.n + 2 * D.nc + 16;
+  D.ws_tang = D.ws_H + (int64_t)D.M * D.N * D.M * (DG_MAXEFF * DG_MAXEFF);
+  D.ws_doubles = D.ws_tang + (int64_t)(D.N + 1) * DGSQP_MAX_NQA * D.n;
   D.ws_doubles = (D.ws_doubles + 31) / 32 * 32;
   // ---- LDS arena
   DgLds& L = D.L;
@@ -179,10 +188,8 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   L.e_x = take((N + 1) * nq); L.e_ue = take(n);
   for (int a = 0; a < D.M; a++) { L.e_A[a] = take(N * D.nqa[a] * D.nqa[a]); L.e_B[a] = take(N * D.nqa[a] * DGSQP_NUA); }
   L.e_dJ = take((N + 1) * nq);
-  L.e_Dx = take(2 * nq); L.e_Dxx = take(nq * nq); L.e_nDxx = take(nq * nq); L.e_tQA = take(nq * nq); L.e_tQB = take(nq * nu);
-  L.e_A1 = take(nu * nu); L.e_A2 = take(nu * nq); L.e_Dxu = take(2 * n * nq);
-  L.e_Hc = take(D.M * (DG_MAXEFF * DG_MAXEFF)); L.e_cv = take(D.M * DG_MAXDIR); L.e_inj = take(nq + nq * nq);
-  const int eval_end = o;
+  L.e_lam = take(D.M * (N + 1) * nq); L.e_Dxs = take(D.M * (N + 1) * nq); L.e_K = take(D.M * (N + 1) * D.M * 5);
+  int eval_end = o;
   // EIG: packed P, packed Householder reflectors, tridiagonal workspace
   o = L.scr;
   const int npk = n * (n + 1) / 2;
@@ -203,6 +210,22 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   o = L.scr;
   L.s_u = take(nc); L.s_v = take(nc); L.s_w = take(nc); L.s_x = take(nc); L.s_t = take(nc > n ? nc : n);
   const int lsqr_end = o;
+  {
+    // give the speculative rollouts the scratch the EIG / QP phases need anyway (the arena does not grow for them)
+    int tot0 = eig_end > out_end ? eig_end : out_end;
+    if (lsqr_end > tot0) tot0 = lsqr_end;
+    const int xsz = ((N + 1) * nq + 1) & ~1;
+    bool all_dyn = true;
+    for (int a = 0; a < D.M; a++) all_dyn = all_dyn && D.nqa[a] == 8;
+    const int lanes_per_traj = all_dyn ? 2 * D.M : D.M;
+    L.e_xs = eval_end > lsqr_end ? eval_end : lsqr_end;   // above everything a trial evaluation / merit touches
+    int K = (L.o_du - L.e_xs) / xsz;                      // must end below the QP outputs (du, lhat are live during trials)
+    if (K > 64 / lanes_per_traj) K = 64 / lanes_per_traj;
+    if (K > 16) K = 16;
+    if (K < 1) K = 0;
+    D.ls_spec = K;
+    if (L.e_xs + K * xsz > eval_end) eval_end = L.e_xs + K * xsz;
+  }
   int tot = eval_end;
   if (eig_end > tot) tot = eig_end;
   if (out_end > tot) tot = out_end;

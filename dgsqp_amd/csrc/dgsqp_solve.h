@@ -344,6 +344,7 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
 }
 
 __device__ inline void dev_psd_inverse(const Ctx& c, gptr Qpd) {
+  if (TID == 0) LP(dg_prob.L.scal)[DG_XVALID] = 0.0;   // the EIG scratch overwrites the trajectory
   const int n = dg_prob.n;
   bool ok;
   if (n <= 32) ok = dev_psd_inverse_tridiag<32 / DG_NH>(c, Qpd);
@@ -673,6 +674,7 @@ __device__ inline void dev_sym_ortho(double a, double b, double& cs, double& sn,
   else { const double tau = b / a; cs = ((a > 0) - (a < 0)) / sqrt(1 + tau * tau); sn = cs * tau; r = a / cs; }
 }
 __device__ __noinline__ void dev_dual_init(const Ctx& c) {
+  if (TID == 0) LP(dg_prob.L.scal)[DG_XVALID] = 0.0;   // the LSQR vectors overwrite the trajectory
   const DgProb& D = dg_prob;
   const DgLds& L = D.L;
   lptr lds = LP(0);
@@ -869,15 +871,25 @@ __device__ inline double dev_line_search(const Ctx& c, double mu, double phi, do
   const DgLds& L = D.L;
   lptr lds = LP(0);
   double alpha = 1.0, phit = 0.0;
+  const int K = D.ls_spec, xsz = ((D.N + 1) * D.nq + 1) & ~1;
   for (int i = 0; i < D.par.line_search_iters; i++) {
-    dev_evaluate(c, lds + L.u, alpha, lds + L.o_du, false);
+    if (K > 1) {
+      // trial step sizes are known in advance: roll the next K of them out concurrently, then test them in order
+      if (i % K == 0) {
+        PROF_BEGIN(pt_);
+        const int left = D.par.line_search_iters - i;
+        dev_rollout_multi(c, lds + L.u, lds + L.o_du, alpha, D.par.tau, left < K ? left : K, lds + L.e_xs, xsz);
+        PROF_END(PH_ROLLOUT, pt_);
+      }
+      dev_evaluate(c, lds + L.u, alpha, lds + L.o_du, false, lds + L.e_xs + (i % K) * xsz);
+    } else dev_evaluate(c, lds + L.u, alpha, lds + L.o_du, false);
     phit = dev_phi_trial(c, alpha, S0 + alpha * S1, mu);
     dev_tr(c, 30, alpha); dev_tr(c, 31, phit);
     if (phit <= phi + D.par.beta * alpha * dphi) break;
     if (i + 1 < D.par.line_search_iters) alpha *= D.par.tau;
   }
   __syncthreads();
-  for (int i = TID; i < D.n; i += NT) lds[L.u + i] += alpha * lds[L.o_du + i];
+  for (int i = TID; i < D.n; i += NT) lds[L.u + i] = step_u(lds[L.u + i], alpha, lds[L.o_du + i]);
   for (int r = TID; r < D.nc; r += NT) lds[L.l + r] += alpha * (lds[L.o_lhat + r] - lds[L.l + r]);
   __syncthreads();
   return phit;
@@ -926,7 +938,7 @@ __device__ inline void dev_take_full_step(const Ctx& c) {  // u += du ; l = lhat
   const DgProb& D = dg_prob;
   const DgLds& L = D.L;
   __syncthreads();
-  for (int i = TID; i < D.n; i += NT) LP(0)[L.u + i] += LP(0)[L.o_du + i];
+  for (int i = TID; i < D.n; i += NT) LP(0)[L.u + i] = step_u(LP(0)[L.u + i], 1.0, LP(0)[L.o_du + i]);
   for (int r = TID; r < D.nc; r += NT) LP(0)[L.l + r] = LP(0)[L.o_lhat + r];
   __syncthreads();
 }
@@ -1011,6 +1023,7 @@ __device__ inline void dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
   lptr lds = LP(0);
   const int n = D.n, nc = D.nc;
   __syncthreads();
+  if (TID == 0) lds[L.scal + DG_XVALID] = 0.0;
   for (int i = TID; i < n; i += NT) lds[L.u + i] = u_ws[i];
   for (int r = TID; r < nc; r += NT) lds[L.l + r] = 0.0;
   __syncthreads();

@@ -23,3 +23,17 @@ if hasattr(lib, 'dgsqp_prof_read'):
     for i in range(nph):
         if buf[2 * i + 1]:
             print(f'  {names[i]:8s} cycles {buf[2*i]:>16d} calls {buf[2*i+1]:>9d} per call {buf[2*i]/buf[2*i+1]:>12.0f} share {buf[2*i]/max(tot,1):.3f}')
+
+if hasattr(lib, 'dgsqp_prof_scn'):
+    sc = (ctypes.c_ulonglong * B)()
+    if lib.dgsqp_prof_scn(sc, B) == 0:
+        cyc = np.array(sc[:], dtype=np.float64)
+        order = np.argsort(-cyc)
+        print('total Mcycles', cyc.sum() / 1e6, 'mean', cyc.mean() / 1e6, 'max', cyc.max() / 1e6)
+        for i in order[:12]:
+            print(f'  scn {i:5d} Mcyc {cyc[i]/1e6:9.1f} status {st[i]} iters {res["num_iters"][i]} qps {res["qp_solves"][i]} Mcyc/qp {cyc[i]/1e6/max(res["qp_solves"][i],1):.2f}')
+        qps = res['qp_solves'].astype(float)
+        print('corr Mcyc/qp overall', cyc.sum() / 1e6 / qps.sum())
+        for lo, hi in ((0, 10), (10, 20), (20, 50), (50, 100), (100, 1000)):
+            m = (qps >= lo) & (qps < hi)
+            if m.any(): print(f'  qps in [{lo},{hi}): n={m.sum()} Mcyc/qp {cyc[m].sum()/1e6/qps[m].sum():.2f} share of total {cyc[m].sum()/cyc.sum():.3f}')
