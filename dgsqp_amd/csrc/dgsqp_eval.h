@@ -826,6 +826,7 @@ __device__ __noinline__ void dev_hessian_adjoint(const Ctx& c) {
 // the EVAL scratch still holding the rollout of a bit-identical input (tag in scal[60], cleared by the phases that
 // overwrite the scratch) -- e.g. the full evaluation that follows an accepted trial point.
 #define DG_XVALID 60
+#define DG_QP_NPREV 59   // scal slot: size of the saved active set
 __device__ inline void dev_evaluate(const Ctx& c, clptr usrc, double alpha, clptr dusrc, bool hessian, clptr xsrc = nullptr) {
   const DgProb& D = dg_prob;
   const DgLds& L = D.L;

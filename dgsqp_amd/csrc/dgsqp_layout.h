@@ -38,6 +38,7 @@ struct DgDense {    // one distinct dense gradient: d x^a_k[idx] / du   or the o
 struct DgLds {
   // persistent
   int u, l, q, g, d, v, gd, yd, red, scal;
+  int w_prev;           // active set of the previous QP (ints)
   int t_rows, t_dense;  // LDS copies of the row / dense-gradient tables (8 and 16 bytes per entry)
   int t_track;          // LDS copy of the track tables: seg_s[17], seg_curv[16], seg_ang[17], slope[16]
   int scr;  // start of phase scratch
@@ -181,6 +182,8 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
   L.u = take(n); L.l = take(nc); L.q = take(n); L.g = take(nc); L.d = take(n); L.v = take(n);
   L.gd = take(D.ngd); L.yd = take(nd); L.red = take(64); L.scal = take(64);
+  L.w_prev = take((n + 2) / 2 + 1);   // final active set of the previous QP of this scenario (warm start)
+  L.w_prev = take((n + 2) / 2 + 1);
   L.t_rows = take(nc); L.t_dense = take(2 * nd); L.t_track = take(4 * (DGSQP_MAX_SEGS + 1));
   L.scr = o;
   // EVAL

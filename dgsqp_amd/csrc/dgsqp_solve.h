@@ -450,6 +450,67 @@ __device__ inline double qp_wave_solve(clptr R, int m, int lane, clptr cvec, lpt
   return ww;
 }
 
+// wavefront-0 helper: forward substitution only, R^T w = c; w to wv, returns |w|^2 to every lane
+__device__ inline double qp_wave_fwd(clptr R, int m, int lane, clptr cvec, lptr wv) {
+  double c0 = lane < m ? cvec[lane] : 0.0, c1 = lane + 64 < m ? cvec[lane + 64] : 0.0;
+  double w0 = 0, w1 = 0;
+  for (int i = 0; i < m; i++) {
+    const double ci = lane_bcast(i < 64 ? c0 : c1, i & 63);
+    const double wi = ci / R[tri(i, i)];
+    if (lane == (i & 63)) { if (i < 64) w0 = wi; else w1 = wi; }
+    if (lane > i && lane < m) c0 -= R[tri(lane, i)] * wi;
+    if (lane + 64 > i && lane + 64 < m) c1 -= R[tri(lane + 64, i)] * wi;
+  }
+  if (lane < m) wv[lane] = w0;
+  if (lane + 64 < m) wv[lane + 64] = w1;
+  return wave_sum(w0 * w0 + w1 * w1);
+}
+
+// wavefront-0 helper: remove active constraint jd (column deletion in R followed by Givens rotations)
+typedef __attribute__((address_space(3))) int lds_i_t;
+typedef __attribute__((address_space(3))) unsigned char lds_b_t;
+__device__ inline void qp_wave_drop(lptr R, lds_i_t* alist, lptr lam, lds_b_t* act, int m, int jd, int lane) {
+    const int mn = m - 1;
+    const int ca = lane, cb = lane + 64;
+    const bool sa = ca >= jd && ca < mn, sb = cb >= jd && cb < mn;
+    if (lane == 0) act[alist[jd]] = 0;
+    // old diagonals become the sub-diagonal of the shifted columns
+    double suba = sa ? R[tri(ca + 1, ca + 1)] : 0.0, subb = sb ? R[tri(cb + 1, cb + 1)] : 0.0;
+    const int ala = sa ? alist[ca + 1] : 0, alb = sb ? alist[cb + 1] : 0;
+    const double lma = sa ? lam[ca + 1] : 0.0, lmb = sb ? lam[cb + 1] : 0.0;
+    for (int i = 0; i < mn; i++) {  // row-synchronous shift: new column cc <- old column cc+1, rows 0..cc
+      double ta = 0, tb = 0;
+      const bool da = sa && i <= ca, db = sb && i <= cb;
+      if (da) ta = R[tri(ca + 1, i)];
+      if (db) tb = R[tri(cb + 1, i)];
+      if (da) R[tri(ca, i)] = ta;
+      if (db) R[tri(cb, i)] = tb;
+    }
+    if (sa) { alist[ca] = ala; lam[ca] = lma; }
+    if (sb) { alist[cb] = alb; lam[cb] = lmb; }
+    for (int k = jd; k < mn; k++) {
+      double dk = 0;
+      if (lane == (k & 63)) dk = R[tri(k, k)];
+      dk = lane_bcast(dk, k & 63);
+      const double sub = lane_bcast(k < 64 ? suba : subb, k & 63);
+      const double h = hypot(dk, sub);
+      const double cs = h > 0 ? dk / h : 1.0, sn = h > 0 ? sub / h : 0.0;
+      if (lane == (k & 63)) R[tri(k, k)] = h;
+      if (ca > k && ca < mn) {
+        const double ra = R[tri(ca, k)];
+        if (ca == k + 0) {}
+        const double rb = R[tri(ca, k + 1)];
+        R[tri(ca, k)] = cs * ra + sn * rb;
+        R[tri(ca, k + 1)] = -sn * ra + cs * rb;
+      }
+      if (cb > k && cb < mn) {
+        const double ra = R[tri(cb, k)], rb = R[tri(cb, k + 1)];
+        R[tri(cb, k)] = cs * ra + sn * rb;
+        R[tri(cb, k + 1)] = -sn * ra + cs * rb;
+      }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // _solve_qp core (DGSQP.py:246):  min 1/2 x'Bx + q'x  s.t.  G x <= -g   with P = B^-1 in LDS.
 // Dual active-set method (Goldfarb-Idnani 1983) in range-space form: the Cholesky factor R of the
@@ -484,6 +545,91 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
   dev_p_mul(c, q, x, -1.0);  // unconstrained minimiser x = -P q
   int m = 0;
   int ret = 2;
+  // ---- warm start from the final active set W of this scenario's previous QP.  (x(W'), W') with x(W') the minimiser on
+  // the rows W' held as equalities and multipliers >= 0 is a valid S-pair for any independent W' subset of W, so the dual
+  // method continues from it and reaches the same (unique) minimiser; only the path is shorter.  Building R for W costs
+  // one P a_j (a column copy for box / rate rows) and one forward substitution per row instead of a full dual step.
+  lds_i* prev = (lds_i*)(lds + L.w_prev);
+  const int nprev = D.par.qp_warm_start ? (int)scal[DG_QP_NPREV] : 0;
+  if (nprev > 0) {
+    PROF_BEGIN(pqw);
+    clptr Pp = LP(L.g_Bp);
+    PROF_BEGIN(pw1);
+    for (int jj = 0; jj < nprev; jj++) {
+      const int p = prev[jj];
+      const DgRow Rw = ld_row(p);
+      __syncthreads();
+      if (Rw.dense < 0) {
+        const int c1 = am_col(D, Rw.a, Rw.k, Rw.idx);
+        const bool has0 = (Rw.type == DG_R_RATE_UB || Rw.type == DG_R_RATE_LB) && Rw.k > 0;
+        const double sgn = (Rw.type == DG_R_IN_UB || Rw.type == DG_R_RATE_UB) ? 1.0 : -1.0;
+        for (int i = TID; i < n; i += NT) {
+          double pv = Pp[tri(i, c1)], av = i == c1 ? 1.0 : 0.0;
+          if (has0) { pv -= Pp[tri(i, c1 - DGSQP_NUA)]; if (i == c1 - DGSQP_NUA) av = -1.0; }
+          y[i] = sgn * pv; tv[i] = sgn * av;
+        }
+      } else {
+        for (int col = TID; col < n; col += NT) tv[col] = g_row_coef(D, gd, p, col);
+        dev_p_mul(c, tv, y, 1.0);
+      }
+      __syncthreads();
+      for (int j = TID; j < m; j += NT) cvec[j] = g_row_dot(D, gd, alist[j], y);
+      double part = 0, part2 = 0;
+      for (int i = TID; i < n; i += NT) { part += tv[i] * y[i]; part2 += tv[i] * tv[i]; }
+      const double app = block_sum(part, red);
+      const double apap = block_sum(part2, red);
+      if (TID < 64) {
+        const double ww = qp_wave_fwd(R, m, lane, cvec, wv);
+        const double delta = app - ww;
+        const bool indep = delta > 1e-11 * app && delta > 1e-18 * apap;
+        if (indep) {
+          if (lane < m) R[tri(m, lane)] = wv[lane];
+          if (lane + 64 < m) R[tri(m, lane + 64)] = wv[lane + 64];
+          if (lane == 0) { R[tri(m, m)] = sqrt(delta); alist[m] = p; act[p] = 1; }
+        }
+        if (lane == 0) scal[0] = indep ? 1.0 : 0.0;
+      }
+      __syncthreads();
+      if (scal[0] != 0.0) m++;
+    }
+    PROF_END(PH_W_BUILD, pw1);
+    PROF_BEGIN(pw2);
+    // multipliers of W held as equalities at the unconstrained minimiser; negative ones leave one at a time
+    while (m > 0) {
+      __syncthreads();
+      for (int j = TID; j < m; j += NT) cvec[j] = g[alist[j]] + g_row_dot(D, gd, alist[j], x);
+      __syncthreads();
+      if (TID < 64) {
+        double r0, r1;
+        (void)qp_wave_solve(R, m, lane, cvec, wv, rv, r0, r1);
+        double worst = 0.0; int jd = NONE;
+        if (lane < m && r0 < worst) { worst = r0; jd = lane; }
+        if (lane + 64 < m && r1 < worst) { worst = r1; jd = lane + 64; }
+        wave_argmin(worst, jd);
+        if (jd != NONE) qp_wave_drop(R, alist, lam, act, m, jd, lane);
+        if (lane == 0) scal[1] = (double)jd;
+      }
+      __syncthreads();
+      if ((int)scal[1] == NONE) break;
+      m--;
+    }
+    __syncthreads();
+    PROF_END(PH_W_MULT, pw2);
+    PROF_BEGIN(pw3);
+    if (m > 0) {
+      for (int j = TID; j < m; j += NT) lam[j] = rv[j];
+      for (int col = TID; col < n; col += NT) {
+        double s2 = 0;
+        for (int j = 0; j < m; j++) s2 += rv[j] * g_row_coef(D, gd, alist[j], col);
+        z[col] = s2;
+      }
+      dev_p_mul(c, z, cvec, 1.0);
+      for (int i = TID; i < n; i += NT) x[i] -= cvec[i];
+      __syncthreads();
+    }
+    PROF_END(PH_W_X, pw3);
+    PROF_END(PH_Q_WARM, pqw);
+  }
   const int max_outer = 4 * (n + nc);
   for (int iter = 0; iter < max_outer; iter++) {
     // ---- step 1: most violated inactive constraint (lowest index on ties)
@@ -575,47 +721,7 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
 #ifdef DG_PROF
       if (TID == 0) { atomicAdd(&dg_prof[2 * PH_SWEEP + 1], 1ULL); }
 #endif
-      if (TID < 64) {
-        const int mn = m - 1;
-        const int ca = lane, cb = lane + 64;
-        const bool sa = ca >= jd && ca < mn, sb = cb >= jd && cb < mn;
-        if (lane == 0) act[alist[jd]] = 0;
-        // old diagonals become the sub-diagonal of the shifted columns
-        double suba = sa ? R[tri(ca + 1, ca + 1)] : 0.0, subb = sb ? R[tri(cb + 1, cb + 1)] : 0.0;
-        const int ala = sa ? alist[ca + 1] : 0, alb = sb ? alist[cb + 1] : 0;
-        const double lma = sa ? lam[ca + 1] : 0.0, lmb = sb ? lam[cb + 1] : 0.0;
-        for (int i = 0; i < mn; i++) {  // row-synchronous shift: new column cc <- old column cc+1, rows 0..cc
-          double ta = 0, tb = 0;
-          const bool da = sa && i <= ca, db = sb && i <= cb;
-          if (da) ta = R[tri(ca + 1, i)];
-          if (db) tb = R[tri(cb + 1, i)];
-          if (da) R[tri(ca, i)] = ta;
-          if (db) R[tri(cb, i)] = tb;
-        }
-        if (sa) { alist[ca] = ala; lam[ca] = lma; }
-        if (sb) { alist[cb] = alb; lam[cb] = lmb; }
-        for (int k = jd; k < mn; k++) {
-          double dk = 0;
-          if (lane == (k & 63)) dk = R[tri(k, k)];
-          dk = lane_bcast(dk, k & 63);
-          const double sub = lane_bcast(k < 64 ? suba : subb, k & 63);
-          const double h = hypot(dk, sub);
-          const double cs = h > 0 ? dk / h : 1.0, sn = h > 0 ? sub / h : 0.0;
-          if (lane == (k & 63)) R[tri(k, k)] = h;
-          if (ca > k && ca < mn) {
-            const double ra = R[tri(ca, k)];
-            if (ca == k + 0) {}
-            const double rb = R[tri(ca, k + 1)];
-            R[tri(ca, k)] = cs * ra + sn * rb;
-            R[tri(ca, k + 1)] = -sn * ra + cs * rb;
-          }
-          if (cb > k && cb < mn) {
-            const double ra = R[tri(cb, k)], rb = R[tri(cb, k + 1)];
-            R[tri(cb, k)] = cs * ra + sn * rb;
-            R[tri(cb, k + 1)] = -sn * ra + cs * rb;
-          }
-        }
-      }
+      if (TID < 64) qp_wave_drop(R, alist, lam, act, m, jd, lane);
       m--;
       __syncthreads();
       PROF_END(PH_Q_UPD, pq5);
@@ -649,7 +755,8 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
   for (int r = TID; r < nc; r += NT) lhat[r] = 0.0;
   __syncthreads();
   if (ret == 0)
-    for (int j = TID; j < m; j += NT) lhat[alist[j]] = lam[j];
+    for (int j = TID; j < m; j += NT) { lhat[alist[j]] = lam[j]; prev[j] = alist[j]; }
+  if (TID == 0) scal[DG_QP_NPREV] = ret == 0 ? (double)m : 0.0;
   __syncthreads();
   PROF_END(PH_QP, pt_qp);
   return ret;
@@ -1023,7 +1130,7 @@ __device__ inline void dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
   lptr lds = LP(0);
   const int n = D.n, nc = D.nc;
   __syncthreads();
-  if (TID == 0) lds[L.scal + DG_XVALID] = 0.0;
+  if (TID == 0) { lds[L.scal + DG_XVALID] = 0.0; lds[L.scal + DG_QP_NPREV] = 0.0; }
   for (int i = TID; i < n; i += NT) lds[L.u + i] = u_ws[i];
   for (int r = TID; r < nc; r += NT) lds[L.l + r] = 0.0;
   __syncthreads();

@@ -129,6 +129,7 @@ def build_params(params: DGSQPParams) -> _ffi.ParamsT:
     p.rel_tol_req = 3                      # DGSQP.py:56
     p.lsqr_iter_lim = 0                    # scipy default 2*n_c
     p.lsqr_atol = p.lsqr_btol = 1e-6       # scipy >= 1.12 defaults of sparse.linalg.lsqr
+    p.qp_warm_start = int(getattr(params, 'qp_warm_start', 1))
     return p
 
 

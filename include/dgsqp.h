@@ -130,6 +130,9 @@ typedef struct {
   int32_t rel_tol_req;    /* 3 (DGSQP.py:56) */
   int32_t lsqr_iter_lim;  /* 0 => 2*n_c (scipy default, DGSQP.py:324) */
   double lsqr_atol, lsqr_btol; /* scipy 1.15 defaults 1e-6 */
+  int32_t qp_warm_start;  /* implementation knob (not in DGSQPParams): 1 = start each QP's active-set search from the
+                             previous QP's final active set (same minimiser, shorter path); 0 = cold start */
+  int32_t reserved_;
 } dgsqp_params_t;
 
 typedef struct {

@@ -224,3 +224,59 @@ def test_statistical_parity_at_default_lsqr_tolerance(oracle, games):
     assert abs(res['num_iters'][both].mean() - ref['num_iters'][both].mean()) <= 0.1 * ref['num_iters'][both].mean()
     for b in np.where(both)[0]:          # converged to the same equilibrium
         assert rel(res['u'][b], ref['u'][b]) < 5e-3, b
+
+
+def test_qp_warm_start_from_unrelated_active_set(oracle, games, solvers):
+    """Warm start of the dual active-set method: with more scenarios than workgroups the QP test hook starts every
+    later QP from the final active set of an UNRELATED scenario; the minimiser must not depend on the guess."""
+    from dgsqp_amd.montecarlo import sample_scenarios
+    g, P, par = games['kb_curve_N10']
+    s = solvers['kb_curve_N10']
+    B = 1200                                   # > 256 CUs x resident workgroups
+    x0, u_tm = sample_scenarios(g, B, seed=31)
+    u = agent_major(u_tm)
+    rng = np.random.default_rng(5)
+    l = np.maximum(0.0, rng.normal(0.0, 0.3, size=(B, s.dims.n_c)))
+    qp = s.qp_batch(x0, u, l)
+    checked = 0
+    for b in list(range(B - 40, B)) + list(range(0, 8)):          # the tail is certainly warm-started
+        o = oracle.evaluate(P, x0[b], u[b], l[b], 1)
+        Qpd = oracle.nearest_pd(o['Q'], par.reg)
+        du, lam, flag = oracle.qp(Qpd, o['q'], o['G'], o['g'])
+        assert qp['flag'][b] == flag
+        if flag != 0:
+            continue
+        cond_scale = max(1.0, np.abs(o['Q']).max() / max(1e-300, np.abs(Qpd).max()))
+        assert rel(qp['du'][b], du) < 1e-8 * cond_scale and rel(qp['lhat'][b], lam) < 1e-6 * cond_scale
+        assert np.array_equal(qp['lhat'][b] > 0, lam > 0)
+        checked += 1
+    assert checked >= 30
+
+
+def test_solve_same_with_and_without_qp_warm_start(games):
+    """qp_warm_start only shortens the active-set path: flags, iteration and QP counts and iterates agree with the
+    cold-started solver on the well-conditioned scenarios."""
+    from dgsqp_amd.montecarlo import sample_scenarios
+    from dgsqp_amd.solver import DGSQP
+    import dgsqp_amd.solver as sv
+    g, P, par = games['kb_chicane_N15']
+    x0, u_tm = sample_scenarios(g, 48, seed=77)
+    res = {}
+    orig = sv.build_params
+    for ws in (0, 1):
+        def bp(p, ws=ws):
+            q = tight_lsqr(orig(p))
+            q.qp_warm_start = ws
+            return q
+        sv.build_params = bp
+        try:
+            res[ws] = DGSQP(*g.solver_args(), print_method=None).solve_batch(x0, u_tm)
+        finally:
+            sv.build_params = orig
+    a, b = res[0], res[1]
+    same = (a['status'] == b['status']) & (a['num_iters'] == b['num_iters']) & (a['qp_solves'] == b['qp_solves'])
+    assert same.mean() >= 0.9, (a['num_iters'], b['num_iters'])
+    easy = same & (a['num_iters'] < 30) & (a['status'] <= 1)
+    assert easy.sum() >= 20
+    for i in np.nonzero(easy)[0]:
+        assert rel(a['u'][i], b['u'][i]) < 1e-6 and rel(a['l'][i], b['l'][i]) < 1e-5
