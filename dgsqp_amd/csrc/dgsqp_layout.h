@@ -13,6 +13,7 @@
 #define DG_MAXEFF 8       // effective variables of one agent's dynamics (dyn bicycle: 6 states + 2 inputs)
 #define DG_MAXDIR 36      // MAXEFF*(MAXEFF+1)/2 Taylor directions
 #ifndef DG_BLOCK
+#define DG_PSD_KMAX 16   // negative eigenpairs handled per batch (two per wavefront)
 #define DG_BLOCK 512      // threads per scenario workgroup (8 wavefronts = 2 per SIMD, to hide LDS latency)
 #endif
 #define DG_NH (DG_BLOCK / 128)  // row-groups of the register-resident matrix slices (thread = column x row-group)
@@ -198,7 +199,7 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   const int npk = n * (n + 1) / 2;
   const int rpt = (n <= 32 ? 32 : (n <= 64 ? 64 : (n <= 100 ? 100 : 128))) / DG_NH;
   L.g_Bp = take(npk); L.g_V = take(npk);
-  L.g_tw = take((5 + DG_NH) * n + 16 + 10 * n /* Z */ + (10 * 3 * n > 3 * (DG_NH * rpt + 4) ? 10 * 3 * n : 3 * (DG_NH * rpt + 4)));
+  L.g_tw = take((5 + DG_NH) * n + 16 + DG_PSD_KMAX * n /* Z */ + 3 * (DG_NH * rpt + 4));
   const int eig_end = o;
   // QP (P aliases Bp)
   o = L.scr + ((npk + 1) & ~1);

@@ -18,7 +18,7 @@ __device__ inline int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : 
 // Returns false (nothing written) when there are more than PSD_KMAX negative eigenvalues: caller falls back
 // to the Jacobi route.
 // ------------------------------------------------------------------------------------------------
-#define PSD_KMAX 10
+#define PSD_KMAX DG_PSD_KMAX
 // Number of eigenvalues of the symmetric tridiagonal (d, e) below sigma = number of sign changes of the
 // Sturm sequence p_0 = 1, p_1 = d_0 - s, p_{i+1} = (d_i - s) p_i - e_{i-1}^2 p_{i-1}  (division-free, rescaled).
 __device__ inline int sturm_count(clptr d, clptr e2, int n, double sigma, double pivmin) {
@@ -37,6 +37,85 @@ __device__ inline int sturm_count(clptr d, clptr e2, int n, double sigma, double
   }
   return cnt;
 }
+// Sturm count (number of eigenvalues of the tridiagonal below sigma) with d and e^2 DISTRIBUTED OVER THE LANES of the
+// calling wavefront (xA: rows 0..63, xB: rows 64..127) and fetched with v_readlane: the loop index is wave-uniform, so
+// the operands arrive as scalars and the only latency left is the recurrence itself (LAPACK dlaebz form
+// q_i = (d_i - s) - e_{i-1}^2 / q_{i-1}, |q| <= pivmin -> -pivmin).  sigma may differ per lane (64 shifts at once).
+__device__ inline int sturm_count_reg(double dA, double dB, double e2A, double e2B, int n, double sigma, double pivmin) {
+  double q = lane_bcast(dA, 0) - sigma;
+  q = (__builtin_fabs(q) <= pivmin) ? -pivmin : q;
+  int cnt = q < 0.0;
+  const int n1 = n < 65 ? n : 65;
+  for (int i = 1; i < n1; i++) {                      // rows 1..64 take e2 from the A half
+    const double di = lane_bcast(i < 64 ? dA : dB, i & 63), ei = lane_bcast(e2A, i - 1);
+    q = (di - sigma) - ei * fast_rcp(q);
+    q = (__builtin_fabs(q) <= pivmin) ? -pivmin : q;
+    cnt += q < 0.0;
+  }
+  for (int i = 65; i < n; i++) {
+    const double di = lane_bcast(dB, i - 64), ei = lane_bcast(e2B, i - 65);
+    q = (di - sigma) - ei * fast_rcp(q);
+    q = (__builtin_fabs(q) <= pivmin) ? -pivmin : q;
+    cnt += q < 0.0;
+  }
+  return cnt;
+}
+// Eigenvector of the tridiagonal for the (accurately known) eigenvalue lam by the twisted factorisation of T - lam I
+// (Parlett & Dhillon; LAPACK dlar1v): stationary qd from the top, progressive qd from the bottom, twist where
+// |gamma_r| = |D+_r + D-_r - (d_r - lam)| is smallest, then z_r = 1 and the two two-term recurrences.  One wavefront
+// per eigenvalue; everything lives in lane-distributed registers (lane i <-> rows i, i+64).  z is returned max-normalised.
+__device__ inline void twisted_eigvec(double dA, double dB, double eA, double eB, int n, double lam, double pivmin, int lane,
+                                      double& zA, double& zB) {
+  const double e2A = eA * eA, e2B = eB * eB;
+  double DpA = 0, DpB = 0, DmA = 0, DmB = 0, DsA = 0, DsB = 0;   // D+_i, D-_i, D-_{i+1}
+  double qf = lane_bcast(dA, 0) - lam;
+  qf = (__builtin_fabs(qf) <= pivmin) ? -pivmin : qf;
+  const int nl = n - 1;
+  double qb = lane_bcast(nl < 64 ? dA : dB, nl & 63) - lam;
+  qb = (__builtin_fabs(qb) <= pivmin) ? -pivmin : qb;
+  if (lane == 0) DpA = qf;
+  if (lane == (nl & 63)) { if (nl < 64) DmA = qb; else DmB = qb; }
+  if (nl >= 1 && lane == ((nl - 1) & 63)) { if (nl - 1 < 64) DsA = qb; else DsB = qb; }
+  for (int s = 1; s < n; s++) {
+    const int i = s, ib = nl - s;
+    const double di = lane_bcast(i < 64 ? dA : dB, i & 63), ei = lane_bcast(i - 1 < 64 ? e2A : e2B, (i - 1) & 63);
+    const double db = lane_bcast(ib < 64 ? dA : dB, ib & 63), eb = lane_bcast(ib < 64 ? e2A : e2B, ib & 63);
+    qf = (di - lam) - ei * fast_rcp(qf);
+    qb = (db - lam) - eb * fast_rcp(qb);
+    qf = (__builtin_fabs(qf) <= pivmin) ? -pivmin : qf;
+    qb = (__builtin_fabs(qb) <= pivmin) ? -pivmin : qb;
+    const bool hf = lane == (i & 63), hb = lane == (ib & 63), hs = ib >= 1 && lane == ((ib - 1) & 63);
+    DpA = (hf && i < 64) ? qf : DpA; DpB = (hf && i >= 64) ? qf : DpB;
+    DmA = (hb && ib < 64) ? qb : DmA; DmB = (hb && ib >= 64) ? qb : DmB;
+    DsA = (hs && ib - 1 < 64) ? qb : DsA; DsB = (hs && ib - 1 >= 64) ? qb : DsB;
+  }
+  // twist index
+  double gA = lane < n ? __builtin_fabs(DpA + DmA - (dA - lam)) : INFINITY;
+  double gB = lane + 64 < n ? __builtin_fabs(DpB + DmB - (dB - lam)) : INFINITY;
+  int r = lane;
+  if (gB < gA) { gA = gB; r = lane + 64; }
+  wave_argmin(gA, r);
+  // multipliers: below the twist  z_i = -(e_i / D+_i) z_{i+1} ; above  z_{i+1} = -(e_i / D-_{i+1}) z_i
+  const double LA = lane < nl ? -eA * fast_rcp(DpA) : 0.0, LB = lane + 64 < nl ? -eB * fast_rcp(DpB) : 0.0;
+  const double UA = lane < nl ? -eA * fast_rcp(DsA) : 0.0, UB = lane + 64 < nl ? -eB * fast_rcp(DsB) : 0.0;
+  zA = 0.0; zB = 0.0;
+  if (lane == (r & 63)) { if (r < 64) zA = 1.0; else zB = 1.0; }
+  double acc = 1.0;
+  for (int k = r - 1; k >= 0; k--) {
+    acc *= lane_bcast(k < 64 ? LA : LB, k & 63);
+    const bool h = lane == (k & 63);
+    zA = (h && k < 64) ? acc : zA; zB = (h && k >= 64) ? acc : zB;
+  }
+  acc = 1.0;
+  for (int k = r; k < nl; k++) {
+    acc *= lane_bcast(k < 64 ? UA : UB, k & 63);
+    const int t = k + 1;
+    const bool h = lane == (t & 63);
+    zA = (h && t < 64) ? acc : zA; zB = (h && t >= 64) ? acc : zB;
+  }
+  const double nr = 1.0 / wave_max(fmax(__builtin_fabs(zA), __builtin_fabs(zB)));
+  zA *= nr; zB *= nr;
+}
 // Register-resident layout: thread (jc = TID & 127, hf = TID >> 7) owns column jc, rows hf, hf+2, hf+4, ...
 // (RPT of them) of the symmetric matrix for the whole Householder reduction AND the Gauss-Jordan sweep; LDS
 // only carries the broadcast vectors (reflector v, w, pivot column) and the stored reflectors.
@@ -54,7 +133,7 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
   lds_d *dv = Wk, *ev = Wk + n, *tau = Wk + 2 * n, *vv = Wk + 3 * n, *pp = Wk + 4 * n /* NH*n */;
   lptr lamv = Wk + (4 + NH) * n;       // PSD_KMAX (+ pad)
   lptr Z = Wk + (4 + NH) * n + 16;     // PSD_KMAX x n eigenvectors
-  lptr tws = Z + PSD_KMAX * n;        // PSD_KMAX x 3n tridiagonal-solve workspace
+  lptr tws = Z + PSD_KMAX * n;        // published-column / w buffers of the Householder and sweep loops
   lds_d* red = lds + L.red;
   lds_d* scal = lds + L.scal;
   cgptr Qg = c.ws + D.ws_q;
@@ -165,12 +244,17 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
     if (jc == n - 2 && i == n - 1) ev[n - 2] = Br[r];
   }
   __syncthreads();
+  PROF_END(PH_E_TRI, pt_t);
   // ---- 3. negative eigenvalues of T by Sturm counts.  pp <- e^2
   double tn = 0;
   for (int i = TID; i < n; i += NT) { pp[i] = ev[i] * ev[i]; tn = fmax(tn, fabs(dv[i]) + fabs(ev[i]) + (i > 0 ? fabs(ev[i - 1]) : 0.0)); }
   const double tnorm = block_max(tn, red);
-  const double pivmin = fmax(1e-300, 2.3e-308 * 4.0 * tnorm * tnorm);
-  const int kneg = sturm_count(dv, pp, n, 0.0, pivmin);
+  const double pivmin = fmax(1e-300, 1e-290 * tnorm * tnorm);   // e^2 / pivmin stays finite
+  const int kneg = sturm_count_reg(lane < n ? dv[lane] : 0.0, lane + 64 < n ? dv[lane + 64] : 0.0, lane < n ? pp[lane] : 0.0,
+                                   lane + 64 < n ? pp[lane + 64] : 0.0, n, 0.0, pivmin);
+#ifdef DG_PROF
+  if (TID == 0) { atomicAdd(&dg_prof[2 * PH_E_KNEG], (unsigned long long)kneg); atomicAdd(&dg_prof[2 * PH_E_KNEG + 1], 1ULL); }
+#endif
   // ---- 4a. M = B + reg I (this thread's slice, back into Br); the negative part is corrected batch by batch
   const double reg = D.par.reg > 0 ? D.par.reg : 0.0;
 #pragma unroll
@@ -186,64 +270,41 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
   for (int j0 = 0; j0 < kneg; j0 += PSD_KMAX) {
     const int kb = kneg - j0 < PSD_KMAX ? kneg - j0 : PSD_KMAX;
     __syncthreads();
-    for (int jj = wave; jj < kb; jj += NT / 64) {
-      const int j = j0 + jj;
-      // eigenvalue j (ascending) lies in [lo, hi) with count(lo) <= j < count(hi): 64-way multisection
-      double lo = -tnorm * 1.0000001 - 1e-300, hi = 0.0;
-      for (int it = 0; it < 10; it++) {   // 65^10 > 2^53: ten 64-way multisection steps always reach fp64 resolution
-        const double wdt = hi - lo;
-        const double sg = lo + wdt * (double)(lane + 1) * (1.0 / 65.0);
-        const int cnt = sturm_count(dv, pp, n, sg, pivmin);
-        const unsigned long long above = __ballot(cnt > j);
-        const int first = above ? __ffsll((long long)above) - 1 : 64;
-        const double nlo = first == 0 ? lo : lane_bcast(sg, first - 1);
-        const double nhi = first == 64 ? hi : lane_bcast(sg, first);
-        lo = nlo; hi = nhi;
-        if (hi - lo <= 4.5e-16 * fmax(fabs(lo), fabs(hi)) + 1e-300) break;
-      }
-      if (lane == 0) lamv[jj] = 0.5 * (lo + hi);
-    }
-    __syncthreads();
-    // ---- 3b. eigenvectors of T: inverse iteration, one lane per eigenvalue
-    if (TID < kb) {
-      const int j = TID;
-      const double lam = lamv[j];
-      lptr z = Z + j * n;
-      lds_d *dd = tws + j * 3 * n, *du = dd + n, *du2 = du + n;
-      const double tiny = 2.3e-16 * tnorm + 1e-300;
-      for (int i = 0; i < n; i++) z[i] = 1.0 + 0.37 * (double)((i * 7 + j * 3) % 5);
-      for (int iter = 0; iter < 2; iter++) {
-        for (int i = 0; i < n; i++) { dd[i] = dv[i] - lam; du[i] = ev[i]; du2[i] = 0.0; }
-        for (int i = 0; i < n - 1; i++) {   // elimination with partial pivoting (LAPACK dgtsv)
-          const double dl = ev[i];
-          if (fabs(dd[i]) >= fabs(dl)) {
-            if (dd[i] == 0.0) dd[i] = tiny;
-            const double f = dl / dd[i];
-            dd[i + 1] -= f * du[i];
-            z[i + 1] -= f * z[i];
-          } else {
-            const double f = dd[i] / dl;
-            dd[i] = dl;
-            const double t = dd[i + 1];
-            dd[i + 1] = du[i] - f * t;
-            if (i < n - 2) { du2[i] = du[i + 1]; du[i + 1] = -f * du2[i]; }
-            du[i] = t;
-            const double zt = z[i];
-            z[i] = z[i + 1];
-            z[i + 1] = zt - f * z[i + 1];
-          }
+    PROF_BEGIN(pe1);
+    {
+      // this wavefront's copy of the tridiagonal, one row (two for n > 64) per lane
+      const double dA = lane < n ? dv[lane] : 0.0, dB = lane + 64 < n ? dv[lane + 64] : 0.0;
+      const double eA = lane < n ? ev[lane] : 0.0, eB = lane + 64 < n ? ev[lane + 64] : 0.0;
+      const double e2A = eA * eA, e2B = eB * eB;
+      for (int jj = wave; jj < kb; jj += NT / 64) {
+        const int j = j0 + jj;
+        // eigenvalue j (ascending) lies in [lo, hi) with count(lo) <= j < count(hi): 64-way multisection
+        double lo = -tnorm * 1.0000001 - 1e-300, hi = 0.0;
+        for (int it = 0; it < 10; it++) {   // 65^10 > 2^53: ten 64-way multisection steps always reach fp64 resolution
+          const double wdt = hi - lo;
+          const double sg = lo + wdt * (double)(lane + 1) * (1.0 / 65.0);
+          const int cnt = sturm_count_reg(dA, dB, e2A, e2B, n, sg, pivmin);
+          const unsigned long long above = __ballot(cnt > j);
+          const int first = above ? __ffsll((long long)above) - 1 : 64;
+          const double nlo = first == 0 ? lo : lane_bcast(sg, first - 1);
+          const double nhi = first == 64 ? hi : lane_bcast(sg, first);
+          lo = nlo; hi = nhi;
+          if (hi - lo <= 4.5e-16 * fmax(fabs(lo), fabs(hi)) + 1e-300) break;
         }
-        if (fabs(dd[n - 1]) < tiny) dd[n - 1] = tiny;
-        z[n - 1] /= dd[n - 1];
-        z[n - 2] = (z[n - 2] - du[n - 2] * z[n - 1]) / dd[n - 2];
-        for (int i = n - 3; i >= 0; i--) z[i] = (z[i] - du[i] * z[i + 1] - du2[i] * z[i + 2]) / dd[i];
-        double nr = 0;
-        for (int i = 0; i < n; i++) nr = fmax(nr, fabs(z[i]));
-        nr = 1.0 / nr;
-        for (int i = 0; i < n; i++) z[i] *= nr;
+        const double lam = 0.5 * (lo + hi);
+        if (lane == 0) lamv[jj] = lam;
+        // ---- 3b. eigenvector of T by twisted factorisation
+        double zA, zB;
+        twisted_eigvec(dA, dB, eA, eB, n, lam, pivmin, lane, zA, zB);
+        if (lane < n) Z[jj * n + lane] = zA;
+        if (lane + 64 < n) Z[jj * n + lane + 64] = zB;
       }
     }
     __syncthreads();
+    PROF_END(PH_E_BIS, pe1);
+    PROF_BEGIN(pe2);
+    PROF_END(PH_E_VEC, pe2);
+    PROF_BEGIN(pe3);
     // ---- 3c. modified Gram-Schmidt (wavefront 0), then back-transformation v = H_0 ... H_{n-3} z (one wavefront per vector)
     if (wave == 0) {
       for (int j = 0; j < kb; j++) {
@@ -276,6 +337,7 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
       if (lane + 64 < n) Z[j * n + lane + 64] = zb;
     }
     __syncthreads();
+    PROF_END(PH_E_BACK, pe3);
     // ---- 4b. M += sum_j (1e-10 - lam_j) v_j v_j^T   (== U diag(s') U^T of DGSQP.py:1290-1296 on the negative part)
 #pragma unroll
     for (int r = 0; r < RPT; r++) {

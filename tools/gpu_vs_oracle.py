@@ -1,0 +1,28 @@
+"""Development aid: device vs oracle on the first scenarios of a bench workload (status / iterations / QP counts)."""
+import sys, time, pathlib, os
+import numpy as np
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+from dgsqp_amd.montecarlo import kinematic_racing_game, dynamic_racing_game, sample_scenarios
+from dgsqp_amd.solver import DGSQP
+from oracle import oracle
+which, N, B = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+game = kinematic_racing_game('curve' if which == 'kbcurve' else 'chicane', N=N) if which.startswith('kb') else dynamic_racing_game(N=N, rk4_substeps=10)
+import dgsqp_amd.solver as sv
+if os.environ.get('TIGHT'):
+    _o = sv.build_params
+    def _bp(p):
+        q = _o(p); q.lsqr_atol = q.lsqr_btol = 1e-13; return q
+    sv.build_params = _bp
+s = DGSQP(*game.solver_args(), print_method=None)
+x0, uws = sample_scenarios(game, B, seed=1)
+res = s.solve_batch(x0, uws)
+oracle.build()
+u_am = np.ascontiguousarray(s._to_agent_major(uws))
+t = time.time()
+o = oracle.solve_batch(s._problem, s._cparams, x0, u_am, nthreads=min(B, os.cpu_count() or 1))
+print('oracle time', time.time() - t)
+same = (res['status'] == o['status']) & (res['num_iters'] == o['num_iters']) & (res['qp_solves'] == o['qp_solves'])
+print('identical (status, iters, qps):', same.mean())
+print('gpu    status', res['status'].tolist()); print('oracle status', o['status'].tolist())
+print('gpu    iters ', res['num_iters'].tolist()); print('oracle iters ', o['num_iters'].tolist())
+print('gpu conv', np.mean(res['status'] <= 1), 'oracle conv', np.mean(o['status'] <= 1))
