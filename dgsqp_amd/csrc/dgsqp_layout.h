@@ -39,7 +39,7 @@ struct DgDense {    // one distinct dense gradient: d x^a_k[idx] / du   or the o
 struct DgLds {
   // persistent
   int u, l, q, g, d, v, gd, yd, red, scal;
-  int w_prev;           // active set of the previous QP (ints)
+  int w_prev, w_prevlam; // active set of the previous QP (ints) and its multipliers
   int t_rows, t_dense;  // LDS copies of the row / dense-gradient tables (8 and 16 bytes per entry)
   int t_track;          // LDS copy of the track tables: seg_s[17], seg_curv[16], seg_ang[17], slope[16]
   int scr;  // start of phase scratch
@@ -48,7 +48,7 @@ struct DgLds {
   // EIG scratch
   int g_Bp, g_V, g_tw;  // packed P / packed Householder reflectors / tridiagonal workspace
   // QP scratch (P shares g_Bp)
-  int p_R, p_lam, p_c, p_w, p_r, p_y, p_z, p_t, p_alist, p_act, p_part;
+  int p_R, p_lam, p_c, p_w, p_r, p_y, p_z, p_t, p_alist, p_rd, p_act, p_part;
   // QP outputs that must survive trial evaluations
   int o_du, o_lhat;
   // LSQR scratch
@@ -184,7 +184,7 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   L.u = take(n); L.l = take(nc); L.q = take(n); L.g = take(nc); L.d = take(n); L.v = take(n);
   L.gd = take(D.ngd); L.yd = take(nd); L.red = take(64); L.scal = take(64);
   L.w_prev = take((n + 2) / 2 + 1);   // final active set of the previous QP of this scenario (warm start)
-  L.w_prev = take((n + 2) / 2 + 1);
+  L.w_prev = take((n + 2) / 2 + 1); L.w_prevlam = take(n + 1);
   L.t_rows = take(nc); L.t_dense = take(2 * nd); L.t_track = take(4 * (DGSQP_MAX_SEGS + 1));
   L.scr = o;
   // EVAL
@@ -204,7 +204,7 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   // QP (P aliases Bp)
   o = L.scr + ((npk + 1) & ~1);
   L.p_R = take(npk); L.p_lam = take(n + 1); L.p_c = take(n + 1); L.p_w = take(n + 1); L.p_r = take(n + 1);
-  L.p_y = take(n); L.p_z = take(n); L.p_t = take(n); L.p_alist = take((n + 2) / 2 + 1); L.p_act = take(nc / 8 + 2); L.p_part = take(DG_NH * n);
+  L.p_y = take(n); L.p_z = take(n); L.p_t = take(n); L.p_alist = take((n + 2) / 2 + 1); L.p_rd = take(n + 1); L.p_act = take(nc / 8 + 2); L.p_part = take(DG_NH * n);
   const int qp_end = o;
   // QP outputs live past the end of both the QP and EVAL scratch
   o = qp_end > eval_end ? qp_end : eval_end;

@@ -481,27 +481,71 @@ __device__ inline double g_row_coef(const DgProb& D, clptr gd, int r, int col) {
   }
 }
 
-// wavefront-0 helper: solve (R^T R) r = c for the packed upper-triangular factor R of order m (<= 128).
-// Lane j keeps entries j and j+64 in registers; pivots are broadcast with shuffles, so there is no LDS
-// hazard inside the substitution loops.  Writes w = R^-T c to wv, r to rv and returns |w|^2 to every lane.
-__device__ inline double qp_wave_solve(clptr R, int m, int lane, clptr cvec, lptr wv, lptr rv,
-                                       double& r0_out, double& r1_out) {
+// wavefront-0 helpers: solve (R^T R) r = c for the packed triangular factor R of order m (<= 128); rd holds 1/R_ii.
+// Lane j keeps entries j and j+64 in registers; pivots are broadcast with v_readlane.  Rows are processed in blocks of
+// four: the 4 reciprocal diagonals and the 4x2 matrix entries of a block are read from LDS up front (independent of the
+// recurrence), so that the sequential part of a step is readlane -> mul -> fma.
+#define QP_NPK_CLAMP(ix) ((ix) < npk ? (ix) : npk - 1)
+__device__ inline double qp_wave_fwd(clptr R, clptr rd, int m, int npk, int lane, clptr cvec, lptr wv, double& w0o, double& w1o) {
   double c0 = lane < m ? cvec[lane] : 0.0, c1 = lane + 64 < m ? cvec[lane + 64] : 0.0;
   double w0 = 0, w1 = 0;
-  for (int i = 0; i < m; i++) {
-    const double ci = lane_bcast(i < 64 ? c0 : c1, i & 63);
-    const double wi = ci / R[tri(i, i)];
-    if (lane == (i & 63)) { if (i < 64) w0 = wi; else w1 = wi; }
-    if (lane > i && lane < m) c0 -= R[tri(lane, i)] * wi;
-    if (lane + 64 > i && lane + 64 < m) c1 -= R[tri(lane + 64, i)] * wi;
+  const int rowA = lane * (lane + 1) / 2, rowB = (lane + 64) * (lane + 65) / 2;
+  int i = 0;
+  for (; i + 3 < m; i += 4) {
+    double d[4], a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      d[k] = rd[i + k];
+      a[k] = R[QP_NPK_CLAMP(rowA + i + k)];
+      b[k] = R[QP_NPK_CLAMP(rowB + i + k)];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int ii = i + k;
+      const double wi = lane_bcast(ii < 64 ? c0 : c1, ii & 63) * d[k];
+      if (lane == (ii & 63)) { if (ii < 64) w0 = wi; else w1 = wi; }
+      c0 -= (lane > ii && lane < m) ? a[k] * wi : 0.0;
+      c1 -= (lane + 64 > ii && lane + 64 < m) ? b[k] * wi : 0.0;
+    }
   }
-  const double ww = wave_sum(w0 * w0 + w1 * w1);
+  for (; i < m; i++) {
+    const double wi = lane_bcast(i < 64 ? c0 : c1, i & 63) * rd[i];
+    if (lane == (i & 63)) { if (i < 64) w0 = wi; else w1 = wi; }
+    if (lane > i && lane < m) c0 -= R[rowA + i] * wi;
+    if (lane + 64 > i && lane + 64 < m) c1 -= R[rowB + i] * wi;
+  }
   if (lane < m) wv[lane] = w0;
   if (lane + 64 < m) wv[lane + 64] = w1;
+  w0o = w0; w1o = w1;
+  return wave_sum(w0 * w0 + w1 * w1);
+}
+// Writes w = R^-T c to wv, r = R^-1 w to rv and returns |w|^2 to every lane.
+__device__ inline double qp_wave_solve(clptr R, clptr rd, int m, int npk, int lane, clptr cvec, lptr wv, lptr rv,
+                                       double& r0_out, double& r1_out) {
+  double w0, w1;
+  const double ww = qp_wave_fwd(R, rd, m, npk, lane, cvec, wv, w0, w1);
   double r0 = 0, r1 = 0;
-  for (int j = m - 1; j >= 0; j--) {
-    const double wj = lane_bcast(j < 64 ? w0 : w1, j & 63);
-    const double rj = wj / R[tri(j, j)];
+  int j = m - 1;
+  for (; j >= 3; j -= 4) {
+    double d[4], a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int jj = j - k, base = jj * (jj + 1) / 2;
+      d[k] = rd[jj];
+      a[k] = R[base + (lane < jj ? lane : jj)];
+      b[k] = R[base + (lane + 64 < jj ? lane + 64 : jj)];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int jj = j - k;
+      const double rj = lane_bcast(jj < 64 ? w0 : w1, jj & 63) * d[k];
+      if (lane == (jj & 63)) { if (jj < 64) r0 = rj; else r1 = rj; }
+      w0 -= lane < jj ? a[k] * rj : 0.0;
+      w1 -= lane + 64 < jj ? b[k] * rj : 0.0;
+    }
+  }
+  for (; j >= 0; j--) {
+    const double rj = lane_bcast(j < 64 ? w0 : w1, j & 63) * rd[j];
     if (lane == (j & 63)) { if (j < 64) r0 = rj; else r1 = rj; }
     if (lane < j) w0 -= R[tri(j, lane)] * rj;
     if (lane + 64 < j) w1 -= R[tri(j, lane + 64)] * rj;
@@ -512,26 +556,10 @@ __device__ inline double qp_wave_solve(clptr R, int m, int lane, clptr cvec, lpt
   return ww;
 }
 
-// wavefront-0 helper: forward substitution only, R^T w = c; w to wv, returns |w|^2 to every lane
-__device__ inline double qp_wave_fwd(clptr R, int m, int lane, clptr cvec, lptr wv) {
-  double c0 = lane < m ? cvec[lane] : 0.0, c1 = lane + 64 < m ? cvec[lane + 64] : 0.0;
-  double w0 = 0, w1 = 0;
-  for (int i = 0; i < m; i++) {
-    const double ci = lane_bcast(i < 64 ? c0 : c1, i & 63);
-    const double wi = ci / R[tri(i, i)];
-    if (lane == (i & 63)) { if (i < 64) w0 = wi; else w1 = wi; }
-    if (lane > i && lane < m) c0 -= R[tri(lane, i)] * wi;
-    if (lane + 64 > i && lane + 64 < m) c1 -= R[tri(lane + 64, i)] * wi;
-  }
-  if (lane < m) wv[lane] = w0;
-  if (lane + 64 < m) wv[lane + 64] = w1;
-  return wave_sum(w0 * w0 + w1 * w1);
-}
-
 // wavefront-0 helper: remove active constraint jd (column deletion in R followed by Givens rotations)
 typedef __attribute__((address_space(3))) int lds_i_t;
 typedef __attribute__((address_space(3))) unsigned char lds_b_t;
-__device__ inline void qp_wave_drop(lptr R, lds_i_t* alist, lptr lam, lds_b_t* act, int m, int jd, int lane) {
+__device__ inline void qp_wave_drop(lptr R, lptr rd, lds_i_t* alist, lptr lam, lds_b_t* act, int m, int jd, int lane) {
     const int mn = m - 1;
     const int ca = lane, cb = lane + 64;
     const bool sa = ca >= jd && ca < mn, sb = cb >= jd && cb < mn;
@@ -557,7 +585,7 @@ __device__ inline void qp_wave_drop(lptr R, lds_i_t* alist, lptr lam, lds_b_t* a
       const double sub = lane_bcast(k < 64 ? suba : subb, k & 63);
       const double h = hypot(dk, sub);
       const double cs = h > 0 ? dk / h : 1.0, sn = h > 0 ? sub / h : 0.0;
-      if (lane == (k & 63)) R[tri(k, k)] = h;
+      if (lane == (k & 63)) { R[tri(k, k)] = h; rd[k] = 1.0 / h; }
       if (ca > k && ca < mn) {
         const double ra = R[tri(ca, k)];
         if (ca == k + 0) {}
@@ -587,7 +615,8 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
   const int n = D.n, nc = D.nc;
   lds_d *x = lds + L.o_du, *lhat = lds + L.o_lhat;
   lds_d *R = lds + L.p_R, *lam = lds + L.p_lam, *cvec = lds + L.p_c, *wv = lds + L.p_w, *rv = lds + L.p_r;
-  lds_d *y = lds + L.p_y, *z = lds + L.p_z, *tv = lds + L.p_t;
+  lds_d *y = lds + L.p_y, *z = lds + L.p_z, *tv = lds + L.p_t, *rd = lds + L.p_rd;
+  const int npk = n * (n + 1) / 2;
   typedef __attribute__((address_space(3))) int lds_i;
   typedef __attribute__((address_space(3))) unsigned char lds_b;
   lds_i* alist = (lds_i*)(lds + L.p_alist);
@@ -612,6 +641,7 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
   // method continues from it and reaches the same (unique) minimiser; only the path is shorter.  Building R for W costs
   // one P a_j (a column copy for box / rate rows) and one forward substitution per row instead of a full dual step.
   lds_i* prev = (lds_i*)(lds + L.w_prev);
+  lptr prevlam = lds + L.w_prevlam;
   const int nprev = D.par.qp_warm_start ? (int)scal[DG_QP_NPREV] : 0;
   if (nprev > 0) {
     PROF_BEGIN(pqw);
@@ -641,13 +671,14 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
       const double app = block_sum(part, red);
       const double apap = block_sum(part2, red);
       if (TID < 64) {
-        const double ww = qp_wave_fwd(R, m, lane, cvec, wv);
+        double w0_, w1_;
+        const double ww = qp_wave_fwd(R, rd, m, npk, lane, cvec, wv, w0_, w1_);
         const double delta = app - ww;
         const bool indep = delta > 1e-11 * app && delta > 1e-18 * apap;
         if (indep) {
           if (lane < m) R[tri(m, lane)] = wv[lane];
           if (lane + 64 < m) R[tri(m, lane + 64)] = wv[lane + 64];
-          if (lane == 0) { R[tri(m, m)] = sqrt(delta); alist[m] = p; act[p] = 1; }
+          if (lane == 0) { const double sd = sqrt(delta); R[tri(m, m)] = sd; rd[m] = 1.0 / sd; alist[m] = p; act[p] = 1; lam[m] = prevlam[jj]; }
         }
         if (lane == 0) scal[0] = indep ? 1.0 : 0.0;
       }
@@ -655,28 +686,45 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
       if (scal[0] != 0.0) m++;
     }
     PROF_END(PH_W_BUILD, pw1);
+    PROF_COUNT(PH_C_NPREV, nprev); PROF_COUNT(PH_C_MBUILD, m);
     PROF_BEGIN(pw2);
-    // multipliers of W held as equalities at the unconstrained minimiser; negative ones leave one at a time
-    while (m > 0) {
-      __syncthreads();
-      for (int j = TID; j < m; j += NT) cvec[j] = g[alist[j]] + g_row_dot(D, gd, alist[j], x);
-      __syncthreads();
-      if (TID < 64) {
+    // Multipliers: primal active-set steps on the dual problem restricted to W (min 1/2 l'Sl - v'l, l >= 0), from the
+    // previous QP's multipliers l0 > 0 towards the equality solution l_eq = S^-1 v; the first multiplier to reach zero
+    // leaves W and l_eq is recomputed.  v = A x_unc - b does not change.  All inside wavefront 0.
+    __syncthreads();
+    for (int j = TID; j < m; j += NT) cvec[j] = g[alist[j]] + g_row_dot(D, gd, alist[j], x);
+    __syncthreads();
+    if (TID < 64) {
+      int mm = m;
+      while (mm > 0) {
         double r0, r1;
-        (void)qp_wave_solve(R, m, lane, cvec, wv, rv, r0, r1);
-        double worst = 0.0; int jd = NONE;
-        if (lane < m && r0 < worst) { worst = r0; jd = lane; }
-        if (lane + 64 < m && r1 < worst) { worst = r1; jd = lane + 64; }
-        wave_argmin(worst, jd);
-        if (jd != NONE) qp_wave_drop(R, alist, lam, act, m, jd, lane);
-        if (lane == 0) scal[1] = (double)jd;
+        (void)qp_wave_solve(R, rd, mm, npk, lane, cvec, wv, rv, r0, r1);   // rv = l_eq
+        const double l0 = lane < mm ? lam[lane] : 0.0, l1 = lane + 64 < mm ? lam[lane + 64] : 0.0;
+        double t = INFINITY; int jd = NONE;
+        if (lane < mm && r0 < 0.0) { t = l0 > 0.0 ? l0 / (l0 - r0) : 0.0; jd = lane; }
+        if (lane + 64 < mm && r1 < 0.0) { const double t1 = l1 > 0.0 ? l1 / (l1 - r1) : 0.0; if (t1 < t) { t = t1; jd = lane + 64; } }
+        wave_argmin(t, jd);
+        if (jd == NONE) {
+          if (lane < mm) lam[lane] = r0;
+          if (lane + 64 < mm) lam[lane + 64] = r1;
+          break;
+        }
+        if (lane < mm) lam[lane] = l0 + t * (r0 - l0);
+        if (lane + 64 < mm) lam[lane + 64] = l1 + t * (r1 - l1);
+        // shift the right-hand side with the columns
+        const double ca = (lane >= jd && lane + 1 < mm) ? cvec[lane + 1] : 0.0, cb = (lane + 64 >= jd && lane + 65 < mm) ? cvec[lane + 65] : 0.0;
+        qp_wave_drop(R, rd, alist, lam, act, mm, jd, lane);
+        if (lane >= jd && lane + 1 < mm) cvec[lane] = ca;
+        if (lane + 64 >= jd && lane + 65 < mm) cvec[lane + 64] = cb;
+        mm--;
       }
-      __syncthreads();
-      if ((int)scal[1] == NONE) break;
-      m--;
+      if (lane == 0) scal[1] = (double)mm;
     }
     __syncthreads();
+    m = (int)scal[1];
+    __syncthreads();
     PROF_END(PH_W_MULT, pw2);
+    PROF_COUNT(PH_C_MWARM, m);
     PROF_BEGIN(pw3);
     if (m > 0) {
       for (int j = TID; j < m; j += NT) lam[j] = rv[j];
@@ -729,7 +777,7 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
       const double viol = block_sum(pv, red) + g[p];  // a_p.x - b_p  (b = -g), > 0
       if (TID < 64) {
         double r0, r1;
-        const double ww = qp_wave_solve(R, m, lane, cvec, wv, rv, r0, r1);
+        const double ww = qp_wave_solve(R, rd, m, npk, lane, cvec, wv, rv, r0, r1);
         // ---- step 2b: step lengths.  t1 keeps the multipliers >= 0, t2 makes constraint p active
         double t1 = INFINITY; int jd = NONE;
         if (lane < m && r0 > 0) { t1 = lam[lane] / r0; jd = lane; }
@@ -773,7 +821,7 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
       if (!dual_only && !partial) {
         // ---- full step: constraint p becomes active, append column [w ; sqrt(delta)] to R
         for (int i = TID; i < m; i += NT) R[tri(m, i)] = wv[i];
-        if (TID == 0) { R[tri(m, m)] = sqrt(delta); alist[m] = p; lam[m] = lp; act[p] = 1; }
+        if (TID == 0) { const double sd = sqrt(delta); R[tri(m, m)] = sd; rd[m] = 1.0 / sd; alist[m] = p; lam[m] = lp; act[p] = 1; }
         m++;
         __syncthreads();
         PROF_END(PH_Q_UPD, pq5);
@@ -783,7 +831,7 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
 #ifdef DG_PROF
       if (TID == 0) { atomicAdd(&dg_prof[2 * PH_SWEEP + 1], 1ULL); }
 #endif
-      if (TID < 64) qp_wave_drop(R, alist, lam, act, m, jd, lane);
+      if (TID < 64) qp_wave_drop(R, rd, alist, lam, act, m, jd, lane);
       m--;
       __syncthreads();
       PROF_END(PH_Q_UPD, pq5);
@@ -795,12 +843,13 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
   // P is an explicit inverse, so the active rows hold to ~1e-12 only; two projection steps
   //   x <- x - P A^T S^-1 (A x - b),  lam <- lam + S^-1 (A x - b)
   // bring them to rounding level.
+  PROF_COUNT(PH_C_MFINAL, m);
   PROF_BEGIN(pq6);
   if (ret == 0 && m > 0) {
     for (int pass = 0; pass < 2; pass++) {
       for (int j = TID; j < m; j += NT) cvec[j] = g[alist[j]] + g_row_dot(D, gd, alist[j], x);
       __syncthreads();
-      if (TID < 64) { double r0, r1; (void)qp_wave_solve(R, m, lane, cvec, wv, rv, r0, r1); }
+      if (TID < 64) { double r0, r1; (void)qp_wave_solve(R, rd, m, npk, lane, cvec, wv, rv, r0, r1); }
       __syncthreads();
       for (int col = TID; col < n; col += NT) {
         double s = 0;
@@ -817,7 +866,7 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
   for (int r = TID; r < nc; r += NT) lhat[r] = 0.0;
   __syncthreads();
   if (ret == 0)
-    for (int j = TID; j < m; j += NT) { lhat[alist[j]] = lam[j]; prev[j] = alist[j]; }
+    for (int j = TID; j < m; j += NT) { lhat[alist[j]] = lam[j]; prev[j] = alist[j]; prevlam[j] = lam[j]; }
   if (TID == 0) scal[DG_QP_NPREV] = ret == 0 ? (double)m : 0.0;
   __syncthreads();
   PROF_END(PH_QP, pt_qp);

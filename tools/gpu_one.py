@@ -10,12 +10,12 @@ game = kinematic_racing_game('curve' if which == 'kbcurve' else 'chicane', N=N) 
 s = DGSQP(*game.solver_args(), print_method=None)
 x0, uws = sample_scenarios(game, B, seed=1)
 lib = s._lib
-names = ['rollout', 'deriv1', 'deriv2', 'chains', 'dp', 'jacobi', 'pform', 'qp', 'merit', 'lsqr', 'qtmul', 'gi_adds/drops', 'wgtotal', 'wgmax', 'q_scan', 'q_y', 'q_dir', 'q_step', 'q_upd', 'q_refine', 'q_warm', 'w_build', 'w_mult', 'w_x', 'e_tri', 'e_bis', 'e_vec', 'e_back', 'e_kneg']
+names = ['rollout', 'deriv1', 'deriv2', 'chains', 'dp', 'jacobi', 'pform', 'qp', 'merit', 'lsqr', 'qtmul', 'gi_adds/drops', 'wgtotal', 'wgmax', 'q_scan', 'q_y', 'q_dir', 'q_step', 'q_upd', 'q_refine', 'q_warm', 'w_build', 'w_mult', 'w_x', 'e_tri', 'e_bis', 'e_vec', 'e_back', 'e_kneg', 'c_nprev', 'c_mbuild', 'c_mwarm', 'c_mfinal']
 for i in sel:
-    buf = (ctypes.c_ulonglong * 64)()
-    lib.dgsqp_prof_read(buf, 64)
+    buf = (ctypes.c_ulonglong * 128)()
+    lib.dgsqp_prof_read(buf, 128)
     res = s.solve_batch(x0[i:i + 1], uws[i:i + 1])
-    nph = lib.dgsqp_prof_read(buf, 64)
+    nph = lib.dgsqp_prof_read(buf, 128)
     print(f'scenario {i}: status {res["status"][0]} iters {res["num_iters"][0]} qps {res["qp_solves"][0]} kernel {res["kernel_ms"]:.1f} ms')
     for p in range(nph):
         if buf[2 * p + 1]:
