@@ -46,6 +46,12 @@ __device__ inline DgDense ld_dense(int d) {
   __builtin_memcpy(&R, w, 16);
   return R;
 }
+__device__ inline DgTask ld_task(int t) {
+  const unsigned long long w = ((const lds_u64*)LP(dg_prob.L.t_task))[t];
+  DgTask R;
+  __builtin_memcpy(&R, &w, 8);
+  return R;
+}
 __device__ inline void dev_load_tables() {
   const DgProb& D = dg_prob;
   lds_u64* tr = (lds_u64*)LP(D.L.t_rows);
@@ -54,6 +60,11 @@ __device__ inline void dev_load_tables() {
   const unsigned long long* sd = (const unsigned long long*)D.dense;
   for (int r = threadIdx.x; r < D.nc; r += DG_BLOCK) tr[r] = sr[r];
   for (int d = threadIdx.x; d < 2 * D.ndense; d += DG_BLOCK) td[d] = sd[d];
+  {
+    lds_u64* tk = (lds_u64*)LP(D.L.t_task);
+    const unsigned long long* sk = (const unsigned long long*)D.dtask;
+    for (int t = threadIdx.x; t < D.ntask; t += DG_BLOCK) tk[t] = sk[t];
+  }
   lptr tt = LP(D.L.t_track);
   constexpr int S1 = DGSQP_MAX_SEGS + 1;
   for (int i = threadIdx.x; i < S1; i += DG_BLOCK) {

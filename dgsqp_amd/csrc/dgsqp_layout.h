@@ -30,10 +30,20 @@ struct DgRow {      // one inequality row
 struct DgDense {    // one distinct dense gradient: d x^a_k[idx] / du   or the obstacle gradient of pair (a,b) at stage k
   int8_t kind;      // 0 state row, 1 obstacle
   int8_t a, b, idx, k;
-  int8_t pad_[3];
+  uint8_t nt, t0lo, t0hi;  // its chunks in the dot-product task table: nt tasks from index t0lo + 256 t0hi
   int32_t off;      // offset in the packed Gd array; kind 0: 2k entries [t][j]; kind 1: 4k entries, agent a then agent b
   int16_t r_pos, r_neg;  // rows using this gradient with coefficient +1 / -1 (-1: none)
 };
+
+// Dot products with the dense gradients are cut into chunks of <= DG_CHUNK contiguous entries (one lane each, all loads
+// issued together): gd[p0 .. p0+len) . v[v0 .. v0+len)
+#define DG_CHUNK 16
+struct DgTask {
+  int32_t p0;
+  uint16_t v0;
+  uint8_t len, pad_;
+};
+#define DG_NTASKMAX 1536
 
 // LDS arena, offsets in doubles
 struct DgLds {
@@ -41,6 +51,7 @@ struct DgLds {
   int u, l, q, g, d, v, gd, yd, red, scal;
   int w_prev, w_prevlam; // active set of the previous QP (ints) and its multipliers
   int t_rows, t_dense;  // LDS copies of the row / dense-gradient tables (8 and 16 bytes per entry)
+  int t_task;           // LDS copy of the dense dot-product task table (8 bytes per entry)
   int t_track;          // LDS copy of the track tables: seg_s[17], seg_curv[16], seg_ang[17], slope[16]
   int scr;  // start of phase scratch
   // EVAL scratch (absolute offsets)
@@ -48,7 +59,7 @@ struct DgLds {
   // EIG scratch
   int g_Bp, g_V, g_tw;  // packed P / packed Householder reflectors / tridiagonal workspace
   // QP scratch (P shares g_Bp)
-  int p_R, p_lam, p_c, p_w, p_r, p_y, p_z, p_t, p_alist, p_rd, p_act, p_part;
+  int p_R, p_lam, p_c, p_w, p_r, p_y, p_z, p_t, p_alist, p_rd, p_yd2, p_yslot, p_yfree, p_dpart, p_act, p_part;
   // QP outputs that must survive trial evaluations
   int o_du, o_lhat;
   // LSQR scratch
@@ -59,7 +70,7 @@ struct DgLds {
 struct DgProb {
   dgsqp_problem_t P;
   dgsqp_params_t par;
-  int M, N, nq, nu, n, nc, npairs, ndense, ngd;
+  int M, N, nq, nu, n, nc, npairs, ndense, ngd, ntask;
   int nqa[DGSQP_MAX_AGENTS], qoff[DGSQP_MAX_AGENTS], sidx[DGSQP_MAX_AGENTS], eyidx[DGSQP_MAX_AGENTS];
   double inv_track_L;
   int uniform_nqa;
@@ -68,7 +79,7 @@ struct DgProb {
   int effvar[DGSQP_MAX_AGENTS][DG_MAXEFF];  // effective variable -> index into z = (q_0..q_{nqa-1}, u_0, u_1)
   int t2off[DGSQP_MAX_AGENTS];              // offset (doubles) of agent block in the Taylor tensor workspace
   int t2k[DGSQP_MAX_AGENTS];                // per-stage stride of that block = nqa*ndir
-  int64_t ws_t2, ws_q, ws_base, ws_H, ws_tang, ws_doubles; // global workspace layout (doubles): Taylor tensor, raw Q, watchdog backups,
+  int64_t ws_t2, ws_q, ws_base, ws_H, ws_tang, ws_Y, ws_doubles; // global workspace layout (doubles): Taylor tensor, raw Q, watchdog backups,
                                                              // costate-contracted dynamics Hessians, tangent trajectories
   DgRow rows[DG_NCMAX];
   DgDense dense[DG_NDMAX];
@@ -76,6 +87,7 @@ struct DgProb {
   int16_t r_rate_ub[DGSQP_MAX_AGENTS][DG_NMAX][DGSQP_NUA], r_rate_lb[DGSQP_MAX_AGENTS][DG_NMAX][DGSQP_NUA];
   int16_t stage_row0[DG_NMAX + 2];   // first row of each stage (rows are ordered by stage)
   int16_t stage_dense0[DG_NMAX + 2]; // first dense gradient of each stage
+  DgTask dtask[DG_NTASKMAX];
   DgLds L;
 };
 
@@ -129,7 +141,7 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
       for (int i = 0; i < P.M; i++)
         for (int j = i + 1; j < P.M; j++) {
           if (nd >= DG_NDMAX) return "too many dense rows";
-          D.dense[nd] = DgDense{1, (int8_t)i, (int8_t)j, 0, (int8_t)k, {0, 0, 0}, off, (int16_t)nc, -1};
+          D.dense[nd] = DgDense{1, (int8_t)i, (int8_t)j, 0, (int8_t)k, 0, 0, 0, off, (int16_t)nc, -1};
           off += 4 * k;
           if (!add_row(DG_R_OBS, k, i, j, 0, 1, nd)) return "too many rows";
           nd++;
@@ -154,7 +166,7 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
           dense_of[i] = -1;
           if (ag.st_ub[i] < INFINITY || ag.st_lb[i] > -INFINITY) {
             if (nd >= DG_NDMAX) return "too many dense rows";
-            D.dense[nd] = DgDense{0, (int8_t)a, -1, (int8_t)i, (int8_t)k, {0, 0, 0}, off, -1, -1};
+            D.dense[nd] = DgDense{0, (int8_t)a, -1, (int8_t)i, (int8_t)k, 0, 0, 0, off, -1, -1};
             off += 2 * k;
             dense_of[i] = nd++;
           }
@@ -168,13 +180,33 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   }
   D.stage_row0[P.N + 1] = (int16_t)nc; D.stage_dense0[P.N + 1] = (int16_t)nd;
   D.nc = nc; D.ndense = nd; D.ngd = off;
+  {
+    int nt = 0;
+    for (int d = 0; d < nd; d++) {
+      DgDense& dd = D.dense[d];
+      const int len = DGSQP_NUA * dd.k, parts = dd.kind == 1 ? 2 : 1;
+      dd.t0lo = (uint8_t)(nt & 255); dd.t0hi = (uint8_t)(nt >> 8);
+      int cnt = 0;
+      for (int part = 0; part < parts; part++) {
+        const int vb = (part == 0 ? dd.a : dd.b) * P.N * DGSQP_NUA;
+        for (int c0 = 0; c0 < len; c0 += DG_CHUNK) {
+          if (nt >= DG_NTASKMAX) return "too many dense-gradient chunks";
+          D.dtask[nt++] = DgTask{dd.off + part * len + c0, (uint16_t)(vb + c0), (uint8_t)(len - c0 < DG_CHUNK ? len - c0 : DG_CHUNK), 0};
+          cnt++;
+        }
+      }
+      dd.nt = (uint8_t)cnt;
+    }
+    D.ntask = nt;
+  }
   // ---- global workspace (doubles)
   D.ws_t2 = 0;
   D.ws_q = D.ws_t2 + t2;
   D.ws_base = D.ws_q + (int64_t)D.n * D.n;
   D.ws_H = D.ws_base + 2 * D.n + 2 * D.nc + 16;
   D.ws_tang = D.ws_H + (int64_t)D.M * D.N * D.M * (DG_MAXEFF * DG_MAXEFF);
-  D.ws_doubles = D.ws_tang + (int64_t)(D.N + 1) * DGSQP_MAX_NQA * D.n;
+  D.ws_Y = D.ws_tang + (int64_t)(D.N + 1) * DGSQP_MAX_NQA * D.n;   // y_j = P a_j of the QP's active rows
+  D.ws_doubles = D.ws_Y + (int64_t)D.n * D.n;
   D.ws_doubles = (D.ws_doubles + 31) / 32 * 32;
   // ---- LDS arena
   DgLds& L = D.L;
@@ -185,7 +217,7 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   L.gd = take(D.ngd); L.yd = take(nd); L.red = take(64); L.scal = take(64);
   L.w_prev = take((n + 2) / 2 + 1);   // final active set of the previous QP of this scenario (warm start)
   L.w_prev = take((n + 2) / 2 + 1); L.w_prevlam = take(n + 1);
-  L.t_rows = take(nc); L.t_dense = take(2 * nd); L.t_track = take(4 * (DGSQP_MAX_SEGS + 1));
+  L.t_rows = take(nc); L.t_dense = take(2 * nd); L.t_task = take(D.ntask); L.t_track = take(4 * (DGSQP_MAX_SEGS + 1));
   L.scr = o;
   // EVAL
   o = L.scr;
@@ -204,7 +236,7 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   // QP (P aliases Bp)
   o = L.scr + ((npk + 1) & ~1);
   L.p_R = take(npk); L.p_lam = take(n + 1); L.p_c = take(n + 1); L.p_w = take(n + 1); L.p_r = take(n + 1);
-  L.p_y = take(n); L.p_z = take(n); L.p_t = take(n); L.p_alist = take((n + 2) / 2 + 1); L.p_rd = take(n + 1); L.p_act = take(nc / 8 + 2); L.p_part = take(DG_NH * n);
+  L.p_y = take(n); L.p_z = take(n); L.p_t = take(n); L.p_alist = take((n + 2) / 2 + 1); L.p_rd = take(n + 1); L.p_yd2 = take(nd); L.p_yslot = take((n + 2) / 2 + 1); L.p_yfree = take((n + 2) / 2 + 1); L.p_dpart = take(D.ntask); L.p_act = take(nc / 8 + 2); L.p_part = take(DG_NH * n);
   const int qp_end = o;
   // QP outputs live past the end of both the QP and EVAL scratch
   o = qp_end > eval_end ? qp_end : eval_end;

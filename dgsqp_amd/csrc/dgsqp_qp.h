@@ -1,0 +1,376 @@
+// QP sub-problem of one SQP iteration.
+//
+// _solve_qp (DGSQP.py:232-266):  min 1/2 x'Bx + q'x  s.t.  G x <= -g,  with P = B^-1 packed in LDS.
+// Dual active-set method (Goldfarb & Idnani 1983) in range-space form.  The problem is small (n <= 128 unknowns, a few
+// dozen active rows) and a step is a chain of short dependent operations, so the work is split by its nature:
+//   * block-wide phases (all wavefronts): scan for the most violated row, y = P a_p, dots with the dense gradients;
+//   * wavefront-0 sections without any block barrier: triangular solves with the Cholesky factor R of the Schur
+//     complement A P A^T (v_readlane broadcasts, rows in blocks of four), step lengths, updates, Givens deletions.
+// Vector element i lives in lane i & 63 of wavefront 0 (two registers per lane for n > 64).  For every active row j the
+// vector y_j = P a_j is kept (global scratch, L2 resident), so the primal step direction is  Y r - y  instead of a
+// second product with P, and the final iterative refinement needs no product with P either.
+// The result is the KKT point OSQP(polish=True) returns when its polish succeeds.
+#pragma once
+
+// Dots of all distinct dense constraint gradients with the vector held in LDS at v (all wavefronts).  One chunk
+// (<= DG_CHUNK contiguous entries of a gradient and of v) per thread, all 2 x DG_CHUNK reads issued together; the chunk
+// sums of a gradient are then added in a fixed order (bitwise reproducible, no atomics).  Two barriers.
+__device__ inline void qp_dense_dots(const DgProb& D, clptr gd, clptr v, lptr part, lptr out) {
+  for (int t = TID; t < D.ntask; t += NT) {
+    const DgTask T = ld_task(t);
+    clptr p = gd + T.p0;
+    clptr w = v + T.v0;
+    double pv[DG_CHUNK], wv[DG_CHUNK];
+#pragma unroll
+    for (int i = 0; i < DG_CHUNK; i++) { pv[i] = p[i]; wv[i] = w[i]; }   // reads past the chunk stay inside the LDS arena
+    double s[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < DG_CHUNK; i++) s[i & 3] += i < T.len ? pv[i] * wv[i] : 0.0;
+    part[t] = (s[0] + s[1]) + (s[2] + s[3]);
+  }
+  __syncthreads();
+  for (int d = TID; d < D.ndense; d += NT) {
+    const DgDense dd = ld_dense(d);
+    const int ts = dd.t0lo + 256 * dd.t0hi;
+    double s = 0;
+    for (int i = 0; i < dd.nt; i++) s += part[ts + i];
+    out[d] = s;
+  }
+  __syncthreads();
+}
+// a_r . v with the dense part taken from precomputed dense dots.  Branch-free: every row is  s1 v[c1] + s0 v[c0] + sd dd[di]
+// with zero coefficients for the parts it does not have, so the three LDS reads are unconditional and independent.
+__device__ inline double qpw_row_dot(const DgProb& D, const DgRow R, clptr v, clptr dd) {
+  const bool dense = R.dense >= 0;
+  const bool rate = R.type == DG_R_RATE_UB || R.type == DG_R_RATE_LB;
+  const bool pos = R.type == DG_R_IN_UB || R.type == DG_R_RATE_UB;
+  const int c1 = dense ? 0 : am_col(D, R.a, R.k, R.idx);
+  const bool has0 = rate && R.k > 0;
+  const int c0 = has0 ? c1 - DGSQP_NUA : c1;
+  const double s1 = dense ? 0.0 : (pos ? 1.0 : -1.0);
+  const double s0 = has0 ? -s1 : 0.0;
+  const double sd = dense ? (double)R.sgn : 0.0;
+  const int di = dense ? R.dense : 0;
+  const double v1 = v[c1], v0 = v[c0], vd = dd[di];
+  return s1 * v1 + s0 * v0 + sd * vd;
+}
+
+// out = sum_j coef_j Y[slot_j]  (lane-distributed), coefficients in LDS at cf, slots in LDS at ys.  Y lives in the
+// workgroup's global scratch (L2): eight columns per iteration so that the loads overlap.
+__device__ inline void qpw_ymul(cgptr Y, int n, int m, int lane, clptr cf, const lds_i_t* ys, double& o0, double& o1) {
+  double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+  const bool okA = lane < n, okB = lane + 64 < n;
+  const int la = okA ? lane : 0, lb = okB ? lane + 64 : 0;
+  int j = 0;
+  for (; j + 7 < m; j += 8) {
+    double ya[8], yb[8], cc[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int64_t base = (int64_t)ys[j + k] * n;
+      cc[k] = cf[j + k];
+      ya[k] = Y[base + la];
+      yb[k] = n > 64 ? Y[base + lb] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) { a[k & 3] = __builtin_fma(ya[k], cc[k], a[k & 3]); b[k & 3] = __builtin_fma(yb[k], cc[k], b[k & 3]); }
+  }
+  for (; j < m; j++) {
+    const int64_t base = (int64_t)ys[j] * n;
+    const double cc = cf[j];
+    a[0] = __builtin_fma(Y[base + la], cc, a[0]);
+    if (n > 64) b[0] = __builtin_fma(Y[base + lb], cc, b[0]);
+  }
+  o0 = okA ? (a[0] + a[1]) + (a[2] + a[3]) : 0.0; o1 = okB ? (b[0] + b[1]) + (b[2] + b[3]) : 0.0;
+}
+
+// state of the active-set iteration kept in wavefront 0's registers between the block-wide phases
+struct QpwState {
+  double x0, x1;   // current primal point (elements lane, lane + 64)
+  int m, nfree;    // active rows, free Y slots
+};
+struct QpPtrs {
+  lptr xv, R, lam, cvec, wv, rv, rd, yv, tv, ddx, ddy, dpart, scal, prevlam;
+  lds_i_t *alist, *yslot, *yfree, *prev;
+  lds_b_t* act;
+  clptr gd, g, Pp;
+  gptr Y;
+};
+__device__ inline QpPtrs qp_ptrs(const Ctx& c) {
+  const DgProb& D = dg_prob;
+  const DgLds& L = D.L;
+  lptr lds = LP(0);
+  QpPtrs q;
+  q.xv = lds + L.o_du; q.R = lds + L.p_R; q.lam = lds + L.p_lam; q.cvec = lds + L.p_c; q.wv = lds + L.p_w; q.rv = lds + L.p_r;
+  q.rd = lds + L.p_rd; q.yv = lds + L.p_y; q.tv = lds + L.p_t; q.ddx = lds + L.yd; q.ddy = lds + L.p_yd2; q.dpart = lds + L.p_dpart;
+  q.scal = lds + L.scal; q.prevlam = lds + L.w_prevlam;
+  q.alist = (lds_i_t*)(lds + L.p_alist); q.yslot = (lds_i_t*)(lds + L.p_yslot); q.yfree = (lds_i_t*)(lds + L.p_yfree);
+  q.prev = (lds_i_t*)(lds + L.w_prev); q.act = (lds_b_t*)(lds + L.p_act);
+  q.gd = lds + L.gd; q.g = lds + L.g; q.Pp = lds + L.g_Bp;
+  q.Y = c.ws + D.ws_Y;
+  return q;
+}
+// All wavefronts: a_p into tv, y = P a_p into yv (a column copy for box / rate rows), dense-gradient dots of y into ddy.
+__device__ inline void qp_row_products(const Ctx& c, const QpPtrs& q, int p) {
+  const DgProb& D = dg_prob;
+  const int n = D.n;
+  const DgRow R = ld_row(p);
+  __syncthreads();   // previous readers of tv / yv are done
+  if (R.dense < 0) {
+    const int c1 = am_col(D, R.a, R.k, R.idx);
+    const bool has0 = (R.type == DG_R_RATE_UB || R.type == DG_R_RATE_LB) && R.k > 0;
+    const double sgn = (R.type == DG_R_IN_UB || R.type == DG_R_RATE_UB) ? 1.0 : -1.0;
+    for (int i = TID; i < n; i += NT) {
+      double pv = q.Pp[tri(i, c1)], av = i == c1 ? 1.0 : 0.0;
+      if (has0) { pv -= q.Pp[tri(i, c1 - DGSQP_NUA)]; if (i == c1 - DGSQP_NUA) av = -1.0; }
+      q.yv[i] = sgn * pv; q.tv[i] = sgn * av;
+    }
+    __syncthreads();
+  } else {
+    for (int col = TID; col < n; col += NT) q.tv[col] = g_row_coef(D, q.gd, p, col);
+    dev_p_mul(c, q.tv, q.yv, 1.0);
+  }
+  qp_dense_dots(D, q.gd, q.yv, q.dpart, q.ddy);
+}
+// All wavefronts: most violated inactive row at the point held in xv (lowest index on ties); NONE if the point is feasible.
+__device__ inline int qp_scan(const QpPtrs& q, double tol) {
+  const DgProb& D = dg_prob;
+  const int NONE = 0x7fffffff;
+  qp_dense_dots(D, q.gd, q.xv, q.dpart, q.ddx);
+  double best = -tol;
+  int bi = NONE;
+  for (int r = TID; r < D.nc; r += NT) {
+    if (q.act[r]) continue;
+    const double s = -(q.g[r] + qpw_row_dot(D, ld_row(r), q.xv, q.ddx));
+    if (s < best) { best = s; bi = r; }     // increasing r per thread: the first minimum is kept
+  }
+  double bv; int p;
+  block_argmin(best, bi, LP(D.L.red), bv, p);
+  return p;
+}
+// wavefront 0: append row p (whose y is in yv, a_p in tv, w in wv) to the factorisation
+__device__ inline void qpw_append(const QpPtrs& q, QpwState& S, int n, int lane, int p, double delta, double lam_p) {
+  const int m = S.m;
+  if (lane < m) q.R[tri(m, lane)] = q.wv[lane];
+  if (lane + 64 < m) q.R[tri(m, lane + 64)] = q.wv[lane + 64];
+  const int slot = q.yfree[S.nfree - 1];
+  if (lane < n) q.Y[(int64_t)slot * n + lane] = q.yv[lane];
+  if (lane + 64 < n) q.Y[(int64_t)slot * n + lane + 64] = q.yv[lane + 64];
+  if (lane == 0) {
+    const double sd = sqrt(delta);
+    q.R[tri(m, m)] = sd; q.rd[m] = 1.0 / sd; q.alist[m] = p; q.lam[m] = lam_p; q.act[p] = 1; q.yslot[m] = slot;
+  }
+  S.nfree--; S.m++;
+}
+__device__ inline void qpw_remove(const QpPtrs& q, QpwState& S, int lane, int jd) {
+  const int freed = q.yslot[jd];
+  qpw_drop(q.R, q.rd, q.alist, q.yslot, q.lam, q.act, S.m, jd, lane);
+  if (lane == 0) q.yfree[S.nfree] = freed;
+  S.nfree++; S.m--;
+}
+// wavefront 0: steps 2a-2c of the dual method for the row p prepared by qp_row_products, until p is active (returns 0)
+// or the QP is found infeasible (returns 1)
+__device__ inline int qpw_add_constraint(const QpPtrs& q, QpwState& S, int lane, int p) {
+  const DgProb& D = dg_prob;
+  const int n = D.n, npk = n * (n + 1) / 2;
+  const int NONE = 0x7fffffff;
+  const bool okA = lane < n, okB = lane + 64 < n;
+  const double t0 = okA ? q.tv[lane] : 0.0, t1 = okB ? q.tv[lane + 64] : 0.0;
+  const double y0 = okA ? q.yv[lane] : 0.0, y1 = okB ? q.yv[lane + 64] : 0.0;
+  const double app = wave_sum(t0 * y0 + t1 * y1), apap = wave_sum(t0 * t0 + t1 * t1);
+  const double gp = q.g[p];
+  double lp = 0.0;
+  for (int inner = 0; inner < 4 * (n + D.nc); inner++) {
+    // ---- step 2a: directions.  c = A_A y ; R^T w = c ; r = R^-1 w
+    PROF_BEGIN(pq3);
+    const int m = S.m;
+    for (int j = lane; j < m; j += 64) q.cvec[j] = qpw_row_dot(D, ld_row(q.alist[j]), q.yv, q.ddy);
+    const double viol = wave_sum(t0 * S.x0 + t1 * S.x1) + gp;   // a_p.x - b_p  (b = -g), > 0
+    double r0, r1;
+    const double ww = qpw_solve(q.R, q.rd, m, npk, lane, q.cvec, q.wv, q.rv, r0, r1);
+    // ---- step 2b: step lengths.  t1 keeps the multipliers >= 0, t2 makes constraint p active
+    double ta = INFINITY; int jd = NONE;
+    if (lane < m && r0 > 0) { ta = q.lam[lane] / r0; jd = lane; }
+    if (lane + 64 < m && r1 > 0) { const double tt = q.lam[lane + 64] / r1; if (tt < ta) { ta = tt; jd = lane + 64; } }
+    wave_argmin(ta, jd);
+    const double delta = app - ww;  // a_p^T (P - P A^T S^-1 A P) a_p >= 0
+    const bool indep = m < n && delta > 1e-11 * app && delta > 1e-18 * apap;   // n active rows span everything
+    const double tb = indep ? viol / delta : INFINITY;
+    const double t = fmin(ta, tb);
+    PROF_END(PH_Q_DIR, pq3);
+    if (!(t < INFINITY)) return 1;
+    PROF_BEGIN(pq4);
+    if (indep) {   // primal direction z = Y r - y;  x += t z
+      double d0, d1;
+      qpw_ymul(q.Y, n, m, lane, q.rv, q.yslot, d0, d1);
+      S.x0 += t * (d0 - y0); S.x1 += t * (d1 - y1);
+    }
+    if (lane < m) q.lam[lane] -= t * r0;
+    if (lane + 64 < m) q.lam[lane + 64] -= t * r1;
+    lp += t;
+    PROF_END(PH_Q_STEP, pq4);
+    PROF_BEGIN(pq5);
+    if (indep && !(ta < tb)) {   // full step: constraint p becomes active
+      qpw_append(q, S, n, lane, p, delta, lp);
+      PROF_END(PH_Q_UPD, pq5);
+      return 0;
+    }
+    // partial / dual-only step: drop blocking constraint jd (column deletion + Givens)
+#ifdef DG_PROF
+    if (lane == 0) { atomicAdd(&dg_prof[2 * PH_SWEEP + 1], 1ULL); }
+#endif
+    qpw_remove(q, S, lane, jd);
+    PROF_END(PH_Q_UPD, pq5);
+  }
+  return 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// _solve_qp core (DGSQP.py:246).  Out: du (L.o_du), lhat (L.o_lhat).  Returns 0 ok, 1 infeasible, 2 iteration limit.
+// Block-wide phases (scan, P a_p, dense dots) alternate with wavefront-0 sections; the other wavefronts wait at the
+// barrier that ends each section.
+// ------------------------------------------------------------------------------------------------
+__device__ __noinline__ int dev_qp(const Ctx& c) {
+  const DgProb& D = dg_prob;
+  const DgLds& L = D.L;
+  lptr lds = LP(0);
+  const int n = D.n, nc = D.nc, npk = n * (n + 1) / 2;
+  const QpPtrs q = qp_ptrs(c);
+  lptr lhat = lds + L.o_lhat;
+  const int lane = TID & 63;
+  const bool w0 = TID < 64;
+  const bool okA = lane < n, okB = lane + 64 < n;
+  const double TOL = 1e-10;
+  const int NONE = 0x7fffffff;
+  __syncthreads();
+  PROF_BEGIN(pt_qp);
+  for (int r = TID; r < nc; r += NT) { q.act[r] = 0; lhat[r] = 0.0; }
+  for (int i = TID; i < n; i += NT) q.yfree[i] = n - 1 - i;     // stack of free Y slots (top = lowest index)
+  dev_p_mul(c, lds + L.q, q.xv, -1.0);  // unconstrained minimiser x = -P q
+  __syncthreads();
+  QpwState S;
+  S.m = 0; S.nfree = n;
+  S.x0 = (w0 && okA) ? q.xv[lane] : 0.0; S.x1 = (w0 && okB) ? q.xv[lane + 64] : 0.0;
+
+  // ---- warm start from the final active set W of this scenario's previous QP.  (x(W'), W') with x(W') the minimiser on
+  // the rows W' held as equalities and multipliers >= 0 is a valid S-pair for any independent subset W' of W, so the
+  // dual method continues from it and reaches the same (unique) minimiser; only the path is shorter.
+  const int nprev = D.par.qp_warm_start ? (int)q.scal[DG_QP_NPREV] : 0;
+  if (nprev > 0) {
+    PROF_BEGIN(pqw);
+    for (int jj = 0; jj < nprev; jj++) {
+      const int p = q.prev[jj];
+      qp_row_products(c, q, p);
+      if (w0) {
+        const int m = S.m;
+        for (int j = lane; j < m; j += 64) q.cvec[j] = qpw_row_dot(D, ld_row(q.alist[j]), q.yv, q.ddy);
+        const double t0 = okA ? q.tv[lane] : 0.0, t1 = okB ? q.tv[lane + 64] : 0.0;
+        const double y0 = okA ? q.yv[lane] : 0.0, y1 = okB ? q.yv[lane + 64] : 0.0;
+        const double app = wave_sum(t0 * y0 + t1 * y1), apap = wave_sum(t0 * t0 + t1 * t1);
+        double wa, wb;
+        const double ww = qpw_fwd(q.R, q.rd, m, npk, lane, q.cvec, q.wv, wa, wb);
+        const double delta = app - ww;
+        if (m < n && delta > 1e-11 * app && delta > 1e-18 * apap) qpw_append(q, S, n, lane, p, delta, q.prevlam[jj]);
+      }
+    }
+    __syncthreads();
+    qp_dense_dots(D, q.gd, q.xv, q.dpart, q.ddx);     // xv still holds the unconstrained minimiser
+    if (w0) {
+      PROF_COUNT(PH_C_NPREV, nprev); PROF_COUNT(PH_C_MBUILD, S.m);
+      // Multipliers: primal active-set steps on the dual problem restricted to W (min 1/2 l'Sl - v'l, l >= 0), from the
+      // previous QP's multipliers towards the equality solution l_eq = S^-1 v, v = A x_unc - b; the first multiplier to
+      // reach zero leaves W and l_eq is recomputed.
+      for (int j = lane; j < S.m; j += 64) q.cvec[j] = q.g[q.alist[j]] + qpw_row_dot(D, ld_row(q.alist[j]), q.xv, q.ddx);
+      while (S.m > 0) {
+        const int m = S.m;
+        double r0, r1;
+        (void)qpw_solve(q.R, q.rd, m, npk, lane, q.cvec, q.wv, q.rv, r0, r1);   // rv = l_eq
+        const double l0 = lane < m ? q.lam[lane] : 0.0, l1 = lane + 64 < m ? q.lam[lane + 64] : 0.0;
+        double t = INFINITY; int jd = NONE;
+        if (lane < m && r0 < 0.0) { t = l0 > 0.0 ? l0 / (l0 - r0) : 0.0; jd = lane; }
+        if (lane + 64 < m && r1 < 0.0) { const double t1 = l1 > 0.0 ? l1 / (l1 - r1) : 0.0; if (t1 < t) { t = t1; jd = lane + 64; } }
+        wave_argmin(t, jd);
+        if (jd == NONE) {
+          if (lane < m) q.lam[lane] = r0;
+          if (lane + 64 < m) q.lam[lane + 64] = r1;
+          break;
+        }
+        if (lane < m) q.lam[lane] = l0 + t * (r0 - l0);
+        if (lane + 64 < m) q.lam[lane + 64] = l1 + t * (r1 - l1);
+        const double ca = (lane >= jd && lane + 1 < m) ? q.cvec[lane + 1] : 0.0, cb = (lane + 64 >= jd && lane + 65 < m) ? q.cvec[lane + 65] : 0.0;
+        qpw_remove(q, S, lane, jd);
+        if (lane >= jd && lane + 1 < m) q.cvec[lane] = ca;
+        if (lane + 64 >= jd && lane + 65 < m) q.cvec[lane + 64] = cb;
+      }
+      PROF_COUNT(PH_C_MWARM, S.m);
+      if (S.m > 0) {   // x = x_unc - Y l
+        double d0, d1;
+        qpw_ymul(q.Y, n, S.m, lane, q.lam, q.yslot, d0, d1);
+        S.x0 -= d0; S.x1 -= d1;
+        if (okA) q.xv[lane] = S.x0;
+        if (okB) q.xv[lane + 64] = S.x1;
+      }
+    }
+    __syncthreads();
+    PROF_END(PH_Q_WARM, pqw);
+  }
+
+  int ret = 2;
+  const int max_outer = 4 * (n + nc);
+  for (int iter = 0; iter < max_outer; iter++) {
+    // ---- step 1: most violated inactive constraint (lowest index on ties)
+    PROF_BEGIN(pq1);
+    const int p = qp_scan(q, TOL);
+    PROF_END(PH_Q_SCAN, pq1);
+    if (p == NONE) { ret = 0; break; }
+#ifdef DG_PROF
+    if (TID == 0) { atomicAdd(&dg_prof[2 * PH_SWEEP], 1ULL); }
+#endif
+    PROF_BEGIN(pq2);
+    qp_row_products(c, q, p);
+    PROF_END(PH_Q_Y, pq2);
+    if (w0) {
+      const int st = qpw_add_constraint(q, S, lane, p);
+      if (okA) q.xv[lane] = S.x0;
+      if (okB) q.xv[lane + 64] = S.x1;
+      if (lane == 0) q.scal[0] = (double)st;
+    }
+    __syncthreads();
+    if (q.scal[0] != 0.0) { ret = 1; break; }
+  }
+  // Iterative refinement on the final active set (what OSQP's polish does with polish_refine_iter):
+  // P is an explicit inverse, so the active rows hold to ~1e-12 only; two projection steps
+  //   x <- x - Y S^-1 (A x - b),  lam <- lam + S^-1 (A x - b)      (Y = P A^T)
+  // bring them to rounding level.
+  PROF_BEGIN(pq6);
+  if (ret == 0) {
+    for (int pass = 0; pass < 2; pass++) {
+      qp_dense_dots(D, q.gd, q.xv, q.dpart, q.ddx);
+      if (w0 && S.m > 0) {
+        const int m = S.m;
+        for (int j = lane; j < m; j += 64) q.cvec[j] = q.g[q.alist[j]] + qpw_row_dot(D, ld_row(q.alist[j]), q.xv, q.ddx);
+        double r0, r1;
+        (void)qpw_solve(q.R, q.rd, m, npk, lane, q.cvec, q.wv, q.rv, r0, r1);
+        double d0, d1;
+        qpw_ymul(q.Y, n, m, lane, q.rv, q.yslot, d0, d1);
+        S.x0 -= d0; S.x1 -= d1;
+        if (lane < m) q.lam[lane] += r0;
+        if (lane + 64 < m) q.lam[lane + 64] += r1;
+        if (okA) q.xv[lane] = S.x0;
+        if (okB) q.xv[lane + 64] = S.x1;
+      }
+      __syncthreads();
+    }
+  }
+  PROF_END(PH_Q_REFINE, pq6);
+  if (TID == 0) q.scal[1] = (double)S.m;
+  __syncthreads();
+  const int m = (int)q.scal[1];
+  PROF_COUNT(PH_C_MFINAL, m);
+  if (ret == 0)
+    for (int j = TID; j < m; j += NT) { lhat[q.alist[j]] = q.lam[j]; q.prev[j] = q.alist[j]; q.prevlam[j] = q.lam[j]; }
+  __syncthreads();
+  if (TID == 0) q.scal[DG_QP_NPREV] = ret == 0 ? (double)m : 0.0;
+  __syncthreads();
+  PROF_END(PH_QP, pt_qp);
+  return ret;
+}

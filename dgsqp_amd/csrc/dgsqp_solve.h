@@ -486,7 +486,7 @@ __device__ inline double g_row_coef(const DgProb& D, clptr gd, int r, int col) {
 // four: the 4 reciprocal diagonals and the 4x2 matrix entries of a block are read from LDS up front (independent of the
 // recurrence), so that the sequential part of a step is readlane -> mul -> fma.
 #define QP_NPK_CLAMP(ix) ((ix) < npk ? (ix) : npk - 1)
-__device__ inline double qp_wave_fwd(clptr R, clptr rd, int m, int npk, int lane, clptr cvec, lptr wv, double& w0o, double& w1o) {
+__device__ inline double qpw_fwd(clptr R, clptr rd, int m, int npk, int lane, clptr cvec, lptr wv, double& w0o, double& w1o) {
   double c0 = lane < m ? cvec[lane] : 0.0, c1 = lane + 64 < m ? cvec[lane + 64] : 0.0;
   double w0 = 0, w1 = 0;
   const int rowA = lane * (lane + 1) / 2, rowB = (lane + 64) * (lane + 65) / 2;
@@ -520,10 +520,10 @@ __device__ inline double qp_wave_fwd(clptr R, clptr rd, int m, int npk, int lane
   return wave_sum(w0 * w0 + w1 * w1);
 }
 // Writes w = R^-T c to wv, r = R^-1 w to rv and returns |w|^2 to every lane.
-__device__ inline double qp_wave_solve(clptr R, clptr rd, int m, int npk, int lane, clptr cvec, lptr wv, lptr rv,
+__device__ inline double qpw_solve(clptr R, clptr rd, int m, int npk, int lane, clptr cvec, lptr wv, lptr rv,
                                        double& r0_out, double& r1_out) {
   double w0, w1;
-  const double ww = qp_wave_fwd(R, rd, m, npk, lane, cvec, wv, w0, w1);
+  const double ww = qpw_fwd(R, rd, m, npk, lane, cvec, wv, w0, w1);
   double r0 = 0, r1 = 0;
   int j = m - 1;
   for (; j >= 3; j -= 4) {
@@ -559,7 +559,7 @@ __device__ inline double qp_wave_solve(clptr R, clptr rd, int m, int npk, int la
 // wavefront-0 helper: remove active constraint jd (column deletion in R followed by Givens rotations)
 typedef __attribute__((address_space(3))) int lds_i_t;
 typedef __attribute__((address_space(3))) unsigned char lds_b_t;
-__device__ inline void qp_wave_drop(lptr R, lptr rd, lds_i_t* alist, lptr lam, lds_b_t* act, int m, int jd, int lane) {
+__device__ inline void qpw_drop(lptr R, lptr rd, lds_i_t* alist, lds_i_t* yslot, lptr lam, lds_b_t* act, int m, int jd, int lane) {
     const int mn = m - 1;
     const int ca = lane, cb = lane + 64;
     const bool sa = ca >= jd && ca < mn, sb = cb >= jd && cb < mn;
@@ -567,6 +567,7 @@ __device__ inline void qp_wave_drop(lptr R, lptr rd, lds_i_t* alist, lptr lam, l
     // old diagonals become the sub-diagonal of the shifted columns
     double suba = sa ? R[tri(ca + 1, ca + 1)] : 0.0, subb = sb ? R[tri(cb + 1, cb + 1)] : 0.0;
     const int ala = sa ? alist[ca + 1] : 0, alb = sb ? alist[cb + 1] : 0;
+    const int ysa = sa ? yslot[ca + 1] : 0, ysb = sb ? yslot[cb + 1] : 0;
     const double lma = sa ? lam[ca + 1] : 0.0, lmb = sb ? lam[cb + 1] : 0.0;
     for (int i = 0; i < mn; i++) {  // row-synchronous shift: new column cc <- old column cc+1, rows 0..cc
       double ta = 0, tb = 0;
@@ -576,8 +577,8 @@ __device__ inline void qp_wave_drop(lptr R, lptr rd, lds_i_t* alist, lptr lam, l
       if (da) R[tri(ca, i)] = ta;
       if (db) R[tri(cb, i)] = tb;
     }
-    if (sa) { alist[ca] = ala; lam[ca] = lma; }
-    if (sb) { alist[cb] = alb; lam[cb] = lmb; }
+    if (sa) { alist[ca] = ala; lam[ca] = lma; yslot[ca] = ysa; }
+    if (sb) { alist[cb] = alb; lam[cb] = lmb; yslot[cb] = ysb; }
     for (int k = jd; k < mn; k++) {
       double dk = 0;
       if (lane == (k & 63)) dk = R[tri(k, k)];
@@ -601,277 +602,7 @@ __device__ inline void qp_wave_drop(lptr R, lptr rd, lds_i_t* alist, lptr lam, l
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// _solve_qp core (DGSQP.py:246):  min 1/2 x'Bx + q'x  s.t.  G x <= -g   with P = B^-1 in LDS.
-// Dual active-set method (Goldfarb-Idnani 1983) in range-space form: the Cholesky factor R of the
-// Schur complement G_A P G_A^T is kept packed in LDS and updated by wavefront 0 with shuffles.
-// This is the KKT point OSQP(polish=True) returns when its polish succeeds.
-// Out: du (L.o_du), lhat (L.o_lhat).  Returns 0 ok, 1 infeasible, 2 iteration limit.
-// ------------------------------------------------------------------------------------------------
-__device__ __noinline__ int dev_qp(const Ctx& c) {
-  const DgProb& D = dg_prob;
-  const DgLds& L = D.L;
-  lptr lds = LP(0);
-  const int n = D.n, nc = D.nc;
-  lds_d *x = lds + L.o_du, *lhat = lds + L.o_lhat;
-  lds_d *R = lds + L.p_R, *lam = lds + L.p_lam, *cvec = lds + L.p_c, *wv = lds + L.p_w, *rv = lds + L.p_r;
-  lds_d *y = lds + L.p_y, *z = lds + L.p_z, *tv = lds + L.p_t, *rd = lds + L.p_rd;
-  const int npk = n * (n + 1) / 2;
-  typedef __attribute__((address_space(3))) int lds_i;
-  typedef __attribute__((address_space(3))) unsigned char lds_b;
-  lds_i* alist = (lds_i*)(lds + L.p_alist);
-  lds_b* act = (lds_b*)(lds + L.p_act);
-  lds_d* red = lds + L.red;
-  lds_d* scal = lds + L.scal;
-  const lds_d* gd = lds + L.gd;
-  const lds_d* g = lds + L.g;
-  const lds_d* q = lds + L.q;
-  const double TOL = 1e-10;
-  const int lane = TID & 63;
-  const int NONE = 0x7fffffff;
-
-  __syncthreads();
-  PROF_BEGIN(pt_qp);
-  for (int r = TID; r < nc; r += NT) act[r] = 0;
-  dev_p_mul(c, q, x, -1.0);  // unconstrained minimiser x = -P q
-  int m = 0;
-  int ret = 2;
-  // ---- warm start from the final active set W of this scenario's previous QP.  (x(W'), W') with x(W') the minimiser on
-  // the rows W' held as equalities and multipliers >= 0 is a valid S-pair for any independent W' subset of W, so the dual
-  // method continues from it and reaches the same (unique) minimiser; only the path is shorter.  Building R for W costs
-  // one P a_j (a column copy for box / rate rows) and one forward substitution per row instead of a full dual step.
-  lds_i* prev = (lds_i*)(lds + L.w_prev);
-  lptr prevlam = lds + L.w_prevlam;
-  const int nprev = D.par.qp_warm_start ? (int)scal[DG_QP_NPREV] : 0;
-  if (nprev > 0) {
-    PROF_BEGIN(pqw);
-    clptr Pp = LP(L.g_Bp);
-    PROF_BEGIN(pw1);
-    for (int jj = 0; jj < nprev; jj++) {
-      const int p = prev[jj];
-      const DgRow Rw = ld_row(p);
-      __syncthreads();
-      if (Rw.dense < 0) {
-        const int c1 = am_col(D, Rw.a, Rw.k, Rw.idx);
-        const bool has0 = (Rw.type == DG_R_RATE_UB || Rw.type == DG_R_RATE_LB) && Rw.k > 0;
-        const double sgn = (Rw.type == DG_R_IN_UB || Rw.type == DG_R_RATE_UB) ? 1.0 : -1.0;
-        for (int i = TID; i < n; i += NT) {
-          double pv = Pp[tri(i, c1)], av = i == c1 ? 1.0 : 0.0;
-          if (has0) { pv -= Pp[tri(i, c1 - DGSQP_NUA)]; if (i == c1 - DGSQP_NUA) av = -1.0; }
-          y[i] = sgn * pv; tv[i] = sgn * av;
-        }
-      } else {
-        for (int col = TID; col < n; col += NT) tv[col] = g_row_coef(D, gd, p, col);
-        dev_p_mul(c, tv, y, 1.0);
-      }
-      __syncthreads();
-      for (int j = TID; j < m; j += NT) cvec[j] = g_row_dot(D, gd, alist[j], y);
-      double part = 0, part2 = 0;
-      for (int i = TID; i < n; i += NT) { part += tv[i] * y[i]; part2 += tv[i] * tv[i]; }
-      const double app = block_sum(part, red);
-      const double apap = block_sum(part2, red);
-      if (TID < 64) {
-        double w0_, w1_;
-        const double ww = qp_wave_fwd(R, rd, m, npk, lane, cvec, wv, w0_, w1_);
-        const double delta = app - ww;
-        const bool indep = delta > 1e-11 * app && delta > 1e-18 * apap;
-        if (indep) {
-          if (lane < m) R[tri(m, lane)] = wv[lane];
-          if (lane + 64 < m) R[tri(m, lane + 64)] = wv[lane + 64];
-          if (lane == 0) { const double sd = sqrt(delta); R[tri(m, m)] = sd; rd[m] = 1.0 / sd; alist[m] = p; act[p] = 1; lam[m] = prevlam[jj]; }
-        }
-        if (lane == 0) scal[0] = indep ? 1.0 : 0.0;
-      }
-      __syncthreads();
-      if (scal[0] != 0.0) m++;
-    }
-    PROF_END(PH_W_BUILD, pw1);
-    PROF_COUNT(PH_C_NPREV, nprev); PROF_COUNT(PH_C_MBUILD, m);
-    PROF_BEGIN(pw2);
-    // Multipliers: primal active-set steps on the dual problem restricted to W (min 1/2 l'Sl - v'l, l >= 0), from the
-    // previous QP's multipliers l0 > 0 towards the equality solution l_eq = S^-1 v; the first multiplier to reach zero
-    // leaves W and l_eq is recomputed.  v = A x_unc - b does not change.  All inside wavefront 0.
-    __syncthreads();
-    for (int j = TID; j < m; j += NT) cvec[j] = g[alist[j]] + g_row_dot(D, gd, alist[j], x);
-    __syncthreads();
-    if (TID < 64) {
-      int mm = m;
-      while (mm > 0) {
-        double r0, r1;
-        (void)qp_wave_solve(R, rd, mm, npk, lane, cvec, wv, rv, r0, r1);   // rv = l_eq
-        const double l0 = lane < mm ? lam[lane] : 0.0, l1 = lane + 64 < mm ? lam[lane + 64] : 0.0;
-        double t = INFINITY; int jd = NONE;
-        if (lane < mm && r0 < 0.0) { t = l0 > 0.0 ? l0 / (l0 - r0) : 0.0; jd = lane; }
-        if (lane + 64 < mm && r1 < 0.0) { const double t1 = l1 > 0.0 ? l1 / (l1 - r1) : 0.0; if (t1 < t) { t = t1; jd = lane + 64; } }
-        wave_argmin(t, jd);
-        if (jd == NONE) {
-          if (lane < mm) lam[lane] = r0;
-          if (lane + 64 < mm) lam[lane + 64] = r1;
-          break;
-        }
-        if (lane < mm) lam[lane] = l0 + t * (r0 - l0);
-        if (lane + 64 < mm) lam[lane + 64] = l1 + t * (r1 - l1);
-        // shift the right-hand side with the columns
-        const double ca = (lane >= jd && lane + 1 < mm) ? cvec[lane + 1] : 0.0, cb = (lane + 64 >= jd && lane + 65 < mm) ? cvec[lane + 65] : 0.0;
-        qp_wave_drop(R, rd, alist, lam, act, mm, jd, lane);
-        if (lane >= jd && lane + 1 < mm) cvec[lane] = ca;
-        if (lane + 64 >= jd && lane + 65 < mm) cvec[lane + 64] = cb;
-        mm--;
-      }
-      if (lane == 0) scal[1] = (double)mm;
-    }
-    __syncthreads();
-    m = (int)scal[1];
-    __syncthreads();
-    PROF_END(PH_W_MULT, pw2);
-    PROF_COUNT(PH_C_MWARM, m);
-    PROF_BEGIN(pw3);
-    if (m > 0) {
-      for (int j = TID; j < m; j += NT) lam[j] = rv[j];
-      for (int col = TID; col < n; col += NT) {
-        double s2 = 0;
-        for (int j = 0; j < m; j++) s2 += rv[j] * g_row_coef(D, gd, alist[j], col);
-        z[col] = s2;
-      }
-      dev_p_mul(c, z, cvec, 1.0);
-      for (int i = TID; i < n; i += NT) x[i] -= cvec[i];
-      __syncthreads();
-    }
-    PROF_END(PH_W_X, pw3);
-    PROF_END(PH_Q_WARM, pqw);
-  }
-  const int max_outer = 4 * (n + nc);
-  for (int iter = 0; iter < max_outer; iter++) {
-    // ---- step 1: most violated inactive constraint (lowest index on ties)
-    PROF_BEGIN(pq1);
-    double best = -TOL;
-    int bi = NONE;
-    for (int r = TID; r < nc; r += NT) {
-      if (act[r]) continue;
-      const double s = -(g[r] + g_row_dot(D, gd, r, x));
-      if (s < best || (s == best && r < bi)) { best = s; bi = r; }
-    }
-    double bv; int p;
-    block_argmin(best, bi, red, bv, p);
-    PROF_END(PH_Q_SCAN, pq1);
-    if (p == NONE) { ret = 0; break; }
-    PROF_BEGIN(pq2);
-#ifdef DG_PROF
-    if (TID == 0) { atomicAdd(&dg_prof[2 * PH_SWEEP], 1ULL); }
-#endif
-    for (int col = TID; col < n; col += NT) tv[col] = g_row_coef(D, gd, p, col);
-    dev_p_mul(c, tv, y, 1.0);  // y = P a_p
-    double part = 0, part2 = 0;
-    for (int i = TID; i < n; i += NT) { part += tv[i] * y[i]; part2 += tv[i] * tv[i]; }
-    const double app = block_sum(part, red);
-    const double apap = block_sum(part2, red);
-    PROF_END(PH_Q_Y, pq2);
-    double lp = 0.0;
-    bool infeasible = false;
-    for (int inner = 0; inner < 4 * (n + nc); inner++) {
-      // ---- step 2a: directions.  c = A_A y ; R^T w = c ; r = R^-1 w
-      PROF_BEGIN(pq3);
-      for (int j = TID; j < m; j += NT) cvec[j] = g_row_dot(D, gd, alist[j], y);
-      double pv = 0;
-      for (int i = TID; i < n; i += NT) pv += tv[i] * x[i];
-      const double viol = block_sum(pv, red) + g[p];  // a_p.x - b_p  (b = -g), > 0
-      if (TID < 64) {
-        double r0, r1;
-        const double ww = qp_wave_solve(R, rd, m, npk, lane, cvec, wv, rv, r0, r1);
-        // ---- step 2b: step lengths.  t1 keeps the multipliers >= 0, t2 makes constraint p active
-        double t1 = INFINITY; int jd = NONE;
-        if (lane < m && r0 > 0) { t1 = lam[lane] / r0; jd = lane; }
-        if (lane + 64 < m && r1 > 0) { const double tt = lam[lane + 64] / r1; if (tt < t1) { t1 = tt; jd = lane + 64; } }
-        wave_argmin(t1, jd);
-        if (lane == 0) {
-          const double delta = app - ww;  // a_p^T (P - P A^T S^-1 A P) a_p >= 0
-          const bool indep = delta > 1e-11 * app && delta > 1e-18 * apap;
-          const double t2 = indep ? viol / delta : INFINITY;
-          scal[0] = fmin(t1, t2);
-          scal[1] = (double)jd;
-          scal[2] = delta;
-          scal[3] = indep ? 0.0 : 1.0;          // 1: dual step only
-          scal[4] = (t1 < t2) ? 1.0 : 0.0;      // 1: partial step (blocking multiplier reaches 0 first)
-        }
-      }
-      __syncthreads();
-      PROF_END(PH_Q_DIR, pq3);
-      PROF_BEGIN(pq4);
-      const double t = scal[0];
-      const int jd = (int)scal[1];
-      const double delta = scal[2];
-      const bool dual_only = scal[3] != 0.0;
-      const bool partial = scal[4] != 0.0;
-      if (!(t < INFINITY)) { infeasible = true; break; }
-      if (!dual_only) {
-        // primal direction z = -(y - P A_A^T r);  x += t z
-        for (int col = TID; col < n; col += NT) {
-          double s = 0;
-          for (int j = 0; j < m; j++) s += rv[j] * g_row_coef(D, gd, alist[j], col);
-          z[col] = s;
-        }
-        dev_p_mul(c, z, cvec, 1.0);
-        for (int i = TID; i < n; i += NT) x[i] += t * (cvec[i] - y[i]);
-      }
-      for (int j = TID; j < m; j += NT) lam[j] -= t * rv[j];
-      lp += t;
-      __syncthreads();
-      PROF_END(PH_Q_STEP, pq4);
-      PROF_BEGIN(pq5);
-      if (!dual_only && !partial) {
-        // ---- full step: constraint p becomes active, append column [w ; sqrt(delta)] to R
-        for (int i = TID; i < m; i += NT) R[tri(m, i)] = wv[i];
-        if (TID == 0) { const double sd = sqrt(delta); R[tri(m, m)] = sd; rd[m] = 1.0 / sd; alist[m] = p; lam[m] = lp; act[p] = 1; }
-        m++;
-        __syncthreads();
-        PROF_END(PH_Q_UPD, pq5);
-        break;
-      }
-      // ---- partial / dual-only step: drop blocking constraint jd (column deletion + Givens)
-#ifdef DG_PROF
-      if (TID == 0) { atomicAdd(&dg_prof[2 * PH_SWEEP + 1], 1ULL); }
-#endif
-      if (TID < 64) qp_wave_drop(R, rd, alist, lam, act, m, jd, lane);
-      m--;
-      __syncthreads();
-      PROF_END(PH_Q_UPD, pq5);
-    }
-    if (infeasible) { ret = 1; break; }
-  }
-  __syncthreads();
-  // Iterative refinement on the final active set (what OSQP's polish does with polish_refine_iter):
-  // P is an explicit inverse, so the active rows hold to ~1e-12 only; two projection steps
-  //   x <- x - P A^T S^-1 (A x - b),  lam <- lam + S^-1 (A x - b)
-  // bring them to rounding level.
-  PROF_COUNT(PH_C_MFINAL, m);
-  PROF_BEGIN(pq6);
-  if (ret == 0 && m > 0) {
-    for (int pass = 0; pass < 2; pass++) {
-      for (int j = TID; j < m; j += NT) cvec[j] = g[alist[j]] + g_row_dot(D, gd, alist[j], x);
-      __syncthreads();
-      if (TID < 64) { double r0, r1; (void)qp_wave_solve(R, rd, m, npk, lane, cvec, wv, rv, r0, r1); }
-      __syncthreads();
-      for (int col = TID; col < n; col += NT) {
-        double s = 0;
-        for (int j = 0; j < m; j++) s += rv[j] * g_row_coef(D, gd, alist[j], col);
-        z[col] = s;
-      }
-      dev_p_mul(c, z, cvec, 1.0);
-      for (int i = TID; i < n; i += NT) x[i] -= cvec[i];
-      for (int j = TID; j < m; j += NT) lam[j] += rv[j];
-      __syncthreads();
-    }
-  }
-  PROF_END(PH_Q_REFINE, pq6);
-  for (int r = TID; r < nc; r += NT) lhat[r] = 0.0;
-  __syncthreads();
-  if (ret == 0)
-    for (int j = TID; j < m; j += NT) { lhat[alist[j]] = lam[j]; prev[j] = alist[j]; prevlam[j] = lam[j]; }
-  if (TID == 0) scal[DG_QP_NPREV] = ret == 0 ? (double)m : 0.0;
-  __syncthreads();
-  PROF_END(PH_QP, pt_qp);
-  return ret;
-}
+#include "dgsqp_qp.h"
 
 // ------------------------------------------------------------------------------------------------
 // dual initialisation  l = max(0, -lsqr(G G^T, G q))   (DGSQP.py:320-327).
