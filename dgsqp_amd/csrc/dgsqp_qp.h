@@ -257,7 +257,109 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
   const int nprev = D.par.qp_warm_start ? (int)q.scal[DG_QP_NPREV] : 0;
   if (nprev > 0) {
     PROF_BEGIN(pqw);
-    for (int jj = 0; jj < nprev; jj++) {
+    // (a) y_j = P a_j for the first NB guessed rows, straight into Y slot j: box / rate rows are column copies (one
+    //     wavefront per row), dense rows go through the block-wide product.
+    int NB = nprev < 48 ? nprev : 48;
+    { int cap = (int)sqrt((double)npk) - 1; if (NB > cap) NB = cap; if (NB < 0) NB = 0; }
+    lptr Sb = q.R + NB * (NB + 1) / 2;     // S = A Y (packed by rows) lives behind the part of R the batch can fill
+    for (int jj = TID >> 6; jj < NB; jj += NT / 64) {
+      const DgRow Rw = ld_row(q.prev[jj]);
+      if (Rw.dense >= 0) continue;
+      const int c1 = am_col(D, Rw.a, Rw.k, Rw.idx);
+      const bool has0 = (Rw.type == DG_R_RATE_UB || Rw.type == DG_R_RATE_LB) && Rw.k > 0;
+      const double sgn = (Rw.type == DG_R_IN_UB || Rw.type == DG_R_RATE_UB) ? 1.0 : -1.0;
+      for (int i = lane; i < n; i += 64) {
+        double pv = q.Pp[tri(i, c1)];
+        if (has0) pv -= q.Pp[tri(i, c1 - DGSQP_NUA)];
+        q.Y[(int64_t)jj * n + i] = sgn * pv;
+      }
+    }
+    for (int jj = 0; jj < NB; jj++) {
+      const int p = q.prev[jj];
+      if (ld_row(p).dense < 0) continue;          // uniform
+      __syncthreads();
+      for (int col = TID; col < n; col += NT) q.tv[col] = g_row_coef(D, q.gd, p, col);
+      dev_p_mul(c, q.tv, q.yv, 1.0);
+      for (int i = TID; i < n; i += NT) q.Y[(int64_t)jj * n + i] = q.yv[i];
+    }
+    __threadfence_block();
+    __syncthreads();
+    // (b) S_ij = a_i . y_j for i <= j < NB, one thread per pair; |a_j|^2 into tv[j]
+    for (int t = TID; t < NB * (NB + 1) / 2; t += NT) {
+      int j = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+      while ((j + 1) * (j + 2) / 2 <= t) j++;
+      while (j * (j + 1) / 2 > t) j--;
+      const int i = t - j * (j + 1) / 2;
+      const DgRow Ri = ld_row(q.prev[i]);
+      cgptr yj = q.Y + (int64_t)j * n;
+      double sv, a2;
+      if (Ri.dense < 0) {
+        const int c1 = am_col(D, Ri.a, Ri.k, Ri.idx);
+        const bool has0 = (Ri.type == DG_R_RATE_UB || Ri.type == DG_R_RATE_LB) && Ri.k > 0;
+        const double sgn = (Ri.type == DG_R_IN_UB || Ri.type == DG_R_RATE_UB) ? 1.0 : -1.0;
+        sv = yj[c1];
+        if (has0) sv -= yj[c1 - DGSQP_NUA];
+        sv *= sgn;
+        a2 = has0 ? 2.0 : 1.0;
+      } else {
+        const DgDense dd = ld_dense(Ri.dense);
+        const int len = DGSQP_NUA * dd.k;
+        clptr gp = q.gd + dd.off;
+        double s0 = 0, s1 = 0, n0 = 0, n1 = 0;
+        for (int part = 0; part < (dd.kind == 1 ? 2 : 1); part++) {
+          cgptr yy = yj + (part == 0 ? dd.a : dd.b) * D.N * DGSQP_NUA;
+          clptr gg = gp + part * len;
+          int e = 0;
+          for (; e + 1 < len; e += 2) {
+            const double g0 = gg[e], g1 = gg[e + 1];
+            s0 = __builtin_fma(g0, yy[e], s0); s1 = __builtin_fma(g1, yy[e + 1], s1);
+            n0 = __builtin_fma(g0, g0, n0); n1 = __builtin_fma(g1, g1, n1);
+          }
+          if (e < len) { const double g0 = gg[e]; s0 = __builtin_fma(g0, yy[e], s0); n0 = __builtin_fma(g0, g0, n0); }
+        }
+        sv = Ri.sgn * (s0 + s1);
+        a2 = n0 + n1;
+      }
+      Sb[t] = sv;
+      if (i == j) q.tv[j] = a2;
+    }
+    __syncthreads();
+    // (c) bordering Cholesky of S in wavefront 0 (rows that are numerically dependent on the accepted ones are skipped);
+    //     yslot[k] is both the Y slot and the batch index of accepted row k
+    if (w0) {
+      for (int j = 0; j < NB; j++) {
+        const int m = S.m;
+        const int rowj = j * (j + 1) / 2;
+        for (int k = lane; k < m; k += 64) q.cvec[k] = Sb[rowj + q.yslot[k]];
+        const double app = Sb[rowj + j], apap = q.tv[j];
+        double wa, wb;
+        const double ww = qpw_fwd(q.R, q.rd, m, npk, lane, q.cvec, q.wv, wa, wb);
+        const double delta = app - ww;
+        if (m < n && delta > 1e-11 * app && delta > 1e-18 * apap) {
+          if (lane < m) q.R[tri(m, lane)] = wa;
+          if (lane + 64 < m) q.R[tri(m, lane + 64)] = wb;
+          if (lane == 0) {
+            const int p = q.prev[j];
+            const double sd = sqrt(delta);
+            q.R[tri(m, m)] = sd; q.rd[m] = 1.0 / sd; q.alist[m] = p; q.lam[m] = q.prevlam[j]; q.act[p] = 1; q.yslot[m] = j;
+          }
+          S.m++;
+        }
+      }
+      // free Y slots: everything not taken by an accepted row
+      int base = 0;
+      for (int h = 0; h < 2; h++) {
+        const int sl = lane + 64 * h;
+        bool fr = sl < n;
+        for (int k = 0; k < S.m; k++) fr = fr && q.yslot[k] != sl;
+        const unsigned long long mask = __ballot(fr);
+        if (fr) q.yfree[base + __popcll(mask & ((1ull << lane) - 1ull))] = sl;
+        base += __popcll(mask);
+      }
+      S.nfree = base;
+    }
+    // (d) guesses beyond the batch (rare): one at a time
+    for (int jj = NB; jj < nprev; jj++) {
       const int p = q.prev[jj];
       qp_row_products(c, q, p);
       if (w0) {

@@ -491,6 +491,20 @@ __device__ inline double qpw_fwd(clptr R, clptr rd, int m, int npk, int lane, cl
   double w0 = 0, w1 = 0;
   const int rowA = lane * (lane + 1) / 2, rowB = (lane + 64) * (lane + 65) / 2;
   int i = 0;
+  if (m <= 64) {   // common case: one register per lane
+    for (; i + 3 < m; i += 4) {
+      double d[4], a[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) { d[k] = rd[i + k]; a[k] = R[QP_NPK_CLAMP(rowA + i + k)]; }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int ii = i + k;
+        const double wi = lane_bcast(c0, ii) * d[k];
+        w0 = lane == ii ? wi : w0;
+        c0 -= (lane > ii && lane < m) ? a[k] * wi : 0.0;
+      }
+    }
+  }
   for (; i + 3 < m; i += 4) {
     double d[4], a[4], b[4];
 #pragma unroll
@@ -526,6 +540,24 @@ __device__ inline double qpw_solve(clptr R, clptr rd, int m, int npk, int lane, 
   const double ww = qpw_fwd(R, rd, m, npk, lane, cvec, wv, w0, w1);
   double r0 = 0, r1 = 0;
   int j = m - 1;
+  if (m <= 64) {
+    for (; j >= 3; j -= 4) {
+      double d[4], a[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int jj = j - k;
+        d[k] = rd[jj];
+        a[k] = R[jj * (jj + 1) / 2 + (lane < jj ? lane : jj)];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int jj = j - k;
+        const double rj = lane_bcast(w0, jj) * d[k];
+        r0 = lane == jj ? rj : r0;
+        w0 -= lane < jj ? a[k] * rj : 0.0;
+      }
+    }
+  }
   for (; j >= 3; j -= 4) {
     double d[4], a[4], b[4];
 #pragma unroll
@@ -584,9 +616,10 @@ __device__ inline void qpw_drop(lptr R, lptr rd, lds_i_t* alist, lds_i_t* yslot,
       if (lane == (k & 63)) dk = R[tri(k, k)];
       dk = lane_bcast(dk, k & 63);
       const double sub = lane_bcast(k < 64 ? suba : subb, k & 63);
-      const double h = hypot(dk, sub);
-      const double cs = h > 0 ? dk / h : 1.0, sn = h > 0 ? sub / h : 0.0;
-      if (lane == (k & 63)) { R[tri(k, k)] = h; rd[k] = 1.0 / h; }
+      const double h = sqrt(dk * dk + sub * sub);     // entries of a Cholesky factor: no overflow concern
+      const double ih = h > 0 ? 1.0 / h : 0.0;
+      const double cs = h > 0 ? dk * ih : 1.0, sn = sub * ih;
+      if (lane == (k & 63)) { R[tri(k, k)] = h; rd[k] = ih; }
       if (ca > k && ca < mn) {
         const double ra = R[tri(ca, k)];
         if (ca == k + 0) {}
