@@ -456,45 +456,68 @@ __device__ inline void dev_fc(const dgsqp_problem_t& P, const dgsqp_agent_t& ag,
   if constexpr (NQA == 8) dev_fc_dyn<DEG>(P, ag, q, u, pre, dq); else dev_fc_kin<DEG>(P, ag, q, u, pre, dq);
 }
 
-// one discrete step of the joint model's integrator (dynamics_models.py:88-99, :188-219)
-template <int DEG, int NQA>
-__device__ inline void dev_fd(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const Ty<DEG>* q, const Ty<DEG>* u, Ty<DEG>* qn) {
+// one discrete step of the joint model's integrator (dynamics_models.py:88-99, :188-219).  The integrator is a template
+// parameter so that every instantiation keeps only the stage arrays it needs in registers (rk4: x, k-accumulator, k, t).
+template <int DEG, int NQA, int INTEG>
+__device__ inline void dev_fd_t(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const Ty<DEG>* q, const Ty<DEG>* u, Ty<DEG>* qn) {
   typedef Ty<DEG> T;
-  T x[NQA], k1[NQA], k2[NQA], k3[NQA], t[NQA];
+  T x[NQA], k1[NQA], k2[NQA], t[NQA];
   FcPre<DEG> pre;
   if constexpr (NQA == 8) dev_fc_pre_dyn<DEG>(ag, u, pre); else dev_fc_pre_kin<DEG>(ag, u, pre);
+#pragma unroll
   for (int i = 0; i < NQA; i++) x[i] = q[i];
-  if (P.integrator == DGSQP_INT_EULER) {
+  if constexpr (INTEG == DGSQP_INT_EULER) {
     dev_fc<DEG, NQA>(P, ag, x, u, pre, k1);
+#pragma unroll
     for (int i = 0; i < NQA; i++) qn[i] = x[i] + k1[i] * P.dt;
     return;
   }
   const double h = P.dt / P.substeps;
   for (int m = 0; m < P.substeps; m++) {
-    if (P.integrator == DGSQP_INT_RK4) {
+    if constexpr (INTEG == DGSQP_INT_RK4) {
       dev_fc<DEG, NQA>(P, ag, x, u, pre, k1);
+#pragma unroll
       for (int i = 0; i < NQA; i++) t[i] = x[i] + k1[i] * (h / 2);
       dev_fc<DEG, NQA>(P, ag, t, u, pre, k2);
+#pragma unroll
       for (int i = 0; i < NQA; i++) { t[i] = x[i] + k2[i] * (h / 2); k1[i] = k1[i] + k2[i] * 2.0; }
-      dev_fc<DEG, NQA>(P, ag, t, u, pre, k3);
-      for (int i = 0; i < NQA; i++) { t[i] = x[i] + k3[i] * h; k1[i] = k1[i] + k3[i] * 2.0; }
       dev_fc<DEG, NQA>(P, ag, t, u, pre, k2);
+#pragma unroll
+      for (int i = 0; i < NQA; i++) { t[i] = x[i] + k2[i] * h; k1[i] = k1[i] + k2[i] * 2.0; }
+      dev_fc<DEG, NQA>(P, ag, t, u, pre, k2);
+#pragma unroll
       for (int i = 0; i < NQA; i++) x[i] = x[i] + (k1[i] + k2[i]) * (h / 6.0);
-    } else if (P.integrator == DGSQP_INT_RK3) {
+    } else if constexpr (INTEG == DGSQP_INT_RK3) {
+      T k3[NQA];
       dev_fc<DEG, NQA>(P, ag, x, u, pre, k1);
+#pragma unroll
       for (int i = 0; i < NQA; i++) { k1[i] = k1[i] * h; t[i] = x[i] + k1[i] * 0.5; }
       dev_fc<DEG, NQA>(P, ag, t, u, pre, k2);
+#pragma unroll
       for (int i = 0; i < NQA; i++) { k2[i] = k2[i] * h; t[i] = x[i] - k1[i] + k2[i] * 2.0; }
       dev_fc<DEG, NQA>(P, ag, t, u, pre, k3);
+#pragma unroll
       for (int i = 0; i < NQA; i++) x[i] = x[i] + (k1[i] + k2[i] * 4.0 + k3[i] * h) / 6.0;
     } else {
       dev_fc<DEG, NQA>(P, ag, x, u, pre, k1);
+#pragma unroll
       for (int i = 0; i < NQA; i++) t[i] = x[i] + k1[i] * h;
       dev_fc<DEG, NQA>(P, ag, t, u, pre, k2);
+#pragma unroll
       for (int i = 0; i < NQA; i++) x[i] = x[i] + (k1[i] + k2[i]) * (h / 2);
     }
   }
+#pragma unroll
   for (int i = 0; i < NQA; i++) qn[i] = x[i];
+}
+template <int DEG, int NQA>
+__device__ inline void dev_fd(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const Ty<DEG>* q, const Ty<DEG>* u, Ty<DEG>* qn) {
+  switch (P.integrator) {   // uniform
+    case DGSQP_INT_EULER: dev_fd_t<DEG, NQA, DGSQP_INT_EULER>(P, ag, q, u, qn); break;
+    case DGSQP_INT_RK4: dev_fd_t<DEG, NQA, DGSQP_INT_RK4>(P, ag, q, u, qn); break;
+    case DGSQP_INT_RK3: dev_fd_t<DEG, NQA, DGSQP_INT_RK3>(P, ag, q, u, qn); break;
+    default: dev_fd_t<DEG, NQA, DGSQP_INT_RK2>(P, ag, q, u, qn); break;
+  }
 }
 
 __device__ inline int am_col(const DgProb& D, int a, int k, int j) { return a * D.N * DGSQP_NUA + k * DGSQP_NUA + j; }

@@ -241,8 +241,8 @@ __device__ inline void dir_pair(int neff, int dir, int& i, int& j) {
   while (p >= neff - 1 - i) { p -= neff - 1 - i; i++; }
   j = i + 1 + p;
 }
-template <int DEG, int NQA>
-__device__ inline void dev_taylor_item(const Ctx& c, int a, int k, int dir, clptr ue) {
+template <int DEG, int NQA, int INTEG>
+__device__ __forceinline__ void dev_taylor_item_impl(const Ctx& c, int a, int k, int dir, clptr ue) {
   const DgProb& D = dg_prob;
   const DgLds& L = D.L;
   typedef Ty<DEG> T;
@@ -254,14 +254,14 @@ __device__ inline void dev_taylor_item(const Ctx& c, int a, int k, int dir, clpt
   int ei, ej;
   dir_pair(D.neff[a], dir, ei, ej);
   {
-    const int z = D.effvar[a][ei];
-    if (z < NQA) q[z].c[1] += 1.0; else u[z - NQA].c[1] += 1.0;
+    // seed direction e_i (+ e_j): written with static indices so that q / u stay in registers
+    const int zi = D.effvar[a][ei], zj = ej != ei ? D.effvar[a][ej] : -1;
+#pragma unroll
+    for (int i = 0; i < NQA; i++) q[i].c[1] = (i == zi || i == zj) ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 0; i < 2; i++) u[i].c[1] = (NQA + i == zi || NQA + i == zj) ? 1.0 : 0.0;
   }
-  if (ej != ei) {
-    const int z = D.effvar[a][ej];
-    if (z < NQA) q[z].c[1] += 1.0; else u[z - NQA].c[1] += 1.0;
-  }
-  dev_fd<DEG, NQA>(D.P, D.P.agents[a], q, u, out);
+  dev_fd_t<DEG, NQA, INTEG>(D.P, D.P.agents[a], q, u, out);
   if (dir < D.neff[a]) {
     const int z = D.effvar[a][dir];
     if (z < NQA) {
@@ -278,6 +278,15 @@ __device__ inline void dev_taylor_item(const Ctx& c, int a, int k, int dir, clpt
     for (int o = 0; o < NQA; o++) T2[o * nd + dir] = out[o].c[2];
   }
 }
+// First-derivative items are compiled out of line, one instantiation per (model, integrator), which keeps their register
+// allocation tight (no spills for euler); the second-order items are inlined into their caller.
+template <int DEG, int NQA, int INTEG>
+__device__ __noinline__ void dev_taylor_item_ool(const Ctx& c, int a, int k, int dir, clptr ue) { dev_taylor_item_impl<DEG, NQA, INTEG>(c, a, k, dir, ue); }
+template <int DEG, int NQA, int INTEG>
+__device__ __forceinline__ void dev_taylor_item(const Ctx& c, int a, int k, int dir, clptr ue) {
+  if constexpr (DEG >= 2 && NQA == 8 && INTEG != DGSQP_INT_EULER) dev_taylor_item_impl<DEG, NQA, INTEG>(c, a, k, dir, ue);
+  else dev_taylor_item_ool<DEG, NQA, INTEG>(c, a, k, dir, ue);
+}
 template <int DEG>
 __device__ __noinline__ void dev_dyn_derivs(const Ctx& c, clptr ue) {
   const DgProb& D = dg_prob;
@@ -291,10 +300,50 @@ __device__ __noinline__ void dev_dyn_derivs(const Ctx& c, clptr ue) {
       A[o * nqa + 0] = (o == 0) ? 1.0 : 0.0;
       A[o * nqa + 1] = (o == 1) ? 1.0 : 0.0;
     }
-    const int nd = (DEG >= 2) ? D.ndir[a] : D.neff[a];
-    for (int it = TID; it < D.N * nd; it += NT) {
-      const int k = it / nd, dir = it % nd;
-      if (nqa == 8) dev_taylor_item<DEG, 8>(c, a, k, dir, ue); else dev_taylor_item<DEG, 6>(c, a, k, dir, ue);
+  }
+  // Work is handed out in wave-tasks of 64 items of ONE agent (the agent's constants then live in scalar registers),
+  // round-robin over the wavefronts: all agents are in flight together instead of one 200-item pass per agent.
+  // Measured on MI355X: the second-order pass of the dynamic bicycle under a multi-stage integrator spills ~1.2 KB per
+  // lane and runs 1.6x faster when all wavefronts sweep one agent at a time; every other case prefers the wave-tasks below.
+  bool heavy = DEG >= 2 && D.P.integrator != DGSQP_INT_EULER;
+  for (int a = 0; a < D.M; a++) heavy = heavy && D.nqa[a] == 8;
+  if (heavy) {
+    for (int a = 0; a < D.M; a++) {
+      const int nd = (DEG >= 2) ? D.ndir[a] : D.neff[a];
+      for (int it = TID; it < D.N * nd; it += NT) {
+        const int k = it / nd, dir = it % nd;
+        const bool dyn = D.nqa[a] == 8;
+        switch (D.P.integrator) {
+          case DGSQP_INT_EULER: if (dyn) dev_taylor_item<DEG, 8, DGSQP_INT_EULER>(c, a, k, dir, ue); else dev_taylor_item<DEG, 6, DGSQP_INT_EULER>(c, a, k, dir, ue); break;
+          case DGSQP_INT_RK4: if (dyn) dev_taylor_item<DEG, 8, DGSQP_INT_RK4>(c, a, k, dir, ue); else dev_taylor_item<DEG, 6, DGSQP_INT_RK4>(c, a, k, dir, ue); break;
+          case DGSQP_INT_RK3: if (dyn) dev_taylor_item<DEG, 8, DGSQP_INT_RK3>(c, a, k, dir, ue); else dev_taylor_item<DEG, 6, DGSQP_INT_RK3>(c, a, k, dir, ue); break;
+          default: if (dyn) dev_taylor_item<DEG, 8, DGSQP_INT_RK2>(c, a, k, dir, ue); else dev_taylor_item<DEG, 6, DGSQP_INT_RK2>(c, a, k, dir, ue); break;
+        }
+      }
+    }
+  } else {
+    const int wave = TID >> 6, lane = TID & 63;
+    int ntask = 0;
+    for (int a = 0; a < D.M; a++) ntask += (D.N * ((DEG >= 2) ? D.ndir[a] : D.neff[a]) + 63) >> 6;
+    for (int t = wave; t < ntask; t += NT / 64) {
+      int a = 0, rem = t;
+      for (;; a++) {
+        const int nt = (D.N * ((DEG >= 2) ? D.ndir[a] : D.neff[a]) + 63) >> 6;
+        if (rem < nt) break;
+        rem -= nt;
+      }
+      const int nd = (DEG >= 2) ? D.ndir[a] : D.neff[a];
+      const int it = rem * 64 + lane;
+      if (it < D.N * nd) {
+        const int k = it / nd, dir = it % nd;
+        const bool dyn = D.nqa[a] == 8;
+        switch (D.P.integrator) {   // one out-of-line instantiation per (model, integrator): registers are allocated per variant
+          case DGSQP_INT_EULER: if (dyn) dev_taylor_item<DEG, 8, DGSQP_INT_EULER>(c, a, k, dir, ue); else dev_taylor_item<DEG, 6, DGSQP_INT_EULER>(c, a, k, dir, ue); break;
+          case DGSQP_INT_RK4: if (dyn) dev_taylor_item<DEG, 8, DGSQP_INT_RK4>(c, a, k, dir, ue); else dev_taylor_item<DEG, 6, DGSQP_INT_RK4>(c, a, k, dir, ue); break;
+          case DGSQP_INT_RK3: if (dyn) dev_taylor_item<DEG, 8, DGSQP_INT_RK3>(c, a, k, dir, ue); else dev_taylor_item<DEG, 6, DGSQP_INT_RK3>(c, a, k, dir, ue); break;
+          default: if (dyn) dev_taylor_item<DEG, 8, DGSQP_INT_RK2>(c, a, k, dir, ue); else dev_taylor_item<DEG, 6, DGSQP_INT_RK2>(c, a, k, dir, ue); break;
+        }
+      }
     }
   }
   __syncthreads();
