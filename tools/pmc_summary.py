@@ -1,0 +1,28 @@
+"""Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, see MI355X_MICROARCH.md) into the JSON
+bench.py reads for roofline.traffic.  usage: pmc_summary.py <fetch_counter_csv> <write_counter_csv> <workload> <batch> <out.json>"""
+import csv, json, sys
+
+
+def per_launch(path, counter):
+    tot, n = 0.0, 0
+    for row in csv.DictReader(open(path)):
+        if row['Kernel_Name'].startswith('dg_solve_kernel') and row['Counter_Name'] == counter:
+            tot += float(row['Counter_Value']); n += 1
+    return tot / max(n, 1), n
+
+
+fetch_kb, nf = per_launch(sys.argv[1], 'FETCH_SIZE')
+write_kb, nw = per_launch(sys.argv[2], 'WRITE_SIZE')
+out = {
+    'workload': sys.argv[3], 'batch_per_gpu': int(sys.argv[4]), 'kernel': 'dg_solve_kernel',
+    'launches_averaged': [nf, nw],
+    'FETCH_SIZE_KB': fetch_kb, 'WRITE_SIZE_KB': write_kb,
+    # gfx950: FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads (x2 correction); this kernel's global
+    # traffic is 8-byte per lane (Taylor tensor, raw Q, y_j columns, spills), for which the factor is not calibrated, so
+    # the uncorrected figure is used and the read side is a lower bound.  WRITE_SIZE is exact.
+    'traffic_bytes_per_launch': (fetch_kb + write_kb) * 1024.0,
+    'note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; values are KB per launch of one batch. '
+            'Traffic is per-workgroup scratch (Taylor tensor, raw Q, active-row products, register spills), not the algorithmic I/O.',
+}
+json.dump(out, open(sys.argv[5], 'w'), indent=1)
+print(json.dumps(out))
