@@ -18,6 +18,7 @@ __device__ inline int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : 
 // Returns false (nothing written) when there are more than PSD_KMAX negative eigenvalues: caller falls back
 // to the Jacobi route.
 // ------------------------------------------------------------------------------------------------
+#include <type_traits>
 #define PSD_KMAX DG_PSD_KMAX
 // Number of eigenvalues of the symmetric tridiagonal (d, e) below sigma = number of sign changes of the
 // Sturm sequence p_0 = 1, p_1 = d_0 - s, p_{i+1} = (d_i - s) p_i - e_{i-1}^2 p_{i-1}  (division-free, rescaled).
@@ -163,7 +164,13 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
     for (int r = 0; r < RPT; r++) cb0[hf + NH * r] = Br[r];
   }
   __syncthreads();
-  for (int k = 0; k < n - 2; k++) {
+  // Two barriers per step: every wavefront keeps its OWN copy of w (in the eigenvector area, unused until later), so
+  // w never has to be published.  Rows that are already reduced (i <= k for every thread) are skipped in quarter-steps
+  // of the register tile (R0), which removes about a third of the sweep work.
+  lptr wfw = Z + wave * (NH * RPT + 4);
+  for (int i = lane; i < NH * RPT + 4; i += 64) wfw[i] = 0.0;
+  auto hh_step = [&](int k, auto r0tag) {
+    constexpr int R0 = decltype(r0tag)::value;
     const int m = n - k - 1;
     clptr cb = (k & 1) ? cb1 : cb0;
     lptr cbn = (k & 1) ? cb0 : cb1;
@@ -190,7 +197,7 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
       // p_j = sum_i B[i][j] v_i over this thread's rows (B symmetric => column sums give the matvec)
       double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
-      for (int r = 0; r < RPT; r++) {
+      for (int r = R0; r < RPT; r++) {
         const int i = hf + NH * r;
         double vi = cb[i];
         vi = (i == k + 1) ? vi - dshift : vi;
@@ -199,7 +206,7 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
       }
       if (colok) pp[hf * n + jc] = (s0 + s1) + (s2 + s3);
       __syncthreads();                                                            // barrier 1: partial sums
-      // -- every wave: p, K = beta/2 p^T v ; threads < n publish w = p - K v at full index
+      // -- every wave: p, K = beta/2 p^T v, w = p - K v into its private copy (full row index, zero for rows <= k)
       double pa = 0.0, pb = 0.0;
 #pragma unroll
       for (int h = 0; h < NH; h++) {
@@ -209,24 +216,21 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
       pa *= beta; pb *= beta;
       const double va = lane == 0 ? xa - dshift : xa, vb = xb;
       const double K = 0.5 * beta * wave_sum(pa * va + pb * vb);
-      if (wave == 0) {
-        if (lane < m) wf[k + 1 + lane] = pa - K * va;
-        if (lane + 64 < m) wf[k + 1 + lane + 64] = pb - K * vb;
-        if (lane == 0) wf[k] = 0.0;
-      }
-      __syncthreads();                                                            // barrier 2: w
+      if (lane < m) wfw[k + 1 + lane] = pa - K * va;
+      if (lane + 64 < m) wfw[k + 1 + lane + 64] = pb - K * vb;
+      if (lane == 0) wfw[k] = 0.0;
       {
         double vj = colok ? cb[jc] : 0.0;
         vj = (jc == k + 1) ? vj - dshift : vj;
         vj = (jc > k) ? vj : 0.0;
-        const double wj = colok ? wf[jc] : 0.0;   // zero for columns <= k
+        const double wj = colok ? wfw[jc] : 0.0;   // zero for columns <= k
 #pragma unroll
-        for (int r = 0; r < RPT; r++) {
+        for (int r = R0; r < RPT; r++) {
           const int i = hf + NH * r;
           double vi = cb[i];
           vi = (i == k + 1) ? vi - dshift : vi;
           vi = (i > k) ? vi : 0.0;
-          Br[r] -= vi * wj + wf[i] * vj;
+          Br[r] -= vi * wj + wfw[i] * vj;
         }
       }
     }
@@ -234,7 +238,15 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
 #pragma unroll
       for (int r = 0; r < RPT; r++) cbn[hf + NH * r] = Br[r];
     }
-    __syncthreads();                                                              // barrier 3: next column
+    __syncthreads();                                                              // barrier 2: next column
+  };
+  {
+    constexpr int Q1 = RPT / 4, Q2 = RPT / 2, Q3 = (3 * RPT) / 4;
+    int k = 0;
+    for (; k < n - 2 && k < NH * Q1 - 1; k++) hh_step(k, std::integral_constant<int, 0>());
+    for (; k < n - 2 && k < NH * Q2 - 1; k++) hh_step(k, std::integral_constant<int, Q1>());
+    for (; k < n - 2 && k < NH * Q3 - 1; k++) hh_step(k, std::integral_constant<int, Q2>());
+    for (; k < n - 2; k++) hh_step(k, std::integral_constant<int, Q3>());
   }
 #pragma unroll
   for (int r = 0; r < RPT; r++) {

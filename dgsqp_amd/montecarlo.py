@@ -204,7 +204,7 @@ def sample_scenarios(game: Game, B: int, seed: int = 1, max_rounds: int = 200):
     """Rejection-sample B two-agent scenarios (chicane.py:384-404, :465-467).
     Returns x0 [B, n_q] and u_ws [B, N, n_u] (time-major, as ``set_warm_start`` expects)."""
     if game.joint_model.n_a != 2:
-        raise NotImplementedError('sampler of the 2-agent scripts')
+        return _sample_scenarios_independent(game, B, seed, max_rounds)
     rng = np.random.default_rng(seed)
     track, hw, obs_d = game.track, game.half_width, game.obs_d
     N, dt = game.params.N, game.params.dt
@@ -239,6 +239,50 @@ def sample_scenarios(game: Game, B: int, seed: int = 1, max_rounds: int = 200):
         keep = ~(dist < obs_d).any(axis=1)           # check_collision (chicane.py:38-43)
         x0s.append(np.concatenate([q0[0][keep], q0[1][keep]], axis=1))
         uws.append(np.concatenate([u_ws[0][keep], u_ws[1][keep]], axis=2))
+        have += int(keep.sum())
+    x0 = np.concatenate(x0s)[:B]
+    u = np.concatenate(uws)[:B]
+    if x0.shape[0] < B:
+        raise RuntimeError('sampler did not produce enough collision-free scenarios')
+    return np.ascontiguousarray(x0), np.ascontiguousarray(u)
+
+
+def _sample_scenarios_independent(game: Game, B: int, seed: int, max_rounds: int):
+    """M-agent sampler of scripts/DGSQP_monte_carlo_agents.py:262-308: every agent is placed independently on the first
+    track segment (s, e_y uniform, v in [2,3]), PID warm starts, rejection on any pairwise collision along the horizon."""
+    rng = np.random.default_rng(seed)
+    track, hw = game.track, game.half_width
+    N, dt = game.params.N, game.params.dt
+    first_seg_len = track.cl_segs[0, 0]
+    models = game.joint_model.dynamics_models
+    M = len(models)
+    radii = list(game.shared_constraints.radii) if game.shared_constraints is not None else [game.obs_d / 2] * M
+    x0s, uws = [], []
+    have = 0
+    for _ in range(max_rounds):
+        if have >= B:
+            break
+        n = max(64, 4 * (B - have))
+        q0, q_ws, u_ws = [], [], []
+        for mdl in models:
+            s_ = np.maximum(0.1, rng.random(n) * first_seg_len)
+            ey = rng.random(n) * hw * 2 - hw
+            v = rng.random(n) + 2
+            xy = np.array([track.local_to_global((si, ei_, 0.0))[:2] for si, ei_ in zip(s_, ey)]).reshape(-1, 2)
+            q = np.zeros((n, mdl.n_q))
+            q[:, 0], q[:, 1], q[:, 2] = xy[:, 0], xy[:, 1], v
+            q[:, mdl.s_idx], q[:, mdl.ey_idx] = s_, ey
+            rl = game.agent_constraints[0]
+            du = (10.0, 4.5) if rl is None else tuple(rl.rate_max)
+            qw, uw = pid_warm_start(mdl, q, N, dt, du=du)
+            q0.append(q); q_ws.append(qw); u_ws.append(uw)
+        keep = np.ones(n, bool)
+        for i in range(M):
+            for j in range(i + 1, M):
+                dist = np.linalg.norm(q_ws[i][:, :, :2] - q_ws[j][:, :, :2], axis=2)
+                keep &= ~(dist < radii[i] + radii[j]).any(axis=1)
+        x0s.append(np.concatenate([q[keep] for q in q0], axis=1))
+        uws.append(np.concatenate([u[keep] for u in u_ws], axis=2))
         have += int(keep.sum())
     x0 = np.concatenate(x0s)[:B]
     u = np.concatenate(uws)[:B]

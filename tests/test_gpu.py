@@ -280,3 +280,36 @@ def test_solve_same_with_and_without_qp_warm_start(games):
     assert easy.sum() >= 20
     for i in np.nonzero(easy)[0]:
         assert rel(a['u'][i], b['u'][i]) < 1e-6 and rel(a['l'][i], b['l'][i]) < 1e-5
+
+
+@pytest.mark.parametrize('M,N', [(3, 10), (4, 8)])
+def test_three_and_four_agents(oracle, M, N):
+    """More than two agents (scripts/DGSQP_monte_carlo_agents.py): evaluation incl. the game Hessian, the QP and whole
+    solves against the oracle; exercises the M-agent instantiations of the second-order adjoint rows."""
+    from dgsqp_amd.montecarlo import kinematic_racing_game, sample_scenarios
+    from dgsqp_amd.solver import DGSQP, build_problem, build_params
+    import dgsqp_amd.solver as sv
+    g = kinematic_racing_game('curve', N=N, M=M)
+    P, par = build_problem(*g.solver_args()), tight_lsqr(build_params(g.params))
+    orig = sv.build_params
+    sv.build_params = lambda p: tight_lsqr(orig(p))
+    try:
+        s = DGSQP(*g.solver_args(), print_method=None)
+    finally:
+        sv.build_params = orig
+    B = 8
+    x0, u_tm = sample_scenarios(g, B, seed=4)
+    u = np.ascontiguousarray(u_tm.reshape(B, N, M, 2).transpose(0, 2, 1, 3).reshape(B, -1))
+    rng = np.random.default_rng(1)
+    up = u + 0.01 * rng.standard_normal(u.shape)
+    l = np.maximum(0, rng.standard_normal((B, s.n_c_total)))
+    ev = s.evaluate_batch(x0, up, l)
+    for b in range(B):
+        o = oracle.evaluate(P, x0[b], up[b], l[b], 1)
+        for key in ('x', 'q', 'g', 'G', 'Q'):
+            assert rel(ev[key][b], o[key]) < 1e-12, (key, b)
+    res = s.solve_batch(x0, u_tm)
+    ref = oracle.solve_batch(P, par, x0, u, nthreads=4)
+    assert np.array_equal(res['status'], ref['status']) and np.array_equal(res['num_iters'], ref['num_iters'])
+    for b in range(B):
+        assert rel(res['u'][b], ref['u'][b]) < 1e-6 and rel(res['l'][b], ref['l'][b]) < 1e-5

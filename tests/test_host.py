@@ -180,3 +180,17 @@ def test_two_process_gloo_shard_and_gather(tmp_path):
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert 'GLOO_OK' in out.stdout
+
+
+def test_multi_agent_sampler():
+    """M-agent rejection sampler (scripts/DGSQP_monte_carlo_agents.py:262-308): shapes, bounds, no collision along the
+    PID warm start."""
+    from dgsqp_amd.montecarlo import kinematic_racing_game, sample_scenarios
+    g = kinematic_racing_game('curve', N=8, M=3)
+    x0, u = sample_scenarios(g, 12, seed=2)
+    assert x0.shape == (12, 18) and u.shape == (12, 8, 6)
+    assert np.all(np.abs(u[..., 0::2]) <= 2.1 + 1e-12) and np.all(np.abs(u[..., 1::2]) <= 0.436 + 1e-12)
+    p = x0.reshape(12, 3, 6)[:, :, :2]
+    for i in range(3):
+        for j in range(i + 1, 3):
+            assert np.all(np.linalg.norm(p[:, i] - p[:, j], axis=1) >= 0.4 - 1e-12)
