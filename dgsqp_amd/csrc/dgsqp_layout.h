@@ -57,7 +57,7 @@ struct DgLds {
   // EVAL scratch (absolute offsets)
   int e_x, e_ue, e_A[DGSQP_MAX_AGENTS], e_B[DGSQP_MAX_AGENTS], e_dJ, e_lam, e_Dxs, e_K, e_xs;
   // EIG scratch
-  int g_Bp, g_V, g_tw;  // packed P / packed Householder reflectors / tridiagonal workspace
+  int g_Bp, g_V, g_tw, g_strip;  // packed P / packed Householder reflectors / tridiagonal workspace
   // QP scratch (P shares g_Bp)
   int p_R, p_lam, p_c, p_w, p_r, p_y, p_z, p_t, p_alist, p_rd, p_yd2, p_yslot, p_yfree, p_dpart, p_act, p_part;
   // QP outputs that must survive trial evaluations
@@ -232,6 +232,10 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   const int rpt = (n <= 32 ? 32 : (n <= 64 ? 64 : (n <= 100 ? 100 : 128))) / DG_NH;
   L.g_Bp = take(npk); L.g_V = take(npk);
   L.g_tw = take((5 + DG_NH) * n + 16 + DG_PSD_KMAX * n /* Z */ + 3 * (DG_NH * rpt + 4));
+  // per-wavefront strips of the twisted factorisation (3 n doubles each): the packed-P slot is free until the sweep writes
+  // P at the very end of the phase; tiny problems get their own space
+  const int strips = (DG_BLOCK / 64) * 3 * ((n + 1) & ~1);
+  L.g_strip = strips <= npk ? L.g_Bp : take(strips);
   const int eig_end = o;
   // QP (P aliases Bp)
   o = L.scr + ((npk + 1) & ~1);

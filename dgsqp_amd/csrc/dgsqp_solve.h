@@ -40,80 +40,107 @@ __device__ inline int sturm_count(clptr d, clptr e2, int n, double sigma, double
 }
 // Sturm count (number of eigenvalues of the tridiagonal below sigma) with d and e^2 DISTRIBUTED OVER THE LANES of the
 // calling wavefront (xA: rows 0..63, xB: rows 64..127) and fetched with v_readlane: the loop index is wave-uniform, so
-// the operands arrive as scalars and the only latency left is the recurrence itself (LAPACK dlaebz form
-// q_i = (d_i - s) - e_{i-1}^2 / q_{i-1}, |q| <= pivmin -> -pivmin).  sigma may differ per lane (64 shifts at once).
+// the operands arrive as scalars and the only latency left is the recurrence itself.  Product form of the Sturm sequence
+//   p_0 = 1, p_1 = d_0 - s, p_{i+1} = (d_i - s) p_i - e_{i-1}^2 p_{i-1}      (count = sign changes, a zero counts as one)
+// whose dependent chain is one multiply and one fma per row; both carried terms are rescaled by a power of two every
+// four rows (frexp / ldexp), which keeps them far inside the fp64 range for |T| < 1e30.  sigma may differ per lane.
 __device__ inline int sturm_count_reg(double dA, double dB, double e2A, double e2B, int n, double sigma, double pivmin) {
-  double q = lane_bcast(dA, 0) - sigma;
-  q = (__builtin_fabs(q) <= pivmin) ? -pivmin : q;
-  int cnt = q < 0.0;
-  const int n1 = n < 65 ? n : 65;
-  for (int i = 1; i < n1; i++) {                      // rows 1..64 take e2 from the A half
-    const double di = lane_bcast(i < 64 ? dA : dB, i & 63), ei = lane_bcast(e2A, i - 1);
-    q = (di - sigma) - ei * fast_rcp(q);
-    q = (__builtin_fabs(q) <= pivmin) ? -pivmin : q;
-    cnt += q < 0.0;
+  (void)pivmin;
+  double pp = 1.0, pc = lane_bcast(dA, 0) - sigma;
+  bool neg = !(pc > 0.0);           // "not positive": an exact zero counts as negative; then p_{i+1} = -e^2 p_{i-1}
+  int cnt = neg;                    // has the opposite sign of p_{i-1}, so no special value is needed
+  // one row; HD / HE select the register half of d_r / e^2_{r-1} at compile time
+#define STURM_ROW(r, HD, HE)                                                                     \
+  {                                                                                              \
+    const double di = lane_bcast(HD ? dB : dA, (r) & 63), ei = lane_bcast(HE ? e2B : e2A, ((r) - 1) & 63); \
+    const double pn = __builtin_fma(di - sigma, pc, -ei * pp);                                   \
+    const bool nn = !(pn > 0.0);                                                                 \
+    cnt += nn != neg;                                                                            \
+    neg = nn; pp = pc; pc = pn;                                                                  \
   }
-  for (int i = 65; i < n; i++) {
-    const double di = lane_bcast(dB, i - 64), ei = lane_bcast(e2B, i - 65);
-    q = (di - sigma) - ei * fast_rcp(q);
-    q = (__builtin_fabs(q) <= pivmin) ? -pivmin : q;
-    cnt += q < 0.0;
+#define STURM_RESCALE()                                                                          \
+  {                                                                                              \
+    const int ex = __builtin_amdgcn_frexp_exp(pc);                                               \
+    const int sc = (ex > 200 || ex < -200) ? -ex : 0;                                            \
+    pc = __builtin_ldexp(pc, sc); pp = __builtin_ldexp(pp, sc);                                  \
   }
+  const int nA = n < 64 ? n : 64;   // rows 1 .. nA-1: d and e^2 both from the A half
+  int i = 1;
+  for (; i + 3 < nA; i += 4) { STURM_ROW(i, 0, 0) STURM_ROW(i + 1, 0, 0) STURM_ROW(i + 2, 0, 0) STURM_ROW(i + 3, 0, 0) STURM_RESCALE() }
+  for (; i < nA; i++) STURM_ROW(i, 0, 0)
+  if (n > 64) {
+    STURM_ROW(64, 1, 0)             // d_64 from the B half, e^2_63 from the A half
+    STURM_RESCALE()
+    i = 65;
+    for (; i + 3 < n; i += 4) { STURM_ROW(i, 1, 1) STURM_ROW(i + 1, 1, 1) STURM_ROW(i + 2, 1, 1) STURM_ROW(i + 3, 1, 1) STURM_RESCALE() }
+    for (; i < n; i++) STURM_ROW(i, 1, 1)
+  }
+#undef STURM_ROW
+#undef STURM_RESCALE
   return cnt;
+}
+// inclusive prefix / suffix products over the 64 lanes of a wavefront
+__device__ inline double wave_prefix_prod(double v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const double t = __shfl_up(v, d, 64); v = lane >= d ? v * t : v; }
+  return v;
+}
+__device__ inline double wave_suffix_prod(double v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const double t = __shfl_down(v, d, 64); v = lane + d < 64 ? v * t : v; }
+  return v;
 }
 // Eigenvector of the tridiagonal for the (accurately known) eigenvalue lam by the twisted factorisation of T - lam I
 // (Parlett & Dhillon; LAPACK dlar1v): stationary qd from the top, progressive qd from the bottom, twist where
-// |gamma_r| = |D+_r + D-_r - (d_r - lam)| is smallest, then z_r = 1 and the two two-term recurrences.  One wavefront
-// per eigenvalue; everything lives in lane-distributed registers (lane i <-> rows i, i+64).  z is returned max-normalised.
+// |gamma_r| = |D+_r + D-_r - (d_r - lam)| is smallest, then z_r = 1 and the two two-term recurrences
+//   z_i = -(e_i / D+_i) z_{i+1}  (i < r),   z_{i+1} = -(e_i / D-_{i+1}) z_i  (i >= r),
+// which are prefix / suffix products and are evaluated as wavefront scans.  One wavefront per eigenvalue; d, e come from
+// lane-distributed registers (lane i <-> rows i, i+64), the two pivot sequences go through the wavefront's LDS strip
+// `strip` (3 n doubles).  z is returned max-normalised.
 __device__ inline void twisted_eigvec(double dA, double dB, double eA, double eB, int n, double lam, double pivmin, int lane,
-                                      double& zA, double& zB) {
+                                      lptr strip, double& zA, double& zB) {
   const double e2A = eA * eA, e2B = eB * eB;
-  double DpA = 0, DpB = 0, DmA = 0, DmB = 0, DsA = 0, DsB = 0;   // D+_i, D-_i, D-_{i+1}
-  double qf = lane_bcast(dA, 0) - lam;
-  qf = (__builtin_fabs(qf) <= pivmin) ? -pivmin : qf;
+  const double tA = dA - lam, tB = dB - lam;
+  const int npad = (n + 1) & ~1;
+  lptr Dp = strip, Dm = strip + npad, Ds = strip + 2 * npad;     // D+_i, D-_i, D-_{i+1}
   const int nl = n - 1;
-  double qb = lane_bcast(nl < 64 ? dA : dB, nl & 63) - lam;
+  double qf = lane_bcast(tA, 0);
+  qf = (__builtin_fabs(qf) <= pivmin) ? -pivmin : qf;
+  double qb = lane_bcast(nl < 64 ? tB * 0.0 + tA : tB, nl & 63);
   qb = (__builtin_fabs(qb) <= pivmin) ? -pivmin : qb;
-  if (lane == 0) DpA = qf;
-  if (lane == (nl & 63)) { if (nl < 64) DmA = qb; else DmB = qb; }
-  if (nl >= 1 && lane == ((nl - 1) & 63)) { if (nl - 1 < 64) DsA = qb; else DsB = qb; }
+  if (lane == 0) { Dp[0] = qf; Dm[nl] = qb; if (nl >= 1) Ds[nl - 1] = qb; Ds[nl] = 1.0; }
   for (int s = 1; s < n; s++) {
     const int i = s, ib = nl - s;
-    const double di = lane_bcast(i < 64 ? dA : dB, i & 63), ei = lane_bcast(i - 1 < 64 ? e2A : e2B, (i - 1) & 63);
-    const double db = lane_bcast(ib < 64 ? dA : dB, ib & 63), eb = lane_bcast(ib < 64 ? e2A : e2B, ib & 63);
-    qf = (di - lam) - ei * fast_rcp(qf);
-    qb = (db - lam) - eb * fast_rcp(qb);
+    const double ti = lane_bcast(i < 64 ? tA : tB, i & 63), ei = lane_bcast(i - 1 < 64 ? e2A : e2B, (i - 1) & 63);
+    const double tb = lane_bcast(ib < 64 ? tA : tB, ib & 63), eb = lane_bcast(ib < 64 ? e2A : e2B, ib & 63);
+    qf = ti - ei * fast_rcp(qf);
+    qb = tb - eb * fast_rcp(qb);
     qf = (__builtin_fabs(qf) <= pivmin) ? -pivmin : qf;
     qb = (__builtin_fabs(qb) <= pivmin) ? -pivmin : qb;
-    const bool hf = lane == (i & 63), hb = lane == (ib & 63), hs = ib >= 1 && lane == ((ib - 1) & 63);
-    DpA = (hf && i < 64) ? qf : DpA; DpB = (hf && i >= 64) ? qf : DpB;
-    DmA = (hb && ib < 64) ? qb : DmA; DmB = (hb && ib >= 64) ? qb : DmB;
-    DsA = (hs && ib - 1 < 64) ? qb : DsA; DsB = (hs && ib - 1 >= 64) ? qb : DsB;
+    if (lane == 0) { Dp[i] = qf; Dm[ib] = qb; if (ib >= 1) Ds[ib - 1] = qb; }
   }
   // twist index
-  double gA = lane < n ? __builtin_fabs(DpA + DmA - (dA - lam)) : INFINITY;
-  double gB = lane + 64 < n ? __builtin_fabs(DpB + DmB - (dB - lam)) : INFINITY;
+  const double pA = lane < n ? Dp[lane] : 1.0, pB = lane + 64 < n ? Dp[lane + 64] : 1.0;
+  double gA = lane < n ? __builtin_fabs(pA + Dm[lane] - tA) : INFINITY;
+  double gB = lane + 64 < n ? __builtin_fabs(pB + Dm[lane + 64] - tB) : INFINITY;
   int r = lane;
   if (gB < gA) { gA = gB; r = lane + 64; }
   wave_argmin(gA, r);
-  // multipliers: below the twist  z_i = -(e_i / D+_i) z_{i+1} ; above  z_{i+1} = -(e_i / D-_{i+1}) z_i
-  const double LA = lane < nl ? -eA * fast_rcp(DpA) : 0.0, LB = lane + 64 < nl ? -eB * fast_rcp(DpB) : 0.0;
-  const double UA = lane < nl ? -eA * fast_rcp(DsA) : 0.0, UB = lane + 64 < nl ? -eB * fast_rcp(DsB) : 0.0;
-  zA = 0.0; zB = 0.0;
-  if (lane == (r & 63)) { if (r < 64) zA = 1.0; else zB = 1.0; }
-  double acc = 1.0;
-  for (int k = r - 1; k >= 0; k--) {
-    acc *= lane_bcast(k < 64 ? LA : LB, k & 63);
-    const bool h = lane == (k & 63);
-    zA = (h && k < 64) ? acc : zA; zB = (h && k >= 64) ? acc : zB;
-  }
-  acc = 1.0;
-  for (int k = r; k < nl; k++) {
-    acc *= lane_bcast(k < 64 ? UA : UB, k & 63);
-    const int t = k + 1;
-    const bool h = lane == (t & 63);
-    zA = (h && t < 64) ? acc : zA; zB = (h && t >= 64) ? acc : zB;
-  }
+  // multipliers, set to 1 outside their range:  L_k (k < r) below the twist, U_k (r <= k < n-1) above it
+  const int ka = lane, kb = lane + 64;
+  const double LA = ka < r ? -eA * fast_rcp(pA) : 1.0, LB = kb < r ? -eB * fast_rcp(pB) : 1.0;
+  const double UA = (ka >= r && ka < nl) ? -eA * fast_rcp(Ds[ka]) : 1.0, UB = (kb >= r && kb < nl) ? -eB * fast_rcp(Ds[kb]) : 1.0;
+  // z_i = prod_{k=i}^{r-1} L_k  (suffix product)  *  prod_{k=r}^{i-1} U_k  (exclusive prefix product)
+  const double sB = wave_suffix_prod(LB, lane);
+  const double sA = wave_suffix_prod(LA, lane) * lane_bcast(sB, 0);
+  const double pfA = wave_prefix_prod(UA, lane);
+  const double pfB = wave_prefix_prod(UB, lane) * lane_bcast(pfA, 63);
+  // exclusive: shift by one lane
+  double exA = __shfl_up(pfA, 1, 64), exB = __shfl_up(pfB, 1, 64);
+  exA = lane == 0 ? 1.0 : exA;
+  exB = lane == 0 ? lane_bcast(pfA, 63) : exB;
+  zA = lane < n ? sA * exA : 0.0;
+  zB = lane + 64 < n ? sB * exB : 0.0;
   const double nr = 1.0 / wave_max(fmax(__builtin_fabs(zA), __builtin_fabs(zB)));
   zA *= nr; zB *= nr;
 }
@@ -292,6 +319,7 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
         const int j = j0 + jj;
         // eigenvalue j (ascending) lies in [lo, hi) with count(lo) <= j < count(hi): 64-way multisection
         double lo = -tnorm * 1.0000001 - 1e-300, hi = 0.0;
+        PROF_BEGIN(pms);
         for (int it = 0; it < 10; it++) {   // 65^10 > 2^53: ten 64-way multisection steps always reach fp64 resolution
           const double wdt = hi - lo;
           const double sg = lo + wdt * (double)(lane + 1) * (1.0 / 65.0);
@@ -304,18 +332,17 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
           if (hi - lo <= 4.5e-16 * fmax(fabs(lo), fabs(hi)) + 1e-300) break;
         }
         const double lam = 0.5 * (lo + hi);
+        PROF_END(PH_E_VEC, pms);
         if (lane == 0) lamv[jj] = lam;
         // ---- 3b. eigenvector of T by twisted factorisation
         double zA, zB;
-        twisted_eigvec(dA, dB, eA, eB, n, lam, pivmin, lane, zA, zB);
+        twisted_eigvec(dA, dB, eA, eB, n, lam, pivmin, lane, lds + L.g_strip + wave * 3 * ((n + 1) & ~1), zA, zB);
         if (lane < n) Z[jj * n + lane] = zA;
         if (lane + 64 < n) Z[jj * n + lane + 64] = zB;
       }
     }
     __syncthreads();
     PROF_END(PH_E_BIS, pe1);
-    PROF_BEGIN(pe2);
-    PROF_END(PH_E_VEC, pe2);
     PROF_BEGIN(pe3);
     // ---- 3c. modified Gram-Schmidt (wavefront 0), then back-transformation v = H_0 ... H_{n-3} z (one wavefront per vector)
     if (wave == 0) {
