@@ -876,7 +876,8 @@ __device__ __noinline__ void dev_hessian_adjoint(const Ctx& c) {
 // overwrite the scratch) -- e.g. the full evaluation that follows an accepted trial point.
 #define DG_XVALID 60
 #define DG_QP_NPREV 59   // scal slot: size of the saved active set
-__device__ inline void dev_evaluate(const Ctx& c, clptr usrc, double alpha, clptr dusrc, bool hessian, clptr xsrc = nullptr) {
+// stage 1: trial input, trajectory and constraint values g (no derivatives)
+__device__ inline void dev_evaluate_point(const Ctx& c, clptr usrc, double alpha, clptr dusrc, clptr xsrc = nullptr) {
   const DgProb& D = dg_prob;
   const DgLds& L = D.L;
   lptr ue = LP(L.e_ue);
@@ -895,15 +896,25 @@ __device__ inline void dev_evaluate(const Ctx& c, clptr usrc, double alpha, clpt
     PROF_BEGIN(pt_); dev_rollout(c, ue, LP(L.e_x)); PROF_END(PH_ROLLOUT, pt_);
   }
   if (TID == 0) LP(L.scal)[DG_XVALID] = 1.0;
+  dev_constraint_values(c, ue);
+}
+// stage 2: derivatives at the point prepared by stage 1 -> q, packed G (and raw Q)
+__device__ inline void dev_evaluate_derivs(const Ctx& c, bool hessian) {
+  const DgLds& L = dg_prob.L;
+  lptr ue = LP(L.e_ue);
   if (hessian) { PROF_BEGIN(pt_); dev_dyn_derivs<2>(c, ue); PROF_END(PH_DERIV2, pt_); }
   else { PROF_BEGIN(pt_); dev_dyn_derivs<1>(c, ue); PROF_END(PH_DERIV1, pt_); }
-  { PROF_BEGIN(pt_); dev_chains(c, ue); dev_constraint_values(c, ue); PROF_END(PH_CHAINS, pt_); }
+  { PROF_BEGIN(pt_); dev_chains(c, ue); PROF_END(PH_CHAINS, pt_); }
   if (hessian) {
     PROF_BEGIN(pt_);
     dev_hessian_adjoint(c);
     PROF_END(PH_DP, pt_);
   }
   __syncthreads();
+}
+__device__ inline void dev_evaluate(const Ctx& c, clptr usrc, double alpha, clptr dusrc, bool hessian, clptr xsrc = nullptr) {
+  dev_evaluate_point(c, usrc, alpha, dusrc, xsrc);
+  dev_evaluate_derivs(c, hessian);
 }
 
 // f_J (DGSQP.py:889-893): per-agent cost along the current rollout in the EVAL scratch

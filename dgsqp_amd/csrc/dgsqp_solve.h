@@ -902,8 +902,27 @@ __device__ inline double dev_line_search(const Ctx& c, double mu, double phi, do
         dev_rollout_multi(c, lds + L.u, lds + L.o_du, alpha, D.par.tau, left < K ? left : K, lds + L.e_xs, xsz);
         PROF_END(PH_ROLLOUT, pt_);
       }
-      dev_evaluate(c, lds + L.u, alpha, lds + L.o_du, false, lds + L.e_xs + (i % K) * xsz);
-    } else dev_evaluate(c, lds + L.u, alpha, lds + L.o_du, false);
+      dev_evaluate_point(c, lds + L.u, alpha, lds + L.o_du, lds + L.e_xs + (i % K) * xsz);
+    } else dev_evaluate_point(c, lds + L.u, alpha, lds + L.o_du);
+    // The merit is  1/2 |q + G'l|^2 + 1/2 (l'g)^2 + mu sum(g - s):  the first term is >= 0 and is the only one that needs
+    // derivatives.  When the other two alone exceed the Armijo bound the trial is rejected from the constraint values (the
+    // decision cannot differ; a relative margin covers rounding).  Never for the last allowed trial (its merit is returned)
+    // and not while an event trace is recorded (the trace lists every trial's merit).
+    if (!c.trace && i + 1 < D.par.line_search_iters) {
+      double lg = 0, sg = 0;
+      for (int r = TID; r < D.nc; r += NT) {
+        const double gr = lds[L.g + r];
+        lg += (lds[L.l + r] + alpha * (lds[L.o_lhat + r] - lds[L.l + r])) * gr;
+        sg += gr;
+      }
+      lg = block_sum(lg, lds + L.red); sg = block_sum(sg, lds + L.red);
+      double lb = 0.5 * lg * lg;
+      if (D.par.merit_function == DGSQP_MERIT_STAT_L1) lb += mu * (sg - (S0 + alpha * S1));
+      const double bound = phi + D.par.beta * alpha * dphi;
+      PROF_COUNT(PH_C_TRIALS, lb > bound + 1e-9 * (fabs(bound) + fabs(lb)) ? 1 : 0);
+      if (lb > bound + 1e-9 * (fabs(bound) + fabs(lb))) { alpha *= D.par.tau; continue; }
+    }
+    dev_evaluate_derivs(c, false);
     phit = dev_phi_trial(c, alpha, S0 + alpha * S1, mu);
     dev_tr(c, 30, alpha); dev_tr(c, 31, phit);
     if (phit <= phi + D.par.beta * alpha * dphi) break;
