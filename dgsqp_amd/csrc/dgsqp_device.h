@@ -567,24 +567,30 @@ __device__ __noinline__ void gt_mul(const Ctx& c, clptr y, lptr out) {
     yd[d] = (dd.r_pos >= 0 ? y[dd.r_pos] : 0.0) - (dd.r_neg >= 0 ? y[dd.r_neg] : 0.0);
   }
   __syncthreads();
-  for (int col = TID; col < D.n; col += NT) {
+  // four lanes per column: lane part 0 adds the box / rate rows, all four share the dense gradients (d = part, part+4, ..)
+  for (int it = TID; it < 4 * D.n; it += NT) {
+    const int col = it >> 2, part = it & 3;
     const int a = col / (D.N * DGSQP_NUA), rem = col % (D.N * DGSQP_NUA), t = rem / DGSQP_NUA, j = rem % DGSQP_NUA;
     double s = 0;
-    int r;
-    if ((r = D.r_in_ub[a][t][j]) >= 0) s += y[r];
-    if ((r = D.r_in_lb[a][t][j]) >= 0) s -= y[r];
-    if ((r = D.r_rate_ub[a][t][j]) >= 0) s += y[r];
-    if ((r = D.r_rate_lb[a][t][j]) >= 0) s -= y[r];
-    if (t + 1 < D.N) {
-      if ((r = D.r_rate_ub[a][t + 1][j]) >= 0) s -= y[r];
-      if ((r = D.r_rate_lb[a][t + 1][j]) >= 0) s += y[r];
+    if (part == 0) {
+      int r;
+      if ((r = D.r_in_ub[a][t][j]) >= 0) s += y[r];
+      if ((r = D.r_in_lb[a][t][j]) >= 0) s -= y[r];
+      if ((r = D.r_rate_ub[a][t][j]) >= 0) s += y[r];
+      if ((r = D.r_rate_lb[a][t][j]) >= 0) s -= y[r];
+      if (t + 1 < D.N) {
+        if ((r = D.r_rate_ub[a][t + 1][j]) >= 0) s -= y[r];
+        if ((r = D.r_rate_lb[a][t + 1][j]) >= 0) s += y[r];
+      }
     }
-    for (int d = D.stage_dense0[t + 1]; d < D.ndense; d++) {   // only gradients of later stages reach column (a,t,j)
+    for (int d = D.stage_dense0[t + 1] + part; d < D.ndense; d += 4) {   // only gradients of later stages reach column (a,t,j)
       const DgDense dd = ld_dense(d);
       if (dd.a == a) s += yd[d] * gd[dd.off + t * DGSQP_NUA + j];
       else if (dd.kind == 1 && dd.b == a) s += yd[d] * gd[dd.off + 2 * dd.k + t * DGSQP_NUA + j];
     }
-    out[col] = s;
+    s += dpp_f64<0xB1>(s);
+    s += dpp_f64<0x4E>(s);
+    if (part == 0) out[col] = s;
   }
   __syncthreads();
 }

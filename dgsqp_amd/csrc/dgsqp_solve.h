@@ -685,7 +685,9 @@ __device__ inline void qpw_drop(lptr R, lptr rd, lds_i_t* alist, lds_i_t* yslot,
 __device__ inline void dev_ggt_mul(const Ctx& c, clptr vin, lptr vout, lptr tmpn) {
   const DgProb& D = dg_prob;
   gt_mul(c, vin, tmpn);
-  for (int r = TID; r < D.nc; r += NT) vout[r] = g_row_dot(D, LP(0) + D.L.gd, r, tmpn);
+  lptr dd2 = LP(D.L.p_yd2);     // QP scratch, idle during the dual start
+  qp_dense_dots(D, LP(D.L.gd), tmpn, LP(D.L.p_dpart), dd2);
+  for (int r = TID; r < D.nc; r += NT) vout[r] = qpw_row_dot(D, ld_row(r), tmpn, dd2);
   __syncthreads();
 }
 __device__ inline void dev_sym_ortho(double a, double b, double& cs, double& sn, double& r) {
