@@ -231,7 +231,8 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   const int npk = n * (n + 1) / 2;
   const int rpt = (n <= 32 ? 32 : (n <= 64 ? 64 : (n <= 100 ? 100 : 128))) / DG_NH;
   L.g_Bp = take(npk); L.g_V = take(npk);
-  L.g_tw = take((5 + DG_NH) * n + 16 + DG_PSD_KMAX * n /* Z */ + 3 * (DG_NH * rpt + 4));
+  L.g_tw = take((5 + DG_NH) * n + 16 + DG_PSD_KMAX * n /* Z */ + 3 * (DG_NH * rpt + 4)
+                + 2 * (DG_BLOCK / 64) * (DG_NH * rpt + 4) /* per-wavefront copies of the reflector v and of w */);
   // per-wavefront strips of the twisted factorisation (3 n doubles each): the packed-P slot is free until the sweep writes
   // P at the very end of the phase; tiny problems get their own space
   const int strips = (DG_BLOCK / 64) * 3 * ((n + 1) & ~1);

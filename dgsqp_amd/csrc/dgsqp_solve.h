@@ -194,8 +194,9 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
   // Two barriers per step: every wavefront keeps its OWN copy of w (in the eigenvector area, unused until later), so
   // w never has to be published.  Rows that are already reduced (i <= k for every thread) are skipped in quarter-steps
   // of the register tile (R0), which removes about a third of the sweep work.
-  lptr wfw = Z + wave * (NH * RPT + 4);
-  for (int i = lane; i < NH * RPT + 4; i += 64) wfw[i] = 0.0;
+  lptr wfw = tws + 3 * (NH * RPT + 4) + wave * (NH * RPT + 4);
+  lptr vfw = tws + (3 + NT / 64) * (NH * RPT + 4) + wave * (NH * RPT + 4);   // masked reflector: zero for rows <= k
+  for (int i = lane; i < NH * RPT + 4; i += 64) { wfw[i] = 0.0; vfw[i] = 0.0; }
   auto hh_step = [&](int k, auto r0tag) {
     constexpr int R0 = decltype(r0tag)::value;
     const int m = n - k - 1;
@@ -214,21 +215,23 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
       beta = 2.0 / (tail2 + v0 * v0);
     }
     const double dshift = beta != 0.0 ? alpha : 0.0;   // v_{k+1} = x_{k+1} - dshift
-    if (wave == 0) {
+    {
       const double va = lane == 0 ? xa - dshift : xa;
-      if (lane < m) Rf[RFOFF(k) + lane] = va;
-      if (lane + 64 < m) Rf[RFOFF(k) + lane + 64] = xb;
-      if (lane == 0) { dv[k] = cb[k]; ev[k] = alpha; tau[k] = beta; }
+      if (lane < m) vfw[k + 1 + lane] = va;
+      if (lane + 64 < m) vfw[k + 1 + lane + 64] = xb;
+      if (lane == 0) vfw[k] = 0.0;
+      if (wave == 0) {
+        if (lane < m) Rf[RFOFF(k) + lane] = va;
+        if (lane + 64 < m) Rf[RFOFF(k) + lane + 64] = xb;
+        if (lane == 0) { dv[k] = cb[k]; ev[k] = alpha; tau[k] = beta; }
+      }
     }
     if (beta != 0.0) {   // wave-uniform (all waves computed the same beta)
       // p_j = sum_i B[i][j] v_i over this thread's rows (B symmetric => column sums give the matvec)
       double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
       for (int r = R0; r < RPT; r++) {
-        const int i = hf + NH * r;
-        double vi = cb[i];
-        vi = (i == k + 1) ? vi - dshift : vi;
-        vi = (i > k) ? vi : 0.0;
+        const double vi = vfw[hf + NH * r];
         if ((r & 3) == 0) s0 += Br[r] * vi; else if ((r & 3) == 1) s1 += Br[r] * vi; else if ((r & 3) == 2) s2 += Br[r] * vi; else s3 += Br[r] * vi;
       }
       if (colok) pp[hf * n + jc] = (s0 + s1) + (s2 + s3);
@@ -247,17 +250,11 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
       if (lane + 64 < m) wfw[k + 1 + lane + 64] = pb - K * vb;
       if (lane == 0) wfw[k] = 0.0;
       {
-        double vj = colok ? cb[jc] : 0.0;
-        vj = (jc == k + 1) ? vj - dshift : vj;
-        vj = (jc > k) ? vj : 0.0;
-        const double wj = colok ? wfw[jc] : 0.0;   // zero for columns <= k
+        const double vj = colok ? vfw[jc] : 0.0, wj = colok ? wfw[jc] : 0.0;   // both zero for columns <= k
 #pragma unroll
         for (int r = R0; r < RPT; r++) {
           const int i = hf + NH * r;
-          double vi = cb[i];
-          vi = (i == k + 1) ? vi - dshift : vi;
-          vi = (i > k) ? vi : 0.0;
-          Br[r] -= vi * wj + wfw[i] * vj;
+          Br[r] -= vfw[i] * wj + wfw[i] * vj;
         }
       }
     }
@@ -410,7 +407,7 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
   for (int k = 0; k < n; k++) {
     clptr colk = (k & 1) ? colB : colA;
     lptr coln = (k & 1) ? colA : colB;
-    const double dinv = 1.0 / colk[k];
+    const double dinv = fast_rcp(colk[k]);
     const double rj = colok ? colk[jc] * dinv : 0.0;
     const bool pc = jc == k;
     const double rowv = pc ? -dinv : rj;   // new row k:  a_kj/d, pivot -1/d
@@ -419,13 +416,17 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
     double ci[RPT];
 #pragma unroll
     for (int r = 0; r < RPT; r++) ci[r] = colk[hf + NH * r];
+    if (!pc) {
 #pragma unroll
-    for (int r = 0; r < RPT; r++) {
-      const bool onrow = (hf + NH * r) == k;
-      double base = pc ? ci[r] * dinv : Br[r];
-      base = onrow ? rowv : base;
-      const double mult = (pc || onrow) ? 0.0 : ci[r];
-      Br[r] = fma(-mult, rj, base);
+      for (int r = 0; r < RPT; r++) Br[r] = fma(-ci[r], rj, Br[r]);      // general entry
+    } else {
+#pragma unroll
+      for (int r = 0; r < RPT; r++) Br[r] = ci[r] * dinv;                // pivot column (4 threads per step)
+    }
+    if (hf == (k & (NH - 1))) {      // pivot row: one register (index k / NH, wave-uniform) of these threads
+      const int rs = k / NH;
+#pragma unroll
+      for (int r = 0; r < RPT; r++) Br[r] = (r == rs) ? rowv : Br[r];
     }
     if (jc == k + 1) {   // the next pivot column is final as soon as this update is done
 #pragma unroll
