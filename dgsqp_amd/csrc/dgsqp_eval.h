@@ -209,10 +209,12 @@ __device__ inline void dev_rollout_dyn_pair(const DgProb& D, int a, int role, cl
 }
 // K trajectories x^(j) = rollout(ub + alpha_j du), alpha_j = alpha0 tau^j, j < K, on K * (lanes per trajectory) lanes of
 // wavefront 0 (one instruction stream: K trajectories cost the latency of one).  xs[j] has stride xstride doubles.
-__device__ __noinline__ void dev_rollout_multi(const Ctx& c, clptr ub, clptr du, double alpha0, double tau, int K, lptr xs, int xstride) {
+__device__ __noinline__ void dev_rollout_multi(const Ctx& c, clptr ub, clptr du, double alpha0, double tau, int K, lptr xs, int xstride,
+                                              int K1 = 1 << 30, lptr xs2 = nullptr) {
   const DgProb& D = dg_prob;
   __syncthreads();
-  for (int i = TID; i < K * D.nq; i += NT) xs[(i / D.nq) * xstride + i % D.nq] = c.x0[i % D.nq];
+  // trajectory j lives at xs + j xstride for j < K1 and at xs2 + (j - K1) xstride beyond
+  for (int i = TID; i < K * D.nq; i += NT) { const int j = i / D.nq; (j < K1 ? xs + j * xstride : xs2 + (j - K1) * xstride)[i % D.nq] = c.x0[i % D.nq]; }
   __syncthreads();
   bool all_dyn = true;
   for (int a = 0; a < D.M; a++) all_dyn = all_dyn && D.nqa[a] == 8;
@@ -221,7 +223,7 @@ __device__ __noinline__ void dev_rollout_multi(const Ctx& c, clptr ub, clptr du,
     const int j = TID / per, w = TID % per;
     double alpha = alpha0;
     for (int t = 0; t < j; t++) alpha *= tau;           // same products as the sequential alpha *= tau
-    lptr x = xs + j * xstride;
+    lptr x = j < K1 ? xs + j * xstride : xs2 + (j - K1) * xstride;
     if (all_dyn) dev_rollout_dyn_pair(D, w >> 1, w & 1, ub, du, alpha, x);
     else if (D.nqa[w] == 8) dev_rollout_agent<8>(D, w, ub, du, alpha, x);
     else dev_rollout_agent<6>(D, w, ub, du, alpha, x);

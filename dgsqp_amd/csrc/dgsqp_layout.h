@@ -55,7 +55,7 @@ struct DgLds {
   int t_track;          // LDS copy of the track tables: seg_s[17], seg_curv[16], seg_ang[17], slope[16]
   int scr;  // start of phase scratch
   // EVAL scratch (absolute offsets)
-  int e_x, e_ue, e_A[DGSQP_MAX_AGENTS], e_B[DGSQP_MAX_AGENTS], e_dJ, e_lam, e_Dxs, e_K, e_xs;
+  int e_x, e_ue, e_A[DGSQP_MAX_AGENTS], e_B[DGSQP_MAX_AGENTS], e_dJ, e_lam, e_Dxs, e_K, e_xs, e_xs2;
   // EIG scratch
   int g_Bp, g_V, g_tw, g_strip;  // packed P / packed Householder reflectors / tridiagonal workspace
   // QP scratch (P shares g_Bp)
@@ -74,7 +74,8 @@ struct DgProb {
   int nqa[DGSQP_MAX_AGENTS], qoff[DGSQP_MAX_AGENTS], sidx[DGSQP_MAX_AGENTS], eyidx[DGSQP_MAX_AGENTS];
   double inv_track_L;
   int uniform_nqa;
-  int ls_spec;      // trial step sizes of _line_search_3 rolled out concurrently (speculation width)  // every agent uses the same vehicle model (statically indexed fast paths)
+  int ls_spec;      // trial step sizes of _line_search_3 rolled out concurrently (speculation width)
+  int ls_spec1;     // how many of them live in the first LDS segment (e_xs); the rest in e_xs2  // every agent uses the same vehicle model (statically indexed fast paths)
   int neff[DGSQP_MAX_AGENTS], ndir[DGSQP_MAX_AGENTS];
   int effvar[DGSQP_MAX_AGENTS][DG_MAXEFF];  // effective variable -> index into z = (q_0..q_{nqa-1}, u_0, u_1)
   int t2off[DGSQP_MAX_AGENTS];              // offset (doubles) of agent block in the Taylor tensor workspace
@@ -264,8 +265,16 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
     if (K > 64 / lanes_per_traj) K = 64 / lanes_per_traj;
     if (K > 16) K = 16;
     if (K < 1) K = 0;
-    D.ls_spec = K;
+    // second segment above the QP outputs, up to the LDS limit (phase-multiplexed with the EIG workspace)
+    int cap = 64 / lanes_per_traj; if (cap > 16) cap = 16;
+    L.e_xs2 = (out_end + 1) & ~1;
+    int K2 = K > 0 ? (DG_LDS_LIMIT / 8 - L.e_xs2) / xsz : 0;
+    if (K2 > cap - K) K2 = cap - K;
+    if (K2 < 0) K2 = 0;
+    D.ls_spec1 = K;
+    D.ls_spec = K + K2;
     if (L.e_xs + K * xsz > eval_end) eval_end = L.e_xs + K * xsz;
+    if (K2 > 0 && L.e_xs2 + K2 * xsz > eval_end) eval_end = L.e_xs2 + K2 * xsz;
   }
   int tot = eval_end;
   if (eig_end > tot) tot = eig_end;

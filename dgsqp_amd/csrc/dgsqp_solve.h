@@ -902,10 +902,11 @@ __device__ inline double dev_line_search(const Ctx& c, double mu, double phi, do
       if (i % K == 0) {
         PROF_BEGIN(pt_);
         const int left = D.par.line_search_iters - i;
-        dev_rollout_multi(c, lds + L.u, lds + L.o_du, alpha, D.par.tau, left < K ? left : K, lds + L.e_xs, xsz);
+        dev_rollout_multi(c, lds + L.u, lds + L.o_du, alpha, D.par.tau, left < K ? left : K, lds + L.e_xs, xsz, D.ls_spec1, lds + L.e_xs2);
         PROF_END(PH_ROLLOUT, pt_);
       }
-      dev_evaluate_point(c, lds + L.u, alpha, lds + L.o_du, lds + L.e_xs + (i % K) * xsz);
+      const int jt = i % K;
+      dev_evaluate_point(c, lds + L.u, alpha, lds + L.o_du, jt < D.ls_spec1 ? lds + L.e_xs + jt * xsz : lds + L.e_xs2 + (jt - D.ls_spec1) * xsz);
     } else dev_evaluate_point(c, lds + L.u, alpha, lds + L.o_du);
     // The merit is  1/2 |q + G'l|^2 + 1/2 (l'g)^2 + mu sum(g - s):  the first term is >= 0 and is the only one that needs
     // derivatives.  When the other two alone exceed the Armijo bound the trial is rejected from the constraint values (the
