@@ -57,6 +57,13 @@ class ParamsT(C.Structure):
     ]
 
 
+class PidT(C.Structure):
+    _fields_ = [
+        ('kp_v', C.c_double), ('kp_s', C.c_double), ('ki_s', C.c_double), ('ey_gain', C.c_double), ('ei_max', C.c_double),
+        ('u_max', C.c_double * 2), ('du_max', C.c_double * 2), ('substeps', C.c_int32), ('reserved_', C.c_int32),
+    ]
+
+
 class DimsT(C.Structure):
     _fields_ = [('M', C.c_int32), ('N', C.c_int32), ('n_q', C.c_int32), ('n_u', C.c_int32), ('n', C.c_int32),
                 ('n_c', C.c_int32), ('n_dense', C.c_int32), ('lds_bytes', C.c_int32),
@@ -113,6 +120,8 @@ def load_library() -> C.CDLL:
     lib.dgsqp_evaluate_batch.restype = C.c_int
     lib.dgsqp_qp_batch.argtypes = [H, C.c_int64, _PD, _PD, _PD, _PD, _PD, _PD, _PI]
     lib.dgsqp_qp_batch.restype = C.c_int
+    lib.dgsqp_pid_warm_start_batch.argtypes = [H, C.c_int64, _PD, C.POINTER(PidT), _PD, _PD, _PI]
+    lib.dgsqp_pid_warm_start_batch.restype = C.c_int
     lib.dgsqp_set_trace.argtypes = [H, C.c_int]
     lib.dgsqp_set_trace.restype = C.c_int
     lib.dgsqp_fetch_trace.argtypes = [H, _PD]
@@ -123,7 +132,8 @@ def load_library() -> C.CDLL:
 
 EXPORTED_SYMBOLS = ['dgsqp_create', 'dgsqp_destroy', 'dgsqp_dims', 'dgsqp_last_error', 'dgsqp_backend_info',
                     'dgsqp_solve_batch', 'dgsqp_stage_inputs', 'dgsqp_solve_staged', 'dgsqp_fetch_results',
-                    'dgsqp_evaluate_batch', 'dgsqp_qp_batch', 'dgsqp_set_trace', 'dgsqp_fetch_trace']
+                    'dgsqp_evaluate_batch', 'dgsqp_qp_batch', 'dgsqp_set_trace', 'dgsqp_fetch_trace',
+                    'dgsqp_pid_warm_start_batch']
 
 
 def dptr(a):

@@ -54,6 +54,8 @@ dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restric
 #endif
 }
 
+#include "dgsqp_pid.h"
+
 // Test hook: one _evaluate(hessian=True) (+ dual init) per scenario, results expanded to dense arrays.
 __global__ void __launch_bounds__(DG_BLOCK)
 dg_evaluate_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__ x0, const double* __restrict__ u,
@@ -438,6 +440,36 @@ int dgsqp_evaluate_batch(dgsqp_handle_t h, int64_t B, const double* x0, const do
   if (Q) HIPCHK(h, hipMemcpy(Q, dQ, sizeof(double) * B * n * n, hipMemcpyDeviceToHost));
   if (x) HIPCHK(h, hipMemcpy(x, dx, sizeof(double) * B * nx, hipMemcpyDeviceToHost));
   if (l0) HIPCHK(h, hipMemcpy(l0, dl0, sizeof(double) * B * nc, hipMemcpyDeviceToHost));
+  return DGSQP_OK;
+}
+
+int dgsqp_pid_warm_start_batch(dgsqp_handle_t h, int64_t B, const double* q0, const dgsqp_pid_t* pid, double* u_ws,
+                               double* q_ws, int32_t* collide) {
+  if (!h || B < 0 || !q0 || !pid || !u_ws || pid->substeps < 1) { if (h) h->err = "bad argument"; return DGSQP_E_ARG; }
+  if (B == 0) return DGSQP_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  const DgProb& D = h->hp;
+  TmpBuf tb;
+  const size_t nx = (size_t)(D.N + 1) * D.nq;
+  double* dq0 = tb.alloc<double>(B * D.nq); double* du = tb.alloc<double>(B * D.n);
+  double* dq = (q_ws || collide) ? tb.alloc<double>(B * nx) : nullptr;
+  int32_t* dc = collide ? tb.alloc<int32_t>(B) : nullptr;
+  if (!dq0 || !du || ((q_ws || collide) && !dq) || (collide && !dc)) { h->err = "hipMalloc failed"; return DGSQP_E_NOMEM; }
+  HIPCHK(h, hipMemcpy(dq0, q0, sizeof(double) * B * D.nq, hipMemcpyHostToDevice));
+  { int rcu = upload_problem(h); if (rcu) return rcu; }
+  const int64_t lanes = B * D.M;
+  int grid = (int)((lanes + DG_BLOCK - 1) / DG_BLOCK);
+  if (grid > 4 * h->num_cu) grid = 4 * h->num_cu;
+  hipLaunchKernelGGL(dg_pid_kernel, dim3(grid), dim3(DG_BLOCK), (size_t)D.L.scr * sizeof(double), h->stream, B, dq0, *pid, du, dq);
+  HIPCHK(h, hipGetLastError());
+  if (collide) {
+    hipLaunchKernelGGL(dg_collide_kernel, dim3((int)((B + 255) / 256)), dim3(256), 0, h->stream, B, dq, dc);
+    HIPCHK(h, hipGetLastError());
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(u_ws, du, sizeof(double) * B * D.n, hipMemcpyDeviceToHost));
+  if (q_ws) HIPCHK(h, hipMemcpy(q_ws, dq, sizeof(double) * B * nx, hipMemcpyDeviceToHost));
+  if (collide) HIPCHK(h, hipMemcpy(collide, dc, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
   return DGSQP_OK;
 }
 

@@ -200,9 +200,11 @@ def pid_warm_start(model, q0, N, dt, u_max=(2.1, 0.436), du=(10.0, 4.5)):
     return np.stack(qs, axis=1), np.stack(us, axis=1)
 
 
-def sample_scenarios(game: Game, B: int, seed: int = 1, max_rounds: int = 200):
+def sample_scenarios(game: Game, B: int, seed: int = 1, max_rounds: int = 200, solver=None):
     """Rejection-sample B two-agent scenarios (chicane.py:384-404, :465-467).
-    Returns x0 [B, n_q] and u_ws [B, N, n_u] (time-major, as ``set_warm_start`` expects)."""
+    Returns x0 [B, n_q] and u_ws [B, N, n_u] (time-major, as ``set_warm_start`` expects).
+    With ``solver`` (a ``dgsqp_amd.solver.DGSQP`` of this game) the PID warm starts and the collision check run on the
+    device (``dgsqp_pid_warm_start_batch``); the random draws are the same either way."""
     if game.joint_model.n_a != 2:
         return _sample_scenarios_independent(game, B, seed, max_rounds)
     rng = np.random.default_rng(seed)
@@ -234,6 +236,13 @@ def sample_scenarios(game: Game, B: int, seed: int = 1, max_rounds: int = 200):
             q0.append(q)
         rl = game.agent_constraints[0]
         du = (10.0, 4.5) if rl is None else tuple(rl.rate_max)
+        if solver is not None:
+            dev = solver.pid_warm_start_batch(np.concatenate(q0, axis=1), du_max=du)
+            keep = ~dev['collide']
+            x0s.append(np.concatenate([q0[0][keep], q0[1][keep]], axis=1))
+            uws.append(dev['u_ws'][keep])
+            have += int(keep.sum())
+            continue
         q_ws, u_ws = zip(*[pid_warm_start(m, q, N, dt, du=du) for m, q in zip(models, q0)])
         dist = np.linalg.norm(q_ws[0][:, :, :2] - q_ws[1][:, :, :2], axis=2)
         keep = ~(dist < obs_d).any(axis=1)           # check_collision (chicane.py:38-43)

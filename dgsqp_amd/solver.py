@@ -313,6 +313,33 @@ class DGSQP(AbstractSolver):
             raise RuntimeError(f'dgsqp_qp_batch failed ({rc}): {self._lib.dgsqp_last_error(self._h).decode()}')
         return out
 
+    def pid_warm_start_batch(self, q0, u_max=(2.1, 0.436), du_max=(10.0, 4.5), substeps=10, want_trajectories=False):
+        """PID lane-follower warm start of a batch on the device (chicane.py:411-447 with PID.py; collision check
+        chicane.py:38-43).  q0 [B, n_q] -> dict(u_ws [B, N, n_u] time-major as ``set_warm_start`` / ``solve_batch`` take it,
+        collide [B] bool, optionally q_ws [B, N+1, n_q])."""
+        q0 = np.ascontiguousarray(q0, dtype=np.float64)
+        if q0.ndim != 2 or q0.shape[1] != self.n_q:
+            raise RuntimeError(f'q0 must be [B, {self.n_q}]')
+        B = q0.shape[0]
+        pid = _ffi.PidT()
+        pid.kp_v, pid.kp_s, pid.ki_s, pid.ey_gain, pid.ei_max = 1.0, 1.0, 0.005, 5.0, 100.0
+        pid.u_max[0], pid.u_max[1] = float(u_max[0]), float(u_max[1])
+        pid.du_max[0], pid.du_max[1] = float(du_max[0]), float(du_max[1])
+        pid.substeps = int(substeps)
+        u_am = np.empty((B, self.n))
+        q_ws = np.empty((B, self.N + 1, self.n_q)) if want_trajectories else None
+        col = np.empty(B, np.int32)
+        rc = self._lib.dgsqp_pid_warm_start_batch(self._h, B, _ffi.dptr(q0), C.byref(pid), _ffi.dptr(u_am), _ffi.dptr(q_ws),
+                                                  _ffi.iptr(col))
+        if rc != 0:
+            raise RuntimeError(f'dgsqp_pid_warm_start_batch failed ({rc}): {self._lib.dgsqp_last_error(self._h).decode()}')
+        nua = self.n_u // self.M
+        u_tm = u_am.reshape(B, self.M, self.N, nua).transpose(0, 2, 1, 3).reshape(B, self.N, self.n_u)
+        out = dict(u_ws=np.ascontiguousarray(u_tm), collide=col.astype(bool))
+        if want_trajectories:
+            out['q_ws'] = q_ws
+        return out
+
     # ---- reference single-scenario surface -----------------------------------------------------
     def solve(self, states: List[VehicleState], parameters: np.ndarray = np.array([])) -> dict:
         solve_start = time.time()

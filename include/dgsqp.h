@@ -135,6 +135,19 @@ typedef struct {
   int32_t reserved_;
 } dgsqp_params_t;
 
+/* PID lane follower used for the Monte-Carlo warm start (DGSQP/solvers/PID.py through
+   scripts/DGSQP_ALGAMES_monte_carlo_chicane.py:411-447) */
+typedef struct {
+  double kp_v;        /* speed P gain (1) */
+  double kp_s, ki_s;  /* steering PI gains (1, 0.005) on  ey_gain (e_y - e_y0) + e_psi */
+  double ey_gain;     /* 5 */
+  double ei_max;      /* integrator clamp (100) */
+  double u_max[2];    /* |u_a|, |u_steer| saturation */
+  double du_max[2];   /* per-step change saturation, applied before the magnitude saturation */
+  int32_t substeps;   /* rk4 sub-steps of the plant per dt (10) */
+  int32_t reserved_;
+} dgsqp_pid_t;
+
 typedef struct {
   int32_t M, N, n_q, n_u, n, n_c; /* n = N*n_u decision vars, n_c inequality rows */
   int32_t n_dense;                /* distinct dense constraint gradients */
@@ -206,6 +219,13 @@ int dgsqp_evaluate_batch(dgsqp_handle_t h, int64_t B, const double* x0, const do
  */
 int dgsqp_qp_batch(dgsqp_handle_t h, int64_t B, const double* x0, const double* u,
                    const double* l, double* du, double* lhat, double* Qpd, int32_t* flag);
+
+/* Warm start of a Monte-Carlo batch (row (f) of the hot-path scope): for every scenario and agent roll the PID lane follower
+   out from q0[B][n_q] over the horizon with the agent's own continuous model (rk4).  u_ws[B][n] agent-major (what
+   dgsqp_solve_batch takes); q_ws[B][(N+1) n_q] and collide[B] (1 = some pair closer than r_i + r_j at some stage,
+   check_collision chicane.py:38-43) are optional.  Replaces the per-sample loop chicane.py:411-447 / curve.py:440-467. */
+int dgsqp_pid_warm_start_batch(dgsqp_handle_t h, int64_t B, const double* q0, const dgsqp_pid_t* pid, double* u_ws,
+                               double* q_ws, int32_t* collide);
 
 /*
  * Test hook: event log of the SQP state machine (convergence measures, merit values, step lengths,

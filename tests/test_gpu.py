@@ -313,3 +313,35 @@ def test_three_and_four_agents(oracle, M, N):
     assert np.array_equal(res['status'], ref['status']) and np.array_equal(res['num_iters'], ref['num_iters'])
     for b in range(B):
         assert rel(res['u'][b], ref['u'][b]) < 1e-6 and rel(res['l'][b], ref['l'][b]) < 1e-5
+
+
+@pytest.mark.parametrize('name', ['kb_chicane_N15', 'dyn_curve_N15'])
+def test_pid_warm_start_on_device(games, solvers, name):
+    """Row (f): the PID lane-follower warm start and the collision check of the Monte-Carlo scripts (chicane.py:411-447,
+    :38-43) on the device against the numpy mirror: inputs, trajectories, collision flags, and the sampler built on it."""
+    from dgsqp_amd.montecarlo import pid_warm_start, sample_scenarios
+    g, P, par = games[name]
+    s = solvers[name]
+    rng = np.random.default_rng(3)
+    B = 300
+    models = g.joint_model.dynamics_models
+    q0 = []
+    for m in models:                                   # same placement rules as the sampler, no rejection
+        q = np.zeros((B, m.n_q))
+        sv, ey = 0.1 + rng.random(B) * 2.0, rng.random(B) * 1.6 - 0.8
+        xy = np.array([g.track.local_to_global((a, b, 0.0))[:2] for a, b in zip(sv, ey)])
+        q[:, 0], q[:, 1], q[:, 2] = xy[:, 0], xy[:, 1], rng.random(B) + 2
+        q[:, m.s_idx], q[:, m.ey_idx] = sv, ey
+        q0.append(q)
+    du = tuple(g.agent_constraints[0].rate_max)
+    ref = [pid_warm_start(m, q, g.params.N, g.params.dt, du=du) for m, q in zip(models, q0)]
+    dev = s.pid_warm_start_batch(np.concatenate(q0, axis=1), du_max=du, want_trajectories=True)
+    u_ref = np.concatenate([r[1] for r in ref], axis=2)
+    q_ref = np.concatenate([r[0] for r in ref], axis=2)
+    assert np.abs(dev['u_ws'] - u_ref).max() < 1e-10 and np.abs(dev['q_ws'] - q_ref).max() < 1e-10
+    dist = np.linalg.norm(ref[0][0][:, :, :2] - ref[1][0][:, :, :2], axis=2)
+    margin = np.abs(dist - g.obs_d).min(axis=1) > 1e-9          # flags may differ only on exact ties
+    assert np.array_equal(dev['collide'][margin], (dist < g.obs_d).any(axis=1)[margin]) and dev['collide'].any() and not dev['collide'].all()
+    x0_h, u_h = sample_scenarios(g, 64, seed=9)
+    x0_d, u_d = sample_scenarios(g, 64, seed=9, solver=s)
+    assert np.array_equal(x0_h, x0_d) and np.abs(u_h - u_d).max() < 1e-10

@@ -88,12 +88,12 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header():
     """ctypes mirrors and the C structs agree in size (checked by compiling a tiny C program)."""
     from dgsqp_amd import _ffi
-    src = '#include <stdio.h>\n#include "dgsqp.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(dgsqp_agent_t), sizeof(dgsqp_problem_t), sizeof(dgsqp_params_t), sizeof(dgsqp_dims_t), sizeof(dgsqp_timing_t));return 0;}\n'
+    src = '#include <stdio.h>\n#include "dgsqp.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(dgsqp_agent_t), sizeof(dgsqp_problem_t), sizeof(dgsqp_params_t), sizeof(dgsqp_dims_t), sizeof(dgsqp_timing_t), sizeof(dgsqp_pid_t));return 0;}\n'
     exe = pathlib.Path('/tmp/dgsqp_sizeof')
     subprocess.run(['gcc', '-x', 'c', '-', '-I', str(ROOT / 'include'), '-o', str(exe)], input=src.encode(), check=True)
     sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     assert sizes == [ctypes.sizeof(_ffi.AgentT), ctypes.sizeof(_ffi.ProblemT), ctypes.sizeof(_ffi.ParamsT),
-                     ctypes.sizeof(_ffi.DimsT), ctypes.sizeof(_ffi.TimingT)]
+                     ctypes.sizeof(_ffi.DimsT), ctypes.sizeof(_ffi.TimingT), ctypes.sizeof(_ffi.PidT)]
 
 
 def _has_gpu():
