@@ -61,7 +61,7 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     import torch
     import torch.distributed as dist
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get('DGSQP_BENCH_FORCE_DIST') == '1'   # the env knob lets a 1-GPU box exercise the RCCL path
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
