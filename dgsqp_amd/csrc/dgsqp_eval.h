@@ -822,24 +822,45 @@ __device__ __noinline__ void dev_hessian_adjoint(const Ctx& c) {
   __syncthreads();
   // ---- 2. H[a][k][b] = sum_o lam^a_{k+1}[b,o] * Hessian of f^b_{k,o} in effective variables (interpolated from the
   //         e_i / e_i+e_j Taylor coefficients: H_ii = 2 c_i, H_ij = c_ij - c_i - c_j)
+  // (a) cv[a][k][b][dir] = sum_o lam^a_{k+1}[b,o] T2[b][k][o][dir], once per direction (coalesced over dir), kept in the
+  //     LDS area of the speculative line-search trajectories (idle here)
+  lptr cvb = lds + L.e_xs;
+  const int cvcap = (L.o_du - L.e_xs);
+  int ndmax = 0;
+  for (int b = 0; b < M; b++) ndmax = D.ndir[b] > ndmax ? D.ndir[b] : ndmax;
+  const bool use_cv = M * N * M * ndmax <= cvcap;
+  if (use_cv) {
+    for (int it = TID; it < M * N * M * ndmax; it += NT) {
+      const int dir = it % ndmax, b = (it / ndmax) % M, k = (it / (ndmax * M)) % N, a = it / (ndmax * M * N);
+      double sv = 0.0;
+      if (dir < D.ndir[b]) {
+        cgptr T2 = T2base + D.t2off[b] + (int64_t)k * D.t2k[b];
+        clptr lk = lam + (a * (N + 1) + k + 1) * nq + D.qoff[b];
+        const int nd = D.ndir[b];
+        for (int o = 0; o < D.nqa[b]; o++) sv += lk[o] * T2[o * nd + dir];
+      }
+      cvb[it] = sv;
+    }
+    __syncthreads();
+  }
+  // (b) Hessian entries from the contracted coefficients
   for (int it = TID; it < M * N * M * EE; it += NT) {
     const int e = it % EE, b = (it / EE) % M, k = (it / (EE * M)) % N, a = it / (EE * M * N);
     const int i = e / DG_MAXEFF, j = e % DG_MAXEFF, ne = D.neff[b];
     double h = 0.0;
     if (i < ne && j < ne) {
-      cgptr T2 = T2base + D.t2off[b] + (int64_t)k * D.t2k[b];
-      clptr lk = lam + (a * (N + 1) + k + 1) * nq + D.qoff[b];
-      const int nd = D.ndir[b];
-      if (i == j) {
-        double s = 0;
-        for (int o = 0; o < D.nqa[b]; o++) s += lk[o] * T2[o * nd + i];
-        h = 2.0 * s;
+      const int lo = i < j ? i : j, hi = i < j ? j : i;
+      const int dirp = ne + lo * (ne - 1) - lo * (lo - 1) / 2 + (hi - lo - 1);
+      if (use_cv) {
+        clptr cv = cvb + ((a * N + k) * M + b) * ndmax;
+        h = i == j ? 2.0 * cv[i] : cv[dirp] - cv[lo] - cv[hi];
       } else {
-        const int lo = i < j ? i : j, hi = i < j ? j : i;
-        const int dir = ne + lo * (ne - 1) - lo * (lo - 1) / 2 + (hi - lo - 1);
-        double s = 0;
-        for (int o = 0; o < D.nqa[b]; o++) s += lk[o] * (T2[o * nd + dir] - T2[o * nd + lo] - T2[o * nd + hi]);
-        h = s;
+        cgptr T2 = T2base + D.t2off[b] + (int64_t)k * D.t2k[b];
+        clptr lk = lam + (a * (N + 1) + k + 1) * nq + D.qoff[b];
+        const int nd = D.ndir[b];
+        double sv = 0;
+        if (i == j) { for (int o = 0; o < D.nqa[b]; o++) sv += lk[o] * T2[o * nd + i]; h = 2.0 * sv; }
+        else { for (int o = 0; o < D.nqa[b]; o++) sv += lk[o] * (T2[o * nd + dirp] - T2[o * nd + lo] - T2[o * nd + hi]); h = sv; }
       }
     }
     Hg[it] = h;
