@@ -49,11 +49,13 @@ def algorithmic_bytes_per_solve(d):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=1024, help='scenarios per GPU per step')
     ap.add_argument('--workload', default='dyn_curve_N25', choices=sorted(WORKLOADS))
     ap.add_argument('--cpu-sample', type=int, default=16, help='scenarios timed on the host for cpu_baseline (0 disables)')
+    ap.add_argument('--pipeline', type=int, default=3,
+                    help='independent batches in flight per GPU (each on its own handle / HIP stream); 1 = strictly one launch at a time')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -82,11 +84,19 @@ def main():
     x0, u_tm = sample_scenarios(game, B, seed=1 + rank)          # rejection sampling happens before any timing
     u_am = np.ascontiguousarray(solver._to_agent_major(u_tm))
     lib, h = solver._lib, solver._h
-    assert lib.dgsqp_stage_inputs(h, B, _ffi.dptr(x0), _ffi.dptr(u_am)) == 0, lib.dgsqp_last_error(h)
+    # Steps are independent batches.  With --pipeline P > 1 they are issued round-robin on P handles (own stream, workspace and
+    # result buffers each) without waiting in between: the workgroups of step i+1 take over the compute units while step i
+    # drains its slowest scenarios.  Every step still solves its whole batch; all of them are complete at the closing fence.
+    P = max(1, args.pipeline)
+    solvers = [solver] + [DGSQP(*game.solver_args(), print_method=None, device=local_rank) for _ in range(P - 1)]
+    handles = [sv._h for sv in solvers]
+    for hh in handles:
+        assert lib.dgsqp_stage_inputs(hh, B, _ffi.dptr(x0), _ffi.dptr(u_am)) == 0, lib.dgsqp_last_error(hh)
 
     tm = _ffi.TimingT()
     for _ in range(args.warmup):
-        assert lib.dgsqp_solve_staged(h, C.byref(tm)) == 0, lib.dgsqp_last_error(h)
+        for hh in handles:
+            assert lib.dgsqp_solve_staged(hh, C.byref(tm)) == 0, lib.dgsqp_last_error(hh)
 
     def fence():
         if distributed:
@@ -94,11 +104,27 @@ def main():
         torch.cuda.synchronize()
 
     kernel_ms = []
+    busy = [False] * P
+
+    def wait(i):
+        assert lib.dgsqp_wait(handles[i], C.byref(tm)) == 0, lib.dgsqp_last_error(handles[i])
+        kernel_ms.append(tm.kernel_ms)            # HIP events around that launch on its own stream
+        busy[i] = False
+
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        assert lib.dgsqp_solve_staged(h, C.byref(tm)) == 0, lib.dgsqp_last_error(h)   # launches + waits on the solver's stream
-        kernel_ms.append(tm.kernel_ms)                                               # HIP events around the kernel on that stream
+    for step in range(args.steps):
+        i = step % P
+        if busy[i]:
+            wait(i)
+        assert lib.dgsqp_launch_staged(handles[i]) == 0, lib.dgsqp_last_error(handles[i])
+        busy[i] = True
+        if step + 1 < min(P, args.steps):
+            time.sleep(0.002)      # while the pipeline fills: let this launch occupy the CUs before the next one is enqueued
+    for i in range(P):
+        if busy[i]:
+            wait(i)
+    h = handles[(args.steps - 1) % P]             # results of the last step
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
@@ -139,7 +165,8 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': args.workload, 'description': WORKLOADS[args.workload]['desc'], 'batch_per_gpu': B,
                        'n': int(d.n), 'n_c': int(d.n_c), 'parallelism': f'scenario-sharded x{world}',
-                       'sampler': 'scripts/DGSQP_ALGAMES_monte_carlo_curve.py:384-467 (seed 1+rank), PID warm start'},
+                       'sampler': 'scripts/DGSQP_ALGAMES_monte_carlo_curve.py:384-467 (seed 1+rank), PID warm start',
+                       'batches_in_flight': P},
             'mean_iters': summ['mean_iters_converged'], 'mean_iters_all': summ['mean_iters_all'],
             'mean_qp_solves': summ['mean_qp_solves_all'], 'converged_fraction': summ['converged'],
             'status_fractions': {k: summ[k] for k in ('conv_abs_tol', 'conv_rel_tol', 'max_it', 'diverged', 'qp_fail')},

@@ -130,7 +130,7 @@ struct dgsqp_solver {
   DgProb* dp = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  int num_cu = 0, wg_per_cu = 1, max_grid = 0;
+  int num_cu = 0, wg_per_cu = 1, max_grid = 0, launched_grid = 0;
   size_t lds_bytes = 0;
   double* ws = nullptr;
   size_t ws_groups = 0;
@@ -294,10 +294,10 @@ int dgsqp_stage_inputs(dgsqp_handle_t h, int64_t B, const double* x0, const doub
   return DGSQP_OK;
 }
 
-int dgsqp_solve_staged(dgsqp_handle_t h, dgsqp_timing_t* tm) {
+int dgsqp_launch_staged(dgsqp_handle_t h) {
   if (!h) return DGSQP_E_ARG;
   HIPCHK(h, hipSetDevice(h->device));
-  if (tm) memset(tm, 0, sizeof(*tm));
+  h->launched_grid = 0;
   if (h->B == 0) return DGSQP_OK;
   const int grid = grid_for(h, h->B);
   SolveOutPtrs O{h->d_u, h->d_l, h->d_x, h->d_cond, h->d_cost, h->d_status, h->d_iters, h->d_qps};
@@ -317,13 +317,27 @@ int dgsqp_solve_staged(dgsqp_handle_t h, dgsqp_timing_t* tm) {
   hipLaunchKernelGGL(dg_solve_kernel, dim3(grid), dim3(DG_BLOCK), h->lds_bytes, h->stream, h->dp, h->B, h->d_x0, h->d_uws, O, h->ws, h->ticket, trace, h->trace_cap);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+  h->launched_grid = grid;
+  return DGSQP_OK;
+}
+
+int dgsqp_wait(dgsqp_handle_t h, dgsqp_timing_t* tm) {
+  if (!h) return DGSQP_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (tm) memset(tm, 0, sizeof(*tm));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  if (tm) {
+  if (tm && h->launched_grid > 0) {
     float ms = 0;
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
-    tm->kernel_ms = ms; tm->total_ms = ms; tm->grid = grid; tm->block = DG_BLOCK;
+    tm->kernel_ms = ms; tm->total_ms = ms; tm->grid = h->launched_grid; tm->block = DG_BLOCK;
   }
   return DGSQP_OK;
+}
+
+int dgsqp_solve_staged(dgsqp_handle_t h, dgsqp_timing_t* tm) {
+  const int rc = dgsqp_launch_staged(h);
+  if (rc != DGSQP_OK) return rc;
+  return dgsqp_wait(h, tm);
 }
 
 int dgsqp_fetch_results(dgsqp_handle_t h, double* u_out, double* l_out, double* x_out, int32_t* status, int32_t* iters,

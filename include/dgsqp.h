@@ -196,6 +196,11 @@ int dgsqp_solve_batch(dgsqp_handle_t h, int64_t B, const double* x0, const doubl
  */
 int dgsqp_stage_inputs(dgsqp_handle_t h, int64_t B, const double* x0, const double* u_ws);
 int dgsqp_solve_staged(dgsqp_handle_t h, dgsqp_timing_t* timing);
+/* Asynchronous halves of dgsqp_solve_staged(): enqueue the solve on the handle's own stream / wait for it.  Independent
+   batches held by different handles of the SAME game can be in flight together: the workgroups of the later launch take
+   over the compute units as the earlier launch drains its slowest scenarios. */
+int dgsqp_launch_staged(dgsqp_handle_t h);
+int dgsqp_wait(dgsqp_handle_t h, dgsqp_timing_t* timing);
 int dgsqp_fetch_results(dgsqp_handle_t h, double* u_out, double* l_out, double* x_out,
                         int32_t* status, int32_t* iters, int32_t* qp_solves, double* cond,
                         double* cost);

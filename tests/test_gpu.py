@@ -345,3 +345,31 @@ def test_pid_warm_start_on_device(games, solvers, name):
     x0_h, u_h = sample_scenarios(g, 64, seed=9)
     x0_d, u_d = sample_scenarios(g, 64, seed=9, solver=s)
     assert np.array_equal(x0_h, x0_d) and np.abs(u_h - u_d).max() < 1e-10
+
+
+def test_concurrent_launches_on_two_handles(games):
+    """dgsqp_launch_staged / dgsqp_wait: two batches in flight on two handles of the same game (own stream, workspace,
+    result buffers) give bit-identical results to one-at-a-time solves."""
+    import ctypes as C
+    from dgsqp_amd import _ffi
+    from dgsqp_amd.montecarlo import sample_scenarios
+    from dgsqp_amd.solver import DGSQP
+    g, P, par = games['kb_chicane_N15']
+    sa, sb = DGSQP(*g.solver_args(), print_method=None), DGSQP(*g.solver_args(), print_method=None)
+    xa, ua = sample_scenarios(g, 300, seed=41)
+    xb, ub = sample_scenarios(g, 300, seed=42)
+    ref_a, ref_b = sa.solve_batch(xa, ua), sb.solve_batch(xb, ub)
+    lib = sa._lib
+    for s_, x_, u_ in ((sa, xa, ua), (sb, xb, ub)):
+        u_am = np.ascontiguousarray(s_._to_agent_major(u_))
+        assert lib.dgsqp_stage_inputs(s_._h, x_.shape[0], _ffi.dptr(np.ascontiguousarray(x_)), _ffi.dptr(u_am)) == 0
+    assert lib.dgsqp_launch_staged(sa._h) == 0 and lib.dgsqp_launch_staged(sb._h) == 0      # both in flight
+    tm = _ffi.TimingT()
+    assert lib.dgsqp_wait(sb._h, C.byref(tm)) == 0 and tm.kernel_ms > 0
+    assert lib.dgsqp_wait(sa._h, C.byref(tm)) == 0 and tm.kernel_ms > 0
+    for s_, ref in ((sa, ref_a), (sb, ref_b)):
+        B = ref['u'].shape[0]
+        u = np.empty((B, s_.n)); l = np.empty((B, s_.n_c_total)); st = np.empty(B, np.int32); it = np.empty(B, np.int32)
+        assert lib.dgsqp_fetch_results(s_._h, _ffi.dptr(u), _ffi.dptr(l), None, _ffi.iptr(st), _ffi.iptr(it), None, None, None) == 0
+        assert np.array_equal(st, ref['status']) and np.array_equal(it, ref['num_iters'])
+        assert np.array_equal(u, ref['u']) and np.array_equal(l, ref['l'])
