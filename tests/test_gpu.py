@@ -373,3 +373,46 @@ def test_concurrent_launches_on_two_handles(games):
         assert lib.dgsqp_fetch_results(s_._h, _ffi.dptr(u), _ffi.dptr(l), None, _ffi.iptr(st), _ffi.iptr(it), None, None, None) == 0
         assert np.array_equal(st, ref['status']) and np.array_equal(it, ref['num_iters'])
         assert np.array_equal(u, ref['u']) and np.array_equal(l, ref['l'])
+
+
+@pytest.mark.parametrize('comp_type', ['atan', 'linear'])
+def test_blocking_and_obstacle_cost_terms(oracle, comp_type):
+    """Cost terms of scripts/DGSQP_monte_carlo_ablation.py:229-262 that the preset games leave at zero weight: blocking
+    (e_y coupling), soft obstacle (active hinge) and both competition types -- evaluation incl. Q, and whole solves."""
+    import dataclasses
+    from dgsqp_amd.game import RacingCost
+    from dgsqp_amd.montecarlo import kinematic_racing_game, sample_scenarios
+    from dgsqp_amd.solver import DGSQP, build_problem, build_params
+    import dgsqp_amd.solver as sv
+    g = kinematic_racing_game('curve', N=12, M=3)
+    cost = lambda: RacingCost(input_weight=(1.0, 1.0), input_rate_weight=(1.0, 1.0), comp_weights=(10.0, 5.0), comp_type=comp_type,
+                              blocking_weight=0.7, obs_weight=3.0, obs_r=0.9)     # hinge active for agents closer than 1.8
+    g = dataclasses.replace(g, costs=[cost() for _ in range(3)])
+    P, par = build_problem(*g.solver_args()), tight_lsqr(build_params(g.params))
+    orig = sv.build_params
+    sv.build_params = lambda p: tight_lsqr(orig(p))
+    try:
+        s = DGSQP(*g.solver_args(), print_method=None)
+    finally:
+        sv.build_params = orig
+    B, N, M = 8, 12, 3
+    x0, u_tm = sample_scenarios(g, B, seed=6)
+    u = np.ascontiguousarray(u_tm.reshape(B, N, M, 2).transpose(0, 2, 1, 3).reshape(B, -1))
+    rng = np.random.default_rng(2)
+    up = u + 0.01 * rng.standard_normal(u.shape)
+    l = np.maximum(0, rng.standard_normal((B, s.n_c_total)))
+    ev = s.evaluate_batch(x0, up, l)
+    active = 0
+    for b in range(B):
+        o = oracle.evaluate(P, x0[b], up[b], l[b], 1)
+        for key in ('x', 'q', 'g', 'G', 'Q'):
+            assert rel(ev[key][b], o[key]) < 1e-12, (key, b)
+        p = o['x'].reshape(N + 1, M, 6)[:, :, :2]
+        active += int((np.linalg.norm(p[:, 0] - p[:, 1], axis=1) < 1.8).any())
+    assert active > 0                                   # the hinge really was active somewhere
+    res = s.solve_batch(x0, u_tm)
+    ref = oracle.solve_batch(P, par, x0, u, nthreads=4)
+    same = (res['status'] == ref['status']) & (res['num_iters'] == ref['num_iters'])
+    assert same.mean() >= 0.75, (res['status'], ref['status'], res['num_iters'], ref['num_iters'])
+    for b in np.nonzero(same & (ref['status'] <= 1))[0]:
+        assert rel(res['u'][b], ref['u'][b]) < 1e-5
