@@ -416,3 +416,39 @@ def test_blocking_and_obstacle_cost_terms(oracle, comp_type):
     assert same.mean() >= 0.75, (res['status'], ref['status'], res['num_iters'], ref['num_iters'])
     for b in np.nonzero(same & (ref['status'] <= 1))[0]:
         assert rel(res['u'][b], ref['u'][b]) < 1e-5
+
+
+@pytest.mark.parametrize('kind,method,msub,over', [
+    ('dyn', 'rk3', 2, dict(tire_model='linear')),
+    ('dyn', 'rk2', 2, dict(simple_slip=True, drive_wheels='rear')),
+    ('dyn', 'euler', 1, dict(rolling_resistance=0.05, rolling_resistance_exponent=0.5, drag_coefficient=0.1, damping_coefficient=0.05)),
+    ('kin', 'rk4', 3, dict(rolling_resistance=0.05, rolling_resistance_exponent=0.5)),
+    ('kin', 'rk2', 2, dict()),
+])
+def test_model_and_integrator_variants(oracle, kind, method, msub, over):
+    """Vehicle-model options and integrators the preset games do not use (dynamics_models.py:188-219 rk3/rk2, linear tyres,
+    simple slip angle, rear-wheel drive, rolling resistance): rollout, q, g, G and the game Hessian against the oracle."""
+    import dataclasses
+    from dgsqp_amd.dynamics import (CasadiDynamicBicycleCombined, CasadiKinematicBicycleCombined,
+                                    CasadiDecoupledMultiAgentDynamicsModel)
+    from dgsqp_amd.montecarlo import dynamic_racing_game, kinematic_racing_game, sample_scenarios
+    from dgsqp_amd.solver import DGSQP, build_problem
+    base = dynamic_racing_game(N=8, rk4_substeps=3) if kind == 'dyn' else kinematic_racing_game('curve', N=8)
+    cls = CasadiDynamicBicycleCombined if kind == 'dyn' else CasadiKinematicBicycleCombined
+    models = [cls(0, dataclasses.replace(m.model_config, discretization_method=method, M=msub, **over), track=base.track)
+              for m in base.joint_model.dynamics_models]
+    joint = CasadiDecoupledMultiAgentDynamicsModel(0, models, dataclasses.replace(base.joint_model.model_config,
+                                                                                  discretization_method=method, M=msub))
+    g = dataclasses.replace(base, joint_model=joint)
+    P = build_problem(*g.solver_args())
+    s = DGSQP(*g.solver_args(), print_method=None)
+    B = 4
+    x0, u_tm = sample_scenarios(base, B, seed=8)
+    rng = np.random.default_rng(4)
+    u = agent_major(u_tm) + 0.01 * rng.standard_normal((B, s.n))
+    l = np.maximum(0, rng.standard_normal((B, s.n_c_total)))
+    ev = s.evaluate_batch(x0, u, l)
+    for b in range(B):
+        o = oracle.evaluate(P, x0[b], u[b], l[b], 1)
+        for key in ('x', 'q', 'g', 'G', 'Q'):
+            assert rel(ev[key][b], o[key]) < 1e-11, (key, b)
