@@ -13,6 +13,7 @@ python bench.py --workload kb_curve_N25 --batch 4096 --cpu-sample 0 > $O/bench_k
 python bench.py --workload kb_curve_N25 --batch 16384 --cpu-sample 0 > $O/bench_kb_curve_N25_B16384.json 2>> $O/bench_kb.err
 python bench.py --batch 4096 --cpu-sample 0 > $O/bench_dyn_curve_N25_B4096.json 2>> $O/bench_dyn.err
 cd $R
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DDG_PROF -o dgsqp_amd/csrc/libdgsqp_hip_prof.so dgsqp_amd/csrc/dgsqp_api.hip   # diagnostic build, always fresh
 DGSQP_HIP_LIB=dgsqp_amd/csrc/libdgsqp_hip_prof.so python tools/gpu_time.py dyn 25 1024 > $O/phase_cycles_dyn_curve_N25_B1024.txt 2>&1
 DGSQP_HIP_LIB=dgsqp_amd/csrc/libdgsqp_hip_prof.so python tools/gpu_time.py kbcurve 25 1024 > $O/phase_cycles_kb_curve_N25_B1024.txt 2>&1
 find $O -name "*.csv" | head -40
