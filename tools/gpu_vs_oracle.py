@@ -23,6 +23,11 @@ o = oracle.solve_batch(s._problem, s._cparams, x0, u_am, nthreads=min(B, os.cpu_
 print('oracle time', time.time() - t)
 same = (res['status'] == o['status']) & (res['num_iters'] == o['num_iters']) & (res['qp_solves'] == o['qp_solves'])
 print('identical (status, iters, qps):', same.mean())
-print('gpu    status', res['status'].tolist()); print('oracle status', o['status'].tolist())
-print('gpu    iters ', res['num_iters'].tolist()); print('oracle iters ', o['num_iters'].tolist())
+if B <= 64:
+    print('gpu    status', res['status'].tolist()); print('oracle status', o['status'].tolist())
+    print('gpu    iters ', res['num_iters'].tolist()); print('oracle iters ', o['num_iters'].tolist())
+conv = same & (o['status'] <= 1)
+relu = [np.abs(res['u'][i] - o['u'][i]).max() / max(1e-300, np.abs(o['u'][i]).max()) for i in np.nonzero(conv)[0]]
+print('identical & converged:', int(conv.sum()), 'max rel |du| among them', max(relu) if relu else None, 'median', float(np.median(relu)) if relu else None)
+print('mean iters gpu', res['num_iters'].mean(), 'oracle', o['num_iters'].mean())
 print('gpu conv', np.mean(res['status'] <= 1), 'oracle conv', np.mean(o['status'] <= 1))
