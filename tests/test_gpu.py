@@ -282,8 +282,8 @@ def test_solve_same_with_and_without_qp_warm_start(games):
         assert rel(a['u'][i], b['u'][i]) < 1e-6 and rel(a['l'][i], b['l'][i]) < 1e-5
 
 
-@pytest.mark.parametrize('M,N', [(3, 10), (4, 8)])
-def test_three_and_four_agents(oracle, M, N):
+@pytest.mark.parametrize('M,N', [(1, 10), (3, 10), (4, 8)])
+def test_one_three_and_four_agents(oracle, M, N):
     """More than two agents (scripts/DGSQP_monte_carlo_agents.py): evaluation incl. the game Hessian, the QP and whole
     solves against the oracle; exercises the M-agent instantiations of the second-order adjoint rows."""
     from dgsqp_amd.montecarlo import kinematic_racing_game, sample_scenarios
