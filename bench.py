@@ -19,6 +19,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')     # one hardware queue per in-flight batch (HIP default: 4)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -49,12 +51,12 @@ def algorithmic_bytes_per_solve(d):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=6)
+    ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=1024, help='scenarios per GPU per step')
     ap.add_argument('--workload', default='dyn_curve_N25', choices=sorted(WORKLOADS))
     ap.add_argument('--cpu-sample', type=int, default=16, help='scenarios timed on the host for cpu_baseline (0 disables)')
-    ap.add_argument('--pipeline', type=int, default=3,
+    ap.add_argument('--pipeline', type=int, default=5,
                     help='independent batches in flight per GPU (each on its own handle / HIP stream); 1 = strictly one launch at a time')
     args = ap.parse_args()
 
@@ -105,28 +107,35 @@ def main():
 
     kernel_ms = []
     busy = [False] * P
+    order = []                                        # handles in launch order (oldest first)
 
     def wait(i):
         assert lib.dgsqp_wait(handles[i], C.byref(tm)) == 0, lib.dgsqp_last_error(handles[i])
         kernel_ms.append(tm.kernel_ms)            # HIP events around that launch on its own stream
         busy[i] = False
+        order.remove(i)
 
     fence()
     t0 = time.perf_counter()
+    last = None
     for step in range(args.steps):
-        i = step % P
-        if busy[i]:
-            wait(i)
+        # start the next batch when the previous launch has handed out its last scenario (its workgroups begin to exit and
+        # free compute units) -- not earlier, or two launches would share the GPU from the start and both grow tails
+        if last is not None and P > 1:
+            while not lib.dgsqp_draining(handles[last]):
+                time.sleep(0.0002)
+        if all(busy):
+            wait(order[0])
+        i = busy.index(False)
         assert lib.dgsqp_launch_staged(handles[i]) == 0, lib.dgsqp_last_error(handles[i])
         busy[i] = True
-        if step + 1 < min(P, args.steps):
-            time.sleep(0.002)      # while the pipeline fills: let this launch occupy the CUs before the next one is enqueued
-    for i in range(P):
-        if busy[i]:
-            wait(i)
-    h = handles[(args.steps - 1) % P]             # results of the last step
+        order.append(i)
+        last = i
+    while order:
+        wait(order[0])
     fence()
     elapsed = time.perf_counter() - t0
+    h = handles[last]                                 # results of the last step
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

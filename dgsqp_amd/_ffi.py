@@ -116,6 +116,8 @@ def load_library() -> C.CDLL:
     lib.dgsqp_solve_staged.restype = C.c_int
     lib.dgsqp_launch_staged.argtypes = [H]
     lib.dgsqp_launch_staged.restype = C.c_int
+    lib.dgsqp_draining.argtypes = [H]
+    lib.dgsqp_draining.restype = C.c_int
     lib.dgsqp_wait.argtypes = [H, C.POINTER(TimingT)]
     lib.dgsqp_wait.restype = C.c_int
     lib.dgsqp_fetch_results.argtypes = [H, _PD, _PD, _PD, _PI, _PI, _PI, _PD, _PD]
@@ -137,7 +139,7 @@ def load_library() -> C.CDLL:
 EXPORTED_SYMBOLS = ['dgsqp_create', 'dgsqp_destroy', 'dgsqp_dims', 'dgsqp_last_error', 'dgsqp_backend_info',
                     'dgsqp_solve_batch', 'dgsqp_stage_inputs', 'dgsqp_solve_staged', 'dgsqp_fetch_results',
                     'dgsqp_evaluate_batch', 'dgsqp_qp_batch', 'dgsqp_set_trace', 'dgsqp_fetch_trace',
-                    'dgsqp_pid_warm_start_batch', 'dgsqp_launch_staged', 'dgsqp_wait']
+                    'dgsqp_pid_warm_start_batch', 'dgsqp_launch_staged', 'dgsqp_wait', 'dgsqp_draining']
 
 
 def dptr(a):

@@ -18,7 +18,7 @@
 __global__ void __launch_bounds__(DG_BLOCK)
 dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__ x0, const double* __restrict__ u_ws,
                 SolveOutPtrs O, double* __restrict__ ws_all, unsigned long long* __restrict__ ticket,
-                double* __restrict__ trace, int trace_cap) {
+                double* __restrict__ trace, int trace_cap, unsigned int* __restrict__ drained) {
   Ctx c;
   c.trace_cap = trace_cap;
   c.ws = (gptr)ws_all + (int64_t)blockIdx.x * dg_prob.ws_doubles;
@@ -32,7 +32,12 @@ dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restric
     if (TID == 0) dg_lds[dg_prob.L.scal + 63] = (double)atomicAdd(ticket, 1ULL);
     __syncthreads();
     const int64_t b = (int64_t)dg_lds[dg_prob.L.scal + 63];
-    if (b >= B) break;
+    if (b >= B) {
+      // the queue is empty: from now on this launch only drains.  Tell the host (mapped, fine-grained memory) so that it
+      // can start the next independent batch on the compute units that become free.
+      if (drained && TID == 0) { __hip_atomic_store(drained, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+      break;
+    }
     c.x0 = (cgptr)x0 + b * dg_prob.nq;
     c.trace = trace ? (gptr)trace + b * (int64_t)(1 + 2 * trace_cap) : nullptr;
     if (c.trace && TID == 0) c.trace[0] = 0.0;
@@ -135,6 +140,8 @@ struct dgsqp_solver {
   double* ws = nullptr;
   size_t ws_groups = 0;
   unsigned long long* ticket = nullptr;
+  unsigned int* drained_host = nullptr;   // mapped host memory: 1 once the last launch has handed out its last scenario
+  unsigned int* drained_dev = nullptr;
   // staged batch
   int64_t cap = 0, B = 0;
   double *d_x0 = nullptr, *d_uws = nullptr, *d_u = nullptr, *d_l = nullptr, *d_x = nullptr, *d_cond = nullptr, *d_cost = nullptr;
@@ -243,6 +250,9 @@ int dgsqp_create(const dgsqp_problem_t* prob, const dgsqp_params_t* par, int dev
   if (hipMalloc(&h->dp, sizeof(DgProb)) != hipSuccess) return fail("hipMalloc(problem) failed");
   if (hipMemcpy(h->dp, &h->hp, sizeof(DgProb), hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy(problem) failed");
   if (hipMalloc(&h->ticket, sizeof(unsigned long long)) != hipSuccess) return fail("hipMalloc(ticket) failed");
+  if (hipHostMalloc((void**)&h->drained_host, sizeof(unsigned int), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return fail("hipHostMalloc(flag) failed");
+  *h->drained_host = 1u;
+  if (hipHostGetDevicePointer((void**)&h->drained_dev, h->drained_host, 0) != hipSuccess) return fail("hipHostGetDevicePointer failed");
   const void* kernels[] = {(const void*)dg_solve_kernel, (const void*)dg_evaluate_kernel, (const void*)dg_qp_kernel};
   for (const void* k : kernels) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
@@ -263,6 +273,7 @@ void dgsqp_destroy(dgsqp_handle_t h) {
   if (h->ws) (void)hipFree(h->ws);
   if (h->dp) (void)hipFree(h->dp);
   if (h->ticket) (void)hipFree(h->ticket);
+  if (h->drained_host) (void)hipHostFree(h->drained_host);
   if (h->d_trace) (void)hipFree(h->d_trace);
   for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -314,11 +325,17 @@ int dgsqp_launch_staged(dgsqp_handle_t h) {
     }
     trace = h->d_trace;
   }
-  hipLaunchKernelGGL(dg_solve_kernel, dim3(grid), dim3(DG_BLOCK), h->lds_bytes, h->stream, h->dp, h->B, h->d_x0, h->d_uws, O, h->ws, h->ticket, trace, h->trace_cap);
+  *h->drained_host = 0u;
+  hipLaunchKernelGGL(dg_solve_kernel, dim3(grid), dim3(DG_BLOCK), h->lds_bytes, h->stream, h->dp, h->B, h->d_x0, h->d_uws, O, h->ws, h->ticket, trace, h->trace_cap, h->drained_dev);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
   h->launched_grid = grid;
   return DGSQP_OK;
+}
+
+int dgsqp_draining(dgsqp_handle_t h) {
+  if (!h) return 1;
+  return h->launched_grid == 0 || __atomic_load_n(h->drained_host, __ATOMIC_RELAXED) != 0u;
 }
 
 int dgsqp_wait(dgsqp_handle_t h, dgsqp_timing_t* tm) {

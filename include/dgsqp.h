@@ -201,6 +201,10 @@ int dgsqp_solve_staged(dgsqp_handle_t h, dgsqp_timing_t* timing);
    over the compute units as the earlier launch drains its slowest scenarios. */
 int dgsqp_launch_staged(dgsqp_handle_t h);
 int dgsqp_wait(dgsqp_handle_t h, dgsqp_timing_t* timing);
+/* 1 once the handle's last launch has handed out its last scenario (it only drains from then on, compute units are
+   becoming free) or when nothing is in flight; 0 while scenarios are still queued.  Polled by bench.py to start the next
+   independent batch on another handle at exactly that moment. */
+int dgsqp_draining(dgsqp_handle_t h);
 int dgsqp_fetch_results(dgsqp_handle_t h, double* u_out, double* l_out, double* x_out,
                         int32_t* status, int32_t* iters, int32_t* qp_solves, double* cond,
                         double* cost);

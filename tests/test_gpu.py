@@ -366,6 +366,7 @@ def test_concurrent_launches_on_two_handles(games):
     assert lib.dgsqp_launch_staged(sa._h) == 0 and lib.dgsqp_launch_staged(sb._h) == 0      # both in flight
     tm = _ffi.TimingT()
     assert lib.dgsqp_wait(sb._h, C.byref(tm)) == 0 and tm.kernel_ms > 0
+    assert lib.dgsqp_draining(sb._h) == 1          # nothing queued any more on a finished launch
     assert lib.dgsqp_wait(sa._h, C.byref(tm)) == 0 and tm.kernel_ms > 0
     for s_, ref in ((sa, ref_a), (sb, ref_b)):
         B = ref['u'].shape[0]
