@@ -3,8 +3,11 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "dgsqp_solve.h"
@@ -129,6 +132,15 @@ dg_qp_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// Overlapping launches on several handles (bench.py --pipeline) need one hardware queue per stream; the HIP runtime creates
+// 4 by default and reads this variable when it initialises (first HIP call), so set it when the library is loaded unless
+// the user already chose a value.
+namespace {
+struct DgEnvInit {
+  DgEnvInit() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+} dg_env_init;
+}  // namespace
+
 struct dgsqp_solver {
   int device = 0;
   DgProb hp;

@@ -453,3 +453,18 @@ def test_model_and_integrator_variants(oracle, kind, method, msub, over):
         o = oracle.evaluate(P, x0[b], u[b], l[b], 1)
         for key in ('x', 'q', 'g', 'G', 'Q'):
             assert rel(ev[key][b], o[key]) < 1e-11, (key, b)
+
+
+def test_large_batch_equals_small_batches(games):
+    """Every scenario of a 3,500-scenario launch (14 per workgroup, dynamic ticket order) comes out exactly as in a small
+    launch: no state leaks between the scenarios a workgroup processes (warm-started active sets, trajectory tags)."""
+    from dgsqp_amd.montecarlo import sample_scenarios
+    from dgsqp_amd.solver import DGSQP
+    g, P, par = games['kb_curve_N10']
+    s = DGSQP(*g.solver_args(), print_method=None)
+    x0, u = sample_scenarios(g, 3500, seed=13)
+    big = s.solve_batch(x0, u)
+    for lo in (0, 1024, 2900):
+        small = s.solve_batch(x0[lo:lo + 600], u[lo:lo + 600])
+        for key in ('status', 'num_iters', 'qp_solves', 'u', 'l', 'x', 'cond', 'cost'):
+            assert np.array_equal(big[key][lo:lo + 600], small[key]), (key, lo)
