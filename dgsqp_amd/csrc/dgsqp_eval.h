@@ -117,11 +117,13 @@ __device__ inline void dyn_fc_pair(DynLane& Z, const double* q, double ua, doubl
   const double c = Z.curv;
   const double psit = (q[6] + (sbar - q[6] - Z.lo)) * Z.slope + Z.ang0;
   const double vyf = __builtin_fma(w, Z.L_f, vy);
-  // role 0: front axle and e_psi ; role 1: rear axle and e_psi + psi_t
-  double ay_, ax_, add;
-  if (Z.role == 0) {
-    if (Z.simple_slip) { ay_ = vyf; ax_ = vx; add = us; } else { ay_ = vyf * cd - vx * sd; ax_ = vx * cd + vyf * sd; add = 0.0; }
-  } else { ay_ = __builtin_fma(-w, Z.L_r, vy); ax_ = vx; add = 0.0; }
+  // role 0: front axle and e_psi ; role 1: rear axle and e_psi + psi_t.  Even / odd lanes differ here, so the arms are
+  // evaluated for everybody and selected (a divergent branch costs more than the four extra multiplies)
+  const bool front = Z.role == 0, rot = front && !Z.simple_slip;
+  const double yF = __builtin_fma(vyf, cd, -vx * sd), xF = __builtin_fma(vx, cd, vyf * sd);
+  const double ay_ = rot ? yF : (front ? vyf : __builtin_fma(-w, Z.L_r, vy));
+  const double ax_ = rot ? xF : vx;
+  const double add = (front && Z.simple_slip) ? us : 0.0;
   const double alpha = add - dev_atan2(ay_, ax_);
   double F;
   if (Z.pacejka) {
@@ -132,7 +134,7 @@ __device__ inline void dyn_fc_pair(DynLane& Z, const double* q, double ua, doubl
     F = alpha * Z.lin;
   }
   double sa, ca;
-  dev_sincos(Z.role == 0 ? q[5] : q[5] + psit, sa, ca);
+  dev_sincos(front ? q[5] : q[5] + psit, sa, ca);
   // exchange inside the pair: quad_perm [0,0,2,2] takes the even lane's value, [1,1,3,3] the odd lane's
   const double fyf = dpp_f64<0xA0>(F), fyr = dpp_f64<0xF5>(F);
   const double se = dpp_f64<0xA0>(sa), ce = dpp_f64<0xA0>(ca), st = dpp_f64<0xF5>(sa), ct = dpp_f64<0xF5>(ca);

@@ -468,3 +468,28 @@ def test_large_batch_equals_small_batches(games):
         small = s.solve_batch(x0[lo:lo + 600], u[lo:lo + 600])
         for key in ('status', 'num_iters', 'qp_solves', 'u', 'l', 'x', 'cond', 'cost'):
             assert np.array_equal(big[key][lo:lo + 600], small[key]), (key, lo)
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the contract's keys, the roofline object and the CPU baseline (tiny batch)."""
+    import json
+    import pathlib
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, str(root / 'bench.py'), '--workload', 'kb_curve_N25', '--batch', '64', '--steps', '3',
+                          '--warmup', '1', '--cpu-sample', '2', '--pipeline', '2'], capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in d, key
+    assert d['unit'] == 'scenarios/s' and d['n_gpus'] == 1 and d['steps'] == 3 and d['scaling'] == 'weak' and d['dtype'] == 'f64'
+    assert d['config']['workload'] == 'kb_curve_N25' and d['config']['batch_per_gpu'] == 64
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-15 and r['kernel_ms'] > 0
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['value'] > 0 and c['cores'] >= 1
+    assert abs(d['value'] - 64 * 3 / (d['ms_per_step'] * 3e-3)) < 1e-6 * d['value']
