@@ -122,7 +122,8 @@ def main():
         # start the next batch when the previous launch has handed out its last scenario (its workgroups begin to exit and
         # free compute units) -- not earlier, or two launches would share the GPU from the start and both grow tails
         if last is not None and P > 1:
-            while not lib.dgsqp_draining(handles[last]):
+            deadline = time.perf_counter() + 600.0           # never spin forever on a launch that died
+            while not lib.dgsqp_draining(handles[last]) and time.perf_counter() < deadline:
                 time.sleep(0.0002)
         if all(busy):
             wait(order[0])
