@@ -200,23 +200,28 @@ __device__ inline double fast_rcp(double x) {
   e = __builtin_fma(-x, r, 1.0);
   return __builtin_fma(r, e, r);
 }
+// p * z + C with the coefficient as a scalar operand of a three-operand v_fma_f64.  Left to itself the compiler keeps the
+// coefficients in VGPRs and emits v_mov_b64 + v_fmac_f64 (destructive) for every Horner step.
+__device__ inline double horner(double p, double z, double C) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(z), "s"(C));
+  return r;
+}
 __device__ inline void dev_sincos(double x, double& so, double& co) {
   const double k = __builtin_rint(x * 0.63661977236758138);
   double r = __builtin_fma(-k, 1.5707963267948966, x);
   r = __builtin_fma(-k, 6.123233995736766e-17, r);
   const double z = r * r;
-  double ps = 1.58969099521155010221e-10;
-  ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
-  ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
-  ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
-  ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
-  ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
-  double pc = -1.13596475577881948265e-11;
-  pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
-  pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
-  pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
-  pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
-  pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+  double ps = horner(1.58969099521155010221e-10, z, -2.50507602534068634195e-08);
+  ps = horner(ps, z, 2.75573137070700676789e-06);
+  ps = horner(ps, z, -1.98412698298579493134e-04);
+  ps = horner(ps, z, 8.33333333332248946124e-03);
+  ps = horner(ps, z, -1.66666666666666324348e-01);
+  double pc = horner(-1.13596475577881948265e-11, z, 2.08757232129817482790e-09);
+  pc = horner(pc, z, -2.75573143513906633035e-07);
+  pc = horner(pc, z, 2.48015872894767294178e-05);
+  pc = horner(pc, z, -1.38888888888741095749e-03);
+  pc = horner(pc, z, 4.16666666666666019037e-02);
   const double sn = __builtin_fma(r * z, ps, r);
   const double cs = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
   const int q = (int)k;
@@ -227,26 +232,31 @@ __device__ inline void dev_sincos(double x, double& so, double& co) {
 __device__ inline double dev_atan2(double y, double x) {
   const double ay = __builtin_fabs(y), ax = __builtin_fabs(x);
   const double y16 = 16.0 * ay;
-  // argument reduction atan(t) = atan(k) + atan((t - k)/(1 + k t)), k in {0, 1/2, 1, 3/2, inf}, folded into ONE division
-  double num = ay, den = ax, hi = 0.0, lo = 0.0;
-  if (y16 >= 7.0 * ax) { num = 2.0 * ay - ax; den = __builtin_fma(2.0, ax, ay); hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17; }
-  if (y16 >= 11.0 * ax) { num = ay - ax; den = ax + ay; hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17; }
-  if (y16 >= 19.0 * ax) { num = __builtin_fma(-1.5, ax, ay); den = __builtin_fma(1.5, ay, ax); hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17; }
-  if (y16 >= 39.0 * ax) { num = -ax; den = ay; hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17; }
+  // argument reduction atan(t) = atan(k) + atan((t - k)/(1 + k t)), k in {0, 1/2, 1, 3/2, inf}, folded into ONE division.
+  // The range index is computed arithmetically (no divergent blocks): rid = number of thresholds 7/16, 11/16, 19/16, 39/16 <= t
+  const int rid = (int)(y16 >= 7.0 * ax) + (int)(y16 >= 11.0 * ax) + (int)(y16 >= 19.0 * ax) + (int)(y16 >= 39.0 * ax);
+  const bool big = rid == 4;
+  const double kk = 0.5 * (double)(big ? 0 : rid);
+  double num = big ? -ax : __builtin_fma(-kk, ax, ay);
+  double den = big ? ay : __builtin_fma(kk, ay, ax);
+  // atan(k) high / low parts
+  double hi = rid >= 1 ? 4.63647609000806093515e-01 : 0.0, lo = rid >= 1 ? 2.26987774529616870924e-17 : 0.0;
+  hi = rid >= 2 ? 7.85398163397448278999e-01 : hi; lo = rid >= 2 ? 3.06161699786838301793e-17 : lo;
+  hi = rid >= 3 ? 9.82793723247329054082e-01 : hi; lo = rid >= 3 ? 1.39033110312309984516e-17 : lo;
+  hi = big ? 1.57079632679489655800e+00 : hi; lo = big ? 6.12323399573676603587e-17 : lo;
   den = den == 0.0 ? 1.0 : den;                 // atan2(0, 0) = 0
   const double t = num * fast_rcp(den);
   const double z = t * t;
-  double p = 1.62858201153657823623e-02;
-  p = __builtin_fma(p, z, -3.65315727442169155270e-02);
-  p = __builtin_fma(p, z, 4.97687799461593236017e-02);
-  p = __builtin_fma(p, z, -5.83357013379057348645e-02);
-  p = __builtin_fma(p, z, 6.66107313738753120669e-02);
-  p = __builtin_fma(p, z, -7.69187620504482999495e-02);
-  p = __builtin_fma(p, z, 9.09088713343650656196e-02);
-  p = __builtin_fma(p, z, -1.11111104054623557880e-01);
-  p = __builtin_fma(p, z, 1.42857142725034663711e-01);
-  p = __builtin_fma(p, z, -1.99999999998764832476e-01);
-  p = __builtin_fma(p, z, 3.33333333333329318027e-01);
+  double p = horner(1.62858201153657823623e-02, z, -3.65315727442169155270e-02);
+  p = horner(p, z, 4.97687799461593236017e-02);
+  p = horner(p, z, -5.83357013379057348645e-02);
+  p = horner(p, z, 6.66107313738753120669e-02);
+  p = horner(p, z, -7.69187620504482999495e-02);
+  p = horner(p, z, 9.09088713343650656196e-02);
+  p = horner(p, z, -1.11111104054623557880e-01);
+  p = horner(p, z, 1.42857142725034663711e-01);
+  p = horner(p, z, -1.99999999998764832476e-01);
+  p = horner(p, z, 3.33333333333329318027e-01);
   double r = hi + ((lo - t * z * p) + t);
   r = x < 0.0 ? (3.141592653589793 - r) + 1.2246467991473532e-16 : r;
   return y < 0.0 ? -r : r;
