@@ -65,6 +65,11 @@ __device__ inline void dev_load_tables() {
     const unsigned long long* sk = (const unsigned long long*)D.dtask;
     for (int t = threadIdx.x; t < D.ntask; t += DG_BLOCK) tk[t] = sk[t];
   }
+  if (threadIdx.x == 0) {
+    lptr ta = LP(D.L.t_atan);
+    ta[0] = 0.0; ta[1] = 4.63647609000806093515e-01; ta[2] = 7.85398163397448278999e-01; ta[3] = 9.82793723247329054082e-01; ta[4] = 1.57079632679489655800e+00;
+    ta[5] = 0.0; ta[6] = 2.26987774529616870924e-17; ta[7] = 3.06161699786838301793e-17; ta[8] = 1.39033110312309984516e-17; ta[9] = 6.12323399573676603587e-17;
+  }
   lptr tt = LP(D.L.t_track);
   constexpr int S1 = DGSQP_MAX_SEGS + 1;
   for (int i = threadIdx.x; i < S1; i += DG_BLOCK) {
@@ -225,27 +230,13 @@ __device__ inline void dev_sincos(double x, double& so, double& co) {
   const double sn = __builtin_fma(r * z, ps, r);
   const double cs = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
   const int q = (int)k;
-  double s1 = (q & 1) ? cs : sn, c1 = (q & 1) ? sn : cs;
-  so = (q & 2) ? -s1 : s1;
-  co = ((q + 1) & 2) ? -c1 : c1;
+  const double s1 = (q & 1) ? cs : sn, c1 = (q & 1) ? sn : cs;
+  // quadrant signs by flipping the sign bit: sin negative for q = 2, 3 ; cos negative for q = 1, 2
+  so = __hiloint2double(__double2hiint(s1) ^ ((q & 2) << 30), __double2loint(s1));
+  co = __hiloint2double(__double2hiint(c1) ^ (((q + 1) & 2) << 30), __double2loint(c1));
 }
-__device__ inline double dev_atan2(double y, double x) {
-  const double ay = __builtin_fabs(y), ax = __builtin_fabs(x);
-  const double y16 = 16.0 * ay;
-  // argument reduction atan(t) = atan(k) + atan((t - k)/(1 + k t)), k in {0, 1/2, 1, 3/2, inf}, folded into ONE division.
-  // The range index is computed arithmetically (no divergent blocks): rid = number of thresholds 7/16, 11/16, 19/16, 39/16 <= t
-  const int rid = (int)(y16 >= 7.0 * ax) + (int)(y16 >= 11.0 * ax) + (int)(y16 >= 19.0 * ax) + (int)(y16 >= 39.0 * ax);
-  const bool big = rid == 4;
-  const double kk = 0.5 * (double)(big ? 0 : rid);
-  double num = big ? -ax : __builtin_fma(-kk, ax, ay);
-  double den = big ? ay : __builtin_fma(kk, ay, ax);
-  // atan(k) high / low parts
-  double hi = rid >= 1 ? 4.63647609000806093515e-01 : 0.0, lo = rid >= 1 ? 2.26987774529616870924e-17 : 0.0;
-  hi = rid >= 2 ? 7.85398163397448278999e-01 : hi; lo = rid >= 2 ? 3.06161699786838301793e-17 : lo;
-  hi = rid >= 3 ? 9.82793723247329054082e-01 : hi; lo = rid >= 3 ? 1.39033110312309984516e-17 : lo;
-  hi = big ? 1.57079632679489655800e+00 : hi; lo = big ? 6.12323399573676603587e-17 : lo;
-  den = den == 0.0 ? 1.0 : den;                 // atan2(0, 0) = 0
-  const double t = num * fast_rcp(den);
+// atan polynomial on the reduced argument t (|t| <= 7/16): t - t^3 P(t^2)
+__device__ inline double atan_poly_tail(double t, double hi, double lo) {
   const double z = t * t;
   double p = horner(1.62858201153657823623e-02, z, -3.65315727442169155270e-02);
   p = horner(p, z, 4.97687799461593236017e-02);
@@ -257,11 +248,38 @@ __device__ inline double dev_atan2(double y, double x) {
   p = horner(p, z, 1.42857142725034663711e-01);
   p = horner(p, z, -1.99999999998764832476e-01);
   p = horner(p, z, 3.33333333333329318027e-01);
-  double r = hi + ((lo - t * z * p) + t);
+  return hi + ((lo - t * z * p) + t);
+}
+// Argument reduction atan(t) = atan(k) + atan((t - k)/(1 + k t)), k in {0, 1/2, 1, 3/2, inf}, folded into ONE division.  The
+// range index is computed arithmetically (rid = number of thresholds 7/16, 11/16, 19/16, 39/16 <= t, no divergent blocks)
+// and atan(k) comes from a 10-entry LDS table (dev_load_tables).
+__device__ inline double dev_atan2(double y, double x) {
+  const double ay = __builtin_fabs(y), ax = __builtin_fabs(x);
+  const double y16 = 16.0 * ay;
+  const int rid = (int)(y16 >= 7.0 * ax) + (int)(y16 >= 11.0 * ax) + (int)(y16 >= 19.0 * ax) + (int)(y16 >= 39.0 * ax);
+  clptr ta = LP(dg_prob.L.t_atan);
+  const double hi = ta[rid], lo = ta[5 + rid];
+  const bool big = rid == 4;
+  const double kk = 0.5 * (double)(big ? 0 : rid);
+  const double num = big ? -ax : __builtin_fma(-kk, ax, ay);
+  double den = big ? ay : __builtin_fma(kk, ay, ax);
+  den = den == 0.0 ? 1.0 : den;                 // atan2(0, 0) = 0
+  double r = atan_poly_tail(num * fast_rcp(den), hi, lo);
   r = x < 0.0 ? (3.141592653589793 - r) + 1.2246467991473532e-16 : r;
   return y < 0.0 ? -r : r;
 }
-__device__ inline double dev_atan(double x) { return dev_atan2(x, 1.0); }
+__device__ inline double dev_atan(double x) {
+  const double ay = __builtin_fabs(x);
+  const int rid = (int)(ay >= 0.4375) + (int)(ay >= 0.6875) + (int)(ay >= 1.1875) + (int)(ay >= 2.4375);
+  clptr ta = LP(dg_prob.L.t_atan);
+  const double hi = ta[rid], lo = ta[5 + rid];
+  const bool big = rid == 4;
+  const double kk = 0.5 * (double)(big ? 0 : rid);
+  const double num = big ? -1.0 : ay - kk;
+  const double den = big ? ay : __builtin_fma(kk, ay, 1.0);      // >= 1
+  const double r = atan_poly_tail(num * fast_rcp(den), hi, lo);
+  return x < 0.0 ? -r : r;
+}
 __device__ inline double dev_tan(double x) { double s, c; dev_sincos(x, s, c); return s * fast_rcp(c); }
 
 // ------------------------------------------------------------------------------------------------

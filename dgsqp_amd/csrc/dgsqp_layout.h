@@ -53,6 +53,7 @@ struct DgLds {
   int t_rows, t_dense;  // LDS copies of the row / dense-gradient tables (8 and 16 bytes per entry)
   int t_task;           // LDS copy of the dense dot-product task table (8 bytes per entry)
   int t_track;          // LDS copy of the track tables: seg_s[17], seg_curv[16], seg_ang[17], slope[16]
+  int t_atan;           // atan(k) for k = 0, 1/2, 1, 3/2, inf: 5 high parts, 5 low parts
   int scr;  // start of phase scratch
   // EVAL scratch (absolute offsets)
   int e_x, e_ue, e_A[DGSQP_MAX_AGENTS], e_B[DGSQP_MAX_AGENTS], e_dJ, e_lam, e_Dxs, e_K, e_xs, e_xs2;
@@ -218,7 +219,7 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   L.gd = take(D.ngd); L.yd = take(nd); L.red = take(64); L.scal = take(64);
   L.w_prev = take((n + 2) / 2 + 1);   // final active set of the previous QP of this scenario (warm start)
   L.w_prev = take((n + 2) / 2 + 1); L.w_prevlam = take(n + 1);
-  L.t_rows = take(nc); L.t_dense = take(2 * nd); L.t_task = take(D.ntask); L.t_track = take(4 * (DGSQP_MAX_SEGS + 1));
+  L.t_rows = take(nc); L.t_dense = take(2 * nd); L.t_task = take(D.ntask); L.t_track = take(4 * (DGSQP_MAX_SEGS + 1)); L.t_atan = take(10);
   L.scr = o;
   // EVAL
   o = L.scr;
