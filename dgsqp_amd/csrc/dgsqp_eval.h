@@ -715,21 +715,19 @@ __device__ __noinline__ void dev_hessian_row(const Ctx& c, int row, int a, int k
 // Mathematically identical to the reference's backward DP (DGSQP.py:679-727, :828-877, f_Q :920-934) and to its
 // own f_Duu_L (:937-941); here all N*n_u rows are independent lanes with 25 uniform steps each.
 // ------------------------------------------------------------------------------------------------
-__device__ __noinline__ void dev_hessian_adjoint(const Ctx& c) {
+// Costates of every agent's Lagrangian L^a = J^a + lm^T C along the current trajectory (multipliers lm in LDS):
+//   lam^a_N = L^a_x,N ,  lam^a_k = L^a_x,k + A_k^T lam^a_{k+1}     (joint n_q vectors, e_lam[a][k][.])
+// Stage 0 also leaves the compact state-Hessian columns (e_K) the second-order pass needs.  Used by the game Hessian
+// and by the merit of a line-search trial point (gradient of the Lagrangians without forming G).
+__device__ __noinline__ void dev_costates(const Ctx& c, clptr lm) {
   const DgProb& D = dg_prob;
   const DgLds& L = D.L;
   lptr lds = LP(0);
-  const int nq = D.nq, n = D.n, N = D.N, M = D.M;
+  const int nq = D.nq, N = D.N, M = D.M;
   clptr x = lds + L.e_x;
-  clptr lm = lds + L.l;
   lptr lam = lds + L.e_lam;   // [a][k][nq]
   lptr Dxs = lds + L.e_Dxs;   // [a][k][nq]   d/dx_k of (stage cost a + sum_r l_r c_r)
   lptr Kc = lds + L.e_K;      // [a][k][b][5] columns (block a) of the state Hessian: Kxx, Kxy, Kyy on positions, k_ey, k_s
-  gptr Hg = c.ws + D.ws_H;    // [a][k][b][MAXEFF*MAXEFF]
-  gptr tang = c.ws + D.ws_tang;  // [t][i][lane]
-  gptr Qg = c.ws + D.ws_q;
-  const gptr T2base = c.ws + D.ws_t2;
-  constexpr int EE = DG_MAXEFF * DG_MAXEFF;
   // ---- 0. first / second state derivatives of every agent's stage Lagrangian
   for (int it = TID; it < M * (N + 1); it += NT) {
     const int a = it / (N + 1), k = it % (N + 1);
@@ -822,6 +820,23 @@ __device__ __noinline__ void dev_hessian_adjoint(const Ctx& c) {
     }
   }
   __syncthreads();
+}
+
+__device__ __noinline__ void dev_hessian_adjoint(const Ctx& c) {
+  const DgProb& D = dg_prob;
+  const DgLds& L = D.L;
+  lptr lds = LP(0);
+  const int nq = D.nq, n = D.n, N = D.N, M = D.M;
+  clptr x = lds + L.e_x;
+  lptr lam = lds + L.e_lam;   // [a][k][nq]
+  lptr Dxs = lds + L.e_Dxs;   // [a][k][nq]   d/dx_k of (stage cost a + sum_r l_r c_r)
+  lptr Kc = lds + L.e_K;      // [a][k][b][5] columns (block a) of the state Hessian: Kxx, Kxy, Kyy on positions, k_ey, k_s
+  gptr Hg = c.ws + D.ws_H;    // [a][k][b][MAXEFF*MAXEFF]
+  gptr tang = c.ws + D.ws_tang;  // [t][i][lane]
+  gptr Qg = c.ws + D.ws_q;
+  const gptr T2base = c.ws + D.ws_t2;
+  constexpr int EE = DG_MAXEFF * DG_MAXEFF;
+  dev_costates(c, lds + L.l);
   // ---- 2. H[a][k][b] = sum_o lam^a_{k+1}[b,o] * Hessian of f^b_{k,o} in effective variables (interpolated from the
   //         e_i / e_i+e_j Taylor coefficients: H_ii = 2 c_i, H_ij = c_ij - c_i - c_j)
   // (a) cv[a][k][b][dir] = sum_o lam^a_{k+1}[b,o] T2[b][k][o][dir], once per direction (coalesced over dir), kept in the
@@ -936,6 +951,12 @@ __device__ inline void dev_evaluate_derivs(const Ctx& c, bool hessian) {
     PROF_END(PH_DP, pt_);
   }
   __syncthreads();
+}
+// stage 2 of a line-search TRIAL point: only the dynamics Jacobians A_k, B_k (the merit gets the Lagrangian gradients from
+// a costate sweep, dev_phi_trial; q and the packed G are NOT refreshed -- every accepted point is re-linearised in full)
+__device__ inline void dev_evaluate_trial_derivs(const Ctx& c) {
+  lptr ue = LP(dg_prob.L.e_ue);
+  PROF_BEGIN(pt_); dev_dyn_derivs<1>(c, ue); PROF_END(PH_DERIV1, pt_);
 }
 __device__ inline void dev_evaluate(const Ctx& c, clptr usrc, double alpha, clptr dusrc, bool hessian, clptr xsrc = nullptr) {
   dev_evaluate_point(c, usrc, alpha, dusrc, xsrc);

@@ -860,8 +860,9 @@ __device__ __noinline__ void dev_step_scalars(const Ctx& c, LinScal& S) {
   S.dphi = S.dstat;
   PROF_END(PH_MERIT, pt_m);
 }
-// merit of a trial point: current (q, g, G) in LDS belong to the trial u; multipliers l + alpha (lhat - l)
-__device__ __noinline__ double dev_phi_trial(const Ctx& c, double alpha, double sum_s, double mu) {
+// merit of a trial point through q and the packed G (fallback when the packed-G area is too small to hold the trial
+// multipliers: games with hardly any state / obstacle rows): current (q, g, G) in LDS belong to the trial u
+__device__ __noinline__ double dev_phi_trial_dense(const Ctx& c, double alpha, double sum_s, double mu) {
   const DgProb& D = dg_prob;
   const DgLds& L = D.L;
   lptr lds = LP(0);
@@ -886,6 +887,70 @@ __device__ __noinline__ double dev_phi_trial(const Ctx& c, double alpha, double 
   if (D.par.merit_function == DGSQP_MERIT_STAT_L1) phi += mu * (sg - sum_s);
   PROF_END(PH_MERIT, pt_m);
   return phi;
+}
+
+// Merit of a trial point u + alpha du with multipliers l + alpha (lhat - l):  1/2 |d|^2 + 1/2 (l'g)^2 + mu sum(g - s),
+// d = q + G' l = stacked gradients of the agents' Lagrangians w.r.t. their own inputs.  d comes from one costate sweep
+// per agent at the trial trajectory (x, A_k, B_k and g are current; q and the packed G are not needed):
+//   d_(a,t,j) = dJ^a/du direct + box / rate multipliers + B_t^T lam^a_{t+1}
+// The trial multipliers and d live in the packed-G area, which is dead until the next full linearisation.
+__device__ __noinline__ double dev_phi_trial_adjoint(const Ctx& c, double alpha, double sum_s, double mu) {
+  const DgProb& D = dg_prob;
+  const DgLds& L = D.L;
+  lptr lds = LP(0);
+  lds_d* lt = lds + L.gd;
+  lds_d* red = lds + L.red;
+  const lds_d *l = lds + L.l, *lhat = lds + L.o_lhat, *g = lds + L.g;
+  clptr ue = lds + L.e_ue;
+  __syncthreads();
+  PROF_BEGIN(pt_m);
+  double lg = 0, sg = 0;
+  for (int r = TID; r < D.nc; r += NT) {
+    const double v = l[r] + alpha * (lhat[r] - l[r]);
+    lt[r] = v;
+    lg += v * g[r];
+    sg += g[r];
+  }
+  __syncthreads();
+  dev_costates(c, lt);
+  clptr lam = lds + L.e_lam;
+  double dd = 0;
+  for (int i = TID; i < D.n; i += NT) {
+    const int a = i / (D.N * DGSQP_NUA), rem = i % (D.N * DGSQP_NUA), t = rem / DGSQP_NUA, j = rem % DGSQP_NUA;
+    const dgsqp_agent_t& ag = D.P.agents[a];
+    const double uk = ue[i], um = t > 0 ? ue[i - DGSQP_NUA] : 0.0;
+    double s = ag.w_in[j] * uk + ag.w_rate[j] * (uk - um);
+    if (t + 1 < D.N) s -= ag.w_rate[j] * (ue[i + DGSQP_NUA] - uk);
+    int r;
+    if ((r = D.r_in_ub[a][t][j]) >= 0) s += lt[r];
+    if ((r = D.r_in_lb[a][t][j]) >= 0) s -= lt[r];
+    if ((r = D.r_rate_ub[a][t][j]) >= 0) s += lt[r];
+    if ((r = D.r_rate_lb[a][t][j]) >= 0) s -= lt[r];
+    if (t + 1 < D.N) {
+      if ((r = D.r_rate_ub[a][t + 1][j]) >= 0) s -= lt[r];
+      if ((r = D.r_rate_lb[a][t + 1][j]) >= 0) s += lt[r];
+    }
+    const int nqa = D.nqa[a];
+    clptr B = lds + L.e_B[a] + t * nqa * DGSQP_NUA;
+    clptr lk = lam + (a * (D.N + 1) + t + 1) * D.nq + D.qoff[a];
+    for (int m = 0; m < nqa; m++) s += B[m * DGSQP_NUA + j] * lk[m];
+    dd += s * s;
+  }
+  dd = block_sum(dd, red); lg = block_sum(lg, red); sg = block_sum(sg, red);
+  double phi = 0.5 * (dd + lg * lg);
+  if (D.par.merit_function == DGSQP_MERIT_STAT_L1) phi += mu * (sg - sum_s);
+  PROF_END(PH_MERIT, pt_m);
+  return phi;
+}
+
+// derivatives + merit of the trial point prepared by dev_evaluate_point
+__device__ inline double dev_trial_merit(const Ctx& c, double alpha, double sum_s, double mu) {
+  if (dg_prob.ngd >= dg_prob.nc) {
+    dev_evaluate_trial_derivs(c);
+    return dev_phi_trial_adjoint(c, alpha, sum_s, mu);
+  }
+  dev_evaluate_derivs(c, false);
+  return dev_phi_trial_dense(c, alpha, sum_s, mu);
 }
 
 // _line_search_3 (DGSQP.py:1057-1081) from the base (u, du, l, lhat) held in LDS.  On return u and l hold
@@ -926,8 +991,7 @@ __device__ inline double dev_line_search(const Ctx& c, double mu, double phi, do
       PROF_COUNT(PH_C_TRIALS, lb > bound + 1e-9 * (fabs(bound) + fabs(lb)) ? 1 : 0);
       if (lb > bound + 1e-9 * (fabs(bound) + fabs(lb))) { alpha *= D.par.tau; continue; }
     }
-    dev_evaluate_derivs(c, false);
-    phit = dev_phi_trial(c, alpha, S0 + alpha * S1, mu);
+    phit = dev_trial_merit(c, alpha, S0 + alpha * S1, mu);
     dev_tr(c, 30, alpha); dev_tr(c, 31, phit);
     if (phit <= phi + D.par.beta * alpha * dphi) break;
     if (i + 1 < D.par.line_search_iters) alpha *= D.par.tau;
@@ -998,8 +1062,8 @@ __device__ inline int dev_watchdog(const Ctx& c, double mu, const LinScal& Sk) {
   int nqp = 0;
   dev_save_base(c);
   // relaxed (full) step
-  dev_evaluate(c, lds + L.u, 1.0, lds + L.o_du, false);
-  const double phi1 = dev_phi_trial(c, 1.0, Sk.S0 + Sk.S1, mu);
+  dev_evaluate_point(c, lds + L.u, 1.0, lds + L.o_du);
+  const double phi1 = dev_trial_merit(c, 1.0, Sk.S0 + Sk.S1, mu);
   dev_tr(c, 20, phi1);
   if (phi1 <= phi_k + beta * dphi_k) { dev_take_full_step(c); return 0; }
   dev_take_full_step(c);  // (u_t, l_t) = (u_k + du_k, l_k + dl_k)
@@ -1011,8 +1075,8 @@ __device__ inline int dev_watchdog(const Ctx& c, double mu, const LinScal& Sk) {
     nqp++;
     if (flag != 0) { fail = true; break; }
     dev_step_scalars(c, S);
-    dev_evaluate(c, lds + L.u, 1.0, lds + L.o_du, false);
-    phi_n = dev_phi_trial(c, 1.0, S.S0 + S.S1, mu);
+    dev_evaluate_point(c, lds + L.u, 1.0, lds + L.o_du);
+    phi_n = dev_trial_merit(c, 1.0, S.S0 + S.S1, mu);
     dev_tr(c, 21, phi_n);
     if (phi_n > 1e6) break;                                   // merit_max; (u_t, l_t) not advanced
     if (phi_n <= phi_k + beta * dphi_k) { dev_take_full_step(c); return nqp; }
