@@ -155,15 +155,17 @@ def main():
 
     if rank == 0:
         # HBM traffic from PMC counters is collected offline in separate rocprofv3 --pmc passes (gpurun refuses mixed runs)
-        traffic = None
+        # and so is the fp64 instruction mix (SQ counters, profiles/*_pmc_sq_*.json) behind the vector-ALU figure below
+        traffic, flop_per_solve = None, None
         try:
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_*.json'))):
                 pm = json.load(open(f))
                 if pm.get('workload') == args.workload and pm.get('batch_per_gpu') == B:
-                    traffic = pm['traffic_bytes_per_launch']
+                    traffic = pm.get('traffic_bytes_per_launch', traffic)
+                    flop_per_solve = pm.get('fp64_flop_per_solve_upper_bound', flop_per_solve)
         except Exception:
-            traffic = None
+            pass
         total = B * world * args.steps
         value = total / elapsed
         bytes_per_launch = algorithmic_bytes_per_solve(d) * B
@@ -186,6 +188,12 @@ def main():
                          'traffic': traffic, 'kernel': 'dg_solve_kernel', 'kernel_ms': kms,
                          'algorithmic_bytes_per_solve': algorithmic_bytes_per_solve(d)},
         }
+        if flop_per_solve is not None:
+            # second, honest roof of this path: vector fp64 issue (256 CUs x 4 SIMDs x 32 lanes x 2 flop x 2.4 GHz = 78.6 TF/s).
+            # flop per solve from the offline SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 pass (an upper bound: masked lanes count)
+            line['valu_fp64'] = {'achieved_upper_bound': flop_per_solve * value / world / 1e12, 'peak': 78.6, 'unit': 'TFLOP/s',
+                                 'frac_upper_bound': flop_per_solve * value / world / 1e12 / 78.6,
+                                 'flop_per_solve_upper_bound': flop_per_solve}
         if world == 1 and args.cpu_sample > 0:
             from oracle import oracle            # checker/baseline only: the CPU restatement, NOT CasADi+OSQP
             oracle.build()

@@ -11,11 +11,16 @@ import pathlib
 MAX_AGENTS = 4
 MAX_SEGS = 16
 MAX_NQA = 8
+MAX_LANES = 2
 NUA = 2
 
 STATUS_MSG = ['conv_abs_tol', 'conv_rel_tol', 'max_it', 'diverged', 'qp_fail', 'time_limit']
 
 dbl2 = C.c_double * NUA
+
+
+class LaneT(C.Structure):
+    _fields_ = [('brk', C.c_double), ('n_lo', dbl2), ('n_hi', dbl2), ('anchor', dbl2), ('r', C.c_double)]
 
 
 class AgentT(C.Structure):
@@ -32,6 +37,8 @@ class AgentT(C.Structure):
         ('rate_ub', dbl2), ('rate_lb', dbl2), ('in_ub', dbl2), ('in_lb', dbl2),
         ('st_ub', C.c_double * MAX_NQA), ('st_lb', C.c_double * MAX_NQA),
         ('radius', C.c_double),
+        ('w_goal', C.c_double * MAX_NQA), ('goal', C.c_double * MAX_NQA), ('goal_term_mult', C.c_double),
+        ('n_lane', C.c_int32), ('_pad2', C.c_int32), ('lane', LaneT * MAX_LANES),
     ]
 
 

@@ -19,7 +19,7 @@
 #define DG_NH (DG_BLOCK / 128)  // row-groups of the register-resident matrix slices (thread = column x row-group)
 #define DG_LDS_LIMIT 163840
 
-enum { DG_R_OBS = 0, DG_R_RATE_UB, DG_R_RATE_LB, DG_R_IN_UB, DG_R_IN_LB, DG_R_ST_UB, DG_R_ST_LB };
+enum { DG_R_OBS = 0, DG_R_RATE_UB, DG_R_RATE_LB, DG_R_IN_UB, DG_R_IN_LB, DG_R_ST_UB, DG_R_ST_LB, DG_R_LANE };
 
 struct DgRow {      // one inequality row
   int8_t type, a, b, idx, sgn;  // sgn: coefficient of the shared dense gradient (+1 / -1)
@@ -28,7 +28,7 @@ struct DgRow {      // one inequality row
 };
 
 struct DgDense {    // one distinct dense gradient: d x^a_k[idx] / du   or the obstacle gradient of pair (a,b) at stage k
-  int8_t kind;      // 0 state row, 1 obstacle
+  int8_t kind;      // 0 state row, 1 obstacle, 2 lane half-plane (idx = lane number; n_x dx/du + n_y dy/du)
   int8_t a, b, idx, k;
   uint8_t nt, t0lo, t0hi;  // its chunks in the dot-product task table: nt tasks from index t0lo + 256 t0hi
   int32_t off;      // offset in the packed Gd array; kind 0: 2k entries [t][j]; kind 1: 4k entries, agent a then agent b
@@ -74,6 +74,7 @@ struct DgProb {
   int M, N, nq, nu, n, nc, npairs, ndense, ngd, ntask;
   int nqa[DGSQP_MAX_AGENTS], qoff[DGSQP_MAX_AGENTS], sidx[DGSQP_MAX_AGENTS], eyidx[DGSQP_MAX_AGENTS];
   double inv_track_L;
+  double qp_dep_tol;   // a row whose projected curvature delta is below qp_dep_tol * (a' P a) counts as dependent on the active rows
   int uniform_nqa;
   int ls_spec;      // trial step sizes of _line_search_3 rolled out concurrently (speculation width)
   int ls_spec1;     // how many of them live in the first LDS segment (e_xs); the rest in e_xs2  // every agent uses the same vehicle model (statically indexed fast paths)
@@ -109,13 +110,22 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   int t2 = 0;
   D.uniform_nqa = 1;
   D.inv_track_L = 1.0 / P.track_L;
+  D.qp_dep_tol = 3e-15;
+  if (const char* e = getenv("DGSQP_QP_DEP_TOL")) D.qp_dep_tol = atof(e);
   for (int a = 0; a < P.M; a++) {
     if (P.agents[a].model != P.agents[0].model) D.uniform_nqa = 0;
-    const bool dyn = P.agents[a].model == DGSQP_MODEL_DYN_BICYCLE;
-    if (P.agents[a].model != DGSQP_MODEL_KIN_BICYCLE && !dyn) return "unsupported vehicle model";
-    D.nqa[a] = dyn ? 8 : 6;
+    const int mdl = P.agents[a].model;
+    if (mdl != DGSQP_MODEL_KIN_BICYCLE && mdl != DGSQP_MODEL_DYN_BICYCLE && mdl != DGSQP_MODEL_UNICYCLE) return "unsupported vehicle model";
+    D.nqa[a] = mdl == DGSQP_MODEL_DYN_BICYCLE ? 8 : (mdl == DGSQP_MODEL_UNICYCLE ? 4 : 6);
     D.qoff[a] = D.nq; D.nq += D.nqa[a];
-    D.sidx[a] = dyn ? 6 : 4; D.eyidx[a] = dyn ? 7 : 5;
+    // Frenet states s, e_y are the last two of both bicycles.  The unicycle has none: its slots (v, psi) only ever meet
+    // zero progress / competition / blocking weights, and carry the goal-tracking curvature of the last two states.
+    D.sidx[a] = D.nqa[a] - 2; D.eyidx[a] = D.nqa[a] - 1;
+    if (mdl == DGSQP_MODEL_UNICYCLE && (P.agents[a].w_prog != 0.0 || P.agents[a].w_comp != 0.0 || P.agents[a].w_block != 0.0))
+      return "progress / competition / blocking costs need a Frenet-frame model";
+    if (P.agents[a].n_lane < 0 || P.agents[a].n_lane > DGSQP_MAX_LANES) return "bad number of lane rows";
+    for (int i = 2; i < D.nqa[a] - 2; i++)
+      if (P.agents[a].w_goal[i] != 0.0) return "goal-tracking weights are supported on the positions and the last two states";
     // x, y (state 0,1) never enter fc: effective variables are the remaining states and the two inputs
     D.neff[a] = D.nqa[a];  // (nqa-2) states + 2 inputs
     for (int e = 0; e < D.nqa[a] - 2; e++) D.effvar[a][e] = e + 2;
@@ -156,6 +166,16 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
             D.r_rate_ub[a][k][j] = (int16_t)nc; if (!add_row(DG_R_RATE_UB, k, a, -1, j, 1, -1)) return "too many rows";
             D.r_rate_lb[a][k][j] = (int16_t)nc; if (!add_row(DG_R_RATE_LB, k, a, -1, j, -1, -1)) return "too many rows";
           }
+      }
+      // lane half-planes at every stage, k = 0 included (a gradient of length 0: the row only depends on x_0)
+      for (int j = 0; j < ag.n_lane; j++) {
+        if (nd >= DG_NDMAX) return "too many dense rows";
+        D.dense[nd] = DgDense{2, (int8_t)a, -1, (int8_t)j, (int8_t)k, 0, 0, 0, off, (int16_t)nc, -1};
+        off += 2 * k;
+        if (!add_row(DG_R_LANE, k, a, -1, j, 1, nd)) return "too many rows";
+        nd++;
+      }
+      if (k < P.N) {
         for (int j = 0; j < DGSQP_NUA; j++)
           if (ag.in_ub[j] < INFINITY) { D.r_in_ub[a][k][j] = (int16_t)nc; if (!add_row(DG_R_IN_UB, k, a, -1, j, 1, -1)) return "too many rows"; }
         for (int j = 0; j < DGSQP_NUA; j++)

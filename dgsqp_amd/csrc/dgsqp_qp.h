@@ -193,17 +193,28 @@ __device__ inline int qpw_add_constraint(const QpPtrs& q, QpwState& S, int lane,
     if (lane + 64 < m && r1 > 0) { const double tt = q.lam[lane + 64] / r1; if (tt < ta) { ta = tt; jd = lane + 64; } }
     wave_argmin(ta, jd);
     const double delta = app - ww;  // a_p^T (P - P A^T S^-1 A P) a_p >= 0
-    const bool indep = m < n && delta > 1e-11 * app && delta > 1e-18 * apap;   // n active rows span everything
+    // Is a_p independent of the active rows (n active rows span everything)?  delta is a difference of numbers of size app:
+    // above 1e-9 app it is trusted.  With reg = 0 the projected Hessian keeps eigenvalues of 1e-10, P spans ten decades and
+    // legitimate rows come down to delta ~ 1e-14 app, next to the rounding noise an exactly dependent row leaves.  There
+    // the explicit primal direction z = Y r - y decides: for an independent row -a_p.z reproduces delta, for a dependent
+    // one both are unrelated noise.
+    bool indep = m < n && delta > D.qp_dep_tol * app && delta > 1e-18 * apap;
+    double z0 = 0.0, z1 = 0.0;
+    if (indep) {
+      double d0, d1;
+      qpw_ymul(q.Y, n, m, lane, q.rv, q.yslot, d0, d1);
+      z0 = d0 - y0; z1 = d1 - y1;
+      if (!(delta > 1e-9 * app)) {
+        const double dz = -wave_sum(t0 * z0 + t1 * z1);
+        indep = __builtin_fabs(delta - dz) <= 0.3 * delta;
+      }
+    }
     const double tb = indep ? viol / delta : INFINITY;
     const double t = fmin(ta, tb);
     PROF_END(PH_Q_DIR, pq3);
     if (!(t < INFINITY)) return 1;
     PROF_BEGIN(pq4);
-    if (indep) {   // primal direction z = Y r - y;  x += t z
-      double d0, d1;
-      qpw_ymul(q.Y, n, m, lane, q.rv, q.yslot, d0, d1);
-      S.x0 += t * (d0 - y0); S.x1 += t * (d1 - y1);
-    }
+    if (indep) { S.x0 += t * z0; S.x1 += t * z1; }   // x += t z
     if (lane < m) q.lam[lane] -= t * r0;
     if (lane + 64 < m) q.lam[lane + 64] -= t * r1;
     lp += t;
@@ -335,7 +346,7 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
         double wa, wb;
         const double ww = qpw_fwd(q.R, q.rd, m, npk, lane, q.cvec, q.wv, wa, wb);
         const double delta = app - ww;
-        if (m < n && delta > 1e-11 * app && delta > 1e-18 * apap) {
+        if (m < n && delta > 1e-11 * app && delta > 1e-18 * apap) {   // conservative: a skipped guess is found again by the main loop
           if (lane < m) q.R[tri(m, lane)] = wa;
           if (lane + 64 < m) q.R[tri(m, lane + 64)] = wb;
           if (lane == 0) {

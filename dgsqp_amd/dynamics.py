@@ -116,6 +116,16 @@ class DynamicBicycleConfig(DynamicsConfig):
 
 
 @dataclass
+class UnicycleConfig(DynamicsConfig):
+    """model_types.py:107-113."""
+    mass: float = 2.366
+    damping_coefficient: float = 0.0
+    drag_coefficient: float = 0.0
+    rolling_resistance: float = 0.0
+    rolling_resistance_exponent: float = 0.5
+
+
+@dataclass
 class MultiAgentModelConfig(DynamicsConfig):
     use_mx: bool = False
 
@@ -125,6 +135,7 @@ class MultiAgentModelConfig(DynamicsConfig):
 # ---------------------------------------------------------------------------------------------
 MODEL_KIN_BICYCLE = 0
 MODEL_DYN_BICYCLE = 1
+MODEL_UNICYCLE = 2
 INTEGRATORS = {'euler': 0, 'rk4': 1, 'rk3': 2, 'rk2': 3}
 
 
@@ -311,6 +322,63 @@ class CasadiDynamicBicycleCombined(_FrenetBicycle):
             prediction.u_a = array.array('d', u[:, 0])
             prediction.u_steer = array.array('d', u[:, 1])
         return prediction
+
+
+class CasadiKinematicUnicycle(_FrenetBicycle):
+    """Global-frame kinematic unicycle (dynamics_models.py:306-390): state [x, y, v, psi], input [F, omega].
+    The merge script builds it from a plain ``DynamicsConfig`` (DGSQP_merge_monte_carlo.py:95-101), which has no ``mass``
+    field; ``UnicycleConfig`` (mass 2.366) is the config the class reads."""
+    model_id = MODEL_UNICYCLE
+    curvature_model = False
+    n_q = 4
+
+    def __init__(self, t0: float, model_config: UnicycleConfig = None, track=None):
+        super().__init__(t0, model_config or UnicycleConfig(), track=track)
+        self.m = getattr(self.model_config, 'mass', 2.366)
+
+    def fc(self, q, u) -> np.ndarray:
+        return np.array([q[2] * np.cos(q[3]), q[2] * np.sin(q[3]), u[0] / self.m, u[1]])
+
+    def state2q(self, state: VehicleState) -> np.ndarray:
+        return np.array([state.x.x, state.x.y, state.v.v_long, state.e.psi])
+
+    def q2state(self, state: VehicleState, q):
+        state.x.x, state.x.y, state.v.v_long, state.e.psi = (float(v) for v in q[:4])
+
+    def qu2state(self, state: VehicleState, q=None, u=None):
+        if q is not None:
+            self.q2state(state, q)
+        if u is not None:
+            state.u.u_a, state.u.u_steer = float(u[0]), float(u[1])
+
+    def qu2prediction(self, prediction: VehiclePrediction, q=None, u=None):
+        if prediction is None:
+            prediction = VehiclePrediction()
+        if q is not None:
+            for name, col in (('x', 0), ('y', 1), ('v_long', 2), ('psi', 3)):
+                setattr(prediction, name, array.array('d', q[:, col]))
+        if u is not None:
+            prediction.u_a = array.array('d', u[:, 0])
+            prediction.u_steer = array.array('d', u[:, 1])
+        return prediction
+
+    def fd(self, q, u):
+        """One step of the model's own discretisation (dynamics_models.py:88-125, rk3 :200-211)."""
+        q = np.asarray(q, float)
+        meth, h = self.model_config.discretization_method, self.dt / self.M
+        if meth == 'euler':
+            return q + self.dt * self.fc(q, u)
+        for _ in range(self.M):
+            if meth == 'rk4':
+                a1 = self.fc(q, u); a2 = self.fc(q + h / 2 * a1, u); a3 = self.fc(q + h / 2 * a2, u); a4 = self.fc(q + h * a3, u)
+                q = q + h * (a1 + 2 * a2 + 2 * a3 + a4) / 6
+            elif meth == 'rk3':
+                a1 = h * self.fc(q, u); a2 = h * self.fc(q + a1 / 2, u); a3 = h * self.fc(q - a1 + 2 * a2, u)
+                q = q + (a1 + 4 * a2 + a3) / 6
+            else:
+                a1 = self.fc(q, u); a2 = self.fc(q + h * a1, u)
+                q = q + h * (a1 + a2) / 2
+        return q
 
 
 class CasadiDecoupledMultiAgentDynamicsModel:

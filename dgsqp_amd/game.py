@@ -13,6 +13,10 @@ signature: ``costs`` / ``agent_constraints`` /
 * ``InputRateLimits`` -- chicane.py:282-290 (rows ordered ``[a ub, a lb, steer ub, steer lb]``),
 * ``CollisionAvoidance`` -- chicane.py:292-293,322-330: one row per agent pair (i<j),
                          absent at k=0, present at k=1..N.
+* ``GoalTrackingCost`` -- scripts/DGSQP_merge_monte_carlo.py:253-261: ``1/2 sum w_u u^2 + 1/2 (q-goal)^T diag(w_q) (q-goal)``
+                         per stage, ``terminal_multiplier`` times the state part at k=N,
+* ``LaneBoundaries``  -- merge.py:66-74,316-342: half-plane rows ``n(p_x)^T (p - (anchor - r n(p_x))) <= 0`` with a
+                         piecewise-constant normal, present at every stage k=0..N.
 """
 from __future__ import annotations
 
@@ -57,3 +61,27 @@ class InputRateLimits:
 class CollisionAvoidance:
     """Row for pair (i<j): (r_i+r_j)^2 - |p_i-p_j|^2 <= 0."""
     radii: Sequence[float] = field(default_factory=lambda: [0.2, 0.2])
+
+
+@dataclass
+class GoalTrackingCost:
+    input_weight: Sequence[float] = (0.1, 0.1)
+    state_weight: Sequence[float] = (1.0, 10.0, 1.0, 1.0)     # diagonal of Q over the agent's state
+    goal: Sequence[float] = (4.0, 0.15, 0.3, 0.0)
+    terminal_multiplier: float = 10.0
+    input_rate_weight: Sequence[float] = (0.0, 0.0)
+
+
+@dataclass
+class LaneHalfPlane:
+    """``n(p_x) = n_lo`` for ``p_x < brk`` else ``n_hi`` (CasADi ``pw_const``); constant normal when ``brk`` is +inf."""
+    n_lo: Sequence[float]
+    anchor: Sequence[float]
+    r: float = 0.1
+    n_hi: Sequence[float] = None
+    brk: float = float('inf')
+
+
+@dataclass
+class LaneBoundaries:
+    lanes: List[LaneHalfPlane] = field(default_factory=list)

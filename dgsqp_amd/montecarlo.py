@@ -22,7 +22,7 @@ from .dynamics import (CasadiDecoupledMultiAgentDynamicsModel, CasadiDynamicBicy
                        MultiAgentModelConfig)
 from .game import CollisionAvoidance, InputRateLimits, RacingCost
 from .solver_types import DGSQPParams
-from .tracks import ChicaneTrack, CurveTrack
+from .tracks import ChicaneTrack, CurveTrack, get_track
 from .types import (BodyAngularVelocity, BodyLinearVelocity, OrientationEuler, ParametricPose, Position,
                     VehicleActuation, VehicleState)
 
@@ -40,6 +40,7 @@ class Game:
     half_width: float
     obs_d: float
     name: str = ''
+    sampler: str = 'first_segment'      # 'first_segment' (chicane.py/curve.py/agents.py) or 'circuit' (comp.py)
 
     def solver_args(self):
         return (self.joint_model, self.costs, self.agent_constraints, self.shared_constraints, self.bounds, self.params)
@@ -115,6 +116,30 @@ def dynamic_racing_game(track_kind='curve', theta_deg=45, N=25, reg=1e-3, rk4_su
     return Game(joint, [cost() for _ in range(M)], [InputRateLimits((10.0, 4.5), (-10.0, -4.5)) for _ in range(M)],
                 CollisionAvoidance([r] * M), _bounds(half_width, M), params, track, half_width, 2 * r,
                 name=f'dyn_{track_kind}_N{N}')
+
+
+def barc_racing_game(N=15, M=2, reg=0.0) -> Game:
+    """Head-to-head race on the L_track_barc circuit, scripts/DGSQP_comp_monte_carlo.py: kinematic bicycles (euler,
+    dt 0.1, :79-97), lateral bounds +-(H-0.1) (:108-134), weights (:141-146), radii 0.2 (:149-150), solver parameters with
+    reg=0 (:157-171), rate limits (:254-261), obstacle rows from k=1 (:285-292).  M=3 with N=25 is BASELINE configs[2]
+    (its 150 unknowns exceed the current device limit of 128; M=3 fits up to N=21)."""
+    dt = 0.1
+    track = get_track('L_track_barc')
+    H = track.half_width
+    cfg = lambda: KinematicBicycleConfig(dt=dt, model_name='kinematic_bicycle', noise=False,
+                                         discretization_method='euler', wheel_dist_front=0.13, wheel_dist_rear=0.13,
+                                         code_gen=False)
+    models = [CasadiKinematicBicycleCombined(0, cfg(), track=track) for _ in range(M)]
+    joint = CasadiDecoupledMultiAgentDynamicsModel(0, models, MultiAgentModelConfig(
+        dt=dt, discretization_method='euler', use_mx=False, code_gen=False, verbose=True, compute_hessians=True))
+    r = 0.2
+    params = DGSQPParams(solver_name='DGSQP', dt=dt, N=N, reg=reg, nonmono_ls=True, line_search_iters=50, sqp_iters=50,
+                         p_tol=1e-3, d_tol=1e-3, beta=0.01, tau=0.5, verbose=False, merit_function='stat_l1')
+    cost = lambda: RacingCost(input_weight=(0.1, 0.1), input_rate_weight=(1.0, 1.0), comp_weights=(0.0, 1.0),
+                              comp_type='atan')
+    return Game(joint, [cost() for _ in range(M)], [InputRateLimits((10.0, 4.5), (-10.0, -4.5)) for _ in range(M)],
+                CollisionAvoidance([r] * M), _bounds(H - 0.1, M), params, track, H - 0.1, 2 * r,
+                name=f'kb_barc_M{M}_N{N}', sampler='circuit')
 
 
 # ---------------------------------------------------------------------------------------------
@@ -205,6 +230,8 @@ def sample_scenarios(game: Game, B: int, seed: int = 1, max_rounds: int = 200, s
     Returns x0 [B, n_q] and u_ws [B, N, n_u] (time-major, as ``set_warm_start`` expects).
     With ``solver`` (a ``dgsqp_amd.solver.DGSQP`` of this game) the PID warm starts and the collision check run on the
     device (``dgsqp_pid_warm_start_batch``); the random draws are the same either way."""
+    if game.sampler == 'circuit':
+        return _sample_scenarios_circuit(game, B, seed, max_rounds)
     if game.joint_model.n_a != 2:
         return _sample_scenarios_independent(game, B, seed, max_rounds)
     rng = np.random.default_rng(seed)
@@ -283,6 +310,53 @@ def _sample_scenarios_independent(game: Game, B: int, seed: int, max_rounds: int
             q[:, mdl.s_idx], q[:, mdl.ey_idx] = s_, ey
             rl = game.agent_constraints[0]
             du = (10.0, 4.5) if rl is None else tuple(rl.rate_max)
+            qw, uw = pid_warm_start(mdl, q, N, dt, du=du)
+            q0.append(q); q_ws.append(qw); u_ws.append(uw)
+        keep = np.ones(n, bool)
+        for i in range(M):
+            for j in range(i + 1, M):
+                dist = np.linalg.norm(q_ws[i][:, :, :2] - q_ws[j][:, :, :2], axis=2)
+                keep &= ~(dist < radii[i] + radii[j]).any(axis=1)
+        x0s.append(np.concatenate([q[keep] for q in q0], axis=1))
+        uws.append(np.concatenate([u[keep] for u in u_ws], axis=2))
+        have += int(keep.sum())
+    x0 = np.concatenate(x0s)[:B]
+    u = np.concatenate(uws)[:B]
+    if x0.shape[0] < B:
+        raise RuntimeError('sampler did not produce enough collision-free scenarios')
+    return np.ascontiguousarray(x0), np.ascontiguousarray(u)
+
+
+def _sample_scenarios_circuit(game: Game, B: int, seed: int, max_rounds: int):
+    """Sampler of scripts/DGSQP_comp_monte_carlo.py:365-382 (the script seeds with 0): the first car anywhere on the
+    circuit, every further car within 1.2 obstacle distances along the track, speeds within 25 %, headings within 5 deg;
+    PID warm starts; rejection on a collision along the warm start (:448)."""
+    rng = np.random.default_rng(seed)
+    track, hw, obs_d = game.track, game.half_width, game.obs_d
+    N, dt = game.params.N, game.params.dt
+    L = track.track_length
+    models = game.joint_model.dynamics_models
+    M = len(models)
+    radii = list(game.shared_constraints.radii)
+    x0s, uws = [], []
+    have = 0
+    rl = game.agent_constraints[0]
+    du = (10.0, 4.5) if rl is None else tuple(rl.rate_max)
+    for _ in range(max_rounds):
+        if have >= B:
+            break
+        n = max(64, 2 * (B - have))
+        s1 = L * rng.random(n)
+        place = [(s1, hw * (2 * rng.random(n) - 1), 2.0 + (rng.random(n) - 0.5), 5.0 * (2 * rng.random(n) - 1) * np.pi / 180)]
+        for _a in range(1, M):
+            place.append((s1 + 1.2 * obs_d * (2 * rng.random(n) - 1), hw * (2 * rng.random(n) - 1),
+                          (1 + 0.25 * (2 * rng.random(n) - 1)) * place[0][2], 5.0 * (2 * rng.random(n) - 1) * np.pi / 180))
+        q0, q_ws, u_ws = [], [], []
+        for mdl, (s_, ey, v, ep) in zip(models, place):
+            xy = np.array([track.local_to_global((si, ei_, pi_))[:2] for si, ei_, pi_ in zip(s_, ey, ep)]).reshape(-1, 2)
+            q = np.zeros((n, mdl.n_q))
+            q[:, 0], q[:, 1], q[:, 2] = xy[:, 0], xy[:, 1], v
+            q[:, mdl.s_idx], q[:, mdl.ey_idx], q[:, 3] = s_, ey, ep
             qw, uw = pid_warm_start(mdl, q, N, dt, du=du)
             q0.append(q); q_ws.append(qw); u_ws.append(uw)
         keep = np.ones(n, bool)

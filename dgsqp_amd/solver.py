@@ -18,7 +18,7 @@ import numpy as np
 
 from . import _ffi
 from .dynamics import CasadiDecoupledMultiAgentDynamicsModel, INTEGRATORS
-from .game import CollisionAvoidance, InputRateLimits, RacingCost
+from .game import CollisionAvoidance, GoalTrackingCost, InputRateLimits, LaneBoundaries, RacingCost
 from .solver_types import DGSQPParams
 from .types import VehiclePrediction, VehicleState
 
@@ -61,7 +61,10 @@ def build_problem(joint_dynamics: CasadiDecoupledMultiAgentDynamicsModel,
     P.substeps = int(cfg.M) if cfg.discretization_method != 'euler' else 1
     P.dt = float(cfg.dt)
     track = joint_dynamics.track
-    L, seg_s, seg_curv, seg_ang = track.tables()
+    if track is None:                       # global-frame models (unicycle): a one-segment placeholder table
+        L, seg_s, seg_curv, seg_ang = 1.0, [0.0, 1.0], [0.0], [0.0, 0.0]
+    else:
+        L, seg_s, seg_curv, seg_ang = track.tables()
     n_segs = len(seg_curv)
     if n_segs > _ffi.MAX_SEGS:
         raise ValueError(f'track has {n_segs} segments, limit is {_ffi.MAX_SEGS}')
@@ -78,10 +81,16 @@ def build_problem(joint_dynamics: CasadiDecoupledMultiAgentDynamicsModel,
         A = P.agents[a]
         c = mdl.model_config
         A.model = mdl.model_id
-        A.L_f, A.L_r, A.mass = c.wheel_dist_front, c.wheel_dist_rear, c.mass
-        A.c_dr, A.c_da = c.drag_coefficient, c.damping_coefficient
-        A.c_r, A.p_r = c.rolling_resistance, c.rolling_resistance_exponent
-        if mdl.model_id == 0:
+        if mdl.model_id != 2:
+            A.L_f, A.L_r, A.mass = c.wheel_dist_front, c.wheel_dist_rear, c.mass
+            A.c_dr, A.c_da = c.drag_coefficient, c.damping_coefficient
+            A.c_r, A.p_r = c.rolling_resistance, c.rolling_resistance_exponent
+        if mdl.model_id == 2:
+            A.L_f = A.L_r = 0.13
+            A.mass, A.I_z, A.gravity = float(mdl.m), 1.0, 9.81
+            A.c_dr = A.c_da = A.c_r = 0.0
+            A.p_r = 0.5
+        elif mdl.model_id == 0:
             A.c_s = c.slip_coefficient
             A.I_z, A.gravity = 1.0, 9.81
         else:
@@ -95,10 +104,29 @@ def build_problem(joint_dynamics: CasadiDecoupledMultiAgentDynamicsModel,
         for j in range(2):
             A.w_in[j] = float(cost.input_weight[j])
             A.w_rate[j] = float(cost.input_rate_weight[j])
-        A.w_prog, A.w_comp = float(cost.comp_weights[0]), float(cost.comp_weights[1])
-        A.comp_type = {'atan': 0, 'linear': 1}[cost.comp_type]
-        A.w_block, A.w_obs, A.obs_cost_r = float(cost.blocking_weight), float(cost.obs_weight), float(cost.obs_r)
+        if isinstance(cost, GoalTrackingCost):
+            if len(cost.state_weight) != mdl.n_q or len(cost.goal) != mdl.n_q:
+                raise ValueError('GoalTrackingCost needs one weight and one goal entry per state')
+            for i in range(mdl.n_q):
+                if cost.state_weight[i] != 0 and i not in (0, 1, mdl.n_q - 2, mdl.n_q - 1):
+                    raise NotImplementedError('goal-tracking weights are supported on the positions and the last two states')
+                A.w_goal[i], A.goal[i] = float(cost.state_weight[i]), float(cost.goal[i])
+            A.goal_term_mult = float(cost.terminal_multiplier)
+        else:
+            A.w_prog, A.w_comp = float(cost.comp_weights[0]), float(cost.comp_weights[1])
+            A.comp_type = {'atan': 0, 'linear': 1}[cost.comp_type]
+            A.w_block, A.w_obs, A.obs_cost_r = float(cost.blocking_weight), float(cost.obs_weight), float(cost.obs_r)
         rate = agent_constraints[a] if agent_constraints is not None else None
+        if isinstance(rate, LaneBoundaries):
+            if len(rate.lanes) > _ffi.MAX_LANES:
+                raise ValueError(f'at most {_ffi.MAX_LANES} lane rows per agent')
+            A.n_lane = len(rate.lanes)
+            for j, ln in enumerate(rate.lanes):
+                hi = ln.n_lo if ln.n_hi is None else ln.n_hi
+                A.lane[j].brk, A.lane[j].r = float(ln.brk), float(ln.r)
+                for i in range(2):
+                    A.lane[j].n_lo[i], A.lane[j].n_hi[i], A.lane[j].anchor[i] = float(ln.n_lo[i]), float(hi[i]), float(ln.anchor[i])
+            rate = None
         A.has_rate = 0 if rate is None else 1
         for j in range(2):
             A.rate_ub[j] = 0.0 if rate is None else float(rate.rate_max[j])

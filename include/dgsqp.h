@@ -36,7 +36,9 @@ extern "C" {
 enum {
   DGSQP_MODEL_KIN_BICYCLE = 0, /* CasadiKinematicBicycleCombined :997  */
   DGSQP_MODEL_DYN_BICYCLE = 1, /* CasadiDynamicBicycleCombined   :1945 */
+  DGSQP_MODEL_UNICYCLE = 2,    /* CasadiKinematicUnicycle        :306 : state [x, y, v, psi], input [F, omega] */
 };
+#define DGSQP_MAX_LANES 2 /* lane half-plane rows per agent and stage */
 /* discretisation (dynamics_models.py:88-125, :188-219) */
 enum { DGSQP_INT_EULER = 0, DGSQP_INT_RK4 = 1, DGSQP_INT_RK3 = 2, DGSQP_INT_RK2 = 3 };
 /* terminal competition cost shape */
@@ -96,6 +98,21 @@ typedef struct {
   double in_ub[DGSQP_NUA], in_lb[DGSQP_NUA];     /* +-inf = absent (DGSQP.py:145-148) */
   double st_ub[DGSQP_MAX_NQA], st_lb[DGSQP_MAX_NQA];
   double radius; /* obstacle row for pair (i,j): (r_i+r_j)^2 - |p_i-p_j|^2 <= 0 */
+
+  /* goal-tracking state cost (scripts/DGSQP_merge_monte_carlo.py:253-261): stage 1/2 sum_i w_goal[i] (q_i - goal[i])^2 at
+     k = 0..N-1, goal_term_mult times that at k = N.  Weights may sit on the positions and the last two states. */
+  double w_goal[DGSQP_MAX_NQA], goal[DGSQP_MAX_NQA];
+  double goal_term_mult;
+  /* lane half-planes (merge.py:66-74, :316-318), rows at every stage k = 0..N placed where the rate rows would be:
+       n(p_x)^T (p - anchor) + r n^T n <= 0,   n(p_x) = n_lo + (n_hi - n_lo) [p_x >= brk]   (CasADi pw_const)        */
+  int32_t n_lane;
+  int32_t _pad2;
+  struct {
+    double brk;          /* +inf: constant normal n_lo */
+    double n_lo[2], n_hi[2];
+    double anchor[2];
+    double r;
+  } lane[DGSQP_MAX_LANES];
 } dgsqp_agent_t;
 
 /*

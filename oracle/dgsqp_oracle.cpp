@@ -48,7 +48,7 @@ static const double INF = std::numeric_limits<double>::infinity();
 // -----------------------------------------------------------------------------
 // layout (DGSQP.py:150-170, :729-821)
 // -----------------------------------------------------------------------------
-enum RowType { R_OBS = 0, R_RATE_UB, R_RATE_LB, R_IN_UB, R_IN_LB, R_ST_UB, R_ST_LB };
+enum RowType { R_OBS = 0, R_RATE_UB, R_RATE_LB, R_IN_UB, R_IN_LB, R_ST_UB, R_ST_LB, R_LANE };
 struct Row {
   int type, k, a, b, idx;
 };
@@ -62,7 +62,7 @@ struct Layout {
   int col(int a, int k, int j) const { return a * N * DGSQP_NUA + k * DGSQP_NUA + j; }
 };
 
-static int model_nq(int model) { return model == DGSQP_MODEL_DYN_BICYCLE ? 8 : 6; }
+static int model_nq(int model) { return model == DGSQP_MODEL_DYN_BICYCLE ? 8 : (model == DGSQP_MODEL_UNICYCLE ? 4 : 6); }
 
 static Layout make_layout(const dgsqp_problem_t& P) {
   Layout L;
@@ -71,8 +71,9 @@ static Layout make_layout(const dgsqp_problem_t& P) {
     L.nqa[a] = model_nq(P.agents[a].model);
     L.qoff[a] = L.nq;
     L.nq += L.nqa[a];
-    L.s_idx[a] = P.agents[a].model == DGSQP_MODEL_DYN_BICYCLE ? 6 : 4;
-    L.ey_idx[a] = P.agents[a].model == DGSQP_MODEL_DYN_BICYCLE ? 7 : 5;
+    // Frenet states s, e_y: the last two of both bicycles (the unicycle has none; its slots only meet zero weights)
+    L.s_idx[a] = L.nqa[a] - 2;
+    L.ey_idx[a] = L.nqa[a] - 1;
   }
   L.n = L.N * L.nu;
   // row order per stage: [shared ; agent0: fn rows, input ub, input lb, (k>0) state ub, state lb ; agent1 ...]
@@ -90,6 +91,11 @@ static Layout make_layout(const dgsqp_problem_t& P) {
             L.rows.push_back({R_RATE_UB, k, a, -1, j});
             L.rows.push_back({R_RATE_LB, k, a, -1, j});
           }
+      }
+      // agent constraint function rows of the merge game: lane half-planes at every stage incl. k = 0 and k = N
+      // (merge.py:316-342; rows of stage 0 depend on x_0 only and keep a zero gradient, SURVEY.md hazard 8)
+      for (int j = 0; j < ag.n_lane; j++) L.rows.push_back({R_LANE, k, a, -1, j});
+      if (k < P.N) {
         for (int j = 0; j < DGSQP_NUA; j++)
           if (ag.in_ub[j] < INF) L.rows.push_back({R_IN_UB, k, a, -1, j});
         for (int j = 0; j < DGSQP_NUA; j++)
@@ -198,9 +204,21 @@ static void fc_dyn(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const T* q
   dq[7] = vx * sin(epsi) + vy * cos(epsi);
 }
 
+// kinematic unicycle in the global frame (dynamics_models.py:331-339): state [x, y, v, psi], input [F, omega]
+template <class T>
+static void fc_uni(const dgsqp_agent_t& ag, const T* q, const T* u, T* dq) {
+  using std::sin; using std::cos;
+  dq[0] = q[2] * cos(q[3]);
+  dq[1] = q[2] * sin(q[3]);
+  dq[2] = u[0] / ag.mass;
+  dq[3] = u[1];
+}
+
 template <class T>
 static void fc(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const T* q, const T* u, T* dq) {
-  if (ag.model == DGSQP_MODEL_DYN_BICYCLE) fc_dyn(P, ag, q, u, dq); else fc_kin(P, ag, q, u, dq);
+  if (ag.model == DGSQP_MODEL_DYN_BICYCLE) fc_dyn(P, ag, q, u, dq);
+  else if (ag.model == DGSQP_MODEL_UNICYCLE) fc_uni(ag, q, u, dq);
+  else fc_kin(P, ag, q, u, dq);
 }
 
 // discretisation of the JOINT model's config applied per (decoupled) agent
@@ -252,6 +270,12 @@ static T state_cost(const dgsqp_problem_t& P, const Layout& L, int a, const T* x
   using std::sqrt; using std::atan;
   const dgsqp_agent_t& ag = P.agents[a];
   T J(0.0);
+  // goal tracking 1/2 (q - goal)^T diag(w) (q - goal), terminal = mult x stage (merge.py:253-261)
+  for (int i = 0; i < L.nqa[a]; i++)
+    if (ag.w_goal[i] != 0.0) {
+      T d = x[L.qoff[a] + i] - ag.goal[i];
+      J = J + (terminal ? ag.goal_term_mult : 1.0) * 0.5 * ag.w_goal[i] * (d * d);
+    }
   for (int b = 0; b < P.M; b++) {
     if (b == a) continue;
     if (ag.w_block != 0.0) {
@@ -400,6 +424,18 @@ static void constraints(const dgsqp_problem_t& P, const Layout& L, const double*
         ev.g[r] = ag.in_lb[R.idx] - u[L.col(R.a, R.k, R.idx)];
         if (jac) Gr[L.col(R.a, R.k, R.idx)] = -1.0;
         break;
+      case R_LANE: {
+        // n(p_x)^T (p - (anchor - r n(p_x))), n = pw_const(p_x, brk, [n_lo, n_hi]) (merge.py:66-74); d pw_const / d p_x = 0
+        const auto& ln = ag.lane[R.idx];
+        const int ia = L.qoff[R.a];
+        const double hi = xk[ia] >= ln.brk ? 1.0 : 0.0;
+        const double nx = ln.n_lo[0] + (ln.n_hi[0] - ln.n_lo[0]) * hi, ny = ln.n_lo[1] + (ln.n_hi[1] - ln.n_lo[1]) * hi;
+        ev.g[r] = nx * (xk[ia] - (ln.anchor[0] - ln.r * nx)) + ny * (xk[ia + 1] - (ln.anchor[1] - ln.r * ny));
+        if (jac) {
+          const double* Dp = &ev.Dux[((size_t)R.k * nq + ia) * n];
+          for (int c = 0; c < n; c++) Gr[c] = nx * Dp[c] + ny * Dp[n + c];
+        }
+      } break;
       case R_ST_UB:
       case R_ST_LB: {
         const int xi = L.qoff[R.a] + R.idx;
@@ -563,7 +599,7 @@ static void lagrangian_hessian(const dgsqp_problem_t& P, const Layout& L, const 
     bool any = false;
     for (int r = L.stage_row0[k]; r < L.stage_row0[k + 1]; r++) {
       const Row& R = L.rows[r];
-      if (R.type != R_OBS && R.type != R_ST_UB && R.type != R_ST_LB) continue;
+      if (R.type != R_OBS && R.type != R_ST_UB && R.type != R_ST_LB && R.type != R_LANE) continue;
       vec dx(nq, 0.0), dxx((size_t)nq * nq, 0.0);
       const double* xk = &ev.x[(size_t)k * nq];
       if (R.type == R_OBS) {
@@ -574,6 +610,11 @@ static void lagrangian_hessian(const dgsqp_problem_t& P, const Layout& L, const 
           dxx[(ia + c) * nq + ia + c] = -2; dxx[(ib + c) * nq + ib + c] = -2;
           dxx[(ia + c) * nq + ib + c] = 2;  dxx[(ib + c) * nq + ia + c] = 2;
         }
+      } else if (R.type == R_LANE) {
+        const auto& ln = P.agents[R.a].lane[R.idx];
+        const double hi = xk[L.qoff[R.a]] >= ln.brk ? 1.0 : 0.0;
+        dx[L.qoff[R.a]] = ln.n_lo[0] + (ln.n_hi[0] - ln.n_lo[0]) * hi;
+        dx[L.qoff[R.a] + 1] = ln.n_lo[1] + (ln.n_hi[1] - ln.n_lo[1]) * hi;
       } else {
         dx[L.qoff[R.a] + R.idx] = R.type == R_ST_UB ? 1.0 : -1.0;
       }
