@@ -27,19 +27,20 @@ if ROOT not in sys.path:
 
 WORKLOADS = {
     # BASELINE.json configs[1]
-    'dyn_curve_N25': dict(desc='2-agent dynamic-bicycle (Pacejka, rk4 M=10) curve track, N=25, fp64', kind='dyn', track='curve', N=25),
+    'dyn_curve_N25': dict(desc='2-agent dynamic-bicycle (Pacejka, rk4 M=10) curve track, N=25, fp64', kind='dyn', track='curve', N=25, reg=1e-3),
     # the reference's own Monte-Carlo experiment (scripts/DGSQP_ALGAMES_monte_carlo_curve.py), kinematic bicycle
-    'kb_curve_N25': dict(desc='2-agent kinematic-bicycle (euler) curve track, N=25, fp64', kind='kb', track='curve', N=25),
-    'kb_chicane_N25': dict(desc='2-agent kinematic-bicycle (euler) chicane track, N=25, fp64', kind='kb', track='chicane', N=25),
+    'kb_curve_N25': dict(desc='2-agent kinematic-bicycle (euler) curve track, N=25, reg=0 (curve.py:161), fp64', kind='kb', track='curve', N=25, reg=0.0),
+    'kb_chicane_N25': dict(desc='2-agent kinematic-bicycle (euler) chicane track, N=25, reg=1e-3 (chicane.py:164), fp64', kind='kb', track='chicane', N=25, reg=1e-3),
 }
 
 
-def make_game(name):
+def make_game(name, reg=None):
     from dgsqp_amd.montecarlo import dynamic_racing_game, kinematic_racing_game
     w = WORKLOADS[name]
+    reg = w['reg'] if reg is None else reg
     if w['kind'] == 'dyn':
-        return dynamic_racing_game(w['track'], N=w['N'], rk4_substeps=10)
-    return kinematic_racing_game(w['track'], N=w['N'])
+        return dynamic_racing_game(w['track'], N=w['N'], rk4_substeps=10, reg=reg)
+    return kinematic_racing_game(w['track'], N=w['N'], reg=reg)
 
 
 def algorithmic_bytes_per_solve(d):
@@ -58,6 +59,7 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=16, help='scenarios timed on the host for cpu_baseline (0 disables)')
     ap.add_argument('--pipeline', type=int, default=5,
                     help='independent batches in flight per GPU (each on its own handle / HIP stream); 1 = strictly one launch at a time')
+    ap.add_argument('--reg', type=float, default=None, help='DGSQPParams.reg (default: the value of the workload)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -79,7 +81,7 @@ def main():
     from dgsqp_amd.solver import DGSQP
     import ctypes as C
 
-    game = make_game(args.workload)
+    game = make_game(args.workload, args.reg)
     solver = DGSQP(*game.solver_args(), print_method=None, device=local_rank)
     d = solver.dims
     B = args.batch
@@ -178,7 +180,7 @@ def main():
             'config': {'workload': args.workload, 'description': WORKLOADS[args.workload]['desc'], 'batch_per_gpu': B,
                        'n': int(d.n), 'n_c': int(d.n_c), 'parallelism': f'scenario-sharded x{world}',
                        'sampler': 'scripts/DGSQP_ALGAMES_monte_carlo_curve.py:384-467 (seed 1+rank), PID warm start',
-                       'batches_in_flight': P},
+                       'batches_in_flight': P, 'reg': float(game.params.reg), 'eig_floor': float(solver._cparams.eig_floor)},
             'mean_iters': summ['mean_iters_converged'], 'mean_iters_all': summ['mean_iters_all'],
             'mean_qp_solves': summ['mean_qp_solves_all'], 'converged_fraction': summ['converged'],
             'status_fractions': {k: summ[k] for k in ('conv_abs_tol', 'conv_rel_tol', 'max_it', 'diverged', 'qp_fail')},

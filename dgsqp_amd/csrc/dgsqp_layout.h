@@ -74,6 +74,7 @@ struct DgProb {
   int M, N, nq, nu, n, nc, npairs, ndense, ngd, ntask;
   int nqa[DGSQP_MAX_AGENTS], qoff[DGSQP_MAX_AGENTS], sidx[DGSQP_MAX_AGENTS], eyidx[DGSQP_MAX_AGENTS];
   double inv_track_L;
+  double eig_floor;    // value given to negative eigenvalues by _nearestPD (par.eig_floor, 1e-10 when not set)
   double qp_dep_tol;   // a row whose projected curvature delta is below qp_dep_tol * (a' P a) counts as dependent on the active rows
   int uniform_nqa;
   int ls_spec;      // trial step sizes of _line_search_3 rolled out concurrently (speculation width)
@@ -111,7 +112,7 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   D.uniform_nqa = 1;
   D.inv_track_L = 1.0 / P.track_L;
   D.qp_dep_tol = 3e-15;
-  if (const char* e = getenv("DGSQP_QP_DEP_TOL")) D.qp_dep_tol = atof(e);
+  D.eig_floor = par.eig_floor > 0.0 ? par.eig_floor : 1e-10;
   for (int a = 0; a < P.M; a++) {
     if (P.agents[a].model != P.agents[0].model) D.uniform_nqa = 0;
     const int mdl = P.agents[a].model;

@@ -87,6 +87,7 @@ __device__ inline void qpw_ymul(cgptr Y, int n, int m, int lane, clptr cf, const
 struct QpwState {
   double x0, x1;   // current primal point (elements lane, lane + 64)
   int m, nfree;    // active rows, free Y slots
+  int ill;         // a row was accepted or rejected on a curvature below 1e-9 of its unprojected value (reg = 0 regime)
 };
 struct QpPtrs {
   lptr xv, R, lam, cvec, wv, rv, rd, yv, tv, ddx, ddy, dpart, scal, prevlam;
@@ -205,6 +206,7 @@ __device__ inline int qpw_add_constraint(const QpPtrs& q, QpwState& S, int lane,
       qpw_ymul(q.Y, n, m, lane, q.rv, q.yslot, d0, d1);
       z0 = d0 - y0; z1 = d1 - y1;
       if (!(delta > 1e-9 * app)) {
+        S.ill = 1;
         const double dz = -wave_sum(t0 * z0 + t1 * z1);
         indep = __builtin_fabs(delta - dz) <= 0.3 * delta;
       }
@@ -255,11 +257,12 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
   __syncthreads();
   PROF_BEGIN(pt_qp);
   for (int r = TID; r < nc; r += NT) { q.act[r] = 0; lhat[r] = 0.0; }
+  if (TID == 0) q.scal[2] = 0.0;   // set when the active-set loop meets the ill-conditioned regime
   for (int i = TID; i < n; i += NT) q.yfree[i] = n - 1 - i;     // stack of free Y slots (top = lowest index)
   dev_p_mul(c, lds + L.q, q.xv, -1.0);  // unconstrained minimiser x = -P q
   __syncthreads();
   QpwState S;
-  S.m = 0; S.nfree = n;
+  S.m = 0; S.nfree = n; S.ill = 0;
   S.x0 = (w0 && okA) ? q.xv[lane] : 0.0; S.x1 = (w0 && okB) ? q.xv[lane + 64] : 0.0;
 
   // ---- warm start from the final active set W of this scenario's previous QP.  (x(W'), W') with x(W') the minimiser on
@@ -429,33 +432,51 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
 
   int ret = 2;
   const int max_outer = 4 * (n + nc);
-  for (int iter = 0; iter < max_outer; iter++) {
-    // ---- step 1: most violated inactive constraint (lowest index on ties)
-    PROF_BEGIN(pq1);
-    const int p = qp_scan(q, TOL);
-    PROF_END(PH_Q_SCAN, pq1);
-    if (p == NONE) { ret = 0; break; }
+  int iter = 0;
+  // The active-set loop ends at a point the scan finds feasible; the polish below (what OSQP's polish does with
+  // polish_refine_iter) then moves it, so the loop is entered again until a polished point passes the scan unchanged.
+  for (int round = 0; round < 4; round++) {
+    int added = 0;
+    ret = 2;
+    for (; iter < max_outer; iter++) {
+      // ---- step 1: most violated inactive constraint (lowest index on ties)
+      PROF_BEGIN(pq1);
+      const int p = qp_scan(q, TOL);
+      PROF_END(PH_Q_SCAN, pq1);
+      if (p == NONE) { ret = 0; break; }
+      added++;
 #ifdef DG_PROF
-    if (TID == 0) { atomicAdd(&dg_prof[2 * PH_SWEEP], 1ULL); }
+      if (TID == 0) { atomicAdd(&dg_prof[2 * PH_SWEEP], 1ULL); }
 #endif
-    PROF_BEGIN(pq2);
-    qp_row_products(c, q, p);
-    PROF_END(PH_Q_Y, pq2);
-    if (w0) {
-      const int st = qpw_add_constraint(q, S, lane, p);
-      if (okA) q.xv[lane] = S.x0;
-      if (okB) q.xv[lane + 64] = S.x1;
-      if (lane == 0) q.scal[0] = (double)st;
+      PROF_BEGIN(pq2);
+      qp_row_products(c, q, p);
+      PROF_END(PH_Q_Y, pq2);
+      if (w0) {
+        const int st = qpw_add_constraint(q, S, lane, p);
+        if (okA) q.xv[lane] = S.x0;
+        if (okB) q.xv[lane + 64] = S.x1;
+        if (lane == 0) { q.scal[0] = (double)st; q.scal[2] = (double)S.ill; }
+      }
+      __syncthreads();
+      if (q.scal[0] != 0.0) { ret = 1; break; }
     }
-    __syncthreads();
-    if (q.scal[0] != 0.0) { ret = 1; break; }
-  }
-  // Iterative refinement on the final active set (what OSQP's polish does with polish_refine_iter):
-  // P is an explicit inverse, so the active rows hold to ~1e-12 only; two projection steps
-  //   x <- x - Y S^-1 (A x - b),  lam <- lam + S^-1 (A x - b)      (Y = P A^T)
-  // bring them to rounding level.
-  PROF_BEGIN(pq6);
-  if (ret == 0) {
+    if (ret != 0 || (round > 0 && added == 0)) break;
+    PROF_BEGIN(pq6);
+    // With reg = 0 (P spans ten decades) the increments of x carry absolute errors of 1e-6 and a legitimate row can be
+    // taken for a dependent one: put x back on the stationarity manifold of the multipliers, x = -P (q + A^T lam).
+    if (added > 0 && q.scal[2] != 0.0) {
+      dev_p_mul(c, lds + L.q, q.yv, -1.0);
+      if (w0) {
+        double d0, d1;
+        qpw_ymul(q.Y, n, S.m, lane, q.lam, q.yslot, d0, d1);
+        S.x0 = (okA ? q.yv[lane] : 0.0) - d0; S.x1 = (okB ? q.yv[lane + 64] : 0.0) - d1;
+        if (okA) q.xv[lane] = S.x0;
+        if (okB) q.xv[lane + 64] = S.x1;
+      }
+      __syncthreads();
+    }
+    // Iterative refinement on the active set: P is an explicit inverse, so the active rows hold to ~1e-12 only; two
+    // projection steps  x <- x - Y S^-1 (A x - b),  lam <- lam + S^-1 (A x - b)  (Y = P A^T) bring them to rounding level.
     for (int pass = 0; pass < 2; pass++) {
       qp_dense_dots(D, q.gd, q.xv, q.dpart, q.ddx);
       if (w0 && S.m > 0) {
@@ -473,11 +494,23 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
       }
       __syncthreads();
     }
+    PROF_END(PH_Q_REFINE, pq6);
   }
-  PROF_END(PH_Q_REFINE, pq6);
   if (TID == 0) q.scal[1] = (double)S.m;
   __syncthreads();
   const int m = (int)q.scal[1];
+  // reg = 0 regime: the polished point holds its active rows to ~1e-9 only.  The input-box rows are linear in u, the next
+  // linearisation sees exactly these residuals, and _get_mu switches on their sign (DGSQP.py:566-585): put du on the active
+  // bounds exactly, as an exact active-set solution is.
+  if (ret == 0 && q.scal[2] != 0.0) {
+    for (int j = TID; j < m; j += NT) {
+      const int r = q.alist[j];
+      const DgRow Rw = ld_row(r);
+      if (Rw.type == DG_R_IN_UB) q.xv[am_col(D, Rw.a, Rw.k, Rw.idx)] = -q.g[r];
+      else if (Rw.type == DG_R_IN_LB) q.xv[am_col(D, Rw.a, Rw.k, Rw.idx)] = q.g[r];
+    }
+    __syncthreads();
+  }
   PROF_COUNT(PH_C_MFINAL, m);
   if (ret == 0)
     for (int j = TID; j < m; j += NT) { lhat[q.alist[j]] = q.lam[j]; q.prev[j] = q.alist[j]; q.prevlam[j] = q.lam[j]; }

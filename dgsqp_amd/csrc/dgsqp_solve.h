@@ -13,7 +13,7 @@ __device__ inline int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : 
 //      evaluates 64 Sturm sequences per step),
 //   3. eigenvectors of T by inverse iteration (tridiagonal LU with partial pivoting, one lane each),
 //      modified Gram-Schmidt, back-transformation through the reflectors (one wavefront per vector),
-//   4. M = B + sum_j (1e-10 - lambda_j) v_j v_j^T + reg I   (== U diag(s') U^T + reg I of DGSQP.py:1290-1296),
+//   4. M = B + sum_j (floor - lambda_j) v_j v_j^T + reg I   (== U diag(s') U^T + reg I of DGSQP.py:1290-1296, floor = 1e-10 there),
 //   5. P = M^-1 by the symmetric Gauss-Jordan sweep (SPD => no pivoting), packed into L.g_Bp.
 // Returns false (nothing written) when there are more than PSD_KMAX negative eigenvalues: caller falls back
 // to the Jacobi route.
@@ -374,13 +374,13 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
     }
     __syncthreads();
     PROF_END(PH_E_BACK, pe3);
-    // ---- 4b. M += sum_j (1e-10 - lam_j) v_j v_j^T   (== U diag(s') U^T of DGSQP.py:1290-1296 on the negative part)
+    // ---- 4b. M += sum_j (floor - lam_j) v_j v_j^T   (== U diag(s') U^T of DGSQP.py:1290-1296 on the negative part)
 #pragma unroll
     for (int r = 0; r < RPT; r++) {
       const int i = hf + NH * r;
       if (colok && i < n) {
         double a = Br[r];
-        for (int j = 0; j < kb; j++) a += (1e-10 - lamv[j]) * Z[j * n + i] * Z[j * n + jc];
+        for (int j = 0; j < kb; j++) a += (D.eig_floor - lamv[j]) * Z[j * n + i] * Z[j * n + jc];
         Br[r] = a;
       }
     }

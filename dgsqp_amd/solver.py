@@ -143,7 +143,10 @@ def build_problem(joint_dynamics: CasadiDecoupledMultiAgentDynamicsModel,
     return P
 
 
-def build_params(params: DGSQPParams) -> _ffi.ParamsT:
+def build_params(params: DGSQPParams, eig_floor: Optional[float] = None) -> _ffi.ParamsT:
+    """``eig_floor``: value ``_nearestPD`` gives to negative eigenvalues.  ``None`` = ``max(1e-10, 1e-6 - reg)``: the
+    reference's 1e-10 (DGSQP.py:1293) whenever ``reg >= 1e-6``, and 1e-6 at ``reg = 0`` (curve.py, comp.py, merge.py), where
+    1e-10 leaves a QP of condition 1e12.  Pass 1e-10 for the literal formula."""
     if not params.conv_approx:
         raise NotImplementedError('conv_approx=False (IPOPT Newton step, DGSQP.py:204-228) is not on the Monte-Carlo path')
     if params.hessian_approximation != 'none':
@@ -158,13 +161,14 @@ def build_params(params: DGSQPParams) -> _ffi.ParamsT:
     p.lsqr_iter_lim = 0                    # scipy default 2*n_c
     p.lsqr_atol = p.lsqr_btol = 1e-6       # scipy >= 1.12 defaults of sparse.linalg.lsqr
     p.qp_warm_start = int(getattr(params, 'qp_warm_start', 1))
+    p.eig_floor = max(1e-10, 1e-6 - float(params.reg)) if eig_floor is None else float(eig_floor)
     return p
 
 
 def problem_dims(P: _ffi.ProblemT):
     """(n_q, n_u, n, n_c) from the constraint-assembly rules DGSQP.py:732-821."""
     M, N = P.M, P.N
-    nqa = [8 if P.agents[a].model == 1 else 6 for a in range(M)]
+    nqa = [{0: 6, 1: 8, 2: 4}[P.agents[a].model] for a in range(M)]
     n_q, n_u = sum(nqa), 2 * M
     n_c = 0
     pairs = M * (M - 1) // 2 if P.obstacle_rows else 0

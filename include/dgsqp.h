@@ -150,6 +150,10 @@ typedef struct {
   int32_t qp_warm_start;  /* implementation knob (not in DGSQPParams): 1 = start each QP's active-set search from the
                              previous QP's final active set (same minimiser, shorter path); 0 = cold start */
   int32_t reserved_;
+  double eig_floor;       /* value _nearestPD gives to the negative eigenvalues; the reference uses 1e-10 (DGSQP.py:1293).
+                             <= 0 selects 1e-10.  With reg = 0 that leaves a Hessian with condition 1e12 which neither
+                             OSQP (sigma = 1e-6, polish delta = 1e-6) nor an explicit-inverse QP solves to better than
+                             1e-3; the host mirror therefore passes max(1e-10, 1e-6 - reg) unless told otherwise. */
 } dgsqp_params_t;
 
 /* PID lane follower used for the Monte-Carlo warm start (DGSQP/solvers/PID.py through

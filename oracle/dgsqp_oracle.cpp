@@ -720,12 +720,13 @@ static void jacobi_eigh(int n, vec A, vec& s, vec& U) {
 }
 
 // _nearestPD (DGSQP.py:1290-1296) followed by Q += reg*I (:238-239)
-static void nearest_pd(int n, const double* Qin, double reg, vec& out) {
+static void nearest_pd(int n, const double* Qin, double reg, vec& out, double floor_ = 1e-10) {
+  if (!(floor_ > 0)) floor_ = 1e-10;
   vec Bm((size_t)n * n), s, U;
   for (int i = 0; i < n; i++)
     for (int j = 0; j < n; j++) Bm[(size_t)i * n + j] = (Qin[(size_t)i * n + j] + Qin[(size_t)j * n + i]) / 2;
   jacobi_eigh(n, Bm, s, U);
-  for (int i = 0; i < n; i++) if (s[i] < 0) s[i] = 1e-10;
+  for (int i = 0; i < n; i++) if (s[i] < 0) s[i] = floor_;
   vec C((size_t)n * n, 0.0);
   for (int i = 0; i < n; i++)
     for (int j = 0; j < n; j++) {
@@ -1047,7 +1048,7 @@ static void eval_lin(const Ctx& c, const vec& u, const vec& l, bool hessian, Lin
 // _solve_qp (DGSQP.py:232-266); returns false on failure ("None in du")
 static bool solve_qp(const Ctx& c, const Lin& k, vec& du, vec& lhat) {
   vec Qpd;
-  nearest_pd(c.L.n, k.Q.data(), c.par.reg, Qpd);
+  nearest_pd(c.L.n, k.Q.data(), c.par.reg, Qpd, c.par.eig_floor);   // eig_floor: 1e-10 in the reference (DGSQP.py:1293)
   du.assign(c.L.n, 0.0); lhat.assign(c.L.nc, 0.0);
   return qp_gi(c.L.n, c.L.nc, Qpd.data(), k.q.data(), k.G.data(), k.g.data(), du.data(), lhat.data()) == 0;
 }
@@ -1292,6 +1293,12 @@ int oracle_dual_init(const dgsqp_problem_t* P, const dgsqp_params_t* par, const 
   return 0;
 }
 
+int oracle_nearest_pd2(int n, const double* Q, double reg, double eig_floor, double* out) {
+  vec o;
+  nearest_pd(n, Q, reg, o, eig_floor);
+  std::memcpy(out, o.data(), sizeof(double) * (size_t)n * n);
+  return 0;
+}
 int oracle_nearest_pd(int n, const double* Q, double reg, double* out) {
   vec o;
   nearest_pd(n, Q, reg, o);

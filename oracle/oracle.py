@@ -95,10 +95,10 @@ def dual_init(P, par, x0, u):
     return l0
 
 
-def nearest_pd(Q, reg):
+def nearest_pd(Q, reg, eig_floor=1e-10):
     Q = np.ascontiguousarray(Q, float)
     out = np.zeros_like(Q)
-    lib().oracle_nearest_pd(C.c_int(Q.shape[0]), _d(Q), C.c_double(reg), _d(out))
+    lib().oracle_nearest_pd2(C.c_int(Q.shape[0]), _d(Q), C.c_double(reg), C.c_double(eig_floor), _d(out))
     return out
 
 

@@ -194,3 +194,36 @@ def test_multi_agent_sampler():
     for i in range(3):
         for j in range(i + 1, 3):
             assert np.all(np.linalg.norm(p[:, i] - p[:, j], axis=1) >= 0.4 - 1e-12)
+
+
+def test_eig_floor_rule_and_oracle_projection(oracle):
+    """_nearestPD floor (DGSQP.py:1293 uses 1e-10): the host passes the literal value whenever reg >= 1e-6 and 1e-6 at
+    reg = 0 (condition 1e12 otherwise); the oracle's projection honours the parameter."""
+    from dgsqp_amd.solver import build_params
+    from dgsqp_amd.solver_types import DGSQPParams
+    assert build_params(DGSQPParams(reg=1e-3)).eig_floor == 1e-10
+    assert build_params(DGSQPParams(reg=0.0)).eig_floor == pytest.approx(1e-6)
+    assert build_params(DGSQPParams(reg=0.0), eig_floor=1e-10).eig_floor == 1e-10
+    rng = np.random.default_rng(0)
+    Q = rng.standard_normal((12, 12))
+    w_ref = np.linalg.eigvalsh(0.5 * (Q + Q.T))
+    for floor in (1e-10, 1e-6):
+        w = np.linalg.eigvalsh(oracle.nearest_pd(Q, 0.0, floor))
+        k = int((w_ref < 0).sum())
+        assert np.allclose(w[:k], floor, rtol=1e-3, atol=1e-13) and np.allclose(w[k:], w_ref[k:], atol=1e-12)
+
+
+def test_barc_circuit_game_and_sampler():
+    """scripts/DGSQP_comp_monte_carlo.py: L_track_barc circuit, reg = 0, sampler anywhere on the circuit (s wraps)."""
+    from dgsqp_amd.montecarlo import barc_racing_game, sample_scenarios
+    from dgsqp_amd.solver import build_problem, problem_dims
+    g = barc_racing_game(N=15, M=2)
+    assert g.params.reg == 0.0 and g.track.track_length == pytest.approx(17.461, abs=1e-2)
+    P = build_problem(*g.solver_args())
+    assert problem_dims(P) == (12, 4, 60, 315) and P.n_segs == 9
+    x0, u = sample_scenarios(g, 24, seed=0)
+    assert x0.shape == (24, 12) and u.shape == (24, 15, 4)
+    assert np.all(np.abs(x0[:, [5, 11]]) <= g.half_width + 1e-12) and np.all(np.abs(x0[:, [3, 9]]) <= 5 * np.pi / 180 + 1e-12)
+    assert np.all(np.linalg.norm(x0[:, :2] - x0[:, 6:8], axis=1) >= 0.4)
+    g3 = barc_racing_game(N=15, M=3)
+    assert problem_dims(build_problem(*g3.solver_args())) == (18, 6, 90, 495)     # 24 / 33 / 9 rows per stage (SURVEY.md section 8)

@@ -1,6 +1,6 @@
 """Device vs oracle on a game preset that is not one of the bench workloads (run on the GPU box).
 usage: gpu_games.py <barc2|barc3|merge> [B] [N]"""
-import sys, time, pathlib
+import os, sys, time, pathlib
 import numpy as np
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 from oracle import oracle
@@ -24,6 +24,8 @@ M, N = g.joint_model.n_a, g.params.N
 def tight(par):
     par.lsqr_atol = par.lsqr_btol = 1e-13
     par.lsqr_iter_mult = 20
+    if os.environ.get('DGSQP_NO_WARM'):
+        par.qp_warm_start = 0
     return par
 
 
