@@ -122,7 +122,7 @@ def barc_racing_game(N=15, M=2, reg=0.0) -> Game:
     """Head-to-head race on the L_track_barc circuit, scripts/DGSQP_comp_monte_carlo.py: kinematic bicycles (euler,
     dt 0.1, :79-97), lateral bounds +-(H-0.1) (:108-134), weights (:141-146), radii 0.2 (:149-150), solver parameters with
     reg=0 (:157-171), rate limits (:254-261), obstacle rows from k=1 (:285-292).  M=3 with N=25 is BASELINE configs[2]
-    (its 150 unknowns exceed the current device limit of 128; M=3 fits up to N=21)."""
+    (its 150 unknowns exceed what the LDS-resident device layout holds; M=3 fits up to N=16)."""
     dt = 0.1
     track = get_track('L_track_barc')
     H = track.half_width
