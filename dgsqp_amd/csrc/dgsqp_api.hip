@@ -492,6 +492,8 @@ int dgsqp_pid_warm_start_batch(dgsqp_handle_t h, int64_t B, const double* q0, co
   if (B == 0) return DGSQP_OK;
   HIPCHK(h, hipSetDevice(h->device));
   const DgProb& D = h->hp;
+  for (int a = 0; a < D.M; a++)
+    if (D.nqa[a] == 4) { h->err = "the PID lane follower needs a Frenet-frame model (the merge script starts from zero inputs)"; return DGSQP_E_ARG; }
   TmpBuf tb;
   const size_t nx = (size_t)(D.N + 1) * D.nq;
   double* dq0 = tb.alloc<double>(B * D.nq); double* du = tb.alloc<double>(B * D.n);

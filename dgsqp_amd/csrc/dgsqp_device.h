@@ -479,9 +479,22 @@ __device__ inline void dev_fc_dyn(const dgsqp_problem_t& P, const dgsqp_agent_t&
   dq[7] = vx * se + vy * ce;
 }
 
+// kinematic unicycle in the global frame (dynamics_models.py:331-339); q = [x, y, v, psi], u = [F, omega]
+template <int DEG>
+__device__ inline void dev_fc_uni(const Ty<DEG>* q, const Ty<DEG>* u, const FcPre<DEG>& pre, Ty<DEG>* dq) {
+  Ty<DEG> s, c;
+  ty_sincos(q[3], s, c);
+  dq[0] = q[2] * c;
+  dq[1] = q[2] * s;
+  dq[2] = u[0] * pre.im;
+  dq[3] = u[1];
+}
+
 template <int DEG, int NQA>
 __device__ inline void dev_fc(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const Ty<DEG>* q, const Ty<DEG>* u, const FcPre<DEG>& pre, Ty<DEG>* dq) {
-  if constexpr (NQA == 8) dev_fc_dyn<DEG>(P, ag, q, u, pre, dq); else dev_fc_kin<DEG>(P, ag, q, u, pre, dq);
+  if constexpr (NQA == 8) dev_fc_dyn<DEG>(P, ag, q, u, pre, dq);
+  else if constexpr (NQA == 4) dev_fc_uni<DEG>(q, u, pre, dq);
+  else dev_fc_kin<DEG>(P, ag, q, u, pre, dq);
 }
 
 // one discrete step of the joint model's integrator (dynamics_models.py:88-99, :188-219).  The integrator is a template
@@ -491,7 +504,9 @@ __device__ inline void dev_fd_t(const dgsqp_problem_t& P, const dgsqp_agent_t& a
   typedef Ty<DEG> T;
   T x[NQA], k1[NQA], k2[NQA], t[NQA];
   FcPre<DEG> pre;
-  if constexpr (NQA == 8) dev_fc_pre_dyn<DEG>(ag, u, pre); else dev_fc_pre_kin<DEG>(ag, u, pre);
+  if constexpr (NQA == 8) dev_fc_pre_dyn<DEG>(ag, u, pre);
+  else if constexpr (NQA == 4) { pre.im = 1.0 / ag.mass; pre.iz = 0.0; pre.ilr = 0.0; }
+  else dev_fc_pre_kin<DEG>(ag, u, pre);
 #pragma unroll
   for (int i = 0; i < NQA; i++) x[i] = q[i];
   if constexpr (INTEG == DGSQP_INT_EULER) {

@@ -12,6 +12,14 @@ __device__ inline double dev_state_cost(const DgProb& D, int a, XP xk, bool term
   const dgsqp_agent_t& ag = D.P.agents[a];
   const int nq = D.nq, ia = D.qoff[a];
   double J = 0;
+  // goal tracking 1/2 (q - goal)^T diag(w) (q - goal), terminal = mult x stage (merge.py:253-261)
+  for (int i = 0; i < D.nqa[a]; i++)
+    if (ag.w_goal[i] != 0.0) {
+      const double w = (terminal ? ag.goal_term_mult : 1.0) * ag.w_goal[i], dd = xk[ia + i] - ag.goal[i];
+      J += 0.5 * w * dd * dd;
+      if (Dx) Dx[ia + i] += w * dd;
+      if (Dxx) Dxx[(ia + i) * nq + ia + i] += w;
+    }
   for (int b = 0; b < D.M; b++) {
     if (b == a) continue;
     const int ib = D.qoff[b];
@@ -228,6 +236,7 @@ __device__ __noinline__ void dev_rollout_multi(const Ctx& c, clptr ub, clptr du,
     lptr x = j < K1 ? xs + j * xstride : xs2 + (j - K1) * xstride;
     if (all_dyn) dev_rollout_dyn_pair(D, w >> 1, w & 1, ub, du, alpha, x);
     else if (D.nqa[w] == 8) dev_rollout_agent<8>(D, w, ub, du, alpha, x);
+    else if (D.nqa[w] == 4) dev_rollout_agent<4>(D, w, ub, du, alpha, x);
     else dev_rollout_agent<6>(D, w, ub, du, alpha, x);
   }
   __syncthreads();
@@ -291,6 +300,12 @@ __device__ __forceinline__ void dev_taylor_item(const Ctx& c, int a, int k, int 
   if constexpr (DEG >= 2 && NQA == 8 && INTEG != DGSQP_INT_EULER) dev_taylor_item_impl<DEG, NQA, INTEG>(c, a, k, dir, ue);
   else dev_taylor_item_ool<DEG, NQA, INTEG>(c, a, k, dir, ue);
 }
+template <int DEG, int INTEG>
+__device__ __forceinline__ void dev_taylor_item_nqa(const Ctx& c, int nqa, int a, int k, int dir, clptr ue) {
+  if (nqa == 8) dev_taylor_item<DEG, 8, INTEG>(c, a, k, dir, ue);
+  else if (nqa == 4) dev_taylor_item<DEG, 4, INTEG>(c, a, k, dir, ue);
+  else dev_taylor_item<DEG, 6, INTEG>(c, a, k, dir, ue);
+}
 template <int DEG>
 __device__ __noinline__ void dev_dyn_derivs(const Ctx& c, clptr ue) {
   const DgProb& D = dg_prob;
@@ -316,12 +331,11 @@ __device__ __noinline__ void dev_dyn_derivs(const Ctx& c, clptr ue) {
       const int nd = (DEG >= 2) ? D.ndir[a] : D.neff[a];
       for (int it = TID; it < D.N * nd; it += NT) {
         const int k = it / nd, dir = it % nd;
-        const bool dyn = D.nqa[a] == 8;
         switch (D.P.integrator) {
-          case DGSQP_INT_EULER: if (dyn) dev_taylor_item<DEG, 8, DGSQP_INT_EULER>(c, a, k, dir, ue); else dev_taylor_item<DEG, 6, DGSQP_INT_EULER>(c, a, k, dir, ue); break;
-          case DGSQP_INT_RK4: if (dyn) dev_taylor_item<DEG, 8, DGSQP_INT_RK4>(c, a, k, dir, ue); else dev_taylor_item<DEG, 6, DGSQP_INT_RK4>(c, a, k, dir, ue); break;
-          case DGSQP_INT_RK3: if (dyn) dev_taylor_item<DEG, 8, DGSQP_INT_RK3>(c, a, k, dir, ue); else dev_taylor_item<DEG, 6, DGSQP_INT_RK3>(c, a, k, dir, ue); break;
-          default: if (dyn) dev_taylor_item<DEG, 8, DGSQP_INT_RK2>(c, a, k, dir, ue); else dev_taylor_item<DEG, 6, DGSQP_INT_RK2>(c, a, k, dir, ue); break;
+          case DGSQP_INT_EULER: dev_taylor_item_nqa<DEG, DGSQP_INT_EULER>(c, D.nqa[a], a, k, dir, ue); break;
+          case DGSQP_INT_RK4: dev_taylor_item_nqa<DEG, DGSQP_INT_RK4>(c, D.nqa[a], a, k, dir, ue); break;
+          case DGSQP_INT_RK3: dev_taylor_item_nqa<DEG, DGSQP_INT_RK3>(c, D.nqa[a], a, k, dir, ue); break;
+          default: dev_taylor_item_nqa<DEG, DGSQP_INT_RK2>(c, D.nqa[a], a, k, dir, ue); break;
         }
       }
     }
@@ -340,12 +354,11 @@ __device__ __noinline__ void dev_dyn_derivs(const Ctx& c, clptr ue) {
       const int it = rem * 64 + lane;
       if (it < D.N * nd) {
         const int k = it / nd, dir = it % nd;
-        const bool dyn = D.nqa[a] == 8;
         switch (D.P.integrator) {   // one out-of-line instantiation per (model, integrator): registers are allocated per variant
-          case DGSQP_INT_EULER: if (dyn) dev_taylor_item<DEG, 8, DGSQP_INT_EULER>(c, a, k, dir, ue); else dev_taylor_item<DEG, 6, DGSQP_INT_EULER>(c, a, k, dir, ue); break;
-          case DGSQP_INT_RK4: if (dyn) dev_taylor_item<DEG, 8, DGSQP_INT_RK4>(c, a, k, dir, ue); else dev_taylor_item<DEG, 6, DGSQP_INT_RK4>(c, a, k, dir, ue); break;
-          case DGSQP_INT_RK3: if (dyn) dev_taylor_item<DEG, 8, DGSQP_INT_RK3>(c, a, k, dir, ue); else dev_taylor_item<DEG, 6, DGSQP_INT_RK3>(c, a, k, dir, ue); break;
-          default: if (dyn) dev_taylor_item<DEG, 8, DGSQP_INT_RK2>(c, a, k, dir, ue); else dev_taylor_item<DEG, 6, DGSQP_INT_RK2>(c, a, k, dir, ue); break;
+          case DGSQP_INT_EULER: dev_taylor_item_nqa<DEG, DGSQP_INT_EULER>(c, D.nqa[a], a, k, dir, ue); break;
+          case DGSQP_INT_RK4: dev_taylor_item_nqa<DEG, DGSQP_INT_RK4>(c, D.nqa[a], a, k, dir, ue); break;
+          case DGSQP_INT_RK3: dev_taylor_item_nqa<DEG, DGSQP_INT_RK3>(c, D.nqa[a], a, k, dir, ue); break;
+          default: dev_taylor_item_nqa<DEG, DGSQP_INT_RK2>(c, D.nqa[a], a, k, dir, ue); break;
         }
       }
     }
@@ -375,7 +388,7 @@ __device__ __noinline__ void dev_chains(const Ctx& c, clptr ue) {
   __syncthreads();
   for (int it = TID; it < D.n; it += NT) {
     const int a = it / (D.N * DGSQP_NUA);
-    if (D.nqa[a] == 8) dev_chain_item<8>(c, ue, it); else dev_chain_item<6>(c, ue, it);
+    if (D.nqa[a] == 8) dev_chain_item<8>(c, ue, it); else if (D.nqa[a] == 4) dev_chain_item<4>(c, ue, it); else dev_chain_item<6>(c, ue, it);
   }
   __syncthreads();
 }
@@ -409,6 +422,12 @@ __device__ inline void dev_chain_item(const Ctx& c, clptr ue, int it) {
 #pragma unroll
             for (int i = 0; i < nqa; i++) val = (i == dd.idx) ? v[i] : val;  // keeps v[] in registers
             lds[L.gd + dd.off + t0 * DGSQP_NUA + j] = val;
+          }
+        } else if (dd.kind == 2) {
+          if (dd.a == a) {     // lane half-plane: n(p_x) . d p_k / du, the normal is piecewise constant in p_x (merge.py:66-74)
+            const auto& ln = ag.lane[dd.idx];
+            const bool hi = xk[qo] >= ln.brk;
+            lds[L.gd + dd.off + t0 * DGSQP_NUA + j] = (hi ? ln.n_hi[0] : ln.n_lo[0]) * v[0] + (hi ? ln.n_hi[1] : ln.n_lo[1]) * v[1];
           }
         } else if (dd.a == a || dd.b == a) {
           const int ia = D.qoff[dd.a], ib = D.qoff[dd.b];
@@ -463,6 +482,13 @@ __device__ __noinline__ void dev_constraint_values(const Ctx& c, clptr ue) {
       case DG_R_IN_UB: g = ue[am_col(D, R.a, R.k, R.idx)] - ag.in_ub[R.idx]; break;
       case DG_R_IN_LB: g = ag.in_lb[R.idx] - ue[am_col(D, R.a, R.k, R.idx)]; break;
       case DG_R_ST_UB: g = xk[D.qoff[R.a] + R.idx] - ag.st_ub[R.idx]; break;
+      case DG_R_LANE: {
+        const auto& ln = ag.lane[R.idx];
+        const int ia = D.qoff[R.a];
+        const bool hi = xk[ia] >= ln.brk;
+        const double nx = hi ? ln.n_hi[0] : ln.n_lo[0], ny = hi ? ln.n_hi[1] : ln.n_lo[1];
+        g = nx * (xk[ia] - (ln.anchor[0] - ln.r * nx)) + ny * (xk[ia + 1] - (ln.anchor[1] - ln.r * ny));
+      } break;
       default: g = ag.st_lb[R.idx] - xk[D.qoff[R.a] + R.idx]; break;
     }
     LP(L.g)[r] = g;
@@ -739,6 +765,12 @@ __device__ __noinline__ void dev_costates(const Ctx& c, clptr lm) {
     const dgsqp_agent_t& ag = D.P.agents[a];
     const int ia = D.qoff[a];
     // cost part (same terms as dev_state_cost, kept in the compact column form)
+    for (int i = 0; i < D.nqa[a]; i++)
+      if (ag.w_goal[i] != 0.0) {   // weights sit on x, y and the last two states only (checked at create)
+        const double w = (k == N ? ag.goal_term_mult : 1.0) * ag.w_goal[i];
+        Dx[ia + i] += w * (xk[ia + i] - ag.goal[i]);
+        Kl[a * 5 + (i == 0 ? 0 : (i == 1 ? 2 : (i == D.nqa[a] - 1 ? 3 : 4)))] += w;
+      }
     for (int b = 0; b < M; b++) {
       if (b == a) continue;
       const int ib = D.qoff[b];
@@ -791,7 +823,12 @@ __device__ __noinline__ void dev_costates(const Ctx& c, clptr lm) {
           Kl[other * 5 + 0] += 2 * lr; Kl[other * 5 + 2] += 2 * lr;
         }
       } else if (R.type == DG_R_ST_UB) Dx[D.qoff[R.a] + R.idx] += lr;
-      else Dx[D.qoff[R.a] + R.idx] -= lr;
+      else if (R.type == DG_R_LANE) {
+        const auto& ln = D.P.agents[R.a].lane[R.idx];
+        const int ip = D.qoff[R.a];
+        const bool hi = xk[ip] >= ln.brk;
+        Dx[ip] += lr * (hi ? ln.n_hi[0] : ln.n_lo[0]); Dx[ip + 1] += lr * (hi ? ln.n_hi[1] : ln.n_lo[1]);
+      } else Dx[D.qoff[R.a] + R.idx] -= lr;
     }
     for (int i = 0; i < nq; i++) Dxs[(a * (N + 1) + k) * nq + i] = Dx[i];
     for (int i = 0; i < M * 5; i++) Kc[(a * (N + 1) + k) * M * 5 + i] = Kl[i];
@@ -887,13 +924,22 @@ __device__ __noinline__ void dev_hessian_adjoint(const Ctx& c) {
   for (int row = TID; row < n; row += NT) {
     const int a = row / (N * DGSQP_NUA), rem = row % (N * DGSQP_NUA), k0 = rem / DGSQP_NUA, j0 = rem % DGSQP_NUA;
     if (!D.uniform_nqa) {
-      if (D.nqa[a] == 8) dev_hessian_row_generic<8>(c, row, a, k0, j0); else dev_hessian_row_generic<6>(c, row, a, k0, j0);
+      if (D.nqa[a] == 8) dev_hessian_row_generic<8>(c, row, a, k0, j0);
+      else if (D.nqa[a] == 4) dev_hessian_row_generic<4>(c, row, a, k0, j0);
+      else dev_hessian_row_generic<6>(c, row, a, k0, j0);
     } else if (D.nqa[0] == 8) {
       switch (M) {
         case 1: dev_hessian_row<8, 1>(c, row, a, k0, j0); break;
         case 2: dev_hessian_row<8, 2>(c, row, a, k0, j0); break;
         case 3: dev_hessian_row<8, 3>(c, row, a, k0, j0); break;
         default: dev_hessian_row<8, 4>(c, row, a, k0, j0); break;
+      }
+    } else if (D.nqa[0] == 4) {
+      switch (M) {
+        case 1: dev_hessian_row<4, 1>(c, row, a, k0, j0); break;
+        case 2: dev_hessian_row<4, 2>(c, row, a, k0, j0); break;
+        case 3: dev_hessian_row<4, 3>(c, row, a, k0, j0); break;
+        default: dev_hessian_row<4, 4>(c, row, a, k0, j0); break;
       }
     } else {
       switch (M) {

@@ -77,13 +77,16 @@ struct DgProb {
   double eig_floor;    // value given to negative eigenvalues by _nearestPD (par.eig_floor, 1e-10 when not set)
   double qp_dep_tol;   // a row whose projected curvature delta is below qp_dep_tol * (a' P a) counts as dependent on the active rows
   int uniform_nqa;
+  int big;          // the packed inverse P and the packed Householder reflectors live in the workgroup's global scratch (L2)
+                    // instead of LDS: games whose LDS-resident layout exceeds the 160 KB arena
   int ls_spec;      // trial step sizes of _line_search_3 rolled out concurrently (speculation width)
   int ls_spec1;     // how many of them live in the first LDS segment (e_xs); the rest in e_xs2  // every agent uses the same vehicle model (statically indexed fast paths)
   int neff[DGSQP_MAX_AGENTS], ndir[DGSQP_MAX_AGENTS];
   int effvar[DGSQP_MAX_AGENTS][DG_MAXEFF];  // effective variable -> index into z = (q_0..q_{nqa-1}, u_0, u_1)
   int t2off[DGSQP_MAX_AGENTS];              // offset (doubles) of agent block in the Taylor tensor workspace
   int t2k[DGSQP_MAX_AGENTS];                // per-stage stride of that block = nqa*ndir
-  int64_t ws_t2, ws_q, ws_base, ws_H, ws_tang, ws_Y, ws_doubles; // global workspace layout (doubles): Taylor tensor, raw Q, watchdog backups,
+  int64_t t2_doubles;
+  int64_t ws_t2, ws_q, ws_base, ws_H, ws_tang, ws_Y, ws_P, ws_V, ws_doubles; // global workspace layout (doubles): Taylor tensor, raw Q, watchdog backups,
                                                              // costate-contracted dynamics Hessians, tangent trajectories
   DgRow rows[DG_NCMAX];
   DgDense dense[DG_NDMAX];
@@ -98,6 +101,101 @@ struct DgProb {
 #include <cmath>
 #include <cstring>
 #include <string>
+
+// Global workspace and LDS arena of a built problem; falls back to the big layout when the arena overflows.
+static inline std::string dg_build_layout(DgProb& D) {
+  // ---- global workspace (doubles)
+  D.ws_t2 = 0;
+  D.ws_q = D.ws_t2 + D.t2_doubles;
+  D.ws_base = D.ws_q + (int64_t)D.n * D.n;
+  D.ws_H = D.ws_base + 2 * D.n + 2 * D.nc + 16;
+  D.ws_tang = D.ws_H + (int64_t)D.M * D.N * D.M * (DG_MAXEFF * DG_MAXEFF);
+  D.ws_Y = D.ws_tang + (int64_t)(D.N + 1) * DGSQP_MAX_NQA * D.n;   // y_j = P a_j of the QP's active rows
+  D.ws_P = D.ws_Y + (int64_t)D.n * D.n;                              // big mode only: packed P, packed reflectors
+  D.ws_V = D.ws_P + (D.big ? (int64_t)D.n * (D.n + 1) / 2 : 0);
+  D.ws_doubles = D.ws_V + (D.big ? (int64_t)D.n * (D.n + 1) / 2 : 0);
+  D.ws_doubles = (D.ws_doubles + 31) / 32 * 32;
+  // ---- LDS arena
+  DgLds& L = D.L;
+  const int n = D.n, nq = D.nq, nu = D.nu, N = D.N, nc = D.nc, nd = D.ndense;
+  (void)nu;
+  int o = 0;
+  auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
+  L.u = take(n); L.l = take(nc); L.q = take(n); L.g = take(nc); L.d = take(n); L.v = take(n);
+  L.gd = take(D.ngd); L.yd = take(nd); L.red = take(64); L.scal = take(64);
+  L.w_prev = take((n + 2) / 2 + 1);   // final active set of the previous QP of this scenario (warm start)
+  L.w_prev = take((n + 2) / 2 + 1); L.w_prevlam = take(n + 1);
+  L.t_rows = take(nc); L.t_dense = take(2 * nd); L.t_task = take(D.ntask); L.t_track = take(4 * (DGSQP_MAX_SEGS + 1)); L.t_atan = take(10);
+  L.scr = o;
+  // EVAL
+  o = L.scr;
+  L.e_x = take((N + 1) * nq); L.e_ue = take(n);
+  for (int a = 0; a < D.M; a++) { L.e_A[a] = take(N * D.nqa[a] * D.nqa[a]); L.e_B[a] = take(N * D.nqa[a] * DGSQP_NUA); }
+  L.e_dJ = take((N + 1) * nq);
+  L.e_lam = take(D.M * (N + 1) * nq); L.e_Dxs = take(D.M * (N + 1) * nq); L.e_K = take(D.M * (N + 1) * D.M * 5);
+  int eval_end = o;
+  // EIG: packed P, packed Householder reflectors, tridiagonal workspace
+  o = L.scr;
+  const int npk = n * (n + 1) / 2;
+  const int rpt = (n <= 32 ? 32 : (n <= 64 ? 64 : (n <= 100 ? 100 : 128))) / DG_NH;
+  if (!D.big) { L.g_Bp = take(npk); L.g_V = take(npk); } else { L.g_Bp = L.g_V = -1; }
+  L.g_tw = take((5 + DG_NH) * n + 16 + DG_PSD_KMAX * n /* Z */ + 3 * (DG_NH * rpt + 4)
+                + 2 * (DG_BLOCK / 64) * (DG_NH * rpt + 4) /* per-wavefront copies of the reflector v and of w */);
+  // per-wavefront strips of the twisted factorisation (3 n doubles each): the packed-P slot is free until the sweep writes
+  // P at the very end of the phase; tiny problems get their own space
+  const int strips = (DG_BLOCK / 64) * 3 * ((n + 1) & ~1);
+  L.g_strip = (!D.big && strips <= npk) ? L.g_Bp : take(strips);
+  const int eig_end = o;
+  // QP (P aliases Bp)
+  o = L.scr + (D.big ? 0 : ((npk + 1) & ~1));
+  L.p_R = take(npk); L.p_lam = take(n + 1); L.p_c = take(n + 1); L.p_w = take(n + 1); L.p_r = take(n + 1);
+  L.p_y = take(n); L.p_t = take(n); L.p_alist = take((n + 2) / 2 + 1); L.p_rd = take(n + 1); L.p_yd2 = take(nd); L.p_yslot = take((n + 2) / 2 + 1); L.p_yfree = take((n + 2) / 2 + 1); L.p_dpart = take(D.ntask); L.p_act = take(nc / 8 + 2); L.p_part = take(DG_NH * n);
+  const int qp_end = o;
+  // QP outputs live past the end of both the QP and EVAL scratch
+  o = qp_end > eval_end ? qp_end : eval_end;
+  L.o_du = take(n); L.o_lhat = take(nc);
+  const int out_end = o;
+  // LSQR
+  o = L.scr;
+  L.s_u = take(nc); L.s_v = take(nc); L.s_w = take(nc); L.s_x = take(nc); L.s_t = take(nc > n ? nc : n);
+  const int lsqr_end = o;
+  {
+    // give the speculative rollouts the scratch the EIG / QP phases need anyway (the arena does not grow for them)
+    int tot0 = eig_end > out_end ? eig_end : out_end;
+    if (lsqr_end > tot0) tot0 = lsqr_end;
+    const int xsz = ((N + 1) * nq + 1) & ~1;
+    bool all_dyn = true;
+    for (int a = 0; a < D.M; a++) all_dyn = all_dyn && D.nqa[a] == 8;
+    const int lanes_per_traj = all_dyn ? 2 * D.M : D.M;
+    L.e_xs = eval_end > lsqr_end ? eval_end : lsqr_end;   // above everything a trial evaluation / merit touches
+    int K = (L.o_du - L.e_xs) / xsz;                      // must end below the QP outputs (du, lhat are live during trials)
+    if (K > 64 / lanes_per_traj) K = 64 / lanes_per_traj;
+    if (K > 16) K = 16;
+    if (K < 1) K = 0;
+    // second segment above the QP outputs, up to the LDS limit (phase-multiplexed with the EIG workspace)
+    int cap = 64 / lanes_per_traj; if (cap > 16) cap = 16;
+    L.e_xs2 = (out_end + 1) & ~1;
+    int K2 = K > 0 ? (DG_LDS_LIMIT / 8 - L.e_xs2) / xsz : 0;
+    if (K2 > cap - K) K2 = cap - K;
+    if (K2 < 0) K2 = 0;
+    D.ls_spec1 = K;
+    D.ls_spec = K + K2;
+    if (L.e_xs + K * xsz > eval_end) eval_end = L.e_xs + K * xsz;
+    if (K2 > 0 && L.e_xs2 + K2 * xsz > eval_end) eval_end = L.e_xs2 + K2 * xsz;
+  }
+  int tot = eval_end;
+  if (eig_end > tot) tot = eig_end;
+  if (out_end > tot) tot = out_end;
+  if (lsqr_end > tot) tot = lsqr_end;
+  L.total = tot;
+  if ((long)tot * 8 > DG_LDS_LIMIT && !D.big) { D.big = 1; return dg_build_layout(D); }
+  if ((long)tot * 8 > DG_LDS_LIMIT) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "problem needs %ld B of LDS per scenario (limit %d): n=%d n_c=%d", (long)tot * 8, DG_LDS_LIMIT, n, nc);
+    return buf;
+  }
+  return "";
+}
 
 // Build the device-side problem description. Returns empty string on success, else an error message.
 static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_t& par, DgProb& D) {
@@ -222,91 +320,7 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
     }
     D.ntask = nt;
   }
-  // ---- global workspace (doubles)
-  D.ws_t2 = 0;
-  D.ws_q = D.ws_t2 + t2;
-  D.ws_base = D.ws_q + (int64_t)D.n * D.n;
-  D.ws_H = D.ws_base + 2 * D.n + 2 * D.nc + 16;
-  D.ws_tang = D.ws_H + (int64_t)D.M * D.N * D.M * (DG_MAXEFF * DG_MAXEFF);
-  D.ws_Y = D.ws_tang + (int64_t)(D.N + 1) * DGSQP_MAX_NQA * D.n;   // y_j = P a_j of the QP's active rows
-  D.ws_doubles = D.ws_Y + (int64_t)D.n * D.n;
-  D.ws_doubles = (D.ws_doubles + 31) / 32 * 32;
-  // ---- LDS arena
-  DgLds& L = D.L;
-  const int n = D.n, nq = D.nq, nu = D.nu, N = D.N;
-  int o = 0;
-  auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
-  L.u = take(n); L.l = take(nc); L.q = take(n); L.g = take(nc); L.d = take(n); L.v = take(n);
-  L.gd = take(D.ngd); L.yd = take(nd); L.red = take(64); L.scal = take(64);
-  L.w_prev = take((n + 2) / 2 + 1);   // final active set of the previous QP of this scenario (warm start)
-  L.w_prev = take((n + 2) / 2 + 1); L.w_prevlam = take(n + 1);
-  L.t_rows = take(nc); L.t_dense = take(2 * nd); L.t_task = take(D.ntask); L.t_track = take(4 * (DGSQP_MAX_SEGS + 1)); L.t_atan = take(10);
-  L.scr = o;
-  // EVAL
-  o = L.scr;
-  L.e_x = take((N + 1) * nq); L.e_ue = take(n);
-  for (int a = 0; a < D.M; a++) { L.e_A[a] = take(N * D.nqa[a] * D.nqa[a]); L.e_B[a] = take(N * D.nqa[a] * DGSQP_NUA); }
-  L.e_dJ = take((N + 1) * nq);
-  L.e_lam = take(D.M * (N + 1) * nq); L.e_Dxs = take(D.M * (N + 1) * nq); L.e_K = take(D.M * (N + 1) * D.M * 5);
-  int eval_end = o;
-  // EIG: packed P, packed Householder reflectors, tridiagonal workspace
-  o = L.scr;
-  const int npk = n * (n + 1) / 2;
-  const int rpt = (n <= 32 ? 32 : (n <= 64 ? 64 : (n <= 100 ? 100 : 128))) / DG_NH;
-  L.g_Bp = take(npk); L.g_V = take(npk);
-  L.g_tw = take((5 + DG_NH) * n + 16 + DG_PSD_KMAX * n /* Z */ + 3 * (DG_NH * rpt + 4)
-                + 2 * (DG_BLOCK / 64) * (DG_NH * rpt + 4) /* per-wavefront copies of the reflector v and of w */);
-  // per-wavefront strips of the twisted factorisation (3 n doubles each): the packed-P slot is free until the sweep writes
-  // P at the very end of the phase; tiny problems get their own space
-  const int strips = (DG_BLOCK / 64) * 3 * ((n + 1) & ~1);
-  L.g_strip = strips <= npk ? L.g_Bp : take(strips);
-  const int eig_end = o;
-  // QP (P aliases Bp)
-  o = L.scr + ((npk + 1) & ~1);
-  L.p_R = take(npk); L.p_lam = take(n + 1); L.p_c = take(n + 1); L.p_w = take(n + 1); L.p_r = take(n + 1);
-  L.p_y = take(n); L.p_t = take(n); L.p_alist = take((n + 2) / 2 + 1); L.p_rd = take(n + 1); L.p_yd2 = take(nd); L.p_yslot = take((n + 2) / 2 + 1); L.p_yfree = take((n + 2) / 2 + 1); L.p_dpart = take(D.ntask); L.p_act = take(nc / 8 + 2); L.p_part = take(DG_NH * n);
-  const int qp_end = o;
-  // QP outputs live past the end of both the QP and EVAL scratch
-  o = qp_end > eval_end ? qp_end : eval_end;
-  L.o_du = take(n); L.o_lhat = take(nc);
-  const int out_end = o;
-  // LSQR
-  o = L.scr;
-  L.s_u = take(nc); L.s_v = take(nc); L.s_w = take(nc); L.s_x = take(nc); L.s_t = take(nc > n ? nc : n);
-  const int lsqr_end = o;
-  {
-    // give the speculative rollouts the scratch the EIG / QP phases need anyway (the arena does not grow for them)
-    int tot0 = eig_end > out_end ? eig_end : out_end;
-    if (lsqr_end > tot0) tot0 = lsqr_end;
-    const int xsz = ((N + 1) * nq + 1) & ~1;
-    bool all_dyn = true;
-    for (int a = 0; a < D.M; a++) all_dyn = all_dyn && D.nqa[a] == 8;
-    const int lanes_per_traj = all_dyn ? 2 * D.M : D.M;
-    L.e_xs = eval_end > lsqr_end ? eval_end : lsqr_end;   // above everything a trial evaluation / merit touches
-    int K = (L.o_du - L.e_xs) / xsz;                      // must end below the QP outputs (du, lhat are live during trials)
-    if (K > 64 / lanes_per_traj) K = 64 / lanes_per_traj;
-    if (K > 16) K = 16;
-    if (K < 1) K = 0;
-    // second segment above the QP outputs, up to the LDS limit (phase-multiplexed with the EIG workspace)
-    int cap = 64 / lanes_per_traj; if (cap > 16) cap = 16;
-    L.e_xs2 = (out_end + 1) & ~1;
-    int K2 = K > 0 ? (DG_LDS_LIMIT / 8 - L.e_xs2) / xsz : 0;
-    if (K2 > cap - K) K2 = cap - K;
-    if (K2 < 0) K2 = 0;
-    D.ls_spec1 = K;
-    D.ls_spec = K + K2;
-    if (L.e_xs + K * xsz > eval_end) eval_end = L.e_xs + K * xsz;
-    if (K2 > 0 && L.e_xs2 + K2 * xsz > eval_end) eval_end = L.e_xs2 + K2 * xsz;
-  }
-  int tot = eval_end;
-  if (eig_end > tot) tot = eig_end;
-  if (out_end > tot) tot = out_end;
-  if (lsqr_end > tot) tot = lsqr_end;
-  L.total = tot;
-  if ((long)tot * 8 > DG_LDS_LIMIT) {
-    char buf[160];
-    snprintf(buf, sizeof buf, "problem needs %ld B of LDS per scenario (limit %d): n=%d n_c=%d", (long)tot * 8, DG_LDS_LIMIT, n, nc);
-    return buf;
-  }
-  return "";
+  D.t2_doubles = t2;
+  return dg_build_layout(D);
 }
+

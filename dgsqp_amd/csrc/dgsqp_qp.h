@@ -94,6 +94,7 @@ struct QpPtrs {
   lds_i_t *alist, *yslot, *yfree, *prev;
   lds_b_t* act;
   clptr gd, g, Pp;
+  cgptr PpG;   // packed P in the global scratch (big layout), else unused
   gptr Y;
 };
 __device__ inline QpPtrs qp_ptrs(const Ctx& c) {
@@ -106,7 +107,7 @@ __device__ inline QpPtrs qp_ptrs(const Ctx& c) {
   q.scal = lds + L.scal; q.prevlam = lds + L.w_prevlam;
   q.alist = (lds_i_t*)(lds + L.p_alist); q.yslot = (lds_i_t*)(lds + L.p_yslot); q.yfree = (lds_i_t*)(lds + L.p_yfree);
   q.prev = (lds_i_t*)(lds + L.w_prev); q.act = (lds_b_t*)(lds + L.p_act);
-  q.gd = lds + L.gd; q.g = lds + L.g; q.Pp = lds + L.g_Bp;
+  q.gd = lds + L.gd; q.g = lds + L.g; q.Pp = lds + (D.big ? 0 : L.g_Bp); q.PpG = c.ws + D.ws_P;
   q.Y = c.ws + D.ws_Y;
   return q;
 }
@@ -121,8 +122,8 @@ __device__ inline void qp_row_products(const Ctx& c, const QpPtrs& q, int p) {
     const bool has0 = (R.type == DG_R_RATE_UB || R.type == DG_R_RATE_LB) && R.k > 0;
     const double sgn = (R.type == DG_R_IN_UB || R.type == DG_R_RATE_UB) ? 1.0 : -1.0;
     for (int i = TID; i < n; i += NT) {
-      double pv = q.Pp[tri(i, c1)], av = i == c1 ? 1.0 : 0.0;
-      if (has0) { pv -= q.Pp[tri(i, c1 - DGSQP_NUA)]; if (i == c1 - DGSQP_NUA) av = -1.0; }
+      double pv = D.big ? q.PpG[tri(i, c1)] : q.Pp[tri(i, c1)], av = i == c1 ? 1.0 : 0.0;
+      if (has0) { pv -= D.big ? q.PpG[tri(i, c1 - DGSQP_NUA)] : q.Pp[tri(i, c1 - DGSQP_NUA)]; if (i == c1 - DGSQP_NUA) av = -1.0; }
       q.yv[i] = sgn * pv; q.tv[i] = sgn * av;
     }
     __syncthreads();
@@ -283,8 +284,8 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
       const bool has0 = (Rw.type == DG_R_RATE_UB || Rw.type == DG_R_RATE_LB) && Rw.k > 0;
       const double sgn = (Rw.type == DG_R_IN_UB || Rw.type == DG_R_RATE_UB) ? 1.0 : -1.0;
       for (int i = lane; i < n; i += 64) {
-        double pv = q.Pp[tri(i, c1)];
-        if (has0) pv -= q.Pp[tri(i, c1 - DGSQP_NUA)];
+        double pv = D.big ? q.PpG[tri(i, c1)] : q.Pp[tri(i, c1)];
+        if (has0) pv -= D.big ? q.PpG[tri(i, c1 - DGSQP_NUA)] : q.Pp[tri(i, c1 - DGSQP_NUA)];
         q.Y[(int64_t)jj * n + i] = sgn * pv;
       }
     }

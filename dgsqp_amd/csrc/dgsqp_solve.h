@@ -154,7 +154,9 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
   lptr lds = LP(0);
   const int n = D.n;
   if (n > DG_NH * RPT || n > 128 || n < 4) return false;
-  lds_d* Rf = lds + L.g_V;   // Householder reflectors, strict lower triangle packed by columns
+  lds_d* Rf = lds + (D.big ? 0 : L.g_V);   // Householder reflectors, strict lower triangle packed by columns
+  gptr RfG = c.ws + D.ws_V;                // ... in the workgroup's global scratch for games beyond the LDS layout
+  const bool big = D.big != 0;
 #define RFOFF(k) ((k) * (2 * n - (k) - 1) / 2)
   lds_d* Wk = lds + L.g_tw;  // workspace (aliases the packed slot when LDS is tight: P is written there last)
   constexpr int NH = DG_NH;
@@ -221,8 +223,13 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
       if (lane + 64 < m) vfw[k + 1 + lane + 64] = xb;
       if (lane == 0) vfw[k] = 0.0;
       if (wave == 0) {
-        if (lane < m) Rf[RFOFF(k) + lane] = va;
-        if (lane + 64 < m) Rf[RFOFF(k) + lane + 64] = xb;
+        if (big) {
+          if (lane < m) RfG[RFOFF(k) + lane] = va;
+          if (lane + 64 < m) RfG[RFOFF(k) + lane + 64] = xb;
+        } else {
+          if (lane < m) Rf[RFOFF(k) + lane] = va;
+          if (lane + 64 < m) Rf[RFOFF(k) + lane + 64] = xb;
+        }
         if (lane == 0) { dv[k] = cb[k]; ev[k] = alpha; tau[k] = beta; }
       }
     }
@@ -279,6 +286,7 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
     if (jc == n - 1 && i == n - 1) { dv[n - 1] = Br[r]; ev[n - 1] = 0.0; }
     if (jc == n - 2 && i == n - 1) ev[n - 2] = Br[r];
   }
+  if (big) __threadfence_block();
   __syncthreads();
   PROF_END(PH_E_TRI, pt_t);
   // ---- 3. negative eigenvalues of T by Sturm counts.  pp <- e^2
@@ -363,8 +371,14 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
       for (int k = n - 3; k >= 0; k--) {
         const double beta = tau[k];
         if (beta == 0.0) continue;
-        const double va = (lane > k && lane < n) ? Rf[RFOFF(k) + lane - k - 1] : 0.0;
-        const double vb = (lane + 64 > k && lane + 64 < n) ? Rf[RFOFF(k) + lane + 64 - k - 1] : 0.0;
+        double va = 0.0, vb = 0.0;
+        if (big) {
+          if (lane > k && lane < n) va = RfG[RFOFF(k) + lane - k - 1];
+          if (lane + 64 > k && lane + 64 < n) vb = RfG[RFOFF(k) + lane + 64 - k - 1];
+        } else {
+          if (lane > k && lane < n) va = Rf[RFOFF(k) + lane - k - 1];
+          if (lane + 64 > k && lane + 64 < n) vb = Rf[RFOFF(k) + lane + 64 - k - 1];
+        }
         double dt = wave_sum(va * za + vb * zb);
         dt *= beta;
         za -= dt * va; zb -= dt * vb;
@@ -434,11 +448,21 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
     }
     __syncthreads();
   }
-  lds_d* Pp = lds + L.g_Bp;
+  if (big) {
+    gptr Pp = c.ws + D.ws_P;
 #pragma unroll
-  for (int r = 0; r < RPT; r++) {
-    const int i = hf + NH * r;
-    if (colok && i < n && i >= jc) Pp[i * (i + 1) / 2 + jc] = -Br[r];
+    for (int r = 0; r < RPT; r++) {
+      const int i = hf + NH * r;
+      if (colok && i < n && i >= jc) Pp[i * (i + 1) / 2 + jc] = -Br[r];
+    }
+    __threadfence_block();
+  } else {
+    lds_d* Pp = lds + L.g_Bp;
+#pragma unroll
+    for (int r = 0; r < RPT; r++) {
+      const int i = hf + NH * r;
+      if (colok && i < n && i >= jc) Pp[i * (i + 1) / 2 + jc] = -Br[r];
+    }
   }
   __syncthreads();
   PROF_END(PH_PFORM, pt_s);
@@ -458,9 +482,9 @@ __device__ inline void dev_psd_inverse(const Ctx& c, gptr Qpd) {
 
 // out = scale * P t  (P packed symmetric in LDS).  Every row is split over NSEG threads, each with four independent
 // accumulators so that the LDS reads of a segment are in flight together; the partial sums meet in LDS.
-__device__ inline void dev_p_mul(const Ctx& c, clptr t, lptr out, double scale) {
+template <class PT>
+__device__ inline void dev_p_mul_t(PT Pp, clptr t, lptr out, double scale) {
   const DgProb& D = dg_prob;
-  clptr Pp = LP(D.L.g_Bp);
   lptr part = LP(D.L.p_part);  // NSEG x n partial sums
   const int n = D.n;
   constexpr int NSEG = NT / 128;
@@ -472,7 +496,7 @@ __device__ inline void dev_p_mul(const Ctx& c, clptr t, lptr out, double scale) 
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     // columns j <= i come from row i of the packed lower triangle (contiguous), j > i from column i (stride j)
     const int split = (i + 1 < j1) ? ((i + 1 > j0) ? i + 1 : j0) : j1;
-    clptr row = Pp + i * (i + 1) / 2;
+    const PT row = Pp + i * (i + 1) / 2;
     int j = j0;
     for (; j + 3 < split; j += 4) {
       a0 += row[j] * t[j]; a1 += row[j + 1] * t[j + 1]; a2 += row[j + 2] * t[j + 2]; a3 += row[j + 3] * t[j + 3];
@@ -495,6 +519,11 @@ __device__ inline void dev_p_mul(const Ctx& c, clptr t, lptr out, double scale) 
     out[TID] = scale * s;
   }
   __syncthreads();
+}
+
+__device__ inline void dev_p_mul(const Ctx& c, clptr t, lptr out, double scale) {
+  if (dg_prob.big) dev_p_mul_t<cgptr>(c.ws + dg_prob.ws_P, t, out, scale);
+  else dev_p_mul_t<clptr>(LP(dg_prob.L.g_Bp), t, out, scale);
 }
 
 // coefficient of constraint row r at column col

@@ -18,9 +18,9 @@ from typing import List
 import numpy as np
 
 from .dynamics import (CasadiDecoupledMultiAgentDynamicsModel, CasadiDynamicBicycleCombined,
-                       CasadiKinematicBicycleCombined, DynamicBicycleConfig, KinematicBicycleConfig,
-                       MultiAgentModelConfig)
-from .game import CollisionAvoidance, InputRateLimits, RacingCost
+                       CasadiKinematicBicycleCombined, CasadiKinematicUnicycle, DynamicBicycleConfig,
+                       KinematicBicycleConfig, MultiAgentModelConfig, UnicycleConfig)
+from .game import (CollisionAvoidance, GoalTrackingCost, InputRateLimits, LaneBoundaries, LaneHalfPlane, RacingCost)
 from .solver_types import DGSQPParams
 from .tracks import ChicaneTrack, CurveTrack, get_track
 from .types import (BodyAngularVelocity, BodyLinearVelocity, OrientationEuler, ParametricPose, Position,
@@ -142,6 +142,39 @@ def barc_racing_game(N=15, M=2, reg=0.0) -> Game:
                 name=f'kb_barc_M{M}_N{N}', sampler='circuit')
 
 
+def merge_game(N=20, reg=0.0) -> Game:
+    """Three-car highway merge of scripts/DGSQP_merge_monte_carlo.py: kinematic unicycles (rk3, one sub-step, dt 0.1,
+    :95-123), two cars on the straight lane and one on the ramp (lane geometry :40-74), goal-tracking costs (:253-303),
+    lane rows at every stage (:316-342), obstacle rows from k=1 (:344-356), |v| <= 2, |F| <= 2, |omega| <= 4.5 (:126-159),
+    radii 0.1 (:162-164), solver parameters with reg=0 (:176-190).  No warm start: the script solves from zero inputs."""
+    dt = 0.1
+    cfg = lambda: UnicycleConfig(dt=dt, model_name='kinematic_bicycle', noise=False, discretization_method='rk3', code_gen=False, M=1)
+    models = [CasadiKinematicUnicycle(0, cfg()) for _ in range(3)]
+    joint = CasadiDecoupledMultiAgentDynamicsModel(0, models, MultiAgentModelConfig(
+        dt=dt, discretization_method='rk3', use_mx=False, code_gen=False, verbose=True, compute_hessians=True, M=1))
+    lw, mw, mp, th, r = 0.3, 0.3, 1.5, np.pi / 12, 0.1
+    ns, nm = (0.0, 1.0), (-np.sin(th), np.cos(th))
+    x1, x3 = (0.0, lw), (0.0, 0.0)
+    x6 = (mp + lw / np.tan(th), lw)
+    x7 = (mp + mw / np.sin(th), 0.0)
+    neg = lambda v: (-v[0], -v[1])
+    straight = lambda: LaneBoundaries([LaneHalfPlane(n_lo=ns, anchor=x1, r=r), LaneHalfPlane(n_lo=neg(ns), anchor=x3, r=r)])
+    ramp = LaneBoundaries([LaneHalfPlane(n_lo=nm, n_hi=ns, brk=x6[0], anchor=x6, r=r),
+                           LaneHalfPlane(n_lo=neg(nm), n_hi=neg(ns), brk=x7[0], anchor=x7, r=r)])
+    goals = ((4.0, 0.15, 0.3, 0.0), (4.5, 0.15, 0.3, 0.0), (4.25, 0.15, 0.3, 0.0))
+    costs = [GoalTrackingCost(input_weight=(0.1, 0.1), state_weight=(1.0, 10.0, 1.0, 1.0), goal=g, terminal_multiplier=10.0)
+             for g in goals]
+    inf = np.inf
+    ub = [VehicleState(x=Position(x=inf, y=inf), e=OrientationEuler(psi=inf), v=BodyLinearVelocity(v_long=2.0, v_tran=inf),
+                       w=BodyAngularVelocity(w_psi=inf), u=VehicleActuation(u_a=2.0, u_steer=4.5)) for _ in range(3)]
+    lb = [VehicleState(x=Position(x=-inf, y=-inf), e=OrientationEuler(psi=-inf), v=BodyLinearVelocity(v_long=-2.0, v_tran=-inf),
+                       w=BodyAngularVelocity(w_psi=-inf), u=VehicleActuation(u_a=-2.0, u_steer=-4.5)) for _ in range(3)]
+    params = DGSQPParams(solver_name='DGSQP', dt=dt, N=N, reg=reg, merit_function='stat_l1', nonmono_ls=True,
+                         line_search_iters=50, sqp_iters=50, p_tol=1e-3, d_tol=1e-3, beta=0.01, tau=0.5, verbose=False)
+    return Game(joint, costs, [straight(), straight(), ramp], CollisionAvoidance([0.1] * 3), {'ub': ub, 'lb': lb}, params,
+                None, 0.0, 0.2, name=f'merge_N{N}', sampler='merge')
+
+
 # ---------------------------------------------------------------------------------------------
 # vectorised plant for the PID warm start
 # ---------------------------------------------------------------------------------------------
@@ -232,6 +265,8 @@ def sample_scenarios(game: Game, B: int, seed: int = 1, max_rounds: int = 200, s
     device (``dgsqp_pid_warm_start_batch``); the random draws are the same either way."""
     if game.sampler == 'circuit':
         return _sample_scenarios_circuit(game, B, seed, max_rounds)
+    if game.sampler == 'merge':
+        return _sample_scenarios_merge(game, B, seed)
     if game.joint_model.n_a != 2:
         return _sample_scenarios_independent(game, B, seed, max_rounds)
     rng = np.random.default_rng(seed)
@@ -372,3 +407,38 @@ def _sample_scenarios_circuit(game: Game, B: int, seed: int, max_rounds: int):
     if x0.shape[0] < B:
         raise RuntimeError('sampler did not produce enough collision-free scenarios')
     return np.ascontiguousarray(x0), np.ascontiguousarray(u)
+
+
+def _sample_scenarios_merge(game: Game, B: int, seed: int):
+    """Sampler of scripts/DGSQP_merge_monte_carlo.py:421-480 (seed 1 there): cars 1 and 2 around x = 0 / 0.5 on the straight
+    lane, car 3 on the ramp; zero warm start; rejection if the zero-input trajectories collide.  The script leaves car 3's
+    check trajectory at the origin (``car2_q_ws[0]`` is assigned twice, :471-472) -- reproduced, it decides which samples pass."""
+    rng = np.random.default_rng(seed)
+    N = game.params.N
+    models = game.joint_model.dynamics_models
+    radii = list(game.shared_constraints.radii)
+    mw, mp, th = 0.3, 1.5, np.pi / 12
+    x5, x7 = mp, mp + mw / np.sin(th)
+    out = []
+    while len(out) < B:
+        q = []
+        for x_nom in (0.0, 0.5):
+            q.append(np.array([x_nom + 0.5 * rng.random() - 0.25, 0.15 + 0.1 * rng.random() - 0.05,
+                               0.3 * (1 + 0.06 * rng.random() - 0.03), (5 * rng.random() - 2.5) * np.pi / 180]))
+        x_nom, y_nom = 0.25, -((x7 + x5) / 2 - 0.25) * np.tan(th)
+        s_rand, ey_rand = 0.5 * rng.random() - 0.25, 0.1 * rng.random() - 0.05
+        q.append(np.array([x_nom + s_rand * np.cos(th) - ey_rand * np.sin(th), y_nom + s_rand * np.sin(th) + ey_rand * np.cos(th),
+                           0.3 * (1 + 0.06 * rng.random() - 0.03), np.pi / 12 + (5 * rng.random() - 2.5) * np.pi / 180]))
+        traj = []
+        for a, mdl in enumerate(models):
+            qa = [q[a].copy() if a < 2 else np.zeros(4)]
+            for _ in range(N):
+                qa.append(mdl.fd(qa[-1], np.zeros(2)))
+            traj.append(np.array(qa))
+        hit = False
+        for i in range(3):
+            for j in range(i + 1, 3):
+                hit |= bool((np.linalg.norm(traj[i][:, :2] - traj[j][:, :2], axis=1) < radii[i] + radii[j]).any())
+        if not hit:
+            out.append(np.concatenate(q))
+    return np.ascontiguousarray(np.array(out)), np.zeros((B, N, 6))

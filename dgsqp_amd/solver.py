@@ -177,6 +177,7 @@ def problem_dims(P: _ffi.ProblemT):
             n_c += pairs
         for a in range(M):
             A = P.agents[a]
+            n_c += A.n_lane                      # lane rows sit at every stage, k = 0 and k = N included
             if k < N:
                 n_c += (4 if A.has_rate else 0) + sum(A.in_ub[j] < np.inf for j in range(2)) + sum(A.in_lb[j] > -np.inf for j in range(2))
             if k > 0:
