@@ -500,10 +500,10 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
   if (TID == 0) q.scal[1] = (double)S.m;
   __syncthreads();
   const int m = (int)q.scal[1];
-  // reg = 0 regime: the polished point holds its active rows to ~1e-9 only.  The input-box rows are linear in u, the next
-  // linearisation sees exactly these residuals, and _get_mu switches on their sign (DGSQP.py:566-585): put du on the active
-  // bounds exactly, as an exact active-set solution is.
-  if (ret == 0 && q.scal[2] != 0.0) {
+  // The exact minimiser sits ON its active input bounds; the polished point holds them to rounding distance (to ~1e-9 in
+  // the reg = 0 regime).  These rows are linear in u, the next linearisation inherits exactly that residual and _get_mu
+  // switches on its sign (DGSQP.py:566-585): put du on the active bounds (the oracle does the same).
+  if (ret == 0) {
     for (int j = TID; j < m; j += NT) {
       const int r = q.alist[j];
       const DgRow Rw = ld_row(r);

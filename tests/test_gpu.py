@@ -491,6 +491,45 @@ def test_reg0_games_track_the_oracle(oracle, kind):
         assert rel(res['u'][b], ref['u'][b]) < 1e-4 and rel(res['l'][b], ref['l'][b]) < 1e-3
 
 
+def test_big_layout_and_merge_game(oracle):
+    """Games beyond the LDS-resident layout keep the packed inverse and the reflectors in the workgroup's L2 scratch
+    (n up to 128): KB curve N=30 (n=120) and the three-car merge of scripts/DGSQP_merge_monte_carlo.py at its own
+    horizon N=20 (unicycles, goal-tracking costs, lane rows, reg=0) against the oracle."""
+    from dgsqp_amd.montecarlo import kinematic_racing_game, merge_game, sample_scenarios
+    from dgsqp_amd.solver import DGSQP, build_problem, build_params
+    import dgsqp_amd.solver as sv
+    for g, B, noise in ((kinematic_racing_game('curve', N=30), 24, 0.01), (merge_game(N=20), 32, 0.05), (merge_game(N=12), 16, 0.05)):
+        N, M = g.params.N, g.joint_model.n_a
+        P, par = build_problem(*g.solver_args()), tight_lsqr(build_params(g.params))
+        orig = sv.build_params
+        sv.build_params = lambda p: tight_lsqr(orig(p))
+        try:
+            s = DGSQP(*g.solver_args(), print_method=None)
+        finally:
+            sv.build_params = orig
+        assert s.dims.lds_bytes <= 163840
+        x0, u_tm = sample_scenarios(g, B, seed=1)
+        u = agent_major(u_tm)
+        rng = np.random.default_rng(1)
+        up = u + noise * rng.standard_normal(u.shape)
+        l = np.maximum(0, rng.standard_normal((B, s.n_c_total)))
+        ev = s.evaluate_batch(x0[:4], up[:4], l[:4])
+        for b in range(4):
+            o = oracle.evaluate(P, x0[b], up[b], l[b], 1)
+            for key in ('x', 'q', 'g', 'G', 'Q'):
+                assert rel(ev[key][b], o[key]) < 1e-11, (g.name, key, b)
+        res = s.solve_batch(x0, u_tm)
+        ref = oracle.solve_batch(P, par, x0, u, nthreads=8)
+        same = (res['status'] == ref['status']) & (res['num_iters'] == ref['num_iters']) & (res['qp_solves'] == ref['qp_solves'])
+        assert same.mean() >= 0.85, (g.name, same.mean())
+        for b in np.where(same & (ref['status'] <= 1))[0]:
+            assert rel(res['u'][b], ref['u'][b]) < 1e-5 and rel(res['l'][b], ref['l'][b]) < 1e-4, (g.name, b)
+        if M == 3:
+            assert (res['status'] <= 1).all()
+            with pytest.raises(RuntimeError):
+                s.pid_warm_start_batch(x0)
+
+
 def test_large_batch_equals_small_batches(games):
     """Every scenario of a 3,500-scenario launch (14 per workgroup, dynamic ticket order) comes out exactly as in a small
     launch: no state leaks between the scenarios a workgroup processes (warm-started active sets, trajectory tags)."""

@@ -61,7 +61,7 @@ def test_integrators_agree_in_the_small_step_limit(oracle, games):
 # ---------------------------------------------------------------------------------------------
 # _evaluate: G, q, Q against finite differences of g, J^a and grad_{u^a} L^a   
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('name', ['kb_chicane_N15', 'dyn_curve_N15'])
+@pytest.mark.parametrize('name', ['kb_chicane_N15', 'dyn_curve_N15', 'merge_N8'])
 def test_evaluate_against_finite_differences(oracle, games, name):
     from dgsqp_amd.montecarlo import sample_scenarios
     g, P, par = games[name]
@@ -69,7 +69,7 @@ def test_evaluate_against_finite_differences(oracle, games, name):
     n, nc = d['n'], d['nc']
     x0, u_tm = sample_scenarios(g, 1, seed=5)
     rng = np.random.default_rng(1)
-    u = agent_major(u_tm)[0] + 0.01 * rng.standard_normal(n)
+    u = agent_major(u_tm)[0] + (0.3 if name.startswith('merge') else 0.01) * rng.standard_normal(n)   # merge starts from zero inputs
     l = np.maximum(0, rng.standard_normal(nc))
     ev = oracle.evaluate(P, x0[0], u, l, hessian=1)
     lit = oracle.evaluate(P, x0[0], u, l, hessian=2)            # literal per-row DP (DGSQP.py:829-877)
@@ -92,7 +92,39 @@ def test_evaluate_against_finite_differences(oracle, games, name):
     assert np.abs(Gfd - ev['G']).max() < 1e-6 * max(1, np.abs(ev['G']).max())
     assert np.abs(qfd - ev['q']).max() < 1e-6 * max(1, np.abs(ev['q']).max())
     assert np.abs(Qfd - ev['Q']).max() < 2e-6 * max(1, np.abs(ev['Q']).max())
-    assert np.abs(ev['Q'] - ev['Q'].T).max() > 1e-3        # the game Hessian is NOT symmetric
+    if not name.startswith('merge'):                       # (the merge game's costs are decoupled: a potential game)
+        assert np.abs(ev['Q'] - ev['Q'].T).max() > 1e-3    # the game Hessian is NOT symmetric
+
+
+def test_unicycle_and_merge_rows(oracle, games):
+    """Kinematic unicycle (dynamics_models.py:331-339) and the merge game's row layout (merge.py:316-356): 18 / 27 / 15 rows
+    per stage for three cars (36 / 63 / 39 for six), lane rows at k = 0 with a zero gradient."""
+    from dgsqp_amd.montecarlo import sample_scenarios
+    g, P, par = games['merge_N8']
+    mdl = g.joint_model.dynamics_models[0]
+    rng = np.random.default_rng(0)
+    q, u = np.array([0.3, 0.1, 0.4, 0.2]), np.array([0.5, -0.7])
+    dq, qn, J, H = oracle.dynamics(P, 0, q, u)
+    np.testing.assert_allclose(dq, mdl.fc(q, u), rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(qn, mdl.fd(q, u), rtol=1e-13, atol=1e-15)          # rk3, one sub-step (:200-211)
+    eps = 1e-6
+    for i in range(6):
+        z = np.concatenate([q, u]); zp, zm = z.copy(), z.copy(); zp[i] += eps; zm[i] -= eps
+        fp, fm = oracle.dynamics(P, 0, zp[:4], zp[4:])[1], oracle.dynamics(P, 0, zm[:4], zm[4:])[1]
+        np.testing.assert_allclose(J[:, i], (fp - fm) / (2 * eps), rtol=1e-6, atol=1e-8)
+    rows = oracle.rows(P)
+    per_stage = np.bincount(rows[:, 1], minlength=9)
+    assert per_stage[0] == 18 and (per_stage[1:8] == 27).all() and per_stage[8] == 15 and len(rows) == 18 + 7 * 27 + 15
+    x0, u_tm = sample_scenarios(g, 4, seed=1)
+    assert np.all(u_tm == 0)
+    ev = oracle.evaluate(P, x0[0], agent_major(u_tm)[0], None, 0)
+    k0 = np.where(rows[:, 1] == 0)[0]
+    lanes0 = [r for r in k0 if rows[r, 0] == 7]
+    assert len(lanes0) == 6 and np.all(ev['G'][lanes0] == 0) and np.all(ev['g'][lanes0] < 0)
+    l0 = oracle.dual_init(P, par, x0[0], agent_major(u_tm)[0])                  # G G^T is singular: min-norm LSQR solution
+    assert np.all(np.isfinite(l0)) and np.all(l0[lanes0] == 0)
+    res = oracle.solve_batch(P, par, x0, agent_major(u_tm))
+    assert np.all(res['status'] <= 1) and np.all(res['num_iters'] < 30)
 
 
 def test_constraint_row_order_and_counts(oracle, games):

@@ -35,10 +35,14 @@ sv.build_params = lambda p: tight(orig(p))
 s = DGSQP(*g.solver_args(), print_method=None)
 sv.build_params = orig
 x0, u_tm = mc.sample_scenarios(g, B, seed=0 if kind.startswith('barc') else 1)
+if kind == 'merge':
+    up_noise = 0.05
+else:
+    up_noise = 0.01
 nua = 2
 u = np.ascontiguousarray(u_tm.reshape(B, N, M, nua).transpose(0, 2, 1, 3).reshape(B, -1))
 rng = np.random.default_rng(1)
-up = u + 0.01 * rng.standard_normal(u.shape)
+up = u + up_noise * rng.standard_normal(u.shape)
 l = np.maximum(0, rng.standard_normal((B, s.n_c_total)))
 ev = s.evaluate_batch(x0[:8], up[:8], l[:8])
 rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / (1e-300 + np.max(np.abs(b))))
