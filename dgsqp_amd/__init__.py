@@ -3,9 +3,10 @@ zhu-edward/DGSQP behind the reference's DGSQPParams / solve() surface)."""
 from .solver_types import DGSQPParams, PIDParams  # noqa: F401
 from .types import (VehicleState, VehiclePrediction, VehicleActuation, Position, ParametricPose,  # noqa: F401
                     OrientationEuler, BodyLinearVelocity, BodyAngularVelocity)
-from .game import RacingCost, InputRateLimits, CollisionAvoidance  # noqa: F401
-from .dynamics import (KinematicBicycleConfig, DynamicBicycleConfig, MultiAgentModelConfig,  # noqa: F401
-                       CasadiKinematicBicycleCombined, CasadiDynamicBicycleCombined,
+from .game import (RacingCost, InputRateLimits, CollisionAvoidance, GoalTrackingCost, LaneBoundaries,  # noqa: F401
+                   LaneHalfPlane)
+from .dynamics import (KinematicBicycleConfig, DynamicBicycleConfig, UnicycleConfig, MultiAgentModelConfig,  # noqa: F401
+                       CasadiKinematicBicycleCombined, CasadiDynamicBicycleCombined, CasadiKinematicUnicycle,
                        CasadiDecoupledMultiAgentDynamicsModel)
 from .tracks import CurveTrack, ChicaneTrack, StraightTrack, RadiusArclengthTrack, get_track  # noqa: F401
 
