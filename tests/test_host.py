@@ -227,3 +227,35 @@ def test_barc_circuit_game_and_sampler():
     assert np.all(np.linalg.norm(x0[:, :2] - x0[:, 6:8], axis=1) >= 0.4)
     g3 = barc_racing_game(N=15, M=3)
     assert problem_dims(build_problem(*g3.solver_args())) == (18, 6, 90, 495)     # 24 / 33 / 9 rows per stage
+
+
+def test_result_records_match_the_post_processing_readers(tmp_path):
+    """scripts/process_data_curve.py:44-53 reads solve_info['status'|'msg'|'cond']['p_feas'|'num_iters'|'time'|'iter_data'];
+    the records written from a solve_batch result carry exactly those (checked by replaying the reader's loop)."""
+    import pickle
+    from dgsqp_amd.results import save_monte_carlo, summarize_like_process_data
+    from dgsqp_amd.solver_types import DGSQPParams
+    from dgsqp_amd import _ffi
+    status = np.array([0, 1, 2, 4, 0], np.int32)
+    res = dict(status=status, msg=[_ffi.STATUS_MSG[s] for s in status], num_iters=np.array([7, 12, 50, 3, 9], np.int32),
+               qp_solves=np.array([7, 15, 80, 4, 9], np.int32), cond=np.arange(15.0).reshape(5, 3) * 1e-4,
+               cost=np.ones((5, 2)), u=np.zeros((5, 4)), l=np.zeros((5, 6)))
+    path = tmp_path / 'data_c_45_N_25.pkl'
+    save_monte_carlo(path, res, DGSQPParams(N=25), wall_time=0.5)
+    data = pickle.load(open(path, 'rb'))
+    recs = data['sqgames']
+    n_conv, n_max, n_div, iters, solves = 0, 0, 0, [], []
+    for r in recs:                                   # the reader's loop
+        si = r['solve_info']
+        if si['status']:
+            n_conv += 1
+            solves.append(np.sum([d['qp_solves'] for d in si['iter_data']]))
+            iters.append(si['num_iters'])
+            assert si['time'] == pytest.approx(0.1) and si['cond']['p_feas'] >= 0
+        if si['msg'] == 'max_it':
+            n_max += 1
+        elif si['msg'] in ('diverged', 'qp_fail'):
+            n_div += 1
+    assert (n_conv, n_max, n_div) == (3, 1, 1) and np.mean(iters) == pytest.approx(28 / 3) and np.mean(solves) == pytest.approx(31 / 3)
+    s = summarize_like_process_data(recs)
+    assert (s['converged'], s['max_it'], s['failed']) == (3, 1, 1) and s['avg_solves'] == pytest.approx(31 / 3)
