@@ -75,7 +75,7 @@ class PidT(C.Structure):
 class DimsT(C.Structure):
     _fields_ = [('M', C.c_int32), ('N', C.c_int32), ('n_q', C.c_int32), ('n_u', C.c_int32), ('n', C.c_int32),
                 ('n_c', C.c_int32), ('n_dense', C.c_int32), ('lds_bytes', C.c_int32),
-                ('workspace_bytes', C.c_int64)]
+                ('workspace_bytes', C.c_int64), ('layout', C.c_int32), ('reserved_', C.c_int32)]
 
 
 class TimingT(C.Structure):
@@ -112,6 +112,8 @@ def load_library() -> C.CDLL:
     lib.dgsqp_destroy.restype = None
     lib.dgsqp_dims.argtypes = [H, C.POINTER(DimsT)]
     lib.dgsqp_dims.restype = C.c_int
+    lib.dgsqp_plan.argtypes = [C.POINTER(ProblemT), C.POINTER(ParamsT), C.POINTER(DimsT), C.c_char_p, C.c_int]
+    lib.dgsqp_plan.restype = C.c_int
     lib.dgsqp_last_error.argtypes = [H]
     lib.dgsqp_last_error.restype = C.c_char_p
     lib.dgsqp_backend_info.argtypes = [C.c_char_p, C.c_int]
@@ -144,7 +146,7 @@ def load_library() -> C.CDLL:
     return lib
 
 
-EXPORTED_SYMBOLS = ['dgsqp_create', 'dgsqp_destroy', 'dgsqp_dims', 'dgsqp_last_error', 'dgsqp_backend_info',
+EXPORTED_SYMBOLS = ['dgsqp_create', 'dgsqp_destroy', 'dgsqp_dims', 'dgsqp_plan', 'dgsqp_last_error', 'dgsqp_backend_info',
                     'dgsqp_solve_batch', 'dgsqp_stage_inputs', 'dgsqp_solve_staged', 'dgsqp_fetch_results',
                     'dgsqp_evaluate_batch', 'dgsqp_qp_batch', 'dgsqp_set_trace', 'dgsqp_fetch_trace',
                     'dgsqp_pid_warm_start_batch', 'dgsqp_launch_staged', 'dgsqp_wait', 'dgsqp_draining']

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "dgsqp_solve.h"
+#include "dgsqp_xl.h"
 
 
 // ------------------------------------------------------------------------------------------------
@@ -297,6 +298,20 @@ int dgsqp_dims(dgsqp_handle_t h, dgsqp_dims_t* out) {
   const DgProb& D = h->hp;
   out->M = D.M; out->N = D.N; out->n_q = D.nq; out->n_u = D.nu; out->n = D.n; out->n_c = D.nc;
   out->n_dense = D.ndense; out->lds_bytes = (int32_t)h->lds_bytes; out->workspace_bytes = D.ws_doubles * (int64_t)sizeof(double);
+  out->layout = D.big; out->reserved_ = 0;
+  return DGSQP_OK;
+}
+
+int dgsqp_plan(const dgsqp_problem_t* prob, const dgsqp_params_t* par, dgsqp_dims_t* out, char* msg, int msglen) {
+  if (!prob || !par || !out) return DGSQP_E_ARG;
+  static DgProb D;     // ~100 KB: not on the stack (single-threaded helper, like dgsqp_create)
+  const std::string err = dg_build(*prob, *par, D);
+  if (msg && msglen > 0) snprintf(msg, msglen, "%s", err.c_str());
+  memset(out, 0, sizeof(*out));
+  out->M = D.M; out->N = D.N; out->n_q = D.nq; out->n_u = D.nu; out->n = D.n; out->n_c = D.nc;
+  out->n_dense = D.ndense; out->lds_bytes = D.L.total * 8; out->workspace_bytes = D.ws_doubles * (int64_t)sizeof(double);
+  out->layout = D.big;
+  if (!err.empty()) return err.find("LDS") != std::string::npos || err.find("not supported yet") != std::string::npos ? DGSQP_E_TOO_LARGE : DGSQP_E_ARG;
   return DGSQP_OK;
 }
 

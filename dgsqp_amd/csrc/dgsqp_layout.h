@@ -77,7 +77,7 @@ struct DgProb {
   double eig_floor;    // value given to negative eigenvalues by _nearestPD (par.eig_floor, 1e-10 when not set)
   double qp_dep_tol;   // a row whose projected curvature delta is below qp_dep_tol * (a' P a) counts as dependent on the active rows
   int uniform_nqa;
-  int big;          // the packed inverse P and the packed Householder reflectors live in the workgroup's global scratch (L2)
+  int big;          // 2: XL layout (n > 128, dgsqp_xl.h).  1: the packed inverse P and the packed Householder reflectors live in the workgroup's global scratch (L2)
                     // instead of LDS: games whose LDS-resident layout exceeds the 160 KB arena
   int ls_spec;      // trial step sizes of _line_search_3 rolled out concurrently (speculation width)
   int ls_spec1;     // how many of them live in the first LDS segment (e_xs); the rest in e_xs2  // every agent uses the same vehicle model (statically indexed fast paths)
@@ -86,7 +86,7 @@ struct DgProb {
   int t2off[DGSQP_MAX_AGENTS];              // offset (doubles) of agent block in the Taylor tensor workspace
   int t2k[DGSQP_MAX_AGENTS];                // per-stage stride of that block = nqa*ndir
   int64_t t2_doubles;
-  int64_t ws_t2, ws_q, ws_base, ws_H, ws_tang, ws_Y, ws_P, ws_V, ws_doubles; // global workspace layout (doubles): Taylor tensor, raw Q, watchdog backups,
+  int64_t ws_t2, ws_q, ws_base, ws_H, ws_tang, ws_Y, ws_P, ws_V, ws_R, ws_doubles; // global workspace layout (doubles): Taylor tensor, raw Q, watchdog backups,
                                                              // costate-contracted dynamics Hessians, tangent trajectories
   DgRow rows[DG_NCMAX];
   DgDense dense[DG_NDMAX];
@@ -111,9 +111,11 @@ static inline std::string dg_build_layout(DgProb& D) {
   D.ws_H = D.ws_base + 2 * D.n + 2 * D.nc + 16;
   D.ws_tang = D.ws_H + (int64_t)D.M * D.N * D.M * (DG_MAXEFF * DG_MAXEFF);
   D.ws_Y = D.ws_tang + (int64_t)(D.N + 1) * DGSQP_MAX_NQA * D.n;   // y_j = P a_j of the QP's active rows
-  D.ws_P = D.ws_Y + (int64_t)D.n * D.n;                              // big mode only: packed P, packed reflectors
-  D.ws_V = D.ws_P + (D.big ? (int64_t)D.n * (D.n + 1) / 2 : 0);
-  D.ws_doubles = D.ws_V + (D.big ? (int64_t)D.n * (D.n + 1) / 2 : 0);
+  D.ws_P = D.ws_Y + (int64_t)D.n * D.n;                              // big layout: packed P, packed reflectors;
+  const int64_t matsz = D.big == 2 ? (int64_t)D.n * D.n : (D.big ? (int64_t)D.n * (D.n + 1) / 2 : 0);   // XL: three full matrices
+  D.ws_V = D.ws_P + matsz;
+  D.ws_R = D.ws_V + matsz;
+  D.ws_doubles = D.ws_R + (D.big == 2 ? matsz + 4 * D.n : 0);
   D.ws_doubles = (D.ws_doubles + 31) / 32 * 32;
   // ---- LDS arena
   DgLds& L = D.L;
@@ -123,8 +125,7 @@ static inline std::string dg_build_layout(DgProb& D) {
   auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
   L.u = take(n); L.l = take(nc); L.q = take(n); L.g = take(nc); L.d = take(n); L.v = take(n);
   L.gd = take(D.ngd); L.yd = take(nd); L.red = take(64); L.scal = take(64);
-  L.w_prev = take((n + 2) / 2 + 1);   // final active set of the previous QP of this scenario (warm start)
-  L.w_prev = take((n + 2) / 2 + 1); L.w_prevlam = take(n + 1);
+  L.w_prev = take((n + 2) / 2 + 1); L.w_prevlam = take(n + 1);   // final active set of the previous QP of this scenario (warm start)
   L.t_rows = take(nc); L.t_dense = take(2 * nd); L.t_task = take(D.ntask); L.t_track = take(4 * (DGSQP_MAX_SEGS + 1)); L.t_atan = take(10);
   L.scr = o;
   // EVAL
@@ -139,17 +140,23 @@ static inline std::string dg_build_layout(DgProb& D) {
   const int npk = n * (n + 1) / 2;
   const int rpt = (n <= 32 ? 32 : (n <= 64 ? 64 : (n <= 100 ? 100 : 128))) / DG_NH;
   if (!D.big) { L.g_Bp = take(npk); L.g_V = take(npk); } else { L.g_Bp = L.g_V = -1; }
-  L.g_tw = take((5 + DG_NH) * n + 16 + DG_PSD_KMAX * n /* Z */ + 3 * (DG_NH * rpt + 4)
-                + 2 * (DG_BLOCK / 64) * (DG_NH * rpt + 4) /* per-wavefront copies of the reflector v and of w */);
+  L.g_tw = D.big == 2 ? take(4 * n + 16)
+                      : take((5 + DG_NH) * n + 16 + DG_PSD_KMAX * n /* Z */ + 3 * (DG_NH * rpt + 4)
+                             + 2 * (DG_BLOCK / 64) * (DG_NH * rpt + 4) /* per-wavefront copies of the reflector v and of w */);
   // per-wavefront strips of the twisted factorisation (3 n doubles each): the packed-P slot is free until the sweep writes
   // P at the very end of the phase; tiny problems get their own space
   const int strips = (DG_BLOCK / 64) * 3 * ((n + 1) & ~1);
-  L.g_strip = (!D.big && strips <= npk) ? L.g_Bp : take(strips);
+  L.g_strip = (!D.big && strips <= npk) ? L.g_Bp : (D.big == 2 ? L.g_tw : take(strips));
   const int eig_end = o;
   // QP (P aliases Bp)
   o = L.scr + (D.big ? 0 : ((npk + 1) & ~1));
-  L.p_R = take(npk); L.p_lam = take(n + 1); L.p_c = take(n + 1); L.p_w = take(n + 1); L.p_r = take(n + 1);
-  L.p_y = take(n); L.p_t = take(n); L.p_alist = take((n + 2) / 2 + 1); L.p_rd = take(n + 1); L.p_yd2 = take(nd); L.p_yslot = take((n + 2) / 2 + 1); L.p_yfree = take((n + 2) / 2 + 1); L.p_dpart = take(D.ntask); L.p_act = take(nc / 8 + 2); L.p_part = take(DG_NH * n);
+  L.p_R = D.big == 2 ? -1 : take(npk); L.p_lam = take(n + 1); L.p_c = take(n + 1); L.p_w = take(n + 1); L.p_r = take(n + 1);
+  L.p_y = take(n); L.p_t = take(n); L.p_alist = take((n + 2) / 2 + 1); L.p_rd = take(n + 1);
+  {   // the dual start borrows p_yd2 / p_dpart while its own vectors (5 of length n_c) sit at L.scr: keep them apart
+    const int lsqr_size = 4 * ((nc + 1) & ~1) + (((nc > n ? nc : n) + 1) & ~1);
+    if (o < L.scr + lsqr_size) o = L.scr + lsqr_size;
+  }
+  L.p_yd2 = take(nd); L.p_yslot = take((n + 2) / 2 + 1); L.p_yfree = take((n + 2) / 2 + 1); L.p_dpart = take(D.ntask); L.p_act = take(nc / 8 + 2); L.p_part = take(DG_NH * n);
   const int qp_end = o;
   // QP outputs live past the end of both the QP and EVAL scratch
   o = qp_end > eval_end ? qp_end : eval_end;
@@ -159,6 +166,7 @@ static inline std::string dg_build_layout(DgProb& D) {
   o = L.scr;
   L.s_u = take(nc); L.s_v = take(nc); L.s_w = take(nc); L.s_x = take(nc); L.s_t = take(nc > n ? nc : n);
   const int lsqr_end = o;
+  if (L.p_yd2 < lsqr_end || L.p_dpart < lsqr_end) return "internal layout error: the dual start's borrowed QP scratch overlaps its vectors";
   {
     // give the speculative rollouts the scratch the EIG / QP phases need anyway (the arena does not grow for them)
     int tot0 = eig_end > out_end ? eig_end : out_end;
@@ -188,7 +196,7 @@ static inline std::string dg_build_layout(DgProb& D) {
   if (out_end > tot) tot = out_end;
   if (lsqr_end > tot) tot = lsqr_end;
   L.total = tot;
-  if ((long)tot * 8 > DG_LDS_LIMIT && !D.big) { D.big = 1; return dg_build_layout(D); }
+  if ((long)tot * 8 > DG_LDS_LIMIT && !D.big) { D.big = 1; return dg_build_layout(D); }   // (n > 128 starts at big = 2)
   if ((long)tot * 8 > DG_LDS_LIMIT) {
     char buf[160];
     snprintf(buf, sizeof buf, "problem needs %ld B of LDS per scenario (limit %d): n=%d n_c=%d", (long)tot * 8, DG_LDS_LIMIT, n, nc);
@@ -203,7 +211,7 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   D.P = P; D.par = par;
   if (P.M < 1 || P.M > DGSQP_MAX_AGENTS) return "unsupported number of agents";
   if (P.N < 1 || P.N > DG_NMAX) return "unsupported horizon";
-  if (P.N * P.M * DGSQP_NUA > 128) return "more than 128 decision variables are not supported yet";
+  if (P.N * P.M * DGSQP_NUA > 192) return "more than 192 decision variables are not supported yet";
   if (P.n_segs < 1 || P.n_segs > DGSQP_MAX_SEGS) return "bad track table";
   D.M = P.M; D.N = P.N; D.nq = 0; D.nu = P.M * DGSQP_NUA;
   int t2 = 0;
@@ -321,6 +329,7 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
     D.ntask = nt;
   }
   D.t2_doubles = t2;
+  D.big = D.n > 128 ? 2 : 0;   // XL layout: every matrix of the PSD / QP phases in the global scratch, generic (slow) kernels
   return dg_build_layout(D);
 }
 

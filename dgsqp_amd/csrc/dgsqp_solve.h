@@ -705,6 +705,8 @@ __device__ inline void qpw_drop(lptr R, lptr rd, lds_i_t* alist, lds_i_t* yslot,
 }
 
 #include "dgsqp_qp.h"
+__device__ void dev_xl_psd(const Ctx& c, gptr Qpd);   // XL layout (n > 128), dgsqp_xl.h
+__device__ int dev_xl_qp(const Ctx& c);
 
 // ------------------------------------------------------------------------------------------------
 // dual initialisation  l = max(0, -lsqr(G G^T, G q))   (DGSQP.py:320-327).
@@ -1050,6 +1052,7 @@ __device__ inline int dev_linearize_and_qp(const Ctx& c, bool do_qp, double* con
   }
   if (!do_qp) return 0;
   dev_qt_mul(c);
+  if (dg_prob.big == 2) { dev_xl_psd(c, Qpd); return dev_xl_qp(c); }   // n > 128: dgsqp_xl.h
   dev_psd_inverse(c, Qpd);
   return dev_qp(c);
 }
@@ -1185,8 +1188,9 @@ __device__ inline void dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
     if (cond[2] > 1e5) { status = DGSQP_DIVERGED; break; }
     if (cond[0] < D.par.p_tol && cond[1] < D.par.d_tol && cond[2] < D.par.d_tol) { status = DGSQP_CONV_ABS_TOL; break; }
     dev_qt_mul(c);
-    dev_psd_inverse(c, nullptr);
-    const int flag = dev_qp(c);
+    int flag;
+    if (D.big == 2) { dev_xl_psd(c, nullptr); flag = dev_xl_qp(c); }   // n > 128: dgsqp_xl.h
+    else { dev_psd_inverse(c, nullptr); flag = dev_qp(c); }
     total_qp++;
     if (flag != 0) { status = DGSQP_QP_FAIL; break; }
     LinScal S;

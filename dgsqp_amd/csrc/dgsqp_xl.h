@@ -1,0 +1,284 @@
+// XL layout (128 < n <= 192): _nearestPD + _solve_qp for games whose matrices do not fit the LDS-resident layouts
+// (BASELINE configs[2]: 3 agents, N=25, n=150; scripts/DGSQP_monte_carlo_agents.py at its M=3, N=25 setting).
+// Every n x n matrix lives in the workgroup's global scratch (L2); the kernels are plain block-wide loops -- a correct,
+// unoptimised path with the same semantics as the fast one:
+//   _nearestPD (DGSQP.py:1290-1296): eigen-decomposition of B = (Q+Q^T)/2 by one-sided (Hestenes) Jacobi rotations,
+//                M = B + sum_{lambda_j < 0} (floor - lambda_j) v_j v_j^T + reg I;
+//   _solve_qp  (DGSQP.py:232-266): Goldfarb-Idnani dual active set in the classical J = L^-T / R form, cold start, the same
+//                pivot rules and tolerances as the test suite's CPU restatement (most violated row first, lowest index on ties).
+#pragma once
+#include "dgsqp_solve.h"
+
+#define XSYNC() do { __threadfence_block(); __syncthreads(); } while (0)
+
+// ---- _nearestPD: M (row-major, n x n) into c.ws + ws_R
+__device__ __noinline__ void dev_xl_psd(const Ctx& c, gptr Qpd) {
+  const DgProb& D = dg_prob;
+  const int n = D.n, lane = TID & 63, wave = TID >> 6;
+  lptr lds = LP(0);
+  cgptr Qg = c.ws + D.ws_q;
+  gptr G = c.ws + D.ws_P, V = c.ws + D.ws_V, Mx = c.ws + D.ws_R;   // G, V column-major: column j at [j*n, j*n+n)
+  lptr lamv = lds + D.L.g_tw;             // n eigenvalues
+  lds_d* scal = lds + D.L.scal;
+  if (TID == 0) scal[DG_XVALID] = 0.0;    // (the EIG scratch may overlap the trajectory)
+  __syncthreads();
+  PROF_BEGIN(pt_t);
+  for (int e = TID; e < n * n; e += NT) {
+    const int col = e / n, row = e % n;
+    G[e] = 0.5 * (Qg[(int64_t)row * n + col] + Qg[(int64_t)col * n + row]);
+    V[e] = row == col ? 1.0 : 0.0;
+  }
+  XSYNC();
+  const int npad = n + (n & 1), rounds = npad - 1, half = npad / 2;
+  for (int sweep = 0; sweep < 40; sweep++) {
+    if (TID == 0) scal[3] = 0.0;
+    __syncthreads();
+    int rotated = 0;
+    for (int r = 0; r < rounds; r++) {
+      for (int k = wave; k < half; k += NT / 64) {
+        // round-robin tournament: every pair meets once per sweep, the pairs of one round are disjoint
+        int p = k == 0 ? npad - 1 : (r + k) % rounds, q = k == 0 ? r : (r - k + rounds) % rounds;
+        if (p >= n || q >= n) continue;
+        if (p > q) { const int t = p; p = q; q = t; }
+        gptr gp = G + (int64_t)p * n, gq = G + (int64_t)q * n;
+        double al = 0, be = 0, ga = 0;
+        for (int i = lane; i < n; i += 64) { const double a = gp[i], b = gq[i]; al += a * a; be += b * b; ga += a * b; }
+        al = wave_sum(al); be = wave_sum(be); ga = wave_sum(ga);
+        if (!(__builtin_fabs(ga) > 1e-15 * sqrt(al * be)) || !(al * be > 0.0)) continue;
+        const double zeta = (be - al) / (2.0 * ga);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (__builtin_fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+        gptr vp = V + (int64_t)p * n, vq = V + (int64_t)q * n;
+        for (int i = lane; i < n; i += 64) {
+          const double a = gp[i], b = gq[i];
+          gp[i] = cs * a - sn * b; gq[i] = sn * a + cs * b;
+          const double va = vp[i], vb = vq[i];
+          vp[i] = cs * va - sn * vb; vq[i] = sn * va + cs * vb;
+        }
+        rotated = 1;
+      }
+      XSYNC();
+    }
+    if (rotated && lane == 0) scal[3] = 1.0;
+    __syncthreads();
+    const bool again = scal[3] != 0.0;
+    __syncthreads();
+    if (!again) break;
+  }
+  // eigenvalues lambda_j = v_j . (B v_j) = v_j . g_j
+  for (int j = wave; j < n; j += NT / 64) {
+    double s = 0;
+    for (int i = lane; i < n; i += 64) s += V[(int64_t)j * n + i] * G[(int64_t)j * n + i];
+    s = wave_sum(s);
+    if (lane == 0) lamv[j] = s;
+  }
+  __syncthreads();
+  const double reg = D.par.reg > 0 ? D.par.reg : 0.0;
+  for (int e = TID; e < n * n; e += NT) {
+    const int i = e / n, k = e % n;
+    double a = 0.5 * (Qg[(int64_t)i * n + k] + Qg[(int64_t)k * n + i]);
+    for (int j = 0; j < n; j++) {
+      const double lj = lamv[j];
+      if (lj < 0.0) a += (D.eig_floor - lj) * V[(int64_t)j * n + i] * V[(int64_t)j * n + k];
+    }
+    if (i == k) a += reg;
+    Mx[e] = a;
+    if (Qpd) Qpd[e] = a;
+  }
+  XSYNC();
+  PROF_END(PH_JACOBI, pt_t);
+}
+
+// one Givens rotation of columns (ja, jb) of the row-major matrix X over rows [0, rows): [xa, xb] <- [c xa + s xb, -s xa + c xb]
+__device__ inline void xl_rot_cols(gptr X, int n, int rows, int ja, int jb, double cc, double ss) {
+  for (int i = TID; i < rows; i += NT) {
+    const double a = X[(int64_t)i * n + ja], b = X[(int64_t)i * n + jb];
+    X[(int64_t)i * n + ja] = cc * a + ss * b;
+    X[(int64_t)i * n + jb] = -ss * a + cc * b;
+  }
+}
+
+// ---- _solve_qp.  Out: du (L.o_du), lhat (L.o_lhat).  Returns 0 ok, 1 infeasible, 2 numerical failure / iteration limit.
+__device__ __noinline__ int dev_xl_qp(const Ctx& c) {
+  const DgProb& D = dg_prob;
+  const DgLds& L = D.L;
+  lptr lds = LP(0);
+  const int n = D.n, nc = D.nc;
+  const QpPtrs q = qp_ptrs(c);
+  gptr Lc = c.ws + D.ws_R, J = c.ws + D.ws_P, R = c.ws + D.ws_V;      // all row-major n x n
+  lptr lhat = lds + L.o_lhat, x = q.xv, np = q.yv, dv = q.cvec, zv = q.wv, rv = q.rv, uu = q.lam, tv = q.tv, acc = q.rd;
+  lds_d* scal = lds + L.scal;
+  lds_d* red = lds + L.red;
+  const int NONE = 0x7fffffff;
+  const double TOL = 1e-10;
+  PROF_BEGIN(pt_qp);
+  __syncthreads();
+  for (int r = TID; r < nc; r += NT) { q.act[r] = 0; lhat[r] = 0.0; }
+  // ---- Cholesky M = L L^T in place (lower triangle), right-looking
+  if (TID == 0) scal[4] = 0.0;
+  __syncthreads();
+  for (int j = 0; j < n; j++) {
+    const double djj = Lc[(int64_t)j * n + j];
+    if (!(djj > 0.0)) { if (TID == 0) scal[4] = 1.0; }
+    const double dd = sqrt(djj > 0.0 ? djj : 1.0);
+    __syncthreads();
+    for (int i = j + 1 + TID; i < n; i += NT) Lc[(int64_t)i * n + j] /= dd;
+    if (TID == 0) Lc[(int64_t)j * n + j] = dd;
+    XSYNC();
+    const int m = n - j - 1;
+    for (int e = TID; e < m * m; e += NT) {
+      const int i = j + 1 + e / m, k = j + 1 + e % m;
+      if (k <= i) Lc[(int64_t)i * n + k] -= Lc[(int64_t)i * n + j] * Lc[(int64_t)k * n + j];
+    }
+    XSYNC();
+  }
+  if (scal[4] != 0.0) { PROF_END(PH_QP, pt_qp); return 2; }
+  // ---- J = L^-T (upper triangular): column col solves L^T y = e_col
+  for (int col = TID; col < n; col += NT) {
+    for (int i = n - 1; i > col; i--) J[(int64_t)i * n + col] = 0.0;
+    for (int i = col; i >= 0; i--) {
+      double s = i == col ? 1.0 : 0.0;
+      for (int k = i + 1; k <= col; k++) s -= Lc[(int64_t)k * n + i] * J[(int64_t)k * n + col];
+      J[(int64_t)i * n + col] = s / Lc[(int64_t)i * n + i];
+    }
+  }
+  XSYNC();
+  // ---- x = -M^-1 q = -J (J^T q)
+  for (int i = TID; i < n; i += NT) { double s = 0; for (int k = 0; k <= i; k++) s += J[(int64_t)k * n + i] * lds[L.q + k]; dv[i] = s; }
+  __syncthreads();
+  for (int i = TID; i < n; i += NT) { double s = 0; for (int k = i; k < n; k++) s += J[(int64_t)i * n + k] * dv[k]; x[i] = -s; }
+  __syncthreads();
+  int iq = 0, ret = 2;
+  auto row_slack = [&](int p) -> double {       // -(g_p + a_p . x), block-uniform; tv must hold a_p
+    double s = 0;
+    for (int i = TID; i < n; i += NT) s += tv[i] * x[i];
+    return -(q.g[p] + block_sum(s, red));
+  };
+  auto drop = [&](int l) {   // remove the active constraint at position l, restore R upper triangular (rotations also on J)
+    if (TID == 0) q.act[q.alist[l]] = 0;
+    __syncthreads();
+    for (int i = TID; i < n; i += NT) {          // shift columns l+1.. of R one to the left (every thread owns its rows)
+      for (int k = l; k < iq - 1; k++) R[(int64_t)i * n + k] = R[(int64_t)i * n + k + 1];
+      R[(int64_t)i * n + iq - 1] = 0.0;
+    }
+    if (TID == 0) {
+      for (int k = l; k < iq - 1; k++) { q.alist[k] = q.alist[k + 1]; uu[k] = uu[k + 1]; }
+      q.alist[iq - 1] = q.alist[iq]; uu[iq - 1] = uu[iq]; uu[iq] = 0.0; q.alist[iq] = -1;
+    }
+    XSYNC();
+    iq--;
+    for (int k = l; k < iq; k++) {
+      const double a = R[(int64_t)k * n + k], b = R[(int64_t)(k + 1) * n + k];
+      const double h = hypot(a, b);
+      __syncthreads();
+      if (h != 0.0) {
+        const double cc = a / h, s2 = b / h;
+        for (int j2 = k + TID; j2 < iq; j2 += NT) {
+          const double ra = R[(int64_t)k * n + j2], rb = R[(int64_t)(k + 1) * n + j2];
+          R[(int64_t)k * n + j2] = cc * ra + s2 * rb;
+          R[(int64_t)(k + 1) * n + j2] = -s2 * ra + cc * rb;
+        }
+        xl_rot_cols(J, n, n, k, k + 1, cc, s2);
+      }
+      XSYNC();
+    }
+  };
+  const int max_outer = 20 * (n + nc);
+  for (int iter = 0; iter < max_outer; iter++) {
+    const int ip = qp_scan(q, TOL);
+    if (ip == NONE) { ret = 0; break; }
+    for (int col = TID; col < n; col += NT) { const double a = g_row_coef(D, q.gd, ip, col); tv[col] = a; np[col] = -a; }
+    if (TID == 0) { uu[iq] = 0.0; q.alist[iq] = ip; }
+    __syncthreads();
+    double npnp;
+    { double s = 0; for (int i = TID; i < n; i += NT) s += np[i] * np[i]; npnp = block_sum(s, red); }
+    double sp = row_slack(ip);
+    int st = -1;          // -1 running, 0 constraint added, 1 infeasible, 2 iteration limit
+    for (int inner = 0; inner < 10 * (n + nc) && st < 0; inner++) {
+      // step 2a: d = J^T np ; z = J2 d2 ; r = R^-1 d1
+      for (int i = TID; i < n; i += NT) { double s = 0; for (int k = 0; k < n; k++) s += J[(int64_t)k * n + i] * np[k]; dv[i] = s; }
+      __syncthreads();
+      for (int i = TID; i < n; i += NT) { double s = 0; for (int k = iq; k < n; k++) s += J[(int64_t)i * n + k] * dv[k]; zv[i] = s; }
+      for (int i = TID; i < iq; i += NT) acc[i] = dv[i];
+      __syncthreads();
+      for (int k = iq - 1; k >= 0; k--) {      // back substitution, column oriented
+        const double rk = acc[k] / R[(int64_t)k * n + k];
+        __syncthreads();
+        if (TID == 0) rv[k] = rk;
+        for (int i = TID; i < k; i += NT) acc[i] -= R[(int64_t)i * n + k] * rk;
+        __syncthreads();
+      }
+      // step 2b: step lengths
+      double t1 = INFINITY; int lidx = NONE;
+      for (int k = TID; k < iq; k += NT) if (rv[k] > 0.0) { const double tt = uu[k] / rv[k]; if (tt < t1) { t1 = tt; lidx = k; } }
+      { double bv; int bi; block_argmin(t1, lidx, red, bv, bi); t1 = bv; lidx = bi; }
+      double znp;
+      { double s = 0; for (int k = iq + TID; k < n; k += NT) s += dv[k] * dv[k]; znp = block_sum(s, red); }
+      const double t2 = (znp > 1e-18 * npnp && iq < n) ? -sp / znp : INFINITY;
+      const double t = fmin(t1, t2);
+      if (!(t < INFINITY)) { st = 1; break; }
+      if (!(t2 < INFINITY)) {   // dual step only
+        for (int k = TID; k < iq; k += NT) uu[k] -= t * rv[k];
+        if (TID == 0) uu[iq] += t;
+        __syncthreads();
+        drop(lidx);
+        continue;
+      }
+      for (int i = TID; i < n; i += NT) x[i] += t * zv[i];
+      for (int k = TID; k < iq; k += NT) uu[k] -= t * rv[k];
+      if (TID == 0) uu[iq] += t;
+      __syncthreads();
+      if (t == t2) {   // full step: add constraint ip.  Givens rotations zero d[iq+1..n-1] into d[iq], applied to J's columns
+        // (coefficients by one thread -- the recurrence on d is sequential --, then every thread carries its own row of J
+        //  through the whole sequence: one pass over J instead of one barrier per rotation)
+        lptr gc = acc, gs = lds + L.p_part;
+        if (TID == 0) {
+          for (int j2 = n - 1; j2 > iq; j2--) {
+            const double a = dv[j2 - 1], b = dv[j2];
+            const double h = hypot(a, b);
+            if (h != 0.0) { gc[j2] = a / h; gs[j2] = b / h; dv[j2 - 1] = h; dv[j2] = 0.0; }
+            else { gc[j2] = 1.0; gs[j2] = 0.0; }
+          }
+        }
+        __syncthreads();
+        for (int i = TID; i < n; i += NT) {
+          gptr Ji = J + (int64_t)i * n;
+          double carry = Ji[n - 1];
+          for (int j2 = n - 1; j2 > iq; j2--) {
+            const double ja = Ji[j2 - 1], cc = gc[j2], s2 = gs[j2];
+            Ji[j2] = -s2 * ja + cc * carry;
+            carry = cc * ja + s2 * carry;
+          }
+          Ji[iq] = carry;
+        }
+        XSYNC();
+        for (int i = TID; i <= iq; i += NT) R[(int64_t)i * n + iq] = dv[i];
+        if (TID == 0) q.act[ip] = 1;
+        XSYNC();
+        iq++;
+        st = 0;
+      } else {          // partial step: drop the blocking constraint, recompute the slack of ip
+        drop(lidx);
+        sp = row_slack(ip);
+      }
+    }
+    if (st < 0) st = 2;
+    if (st != 0) { ret = st; break; }
+  }
+  if (ret == 0) {
+    __syncthreads();
+    for (int k = TID; k < iq; k += NT) lhat[q.alist[k]] = uu[k];
+    __syncthreads();
+    // the exact minimiser sits ON its active input bounds (same step in dev_qp and in the oracle)
+    for (int k = TID; k < iq; k += NT) {
+      const int r = q.alist[k];
+      const DgRow Rw = ld_row(r);
+      if (uu[k] > 0.0 && Rw.type == DG_R_IN_UB) x[am_col(D, Rw.a, Rw.k, Rw.idx)] = -q.g[r];
+      else if (uu[k] > 0.0 && Rw.type == DG_R_IN_LB) x[am_col(D, Rw.a, Rw.k, Rw.idx)] = q.g[r];
+    }
+  }
+  if (TID == 0) scal[DG_QP_NPREV] = 0.0;
+  __syncthreads();
+  PROF_END(PH_QP, pt_qp);
+  return ret;
+}

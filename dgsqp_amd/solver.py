@@ -165,6 +165,18 @@ def build_params(params: DGSQPParams, eig_floor: Optional[float] = None) -> _ffi
     return p
 
 
+def plan(P: _ffi.ProblemT, par: _ffi.ParamsT) -> dict:
+    """What ``dgsqp_create`` would build for this game (host only, no GPU): dimensions, LDS bytes, scratch bytes and the
+    layout (0 LDS-resident, 1 big, 2 XL); raises ``ValueError`` with the library's reason for unsupported games."""
+    lib = _ffi.load_library()
+    d = _ffi.DimsT()
+    msg = C.create_string_buffer(256)
+    rc = lib.dgsqp_plan(C.byref(P), C.byref(par), C.byref(d), msg, 256)
+    if rc != 0:
+        raise ValueError(f'unsupported game ({rc}): {msg.value.decode()}')
+    return {k: getattr(d, k) for k, _ in _ffi.DimsT._fields_ if k != 'reserved_'}
+
+
 def problem_dims(P: _ffi.ProblemT):
     """(n_q, n_u, n, n_c) from the constraint-assembly rules DGSQP.py:732-821."""
     M, N = P.M, P.N

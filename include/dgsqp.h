@@ -174,6 +174,8 @@ typedef struct {
   int32_t n_dense;                /* distinct dense constraint gradients */
   int32_t lds_bytes;              /* dynamic LDS per scenario workgroup */
   int64_t workspace_bytes;        /* HBM scratch per resident workgroup */
+  int32_t layout;                 /* 0 LDS-resident, 1 big (P and reflectors in the L2 scratch), 2 XL (n > 128, generic kernels) */
+  int32_t reserved_;
 } dgsqp_dims_t;
 
 typedef struct {
@@ -189,6 +191,9 @@ int dgsqp_create(const dgsqp_problem_t* prob, const dgsqp_params_t* par, int dev
                  dgsqp_handle_t* out);
 void dgsqp_destroy(dgsqp_handle_t h);
 int dgsqp_dims(dgsqp_handle_t h, dgsqp_dims_t* out);
+/* What dgsqp_create would build for this game -- dimensions, LDS / scratch need and the layout chosen -- without touching a
+   device (host only).  Returns DGSQP_E_TOO_LARGE / DGSQP_E_ARG with the reason in msg when the game is not supported. */
+int dgsqp_plan(const dgsqp_problem_t* prob, const dgsqp_params_t* par, dgsqp_dims_t* out, char* msg, int msglen);
 const char* dgsqp_last_error(dgsqp_handle_t h); /* h may be NULL: last create() error */
 int dgsqp_backend_info(char* buf, int buflen);  /* device name / arch / CU count */
 

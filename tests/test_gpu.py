@@ -530,6 +530,49 @@ def test_big_layout_and_merge_game(oracle):
                 s.pid_warm_start_batch(x0)
 
 
+def test_xl_layout_three_agents_n150(oracle):
+    """BASELINE configs[2] size / scripts/DGSQP_monte_carlo_agents.py at exp_M=[3], exp_N=[25] (:101-102): n = 150 decision
+    variables, 825 rows.  Beyond 128 variables the PSD / QP phases run the generic global-memory kernels of dgsqp_xl.h
+    (Jacobi eigen-decomposition, classical Goldfarb-Idnani); evaluation, dual start and the SQP logic are the common code."""
+    from dgsqp_amd.montecarlo import kinematic_racing_game, sample_scenarios
+    from dgsqp_amd.solver import DGSQP, build_problem, build_params
+    import dgsqp_amd.solver as sv
+    g = kinematic_racing_game('curve', N=25, M=3)
+    P, par = build_problem(*g.solver_args()), tight_lsqr(build_params(g.params))
+    orig = sv.build_params
+    sv.build_params = lambda p: tight_lsqr(orig(p))
+    try:
+        s = DGSQP(*g.solver_args(), print_method=None)
+    finally:
+        sv.build_params = orig
+    assert (s.n, s.n_c_total) == (150, 825) and s.dims.lds_bytes <= 163840
+    B = 8
+    x0, u_tm = sample_scenarios(g, B, seed=1)
+    u = agent_major(u_tm)
+    rng = np.random.default_rng(1)
+    up = u + 0.01 * rng.standard_normal(u.shape)
+    l = np.maximum(0, rng.standard_normal((B, s.n_c_total)))
+    ev = s.evaluate_batch(x0[:2], up[:2], l[:2])
+    l0 = [oracle.dual_init(P, par, x0[b], u[b]) for b in range(2)]
+    qp = s.qp_batch(x0[:2], u[:2], np.array(l0))
+    for b in range(2):
+        o = oracle.evaluate(P, x0[b], up[b], l[b], 1)
+        for key in ('x', 'q', 'g', 'G', 'Q'):
+            assert rel(ev[key][b], o[key]) < 1e-11, (key, b)
+        assert rel(ev['l0'][b], oracle.dual_init(P, par, x0[b], up[b])) < 1e-7
+        o = oracle.evaluate(P, x0[b], u[b], l0[b], 1)
+        Qpd = oracle.nearest_pd(o['Q'], par.reg, par.eig_floor)
+        du, lam, flag = oracle.qp(Qpd, o['q'], o['G'], o['g'])
+        assert qp['flag'][b] == flag == 0 and np.abs(qp['Qpd'][b] - Qpd).max() < 1e-10 * np.abs(o['Q']).max()
+        assert rel(qp['du'][b], du) < 1e-8 and np.array_equal(qp['lhat'][b] > 0, lam > 0)
+    res = s.solve_batch(x0, u_tm)
+    ref = oracle.solve_batch(P, par, x0, u, nthreads=8)
+    same = (res['status'] == ref['status']) & (res['num_iters'] == ref['num_iters']) & (res['qp_solves'] == ref['qp_solves'])
+    assert same.sum() >= B - 2, same
+    for b in np.where(same & (ref['status'] <= 1))[0]:
+        assert rel(res['u'][b], ref['u'][b]) < 1e-6 and rel(res['l'][b], ref['l'][b]) < 1e-5
+
+
 def test_large_batch_equals_small_batches(games):
     """Every scenario of a 3,500-scenario launch (14 per workgroup, dynamic ticket order) comes out exactly as in a small
     launch: no state leaks between the scenarios a workgroup processes (warm-started active sets, trajectory tags)."""

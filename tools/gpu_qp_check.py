@@ -10,6 +10,7 @@ which, reg = sys.argv[1], float(sys.argv[2])
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 if which == 'barc2': g = mc.barc_racing_game(N=15, M=2, reg=reg)
 elif which == 'barc3': g = mc.barc_racing_game(N=15, M=3, reg=reg)
+elif which == 'agents3': g = mc.kinematic_racing_game('curve', N=25, M=3, reg=reg)
 else: g = mc.kinematic_racing_game('curve' if which == 'kbcurve' else 'chicane', N=25, reg=reg)
 M, N = g.joint_model.n_a, g.params.N
 P, par = build_problem(*g.solver_args()), build_params(g.params)
@@ -23,7 +24,7 @@ for b in range(B):
     o = oracle.evaluate(P, x0[b], u[b], l[b], 1)
     Bs = 0.5 * (o['Q'] + o['Q'].T)
     w = np.linalg.eigvalsh(Bs)
-    Qpd = oracle.nearest_pd(o['Q'], reg)
+    Qpd = oracle.nearest_pd(o['Q'], reg, par.eig_floor)
     du, lam, flag = oracle.qp(Qpd, o['q'], o['G'], o['g'])
     Qd = qp['Qpd'][b]
     wd = np.linalg.eigvalsh(0.5 * (Qd + Qd.T))

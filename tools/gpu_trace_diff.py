@@ -11,7 +11,7 @@ from dgsqp_amd.solver import DGSQP, build_problem, build_params
 kind = sys.argv[1]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 25
-g = mc.merge_game(N=N) if kind == 'merge' else (mc.barc_racing_game(N=N, M=2) if kind == 'barc2' else mc.kinematic_racing_game('curve' if kind == 'kbcurve0' else 'chicane', N=N, reg=0.0))
+g = mc.kinematic_racing_game('curve', N=N, M=3) if kind == 'agents3' else mc.merge_game(N=N) if kind == 'merge' else (mc.barc_racing_game(N=N, M=2) if kind == 'barc2' else mc.kinematic_racing_game('curve' if kind == 'kbcurve0' else 'chicane', N=N, reg=0.0))
 M = g.joint_model.n_a
 
 
