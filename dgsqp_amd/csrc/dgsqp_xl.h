@@ -10,6 +10,9 @@
 #include "dgsqp_solve.h"
 
 #define XSYNC() do { __threadfence_block(); __syncthreads(); } while (0)
+#define XL_NV 3      // registers per lane for one column (n <= 192)
+#define XL_MAXP 12   // pairs of one tournament round per wavefront (96 pairs / 8 wavefronts)
+#define XL_GRP 4     // ... handled four at a time (their four columns each stay in registers)
 
 // ---- _nearestPD: M (row-major, n x n) into c.ws + ws_R
 __device__ __noinline__ void dev_xl_psd(const Ctx& c, gptr Qpd) {
@@ -30,32 +33,70 @@ __device__ __noinline__ void dev_xl_psd(const Ctx& c, gptr Qpd) {
   }
   XSYNC();
   const int npad = n + (n & 1), rounds = npad - 1, half = npad / 2;
-  for (int sweep = 0; sweep < 40; sweep++) {
+  // columns whose norm falls below 1e-14 |B| carry a numerically zero eigenvalue: rotating two of them against each other
+  // never converges (their inner product is noise) and changes nothing that matters
+  double bn = 0;
+  for (int e = TID; e < n * n; e += NT) bn += G[e] * G[e];
+  const double tiny = 1e-28 * block_sum(bn, lds + D.L.red);
+  for (int sweep = 0; sweep < 20; sweep++) {
     if (TID == 0) scal[3] = 0.0;
     __syncthreads();
     int rotated = 0;
     for (int r = 0; r < rounds; r++) {
-      for (int k = wave; k < half; k += NT / 64) {
-        // round-robin tournament: every pair meets once per sweep, the pairs of one round are disjoint
-        int p = k == 0 ? npad - 1 : (r + k) % rounds, q = k == 0 ? r : (r - k + rounds) % rounds;
-        if (p >= n || q >= n) continue;
-        if (p > q) { const int t = p; p = q; q = t; }
-        gptr gp = G + (int64_t)p * n, gq = G + (int64_t)q * n;
-        double al = 0, be = 0, ga = 0;
-        for (int i = lane; i < n; i += 64) { const double a = gp[i], b = gq[i]; al += a * a; be += b * b; ga += a * b; }
-        al = wave_sum(al); be = wave_sum(be); ga = wave_sum(ga);
-        if (!(__builtin_fabs(ga) > 1e-15 * sqrt(al * be)) || !(al * be > 0.0)) continue;
-        const double zeta = (be - al) / (2.0 * ga);
-        const double t = (zeta >= 0 ? 1.0 : -1.0) / (__builtin_fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
-        gptr vp = V + (int64_t)p * n, vq = V + (int64_t)q * n;
-        for (int i = lane; i < n; i += 64) {
-          const double a = gp[i], b = gq[i];
-          gp[i] = cs * a - sn * b; gq[i] = sn * a + cs * b;
-          const double va = vp[i], vb = vq[i];
-          vp[i] = cs * va - sn * vb; vq[i] = sn * va + cs * vb;
+      // round-robin tournament: every pair meets once per sweep, the pairs of one round are disjoint.  A wavefront owns up
+      // to XL_MAXP pairs of the round and handles them TOGETHER: all column loads are issued before the first reduction, so
+      // the global-memory latency is paid once per round instead of once per pair.
+      for (int g0 = 0; g0 < XL_MAXP; g0 += XL_GRP) {     // XL_GRP pairs at a time: their columns fit the register file
+        int pp[XL_GRP], qq[XL_GRP];
+        double ga[XL_GRP][XL_NV], gb[XL_GRP][XL_NV], va[XL_GRP][XL_NV], vb[XL_GRP][XL_NV];
+  #pragma unroll
+        for (int s = 0; s < XL_GRP; s++) {
+          const int k = wave + (g0 + s) * (NT / 64);
+          int p = k == 0 ? npad - 1 : (r + k) % rounds, q = k == 0 ? r : (r - k + rounds) % rounds;
+          if (k >= half || p >= n || q >= n) { p = -1; q = -1; }
+          else if (p > q) { const int t = p; p = q; q = t; }
+          pp[s] = p; qq[s] = q;
+  #pragma unroll
+          for (int h = 0; h < XL_NV; h++) {
+            const int i = lane + 64 * h;
+            const bool ok = p >= 0 && i < n;
+            ga[s][h] = ok ? G[(int64_t)p * n + i] : 0.0;
+            gb[s][h] = ok ? G[(int64_t)q * n + i] : 0.0;
+            va[s][h] = ok ? V[(int64_t)p * n + i] : 0.0;     // the eigenvector columns ride along: one latency per group
+            vb[s][h] = ok ? V[(int64_t)q * n + i] : 0.0;
+          }
         }
-        rotated = 1;
+        double cs_[XL_GRP], sn_[XL_GRP];
+  #pragma unroll
+        for (int s = 0; s < XL_GRP; s++) {
+          double al = 0, be = 0, gm = 0;
+  #pragma unroll
+          for (int h = 0; h < XL_NV; h++) { al += ga[s][h] * ga[s][h]; be += gb[s][h] * gb[s][h]; gm += ga[s][h] * gb[s][h]; }
+          al = wave_sum(al); be = wave_sum(be); gm = wave_sum(gm);
+          double cs = 1.0, sn = 0.0;
+          if (pp[s] >= 0 && __builtin_fabs(gm) > 1e-14 * sqrt(al * be) && al > tiny && be > tiny) {
+            const double zeta = (be - al) / (2.0 * gm);
+            const double t = (zeta >= 0 ? 1.0 : -1.0) / (__builtin_fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            cs = 1.0 / sqrt(1.0 + t * t); sn = cs * t;
+            rotated = 1;
+          }
+          cs_[s] = cs; sn_[s] = sn;
+        }
+  #pragma unroll
+        for (int s = 0; s < XL_GRP; s++) {
+          if (sn_[s] == 0.0) continue;       // wave-uniform
+          const int p = pp[s], q = qq[s];
+  #pragma unroll
+          for (int h = 0; h < XL_NV; h++) {
+            const int i = lane + 64 * h;
+            if (i < n) {
+              G[(int64_t)p * n + i] = cs_[s] * ga[s][h] - sn_[s] * gb[s][h];
+              G[(int64_t)q * n + i] = sn_[s] * ga[s][h] + cs_[s] * gb[s][h];
+              V[(int64_t)p * n + i] = cs_[s] * va[s][h] - sn_[s] * vb[s][h];
+              V[(int64_t)q * n + i] = sn_[s] * va[s][h] + cs_[s] * vb[s][h];
+            }
+          }
+        }
       }
       XSYNC();
     }
@@ -64,6 +105,7 @@ __device__ __noinline__ void dev_xl_psd(const Ctx& c, gptr Qpd) {
     const bool again = scal[3] != 0.0;
     __syncthreads();
     if (!again) break;
+    PROF_COUNT(PH_C_NPREV, 1);
   }
   // eigenvalues lambda_j = v_j . (B v_j) = v_j . g_j
   for (int j = wave; j < n; j += NT / 64) {

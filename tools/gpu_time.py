@@ -6,7 +6,12 @@ from dgsqp_amd.montecarlo import kinematic_racing_game, dynamic_racing_game, sam
 from dgsqp_amd.solver import DGSQP
 which, N, B = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 M = int(sys.argv[4]) if len(sys.argv) > 4 else 10
-game = kinematic_racing_game('curve' if which == 'kbcurve' else 'chicane', N=N) if which.startswith('kb') else dynamic_racing_game(N=N, rk4_substeps=M)
+if which == 'agents3':      # XL layout: scripts/DGSQP_monte_carlo_agents.py at M=3, N=25
+    game = kinematic_racing_game('curve', N=N, M=3)
+elif which.startswith('kb'):  # reg as in the scripts: curve.py:161 reg=0, chicane.py:164 reg=1e-3
+    game = kinematic_racing_game('curve' if which == 'kbcurve' else 'chicane', N=N, reg=0.0 if which == 'kbcurve' else 1e-3)
+else:
+    game = dynamic_racing_game(N=N, rk4_substeps=M)
 s = DGSQP(*game.solver_args(), print_method=None)
 t = time.time(); x0, uws = sample_scenarios(game, B, seed=1); print('sample', time.time() - t)
 for rep in range(2):
