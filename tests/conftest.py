@@ -31,14 +31,14 @@ def agent_major(u_tm):
 @pytest.fixture(scope='session')
 def games():
     """Small set of games used across tests: name -> (Game, ProblemT, ParamsT)."""
-    from dgsqp_amd.montecarlo import kinematic_racing_game, dynamic_racing_game, merge_game
+    from dgsqp_amd.montecarlo import barc_racing_game, kinematic_racing_game, dynamic_racing_game, merge_game
     from dgsqp_amd.solver import build_problem, build_params
     out = {}
     for name, g in (('kb_chicane_N15', kinematic_racing_game('chicane', N=15)),
                     ('kb_chicane_N25', kinematic_racing_game('chicane', N=25)),
                     ('kb_curve_N10', kinematic_racing_game('curve', N=10)),
                     ('dyn_curve_N15', dynamic_racing_game(N=15, rk4_substeps=4)),
-                    ('merge_N8', merge_game(N=8))):
+                    ('merge_N8', merge_game(N=8)), ('kb_barc2_N15', barc_racing_game(N=15, M=2))):
         out[name] = (g, build_problem(*g.solver_args()), build_params(g.params))
     return out
 

@@ -98,7 +98,7 @@ def test_qp_parity_and_kkt(oracle, games, solvers, name):
         assert np.abs(lh * (o['G'] @ d + o['g'])).max() < 1e-10 * scale
 
 
-@pytest.mark.parametrize('name', ['kb_chicane_N15', 'kb_curve_N10', 'dyn_curve_N15'])
+@pytest.mark.parametrize('name', ['kb_chicane_N15', 'kb_curve_N10', 'dyn_curve_N15', 'kb_barc2_N15', 'merge_N8'])
 def test_solve_matches_golden_fixtures(solvers, name):
     """Committed oracle solutions (tools/make_golden.py): identical flags / iteration / QP counts and iterates
     within 1e-5 relative on every scenario whose control flow is well conditioned; at most 10 % of the
@@ -109,7 +109,8 @@ def test_solve_matches_golden_fixtures(solvers, name):
     same = (res['status'] == gold['status']) & (res['num_iters'] == gold['num_iters']) & (res['qp_solves'] == gold['qp_solves'])
     assert same.mean() >= 0.9, (res['status'], gold['status'], res['num_iters'], gold['num_iters'])
     easy = gold['num_iters'] < 30
-    assert same[easy].all()
+    if name not in ('kb_barc2_N15', 'merge_N8'):       # (reg = 0 games: agreement is statistical)
+        assert same[easy].all()
     for b in np.where(same)[0]:
         assert rel(res['u'][b], gold['u'][b]) < 1e-5, b
         if gold['status'][b] == 0:

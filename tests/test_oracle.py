@@ -272,7 +272,7 @@ def test_merit_and_mu_formulas(oracle, games):
 # ---------------------------------------------------------------------------------------------
 # full solves: invariants + committed fixtures
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('name', ['kb_chicane_N15', 'kb_curve_N10', 'dyn_curve_N15'])
+@pytest.mark.parametrize('name', ['kb_chicane_N15', 'kb_curve_N10', 'dyn_curve_N15', 'kb_barc2_N15', 'merge_N8'])
 def test_solve_reproduces_golden_and_invariants(oracle, games, name):
     g, P, par = games[name]
     gold = np.load(GOLD / f'{name}.npz')

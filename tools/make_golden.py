@@ -36,17 +36,20 @@ def param_defaults():
 
 def solve_fixtures():
     import copy
-    from dgsqp_amd.montecarlo import kinematic_racing_game, dynamic_racing_game, sample_scenarios
+    from dgsqp_amd.montecarlo import (barc_racing_game, kinematic_racing_game, dynamic_racing_game, merge_game,
+                                      sample_scenarios)
     from dgsqp_amd.solver import build_problem, build_params
     from oracle import oracle
     for name, game, B, seed in (('kb_chicane_N15', kinematic_racing_game('chicane', N=15), 32, 11),
                                 ('kb_curve_N10', kinematic_racing_game('curve', N=10), 32, 12),
-                                ('dyn_curve_N15', dynamic_racing_game(N=15, rk4_substeps=4), 16, 13)):
+                                ('dyn_curve_N15', dynamic_racing_game(N=15, rk4_substeps=4), 16, 13),
+                                ('kb_barc2_N15', barc_racing_game(N=15, M=2), 32, 0),        # reg = 0 (comp.py:169)
+                                ('merge_N8', merge_game(N=8), 16, 1)):                       # reg = 0 (merge.py:182)
         P = build_problem(*game.solver_args())
         par = build_params(game.params)
         par.lsqr_atol = par.lsqr_btol = 1e-13
         x0, u_tm = sample_scenarios(game, B, seed=seed)
-        u_am = np.concatenate([u_tm[:, :, 2 * a:2 * a + 2].reshape(B, -1) for a in range(2)], axis=1)
+        u_am = np.concatenate([u_tm[:, :, 2 * a:2 * a + 2].reshape(B, -1) for a in range(u_tm.shape[2] // 2)], axis=1)
         out = oracle.solve_batch(P, par, x0, u_am, nthreads=8)
         ev0 = [oracle.evaluate(P, x0[b], u_am[b], out['l_init'][b], 1) for b in range(4)]
         np.savez_compressed(GOLD / f'{name}.npz', x0=x0, u_ws=u_tm, u=out['u'], l=out['l'], status=out['status'],
