@@ -31,6 +31,10 @@ WORKLOADS = {
     # the reference's own Monte-Carlo experiment (scripts/DGSQP_ALGAMES_monte_carlo_curve.py), kinematic bicycle
     'kb_curve_N25': dict(desc='2-agent kinematic-bicycle (euler) curve track, N=25, reg=0 (curve.py:161), fp64', kind='kb', track='curve', N=25, reg=0.0),
     'kb_chicane_N25': dict(desc='2-agent kinematic-bicycle (euler) chicane track, N=25, reg=1e-3 (chicane.py:164), fp64', kind='kb', track='chicane', N=25, reg=1e-3),
+    # other Monte-Carlo scripts of the reference at their own sizes (not BASELINE's metric; for the DESIGN.md table)
+    'kb_barc2_N15': dict(desc='2-agent kinematic-bicycle race on the L_track_barc circuit, N=15, reg=0 (DGSQP_comp_monte_carlo.py), fp64', kind='barc', M=2, N=15, reg=0.0),
+    'merge_N20': dict(desc='3-car highway merge, kinematic unicycles rk3, N=20, reg=0 (DGSQP_merge_monte_carlo.py), big layout, fp64', kind='merge', N=20, reg=0.0),
+    'kb_curve3_N25': dict(desc='3-agent kinematic-bicycle curve track, N=25, reg=1e-3 (DGSQP_monte_carlo_agents.py M=3 N=25 = BASELINE configs[2] size), XL layout, fp64', kind='kb', track='curve', N=25, M=3, reg=1e-3),
 }
 
 
@@ -40,7 +44,13 @@ def make_game(name, reg=None):
     reg = w['reg'] if reg is None else reg
     if w['kind'] == 'dyn':
         return dynamic_racing_game(w['track'], N=w['N'], rk4_substeps=10, reg=reg)
-    return kinematic_racing_game(w['track'], N=w['N'], reg=reg)
+    if w['kind'] == 'barc':
+        from dgsqp_amd.montecarlo import barc_racing_game
+        return barc_racing_game(N=w['N'], M=w['M'], reg=reg)
+    if w['kind'] == 'merge':
+        from dgsqp_amd.montecarlo import merge_game
+        return merge_game(N=w['N'], reg=reg)
+    return kinematic_racing_game(w['track'], N=w['N'], reg=reg, M=w.get('M', 2))
 
 
 def algorithmic_bytes_per_solve(d):
@@ -174,12 +184,16 @@ def main():
         achieved = bytes_per_launch / (kms * 1e-3) / 1e9
         summ = summarize(stats)
         line = {
-            'metric': 'Monte-Carlo scenarios/sec (SQP solves/sec), 2-agent N=25', 'value': value, 'unit': 'scenarios/s',
+            'metric': 'Monte-Carlo scenarios/sec (SQP solves/sec), 2-agent N=25' if args.workload in ('dyn_curve_N25', 'kb_curve_N25', 'kb_chicane_N25')
+                      else 'Monte-Carlo scenarios/sec (SQP solves/sec)', 'value': value, 'unit': 'scenarios/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': args.workload, 'description': WORKLOADS[args.workload]['desc'], 'batch_per_gpu': B,
                        'n': int(d.n), 'n_c': int(d.n_c), 'parallelism': f'scenario-sharded x{world}',
-                       'sampler': 'scripts/DGSQP_ALGAMES_monte_carlo_curve.py:384-467 (seed 1+rank), PID warm start',
+                       'sampler': {'circuit': 'scripts/DGSQP_comp_monte_carlo.py:365-382 (seed 1+rank), PID warm start',
+                                   'merge': 'scripts/DGSQP_merge_monte_carlo.py:421-480 (seed 1+rank), zero warm start'}.get(
+                                       game.sampler, 'scripts/DGSQP_ALGAMES_monte_carlo_curve.py:384-467 (seed 1+rank), PID warm start'),
+                       'layout': {0: 'lds', 1: 'big', 2: 'xl'}[int(d.layout)],
                        'batches_in_flight': P, 'reg': float(game.params.reg), 'eig_floor': float(solver._cparams.eig_floor)},
             'mean_iters': summ['mean_iters_converged'], 'mean_iters_all': summ['mean_iters_all'],
             'mean_qp_solves': summ['mean_qp_solves_all'], 'converged_fraction': summ['converged'],
