@@ -961,7 +961,7 @@ __device__ __noinline__ void dev_hessian_adjoint(const Ctx& c) {
 // the EVAL scratch still holding the rollout of a bit-identical input (tag in scal[60], cleared by the phases that
 // overwrite the scratch) -- e.g. the full evaluation that follows an accepted trial point.
 #define DG_XVALID 60
-#define DG_QP_NPREV 59   // scal slot: size of the saved active set
+#define DG_QP_NPREV 59   // scal slot: size of the saved active set (XL layout: 1 = the saved eigenvector basis is valid)
 // stage 1: trial input, trajectory and constraint values g (no derivatives)
 __device__ inline void dev_evaluate_point(const Ctx& c, clptr usrc, double alpha, clptr dusrc, clptr xsrc = nullptr) {
   const DgProb& D = dg_prob;

@@ -86,7 +86,7 @@ struct DgProb {
   int t2off[DGSQP_MAX_AGENTS];              // offset (doubles) of agent block in the Taylor tensor workspace
   int t2k[DGSQP_MAX_AGENTS];                // per-stage stride of that block = nqa*ndir
   int64_t t2_doubles;
-  int64_t ws_t2, ws_q, ws_base, ws_H, ws_tang, ws_Y, ws_P, ws_V, ws_R, ws_doubles; // global workspace layout (doubles): Taylor tensor, raw Q, watchdog backups,
+  int64_t ws_t2, ws_q, ws_base, ws_H, ws_tang, ws_Y, ws_P, ws_V, ws_R, ws_Vp, ws_doubles; // global workspace layout (doubles): Taylor tensor, raw Q, watchdog backups,
                                                              // costate-contracted dynamics Hessians, tangent trajectories
   DgRow rows[DG_NCMAX];
   DgDense dense[DG_NDMAX];
@@ -115,7 +115,8 @@ static inline std::string dg_build_layout(DgProb& D) {
   const int64_t matsz = D.big == 2 ? (int64_t)D.n * D.n : (D.big ? (int64_t)D.n * (D.n + 1) / 2 : 0);   // XL: three full matrices
   D.ws_V = D.ws_P + matsz;
   D.ws_R = D.ws_V + matsz;
-  D.ws_doubles = D.ws_R + (D.big == 2 ? matsz + 4 * D.n : 0);
+  D.ws_Vp = D.ws_R + (D.big == 2 ? matsz + 4 * D.n : 0);      // XL: eigenvectors of the scenario's previous _nearestPD (Jacobi warm start)
+  D.ws_doubles = D.ws_Vp + (D.big == 2 ? matsz : 0);
   D.ws_doubles = (D.ws_doubles + 31) / 32 * 32;
   // ---- LDS arena
   DgLds& L = D.L;

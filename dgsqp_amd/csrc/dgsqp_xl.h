@@ -12,7 +12,9 @@
 #define XSYNC() do { __threadfence_block(); __syncthreads(); } while (0)
 #define XL_NV 3      // registers per lane for one column (n <= 192)
 #define XL_MAXP 12   // pairs of one tournament round per wavefront (96 pairs / 8 wavefronts)
+#ifndef XL_GRP
 #define XL_GRP 4     // ... handled four at a time (their four columns each stay in registers)
+#endif
 
 // ---- _nearestPD: M (row-major, n x n) into c.ws + ws_R
 __device__ __noinline__ void dev_xl_psd(const Ctx& c, gptr Qpd) {
@@ -26,12 +28,28 @@ __device__ __noinline__ void dev_xl_psd(const Ctx& c, gptr Qpd) {
   if (TID == 0) scal[DG_XVALID] = 0.0;    // (the EIG scratch may overlap the trajectory)
   __syncthreads();
   PROF_BEGIN(pt_t);
+  // Start from the eigenvectors of this scenario's previous projection when there is one (B changes little from one SQP
+  // iteration to the next): G = B V_prev is then nearly orthogonal and a few sweeps suffice instead of ~11 from V = I.
+  gptr Vp = c.ws + D.ws_Vp;
+  const bool warm = D.par.qp_warm_start && scal[DG_QP_NPREV] != 0.0;
   for (int e = TID; e < n * n; e += NT) {
     const int col = e / n, row = e % n;
-    G[e] = 0.5 * (Qg[(int64_t)row * n + col] + Qg[(int64_t)col * n + row]);
-    V[e] = row == col ? 1.0 : 0.0;
+    const double b = 0.5 * (Qg[(int64_t)row * n + col] + Qg[(int64_t)col * n + row]);
+    if (warm) { Mx[e] = b; V[e] = Vp[e]; }
+    else { G[e] = b; V[e] = row == col ? 1.0 : 0.0; }
   }
   XSYNC();
+  if (warm) {
+    for (int e = TID; e < n * n; e += NT) {
+      const int j = e / n, i = e % n;          // G[:, j] = B V[:, j]; B symmetric: column i of B is read along rows (coalesced over i)
+      double s0 = 0, s1 = 0;
+      int k = 0;
+      for (; k + 1 < n; k += 2) { s0 += Mx[(int64_t)k * n + i] * Vp[(int64_t)j * n + k]; s1 += Mx[(int64_t)(k + 1) * n + i] * Vp[(int64_t)j * n + k + 1]; }
+      if (k < n) s0 += Mx[(int64_t)k * n + i] * Vp[(int64_t)j * n + k];
+      G[e] = s0 + s1;
+    }
+    XSYNC();
+  }
   const int npad = n + (n & 1), rounds = npad - 1, half = npad / 2;
   // columns whose norm falls below 1e-14 |B| carry a numerically zero eigenvalue: rotating two of them against each other
   // never converges (their inner product is noise) and changes nothing that matters
@@ -107,12 +125,13 @@ __device__ __noinline__ void dev_xl_psd(const Ctx& c, gptr Qpd) {
     if (!again) break;
     PROF_COUNT(PH_C_NPREV, 1);
   }
-  // eigenvalues lambda_j = v_j . (B v_j) = v_j . g_j
+  // eigenvalues lambda_j = v_j . (B v_j) / v_j . v_j = v_j . g_j / |v_j|^2 (the basis is carried over many projections:
+  // its norms are not assumed); coefficient of the correction v_j v_j^T in lamv[n + j]
   for (int j = wave; j < n; j += NT / 64) {
-    double s = 0;
-    for (int i = lane; i < n; i += 64) s += V[(int64_t)j * n + i] * G[(int64_t)j * n + i];
-    s = wave_sum(s);
-    if (lane == 0) lamv[j] = s;
+    double s = 0, nv = 0;
+    for (int i = lane; i < n; i += 64) { const double v = V[(int64_t)j * n + i]; s += v * G[(int64_t)j * n + i]; nv += v * v; }
+    s = wave_sum(s); nv = wave_sum(nv);
+    if (lane == 0) { const double lj = s / nv; lamv[j] = lj; lamv[n + j] = lj < 0.0 ? (D.eig_floor - lj) / nv : 0.0; }
   }
   __syncthreads();
   const double reg = D.par.reg > 0 ? D.par.reg : 0.0;
@@ -120,13 +139,15 @@ __device__ __noinline__ void dev_xl_psd(const Ctx& c, gptr Qpd) {
     const int i = e / n, k = e % n;
     double a = 0.5 * (Qg[(int64_t)i * n + k] + Qg[(int64_t)k * n + i]);
     for (int j = 0; j < n; j++) {
-      const double lj = lamv[j];
-      if (lj < 0.0) a += (D.eig_floor - lj) * V[(int64_t)j * n + i] * V[(int64_t)j * n + k];
+      const double cj = lamv[n + j];
+      if (cj != 0.0) a += cj * V[(int64_t)j * n + i] * V[(int64_t)j * n + k];
     }
     if (i == k) a += reg;
     Mx[e] = a;
     if (Qpd) Qpd[e] = a;
+    Vp[e] = V[e];
   }
+  if (TID == 0) scal[DG_QP_NPREV] = 1.0;
   XSYNC();
   PROF_END(PH_JACOBI, pt_t);
 }
@@ -319,7 +340,6 @@ __device__ __noinline__ int dev_xl_qp(const Ctx& c) {
       else if (uu[k] > 0.0 && Rw.type == DG_R_IN_LB) x[am_col(D, Rw.a, Rw.k, Rw.idx)] = q.g[r];
     }
   }
-  if (TID == 0) scal[DG_QP_NPREV] = 0.0;
   __syncthreads();
   PROF_END(PH_QP, pt_qp);
   return ret;
