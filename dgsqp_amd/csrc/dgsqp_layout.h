@@ -75,7 +75,6 @@ struct DgProb {
   int nqa[DGSQP_MAX_AGENTS], qoff[DGSQP_MAX_AGENTS], sidx[DGSQP_MAX_AGENTS], eyidx[DGSQP_MAX_AGENTS];
   double inv_track_L;
   double eig_floor;    // value given to negative eigenvalues by _nearestPD (par.eig_floor, 1e-10 when not set)
-  double qp_dep_tol;   // a row whose projected curvature delta is below qp_dep_tol * (a' P a) counts as dependent on the active rows
   int uniform_nqa;
   int big;          // 2: XL layout (n > 128, dgsqp_xl.h).  1: the packed inverse P and the packed Householder reflectors live in the workgroup's global scratch (L2)
                     // instead of LDS: games whose LDS-resident layout exceeds the 160 KB arena
@@ -218,7 +217,6 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   int t2 = 0;
   D.uniform_nqa = 1;
   D.inv_track_L = 1.0 / P.track_L;
-  D.qp_dep_tol = 3e-15;
   D.eig_floor = par.eig_floor > 0.0 ? par.eig_floor : 1e-10;
   for (int a = 0; a < P.M; a++) {
     if (P.agents[a].model != P.agents[0].model) D.uniform_nqa = 0;

@@ -200,7 +200,7 @@ __device__ inline int qpw_add_constraint(const QpPtrs& q, QpwState& S, int lane,
     // legitimate rows come down to delta ~ 1e-14 app, next to the rounding noise an exactly dependent row leaves.  There
     // the explicit primal direction z = Y r - y decides: for an independent row -a_p.z reproduces delta, for a dependent
     // one both are unrelated noise.
-    bool indep = m < n && delta > D.qp_dep_tol * app && delta > 1e-18 * apap;
+    bool indep = m < n && delta > 3e-15 * app && delta > 1e-18 * apap;
     double z0 = 0.0, z1 = 0.0;
     if (indep) {
       double d0, d1;
