@@ -76,6 +76,8 @@ struct DgProb {
   double inv_track_L;
   double eig_floor;    // value given to negative eigenvalues by _nearestPD (par.eig_floor, 1e-10 when not set)
   int uniform_nqa;
+  int classic_qp;   // the QP runs the classical (J = L^-T) Goldfarb-Idnani kernels of dgsqp_xl.h: XL layout, or a projected Hessian
+                    // whose smallest eigenvalue (eig_floor + reg) is below 1e-8 -- the literal reg = 0 formula
   int big;          // 2: XL layout (n > 128, dgsqp_xl.h).  1: the packed inverse P and the packed Householder reflectors live in the workgroup's global scratch (L2)
                     // instead of LDS: games whose LDS-resident layout exceeds the 160 KB arena
   int ls_spec;      // trial step sizes of _line_search_3 rolled out concurrently (speculation width)
@@ -85,7 +87,7 @@ struct DgProb {
   int t2off[DGSQP_MAX_AGENTS];              // offset (doubles) of agent block in the Taylor tensor workspace
   int t2k[DGSQP_MAX_AGENTS];                // per-stage stride of that block = nqa*ndir
   int64_t t2_doubles;
-  int64_t ws_t2, ws_q, ws_base, ws_H, ws_tang, ws_Y, ws_P, ws_V, ws_R, ws_Vp, ws_doubles; // global workspace layout (doubles): Taylor tensor, raw Q, watchdog backups,
+  int64_t ws_t2, ws_q, ws_base, ws_H, ws_tang, ws_Y, ws_P, ws_V, ws_R, ws_Vp, ws_xM, ws_xJ, ws_xR, ws_doubles; // global workspace layout (doubles): Taylor tensor, raw Q, watchdog backups,
                                                              // costate-contracted dynamics Hessians, tangent trajectories
   DgRow rows[DG_NCMAX];
   DgDense dense[DG_NDMAX];
@@ -116,6 +118,10 @@ static inline std::string dg_build_layout(DgProb& D) {
   D.ws_R = D.ws_V + matsz;
   D.ws_Vp = D.ws_R + (D.big == 2 ? matsz + 4 * D.n : 0);      // XL: eigenvectors of the scenario's previous _nearestPD (Jacobi warm start)
   D.ws_doubles = D.ws_Vp + (D.big == 2 ? matsz : 0);
+  // matrices of the classical QP: M / its Cholesky factor, J, R (row-major n x n).  XL: the Jacobi buffers are reused
+  D.classic_qp = D.big == 2 || D.eig_floor + (D.par.reg > 0 ? D.par.reg : 0.0) < 1e-8;
+  if (D.big == 2) { D.ws_xM = D.ws_R; D.ws_xJ = D.ws_P; D.ws_xR = D.ws_V; }
+  else if (D.classic_qp) { D.ws_xM = D.ws_doubles; D.ws_xJ = D.ws_xM + (int64_t)D.n * D.n; D.ws_xR = D.ws_xJ + (int64_t)D.n * D.n; D.ws_doubles = D.ws_xR + (int64_t)D.n * D.n; }
   D.ws_doubles = (D.ws_doubles + 31) / 32 * 32;
   // ---- LDS arena
   DgLds& L = D.L;

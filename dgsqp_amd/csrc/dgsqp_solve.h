@@ -405,6 +405,7 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
       const int i = hf + NH * r;
       if (colok && i < n) Qpd[i * n + jc] = Br[r];
     }
+    __threadfence_block();   // (read back by other wavefronts when the classical QP takes over)
   }
   __syncthreads();
   PROF_END(PH_JACOBI, pt_t);
@@ -1053,6 +1054,11 @@ __device__ inline int dev_linearize_and_qp(const Ctx& c, bool do_qp, double* con
   if (!do_qp) return 0;
   dev_qt_mul(c);
   if (dg_prob.big == 2) { dev_xl_psd(c, Qpd); return dev_xl_qp(c); }   // n > 128: dgsqp_xl.h
+  if (dg_prob.classic_qp) {    // literal reg = 0 projection: condition ~1e12, classical active-set kernels on M itself
+    dev_psd_inverse(c, c.ws + dg_prob.ws_xM);
+    if (Qpd) { for (int e = TID; e < dg_prob.n * dg_prob.n; e += NT) Qpd[e] = (c.ws + dg_prob.ws_xM)[e]; }
+    return dev_xl_qp(c);
+  }
   dev_psd_inverse(c, Qpd);
   return dev_qp(c);
 }
@@ -1190,6 +1196,7 @@ __device__ inline void dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
     dev_qt_mul(c);
     int flag;
     if (D.big == 2) { dev_xl_psd(c, nullptr); flag = dev_xl_qp(c); }   // n > 128: dgsqp_xl.h
+    else if (D.classic_qp) { dev_psd_inverse(c, c.ws + D.ws_xM); flag = dev_xl_qp(c); }
     else { dev_psd_inverse(c, nullptr); flag = dev_qp(c); }
     total_qp++;
     if (flag != 0) { status = DGSQP_QP_FAIL; break; }

@@ -161,14 +161,16 @@ __device__ inline void xl_rot_cols(gptr X, int n, int rows, int ja, int jb, doub
   }
 }
 
-// ---- _solve_qp.  Out: du (L.o_du), lhat (L.o_lhat).  Returns 0 ok, 1 infeasible, 2 numerical failure / iteration limit.
+// ---- _solve_qp on the projected Hessian M held row-major in the scratch (ws_xM).  Also the QP of the smaller layouts when
+// M is too ill-conditioned for the explicit-inverse kernels (classic_qp, dgsqp_layout.h).
+// Out: du (L.o_du), lhat (L.o_lhat).  Returns 0 ok, 1 infeasible, 2 numerical failure / iteration limit.
 __device__ __noinline__ int dev_xl_qp(const Ctx& c) {
   const DgProb& D = dg_prob;
   const DgLds& L = D.L;
   lptr lds = LP(0);
   const int n = D.n, nc = D.nc;
   const QpPtrs q = qp_ptrs(c);
-  gptr Lc = c.ws + D.ws_R, J = c.ws + D.ws_P, R = c.ws + D.ws_V;      // all row-major n x n
+  gptr Lc = c.ws + D.ws_xM, J = c.ws + D.ws_xJ, R = c.ws + D.ws_xR;      // all row-major n x n
   lptr lhat = lds + L.o_lhat, x = q.xv, np = q.yv, dv = q.cvec, zv = q.wv, rv = q.rv, uu = q.lam, tv = q.tv, acc = q.rd;
   lds_d* scal = lds + L.scal;
   lds_d* red = lds + L.red;

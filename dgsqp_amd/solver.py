@@ -210,7 +210,10 @@ class DGSQP(AbstractSolver):
                  print_method=print,
                  xy_plot=None,
                  use_mx: bool = False,
-                 device: int = 0):
+                 device: int = 0,
+                 eig_floor: Optional[float] = None):
+        """``eig_floor``: see ``build_params`` (None = literal 1e-10 for reg >= 1e-6, 1e-6 at reg = 0; 1e-10 = always the
+        literal ``_nearestPD`` formula, solved by the slower classical active-set kernels when reg < 1e-8)."""
         self.joint_dynamics = joint_dynamics
         self.M = joint_dynamics.n_a
         self.print_method = (lambda s: None) if print_method is None else print_method
@@ -225,7 +228,7 @@ class DGSQP(AbstractSolver):
         self.num_ua_el = [int(self.N * m.n_u) for m in joint_dynamics.dynamics_models]
 
         self._problem = build_problem(joint_dynamics, costs, agent_constraints, shared_constraints, bounds, params)
-        self._cparams = build_params(params)
+        self._cparams = build_params(params) if eig_floor is None else build_params(params, eig_floor=eig_floor)
         _, _, self.n, n_c = problem_dims(self._problem)
         self.n_c_total = n_c
 

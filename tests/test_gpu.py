@@ -574,6 +574,42 @@ def test_xl_layout_three_agents_n150(oracle):
         assert rel(res['u'][b], ref['u'][b]) < 1e-6 and rel(res['l'][b], ref['l'][b]) < 1e-5
 
 
+def test_literal_nearest_pd_floor_runs_the_classical_qp(oracle):
+    """eig_floor = 1e-10 at reg = 0 is the literal DGSQP.py:1293 formula: the projected Hessian has condition ~1e12 and the
+    device switches to the classical (J = L^-T) active-set kernels -- the oracle's own algorithm.  Neither side solves that
+    QP to better than ~1e-3, so agreement is statistical: same converged count within a few, most scenarios identical."""
+    from dgsqp_amd.montecarlo import barc_racing_game, sample_scenarios
+    from dgsqp_amd.solver import DGSQP, build_problem, build_params
+    import dgsqp_amd.solver as sv
+    g = barc_racing_game(N=15, M=2)
+    P, par = build_problem(*g.solver_args()), tight_lsqr(build_params(g.params, eig_floor=1e-10))
+    orig = sv.build_params
+    sv.build_params = lambda p, eig_floor=None: tight_lsqr(orig(p, eig_floor=eig_floor))
+    try:
+        s = DGSQP(*g.solver_args(), print_method=None, eig_floor=1e-10)
+    finally:
+        sv.build_params = orig
+    assert s._cparams.eig_floor == 1e-10
+    B = 32
+    x0, u_tm = sample_scenarios(g, B, seed=0)
+    u = agent_major(u_tm)
+    l0 = np.array([oracle.dual_init(P, par, x0[b], u[b]) for b in range(3)])
+    qp = s.qp_batch(x0[:3], u[:3], l0)
+    for b in range(3):
+        o = oracle.evaluate(P, x0[b], u[b], l0[b], 1)
+        Qpd = oracle.nearest_pd(o['Q'], 0.0, 1e-10)
+        assert np.abs(qp['Qpd'][b] - Qpd).max() < 1e-11 * max(1.0, np.abs(o['Q']).max())
+        du, lam, flag = oracle.qp(Qpd, o['q'], o['G'], o['g'])
+        assert qp['flag'][b] == flag == 0 and (o['G'] @ qp['du'][b] + o['g']).max() < 1e-4    # (the oracle's own: up to 1e-4)
+        obj = lambda z: 0.5 * z @ Qpd @ z + o['q'] @ z
+        assert abs(obj(qp['du'][b]) - obj(du)) < 1e-4 * max(1.0, abs(obj(du)))
+    res = s.solve_batch(x0, u_tm)
+    ref = oracle.solve_batch(P, par, x0, u, nthreads=8)
+    same = (res['status'] == ref['status']) & (res['num_iters'] == ref['num_iters']) & (res['qp_solves'] == ref['qp_solves'])
+    assert same.mean() >= 0.7, same.mean()
+    assert abs(int((res['status'] <= 1).sum()) - int((ref['status'] <= 1).sum())) <= 4
+
+
 def test_large_batch_equals_small_batches(games):
     """Every scenario of a 3,500-scenario launch (14 per workgroup, dynamic ticket order) comes out exactly as in a small
     launch: no state leaks between the scenarios a workgroup processes (warm-started active sets, trajectory tags)."""

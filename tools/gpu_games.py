@@ -28,6 +28,8 @@ def tight(par):
     par.lsqr_iter_mult = 20
     if os.environ.get('DGSQP_NO_WARM'):
         par.qp_warm_start = 0
+    if os.environ.get('DGSQP_EIG_FLOOR'):       # e.g. 1e-10: the literal _nearestPD formula on device and oracle
+        par.eig_floor = float(os.environ['DGSQP_EIG_FLOOR'])
     return par
 
 

@@ -6,7 +6,7 @@ from dgsqp_amd.montecarlo import kinematic_racing_game, dynamic_racing_game, sam
 from dgsqp_amd.solver import DGSQP
 from oracle import oracle
 which, N, B = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-game = kinematic_racing_game('curve' if which == 'kbcurve' else 'chicane', N=N) if which.startswith('kb') else dynamic_racing_game(N=N, rk4_substeps=10)
+game = kinematic_racing_game('curve' if which == 'kbcurve' else 'chicane', N=N, reg=0.0 if which == 'kbcurve' else 1e-3) if which.startswith('kb') else dynamic_racing_game(N=N, rk4_substeps=10)   # reg of curve.py:161 / chicane.py:164
 import dgsqp_amd.solver as sv
 if os.environ.get('TIGHT'):
     _o = sv.build_params
