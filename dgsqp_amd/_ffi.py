@@ -60,7 +60,7 @@ class ParamsT(C.Structure):
         ('line_search_iters', C.c_int32), ('nonmono_ls', C.c_int32), ('sqp_iters', C.c_int32),
         ('merit_function', C.c_int32), ('rel_tol_req', C.c_int32), ('lsqr_iter_lim', C.c_int32),
         ('lsqr_atol', C.c_double), ('lsqr_btol', C.c_double),
-        ('qp_warm_start', C.c_int32), ('reserved_', C.c_int32),
+        ('qp_warm_start', C.c_int32), ('hessian_bfgs', C.c_int32),
         ('eig_floor', C.c_double),
     ]
 

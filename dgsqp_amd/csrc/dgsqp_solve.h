@@ -1157,6 +1157,57 @@ __device__ inline int dev_watchdog(const Ctx& c, double mu, const LinScal& Sk) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// hessian_approximation = 'bfgs' (DGSQP.py:357-364, :535-557): damped BFGS update (Nocedal & Wright, Procedure 18.2) of the
+// PROJECTED Hessian of the previous iteration,
+//   s = u - u_prev,  y = d(u, l) - d(u_prev, l)  with  d = q + G^T l  at the CURRENT multipliers,
+//   B = _nearestPD(Q_prev),  theta = 1 if s'y >= 0.2 s'Bs else 0.8 s'Bs / (s'Bs - s'y),  r = theta y + (1 - theta) B s,
+//   Q = B - (B s)(B s)'/(s'Bs) + r r'/(s'r).
+// Leaves q, g, packed G at u (no exact Hessian is evaluated) and Q in the raw-Hessian slot of the workspace.
+__device__ __noinline__ void dev_bfgs_hessian(const Ctx& c) {
+  const DgProb& D = dg_prob;
+  const DgLds& L = D.L;
+  lptr lds = LP(0);
+  const int n = D.n;
+  gptr up = c.ws + D.ws_bfgs, dm = up + n, Qk = c.ws + D.ws_bfgs + 2 * n, Bm = Qk + (int64_t)n * n, Qg = c.ws + D.ws_q;
+  lptr uprev = lds + L.v;                 // persistent n-vector, rewritten by dev_qt_mul later in the iteration
+  lptr yv = lds + L.p_y, Bs = lds + L.p_t, rv = lds + L.p_c;    // QP scratch (idle here)
+  __syncthreads();
+  for (int i = TID; i < n; i += NT) uprev[i] = up[i];
+  __syncthreads();
+  dev_evaluate(c, uprev, 0.0, nullptr, false);
+  dev_stat_vector(c, lds + L.l, lds + L.d);
+  for (int i = TID; i < n; i += NT) dm[i] = lds[L.d + i];
+  // B = _nearestPD(Q_prev) (no reg, :364): through the projection kernel, whose output includes reg on the diagonal
+  for (int e = TID; e < n * n; e += NT) Qg[e] = Qk[e];
+  __threadfence_block();
+  __syncthreads();
+  if (D.big == 2) dev_xl_psd(c, Bm); else dev_psd_inverse(c, Bm);
+  __threadfence_block();
+  __syncthreads();
+  dev_evaluate(c, lds + L.u, 0.0, nullptr, false);
+  dev_stat_vector(c, lds + L.l, lds + L.d);
+  const double reg = D.par.reg > 0 ? D.par.reg : 0.0;
+  for (int i = TID; i < n; i += NT) { uprev[i] = lds[L.u + i] - up[i]; yv[i] = lds[L.d + i] - dm[i]; }   // uprev <- s
+  __syncthreads();
+  double a = 0, b = 0;
+  for (int i = TID; i < n; i += NT) {
+    double t = 0;
+    for (int j = 0; j < n; j++) t += (Bm[(int64_t)j * n + i] - (i == j ? reg : 0.0)) * uprev[j];     // B symmetric: coalesced over i
+    Bs[i] = t; a += uprev[i] * t; b += uprev[i] * yv[i];
+  }
+  const double sBs = block_sum(a, lds + L.red), sy = block_sum(b, lds + L.red);
+  const double th = sy >= 0.2 * sBs ? 1.0 : 0.8 * sBs / (sBs - sy);
+  a = 0;
+  for (int i = TID; i < n; i += NT) { const double r = th * yv[i] + (1.0 - th) * Bs[i]; rv[i] = r; a += uprev[i] * r; }
+  const double sr = block_sum(a, lds + L.red);
+  for (int e = TID; e < n * n; e += NT) {
+    const int i = e / n, j = e % n;
+    Qg[e] = (Bm[e] - (i == j ? reg : 0.0)) - Bs[i] * Bs[j] / sBs + rv[i] * rv[j] / sr;
+  }
+  __threadfence_block();
+  __syncthreads();
+}
+
 // DGSQP.solve() for one scenario (DGSQP.py:302-507)
 // ------------------------------------------------------------------------------------------------
 struct SolveOutPtrs {
@@ -1180,7 +1231,16 @@ __device__ inline void dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
   double cond[3] = {0, 0, 0};
   const bool l1 = D.par.merit_function == DGSQP_MERIT_STAT_L1;
   while (true) {
-    dev_evaluate(c, lds + L.u, 0.0, nullptr, true);
+    if (sqp_it == 0 || !D.par.hessian_bfgs) dev_evaluate(c, lds + L.u, 0.0, nullptr, true);   // exact Hessian (DGSQP.py:353-355)
+    else dev_bfgs_hessian(c);
+    if (D.par.hessian_bfgs) {    // what the next iteration's update starts from: this iteration's Hessian and point
+      gptr up = c.ws + D.ws_bfgs, Qk = c.ws + D.ws_bfgs + 2 * n;
+      cgptr Qg = c.ws + D.ws_q;
+      for (int i = TID; i < n; i += NT) up[i] = lds[L.u + i];
+      for (int e = TID; e < n * n; e += NT) Qk[e] = Qg[e];
+      __threadfence_block();
+      __syncthreads();
+    }
     dev_stat_vector(c, lds + L.l, lds + L.d);
     {
       double gm = -INFINITY, cm = 0, sm = 0;

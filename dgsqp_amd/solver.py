@@ -149,8 +149,8 @@ def build_params(params: DGSQPParams, eig_floor: Optional[float] = None) -> _ffi
     1e-10 leaves a QP of condition 1e12.  Pass 1e-10 for the literal formula."""
     if not params.conv_approx:
         raise NotImplementedError('conv_approx=False (IPOPT Newton step, DGSQP.py:204-228) is not on the Monte-Carlo path')
-    if params.hessian_approximation != 'none':
-        raise NotImplementedError("hessian_approximation='bfgs' (DGSQP.py:535-557) is not implemented")
+    if params.hessian_approximation not in ('none', 'bfgs'):
+        raise ValueError(f'Hessian approximation method {params.hessian_approximation} not implmented')   # (DGSQP.py:550)
     if params.merit_function not in ('stat_l1', 'stat'):
         raise ValueError(f'Merit function option {params.merit_function} not recognized')
     p = _ffi.ParamsT()
@@ -161,6 +161,7 @@ def build_params(params: DGSQPParams, eig_floor: Optional[float] = None) -> _ffi
     p.lsqr_iter_lim = 0                    # scipy default 2*n_c
     p.lsqr_atol = p.lsqr_btol = 1e-6       # scipy >= 1.12 defaults of sparse.linalg.lsqr
     p.qp_warm_start = int(getattr(params, 'qp_warm_start', 1))
+    p.hessian_bfgs = 1 if params.hessian_approximation == 'bfgs' else 0
     p.eig_floor = max(1e-10, 1e-6 - float(params.reg)) if eig_floor is None else float(eig_floor)
     return p
 

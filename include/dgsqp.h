@@ -149,7 +149,8 @@ typedef struct {
   double lsqr_atol, lsqr_btol; /* scipy 1.15 defaults 1e-6 */
   int32_t qp_warm_start;  /* implementation knob (not in DGSQPParams): 1 = start each QP's active-set search from the
                              previous QP's final active set (same minimiser, shorter path); 0 = cold start */
-  int32_t reserved_;
+  int32_t hessian_bfgs;   /* DGSQPParams.hessian_approximation: 0 'none' (exact game Hessian every iteration), 1 'bfgs' (damped BFGS
+                             update of the projected Hessian after the first iteration, DGSQP.py:353-364, :535-557) */
   double eig_floor;       /* value _nearestPD gives to the negative eigenvalues; the reference uses 1e-10 (DGSQP.py:1293).
                              <= 0 selects 1e-10.  With reg = 0 that leaves a Hessian with condition 1e12 which neither
                              OSQP (sigma = 1e-6, polish delta = 1e-6) nor an explicit-inverse QP solves to better than

@@ -1177,10 +1177,37 @@ static void solve_one(const dgsqp_problem_t& P, const dgsqp_params_t& par, const
   out.l_init = l;
   int rel_tol_its = 0, sqp_it = 0, status = DGSQP_MAX_IT, total_qp = 0;
   double p_feas = 0, comp = 0, stat = 0;
+  vec u_im1, Q_prev;
   while (true) {
     Lin k;
-    eval_lin(c, u, l, true, k);
-    vec u_im1 = u, l_im1 = l;
+    if (sqp_it == 0 || !par.hessian_bfgs) {
+      eval_lin(c, u, l, true, k);          // exact Hessian (DGSQP.py:353-355)
+    } else {
+      // damped BFGS (Nocedal & Wright, Procedure 18.2) on the projected Hessian of the previous iteration (:357-364, :535-557):
+      // s = u - u_prev, y = d(u, l) - d(u_prev, l) with d = q + G^T l at the CURRENT multipliers
+      eval_lin(c, u, l, false, k);
+      Lin km;
+      eval_lin(c, u_im1, l, false, km);
+      const int n = L.n, nc = L.nc;
+      vec s(n), y(n), Bm, Bs(n), r(n);
+      for (int i = 0; i < n; i++) {
+        double d = k.q[i], dm = km.q[i];
+        for (int rr = 0; rr < nc; rr++) { d += k.G[(size_t)rr * n + i] * l[rr]; dm += km.G[(size_t)rr * n + i] * l[rr]; }
+        s[i] = u[i] - u_im1[i]; y[i] = d - dm;
+      }
+      nearest_pd(n, Q_prev.data(), 0.0, Bm, par.eig_floor);           // self._nearestPD(Q_i): no reg (:364, :1290-1296)
+      double sBs = 0, sy = 0;
+      for (int i = 0; i < n; i++) { double t = 0; for (int j = 0; j < n; j++) t += Bm[(size_t)i * n + j] * s[j]; Bs[i] = t; sBs += s[i] * t; sy += s[i] * y[i]; }
+      const double th = sy >= 0.2 * sBs ? 1.0 : 0.8 * sBs / (sBs - sy);
+      double sr = 0;
+      for (int i = 0; i < n; i++) { r[i] = th * y[i] + (1 - th) * Bs[i]; sr += s[i] * r[i]; }
+      k.Q.assign((size_t)n * n, 0.0);
+      for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) k.Q[(size_t)i * n + j] = Bm[(size_t)i * n + j] - Bs[i] * Bs[j] / sBs + r[i] * r[j] / sr;
+    }
+    Q_prev = k.Q;
+    u_im1 = u;
+    vec l_im1 = l;
     // convergence test (:368-398)
     p_feas = 0; comp = 0; stat = 0;
     double gmax = -INF;

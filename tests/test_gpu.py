@@ -610,6 +610,36 @@ def test_literal_nearest_pd_floor_runs_the_classical_qp(oracle):
     assert abs(int((res['status'] <= 1).sum()) - int((ref['status'] <= 1).sum())) <= 4
 
 
+def test_bfgs_hessian_option(oracle):
+    """DGSQPParams.hessian_approximation = 'bfgs' (DGSQP.py:353-364, :535-557): exact Hessian at the first iteration, damped
+    BFGS updates of the projected Hessian afterwards, against the oracle; more iterations than with exact Hessians."""
+    from dgsqp_amd.montecarlo import kinematic_racing_game, sample_scenarios
+    from dgsqp_amd.solver import DGSQP, build_problem, build_params
+    import dgsqp_amd.solver as sv
+    g = kinematic_racing_game('curve', N=15)
+    g.params.hessian_approximation = 'bfgs'
+    P, par = build_problem(*g.solver_args()), tight_lsqr(build_params(g.params))
+    assert par.hessian_bfgs == 1
+    orig = sv.build_params
+    sv.build_params = lambda p: tight_lsqr(orig(p))
+    try:
+        s = DGSQP(*g.solver_args(), print_method=None)
+    finally:
+        sv.build_params = orig
+    B = 24
+    x0, u_tm = sample_scenarios(g, B, seed=1)
+    u = agent_major(u_tm)
+    res = s.solve_batch(x0, u_tm)
+    ref = oracle.solve_batch(P, par, x0, u, nthreads=8)
+    same = (res['status'] == ref['status']) & (res['num_iters'] == ref['num_iters']) & (res['qp_solves'] == ref['qp_solves'])
+    assert same.mean() >= 0.85, (same.mean(), res['num_iters'], ref['num_iters'])
+    for b in np.where(same & (ref['status'] <= 1))[0]:
+        assert rel(res['u'][b], ref['u'][b]) < 1e-5 and rel(res['l'][b], ref['l'][b]) < 1e-4
+    g.params.hessian_approximation = 'none'
+    exact = oracle.solve_batch(P, tight_lsqr(build_params(g.params)), x0, u, nthreads=8)
+    assert ref['num_iters'].mean() > exact['num_iters'].mean()
+
+
 def test_large_batch_equals_small_batches(games):
     """Every scenario of a 3,500-scenario launch (14 per workgroup, dynamic ticket order) comes out exactly as in a small
     launch: no state leaks between the scenarios a workgroup processes (warm-started active sets, trajectory tags)."""

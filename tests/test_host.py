@@ -33,8 +33,9 @@ def test_unsupported_options_raise():
     from dgsqp_amd.solver_types import DGSQPParams
     with pytest.raises(NotImplementedError):
         build_params(DGSQPParams(conv_approx=False))
-    with pytest.raises(NotImplementedError):
-        build_params(DGSQPParams(hessian_approximation='bfgs'))
+    assert build_params(DGSQPParams(hessian_approximation='bfgs')).hessian_bfgs == 1
+    with pytest.raises(ValueError):
+        build_params(DGSQPParams(hessian_approximation='sr1'))
     with pytest.raises(ValueError):
         build_params(DGSQPParams(merit_function='nope'))
 
