@@ -496,6 +496,7 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
       __syncthreads();
     }
     PROF_END(PH_Q_REFINE, pq6);
+    if (q.scal[2] == 0.0) break;   // well-conditioned QP: the polish moves x by rounding errors only, nothing to re-verify
   }
   if (TID == 0) q.scal[1] = (double)S.m;
   __syncthreads();
