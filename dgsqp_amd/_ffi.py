@@ -8,7 +8,7 @@ import ctypes as C
 import os
 import pathlib
 
-MAX_AGENTS = 4
+MAX_AGENTS = 6
 MAX_SEGS = 16
 MAX_NQA = 8
 MAX_LANES = 2

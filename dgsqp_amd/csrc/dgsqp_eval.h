@@ -932,21 +932,24 @@ __device__ __noinline__ void dev_hessian_adjoint(const Ctx& c) {
         case 1: dev_hessian_row<8, 1>(c, row, a, k0, j0); break;
         case 2: dev_hessian_row<8, 2>(c, row, a, k0, j0); break;
         case 3: dev_hessian_row<8, 3>(c, row, a, k0, j0); break;
-        default: dev_hessian_row<8, 4>(c, row, a, k0, j0); break;
+        case 4: dev_hessian_row<8, 4>(c, row, a, k0, j0); break;
+        default: dev_hessian_row_generic<8>(c, row, a, k0, j0); break;   // 5, 6 agents
       }
     } else if (D.nqa[0] == 4) {
       switch (M) {
         case 1: dev_hessian_row<4, 1>(c, row, a, k0, j0); break;
         case 2: dev_hessian_row<4, 2>(c, row, a, k0, j0); break;
         case 3: dev_hessian_row<4, 3>(c, row, a, k0, j0); break;
-        default: dev_hessian_row<4, 4>(c, row, a, k0, j0); break;
+        case 4: dev_hessian_row<4, 4>(c, row, a, k0, j0); break;
+        default: dev_hessian_row_generic<4>(c, row, a, k0, j0); break;   // 5, 6 agents
       }
     } else {
       switch (M) {
         case 1: dev_hessian_row<6, 1>(c, row, a, k0, j0); break;
         case 2: dev_hessian_row<6, 2>(c, row, a, k0, j0); break;
         case 3: dev_hessian_row<6, 3>(c, row, a, k0, j0); break;
-        default: dev_hessian_row<6, 4>(c, row, a, k0, j0); break;
+        case 4: dev_hessian_row<6, 4>(c, row, a, k0, j0); break;
+        default: dev_hessian_row_generic<6>(c, row, a, k0, j0); break;   // 5, 6 agents
       }
     }
   }

@@ -17,7 +17,7 @@
 #define DG_BLOCK 512      // threads per scenario workgroup (8 wavefronts = 2 per SIMD, to hide LDS latency)
 #endif
 #define DG_NH (DG_BLOCK / 128)  // row-groups of the register-resident matrix slices (thread = column x row-group)
-#define DG_LDS_LIMIT 163840
+#define DG_LDS_LIMIT (163840 - 512)   // 160 KB per CU minus the kernel's static LDS (256 B)
 
 enum { DG_R_OBS = 0, DG_R_RATE_UB, DG_R_RATE_LB, DG_R_IN_UB, DG_R_IN_LB, DG_R_ST_UB, DG_R_ST_LB, DG_R_LANE };
 

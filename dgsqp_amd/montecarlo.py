@@ -142,14 +142,19 @@ def barc_racing_game(N=15, M=2, reg=0.0) -> Game:
                 name=f'kb_barc_M{M}_N{N}', sampler='circuit')
 
 
-def merge_game(N=20, reg=0.0) -> Game:
-    """Three-car highway merge of scripts/DGSQP_merge_monte_carlo.py: kinematic unicycles (rk3, one sub-step, dt 0.1,
-    :95-123), two cars on the straight lane and one on the ramp (lane geometry :40-74), goal-tracking costs (:253-303),
-    lane rows at every stage (:316-342), obstacle rows from k=1 (:344-356), |v| <= 2, |F| <= 2, |omega| <= 4.5 (:126-159),
-    radii 0.1 (:162-164), solver parameters with reg=0 (:176-190).  No warm start: the script solves from zero inputs."""
+_MERGE_GOAL_X = (4.0, 4.5, 4.25, 4.75, 5.25, 5.0)          # merge.py:85-87 for the first three cars
+_MERGE_X_NOM = (0.0, 0.5, 0.25, 1.0, 1.5, -0.35)          # merge.py:430,443,456: cars 1, 2 on the straight lane, car 3 on the ramp
+
+
+def merge_game(N=20, reg=0.0, M=3) -> Game:
+    """Highway merge of scripts/DGSQP_merge_monte_carlo.py: kinematic unicycles (rk3, one sub-step, dt 0.1, :95-123), cars on
+    the straight lane and on the ramp (lane geometry :40-74), goal-tracking costs (:253-303), lane rows at every stage
+    (:316-342), obstacle rows for every pair from k=1 (:344-356), |v| <= 2, |F| <= 2, |omega| <= 4.5 (:126-159), radii 0.1
+    (:162-164), solver parameters with reg=0 (:176-190).  No warm start: the script solves from zero inputs.
+    ``M = 3`` is the script; up to 6 cars (BASELINE configs[4]'s family) repeat its pattern -- every third car on the ramp."""
     dt = 0.1
     cfg = lambda: UnicycleConfig(dt=dt, model_name='kinematic_bicycle', noise=False, discretization_method='rk3', code_gen=False, M=1)
-    models = [CasadiKinematicUnicycle(0, cfg()) for _ in range(3)]
+    models = [CasadiKinematicUnicycle(0, cfg()) for _ in range(M)]
     joint = CasadiDecoupledMultiAgentDynamicsModel(0, models, MultiAgentModelConfig(
         dt=dt, discretization_method='rk3', use_mx=False, code_gen=False, verbose=True, compute_hessians=True, M=1))
     lw, mw, mp, th, r = 0.3, 0.3, 1.5, np.pi / 12, 0.1
@@ -159,20 +164,19 @@ def merge_game(N=20, reg=0.0) -> Game:
     x7 = (mp + mw / np.sin(th), 0.0)
     neg = lambda v: (-v[0], -v[1])
     straight = lambda: LaneBoundaries([LaneHalfPlane(n_lo=ns, anchor=x1, r=r), LaneHalfPlane(n_lo=neg(ns), anchor=x3, r=r)])
-    ramp = LaneBoundaries([LaneHalfPlane(n_lo=nm, n_hi=ns, brk=x6[0], anchor=x6, r=r),
-                           LaneHalfPlane(n_lo=neg(nm), n_hi=neg(ns), brk=x7[0], anchor=x7, r=r)])
-    goals = ((4.0, 0.15, 0.3, 0.0), (4.5, 0.15, 0.3, 0.0), (4.25, 0.15, 0.3, 0.0))
-    costs = [GoalTrackingCost(input_weight=(0.1, 0.1), state_weight=(1.0, 10.0, 1.0, 1.0), goal=g, terminal_multiplier=10.0)
-             for g in goals]
+    ramp = lambda: LaneBoundaries([LaneHalfPlane(n_lo=nm, n_hi=ns, brk=x6[0], anchor=x6, r=r),
+                                   LaneHalfPlane(n_lo=neg(nm), n_hi=neg(ns), brk=x7[0], anchor=x7, r=r)])
+    costs = [GoalTrackingCost(input_weight=(0.1, 0.1), state_weight=(1.0, 10.0, 1.0, 1.0), goal=(_MERGE_GOAL_X[i], 0.15, 0.3, 0.0),
+                              terminal_multiplier=10.0) for i in range(M)]
     inf = np.inf
     ub = [VehicleState(x=Position(x=inf, y=inf), e=OrientationEuler(psi=inf), v=BodyLinearVelocity(v_long=2.0, v_tran=inf),
-                       w=BodyAngularVelocity(w_psi=inf), u=VehicleActuation(u_a=2.0, u_steer=4.5)) for _ in range(3)]
+                       w=BodyAngularVelocity(w_psi=inf), u=VehicleActuation(u_a=2.0, u_steer=4.5)) for _ in range(M)]
     lb = [VehicleState(x=Position(x=-inf, y=-inf), e=OrientationEuler(psi=-inf), v=BodyLinearVelocity(v_long=-2.0, v_tran=-inf),
-                       w=BodyAngularVelocity(w_psi=-inf), u=VehicleActuation(u_a=-2.0, u_steer=-4.5)) for _ in range(3)]
+                       w=BodyAngularVelocity(w_psi=-inf), u=VehicleActuation(u_a=-2.0, u_steer=-4.5)) for _ in range(M)]
     params = DGSQPParams(solver_name='DGSQP', dt=dt, N=N, reg=reg, merit_function='stat_l1', nonmono_ls=True,
                          line_search_iters=50, sqp_iters=50, p_tol=1e-3, d_tol=1e-3, beta=0.01, tau=0.5, verbose=False)
-    return Game(joint, costs, [straight(), straight(), ramp], CollisionAvoidance([0.1] * 3), {'ub': ub, 'lb': lb}, params,
-                None, 0.0, 0.2, name=f'merge_N{N}', sampler='merge')
+    return Game(joint, costs, [ramp() if i % 3 == 2 else straight() for i in range(M)], CollisionAvoidance([0.1] * M),
+                {'ub': ub, 'lb': lb}, params, None, 0.0, 0.2, name=f'merge_N{N}' if M == 3 else f'merge_M{M}_N{N}', sampler='merge')
 
 
 # ---------------------------------------------------------------------------------------------
@@ -410,35 +414,40 @@ def _sample_scenarios_circuit(game: Game, B: int, seed: int, max_rounds: int):
 
 
 def _sample_scenarios_merge(game: Game, B: int, seed: int):
-    """Sampler of scripts/DGSQP_merge_monte_carlo.py:421-480 (seed 1 there): cars 1 and 2 around x = 0 / 0.5 on the straight
-    lane, car 3 on the ramp; zero warm start; rejection if the zero-input trajectories collide.  The script leaves car 3's
-    check trajectory at the origin (``car2_q_ws[0]`` is assigned twice, :471-472) -- reproduced, it decides which samples pass."""
+    """Sampler of scripts/DGSQP_merge_monte_carlo.py:421-480 (seed 1 there): cars on the straight lane around their nominal
+    x, every third car on the ramp; zero warm start; rejection if the zero-input trajectories collide.  For the script's
+    three cars its quirk is reproduced -- car 3's check trajectory is left at the origin (``car2_q_ws[0]`` is assigned
+    twice, :471-472) --, it decides which samples pass; with more cars every trajectory is checked."""
     rng = np.random.default_rng(seed)
     N = game.params.N
     models = game.joint_model.dynamics_models
+    M = len(models)
     radii = list(game.shared_constraints.radii)
     mw, mp, th = 0.3, 1.5, np.pi / 12
     x5, x7 = mp, mp + mw / np.sin(th)
     out = []
     while len(out) < B:
         q = []
-        for x_nom in (0.0, 0.5):
-            q.append(np.array([x_nom + 0.5 * rng.random() - 0.25, 0.15 + 0.1 * rng.random() - 0.05,
-                               0.3 * (1 + 0.06 * rng.random() - 0.03), (5 * rng.random() - 2.5) * np.pi / 180]))
-        x_nom, y_nom = 0.25, -((x7 + x5) / 2 - 0.25) * np.tan(th)
-        s_rand, ey_rand = 0.5 * rng.random() - 0.25, 0.1 * rng.random() - 0.05
-        q.append(np.array([x_nom + s_rand * np.cos(th) - ey_rand * np.sin(th), y_nom + s_rand * np.sin(th) + ey_rand * np.cos(th),
-                           0.3 * (1 + 0.06 * rng.random() - 0.03), np.pi / 12 + (5 * rng.random() - 2.5) * np.pi / 180]))
+        for i in range(M):
+            x_nom = _MERGE_X_NOM[i]
+            if i % 3 != 2:
+                q.append(np.array([x_nom + 0.5 * rng.random() - 0.25, 0.15 + 0.1 * rng.random() - 0.05,
+                                   0.3 * (1 + 0.06 * rng.random() - 0.03), (5 * rng.random() - 2.5) * np.pi / 180]))
+            else:
+                y_nom = -((x7 + x5) / 2 - x_nom) * np.tan(th)
+                s_rand, ey_rand = 0.5 * rng.random() - 0.25, 0.1 * rng.random() - 0.05
+                q.append(np.array([x_nom + s_rand * np.cos(th) - ey_rand * np.sin(th), y_nom + s_rand * np.sin(th) + ey_rand * np.cos(th),
+                                   0.3 * (1 + 0.06 * rng.random() - 0.03), np.pi / 12 + (5 * rng.random() - 2.5) * np.pi / 180]))
         traj = []
         for a, mdl in enumerate(models):
-            qa = [q[a].copy() if a < 2 else np.zeros(4)]
+            qa = [np.zeros(4) if (M == 3 and a == 2) else q[a].copy()]
             for _ in range(N):
                 qa.append(mdl.fd(qa[-1], np.zeros(2)))
             traj.append(np.array(qa))
         hit = False
-        for i in range(3):
-            for j in range(i + 1, 3):
+        for i in range(M):
+            for j in range(i + 1, M):
                 hit |= bool((np.linalg.norm(traj[i][:, :2] - traj[j][:, :2], axis=1) < radii[i] + radii[j]).any())
         if not hit:
             out.append(np.concatenate(q))
-    return np.ascontiguousarray(np.array(out)), np.zeros((B, N, 6))
+    return np.ascontiguousarray(np.array(out)), np.zeros((B, N, 2 * M))

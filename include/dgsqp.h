@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DGSQP_MAX_AGENTS 4
+#define DGSQP_MAX_AGENTS 6
 #define DGSQP_MAX_SEGS 16
 #define DGSQP_MAX_NQA 8 /* largest per-agent state (dynamic bicycle) */
 #define DGSQP_NUA 2     /* every vehicle model of the path has 2 inputs */

@@ -269,7 +269,7 @@ def test_layout_plan_of_the_supported_games():
     from dgsqp_amd.solver import build_params, build_problem, plan, problem_dims
     cases = [(kinematic_racing_game('chicane', N=25), 0), (dynamic_racing_game(N=25), 0), (kinematic_racing_game('curve', N=10), 0),
              (kinematic_racing_game('curve', N=5, M=1), 0), (barc_racing_game(N=15, M=3), 0), (kinematic_racing_game('curve', N=30), 1),
-             (merge_game(N=20), 1), (barc_racing_game(N=21, M=3), 1), (kinematic_racing_game('curve', N=16, M=4), 1),
+             (merge_game(N=20), 1), (merge_game(N=10, M=6), 1), (barc_racing_game(N=21, M=3), 1), (kinematic_racing_game('curve', N=16, M=4), 1),
              (kinematic_racing_game('curve', N=25, M=3), 2), (kinematic_racing_game('curve', N=40), 2)]
     for g, layout in cases:
         P, par = build_problem(*g.solver_args()), build_params(g.params)

@@ -21,7 +21,7 @@ elif kind == 'agents3':     # scripts/DGSQP_monte_carlo_agents.py at exp_M = [3]
 elif kind in ('kbcurve0', 'kbchicane0'):
     g = mc.kinematic_racing_game('curve' if kind == 'kbcurve0' else 'chicane', N=int(sys.argv[3]) if len(sys.argv) > 3 else 25, reg=0.0)
 else:
-    g = mc.merge_game(N=int(sys.argv[3]) if len(sys.argv) > 3 else 20)
+    g = mc.merge_game(N=int(sys.argv[3]) if len(sys.argv) > 3 else 20, M=int(os.environ.get('DGSQP_M', '3')))
 if os.environ.get('DGSQP_BFGS'):
     g.params.hessian_approximation = 'bfgs'
 M, N = g.joint_model.n_a, g.params.N
