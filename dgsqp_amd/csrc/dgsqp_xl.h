@@ -85,20 +85,28 @@ __device__ __noinline__ void dev_xl_psd(const Ctx& c, gptr Qpd) {
           }
         }
         double cs_[XL_GRP], sn_[XL_GRP];
+        // the three inner products of every pair by wavefront reductions; the rotation angles of the XL_GRP pairs are then
+        // computed side by side, pair s in lane s (fp64 sqrt / divide chains are the expensive part), and broadcast
+        double mal = 0.0, mbe = 0.0, mgm = 0.0;
   #pragma unroll
         for (int s = 0; s < XL_GRP; s++) {
           double al = 0, be = 0, gm = 0;
   #pragma unroll
           for (int h = 0; h < XL_NV; h++) { al += ga[s][h] * ga[s][h]; be += gb[s][h] * gb[s][h]; gm += ga[s][h] * gb[s][h]; }
           al = wave_sum(al); be = wave_sum(be); gm = wave_sum(gm);
-          double cs = 1.0, sn = 0.0;
-          if (pp[s] >= 0 && __builtin_fabs(gm) > 1e-14 * sqrt(al * be) && al > tiny && be > tiny) {
-            const double zeta = (be - al) / (2.0 * gm);
-            const double t = (zeta >= 0 ? 1.0 : -1.0) / (__builtin_fabs(zeta) + sqrt(1.0 + zeta * zeta));
-            cs = 1.0 / sqrt(1.0 + t * t); sn = cs * t;
-            rotated = 1;
-          }
-          cs_[s] = cs; sn_[s] = sn;
+          if (pp[s] < 0) gm = 0.0;
+          if (lane == s) { mal = al; mbe = be; mgm = gm; }
+        }
+        double mcs = 1.0, msn = 0.0;
+        if (__builtin_fabs(mgm) > 1e-14 * sqrt(mal * mbe) && mal > tiny && mbe > tiny) {
+          const double zeta = (mbe - mal) / (2.0 * mgm);
+          const double t = (zeta >= 0 ? 1.0 : -1.0) / (__builtin_fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          mcs = 1.0 / sqrt(1.0 + t * t); msn = mcs * t;
+        }
+  #pragma unroll
+        for (int s = 0; s < XL_GRP; s++) {
+          cs_[s] = lane_bcast(mcs, s); sn_[s] = lane_bcast(msn, s);
+          if (sn_[s] != 0.0) rotated = 1;
         }
   #pragma unroll
         for (int s = 0; s < XL_GRP; s++) {
