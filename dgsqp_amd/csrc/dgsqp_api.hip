@@ -89,7 +89,8 @@ dg_evaluate_kernel(const DgProb* __restrict__ D, int64_t B, const double* __rest
     if (x) for (int i = TID; i < (dg_prob.N + 1) * dg_prob.nq; i += NT) x[b * (int64_t)(dg_prob.N + 1) * dg_prob.nq + i] = dg_lds[L.e_x + i];
     if (G)
       for (int64_t t = TID; t < (int64_t)nc * n; t += NT)
-        G[b * (int64_t)nc * n + t] = g_row_coef(dg_prob, LP(L.gd), (int)(t / n), (int)(t % n));
+        G[b * (int64_t)nc * n + t] = dg_prob.gd_global ? g_row_coef<cgptr>(dg_prob, dev_gd_global(c), (int)(t / n), (int)(t % n))
+                                                          : g_row_coef<clptr>(dg_prob, LP(L.gd), (int)(t / n), (int)(t % n));
     if (Q) {
       cgptr Qg = c.ws + dg_prob.ws_q;
       for (int t = TID; t < n * n; t += NT) Q[b * (int64_t)n * n + t] = Qg[t];

@@ -568,8 +568,10 @@ __device__ inline int am_col(const DgProb& D, int a, int k, int j) { return a * 
 // ------------------------------------------------------------------------------------------------
 // structured products with the constraint Jacobian G (n_c x n), never formed densely
 // ------------------------------------------------------------------------------------------------
-// y[r] = (G x)[r] for one row
-__device__ inline double g_row_dot(const DgProb& D, clptr gd, int r, clptr x) {
+// y[r] = (G x)[r] for one row.  GP: where the packed gradients live -- LDS (clptr) or, for games whose gradients exceed the
+// arena (XL layout, n > ~160), the workgroup's global scratch (cgptr)
+template <class GP>
+__device__ inline double g_row_dot(const DgProb& D, GP gd, int r, clptr x) {
   const DgRow R = ld_row(r);
   switch (R.type) {
     case DG_R_IN_UB: return x[am_col(D, R.a, R.k, R.idx)];
@@ -582,7 +584,7 @@ __device__ inline double g_row_dot(const DgProb& D, clptr gd, int r, clptr x) {
     }
     default: {
       const DgDense dd = ld_dense(R.dense);
-      clptr p = gd + dd.off;
+      const GP p = gd + dd.off;
       const int len = 2 * dd.k;
       double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
       clptr xa = x + dd.a * D.N * DGSQP_NUA;
@@ -591,7 +593,7 @@ __device__ inline double g_row_dot(const DgProb& D, clptr gd, int r, clptr x) {
       for (; i < len; i++) s0 += p[i] * xa[i];
       if (dd.kind == 1) {
         clptr xb = x + dd.b * D.N * DGSQP_NUA;
-        clptr pb = p + len;
+        const GP pb = p + len;
         for (i = 0; i + 3 < len; i += 4) { s0 += pb[i] * xb[i]; s1 += pb[i + 1] * xb[i + 1]; s2 += pb[i + 2] * xb[i + 2]; s3 += pb[i + 3] * xb[i + 3]; }
         for (; i < len; i++) s0 += pb[i] * xb[i];
       }
@@ -600,10 +602,10 @@ __device__ inline double g_row_dot(const DgProb& D, clptr gd, int r, clptr x) {
   }
 }
 // out[n] = G^T y.  yd is an LDS scratch of ndense doubles.  Contains barriers.
-__device__ __noinline__ void gt_mul(const Ctx& c, clptr y, lptr out) {
+template <class GP>
+__device__ __noinline__ void gt_mul_t(const Ctx& c, GP gd, clptr y, lptr out) {
   const DgProb& D = dg_prob;
   lptr yd = LP(D.L.yd);
-  clptr gd = LP(D.L.gd);
   __syncthreads();
   for (int d = TID; d < D.ndense; d += NT) {
     const DgDense dd = ld_dense(d);
@@ -636,4 +638,13 @@ __device__ __noinline__ void gt_mul(const Ctx& c, clptr y, lptr out) {
     if (part == 0) out[col] = s;
   }
   __syncthreads();
+}
+// the packed gradients of this workgroup: LDS, or the global scratch when they do not fit (DgProb.gd_global)
+__device__ inline cgptr dev_gd_global(const Ctx& c) { return c.ws + dg_prob.ws_gd; }
+__device__ inline void gt_mul(const Ctx& c, clptr y, lptr out) {
+  if (dg_prob.gd_global) gt_mul_t<cgptr>(c, dev_gd_global(c), y, out);
+  else gt_mul_t<clptr>(c, LP(dg_prob.L.gd), y, out);
+}
+__device__ inline double g_row_dot_any(const Ctx& c, int r, clptr x) {
+  return dg_prob.gd_global ? g_row_dot<cgptr>(dg_prob, dev_gd_global(c), r, x) : g_row_dot<clptr>(dg_prob, LP(dg_prob.L.gd), r, x);
 }

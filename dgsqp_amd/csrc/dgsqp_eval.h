@@ -370,6 +370,10 @@ __device__ __noinline__ void dev_dyn_derivs(const Ctx& c, clptr ue) {
 // sensitivity chains S^a_{k,t0}[:, j] = A_{k-1} ... A_{t0+1} B_{t0}[:, j]  (f_Du_x, DGSQP.py:642-650),
 // consumed on the fly into the packed dense gradients (f_Du_C :823-826) and q (f_q :672-676, 898-899)
 // ------------------------------------------------------------------------------------------------
+// one entry of the packed constraint gradients (LDS, or the global scratch for games whose gradients exceed the arena)
+__device__ inline void gd_store(const Ctx& c, int idx, double val) {
+  if (dg_prob.gd_global) (c.ws + dg_prob.ws_gd)[idx] = val; else LP(dg_prob.L.gd)[idx] = val;
+}
 template <int NQA>
 __device__ inline void dev_chain_item(const Ctx& c, clptr ue, int it);
 __device__ __noinline__ void dev_chains(const Ctx& c, clptr ue) {
@@ -421,20 +425,20 @@ __device__ inline void dev_chain_item(const Ctx& c, clptr ue, int it) {
             double val = 0.0;
 #pragma unroll
             for (int i = 0; i < nqa; i++) val = (i == dd.idx) ? v[i] : val;  // keeps v[] in registers
-            lds[L.gd + dd.off + t0 * DGSQP_NUA + j] = val;
+            gd_store(c, dd.off + t0 * DGSQP_NUA + j, val);
           }
         } else if (dd.kind == 2) {
           if (dd.a == a) {     // lane half-plane: n(p_x) . d p_k / du, the normal is piecewise constant in p_x (merge.py:66-74)
             const auto& ln = ag.lane[dd.idx];
             const bool hi = xk[qo] >= ln.brk;
-            lds[L.gd + dd.off + t0 * DGSQP_NUA + j] = (hi ? ln.n_hi[0] : ln.n_lo[0]) * v[0] + (hi ? ln.n_hi[1] : ln.n_lo[1]) * v[1];
+            gd_store(c, dd.off + t0 * DGSQP_NUA + j, (hi ? ln.n_hi[0] : ln.n_lo[0]) * v[0] + (hi ? ln.n_hi[1] : ln.n_lo[1]) * v[1]);
           }
         } else if (dd.a == a || dd.b == a) {
           const int ia = D.qoff[dd.a], ib = D.qoff[dd.b];
           const double dx = xk[ia] - xk[ib], dy = xk[ia + 1] - xk[ib + 1];
           const double s = 2.0 * (dx * v[0] + dy * v[1]);
-          if (dd.a == a) lds[L.gd + dd.off + t0 * DGSQP_NUA + j] = -s;
-          else lds[L.gd + dd.off + 2 * k + t0 * DGSQP_NUA + j] = s;
+          if (dd.a == a) gd_store(c, dd.off + t0 * DGSQP_NUA + j, -s);
+          else gd_store(c, dd.off + 2 * k + t0 * DGSQP_NUA + j, s);
         }
       }
       clptr dJ = lds + L.e_dJ + k * D.nq + qo;

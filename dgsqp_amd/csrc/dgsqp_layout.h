@@ -76,6 +76,7 @@ struct DgProb {
   double inv_track_L;
   double eig_floor;    // value given to negative eigenvalues by _nearestPD (par.eig_floor, 1e-10 when not set)
   int uniform_nqa;
+  int gd_global;    // the packed constraint gradients live in the global scratch (ws_gd) instead of LDS: XL games beyond n ~ 160
   int classic_qp;   // the QP runs the classical (J = L^-T) Goldfarb-Idnani kernels of dgsqp_xl.h: XL layout, or a projected Hessian
                     // whose smallest eigenvalue (eig_floor + reg) is below 1e-8 -- the literal reg = 0 formula
   int big;          // 2: XL layout (n > 128, dgsqp_xl.h).  1: the packed inverse P and the packed Householder reflectors live in the workgroup's global scratch (L2)
@@ -87,7 +88,7 @@ struct DgProb {
   int t2off[DGSQP_MAX_AGENTS];              // offset (doubles) of agent block in the Taylor tensor workspace
   int t2k[DGSQP_MAX_AGENTS];                // per-stage stride of that block = nqa*ndir
   int64_t t2_doubles;
-  int64_t ws_t2, ws_q, ws_base, ws_H, ws_tang, ws_Y, ws_P, ws_V, ws_R, ws_Vp, ws_xM, ws_xJ, ws_xR, ws_bfgs, ws_doubles; // global workspace layout (doubles): Taylor tensor, raw Q, watchdog backups,
+  int64_t ws_t2, ws_q, ws_base, ws_H, ws_tang, ws_Y, ws_P, ws_V, ws_R, ws_Vp, ws_xM, ws_xJ, ws_xR, ws_bfgs, ws_gd, ws_doubles; // global workspace layout (doubles): Taylor tensor, raw Q, watchdog backups,
                                                              // costate-contracted dynamics Hessians, tangent trajectories
   DgRow rows[DG_NCMAX];
   DgDense dense[DG_NDMAX];
@@ -126,6 +127,8 @@ static inline std::string dg_build_layout(DgProb& D) {
   // previous iteration and its projection (n x n each)
   D.ws_bfgs = D.ws_doubles;
   if (D.par.hessian_bfgs) D.ws_doubles += 2 * (int64_t)D.n + 2 * (int64_t)D.n * D.n;
+  D.ws_gd = D.ws_doubles;
+  if (D.gd_global) D.ws_doubles += D.ngd + DG_CHUNK;   // (chunked dots read up to one chunk past the last gradient)
   D.ws_doubles = (D.ws_doubles + 31) / 32 * 32;
   // ---- LDS arena
   DgLds& L = D.L;
@@ -134,7 +137,8 @@ static inline std::string dg_build_layout(DgProb& D) {
   int o = 0;
   auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
   L.u = take(n); L.l = take(nc); L.q = take(n); L.g = take(nc); L.d = take(n); L.v = take(n);
-  L.gd = take(D.ngd); L.yd = take(nd); L.red = take(64); L.scal = take(64);
+  L.gd = take(D.gd_global ? (nc > 2 ? nc : 2) : D.ngd);   // gd_global: only the nc-vector the trial merits keep there
+  L.yd = take(nd); L.red = take(64); L.scal = take(64);
   L.w_prev = take((n + 2) / 2 + 1); L.w_prevlam = take(n + 1);   // final active set of the previous QP of this scenario (warm start)
   L.t_rows = take(nc); L.t_dense = take(2 * nd); L.t_task = take(D.ntask); L.t_track = take(4 * (DGSQP_MAX_SEGS + 1)); L.t_atan = take(10);
   L.scr = o;
@@ -207,6 +211,7 @@ static inline std::string dg_build_layout(DgProb& D) {
   if (lsqr_end > tot) tot = lsqr_end;
   L.total = tot;
   if ((long)tot * 8 > DG_LDS_LIMIT && !D.big) { D.big = 1; return dg_build_layout(D); }   // (n > 128 starts at big = 2)
+  if ((long)tot * 8 > DG_LDS_LIMIT && D.big == 2 && !D.gd_global) { D.gd_global = 1; return dg_build_layout(D); }
   if ((long)tot * 8 > DG_LDS_LIMIT) {
     char buf[160];
     snprintf(buf, sizeof buf, "problem needs %ld B of LDS per scenario (limit %d): n=%d n_c=%d", (long)tot * 8, DG_LDS_LIMIT, n, nc);
@@ -221,7 +226,7 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   D.P = P; D.par = par;
   if (P.M < 1 || P.M > DGSQP_MAX_AGENTS) return "unsupported number of agents";
   if (P.N < 1 || P.N > DG_NMAX) return "unsupported horizon";
-  if (P.N * P.M * DGSQP_NUA > 192) return "more than 192 decision variables are not supported yet";
+  if (P.N * P.M * DGSQP_NUA > 256) return "more than 256 decision variables are not supported yet";
   if (P.n_segs < 1 || P.n_segs > DGSQP_MAX_SEGS) return "bad track table";
   D.M = P.M; D.N = P.N; D.nq = 0; D.nu = P.M * DGSQP_NUA;
   int t2 = 0;

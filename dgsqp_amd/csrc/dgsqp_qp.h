@@ -15,10 +15,11 @@
 // Dots of all distinct dense constraint gradients with the vector held in LDS at v (all wavefronts).  One chunk
 // (<= DG_CHUNK contiguous entries of a gradient and of v) per thread, all 2 x DG_CHUNK reads issued together; the chunk
 // sums of a gradient are then added in a fixed order (bitwise reproducible, no atomics).  Two barriers.
-__device__ inline void qp_dense_dots(const DgProb& D, clptr gd, clptr v, lptr part, lptr out) {
+template <class GP>
+__device__ inline void qp_dense_dots(const DgProb& D, GP gd, clptr v, lptr part, lptr out) {
   for (int t = TID; t < D.ntask; t += NT) {
     const DgTask T = ld_task(t);
-    clptr p = gd + T.p0;
+    const GP p = gd + T.p0;
     clptr w = v + T.v0;
     double pv[DG_CHUNK], wv[DG_CHUNK];
 #pragma unroll
@@ -94,6 +95,7 @@ struct QpPtrs {
   lds_i_t *alist, *yslot, *yfree, *prev;
   lds_b_t* act;
   clptr gd, g, Pp;
+  cgptr gdG;   // packed gradients in the global scratch (DgProb.gd_global), else null
   cgptr PpG;   // packed P in the global scratch (big layout), else unused
   gptr Y;
 };
@@ -107,7 +109,7 @@ __device__ inline QpPtrs qp_ptrs(const Ctx& c) {
   q.scal = lds + L.scal; q.prevlam = lds + L.w_prevlam;
   q.alist = (lds_i_t*)(lds + L.p_alist); q.yslot = (lds_i_t*)(lds + L.p_yslot); q.yfree = (lds_i_t*)(lds + L.p_yfree);
   q.prev = (lds_i_t*)(lds + L.w_prev); q.act = (lds_b_t*)(lds + L.p_act);
-  q.gd = lds + L.gd; q.g = lds + L.g; q.Pp = lds + (D.big ? 0 : L.g_Bp); q.PpG = c.ws + D.ws_P;
+  q.gd = lds + L.gd; q.gdG = D.gd_global ? c.ws + D.ws_gd : nullptr; q.g = lds + L.g; q.Pp = lds + (D.big ? 0 : L.g_Bp); q.PpG = c.ws + D.ws_P;
   q.Y = c.ws + D.ws_Y;
   return q;
 }
@@ -137,7 +139,7 @@ __device__ inline void qp_row_products(const Ctx& c, const QpPtrs& q, int p) {
 __device__ inline int qp_scan(const QpPtrs& q, double tol) {
   const DgProb& D = dg_prob;
   const int NONE = 0x7fffffff;
-  qp_dense_dots(D, q.gd, q.xv, q.dpart, q.ddx);
+  if (q.gdG) qp_dense_dots<cgptr>(D, q.gdG, q.xv, q.dpart, q.ddx); else qp_dense_dots<clptr>(D, q.gd, q.xv, q.dpart, q.ddx);
   double best = -tol;
   int bi = NONE;
   for (int r = TID; r < D.nc; r += NT) {

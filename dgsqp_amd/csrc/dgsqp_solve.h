@@ -528,7 +528,8 @@ __device__ inline void dev_p_mul(const Ctx& c, clptr t, lptr out, double scale) 
 }
 
 // coefficient of constraint row r at column col
-__device__ inline double g_row_coef(const DgProb& D, clptr gd, int r, int col) {
+template <class GP>
+__device__ inline double g_row_coef(const DgProb& D, GP gd, int r, int col) {
   const DgRow R = ld_row(r);
   const int a = col / (D.N * DGSQP_NUA), rem = col % (D.N * DGSQP_NUA), t = rem / DGSQP_NUA, j = rem % DGSQP_NUA;
   switch (R.type) {
@@ -719,7 +720,8 @@ __device__ inline void dev_ggt_mul(const Ctx& c, clptr vin, lptr vout, lptr tmpn
   const DgProb& D = dg_prob;
   gt_mul(c, vin, tmpn);
   lptr dd2 = LP(D.L.p_yd2);     // QP scratch, idle during the dual start
-  qp_dense_dots(D, LP(D.L.gd), tmpn, LP(D.L.p_dpart), dd2);
+  if (D.gd_global) qp_dense_dots<cgptr>(D, dev_gd_global(c), tmpn, LP(D.L.p_dpart), dd2);
+  else qp_dense_dots<clptr>(D, LP(D.L.gd), tmpn, LP(D.L.p_dpart), dd2);
   for (int r = TID; r < D.nc; r += NT) vout[r] = qpw_row_dot(D, ld_row(r), tmpn, dd2);
   __syncthreads();
 }
@@ -746,7 +748,7 @@ __device__ __noinline__ void dev_dual_init(const Ctx& c) {
   // b = G q
   __syncthreads();
   double p = 0;
-  for (int r = TID; r < nc; r += NT) { const double b = g_row_dot(D, lds + L.gd, r, lds + L.q); u[r] = b; x[r] = 0.0; p += b * b; }
+  for (int r = TID; r < nc; r += NT) { const double b = g_row_dot_any(c, r, lds + L.q); u[r] = b; x[r] = 0.0; p += b * b; }
   const double bnorm = sqrt(block_sum(p, red));
   double beta = bnorm, alfa = 0;
   if (beta > 0) {
@@ -880,7 +882,7 @@ __device__ __noinline__ void dev_step_scalars(const Ctx& c, LinScal& S) {
     lhg += lhat[r] * gr;
     vio += fmax(gr, 0.0);                  // g - min(0,g)
     s0 += fmin(gr, 0.0);
-    ssum += gr + g_row_dot(D, lds + L.gd, r, du);  // s + ds
+    ssum += gr + g_row_dot_any(c, r, du);  // s + ds
   }
   a1 = block_sum(a1, red); a2 = block_sum(a2, red); lGdu = block_sum(lGdu, red); dd = block_sum(dd, red);
   lg = block_sum(lg, red); lhg = block_sum(lhg, red); vio = block_sum(vio, red); s0 = block_sum(s0, red); ssum = block_sum(ssum, red);

@@ -10,8 +10,8 @@
 #include "dgsqp_solve.h"
 
 #define XSYNC() do { __threadfence_block(); __syncthreads(); } while (0)
-#define XL_NV 3      // registers per lane for one column (n <= 192)
-#define XL_MAXP 12   // pairs of one tournament round per wavefront (96 pairs / 8 wavefronts)
+#define XL_NV 4      // registers per lane for one column (n <= 256)
+#define XL_MAXP 16   // pairs of one tournament round per wavefront (128 pairs / 8 wavefronts)
 #ifndef XL_GRP
 #define XL_GRP 4     // ... handled four at a time (their four columns each stay in registers)
 #endif
@@ -260,7 +260,7 @@ __device__ __noinline__ int dev_xl_qp(const Ctx& c) {
   for (int iter = 0; iter < max_outer; iter++) {
     const int ip = qp_scan(q, TOL);
     if (ip == NONE) { ret = 0; break; }
-    for (int col = TID; col < n; col += NT) { const double a = g_row_coef(D, q.gd, ip, col); tv[col] = a; np[col] = -a; }
+    for (int col = TID; col < n; col += NT) { const double a = q.gdG ? g_row_coef<cgptr>(D, q.gdG, ip, col) : g_row_coef<clptr>(D, q.gd, ip, col); tv[col] = a; np[col] = -a; }
     if (TID == 0) { uu[iq] = 0.0; q.alist[iq] = ip; }
     __syncthreads();
     double npnp;

@@ -642,6 +642,41 @@ def test_bfgs_hessian_option(oracle):
     assert ref['num_iters'].mean() > exact['num_iters'].mean()
 
 
+def test_xl_layout_long_horizon_n200(oracle):
+    """BASELINE configs[3] size: 2 agents, N = 50 -> 200 decision variables, 1,050 rows.  XL layout with the packed constraint
+    gradients (82 KB) in the L2 scratch as well; same common code for evaluation / dual start / SQP logic."""
+    from dgsqp_amd.montecarlo import kinematic_racing_game, sample_scenarios
+    from dgsqp_amd.solver import DGSQP, build_problem, build_params
+    import dgsqp_amd.solver as sv
+    g = kinematic_racing_game('curve', N=50)
+    P, par = build_problem(*g.solver_args()), tight_lsqr(build_params(g.params))
+    orig = sv.build_params
+    sv.build_params = lambda p: tight_lsqr(orig(p))
+    try:
+        s = DGSQP(*g.solver_args(), print_method=None)
+    finally:
+        sv.build_params = orig
+    assert (s.n, s.n_c_total) == (200, 1050) and s.dims.layout == 2 and s.dims.lds_bytes <= 163840
+    B = 4
+    x0, u_tm = sample_scenarios(g, B, seed=1)
+    u = agent_major(u_tm)
+    rng = np.random.default_rng(1)
+    up = u + 0.01 * rng.standard_normal(u.shape)
+    l = np.maximum(0, rng.standard_normal((B, s.n_c_total)))
+    ev = s.evaluate_batch(x0[:2], up[:2], l[:2])
+    for b in range(2):
+        o = oracle.evaluate(P, x0[b], up[b], l[b], 1)
+        for key in ('x', 'q', 'g', 'G', 'Q'):
+            assert rel(ev[key][b], o[key]) < 1e-11, (key, b)
+        assert rel(ev['l0'][b], oracle.dual_init(P, par, x0[b], up[b])) < 1e-7
+    res = s.solve_batch(x0, u_tm)
+    ref = oracle.solve_batch(P, par, x0, u, nthreads=8)
+    same = (res['status'] == ref['status']) & (res['num_iters'] == ref['num_iters']) & (res['qp_solves'] == ref['qp_solves'])
+    assert same.sum() >= B - 1, (res['status'], ref['status'], res['num_iters'], ref['num_iters'])
+    for b in np.where(same & (ref['status'] <= 1))[0]:
+        assert rel(res['u'][b], ref['u'][b]) < 1e-6 and rel(res['l'][b], ref['l'][b]) < 1e-5
+
+
 def test_large_batch_equals_small_batches(games):
     """Every scenario of a 3,500-scenario launch (14 per workgroup, dynamic ticket order) comes out exactly as in a small
     launch: no state leaks between the scenarios a workgroup processes (warm-started active sets, trajectory tags)."""

@@ -264,19 +264,21 @@ def test_result_records_match_the_post_processing_readers(tmp_path):
 
 def test_layout_plan_of_the_supported_games():
     """dgsqp_plan (host only): which layout dgsqp_create picks and what it needs.  LDS-resident up to n ~ 100, big (P and
-    reflectors in L2) up to n = 128, XL (generic kernels) up to n ~ 160; the 160 KB arena is never exceeded."""
+    reflectors in L2) up to n = 128, XL (generic kernels; beyond n ~ 160 also the packed gradients in L2) up to n = 256 as long as
+    the remaining vectors fit; the 160 KB arena is never exceeded."""
     from dgsqp_amd.montecarlo import barc_racing_game, dynamic_racing_game, kinematic_racing_game, merge_game
     from dgsqp_amd.solver import build_params, build_problem, plan, problem_dims
     cases = [(kinematic_racing_game('chicane', N=25), 0), (dynamic_racing_game(N=25), 0), (kinematic_racing_game('curve', N=10), 0),
              (kinematic_racing_game('curve', N=5, M=1), 0), (barc_racing_game(N=15, M=3), 0), (kinematic_racing_game('curve', N=30), 1),
              (merge_game(N=20), 1), (merge_game(N=10, M=6), 1), (barc_racing_game(N=21, M=3), 1), (kinematic_racing_game('curve', N=16, M=4), 1),
-             (kinematic_racing_game('curve', N=25, M=3), 2), (kinematic_racing_game('curve', N=40), 2)]
+             (kinematic_racing_game('curve', N=25, M=3), 2), (kinematic_racing_game('curve', N=40), 2),
+             (kinematic_racing_game('curve', N=50), 2), (kinematic_racing_game('curve', N=20, M=4), 2)]      # packed gradients in L2
     for g, layout in cases:
         P, par = build_problem(*g.solver_args()), build_params(g.params)
         d = plan(P, par)
         assert d['layout'] == layout, (g.name, d)
         assert (d['n_q'], d['n_u'], d['n'], d['n_c']) == problem_dims(P)
         assert 0 < d['lds_bytes'] <= 163840 and d['workspace_bytes'] < 4 << 20
-    for g in (kinematic_racing_game('curve', N=50), kinematic_racing_game('curve', N=25, M=4)):      # n = 200: not built yet
+    for g in (merge_game(N=25, M=6), kinematic_racing_game('curve', N=24, M=4)):      # n = 300 / 187 KB of gradients, n = 192 with 1,104 rows
         with pytest.raises(ValueError, match='not supported yet|LDS'):
             plan(build_problem(*g.solver_args()), build_params(g.params))

@@ -16,6 +16,8 @@ elif kind == 'barc3':
     g = mc.barc_racing_game(N=int(sys.argv[3]) if len(sys.argv) > 3 else 15, M=3)
 elif kind == 'kbcurve':       # reg = 1e-3
     g = mc.kinematic_racing_game('curve', N=int(sys.argv[3]) if len(sys.argv) > 3 else 25)
+elif kind == 'kbcurve_m':      # curve game with DGSQP_M agents (reg = 1e-3)
+    g = mc.kinematic_racing_game('curve', N=int(sys.argv[3]) if len(sys.argv) > 3 else 25, M=int(os.environ.get('DGSQP_M', '2')))
 elif kind == 'agents3':     # scripts/DGSQP_monte_carlo_agents.py at exp_M = [3], exp_N = [25] (:101-102), reg = 1e-3 (:146)
     g = mc.kinematic_racing_game('curve', N=int(sys.argv[3]) if len(sys.argv) > 3 else 25, M=3)
 elif kind in ('kbcurve0', 'kbchicane0'):
