@@ -16,8 +16,178 @@
 #define XL_GRP 4     // ... handled four at a time (their four columns each stay in registers)
 #endif
 
+// ---- _nearestPD through the tridiagonal form (the same algorithm as the fast layouts, written generically):
+//   Householder tridiagonalisation of B (block-wide, B and the reflectors in the L2 scratch), Sturm-count multisection
+//   for the NEGATIVE eigenvalues only, eigenvectors by twisted factorisation (one wavefront each), modified Gram-Schmidt,
+//   back-transformation, M = B + sum_j (floor - lambda_j) v_j v_j^T + reg I.
+// Returns false (nothing written) when there are more than XL_KMAX negative eigenvalues: the Jacobi path takes over.
+#define XL_KMAX 32
+__device__ __noinline__ bool dev_xl_psd_tri(const Ctx& c, gptr Qpd) {
+  const DgProb& D = dg_prob;
+  const int n = D.n, lane = TID & 63, wave = TID >> 6;
+  lptr lds = LP(0);
+  cgptr Qg = c.ws + D.ws_q;
+  gptr Bm = c.ws + D.ws_P, Vr = c.ws + D.ws_V, Mx = c.ws + D.ws_R, Z = c.ws + D.ws_Vp;   // Z: XL_KMAX x n (the Jacobi basis slot)
+  lptr W = lds + D.L.g_tw;
+  lptr dv = W, ev = W + n, tau = W + 2 * n, vv = W + 3 * n, pv = W + 4 * n, e2 = W + 5 * n, lamv = W + 6 * n;   // lamv: XL_KMAX
+  lptr strips = W + 6 * n + XL_KMAX + 16;                                            // 3 n per wavefront
+  lds_d* red = lds + D.L.red;
+  lds_d* scal = lds + D.L.scal;
+  if (TID == 0) { scal[DG_XVALID] = 0.0; scal[DG_QP_NPREV] = 0.0; }   // (Z overwrites the Jacobi warm-start basis)
+  __syncthreads();
+  PROF_BEGIN(pt_t);
+  for (int e = TID; e < n * n; e += NT) {
+    const int i = e / n, k = e % n;
+    Bm[e] = 0.5 * (Qg[(int64_t)i * n + k] + Qg[(int64_t)k * n + i]);
+  }
+  XSYNC();
+  // ---- Householder tridiagonalisation
+  for (int k = 0; k + 2 < n; k++) {
+    const int m = n - k - 1;
+    double s2 = 0;
+    for (int i = k + 1 + TID; i < n; i += NT) { const double x = Bm[(int64_t)i * n + k]; vv[i] = x; s2 += x * x; }
+    const double nrm2 = block_sum(s2, red);
+    const double x0 = vv[k + 1];
+    const double tail2 = nrm2 - x0 * x0;
+    double alpha, beta;
+    if (!(tail2 > 0.0)) { alpha = x0; beta = 0.0; }
+    else { alpha = x0 >= 0 ? -sqrt(nrm2) : sqrt(nrm2); const double v0 = x0 - alpha; beta = 2.0 / (tail2 + v0 * v0); }
+    __syncthreads();
+    if (TID == 0) { dv[k] = Bm[(int64_t)k * n + k]; ev[k] = alpha; tau[k] = beta; if (beta != 0.0) vv[k + 1] = x0 - alpha; }
+    __syncthreads();
+    for (int i = k + 1 + TID; i < n; i += NT) Vr[(int64_t)k * n + i] = vv[i];
+    if (beta != 0.0) {
+      // p = beta B v (B symmetric: column i is read along rows, coalesced over i)
+      double pvsum = 0;
+      for (int i = k + 1 + TID; i < n; i += NT) {
+        double a0 = 0, a1 = 0;
+        int j = k + 1;
+        for (; j + 1 < n; j += 2) { a0 += Bm[(int64_t)j * n + i] * vv[j]; a1 += Bm[(int64_t)(j + 1) * n + i] * vv[j + 1]; }
+        if (j < n) a0 += Bm[(int64_t)j * n + i] * vv[j];
+        const double p = beta * (a0 + a1);
+        pv[i] = p; pvsum += p * vv[i];
+      }
+      const double K = 0.5 * beta * block_sum(pvsum, red);
+      for (int i = k + 1 + TID; i < n; i += NT) pv[i] -= K * vv[i];       // w
+      __syncthreads();
+      for (int e = TID; e < m * m; e += NT) {
+        const int i = k + 1 + e / m, j = k + 1 + e % m;
+        Bm[(int64_t)i * n + j] -= vv[i] * pv[j] + pv[i] * vv[j];
+      }
+    }
+    XSYNC();
+  }
+  if (TID == 0) {
+    dv[n - 2] = Bm[(int64_t)(n - 2) * n + n - 2]; dv[n - 1] = Bm[(int64_t)(n - 1) * n + n - 1];
+    ev[n - 2] = Bm[(int64_t)(n - 1) * n + n - 2]; ev[n - 1] = 0.0; tau[n - 2] = 0.0; tau[n - 1] = 0.0;
+  }
+  __syncthreads();
+  PROF_END(PH_E_TRI, pt_t);
+  // ---- negative eigenvalues of T
+  double tn = 0;
+  for (int i = TID; i < n; i += NT) { e2[i] = ev[i] * ev[i]; tn = fmax(tn, fabs(dv[i]) + fabs(ev[i]) + (i > 0 ? fabs(ev[i - 1]) : 0.0)); }
+  const double tnorm = block_max(tn, red);
+  const double pivmin = fmax(1e-300, 1e-290 * tnorm * tnorm);
+  __syncthreads();
+  const int kneg = sturm_count(dv, e2, n, 0.0, pivmin);      // every thread, same result
+  if (kneg > XL_KMAX) return false;
+  PROF_BEGIN(pe1);
+  for (int j = wave; j < kneg; j += NT / 64) {
+    double lo = -tnorm * 1.0000001 - 1e-300, hi = 0.0;
+    for (int it = 0; it < 10; it++) {      // 65^10 > 2^53
+      const double wdt = hi - lo;
+      const double sg = lo + wdt * (double)(lane + 1) * (1.0 / 65.0);
+      const int cnt = sturm_count(dv, e2, n, sg, pivmin);
+      const unsigned long long above = __ballot(cnt > j);
+      const int first = above ? __ffsll((long long)above) - 1 : 64;
+      const double nlo = first == 0 ? lo : lane_bcast(sg, first - 1);
+      const double nhi = first == 64 ? hi : lane_bcast(sg, first);
+      lo = nlo; hi = nhi;
+      if (hi - lo <= 4.5e-16 * fmax(fabs(lo), fabs(hi)) + 1e-300) break;
+    }
+    const double lam = 0.5 * (lo + hi);
+    // eigenvector by twisted factorisation (Parlett & Dhillon; LAPACK dlar1v): the two pivot sequences sequentially by
+    // lane 0 into the wavefront's strip, twist index and the two-term recurrences by the whole wavefront
+    lptr Dp = strips + wave * 3 * n, Dm = Dp + n, zz = Dp + 2 * n;
+    if (lane == 0) {
+      lamv[j] = lam;
+      double qf = dv[0] - lam;
+      qf = (__builtin_fabs(qf) <= pivmin) ? -pivmin : qf;
+      Dp[0] = qf;
+      for (int i = 1; i < n; i++) { qf = (dv[i] - lam) - e2[i - 1] / qf; qf = (__builtin_fabs(qf) <= pivmin) ? -pivmin : qf; Dp[i] = qf; }
+      double qb = dv[n - 1] - lam;
+      qb = (__builtin_fabs(qb) <= pivmin) ? -pivmin : qb;
+      Dm[n - 1] = qb;
+      for (int i = n - 2; i >= 0; i--) { qb = (dv[i] - lam) - e2[i] / qb; qb = (__builtin_fabs(qb) <= pivmin) ? -pivmin : qb; Dm[i] = qb; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    double gbest = INFINITY; int r = 0;
+    for (int i = lane; i < n; i += 64) { const double gm = __builtin_fabs(Dp[i] + Dm[i] - (dv[i] - lam)); if (gm < gbest) { gbest = gm; r = i; } }
+    wave_argmin(gbest, r);
+    if (lane == 0) {
+      zz[r] = 1.0;
+      for (int i = r - 1; i >= 0; i--) zz[i] = -(ev[i] / Dp[i]) * zz[i + 1];
+      for (int i = r; i + 1 < n; i++) zz[i + 1] = -(ev[i] / Dm[i + 1]) * zz[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    double mx = 0;
+    for (int i = lane; i < n; i += 64) mx = fmax(mx, __builtin_fabs(zz[i]));
+    mx = wave_max(mx);
+    for (int i = lane; i < n; i += 64) Z[(int64_t)j * n + i] = zz[i] / mx;
+  }
+  XSYNC();
+  PROF_END(PH_E_BIS, pe1);
+  // ---- modified Gram-Schmidt (close eigenvalues give nearly parallel vectors), block-wide
+  for (int j = 0; j < kneg; j++) {
+    for (int i = 0; i < j; i++) {
+      double dsum = 0;
+      for (int t = TID; t < n; t += NT) dsum += Z[(int64_t)j * n + t] * Z[(int64_t)i * n + t];
+      const double dt = block_sum(dsum, red);
+      for (int t = TID; t < n; t += NT) Z[(int64_t)j * n + t] -= dt * Z[(int64_t)i * n + t];
+      XSYNC();
+    }
+    double nsum = 0;
+    for (int t = TID; t < n; t += NT) { const double z = Z[(int64_t)j * n + t]; nsum += z * z; }
+    const double nr = 1.0 / sqrt(block_sum(nsum, red));
+    for (int t = TID; t < n; t += NT) Z[(int64_t)j * n + t] *= nr;
+    XSYNC();
+  }
+  // ---- back-transformation v = H_0 ... H_{n-3} z, one wavefront per vector, z in registers
+  for (int j = wave; j < kneg; j += NT / 64) {
+    double z[XL_NV];
+#pragma unroll
+    for (int h = 0; h < XL_NV; h++) { const int i = lane + 64 * h; z[h] = i < n ? Z[(int64_t)j * n + i] : 0.0; }
+    for (int k = n - 3; k >= 0; k--) {
+      const double beta = tau[k];
+      if (beta == 0.0) continue;
+      double v[XL_NV], dt = 0;
+#pragma unroll
+      for (int h = 0; h < XL_NV; h++) { const int i = lane + 64 * h; v[h] = (i > k && i < n) ? Vr[(int64_t)k * n + i] : 0.0; dt += v[h] * z[h]; }
+      dt = beta * wave_sum(dt);
+#pragma unroll
+      for (int h = 0; h < XL_NV; h++) z[h] -= dt * v[h];
+    }
+#pragma unroll
+    for (int h = 0; h < XL_NV; h++) { const int i = lane + 64 * h; if (i < n) Z[(int64_t)j * n + i] = z[h]; }
+  }
+  XSYNC();
+  // ---- M = B + sum_j (floor - lambda_j) v_j v_j^T + reg I
+  const double reg = D.par.reg > 0 ? D.par.reg : 0.0;
+  for (int e = TID; e < n * n; e += NT) {
+    const int i = e / n, k = e % n;
+    double a = 0.5 * (Qg[(int64_t)i * n + k] + Qg[(int64_t)k * n + i]);
+    for (int j = 0; j < kneg; j++) a += (D.eig_floor - lamv[j]) * Z[(int64_t)j * n + i] * Z[(int64_t)j * n + k];
+    if (i == k) a += reg;
+    Mx[e] = a;
+    if (Qpd) Qpd[e] = a;
+  }
+  XSYNC();
+  PROF_END(PH_JACOBI, pt_t);
+  return true;
+}
+
 // ---- _nearestPD: M (row-major, n x n) into c.ws + ws_R
-__device__ __noinline__ void dev_xl_psd(const Ctx& c, gptr Qpd) {
+__device__ __noinline__ void dev_xl_psd_jacobi(const Ctx& c, gptr Qpd) {
   const DgProb& D = dg_prob;
   const int n = D.n, lane = TID & 63, wave = TID >> 6;
   lptr lds = LP(0);
@@ -353,4 +523,8 @@ __device__ __noinline__ int dev_xl_qp(const Ctx& c) {
   __syncthreads();
   PROF_END(PH_QP, pt_qp);
   return ret;
+}
+
+__device__ void dev_xl_psd(const Ctx& c, gptr Qpd) {
+  if (!dev_xl_psd_tri(c, Qpd)) dev_xl_psd_jacobi(c, Qpd);     // (more than XL_KMAX negative eigenvalues)
 }
