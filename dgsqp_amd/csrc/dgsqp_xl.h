@@ -22,6 +22,7 @@
 //   back-transformation, M = B + sum_j (floor - lambda_j) v_j v_j^T + reg I.
 // Returns false (nothing written) when there are more than XL_KMAX negative eigenvalues: the Jacobi path takes over.
 #define XL_KMAX 32
+#define XL_RCH 16      // Givens rotations applied to a row of J per pass
 __device__ __noinline__ bool dev_xl_psd_tri(const Ctx& c, gptr Qpd) {
   const DgProb& D = dg_prob;
   const int n = D.n, lane = TID & 63, wave = TID >> 6;
@@ -358,6 +359,7 @@ __device__ __noinline__ int dev_xl_qp(const Ctx& c) {
   __syncthreads();
   for (int r = TID; r < nc; r += NT) { q.act[r] = 0; lhat[r] = 0.0; }
   // ---- Cholesky M = L L^T in place (lower triangle), right-looking
+  PROF_BEGIN(px1);
   if (TID == 0) scal[4] = 0.0;
   __syncthreads();
   for (int j = 0; j < n; j++) {
@@ -376,16 +378,24 @@ __device__ __noinline__ int dev_xl_qp(const Ctx& c) {
     XSYNC();
   }
   if (scal[4] != 0.0) { PROF_END(PH_QP, pt_qp); return 2; }
+  PROF_END(PH_Q_WARM, px1);
+  PROF_BEGIN(px2);
   // ---- J = L^-T (upper triangular): column col solves L^T y = e_col
   for (int col = TID; col < n; col += NT) {
     for (int i = n - 1; i > col; i--) J[(int64_t)i * n + col] = 0.0;
     for (int i = col; i >= 0; i--) {
-      double s = i == col ? 1.0 : 0.0;
-      for (int k = i + 1; k <= col; k++) s -= Lc[(int64_t)k * n + i] * J[(int64_t)k * n + col];
-      J[(int64_t)i * n + col] = s / Lc[(int64_t)i * n + i];
+      double s0 = i == col ? 1.0 : 0.0, s1 = 0, s2 = 0, s3 = 0;      // independent accumulators: the loads overlap
+      int k = i + 1;
+      for (; k + 3 <= col; k += 4) {
+        s0 -= Lc[(int64_t)k * n + i] * J[(int64_t)k * n + col]; s1 -= Lc[(int64_t)(k + 1) * n + i] * J[(int64_t)(k + 1) * n + col];
+        s2 -= Lc[(int64_t)(k + 2) * n + i] * J[(int64_t)(k + 2) * n + col]; s3 -= Lc[(int64_t)(k + 3) * n + i] * J[(int64_t)(k + 3) * n + col];
+      }
+      for (; k <= col; k++) s0 -= Lc[(int64_t)k * n + i] * J[(int64_t)k * n + col];
+      J[(int64_t)i * n + col] = ((s0 + s1) + (s2 + s3)) / Lc[(int64_t)i * n + i];
     }
   }
   XSYNC();
+  PROF_END(PH_Q_Y, px2);
   // ---- x = -M^-1 q = -J (J^T q)
   for (int i = TID; i < n; i += NT) { double s = 0; for (int k = 0; k <= i; k++) s += J[(int64_t)k * n + i] * lds[L.q + k]; dv[i] = s; }
   __syncthreads();
@@ -410,25 +420,65 @@ __device__ __noinline__ int dev_xl_qp(const Ctx& c) {
     }
     XSYNC();
     iq--;
-    for (int k = l; k < iq; k++) {
-      const double a = R[(int64_t)k * n + k], b = R[(int64_t)(k + 1) * n + k];
-      const double h = hypot(a, b);
-      __syncthreads();
-      if (h != 0.0) {
-        const double cc = a / h, s2 = b / h;
-        for (int j2 = k + TID; j2 < iq; j2 += NT) {
-          const double ra = R[(int64_t)k * n + j2], rb = R[(int64_t)(k + 1) * n + j2];
-          R[(int64_t)k * n + j2] = cc * ra + s2 * rb;
-          R[(int64_t)(k + 1) * n + j2] = -s2 * ra + cc * rb;
+    // Givens rotations of rows (k, k+1), k = l .. iq-1, restore the triangle.  Thread j owns column j of R and carries the
+    // current value of row k in a register: it only ever touches its own column (no global fences), the coefficients of
+    // rotation k come from the thread of column k through LDS.  The rows it needs are prefetched XL_RCH at a time.
+    lptr gc = acc, gs = lds + L.p_part;
+    {
+      const int j2 = TID;
+      const bool mine = j2 >= l && j2 < iq;
+      double ra = mine ? R[(int64_t)l * n + j2] : 0.0;
+      for (int k0 = l; k0 < iq; k0 += XL_RCH) {
+        double rbv[XL_RCH];
+#pragma unroll
+        for (int t = 0; t < XL_RCH; t++) { const int k = k0 + t; rbv[t] = (mine && k < iq && j2 >= k) ? R[(int64_t)(k + 1) * n + j2] : 0.0; }
+#pragma unroll
+        for (int t = 0; t < XL_RCH; t++) {
+          const int k = k0 + t;
+          if (k < iq) {       // uniform
+            if (j2 == k) {
+              const double h = sqrt(ra * ra + rbv[t] * rbv[t]);
+              gc[k] = h != 0.0 ? ra / h : 1.0; gs[k] = h != 0.0 ? rbv[t] / h : 0.0;
+            }
+            __syncthreads();
+            if (mine && j2 >= k) {
+              const double cc = gc[k], s2 = gs[k];
+              R[(int64_t)k * n + j2] = cc * ra + s2 * rbv[t];
+              ra = -s2 * ra + cc * rbv[t];
+            }
+          }
         }
-        xl_rot_cols(J, n, n, k, k + 1, cc, s2);
       }
-      XSYNC();
+      if (mine) R[(int64_t)iq * n + j2] = ra;
     }
+    __syncthreads();
+    // the same rotations on the columns of J: every thread carries its own row through the whole sequence
+    for (int i = TID; i < n; i += NT) {
+      gptr Ji = J + (int64_t)i * n;
+      double carry = Ji[l];
+      for (int k0 = l; k0 < iq; k0 += XL_RCH) {
+        const int cnt = iq - k0 < XL_RCH ? iq - k0 : XL_RCH;
+        double jb[XL_RCH], out[XL_RCH];
+#pragma unroll
+        for (int t = 0; t < XL_RCH; t++) jb[t] = t < cnt ? Ji[k0 + t + 1] : 0.0;
+#pragma unroll
+        for (int t = 0; t < XL_RCH; t++) {
+          const double cc = t < cnt ? gc[k0 + t] : 1.0, s2 = t < cnt ? gs[k0 + t] : 0.0;
+          out[t] = cc * carry + s2 * jb[t];
+          carry = t < cnt ? -s2 * carry + cc * jb[t] : carry;
+        }
+#pragma unroll
+        for (int t = 0; t < XL_RCH; t++) if (t < cnt) Ji[k0 + t] = out[t];
+      }
+      Ji[iq] = carry;
+    }
+    XSYNC();
   };
   const int max_outer = 20 * (n + nc);
   for (int iter = 0; iter < max_outer; iter++) {
+    PROF_BEGIN(px3);
     const int ip = qp_scan(q, TOL);
+    PROF_END(PH_Q_SCAN, px3);
     if (ip == NONE) { ret = 0; break; }
     for (int col = TID; col < n; col += NT) { const double a = q.gdG ? g_row_coef<cgptr>(D, q.gdG, ip, col) : g_row_coef<clptr>(D, q.gd, ip, col); tv[col] = a; np[col] = -a; }
     if (TID == 0) { uu[iq] = 0.0; q.alist[iq] = ip; }
@@ -439,9 +489,28 @@ __device__ __noinline__ int dev_xl_qp(const Ctx& c) {
     int st = -1;          // -1 running, 0 constraint added, 1 infeasible, 2 iteration limit
     for (int inner = 0; inner < 10 * (n + nc) && st < 0; inner++) {
       // step 2a: d = J^T np ; z = J2 d2 ; r = R^-1 d1
-      for (int i = TID; i < n; i += NT) { double s = 0; for (int k = 0; k < n; k++) s += J[(int64_t)k * n + i] * np[k]; dv[i] = s; }
+      PROF_BEGIN(px4);
+      for (int i = TID; i < n; i += NT) {
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        int k = 0;
+        for (; k + 3 < n; k += 4) {
+          s0 += J[(int64_t)k * n + i] * np[k]; s1 += J[(int64_t)(k + 1) * n + i] * np[k + 1];
+          s2 += J[(int64_t)(k + 2) * n + i] * np[k + 2]; s3 += J[(int64_t)(k + 3) * n + i] * np[k + 3];
+        }
+        for (; k < n; k++) s0 += J[(int64_t)k * n + i] * np[k];
+        dv[i] = (s0 + s1) + (s2 + s3);
+      }
       __syncthreads();
-      for (int i = TID; i < n; i += NT) { double s = 0; for (int k = iq; k < n; k++) s += J[(int64_t)i * n + k] * dv[k]; zv[i] = s; }
+      for (int i = TID; i < n; i += NT) {
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        int k = iq;
+        for (; k + 3 < n; k += 4) {
+          s0 += J[(int64_t)i * n + k] * dv[k]; s1 += J[(int64_t)i * n + k + 1] * dv[k + 1];
+          s2 += J[(int64_t)i * n + k + 2] * dv[k + 2]; s3 += J[(int64_t)i * n + k + 3] * dv[k + 3];
+        }
+        for (; k < n; k++) s0 += J[(int64_t)i * n + k] * dv[k];
+        zv[i] = (s0 + s1) + (s2 + s3);
+      }
       for (int i = TID; i < iq; i += NT) acc[i] = dv[i];
       __syncthreads();
       for (int k = iq - 1; k >= 0; k--) {      // back substitution, column oriented
@@ -451,6 +520,7 @@ __device__ __noinline__ int dev_xl_qp(const Ctx& c) {
         for (int i = TID; i < k; i += NT) acc[i] -= R[(int64_t)i * n + k] * rk;
         __syncthreads();
       }
+      PROF_END(PH_Q_DIR, px4);
       // step 2b: step lengths
       double t1 = INFINITY; int lidx = NONE;
       for (int k = TID; k < iq; k += NT) if (rv[k] > 0.0) { const double tt = uu[k] / rv[k]; if (tt < t1) { t1 = tt; lidx = k; } }
@@ -471,26 +541,53 @@ __device__ __noinline__ int dev_xl_qp(const Ctx& c) {
       for (int k = TID; k < iq; k += NT) uu[k] -= t * rv[k];
       if (TID == 0) uu[iq] += t;
       __syncthreads();
+      PROF_BEGIN(px5);
       if (t == t2) {   // full step: add constraint ip.  Givens rotations zero d[iq+1..n-1] into d[iq], applied to J's columns
         // (coefficients by one thread -- the recurrence on d is sequential --, then every thread carries its own row of J
         //  through the whole sequence: one pass over J instead of one barrier per rotation)
+        // Rotation j2 combines d[j2-1] with what the previous ones accumulated in d[j2], i.e. with the suffix norm
+        // h_j2 = |d[j2..n-1]|: c = d[j2-1] / h_{j2-1}, s = h_j2 / h_{j2-1}.  The suffix sums of squares are one short serial
+        // pass; the square roots and quotients are then computed by all threads at once.
         lptr gc = acc, gs = lds + L.p_part;
         if (TID == 0) {
-          for (int j2 = n - 1; j2 > iq; j2--) {
-            const double a = dv[j2 - 1], b = dv[j2];
-            const double h = hypot(a, b);
-            if (h != 0.0) { gc[j2] = a / h; gs[j2] = b / h; dv[j2 - 1] = h; dv[j2] = 0.0; }
-            else { gc[j2] = 1.0; gs[j2] = 0.0; }
+          double sfx = 0.0;
+          for (int k = n - 1; k >= iq; k--) { sfx += dv[k] * dv[k]; gs[k] = sfx; }
+        }
+        __syncthreads();
+        double rc[(256 + NT - 1) / NT], rs[(256 + NT - 1) / NT];
+        {
+          int slot = 0;
+          for (int j2 = iq + 1 + TID; j2 < n; j2 += NT, slot++) {
+            const double h0 = sqrt(gs[j2 - 1]), h1 = sqrt(gs[j2]);
+            rc[slot] = h0 != 0.0 ? dv[j2 - 1] / h0 : 1.0;
+            rs[slot] = h0 != 0.0 ? (j2 == n - 1 ? dv[n - 1] : h1) / h0 : 0.0;     // (the first rotation meets the signed d[n-1])
           }
+        }
+        const double hfin = sqrt(gs[iq]);
+        __syncthreads();
+        {
+          int slot = 0;
+          for (int j2 = iq + 1 + TID; j2 < n; j2 += NT, slot++) { gc[j2] = rc[slot]; gs[j2] = rs[slot]; dv[j2] = 0.0; }
+          if (TID == 0) dv[iq] = hfin;
         }
         __syncthreads();
         for (int i = TID; i < n; i += NT) {
           gptr Ji = J + (int64_t)i * n;
           double carry = Ji[n - 1];
-          for (int j2 = n - 1; j2 > iq; j2--) {
-            const double ja = Ji[j2 - 1], cc = gc[j2], s2 = gs[j2];
-            Ji[j2] = -s2 * ja + cc * carry;
-            carry = cc * ja + s2 * carry;
+          for (int hi = n - 1; hi > iq; hi -= XL_RCH) {      // XL_RCH rotations per pass: their loads are issued together
+            const int cnt = hi - iq < XL_RCH ? hi - iq : XL_RCH;
+            double ja[XL_RCH], out[XL_RCH];
+#pragma unroll
+            for (int t = 0; t < XL_RCH; t++) ja[t] = t < cnt ? Ji[hi - 1 - t] : 0.0;
+#pragma unroll
+            for (int t = 0; t < XL_RCH; t++) {
+              const int j2 = t < cnt ? hi - t : hi;              // (idle steps: identity)
+              const double cc = t < cnt ? gc[j2] : 1.0, s2 = t < cnt ? gs[j2] : 0.0;
+              out[t] = -s2 * ja[t] + cc * carry;
+              carry = t < cnt ? cc * ja[t] + s2 * carry : carry;
+            }
+#pragma unroll
+            for (int t = 0; t < XL_RCH; t++) if (t < cnt) Ji[hi - t] = out[t];
           }
           Ji[iq] = carry;
         }
@@ -504,6 +601,7 @@ __device__ __noinline__ int dev_xl_qp(const Ctx& c) {
         drop(lidx);
         sp = row_slack(ip);
       }
+      PROF_END(PH_Q_UPD, px5);
     }
     if (st < 0) st = 2;
     if (st != 0) { ret = st; break; }
