@@ -61,7 +61,7 @@ class ParamsT(C.Structure):
         ('merit_function', C.c_int32), ('rel_tol_req', C.c_int32), ('lsqr_iter_lim', C.c_int32),
         ('lsqr_atol', C.c_double), ('lsqr_btol', C.c_double),
         ('qp_warm_start', C.c_int32), ('hessian_bfgs', C.c_int32),
-        ('eig_floor', C.c_double),
+        ('eig_floor', C.c_double), ('time_limit', C.c_double),
     ]
 
 

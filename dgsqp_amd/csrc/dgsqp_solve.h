@@ -1230,6 +1230,7 @@ __device__ inline void dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
   dev_evaluate(c, lds + L.u, 0.0, nullptr, false);
   dev_dual_init(c);
   int sqp_it = 0, rel_tol_its = 0, status = DGSQP_MAX_IT, total_qp = 0;
+  const unsigned long long t_start = wall_clock64();      // 100 MHz constant-rate counter (time_limit, DGSQP.py:470)
   double cond[3] = {0, 0, 0};
   const bool l1 = D.par.merit_function == DGSQP_MERIT_STAT_L1;
   while (true) {
@@ -1290,6 +1291,7 @@ __device__ inline void dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
     } else rel_tol_its = 0;
     sqp_it++;
     if (sqp_it >= D.par.sqp_iters) { status = DGSQP_MAX_IT; break; }
+    if (D.par.time_limit > 0.0 && (double)(wall_clock64() - t_start) * 1e-8 > D.par.time_limit) { status = DGSQP_TIME_LIMIT; break; }
   }
   // outputs: q_pred = evaluate_dynamics(u, x0) (DGSQP.py:476), cost = f_J (:492)
   __syncthreads();

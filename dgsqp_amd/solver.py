@@ -162,6 +162,7 @@ def build_params(params: DGSQPParams, eig_floor: Optional[float] = None) -> _ffi
     p.lsqr_atol = p.lsqr_btol = 1e-6       # scipy >= 1.12 defaults of sparse.linalg.lsqr
     p.qp_warm_start = int(getattr(params, 'qp_warm_start', 1))
     p.hessian_bfgs = 1 if params.hessian_approximation == 'bfgs' else 0
+    p.time_limit = 0.0 if params.time_limit is None else float(params.time_limit)
     p.eig_floor = max(1e-10, 1e-6 - float(params.reg)) if eig_floor is None else float(eig_floor)
     return p
 

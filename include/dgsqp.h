@@ -155,6 +155,9 @@ typedef struct {
                              <= 0 selects 1e-10.  With reg = 0 that leaves a Hessian with condition 1e12 which neither
                              OSQP (sigma = 1e-6, polish delta = 1e-6) nor an explicit-inverse QP solves to better than
                              1e-3; the host mirror therefore passes max(1e-10, 1e-6 - reg) unless told otherwise. */
+  double time_limit;      /* DGSQPParams.time_limit: wall-clock seconds per solve() after which the scenario ends with DGSQP_TIME_LIMIT
+                             (checked at the end of every SQP iteration, DGSQP.py:470); <= 0: none.  Counted from the moment a
+                             workgroup starts the scenario, not from the launch of the batch. */
 } dgsqp_params_t;
 
 /* PID lane follower used for the Monte-Carlo warm start (DGSQP/solvers/PID.py through

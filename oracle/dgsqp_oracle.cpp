@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <limits>
 #include <thread>
@@ -1176,6 +1177,7 @@ static void solve_one(const dgsqp_problem_t& P, const dgsqp_params_t& par, const
   }
   out.l_init = l;
   int rel_tol_its = 0, sqp_it = 0, status = DGSQP_MAX_IT, total_qp = 0;
+  const auto t_start = std::chrono::steady_clock::now();
   double p_feas = 0, comp = 0, stat = 0;
   vec u_im1, Q_prev;
   while (true) {
@@ -1247,6 +1249,7 @@ static void solve_one(const dgsqp_problem_t& P, const dgsqp_params_t& par, const
     } else rel_tol_its = 0;
     sqp_it++;
     if (sqp_it >= par.sqp_iters) { status = DGSQP_MAX_IT; break; }
+    if (par.time_limit > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > par.time_limit) { status = DGSQP_TIME_LIMIT; break; }   // :470
   }
   out.u = u; out.l = l;
   rollout(P, L, u.data(), x0, out.x);

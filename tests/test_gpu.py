@@ -677,6 +677,24 @@ def test_xl_layout_long_horizon_n200(oracle):
         assert rel(res['u'][b], ref['u'][b]) < 1e-6 and rel(res['l'][b], ref['l'][b]) < 1e-5
 
 
+def test_time_limit_status(oracle, games):
+    """DGSQPParams.time_limit (DGSQP.py:470): checked at the end of every SQP iteration; with a limit of 0.1 microseconds every
+    scenario that is not finished after its first iteration ends with 'time_limit' -- on the device and on the oracle alike."""
+    import copy
+    from dgsqp_amd.montecarlo import sample_scenarios
+    from dgsqp_amd.solver import DGSQP, build_problem, build_params
+    g = copy.deepcopy(games['kb_chicane_N15'][0])
+    g.params.time_limit = 1e-7
+    P, par = build_problem(*g.solver_args()), build_params(g.params)
+    s = DGSQP(*g.solver_args(), print_method=None)
+    x0, u_tm = sample_scenarios(g, 12, seed=3)
+    res = s.solve_batch(x0, u_tm)
+    ref = oracle.solve_batch(P, par, x0, agent_major(u_tm))
+    assert np.array_equal(res['status'], ref['status']) and np.array_equal(res['num_iters'], ref['num_iters'])
+    assert set(res['status']) <= {0, 4, 5} and (res['status'] == 5).sum() >= 10 and (res['num_iters'][res['status'] == 5] == 1).all()
+    assert res['msg'][int(np.argmax(res['status'] == 5))] == 'time_limit'
+
+
 def test_large_batch_equals_small_batches(games):
     """Every scenario of a 3,500-scenario launch (14 per workgroup, dynamic ticket order) comes out exactly as in a small
     launch: no state leaks between the scenarios a workgroup processes (warm-started active sets, trajectory tags)."""
