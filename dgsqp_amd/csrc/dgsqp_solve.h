@@ -1254,15 +1254,16 @@ __device__ inline void dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
       cond[2] = block_max(sm, lds + L.red);
     }
     dev_tr(c, 1, cond[2]); dev_tr(c, 2, cond[0]); dev_tr(c, 3, cond[1]);
-    if (cond[2] > 1e5) { status = DGSQP_DIVERGED; break; }
-    if (cond[0] < D.par.p_tol && cond[1] < D.par.d_tol && cond[2] < D.par.d_tol) { status = DGSQP_CONV_ABS_TOL; break; }
+    const int qp_before = total_qp;      // trace code 40: QP solves of this iteration, at the reference's iter_data records (:386-451)
+    if (cond[2] > 1e5) { dev_tr(c, 40, 0.0); status = DGSQP_DIVERGED; break; }
+    if (cond[0] < D.par.p_tol && cond[1] < D.par.d_tol && cond[2] < D.par.d_tol) { dev_tr(c, 40, 0.0); status = DGSQP_CONV_ABS_TOL; break; }
     dev_qt_mul(c);
     int flag;
     if (D.big == 2) { dev_xl_psd(c, nullptr); flag = dev_xl_qp(c); }   // n > 128: dgsqp_xl.h
     else if (D.classic_qp) { dev_psd_inverse(c, c.ws + D.ws_xM); flag = dev_xl_qp(c); }
     else { dev_psd_inverse(c, nullptr); flag = dev_qp(c); }
     total_qp++;
-    if (flag != 0) { status = DGSQP_QP_FAIL; break; }
+    if (flag != 0) { dev_tr(c, 40, 1.0); status = DGSQP_QP_FAIL; break; }
     LinScal S;
     dev_step_scalars(c, S);
     // _get_mu (DGSQP.py:559-585)
@@ -1285,6 +1286,7 @@ __device__ inline void dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
     for (int r = TID; r < nc; r += NT) { const double t = lds[L.l + r] - bk[2 * n + r]; dl2 += t * t; }
     du2 = block_sum(du2, lds + L.red);
     dl2 = block_sum(dl2, lds + L.red);
+    dev_tr(c, 40, (double)(total_qp - qp_before));
     if (sqrt(du2) < D.par.p_tol / 2 && sqrt(dl2) < D.par.d_tol / 2) {
       rel_tol_its++;
       if (rel_tol_its >= D.par.rel_tol_req && cond[0] < D.par.p_tol) { status = DGSQP_CONV_REL_TOL; break; }

@@ -397,7 +397,15 @@ class DGSQP(AbstractSolver):
         x0 = self.joint_dynamics.state2q(states)
         u_init = copy.copy(self.u_ws)
         self.print_method(self.solver_name)
-        res = self.solve_batch(x0[None, :], u_init[None, :])
+        want_iters = bool(self.save_iter_data)
+        if want_iters:
+            self.set_trace(64 * (int(self._cparams.sqp_iters) + 2) + 64 * int(self._cparams.line_search_iters))
+        try:
+            res = self.solve_batch(x0[None, :], u_init[None, :])
+            events = self.fetch_trace(1)[0] if want_iters else None
+        finally:
+            if want_iters:
+                self.set_trace(0)
         self.q_pred = res['x'][0]
         self.u_pred = res['u_pred'][0]
         self.l_pred = res['l'][0]
@@ -408,10 +416,29 @@ class DGSQP(AbstractSolver):
         self.print_method(f'Solve iters: {int(res["num_iters"][0])}')
         self.print_method(f'Solve time: {solve_dur:.2f}')
         self.print_method(str(res['cost'][0]))
-        # iter_data is a host-debug feature of the reference (DGSQP.py:386); the batched kernels
-        # keep only the totals, so a single summary record is returned.
-        iter_data = [dict(cond=cond, u_sol=res['u'][0], l_sol=res['l'][0], qp_solves=int(res['qp_solves'][0]),
-                          it_time=solve_dur)] if self.save_iter_data else []
+        # iter_data (DGSQP.py:386-451): one record per SQP iteration with the optimality measures at its start and its QP
+        # solves, rebuilt from the kernel's event log (codes 1-3 and 40); the iterates of the intermediate iterations are
+        # not kept on the device, the last record carries the final ones.
+        iter_data = []
+        if want_iters:
+            cur = None
+            for code, val in events:
+                code = int(code)
+                if code == 1:
+                    cur = dict(cond=dict(stat=float(val)), u_sol=None, l_sol=None, qp_solves=0, it_time=None)
+                elif cur is not None and code == 2:
+                    cur['cond']['p_feas'] = float(val)
+                elif cur is not None and code == 3:
+                    cur['cond']['comp'] = float(val)
+                elif cur is not None and code == 40:
+                    cur['qp_solves'] = int(val)
+                    iter_data.append(cur)
+                    cur = None
+            n_it = max(len(iter_data), 1)
+            for d in iter_data:
+                d['it_time'] = solve_dur / n_it
+            if iter_data:
+                iter_data[-1]['u_sol'], iter_data[-1]['l_sol'] = res['u'][0], res['l'][0]
         return dict(time=solve_dur, num_iters=int(res['num_iters'][0]), status=bool(res['converged'][0]),
                     cost=[float(c) for c in res['cost'][0]], cond=cond, iter_data=iter_data, msg=msg,
                     init=dict(u=u_init, l=None))

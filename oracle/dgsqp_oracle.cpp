@@ -1217,12 +1217,13 @@ static void solve_one(const dgsqp_problem_t& P, const dgsqp_params_t& par, const
     p_feas = std::max(0.0, gmax);
     for (int cc = 0; cc < L.n; cc++) { double d = k.q[cc]; for (int r = 0; r < L.nc; r++) d += k.G[(size_t)r * L.n + cc] * l[r]; stat = std::max(stat, std::fabs(d)); }
     tr(c, 1, stat); tr(c, 2, p_feas); tr(c, 3, comp);
-    if (stat > 1e5) { status = DGSQP_DIVERGED; break; }
-    if (p_feas < par.p_tol && comp < par.d_tol && stat < par.d_tol) { status = DGSQP_CONV_ABS_TOL; break; }
+    const int qp_before = total_qp;    // trace code 40: QP solves of this iteration, at the reference's iter_data records (:386-451)
+    if (stat > 1e5) { tr(c, 40, 0.0); status = DGSQP_DIVERGED; break; }
+    if (p_feas < par.p_tol && comp < par.d_tol && stat < par.d_tol) { tr(c, 40, 0.0); status = DGSQP_CONV_ABS_TOL; break; }
     vec du, lhat;
     bool ok = solve_qp(c, k, du, lhat);
     total_qp++;
-    if (!ok) { status = DGSQP_QP_FAIL; break; }
+    if (!ok) { tr(c, 40, 1.0); status = DGSQP_QP_FAIL; break; }
     vec dl, s, ds;
     step_vectors(L, k, du, l, lhat, dl, s, ds);
     const double mu = get_mu(L, par, du, l, dl, s, k);
@@ -1243,6 +1244,7 @@ static void solve_one(const dgsqp_problem_t& P, const dgsqp_params_t& par, const
     double du2 = 0, dl2 = 0;
     for (int i = 0; i < L.n; i++) du2 += (u[i] - u_im1[i]) * (u[i] - u_im1[i]);
     for (int i = 0; i < L.nc; i++) dl2 += (l[i] - l_im1[i]) * (l[i] - l_im1[i]);
+    tr(c, 40, (double)(total_qp - qp_before));
     if (std::sqrt(du2) < par.p_tol / 2 && std::sqrt(dl2) < par.d_tol / 2) {
       rel_tol_its++;
       if (rel_tol_its >= par.rel_tol_req && p_feas < par.p_tol) { status = DGSQP_CONV_REL_TOL; break; }

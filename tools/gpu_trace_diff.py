@@ -34,7 +34,7 @@ s.set_trace(8000)
 res = s.solve_batch(x0, u_tm)
 traces = s.fetch_trace(B)
 s.set_trace(0)
-names = {1: 'stat', 2: 'p_feas', 3: 'comp', 10: '|du|^2', 11: 'mu', 12: 'phi', 13: 'dphi', 20: 'wd phi1', 21: 'wd phi_n', 22: 'wd phi_n2', 30: 'ls alpha', 31: 'ls phi'}
+names = {40: 'qp solves of the iteration', 1: 'stat', 2: 'p_feas', 3: 'comp', 10: '|du|^2', 11: 'mu', 12: 'phi', 13: 'dphi', 20: 'wd phi1', 21: 'wd phi_n', 22: 'wd phi_n2', 30: 'ls alpha', 31: 'ls phi'}
 for b in range(B):
     to = oracle.solve_trace(P, par, x0[b], u[b])
     tg = traces[b]
