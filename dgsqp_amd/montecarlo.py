@@ -94,10 +94,19 @@ def kinematic_racing_game(track_kind='chicane', theta_deg=45, N=25, reg=1e-3, M=
                 name=f'kb_{track_kind}_N{N}')
 
 
-def dynamic_racing_game(track_kind='curve', theta_deg=45, N=25, reg=1e-3, rk4_substeps=10) -> Game:
-    """BASELINE.json config 2: 2-agent dynamic-bicycle (Pacejka) race on the curve track.
-    Vehicle / integrator from comparison_study_barc/exact_dynamic_game_dynamic.py:26-66 and
-    globals.py:17-18 (rk4, M=10); costs / constraints / bounds of curve.py."""
+def dynamic_racing_game(track_kind='curve', theta_deg=45, N=25, reg=1e-3, rk4_substeps=10, game_def='exact_dynamic') -> Game:
+    """BASELINE.json config 2: 2-agent dynamic-bicycle (Pacejka) race on the curve track (curve.py:140-146), rk4 with
+    M=10 sub-steps (comparison_study_barc/globals.py:17-18), vehicle of exact_dynamic_game_dynamic.py:26-66.
+
+    ``game_def='exact_dynamic'`` (default) is the reference's own dynamic-bicycle game,
+    comparison_study_barc/exact_dynamic_game_dynamic.py with its default ``cost_setting 0``
+    (argument_parser.py): input / input-rate weights 1 (:100-105), terminal ``-1*s_a + 5*(s_b - s_a)`` -- linear
+    competition term (:146-147, :167-168) --, NO agent constraint rows (``car*_constrs = [None]*(N+1)``, :197,201), obstacle
+    rows from k=1 with radii 0.23 (globals.py:12-13, :193, :206-213), boxes |u_a| <= 2.1, |steer| <= 0.436, |e_y| <= H
+    (:68-95); rows per stage 8 / 13 / 5.  ``game_def='curve'`` is round 1's synthetic variant -- the costs, rate rows and
+    radii of the kinematic curve.py game (progress weight 10, atan competition) on the Pacejka vehicle; a third of its
+    scenarios drive the open-loop rollout into |dx/du| ~ 1e17 (profiles/r02_dyn_curve_divergence.txt), it is kept as a
+    stress case."""
     dt, half_width, M = 0.1, 1.0, 2
     track = _track(track_kind, theta_deg, half_width)
     cfg = lambda: DynamicBicycleConfig(dt=dt, model_name='dynamic_bicycle', noise=False, discretization_method='rk4',
@@ -108,14 +117,22 @@ def dynamic_racing_game(track_kind='curve', theta_deg=45, N=25, reg=1e-3, rk4_su
     joint = CasadiDecoupledMultiAgentDynamicsModel(0, models, MultiAgentModelConfig(
         dt=dt, discretization_method='rk4', use_mx=False, code_gen=False, verbose=False, compute_hessians=True,
         M=rk4_substeps))
-    r = 0.2
     params = DGSQPParams(solver_name='DGSQP', dt=dt, N=N, reg=reg, nonmono_ls=True, line_search_iters=50,
                          sqp_iters=50, p_tol=1e-3, d_tol=1e-3, beta=0.01, tau=0.5, verbose=False)
-    cost = lambda: RacingCost(input_weight=(1.0, 1.0), input_rate_weight=(1.0, 1.0), comp_weights=(10.0, 5.0),
-                              comp_type='atan')
-    return Game(joint, [cost() for _ in range(M)], [InputRateLimits((10.0, 4.5), (-10.0, -4.5)) for _ in range(M)],
-                CollisionAvoidance([r] * M), _bounds(half_width, M), params, track, half_width, 2 * r,
-                name=f'dyn_{track_kind}_N{N}')
+    if game_def == 'exact_dynamic':
+        r = 0.23
+        cost = lambda: RacingCost(input_weight=(1.0, 1.0), input_rate_weight=(1.0, 1.0), comp_weights=(1.0, 5.0),
+                                  comp_type='linear')
+        rows = [None] * M
+    elif game_def == 'curve':
+        r = 0.2
+        cost = lambda: RacingCost(input_weight=(1.0, 1.0), input_rate_weight=(1.0, 1.0), comp_weights=(10.0, 5.0),
+                                  comp_type='atan')
+        rows = [InputRateLimits((10.0, 4.5), (-10.0, -4.5)) for _ in range(M)]
+    else:
+        raise ValueError(game_def)
+    return Game(joint, [cost() for _ in range(M)], rows, CollisionAvoidance([r] * M), _bounds(half_width, M), params, track,
+                half_width, 2 * r, name=f'dyn_{track_kind}_N{N}' + ('' if game_def == 'exact_dynamic' else '_' + game_def))
 
 
 def barc_racing_game(N=15, M=2, reg=0.0) -> Game:

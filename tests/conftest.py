@@ -37,7 +37,8 @@ def games():
     for name, g in (('kb_chicane_N15', kinematic_racing_game('chicane', N=15)),
                     ('kb_chicane_N25', kinematic_racing_game('chicane', N=25)),
                     ('kb_curve_N10', kinematic_racing_game('curve', N=10)),
-                    ('dyn_curve_N15', dynamic_racing_game(N=15, rk4_substeps=4)),
+                    ('dyn_curve_N15', dynamic_racing_game(N=15, rk4_substeps=4, game_def='curve')),
+                    ('dyn_curve_N25', dynamic_racing_game(N=25, rk4_substeps=10)),      # BASELINE configs[1] itself
                     ('merge_N8', merge_game(N=8)), ('kb_barc2_N15', barc_racing_game(N=15, M=2))):
         out[name] = (g, build_problem(*g.solver_args()), build_params(g.params))
     return out

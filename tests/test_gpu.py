@@ -46,7 +46,7 @@ def test_native_library_is_loaded(solvers):
     assert s.dims.lds_bytes <= 163840 and s.dims.n == 100 and s.dims.n_c == 525 and s.dims.n_dense == 75
 
 
-@pytest.mark.parametrize('name', ['kb_chicane_N15', 'kb_chicane_N25', 'kb_curve_N10', 'dyn_curve_N15'])
+@pytest.mark.parametrize('name', ['kb_chicane_N15', 'kb_chicane_N25', 'kb_curve_N10', 'dyn_curve_N15', 'dyn_curve_N25'])
 def test_evaluate_parity(oracle, games, solvers, name):
     """_evaluate (DGSQP.py:509-533): rollout, q, g, G, raw Q.  Tolerance 1e-12 relative (fp64, different
     derivative techniques: Taylor directions on device vs dense jets in the oracle)."""
@@ -98,7 +98,7 @@ def test_qp_parity_and_kkt(oracle, games, solvers, name):
         assert np.abs(lh * (o['G'] @ d + o['g'])).max() < 1e-10 * scale
 
 
-@pytest.mark.parametrize('name', ['kb_chicane_N15', 'kb_curve_N10', 'dyn_curve_N15', 'kb_barc2_N15', 'merge_N8'])
+@pytest.mark.parametrize('name', ['kb_chicane_N15', 'kb_curve_N10', 'dyn_curve_N15', 'dyn_curve_N25', 'kb_barc2_N15', 'merge_N8'])
 def test_solve_matches_golden_fixtures(solvers, name):
     """Committed oracle solutions (tools/make_golden.py): identical flags / iteration / QP counts and iterates
     within 1e-5 relative on every scenario whose control flow is well conditioned; at most 10 % of the
@@ -116,6 +116,22 @@ def test_solve_matches_golden_fixtures(solvers, name):
         if gold['status'][b] == 0:
             assert rel(res['l'][b], gold['l'][b]) < 1e-5, b
             assert rel(res['cost'][b], gold['cost'][b]) < (1e-6 if name in ('kb_barc2_N15', 'merge_N8') else 1e-8), b
+
+
+def test_baseline_config1_dyn_curve_N25_parity(solvers):
+    """BASELINE configs[1] at its own size (2-agent dynamic bicycle, Pacejka, rk4 M=10, N=25; 64 committed oracle
+    solutions): >= 90 % of the scenarios identical in (status, iterations, QP solves), converged fraction within 3 points,
+    iterates of the identical converged ones within 1e-5 relative (north_star)."""
+    gold = np.load(GOLD / 'dyn_curve_N25.npz')
+    res = solvers['dyn_curve_N25'].solve_batch(gold['x0'], gold['u_ws'])
+    same = (res['status'] == gold['status']) & (res['num_iters'] == gold['num_iters']) & (res['qp_solves'] == gold['qp_solves'])
+    conv_d, conv_o = np.mean(res['status'] <= 1), np.mean(gold['status'] <= 1)
+    print('identical', same.mean(), 'converged device / oracle', conv_d, conv_o, 'forks', np.nonzero(~same)[0].tolist())
+    assert same.mean() >= 0.9, (np.nonzero(~same)[0], res['status'][~same], gold['status'][~same], res['num_iters'][~same], gold['num_iters'][~same])
+    assert abs(conv_d - conv_o) <= 0.03
+    for b in np.where(same & (gold['status'] <= 1))[0]:
+        assert rel(res['u'][b], gold['u'][b]) < 1e-5, b
+        assert rel(res['l'][b], gold['l'][b]) < 1e-5, b
 
 
 def test_event_trace_parity(oracle, games, solvers):
@@ -435,7 +451,7 @@ def test_model_and_integrator_variants(oracle, kind, method, msub, over):
                                     CasadiDecoupledMultiAgentDynamicsModel)
     from dgsqp_amd.montecarlo import dynamic_racing_game, kinematic_racing_game, sample_scenarios
     from dgsqp_amd.solver import DGSQP, build_problem
-    base = dynamic_racing_game(N=8, rk4_substeps=3) if kind == 'dyn' else kinematic_racing_game('curve', N=8)
+    base = dynamic_racing_game(N=8, rk4_substeps=3, game_def='curve') if kind == 'dyn' else kinematic_racing_game('curve', N=8)
     cls = CasadiDynamicBicycleCombined if kind == 'dyn' else CasadiKinematicBicycleCombined
     models = [cls(0, dataclasses.replace(m.model_config, discretization_method=method, M=msub, **over), track=base.track)
               for m in base.joint_model.dynamics_models]

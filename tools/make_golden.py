@@ -34,7 +34,7 @@ def param_defaults():
         del sys.modules[m]
 
 
-def solve_fixtures():
+def solve_fixtures(only=None):
     import copy
     from dgsqp_amd.montecarlo import (barc_racing_game, kinematic_racing_game, dynamic_racing_game, merge_game,
                                       sample_scenarios)
@@ -42,9 +42,12 @@ def solve_fixtures():
     from oracle import oracle
     for name, game, B, seed in (('kb_chicane_N15', kinematic_racing_game('chicane', N=15), 32, 11),
                                 ('kb_curve_N10', kinematic_racing_game('curve', N=10), 32, 12),
-                                ('dyn_curve_N15', dynamic_racing_game(N=15, rk4_substeps=4), 16, 13),
+                                ('dyn_curve_N15', dynamic_racing_game(N=15, rk4_substeps=4, game_def='curve'), 16, 13),
+                                ('dyn_curve_N25', dynamic_racing_game(N=25, rk4_substeps=10), 64, 1),     # BASELINE configs[1]
                                 ('kb_barc2_N15', barc_racing_game(N=15, M=2), 32, 0),        # reg = 0 (comp.py:169)
                                 ('merge_N8', merge_game(N=8), 16, 1)):                       # reg = 0 (merge.py:182)
+        if only and name not in only:
+            continue
         P = build_problem(*game.solver_args())
         par = build_params(game.params)
         par.lsqr_atol = par.lsqr_btol = 1e-13
@@ -60,5 +63,7 @@ def solve_fixtures():
 
 
 if __name__ == '__main__':
-    param_defaults()
-    solve_fixtures()
+    only = sys.argv[1:]
+    if not only:
+        param_defaults()
+    solve_fixtures(only)
