@@ -62,6 +62,7 @@ class ParamsT(C.Structure):
         ('lsqr_atol', C.c_double), ('lsqr_btol', C.c_double),
         ('qp_warm_start', C.c_int32), ('hessian_bfgs', C.c_int32),
         ('eig_floor', C.c_double), ('time_limit', C.c_double),
+        ('snap_active_bounds', C.c_int32), ('reserved_', C.c_int32),
     ]
 
 

@@ -505,8 +505,8 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
   const int m = (int)q.scal[1];
   // The exact minimiser sits ON its active input bounds; the polished point holds them to rounding distance (to ~1e-9 in
   // the reg = 0 regime).  These rows are linear in u, the next linearisation inherits exactly that residual and _get_mu
-  // switches on its sign (DGSQP.py:566-585): put du on the active bounds (the oracle does the same).
-  if (ret == 0) {
+  // switches on its sign (DGSQP.py:566-585).  par.snap_active_bounds (default 0 = literal) puts du on the active bounds.
+  if (ret == 0 && D.par.snap_active_bounds) {
     for (int j = TID; j < m; j += NT) {
       const int r = q.alist[j];
       const DgRow Rw = ld_row(r);

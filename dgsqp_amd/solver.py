@@ -143,10 +143,13 @@ def build_problem(joint_dynamics: CasadiDecoupledMultiAgentDynamicsModel,
     return P
 
 
-def build_params(params: DGSQPParams, eig_floor: Optional[float] = None) -> _ffi.ParamsT:
-    """``eig_floor``: value ``_nearestPD`` gives to negative eigenvalues.  ``None`` = ``max(1e-10, 1e-6 - reg)``: the
-    reference's 1e-10 (DGSQP.py:1293) whenever ``reg >= 1e-6``, and 1e-6 at ``reg = 0`` (curve.py, comp.py, merge.py), where
-    1e-10 leaves a QP of condition 1e12.  Pass 1e-10 for the literal formula."""
+def build_params(params: DGSQPParams, eig_floor: Optional[float] = None, snap_active_bounds: bool = False,
+                 lsqr_tol: Optional[float] = None, qp_warm_start: bool = True) -> _ffi.ParamsT:
+    """``eig_floor``: value ``_nearestPD`` gives to negative eigenvalues; ``None`` = the reference's literal 1e-10
+    (DGSQP.py:1293).  At ``reg = 0`` (curve.py, comp.py, merge.py) that leaves a QP of condition 1e12, which the device solves
+    with its classical (J = L^-T) active-set kernels; passing a larger floor (1e-6) is an explicit opt-in that keeps such games
+    on the faster explicit-inverse kernels.  ``snap_active_bounds``: see include/dgsqp.h (default literal).
+    ``lsqr_tol``: atol = btol of the LSQR dual start; ``None`` = scipy's defaults (1e-6), what ``DGSQP.py:324`` runs with."""
     if not params.conv_approx:
         raise NotImplementedError('conv_approx=False (IPOPT Newton step, DGSQP.py:204-228) is not on the Monte-Carlo path')
     if params.hessian_approximation not in ('none', 'bfgs'):
@@ -159,11 +162,12 @@ def build_params(params: DGSQPParams, eig_floor: Optional[float] = None) -> _ffi
     p.merit_function = 0 if params.merit_function == 'stat_l1' else 1
     p.rel_tol_req = 3                      # DGSQP.py:56
     p.lsqr_iter_lim = 0                    # scipy default 2*n_c
-    p.lsqr_atol = p.lsqr_btol = 1e-6       # scipy >= 1.12 defaults of sparse.linalg.lsqr
-    p.qp_warm_start = int(getattr(params, 'qp_warm_start', 1))
+    p.lsqr_atol = p.lsqr_btol = 1e-6 if lsqr_tol is None else float(lsqr_tol)      # scipy >= 1.12 defaults of sparse.linalg.lsqr
+    p.qp_warm_start = int(bool(qp_warm_start))      # start each QP's active-set search from the previous QP's active set (same minimiser)
     p.hessian_bfgs = 1 if params.hessian_approximation == 'bfgs' else 0
     p.time_limit = 0.0 if params.time_limit is None else float(params.time_limit)
-    p.eig_floor = max(1e-10, 1e-6 - float(params.reg)) if eig_floor is None else float(eig_floor)
+    p.eig_floor = 1e-10 if eig_floor is None else float(eig_floor)
+    p.snap_active_bounds = int(bool(snap_active_bounds))
     return p
 
 
@@ -213,9 +217,12 @@ class DGSQP(AbstractSolver):
                  xy_plot=None,
                  use_mx: bool = False,
                  device: int = 0,
-                 eig_floor: Optional[float] = None):
-        """``eig_floor``: see ``build_params`` (None = literal 1e-10 for reg >= 1e-6, 1e-6 at reg = 0; 1e-10 = always the
-        literal ``_nearestPD`` formula, solved by the slower classical active-set kernels when reg < 1e-8)."""
+                 eig_floor: Optional[float] = None,
+                 snap_active_bounds: bool = False,
+                 lsqr_tol: Optional[float] = None,
+                 qp_warm_start: bool = True):
+        """``eig_floor``, ``snap_active_bounds``: implementation knobs, see ``build_params``; the defaults are the reference's
+        literal formulas (``_nearestPD`` floor 1e-10, DGSQP.py:1293; no adjustment of the QP step)."""
         self.joint_dynamics = joint_dynamics
         self.M = joint_dynamics.n_a
         self.print_method = (lambda s: None) if print_method is None else print_method
@@ -230,7 +237,8 @@ class DGSQP(AbstractSolver):
         self.num_ua_el = [int(self.N * m.n_u) for m in joint_dynamics.dynamics_models]
 
         self._problem = build_problem(joint_dynamics, costs, agent_constraints, shared_constraints, bounds, params)
-        self._cparams = build_params(params) if eig_floor is None else build_params(params, eig_floor=eig_floor)
+        self._cparams = build_params(params, eig_floor=eig_floor, snap_active_bounds=snap_active_bounds, lsqr_tol=lsqr_tol,
+                                     qp_warm_start=qp_warm_start)
         _, _, self.n, n_c = problem_dims(self._problem)
         self.n_c_total = n_c
 

@@ -152,12 +152,19 @@ typedef struct {
   int32_t hessian_bfgs;   /* DGSQPParams.hessian_approximation: 0 'none' (exact game Hessian every iteration), 1 'bfgs' (damped BFGS
                              update of the projected Hessian after the first iteration, DGSQP.py:353-364, :535-557) */
   double eig_floor;       /* value _nearestPD gives to the negative eigenvalues; the reference uses 1e-10 (DGSQP.py:1293).
-                             <= 0 selects 1e-10.  With reg = 0 that leaves a Hessian with condition 1e12 which neither
-                             OSQP (sigma = 1e-6, polish delta = 1e-6) nor an explicit-inverse QP solves to better than
-                             1e-3; the host mirror therefore passes max(1e-10, 1e-6 - reg) unless told otherwise. */
+                             <= 0 selects 1e-10, which is also what the host mirror passes by default.  With reg = 0 that
+                             leaves a Hessian with condition 1e12 (solved by the classical J = L^-T active-set kernels);
+                             a larger floor (e.g. 1e-6) is an explicit opt-in that keeps such games on the faster
+                             explicit-inverse kernels. */
   double time_limit;      /* DGSQPParams.time_limit: wall-clock seconds per solve() after which the scenario ends with DGSQP_TIME_LIMIT
                              (checked at the end of every SQP iteration, DGSQP.py:470); <= 0: none.  Counted from the moment a
                              workgroup starts the scenario, not from the launch of the batch. */
+  int32_t snap_active_bounds; /* implementation knob, default 0 = literal.  1: after each QP put du exactly on the input bounds
+                             whose multiplier is positive.  An exact QP solver leaves them at +-1 ulp, OSQP's polish at ~1e-12
+                             (sign random); the rows are linear, the next iterate inherits that residual and _get_mu switches
+                             on the sign of sum(g - s) with threshold 0 (DGSQP.py:559-585) -- a coin flip in the reference
+                             itself; 1 makes it deterministic (mu = 0 when nothing else is violated). */
+  int32_t reserved_;
 } dgsqp_params_t;
 
 /* PID lane follower used for the Monte-Carlo warm start (DGSQP/solvers/PID.py through

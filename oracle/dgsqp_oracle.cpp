@@ -1052,10 +1052,10 @@ static bool solve_qp(const Ctx& c, const Lin& k, vec& du, vec& lhat) {
   nearest_pd(c.L.n, k.Q.data(), c.par.reg, Qpd, c.par.eig_floor);   // eig_floor: 1e-10 in the reference (DGSQP.py:1293)
   du.assign(c.L.n, 0.0); lhat.assign(c.L.nc, 0.0);
   if (qp_gi(c.L.n, c.L.nc, Qpd.data(), k.q.data(), k.G.data(), k.g.data(), du.data(), lhat.data()) != 0) return false;
-  // The exact minimiser sits ON its active input bounds.  With an ill-conditioned Hessian (reg = 0) the active-set
-  // iterations leave them at rounding distance (+-1e-15); these rows are linear in u, the next iterate inherits exactly
-  // that residual and _get_mu switches on its sign (DGSQP.py:566-585).  Put du on the active bounds.
-  for (int r = 0; r < c.L.nc; r++) {
+  // NOT in the reference, default off (par.snap_active_bounds = 0).  The exact minimiser sits ON its active input bounds;
+  // the active-set iterations leave them at rounding distance (+-1e-15); these rows are linear in u, the next iterate
+  // inherits exactly that residual and _get_mu switches on its sign (DGSQP.py:566-585).  The knob puts du on the active bounds.
+  for (int r = 0; c.par.snap_active_bounds && r < c.L.nc; r++) {
     const Row& R = c.L.rows[r];
     if (lhat[r] > 0 && R.type == R_IN_UB) du[c.L.col(R.a, R.k, R.idx)] = -k.g[r];
     else if (lhat[r] > 0 && R.type == R_IN_LB) du[c.L.col(R.a, R.k, R.idx)] = k.g[r];

@@ -198,13 +198,14 @@ def test_multi_agent_sampler():
 
 
 def test_eig_floor_rule_and_oracle_projection(oracle):
-    """_nearestPD floor (DGSQP.py:1293 uses 1e-10): the host passes the literal value whenever reg >= 1e-6 and 1e-6 at
-    reg = 0 (condition 1e12 otherwise); the oracle's projection honours the parameter."""
+    """_nearestPD floor: the host passes the reference's literal 1e-10 (DGSQP.py:1293) by default, at reg = 0 too; a larger
+    floor and the active-bound snap are explicit opt-ins; the oracle's projection honours the parameter."""
     from dgsqp_amd.solver import build_params
     from dgsqp_amd.solver_types import DGSQPParams
     assert build_params(DGSQPParams(reg=1e-3)).eig_floor == 1e-10
-    assert build_params(DGSQPParams(reg=0.0)).eig_floor == pytest.approx(1e-6)
-    assert build_params(DGSQPParams(reg=0.0), eig_floor=1e-10).eig_floor == 1e-10
+    assert build_params(DGSQPParams(reg=0.0)).eig_floor == 1e-10 and build_params(DGSQPParams(reg=0.0)).snap_active_bounds == 0
+    assert build_params(DGSQPParams(reg=0.0), eig_floor=1e-6, snap_active_bounds=True).eig_floor == pytest.approx(1e-6)
+    assert build_params(DGSQPParams(reg=0.0), snap_active_bounds=True).snap_active_bounds == 1
     rng = np.random.default_rng(0)
     Q = rng.standard_normal((12, 12))
     w_ref = np.linalg.eigvalsh(0.5 * (Q + Q.T))

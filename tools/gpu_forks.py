@@ -1,0 +1,48 @@
+"""Development aid (GPU box): which scenarios of a golden fixture take a different path on the device than in the
+oracle, and the first SQP event at which the two logs differ.
+usage: gpu_forks.py <fixture name, e.g. dyn_curve_N25> [rel tol of the event comparison, default 1e-6]"""
+import os, sys, pathlib
+import numpy as np
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tests'))
+from conftest import agent_major, tight_lsqr
+from oracle import oracle
+import dgsqp_amd.solver as sv
+from dgsqp_amd import montecarlo as mc
+from dgsqp_amd.solver import DGSQP, build_problem, build_params
+
+name = sys.argv[1]
+tol = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-6
+games = {'dyn_curve_N25': lambda: mc.dynamic_racing_game(N=25, rk4_substeps=10),
+         'dyn_curve_N15': lambda: mc.dynamic_racing_game(N=15, rk4_substeps=4, game_def='curve'),
+         'kb_chicane_N15': lambda: mc.kinematic_racing_game('chicane', N=15), 'kb_curve_N10': lambda: mc.kinematic_racing_game('curve', N=10),
+         'kb_barc2_N15': lambda: mc.barc_racing_game(N=15, M=2), 'merge_N8': lambda: mc.merge_game(N=8)}
+g = games[name]()
+gold = np.load(ROOT / 'tests' / 'golden' / f'{name}.npz')
+x0, u_tm = gold['x0'], gold['u_ws']
+B = len(x0)
+P, par = build_problem(*g.solver_args()), tight_lsqr(build_params(g.params))
+orig = sv.build_params
+sv.build_params = lambda p: tight_lsqr(orig(p))
+s = DGSQP(*g.solver_args(), print_method=None)
+sv.build_params = orig
+s.set_trace(20000)
+res = s.solve_batch(x0, u_tm)
+traces = s.fetch_trace(B)
+s.set_trace(0)
+same = (res['status'] == gold['status']) & (res['num_iters'] == gold['num_iters']) & (res['qp_solves'] == gold['qp_solves'])
+print(f'{name}: identical {same.sum()}/{B}; converged device {np.mean(res["status"] <= 1):.3f} oracle {np.mean(gold["status"] <= 1):.3f}')
+names = {40: 'qp solves of the iteration', 1: 'stat', 2: 'p_feas', 3: 'comp', 10: '|du|^2', 11: 'mu', 12: 'phi', 13: 'dphi', 20: 'wd phi1', 21: 'wd phi_n', 22: 'wd phi_n2', 30: 'ls alpha', 31: 'ls phi'}
+u_am = agent_major(u_tm) if u_tm.shape[2] == 4 else np.concatenate([u_tm[:, :, 2 * a:2 * a + 2].reshape(B, -1) for a in range(u_tm.shape[2] // 2)], axis=1)
+for b in np.nonzero(~same)[0]:
+    to = oracle.solve_trace(P, par, x0[b], u_am[b], max_pairs=60000)
+    tg = traces[b]
+    k = 0
+    while k < min(len(to), len(tg)) and to[k, 0] == tg[k, 0] and abs(tg[k, 1] - to[k, 1]) <= tol * max(abs(to[k, 1]), 1e-9):
+        k += 1
+    it = int((to[:k, 0] == 1).sum()) - 1
+    print(f'scn {b}: device (status {res["status"][b]}, iters {res["num_iters"][b]}, qps {res["qp_solves"][b]}) oracle ({gold["status"][b]}, {gold["num_iters"][b]}, {gold["qp_solves"][b]}) | events dev {len(tg)} oracle {len(to)} | agree for {k} events (SQP iteration {it})')
+    for j in range(max(0, k - 4), min(k + 3, max(len(to), len(tg)))):
+        eo = f'{names.get(int(to[j, 0]), int(to[j, 0]))} {to[j, 1]:.10e}' if j < len(to) else '-'
+        ed = f'{names.get(int(tg[j, 0]), int(tg[j, 0]))} {tg[j, 1]:.10e}' if j < len(tg) else '-'
+        print(f'     ev {j}: oracle {eo} | dev {ed}')
