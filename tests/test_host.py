@@ -52,6 +52,34 @@ def test_sampler_is_seeded_and_collision_free(games):
     assert (np.abs(x0[:, [5, 11]]) <= g.half_width).all()
 
 
+def test_pid_against_vectors_of_the_reference_controller(games):
+    """tests/golden/pid_ref.npz is produced by IMPORTING the reference's DGSQP/solvers/PID.py (tools/make_pid_golden.py).
+    (a) dgsqp_amd.pid.PIDLaneFollower reproduces its outputs on open-loop random sequences (saturations, anti-windup,
+    set_x_ref(0) of the steering loop) bit for bit; (b) the vectorised numpy warm start -- the checker of the HIP kernel --
+    reproduces the closed-loop rollouts of the reference controller (chicane.py:411-447) for both vehicle models."""
+    from dgsqp_amd import montecarlo as mc
+    from dgsqp_amd.pid import PIDLaneFollower
+    from dgsqp_amd.solver_types import PIDParams
+    from dgsqp_amd.types import BodyLinearVelocity, ParametricPose, VehicleActuation, VehicleState
+    gold = np.load(pathlib.Path(__file__).parent / 'golden' / 'pid_ref.npz')
+    sat_abs = sat_rel = 0
+    for seq, want, du in zip(gold['open_in'], gold['open_out'], gold['open_du']):
+        ctl = PIDLaneFollower(0.1, PIDParams(dt=0.1, Kp=1.0, Ki=0.005, x_ref=seq[0, 1], u_max=0.436, u_min=-0.436, du_max=du[1], du_min=-du[1]),
+                              PIDParams(dt=0.1, Kp=1.0, x_ref=seq[0, 0], u_max=2.1, u_min=-2.1, du_max=du[0], du_min=-du[0]))
+        for k in range(len(seq)):
+            st = VehicleState(p=ParametricPose(x_tran=seq[k, 1], e_psi=seq[k, 2]), v=BodyLinearVelocity(v_long=seq[k, 0]), u=VehicleActuation())
+            ctl.step(st)
+            assert (st.u.u_a, st.u.u_steer) == (want[k, 0], want[k, 1]), k
+        sat_abs += int(np.abs(want[:, 1]).max() == 0.436)
+        sat_rel += int(np.isclose(np.abs(np.diff(want[:, 1])).max(), du[1]) or np.isclose(np.abs(np.diff(want[:, 0])).max(), du[0]))
+    assert sat_abs >= 2 and sat_rel >= 2           # the vectors do exercise both saturations
+    for tag, game in (('kb', mc.kinematic_racing_game('chicane', N=25)), ('dyn', mc.dynamic_racing_game(N=25))):
+        x0, u_ws, q_ws = gold[f'{tag}_x0'], gold[f'{tag}_u_ws'], gold[f'{tag}_q_ws']
+        for a, m in enumerate(game.joint_model.dynamics_models):
+            q, u = mc.pid_warm_start(m, x0[:, a * m.n_q:(a + 1) * m.n_q], 25, 0.1, du=tuple(gold[f'{tag}_du']))
+            assert np.abs(u - u_ws[:, a]).max() < 1e-12 and np.abs(q - q_ws[:, a]).max() < 1e-12, tag
+
+
 def test_pid_matches_batched_warm_start(games):
     """The scalar PID mirror (reference PID.py) and the vectorised sampler produce the same first inputs."""
     from dgsqp_amd.montecarlo import pid_warm_start

@@ -300,3 +300,54 @@ def test_literal_per_row_hessian_gives_same_solve(oracle, games):
     b = oracle.solve_batch(P, tight_lsqr(par), x0, u, literal=1)
     assert (a['status'] == b['status']).all() and (a['num_iters'] == b['num_iters']).all()
     np.testing.assert_allclose(a['u'], b['u'], atol=1e-8)
+
+
+def test_restated_osqp_solves_small_qps_and_flags_infeasibility(oracle):
+    """oracle/osqp_restate.py (restatement of OSQP's published algorithm, the QP the reference calls): on strictly convex
+    random QPs the polished point is the exact minimiser (KKT to 1e-8, equal to the active-set solution); an infeasible
+    system yields the primal-infeasibility certificate and NaNs, as OSQP stores them."""
+    from oracle import osqp_restate
+    rng = np.random.default_rng(4)
+    polished = 0
+    for trial in range(12):
+        n, m = 12, 30
+        A = rng.standard_normal((n, n))
+        H = A @ A.T + 0.1 * np.eye(n)
+        q = rng.standard_normal(n)
+        G = rng.standard_normal((m, n))
+        g = -rng.random(m) - 0.05                       # x = 0 strictly feasible
+        x, lam, info = osqp_restate.conic(H, q, G, -g)
+        assert info['status'] == osqp_restate.SOLVED and info['iters'] % 25 == 0
+        xe, le, flag = oracle.qp(H, q, G, g)
+        assert flag == 0
+        if info['polished'] == 1:
+            polished += 1
+            assert np.abs(H @ x + q + G.T @ lam).max() < 1e-8 and (G @ x + g).max() < 1e-8
+            if lam.min() > -1e-9:                       # polish does not check multiplier signs; when they are fine it IS the minimiser
+                assert np.abs(x - xe).max() < 1e-6 and np.abs(lam - le).max() < 1e-5
+        else:                                           # ADMM point at eps = 1e-3
+            assert np.abs(x - xe).max() < 5e-2
+    assert polished >= 8
+    G = np.array([[1.0, 0.0], [-1.0, 0.0]])
+    x, lam, info = osqp_restate.conic(np.eye(2), np.zeros(2), G, -np.array([1.0, 1.0]))      # x0 <= -1 and x0 >= 1
+    assert info['status'] == osqp_restate.PRIMAL_INFEASIBLE and np.isnan(x).all()
+
+
+def test_cpp_oracle_follows_the_numpy_loop(oracle, games):
+    """oracle/pyref.py restates DGSQP.solve() line by line in numpy with the library routines the reference itself calls
+    (numpy.linalg.eigh, scipy.sparse.linalg.lsqr at its defaults).  With the same exact QP plugged in, the C++ oracle must take
+    the same path: this separates the SQP logic / _nearestPD / LSQR of the C++ oracle from its QP.  With the restated OSQP
+    as the QP (what the reference runs) the flags and counts still agree on these well-conditioned scenarios."""
+    from dgsqp_amd.montecarlo import sample_scenarios
+    from oracle import pyref
+    g, P, par = games['kb_chicane_N15']
+    x0, u_tm = sample_scenarios(g, 6, seed=3)
+    u = agent_major(u_tm)
+    ref = oracle.solve_batch(P, par, x0, u, nthreads=6)
+    code = {'conv_abs_tol': 0, 'conv_rel_tol': 1, 'max_it': 2, 'diverged': 3, 'exception': 4}
+    for kind, tol in (('gi', 1e-7), ('osqp', 5e-3)):
+        for b in range(6 if kind == 'gi' else 3):
+            s = pyref.PyRef(P, par, qp=kind).solve(x0[b], u[b])
+            assert (code[s['msg']], s['num_iters'], s['qp_solves']) == (ref['status'][b], ref['num_iters'][b], ref['qp_solves'][b]), (kind, b)
+            assert np.abs(s['l_init'] - ref['l_init'][b]).max() < 1e-3          # two LSQR implementations at tolerance 1e-6
+            assert np.abs(s['u'] - ref['u'][b]).max() < tol * max(1.0, np.abs(ref['u'][b]).max()), (kind, b)
