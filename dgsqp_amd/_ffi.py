@@ -141,8 +141,14 @@ def load_library() -> C.CDLL:
     lib.dgsqp_pid_warm_start_batch.restype = C.c_int
     lib.dgsqp_set_trace.argtypes = [H, C.c_int]
     lib.dgsqp_set_trace.restype = C.c_int
-    lib.dgsqp_fetch_trace.argtypes = [H, _PD]
+    lib.dgsqp_fetch_trace.argtypes = [H, _PD, C.c_int64]
     lib.dgsqp_fetch_trace.restype = C.c_int
+    lib.dgsqp_set_iterate_log.argtypes = [H, C.c_int]
+    lib.dgsqp_set_iterate_log.restype = C.c_int
+    lib.dgsqp_fetch_iterate_log.argtypes = [H, _PD, C.c_int64]
+    lib.dgsqp_fetch_iterate_log.restype = C.c_int
+    lib.dgsqp_synchronize.argtypes = [H]
+    lib.dgsqp_synchronize.restype = C.c_int
     _LIB = lib
     return lib
 
@@ -150,7 +156,8 @@ def load_library() -> C.CDLL:
 EXPORTED_SYMBOLS = ['dgsqp_create', 'dgsqp_destroy', 'dgsqp_dims', 'dgsqp_plan', 'dgsqp_last_error', 'dgsqp_backend_info',
                     'dgsqp_solve_batch', 'dgsqp_stage_inputs', 'dgsqp_solve_staged', 'dgsqp_fetch_results',
                     'dgsqp_evaluate_batch', 'dgsqp_qp_batch', 'dgsqp_set_trace', 'dgsqp_fetch_trace',
-                    'dgsqp_pid_warm_start_batch', 'dgsqp_launch_staged', 'dgsqp_wait', 'dgsqp_draining']
+                    'dgsqp_pid_warm_start_batch', 'dgsqp_launch_staged', 'dgsqp_wait', 'dgsqp_draining',
+                    'dgsqp_set_iterate_log', 'dgsqp_fetch_iterate_log', 'dgsqp_synchronize']
 
 
 def dptr(a):

@@ -9,6 +9,8 @@
 #include <chrono>
 #include <thread>
 #include <vector>
+#include <mutex>
+#include <algorithm>
 
 #include "dgsqp_solve.h"
 #include "dgsqp_xl.h"
@@ -22,9 +24,11 @@
 __global__ void __launch_bounds__(DG_BLOCK)
 dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__ x0, const double* __restrict__ u_ws,
                 SolveOutPtrs O, double* __restrict__ ws_all, unsigned long long* __restrict__ ticket,
-                double* __restrict__ trace, int trace_cap, unsigned int* __restrict__ drained) {
+                double* __restrict__ trace, int trace_cap, unsigned int* __restrict__ drained,
+                double* __restrict__ itlog, int itlog_cap) {
   Ctx c;
   c.trace_cap = trace_cap;
+  c.itlog_cap = itlog_cap;
   c.ws = (gptr)ws_all + (int64_t)blockIdx.x * dg_prob.ws_doubles;
 #ifdef DG_PROF
   const long long wg_t0 = clock64();
@@ -45,6 +49,7 @@ dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restric
     c.x0 = (cgptr)x0 + b * dg_prob.nq;
     c.trace = trace ? (gptr)trace + b * (int64_t)(1 + 2 * trace_cap) : nullptr;
     if (c.trace && TID == 0) c.trace[0] = 0.0;
+    c.itlog = itlog ? (gptr)itlog + b * (1 + (int64_t)itlog_cap * (dg_prob.n + dg_prob.nc)) : nullptr;
 #ifdef DG_PROF
     const long long sc_t0 = clock64();
 #endif
@@ -72,7 +77,7 @@ dg_evaluate_kernel(const DgProb* __restrict__ D, int64_t B, const double* __rest
                    double* __restrict__ ws_all) {
   Ctx c;
   c.ws = (gptr)ws_all + (int64_t)blockIdx.x * dg_prob.ws_doubles;
-  c.trace = nullptr; c.trace_cap = 0;
+  c.trace = nullptr; c.trace_cap = 0; c.itlog = nullptr; c.itlog_cap = 0;
   const DgLds& L = dg_prob.L;
   const int n = dg_prob.n, nc = dg_prob.nc;
   dev_load_tables();
@@ -109,7 +114,7 @@ dg_qp_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__
              const double* __restrict__ l, double* du, double* lhat, double* Qpd, int32_t* flag, double* __restrict__ ws_all) {
   Ctx c;
   c.ws = (gptr)ws_all + (int64_t)blockIdx.x * dg_prob.ws_doubles;
-  c.trace = nullptr; c.trace_cap = 0;
+  c.trace = nullptr; c.trace_cap = 0; c.itlog = nullptr; c.itlog_cap = 0;
   const DgLds& L = dg_prob.L;
   const int n = dg_prob.n, nc = dg_prob.nc;
   dev_load_tables();
@@ -160,7 +165,10 @@ struct dgsqp_solver {
   int64_t cap = 0, B = 0;
   double *d_x0 = nullptr, *d_uws = nullptr, *d_u = nullptr, *d_l = nullptr, *d_x = nullptr, *d_cond = nullptr, *d_cost = nullptr;
   int32_t *d_status = nullptr, *d_iters = nullptr, *d_qps = nullptr;
-  double* d_trace = nullptr; int trace_cap = 0; int64_t trace_B = 0;
+  double* d_trace = nullptr; int trace_cap = 0; int64_t trace_B = 0;    // trace_B: scenarios the buffer holds
+  int64_t trace_launch_B = 0;                                             // scenarios of the launch that filled it
+  double* d_itlog = nullptr; int itlog_cap = 0; int64_t itlog_B = 0, itlog_launch_B = 0;
+  bool in_flight = false;       // a solve launch has been enqueued and not yet waited for
   std::string err;
 };
 static thread_local std::string g_create_err;
@@ -206,9 +214,38 @@ static int ensure_ws(dgsqp_solver* h, size_t groups) {
   h->ws_groups = groups;
   return DGSQP_OK;
 }
-// The kernels read the game from the __constant__ symbol dg_prob; (re)upload it on the handle's stream before a launch.
+// The kernels read the game from the __constant__ symbol dg_prob, one per device and process.  Handles of DIFFERENT games
+// (or parameters) may coexist: the registry below remembers which description the symbol of each device holds and which
+// handles have a launch in flight.  A launch whose description differs from the resident one first waits for every launch
+// in flight on that device (they would otherwise read the new constants), then uploads its own; launches of the same
+// description skip the upload and overlap freely (bench.py --pipeline).
+namespace {
+std::mutex g_reg_mutex;
+struct DgResident { bool valid = false; std::vector<unsigned char> bytes; };
+DgResident g_resident[64];
+std::vector<dgsqp_solver*> g_handles;
+}  // namespace
+static int wait_idle(dgsqp_solver* h) {
+  if (h->in_flight) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->in_flight = false;
+  }
+  return DGSQP_OK;
+}
+// Call with g_reg_mutex held and keep it until the kernel that needs the constants has been enqueued and the handle is
+// marked in flight: from then on a launch of a different game waits for that kernel before it overwrites the symbol.
 static int upload_problem(dgsqp_solver* h) {
+  DgResident& r = g_resident[h->device & 63];
+  if (r.valid && r.bytes.size() == sizeof(DgProb) && memcmp(r.bytes.data(), &h->hp, sizeof(DgProb)) == 0) return DGSQP_OK;
+  for (dgsqp_solver* o : g_handles)
+    if (o->device == h->device && o->in_flight) {
+      if (hipStreamSynchronize(o->stream) != hipSuccess) { h->err = "hipStreamSynchronize of a launch in flight failed"; return DGSQP_E_DEVICE; }
+      // (o stays marked in flight: its owner still has to collect it with dgsqp_wait)
+    }
   HIPCHK(h, hipMemcpyToSymbolAsync(HIP_SYMBOL(dg_prob), &h->hp, sizeof(DgProb), 0, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  r.bytes.assign((const unsigned char*)&h->hp, (const unsigned char*)&h->hp + sizeof(DgProb));
+  r.valid = true;
   return DGSQP_OK;
 }
 static int grid_for(dgsqp_solver* h, int64_t B) {
@@ -224,6 +261,12 @@ struct TmpBuf {
   ~TmpBuf() { for (void* p : ptrs) (void)hipFree(p); }
   template <class T> T* alloc(size_t count) { void* p = nullptr; if (hipMalloc(&p, sizeof(T) * (count ? count : 1)) != hipSuccess) return nullptr; ptrs.push_back(p); return (T*)p; }
 };
+
+// one mapping from dg_build()'s message to the ABI's error code, shared by dgsqp_create and dgsqp_plan
+static int build_error_code(const std::string& msg) {
+  const bool too_large = msg.find("LDS") != std::string::npos || msg.find("too many") != std::string::npos || msg.find("not supported yet") != std::string::npos;
+  return too_large ? DGSQP_E_TOO_LARGE : DGSQP_E_ARG;
+}
 
 extern "C" {
 
@@ -245,9 +288,8 @@ int dgsqp_create(const dgsqp_problem_t* prob, const dgsqp_params_t* par, int dev
   std::string msg = dg_build(*prob, *par, h->hp);
   if (!msg.empty()) {
     g_create_err = msg;
-    const bool too_large = msg.find("LDS") != std::string::npos || msg.find("too many") != std::string::npos;
     delete h;
-    return too_large ? DGSQP_E_TOO_LARGE : DGSQP_E_ARG;
+    return build_error_code(msg);
   }
   auto fail = [&](const std::string& m) { g_create_err = m; dgsqp_destroy(h); return DGSQP_E_DEVICE; };
   int ndev = 0;
@@ -276,6 +318,7 @@ int dgsqp_create(const dgsqp_problem_t* prob, const dgsqp_params_t* par, int dev
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, dg_solve_kernel, DG_BLOCK, h->lds_bytes) != hipSuccess || occ < 1) occ = 1;
   h->wg_per_cu = occ;
   h->max_grid = h->num_cu * occ;
+  { std::lock_guard<std::mutex> lk(g_reg_mutex); g_handles.push_back(h); }
   *out = h;
   return DGSQP_OK;
 }
@@ -283,12 +326,15 @@ int dgsqp_create(const dgsqp_problem_t* prob, const dgsqp_params_t* par, int dev
 void dgsqp_destroy(dgsqp_handle_t h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
+  if (h->stream && h->in_flight) (void)hipStreamSynchronize(h->stream);
+  { std::lock_guard<std::mutex> lk(g_reg_mutex); g_handles.erase(std::remove(g_handles.begin(), g_handles.end(), h), g_handles.end()); }
   free_batch(h);
   if (h->ws) (void)hipFree(h->ws);
   if (h->dp) (void)hipFree(h->dp);
   if (h->ticket) (void)hipFree(h->ticket);
   if (h->drained_host) (void)hipHostFree(h->drained_host);
   if (h->d_trace) (void)hipFree(h->d_trace);
+  if (h->d_itlog) (void)hipFree(h->d_itlog);
   for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -312,7 +358,7 @@ int dgsqp_plan(const dgsqp_problem_t* prob, const dgsqp_params_t* par, dgsqp_dim
   out->M = D.M; out->N = D.N; out->n_q = D.nq; out->n_u = D.nu; out->n = D.n; out->n_c = D.nc;
   out->n_dense = D.ndense; out->lds_bytes = D.L.total * 8; out->workspace_bytes = D.ws_doubles * (int64_t)sizeof(double);
   out->layout = D.big;
-  if (!err.empty()) return err.find("LDS") != std::string::npos || err.find("not supported yet") != std::string::npos ? DGSQP_E_TOO_LARGE : DGSQP_E_ARG;
+  if (!err.empty()) return build_error_code(err);
   return DGSQP_OK;
 }
 
@@ -321,9 +367,11 @@ const char* dgsqp_last_error(dgsqp_handle_t h) { return h ? h->err.c_str() : g_c
 int dgsqp_stage_inputs(dgsqp_handle_t h, int64_t B, const double* x0, const double* u_ws) {
   if (!h || B < 0 || (B > 0 && (!x0 || !u_ws))) { if (h) h->err = "bad argument"; return DGSQP_E_ARG; }
   HIPCHK(h, hipSetDevice(h->device));
+  int rc = wait_idle(h);            // the buffers below belong to the launch in flight, if any
+  if (rc) return rc;
   h->B = B;
   if (B == 0) return DGSQP_OK;
-  int rc = ensure_batch(h, B);
+  rc = ensure_batch(h, B);
   if (rc) return rc;
   rc = ensure_ws(h, (size_t)grid_for(h, B));
   if (rc) return rc;
@@ -336,11 +384,14 @@ int dgsqp_stage_inputs(dgsqp_handle_t h, int64_t B, const double* x0, const doub
 int dgsqp_launch_staged(dgsqp_handle_t h) {
   if (!h) return DGSQP_E_ARG;
   HIPCHK(h, hipSetDevice(h->device));
+  { int rcw = wait_idle(h); if (rcw) return rcw; }     // one launch in flight per handle
   h->launched_grid = 0;
   if (h->B == 0) return DGSQP_OK;
   const int grid = grid_for(h, h->B);
   SolveOutPtrs O{h->d_u, h->d_l, h->d_x, h->d_cond, h->d_cost, h->d_status, h->d_iters, h->d_qps};
+  std::unique_lock<std::mutex> game_lock(g_reg_mutex);
   { int rcu = upload_problem(h); if (rcu) return rcu; }
+  h->in_flight = true;
   HIPCHK(h, hipMemsetAsync(h->ticket, 0, sizeof(unsigned long long), h->stream));
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
   double* trace = nullptr;
@@ -352,12 +403,26 @@ int dgsqp_launch_staged(dgsqp_handle_t h) {
       h->trace_B = h->B;
     }
     trace = h->d_trace;
+    h->trace_launch_B = h->B;
+  }
+  double* itlog = nullptr;
+  if (h->itlog_cap > 0) {
+    const size_t per = 1 + (size_t)h->itlog_cap * (h->hp.n + h->hp.nc);
+    if (h->itlog_B < h->B) {
+      if (h->d_itlog) (void)hipFree(h->d_itlog);
+      h->d_itlog = nullptr; h->itlog_B = 0;
+      HIPCHK(h, hipMalloc(&h->d_itlog, sizeof(double) * h->B * per));
+      h->itlog_B = h->B;
+    }
+    itlog = h->d_itlog;
+    h->itlog_launch_B = h->B;
   }
   *h->drained_host = 0u;
-  hipLaunchKernelGGL(dg_solve_kernel, dim3(grid), dim3(DG_BLOCK), h->lds_bytes, h->stream, h->dp, h->B, h->d_x0, h->d_uws, O, h->ws, h->ticket, trace, h->trace_cap, h->drained_dev);
+  hipLaunchKernelGGL(dg_solve_kernel, dim3(grid), dim3(DG_BLOCK), h->lds_bytes, h->stream, h->dp, h->B, h->d_x0, h->d_uws, O, h->ws, h->ticket, trace, h->trace_cap, h->drained_dev, itlog, h->itlog_cap);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
   h->launched_grid = grid;
+  h->in_flight = true;
   return DGSQP_OK;
 }
 
@@ -371,6 +436,7 @@ int dgsqp_wait(dgsqp_handle_t h, dgsqp_timing_t* tm) {
   HIPCHK(h, hipSetDevice(h->device));
   if (tm) memset(tm, 0, sizeof(*tm));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->in_flight = false;
   if (tm && h->launched_grid > 0) {
     float ms = 0;
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
@@ -401,6 +467,7 @@ int dgsqp_fetch_results(dgsqp_handle_t h, double* u_out, double* l_out, double* 
   if (cond) HIPCHK(h, hipMemcpyAsync(cond, h->d_cond, sizeof(double) * B * 3, hipMemcpyDeviceToHost, h->stream));
   if (cost) HIPCHK(h, hipMemcpyAsync(cost, h->d_cost, sizeof(double) * B * D.M, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->in_flight = false;
   return DGSQP_OK;
 }
 
@@ -456,16 +523,49 @@ int dgsqp_prof_read(unsigned long long* out, int n) {
 
 int dgsqp_set_trace(dgsqp_handle_t h, int pairs_per_scenario) {
   if (!h || pairs_per_scenario < 0) return DGSQP_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  { int rc = wait_idle(h); if (rc) return rc; }
   h->trace_cap = pairs_per_scenario;
-  h->trace_B = 0;
+  h->trace_B = h->trace_launch_B = 0;
   if (h->d_trace) { (void)hipFree(h->d_trace); h->d_trace = nullptr; }
   return DGSQP_OK;
 }
 
-int dgsqp_fetch_trace(dgsqp_handle_t h, double* out) {
-  if (!h || !out || h->trace_cap <= 0 || !h->d_trace) { if (h) h->err = "no trace recorded"; return DGSQP_E_ARG; }
+int dgsqp_fetch_trace(dgsqp_handle_t h, double* out, int64_t capacity_doubles) {
+  if (!h || !out || h->trace_cap <= 0 || !h->d_trace || h->trace_launch_B <= 0) { if (h) h->err = "no trace recorded"; return DGSQP_E_ARG; }
+  const int64_t need = h->trace_launch_B * (1 + 2 * (int64_t)h->trace_cap);
+  if (capacity_doubles < need) { h->err = "trace buffer too small: need " + std::to_string(need) + " doubles"; return DGSQP_E_ARG; }
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipMemcpy(out, h->d_trace, sizeof(double) * h->B * (1 + 2 * (size_t)h->trace_cap), hipMemcpyDeviceToHost));
+  { int rc = wait_idle(h); if (rc) return rc; }
+  HIPCHK(h, hipMemcpy(out, h->d_trace, sizeof(double) * need, hipMemcpyDeviceToHost));
+  return DGSQP_OK;
+}
+
+int dgsqp_set_iterate_log(dgsqp_handle_t h, int records_per_scenario) {
+  if (!h || records_per_scenario < 0) return DGSQP_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  { int rc = wait_idle(h); if (rc) return rc; }
+  h->itlog_cap = records_per_scenario;
+  h->itlog_B = h->itlog_launch_B = 0;
+  if (h->d_itlog) { (void)hipFree(h->d_itlog); h->d_itlog = nullptr; }
+  return DGSQP_OK;
+}
+
+int dgsqp_fetch_iterate_log(dgsqp_handle_t h, double* out, int64_t capacity_doubles) {
+  if (!h || !out || h->itlog_cap <= 0 || !h->d_itlog || h->itlog_launch_B <= 0) { if (h) h->err = "no iterate log recorded"; return DGSQP_E_ARG; }
+  const int64_t need = h->itlog_launch_B * (1 + (int64_t)h->itlog_cap * (h->hp.n + h->hp.nc));
+  if (capacity_doubles < need) { h->err = "iterate-log buffer too small: need " + std::to_string(need) + " doubles"; return DGSQP_E_ARG; }
+  HIPCHK(h, hipSetDevice(h->device));
+  { int rc = wait_idle(h); if (rc) return rc; }
+  HIPCHK(h, hipMemcpy(out, h->d_itlog, sizeof(double) * need, hipMemcpyDeviceToHost));
+  return DGSQP_OK;
+}
+
+int dgsqp_synchronize(dgsqp_handle_t h) {
+  if (!h) return DGSQP_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->in_flight = false;
   return DGSQP_OK;
 }
 
@@ -476,7 +576,9 @@ int dgsqp_evaluate_batch(dgsqp_handle_t h, int64_t B, const double* x0, const do
   HIPCHK(h, hipSetDevice(h->device));
   const DgProb& D = h->hp;
   const int grid = grid_for(h, B);
-  int rc = ensure_ws(h, (size_t)grid);
+  int rc = wait_idle(h);
+  if (rc) return rc;
+  rc = ensure_ws(h, (size_t)grid);
   if (rc) return rc;
   TmpBuf tb;
   const size_t n = D.n, nc = D.nc, nx = (size_t)(D.N + 1) * D.nq;
@@ -489,10 +591,13 @@ int dgsqp_evaluate_batch(dgsqp_handle_t h, int64_t B, const double* x0, const do
   HIPCHK(h, hipMemcpy(dx0, x0, sizeof(double) * B * D.nq, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(du, u, sizeof(double) * B * n, hipMemcpyHostToDevice));
   if (l) HIPCHK(h, hipMemcpy(dl, l, sizeof(double) * B * nc, hipMemcpyHostToDevice));
+  std::unique_lock<std::mutex> game_lock(g_reg_mutex);
   { int rcu = upload_problem(h); if (rcu) return rcu; }
+  h->in_flight = true;
   hipLaunchKernelGGL(dg_evaluate_kernel, dim3(grid), dim3(DG_BLOCK), h->lds_bytes, h->stream, h->dp, B, dx0, du, dl, dq, dg, dG, dQ, dx, dl0, h->ws);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->in_flight = false;
   if (q) HIPCHK(h, hipMemcpy(q, dq, sizeof(double) * B * n, hipMemcpyDeviceToHost));
   if (g) HIPCHK(h, hipMemcpy(g, dg, sizeof(double) * B * nc, hipMemcpyDeviceToHost));
   if (G) HIPCHK(h, hipMemcpy(G, dG, sizeof(double) * B * nc * n, hipMemcpyDeviceToHost));
@@ -517,7 +622,9 @@ int dgsqp_pid_warm_start_batch(dgsqp_handle_t h, int64_t B, const double* q0, co
   int32_t* dc = collide ? tb.alloc<int32_t>(B) : nullptr;
   if (!dq0 || !du || ((q_ws || collide) && !dq) || (collide && !dc)) { h->err = "hipMalloc failed"; return DGSQP_E_NOMEM; }
   HIPCHK(h, hipMemcpy(dq0, q0, sizeof(double) * B * D.nq, hipMemcpyHostToDevice));
+  std::unique_lock<std::mutex> game_lock(g_reg_mutex);
   { int rcu = upload_problem(h); if (rcu) return rcu; }
+  h->in_flight = true;
   const int64_t lanes = B * D.M;
   int grid = (int)((lanes + DG_BLOCK - 1) / DG_BLOCK);
   if (grid > 4 * h->num_cu) grid = 4 * h->num_cu;
@@ -528,6 +635,7 @@ int dgsqp_pid_warm_start_batch(dgsqp_handle_t h, int64_t B, const double* q0, co
     HIPCHK(h, hipGetLastError());
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->in_flight = false;
   HIPCHK(h, hipMemcpy(u_ws, du, sizeof(double) * B * D.n, hipMemcpyDeviceToHost));
   if (q_ws) HIPCHK(h, hipMemcpy(q_ws, dq, sizeof(double) * B * nx, hipMemcpyDeviceToHost));
   if (collide) HIPCHK(h, hipMemcpy(collide, dc, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
@@ -541,7 +649,9 @@ int dgsqp_qp_batch(dgsqp_handle_t h, int64_t B, const double* x0, const double* 
   HIPCHK(h, hipSetDevice(h->device));
   const DgProb& D = h->hp;
   const int grid = grid_for(h, B);
-  int rc = ensure_ws(h, (size_t)grid);
+  int rc = wait_idle(h);
+  if (rc) return rc;
+  rc = ensure_ws(h, (size_t)grid);
   if (rc) return rc;
   TmpBuf tb;
   const size_t n = D.n, nc = D.nc;
@@ -552,10 +662,13 @@ int dgsqp_qp_batch(dgsqp_handle_t h, int64_t B, const double* x0, const double* 
   HIPCHK(h, hipMemcpy(dx0, x0, sizeof(double) * B * D.nq, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(du, u, sizeof(double) * B * n, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(dl, l, sizeof(double) * B * nc, hipMemcpyHostToDevice));
+  std::unique_lock<std::mutex> game_lock(g_reg_mutex);
   { int rcu = upload_problem(h); if (rcu) return rcu; }
+  h->in_flight = true;
   hipLaunchKernelGGL(dg_qp_kernel, dim3(grid), dim3(DG_BLOCK), h->lds_bytes, h->stream, h->dp, B, dx0, du, dl, ddu, dlh, dQ, df, h->ws);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->in_flight = false;
   if (du_out) HIPCHK(h, hipMemcpy(du_out, ddu, sizeof(double) * B * n, hipMemcpyDeviceToHost));
   if (lhat) HIPCHK(h, hipMemcpy(lhat, dlh, sizeof(double) * B * nc, hipMemcpyDeviceToHost));
   if (Qpd) HIPCHK(h, hipMemcpy(Qpd, dQ, sizeof(double) * B * n * n, hipMemcpyDeviceToHost));

@@ -86,12 +86,15 @@ struct Ctx {
   cgptr x0;
   gptr trace;   // optional per-scenario event log: [0] = number of (code, value) pairs, then the pairs
   int trace_cap;   // capacity in pairs
+  gptr itlog;   // optional per-scenario iterate log: [0] = number of records, then records of (n + n_c) doubles (u, l):
+  int itlog_cap;   // record 0 = (u_ws, dual start), record i = iterates after SQP iteration i (iter_data u_sol / l_sol, DGSQP.py:386-451)
 };
 // event log compared event-by-event with the oracle's (tests/test_gpu.py::test_event_trace_parity)
 __device__ inline void dev_tr(const Ctx& c, int code, double v) {
   if (c.trace && threadIdx.x == 0) {
     const int p = (int)c.trace[0];
-    if (p < c.trace_cap) { c.trace[1 + 2 * p] = (double)code; c.trace[2 + 2 * p] = v; c.trace[0] = (double)(p + 1); }
+    if (p < c.trace_cap) { c.trace[1 + 2 * p] = (double)code; c.trace[2 + 2 * p] = v; }
+    c.trace[0] = (double)(p + 1);        // keeps counting past the capacity: the host sees count > capacity = truncated log
   }
 }
 

@@ -1093,6 +1093,33 @@ __device__ inline void dev_take_full_step(const Ctx& c) {  // u += du ; l = lhat
 
 // _watchdog_line_search_4 (DGSQP.py:1174-1288; branch order of SURVEY.md A.7).  Base point and step
 // (u_k, du_k, l_k, lhat_k) are in LDS on entry; returns the number of extra QP solves.
+// One reading of the 100 MHz constant-rate counter for the whole workgroup (thread 0 reads, everybody gets the same value),
+// so that wall-clock decisions (time_limit, DGSQP.py:470 and :1243-1247) are uniform across the 8 wavefronts of a scenario.
+#define DG_CLOCK 56
+__device__ inline double dev_block_clock() {
+  lptr sc = LP(dg_prob.L.scal);
+  __syncthreads();
+  if (TID == 0) sc[DG_CLOCK] = (double)wall_clock64();
+  __syncthreads();
+  return sc[DG_CLOCK];
+}
+// iterate log (solve(): iter_data u_sol / l_sol)
+__device__ inline void dev_log_iterate(const Ctx& c) {
+  if (!c.itlog) return;
+  const DgProb& D = dg_prob;
+  const int rec = (int)c.itlog[0];
+  __syncthreads();
+  if (rec < c.itlog_cap) {
+    gptr o = c.itlog + 1 + (int64_t)rec * (D.n + D.nc);
+    for (int i = TID; i < D.n; i += NT) o[i] = LP(D.L.u)[i];
+    for (int r = TID; r < D.nc; r += NT) o[D.n + r] = LP(D.L.l)[r];
+  }
+  __syncthreads();
+  if (TID == 0) c.itlog[0] = (double)(rec + 1);
+  __threadfence_block();
+  __syncthreads();
+}
+
 __device__ inline int dev_watchdog(const Ctx& c, double mu, const LinScal& Sk) {
   const DgProb& D = dg_prob;
   const DgLds& L = D.L;
@@ -1110,6 +1137,8 @@ __device__ inline int dev_watchdog(const Ctx& c, double mu, const LinScal& Sk) {
   bool fail = false;
   LinScal S;
   double phi_n = 0;
+  const bool timed = D.par.time_limit >= 0.0;
+  const double wd_start = timed ? dev_block_clock() : 0.0;     // start_time (DGSQP.py:1205)
   for (int t = 0; t < 5; t++) {
     const int flag = dev_linearize_and_qp(c, true, nullptr, nullptr);
     nqp++;
@@ -1121,6 +1150,7 @@ __device__ inline int dev_watchdog(const Ctx& c, double mu, const LinScal& Sk) {
     if (phi_n > 1e6) break;                                   // merit_max; (u_t, l_t) not advanced
     if (phi_n <= phi_k + beta * dphi_k) { dev_take_full_step(c); return nqp; }
     dev_take_full_step(c);
+    if (timed && (dev_block_clock() - wd_start) * 1e-8 > D.par.time_limit) { fail = true; break; }   // DGSQP.py:1243-1247
   }
   // insist on merit decrease
   {
@@ -1226,11 +1256,14 @@ __device__ inline void dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
   for (int i = TID; i < n; i += NT) lds[L.u + i] = u_ws[i];
   for (int r = TID; r < nc; r += NT) lds[L.l + r] = 0.0;
   __syncthreads();
+  const bool timed = D.par.time_limit >= 0.0;              // < 0: no limit (DGSQPParams.time_limit = None -> inf, DGSQP.py:64-67)
+  const double t_start = timed ? dev_block_clock() : 0.0;  // solve_start (DGSQP.py:304): before the dual start
   // dual warm start
   dev_evaluate(c, lds + L.u, 0.0, nullptr, false);
   dev_dual_init(c);
+  if (c.itlog && TID == 0) c.itlog[0] = 0.0;
+  dev_log_iterate(c);                                      // record 0: (u_ws, dual start) = solve_info['init']
   int sqp_it = 0, rel_tol_its = 0, status = DGSQP_MAX_IT, total_qp = 0;
-  const unsigned long long t_start = wall_clock64();      // 100 MHz constant-rate counter (time_limit, DGSQP.py:470)
   double cond[3] = {0, 0, 0};
   const bool l1 = D.par.merit_function == DGSQP_MERIT_STAT_L1;
   while (true) {
@@ -1255,15 +1288,15 @@ __device__ inline void dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
     }
     dev_tr(c, 1, cond[2]); dev_tr(c, 2, cond[0]); dev_tr(c, 3, cond[1]);
     const int qp_before = total_qp;      // trace code 40: QP solves of this iteration, at the reference's iter_data records (:386-451)
-    if (cond[2] > 1e5) { dev_tr(c, 40, 0.0); status = DGSQP_DIVERGED; break; }
-    if (cond[0] < D.par.p_tol && cond[1] < D.par.d_tol && cond[2] < D.par.d_tol) { dev_tr(c, 40, 0.0); status = DGSQP_CONV_ABS_TOL; break; }
+    if (cond[2] > 1e5) { dev_tr(c, 40, 0.0); dev_log_iterate(c); status = DGSQP_DIVERGED; break; }
+    if (cond[0] < D.par.p_tol && cond[1] < D.par.d_tol && cond[2] < D.par.d_tol) { dev_tr(c, 40, 0.0); dev_log_iterate(c); status = DGSQP_CONV_ABS_TOL; break; }
     dev_qt_mul(c);
     int flag;
     if (D.big == 2) { dev_xl_psd(c, nullptr); flag = dev_xl_qp(c); }   // n > 128: dgsqp_xl.h
     else if (D.classic_qp) { dev_psd_inverse(c, c.ws + D.ws_xM); flag = dev_xl_qp(c); }
     else { dev_psd_inverse(c, nullptr); flag = dev_qp(c); }
     total_qp++;
-    if (flag != 0) { dev_tr(c, 40, 1.0); status = DGSQP_QP_FAIL; break; }
+    if (flag != 0) { dev_tr(c, 40, 1.0); dev_log_iterate(c); status = DGSQP_QP_FAIL; break; }
     LinScal S;
     dev_step_scalars(c, S);
     // _get_mu (DGSQP.py:559-585)
@@ -1287,13 +1320,14 @@ __device__ inline void dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
     du2 = block_sum(du2, lds + L.red);
     dl2 = block_sum(dl2, lds + L.red);
     dev_tr(c, 40, (double)(total_qp - qp_before));
+    dev_log_iterate(c);
     if (sqrt(du2) < D.par.p_tol / 2 && sqrt(dl2) < D.par.d_tol / 2) {
       rel_tol_its++;
       if (rel_tol_its >= D.par.rel_tol_req && cond[0] < D.par.p_tol) { status = DGSQP_CONV_REL_TOL; break; }
     } else rel_tol_its = 0;
     sqp_it++;
     if (sqp_it >= D.par.sqp_iters) { status = DGSQP_MAX_IT; break; }
-    if (D.par.time_limit > 0.0 && (double)(wall_clock64() - t_start) * 1e-8 > D.par.time_limit) { status = DGSQP_TIME_LIMIT; break; }
+    if (timed && (dev_block_clock() - t_start) * 1e-8 > D.par.time_limit) { status = DGSQP_TIME_LIMIT; break; }   // block-uniform
   }
   // outputs: q_pred = evaluate_dynamics(u, x0) (DGSQP.py:476), cost = f_J (:492)
   __syncthreads();

@@ -165,7 +165,7 @@ def build_params(params: DGSQPParams, eig_floor: Optional[float] = None, snap_ac
     p.lsqr_atol = p.lsqr_btol = 1e-6 if lsqr_tol is None else float(lsqr_tol)      # scipy >= 1.12 defaults of sparse.linalg.lsqr
     p.qp_warm_start = int(bool(qp_warm_start))      # start each QP's active-set search from the previous QP's active set (same minimiser)
     p.hessian_bfgs = 1 if params.hessian_approximation == 'bfgs' else 0
-    p.time_limit = 0.0 if params.time_limit is None else float(params.time_limit)
+    p.time_limit = -1.0 if params.time_limit is None else float(params.time_limit)     # None -> no limit (DGSQP.py:64-67)
     p.eig_floor = 1e-10 if eig_floor is None else float(eig_floor)
     p.snap_active_bounds = int(bool(snap_active_bounds))
     return p
@@ -332,13 +332,36 @@ class DGSQP(AbstractSolver):
         self._lib.dgsqp_set_trace(self._h, self._trace_cap)
 
     def fetch_trace(self, B: int):
-        """List of [(code, value)] arrays, one per scenario of the last solve_batch."""
+        """List of [(code, value)] arrays, one per scenario of the last solve_batch (``B`` = its batch size)."""
         cap = getattr(self, '_trace_cap', 0)
         raw = np.zeros((B, 1 + 2 * cap))
-        rc = self._lib.dgsqp_fetch_trace(self._h, _ffi.dptr(raw))
+        rc = self._lib.dgsqp_fetch_trace(self._h, _ffi.dptr(raw), raw.size)
         if rc != 0:
             raise RuntimeError(self._lib.dgsqp_last_error(self._h).decode())
+        if (raw[:, 0] > cap).any():
+            raise RuntimeError(f'event log truncated: {int(raw[:, 0].max())} events, capacity {cap} (set_trace with a larger value)')
         return [raw[b, 1:1 + 2 * int(raw[b, 0])].reshape(-1, 2) for b in range(B)]
+
+    def set_iterate_log(self, records_per_scenario: int):
+        """Keep (u, l) after every SQP iteration of subsequent solves (what ``solve()`` reports in ``iter_data``); 0 disables."""
+        self._itlog_cap = int(records_per_scenario)
+        if self._lib.dgsqp_set_iterate_log(self._h, self._itlog_cap) != 0:
+            raise RuntimeError(self._lib.dgsqp_last_error(self._h).decode())
+
+    def fetch_iterate_log(self, B: int):
+        """Per scenario of the last solve_batch: (u [records, n] agent-major, l [records, n_c]); record 0 is the start (u_ws, l0)."""
+        cap = getattr(self, '_itlog_cap', 0)
+        w = self.n + self.n_c_total
+        raw = np.zeros((B, 1 + cap * w))
+        rc = self._lib.dgsqp_fetch_iterate_log(self._h, _ffi.dptr(raw), raw.size)
+        if rc != 0:
+            raise RuntimeError(self._lib.dgsqp_last_error(self._h).decode())
+        out = []
+        for b in range(B):
+            k = min(int(raw[b, 0]), cap)
+            rec = raw[b, 1:1 + k * w].reshape(k, w)
+            out.append((rec[:, :self.n].copy(), rec[:, self.n:].copy()))
+        return out
 
     # ---- test hooks ----------------------------------------------------------------------------
     def evaluate_batch(self, x0, u, l=None):
@@ -406,14 +429,18 @@ class DGSQP(AbstractSolver):
         u_init = copy.copy(self.u_ws)
         self.print_method(self.solver_name)
         want_iters = bool(self.save_iter_data)
-        if want_iters:
-            self.set_trace(64 * (int(self._cparams.sqp_iters) + 2) + 64 * int(self._cparams.line_search_iters))
+        iters = int(self._cparams.sqp_iters)
+        if want_iters:       # worst case per iteration: 3 + 4 + 1 events, 7 watchdog QPs, 3 line searches of line_search_iters trials
+            self.set_trace((iters + 1) * (16 + 6 * int(self._cparams.line_search_iters)))
+        self.set_iterate_log(iters + 2)
         try:
             res = self.solve_batch(x0[None, :], u_init[None, :])
             events = self.fetch_trace(1)[0] if want_iters else None
+            u_log, l_log = self.fetch_iterate_log(1)[0]
         finally:
             if want_iters:
                 self.set_trace(0)
+            self.set_iterate_log(0)
         self.q_pred = res['x'][0]
         self.u_pred = res['u_pred'][0]
         self.l_pred = res['l'][0]
@@ -425,8 +452,8 @@ class DGSQP(AbstractSolver):
         self.print_method(f'Solve time: {solve_dur:.2f}')
         self.print_method(str(res['cost'][0]))
         # iter_data (DGSQP.py:386-451): one record per SQP iteration with the optimality measures at its start and its QP
-        # solves, rebuilt from the kernel's event log (codes 1-3 and 40); the iterates of the intermediate iterations are
-        # not kept on the device, the last record carries the final ones.
+        # solves, rebuilt from the kernel's event log (codes 1-3 and 40), and the iterates (u_sol, l_sol) the iteration
+        # ended with, from the kernel's iterate log.
         iter_data = []
         if want_iters:
             cur = None
@@ -445,11 +472,12 @@ class DGSQP(AbstractSolver):
             n_it = max(len(iter_data), 1)
             for d in iter_data:
                 d['it_time'] = solve_dur / n_it
-            if iter_data:
-                iter_data[-1]['u_sol'], iter_data[-1]['l_sol'] = res['u'][0], res['l'][0]
+            for i, d in enumerate(iter_data):
+                if i + 1 < len(u_log):
+                    d['u_sol'], d['l_sol'] = u_log[i + 1], l_log[i + 1]
         return dict(time=solve_dur, num_iters=int(res['num_iters'][0]), status=bool(res['converged'][0]),
                     cost=[float(c) for c in res['cost'][0]], cond=cond, iter_data=iter_data, msg=msg,
-                    init=dict(u=u_init, l=None))
+                    init=dict(u=u_log[0] if len(u_log) else None, l=l_log[0] if len(l_log) else None))
 
     def step(self, states: List[VehicleState], parameters: np.ndarray = np.array([])):
         info = self.solve(states, parameters)

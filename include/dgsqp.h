@@ -157,8 +157,10 @@ typedef struct {
                              a larger floor (e.g. 1e-6) is an explicit opt-in that keeps such games on the faster
                              explicit-inverse kernels. */
   double time_limit;      /* DGSQPParams.time_limit: wall-clock seconds per solve() after which the scenario ends with DGSQP_TIME_LIMIT
-                             (checked at the end of every SQP iteration, DGSQP.py:470); <= 0: none.  Counted from the moment a
-                             workgroup starts the scenario, not from the launch of the batch. */
+                             (checked at the end of every SQP iteration, DGSQP.py:470, and inside the watchdog's relaxed steps,
+                             :1243-1247); < 0: none (the reference's None -> inf, DGSQP.py:64-67); 0 ends the solve after its
+                             first iteration, as in the reference.  Counted from the moment a workgroup starts the scenario
+                             (before the dual start, DGSQP.py:304), not from the launch of the batch. */
   int32_t snap_active_bounds; /* implementation knob, default 0 = literal.  1: after each QP put du exactly on the input bounds
                              whose multiplier is positive.  An exact QP solver leaves them at +-1 ulp, OSQP's polish at ~1e-12
                              (sign random); the rows are linear, the next iterate inherits that residual and _get_mu switches
@@ -234,8 +236,10 @@ int dgsqp_solve_batch(dgsqp_handle_t h, int64_t B, const double* x0, const doubl
 int dgsqp_stage_inputs(dgsqp_handle_t h, int64_t B, const double* x0, const double* u_ws);
 int dgsqp_solve_staged(dgsqp_handle_t h, dgsqp_timing_t* timing);
 /* Asynchronous halves of dgsqp_solve_staged(): enqueue the solve on the handle's own stream / wait for it.  Independent
-   batches held by different handles of the SAME game can be in flight together: the workgroups of the later launch take
-   over the compute units as the earlier launch drains its slowest scenarios. */
+   batches held by different handles of the SAME game (same dgsqp_problem_t and dgsqp_params_t) can be in flight together:
+   the workgroups of the later launch take over the compute units as the earlier launch drains its slowest scenarios.
+   Handles of DIFFERENT games are safe too, but serialised: such a launch first waits for the launches in flight on the
+   device (the kernels read the game from one per-device constant block). */
 int dgsqp_launch_staged(dgsqp_handle_t h);
 int dgsqp_wait(dgsqp_handle_t h, dgsqp_timing_t* timing);
 /* 1 once the handle's last launch has handed out its last scenario (it only drains from then on, compute units are
@@ -279,7 +283,18 @@ int dgsqp_pid_warm_start_batch(dgsqp_handle_t h, int64_t B, const double* q0, co
  * oracle's log.  Layout per scenario: [count, (code, value) x pairs_per_scenario].  0 disables.
  */
 int dgsqp_set_trace(dgsqp_handle_t h, int pairs_per_scenario);
-int dgsqp_fetch_trace(dgsqp_handle_t h, double* out);
+/* out: [B_launch][1 + 2 * pairs_per_scenario] of the last launch; capacity_doubles = what out can hold (DGSQP_E_ARG when it
+   is too small).  A count above pairs_per_scenario means that scenario's log was truncated. */
+int dgsqp_fetch_trace(dgsqp_handle_t h, double* out, int64_t capacity_doubles);
+
+/* Iterate log for solve()'s iter_data / init (DGSQP.py:328, :386-451): per scenario [count, records x (n + n_c)], record 0 =
+   (u_ws, dual start l), record i = (u, l) at the end of SQP iteration i (or at the exit test that ended the solve).
+   0 disables (default: Monte-Carlo batches only keep the final iterates). */
+int dgsqp_set_iterate_log(dgsqp_handle_t h, int records_per_scenario);
+int dgsqp_fetch_iterate_log(dgsqp_handle_t h, double* out, int64_t capacity_doubles);
+
+/* Wait for everything enqueued on the handle's stream (what a caller without a HIP runtime of its own uses as a fence). */
+int dgsqp_synchronize(dgsqp_handle_t h);
 
 #ifdef __cplusplus
 }

@@ -1111,6 +1111,7 @@ static void watchdog_4(const Ctx& c, double mu, const vec& u_k, const vec& du_k,
   vec u_t = u1, l_t = l1, du, lhat, dl, s, ds, u_n, l_n;
   double phi_n = 0;
   Lin lt;
+  const auto wd_start = std::chrono::steady_clock::now();    // start_time (:1205)
   for (int t = 0; t < t_hat; t++) {
     eval_lin(c, u_t, l_t, true, lt);
     bool ok = solve_qp(c, lt, du, lhat);
@@ -1124,6 +1125,7 @@ static void watchdog_4(const Ctx& c, double mu, const vec& u_k, const vec& du_k,
     if (phi_n > merit_max) break;
     if (phi_n <= phi_k + c.par.beta * dphi_k) { u_out = u_n; l_out = l_n; return; }
     u_t = u_n; l_t = l_n;
+    if (c.par.time_limit >= 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - wd_start).count() > c.par.time_limit) { fail = true; break; }   // :1243-1247
   }
   // insist on merit decrease (:1250-1259)
   eval_lin(c, u_t, l_t, true, lt);
@@ -1168,6 +1170,7 @@ struct SolveOut {
 };
 static void solve_one(const dgsqp_problem_t& P, const dgsqp_params_t& par, const Layout& L, const double* x0, const double* u_ws, int literal, SolveOut& out, vec* trace = nullptr) {
   Ctx c{P, par, L, x0, literal, trace};
+  const auto t_start = std::chrono::steady_clock::now();     // solve_start (DGSQP.py:304)
   vec u(u_ws, u_ws + L.n), l;
   {
     Eval ev;
@@ -1177,7 +1180,6 @@ static void solve_one(const dgsqp_problem_t& P, const dgsqp_params_t& par, const
   }
   out.l_init = l;
   int rel_tol_its = 0, sqp_it = 0, status = DGSQP_MAX_IT, total_qp = 0;
-  const auto t_start = std::chrono::steady_clock::now();
   double p_feas = 0, comp = 0, stat = 0;
   vec u_im1, Q_prev;
   while (true) {
@@ -1251,7 +1253,7 @@ static void solve_one(const dgsqp_problem_t& P, const dgsqp_params_t& par, const
     } else rel_tol_its = 0;
     sqp_it++;
     if (sqp_it >= par.sqp_iters) { status = DGSQP_MAX_IT; break; }
-    if (par.time_limit > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > par.time_limit) { status = DGSQP_TIME_LIMIT; break; }   // :470
+    if (par.time_limit >= 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > par.time_limit) { status = DGSQP_TIME_LIMIT; break; }   // :470 (< 0: None -> inf, :64-67)
   }
   out.u = u; out.l = l;
   rollout(P, L, u.data(), x0, out.x);

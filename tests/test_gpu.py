@@ -107,7 +107,7 @@ def test_solve_matches_golden_fixtures(solvers, name):
         assert rel(res['u'][b], gold['u'][b]) < (1e-2 if reg0 else 1e-5), b
         if gold['status'][b] == 0:
             assert rel(res['l'][b], gold['l'][b]) < (1e-2 if reg0 else 1e-5), b
-            assert rel(res['cost'][b], gold['cost'][b]) < (1e-5 if reg0 else 1e-8), b
+            assert rel(res['cost'][b], gold['cost'][b]) < (1e-3 if reg0 else 1e-8), b
 
 
 def test_baseline_config1_dyn_curve_N25_parity(solvers):
@@ -507,7 +507,7 @@ def test_reg0_games_track_the_oracle(oracle, kind, opts):
         du, lam, flag = oracle.qp(Qpd, o['q'], o['G'], o['g'])
         obj = lambda z: 0.5 * z @ Qpd @ z + o['q'] @ z
         assert qp['flag'][b] == flag == 0 and (o['G'] @ qp['du'][b] + o['g']).max() < 1e-4
-        assert abs(obj(qp['du'][b]) - obj(du)) < 1e-4 * max(1.0, abs(obj(du)))
+        assert abs(obj(qp['du'][b]) - obj(du)) < (1e-3 if literal else 1e-6) * max(1.0, abs(obj(du)))
     res = s.solve_batch(x0, u_tm)
     ref = oracle.solve_batch(P, par, x0, u, nthreads=8)
     same = assert_control_flow_parity(res, ref, stable_mask(oracle, P, par, x0, u, ref), f'{kind} {opts}',
@@ -663,6 +663,52 @@ def test_time_limit_status(oracle, games):
     assert np.array_equal(res['status'], ref['status']) and np.array_equal(res['num_iters'], ref['num_iters'])
     assert set(res['status']) <= {0, 4, 5} and (res['status'] == 5).sum() >= 10 and (res['num_iters'][res['status'] == 5] == 1).all()
     assert res['msg'][int(np.argmax(res['status'] == 5))] == 'time_limit'
+    # time_limit = 0 is a limit (the reference times out after its first iteration), None is none
+    g.params.time_limit = 0.0
+    r0 = DGSQP(*g.solver_args(), print_method=None).solve_batch(x0, u_tm)
+    assert np.array_equal(r0['status'], res['status'])
+    # a limit of about one SQP iteration: scenarios cross it in the middle of their run, at different iterations.  The decision
+    # is taken once per workgroup (one clock reading shared through LDS); every scenario must end in a valid state, the ones
+    # that finish in time exactly as without a limit, and the kernel must come back.
+    g.params.time_limit = None
+    free = DGSQP(*g.solver_args(), print_method=None).solve_batch(x0, u_tm)
+    x0b, u_b = sample_scenarios(g, 600, seed=4)
+    free_b = DGSQP(*g.solver_args(), print_method=None).solve_batch(x0b, u_b)
+    for lim in (2e-4, 1e-3, 4e-3):
+        g.params.time_limit = lim
+        rl = DGSQP(*g.solver_args(), print_method=None).solve_batch(x0b, u_b)
+        timed_out = rl['status'] == 5
+        assert set(rl['status']) <= {0, 1, 2, 3, 4, 5}
+        assert (rl['num_iters'][timed_out] >= 1).all() and (rl['num_iters'][timed_out] <= free_b['num_iters'][timed_out] + 0).all()
+        fin = ~timed_out
+        assert np.array_equal(rl['status'][fin], free_b['status'][fin]) and np.array_equal(rl['num_iters'][fin], free_b['num_iters'][fin])
+        assert np.array_equal(rl['u'][fin], free_b['u'][fin])
+    assert np.array_equal(free['status'] == 5, np.zeros(12, bool))
+
+
+def test_handles_of_different_games_do_not_mix_constants(games):
+    """The kernels read the game from one per-device constant block: a launch of a different game waits for the launches in
+    flight instead of overwriting their constants.  Two different games launched back to back (asynchronously) give exactly
+    the results of separate solves."""
+    import ctypes as C
+    from dgsqp_amd import _ffi
+    from dgsqp_amd.montecarlo import sample_scenarios
+    from dgsqp_amd.solver import DGSQP
+    ga, gb = games['kb_chicane_N15'][0], games['kb_curve_N10'][0]
+    sa, sb = DGSQP(*ga.solver_args(), print_method=None), DGSQP(*gb.solver_args(), print_method=None)
+    xa, ua = sample_scenarios(ga, 700, seed=21)
+    xb, ub = sample_scenarios(gb, 700, seed=22)
+    ref_a, ref_b = sa.solve_batch(xa, ua), sb.solve_batch(xb, ub)
+    lib = sa._lib
+    for s_, x_, u_ in ((sa, xa, ua), (sb, xb, ub)):
+        assert lib.dgsqp_stage_inputs(s_._h, x_.shape[0], _ffi.dptr(np.ascontiguousarray(x_)), _ffi.dptr(np.ascontiguousarray(s_._to_agent_major(u_)))) == 0
+    assert lib.dgsqp_launch_staged(sa._h) == 0 and lib.dgsqp_launch_staged(sb._h) == 0
+    assert lib.dgsqp_wait(sb._h, None) == 0 and lib.dgsqp_wait(sa._h, None) == 0
+    for s_, ref in ((sa, ref_a), (sb, ref_b)):
+        B = ref['u'].shape[0]
+        u = np.empty((B, s_.n)); st = np.empty(B, np.int32); it = np.empty(B, np.int32)
+        assert lib.dgsqp_fetch_results(s_._h, _ffi.dptr(u), None, None, _ffi.iptr(st), _ffi.iptr(it), None, None, None) == 0
+        assert np.array_equal(st, ref['status']) and np.array_equal(it, ref['num_iters']) and np.array_equal(u, ref['u'])
 
 
 def test_solve_iter_data_records(games, oracle):
@@ -683,8 +729,19 @@ def test_solve_iter_data_records(games, oracle):
         assert info['num_iters'] == int(batch['num_iters'][0]) and info['msg'] == batch['msg'][0]
         assert sum(r['qp_solves'] for r in recs) == int(batch['qp_solves'][0])
         assert len(recs) == info['num_iters'] + (1 if info['msg'] in ('conv_abs_tol', 'diverged', 'qp_fail') else 0)
-        assert recs[-1]['cond'] == pytest.approx(info['cond']) and recs[-1]['u_sol'] is not None
+        assert recs[-1]['cond'] == pytest.approx(info['cond'])
         assert all(set(r['cond']) == {'stat', 'p_feas', 'comp'} for r in recs)
+        # per-iteration iterates (u_sol, l_sol of DGSQP.py:386,451) and the start (init, :328): the last record carries the final
+        # iterates, record i the point whose optimality measures record i + 1 reports, init the warm start and the LSQR duals
+        assert all(r['u_sol'] is not None and r['l_sol'] is not None for r in recs)
+        assert np.array_equal(recs[-1]['u_sol'], batch['u'][0]) and np.array_equal(recs[-1]['l_sol'], batch['l'][0])
+        assert np.array_equal(info['init']['u'], s._to_agent_major(u_tm[b:b + 1])[0])
+        l0 = oracle.dual_init(P, par, x0[b], info['init']['u'])
+        assert np.abs(info['init']['l'] - l0).max() < 1e-3
+        if len(recs) >= 2:
+            ev = oracle.evaluate(P, x0[b], recs[0]['u_sol'], recs[0]['l_sol'], 0)
+            d = ev['q'] + ev['G'].T @ recs[0]['l_sol']
+            assert np.abs(d).max() == pytest.approx(recs[1]['cond']['stat'], rel=1e-6)
 
 
 def test_large_batch_equals_small_batches(games):
