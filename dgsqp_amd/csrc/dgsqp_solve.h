@@ -1103,20 +1103,21 @@ __device__ inline double dev_block_clock() {
   __syncthreads();
   return sc[DG_CLOCK];
 }
-// iterate log (solve(): iter_data u_sol / l_sol)
+// iterate log (solve(): iter_data u_sol / l_sol); the record counter lives in an LDS scalar slot (uniform for the workgroup)
+#define DG_ITREC 55
 __device__ inline void dev_log_iterate(const Ctx& c) {
   if (!c.itlog) return;
   const DgProb& D = dg_prob;
-  const int rec = (int)c.itlog[0];
+  lptr sc = LP(D.L.scal);
   __syncthreads();
+  const int rec = (int)sc[DG_ITREC];
   if (rec < c.itlog_cap) {
     gptr o = c.itlog + 1 + (int64_t)rec * (D.n + D.nc);
     for (int i = TID; i < D.n; i += NT) o[i] = LP(D.L.u)[i];
     for (int r = TID; r < D.nc; r += NT) o[D.n + r] = LP(D.L.l)[r];
   }
   __syncthreads();
-  if (TID == 0) c.itlog[0] = (double)(rec + 1);
-  __threadfence_block();
+  if (TID == 0) { sc[DG_ITREC] = (double)(rec + 1); c.itlog[0] = (double)(rec + 1); }
   __syncthreads();
 }
 
@@ -1261,7 +1262,7 @@ __device__ inline void dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
   // dual warm start
   dev_evaluate(c, lds + L.u, 0.0, nullptr, false);
   dev_dual_init(c);
-  if (c.itlog && TID == 0) c.itlog[0] = 0.0;
+  if (TID == 0) lds[L.scal + DG_ITREC] = 0.0;
   dev_log_iterate(c);                                      // record 0: (u_ws, dual start) = solve_info['init']
   int sqp_it = 0, rel_tol_its = 0, status = DGSQP_MAX_IT, total_qp = 0;
   double cond[3] = {0, 0, 0};
