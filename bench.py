@@ -1,38 +1,47 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Monte-Carlo scenarios/s (= DG-SQP solves/s) of the 2-agent N=25 game.
+"""Headline benchmark: Monte-Carlo scenarios/s (= DG-SQP solves/s) of the 2-agent N=25 game (BASELINE.json configs[1]).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W]                   # N > 1 without a launcher: spawns its own N ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one pass of the hot path (DGSQP.solve(), reference DGSQP/solvers/DGSQP.py:302-507) over one batch
-of synthetic random-initial-condition scenarios that is already resident in HBM (dgsqp_stage_inputs).  Every rank
-owns its own batch of the same size (weak scaling, no data-path collective); the only exchange is ONE all_gather of
-the per-scenario convergence record (RCCL over xGMI with the nccl backend).  Rank 0 prints ONE JSON line.
-
-torch is plumbing here (process group, barrier, gather); the solver itself is the ctypes/HIP library.
+One "step" = one pass of the hot path (DGSQP.solve(), reference DGSQP/solvers/DGSQP.py:302-507) over one batch of synthetic
+random-initial-condition scenarios that is resident in HBM before the timed region starts (dgsqp_stage_inputs); consecutive
+steps solve DIFFERENT batches (own seed each, up to 8 distinct ones).  The timed region is exactly K steps between two fences
+(library stream synchronisation + RCCL barrier), max over ranks.  Scenarios shard over the ranks with no data-path collective
+(--scaling weak: fixed batch per GPU; strong: fixed total batch); the only exchange is ONE ncclAllGather of the 64-byte
+per-scenario record, issued by the HIP library (dgsqp_gather_stats).  No PyTorch: the launcher only provides RANK / LOCAL_RANK /
+WORLD_SIZE.  Rank 0 prints ONE JSON line; next to `value` (K pipelined steps) it carries `value_single_launch` (strictly one
+launch at a time -- the only figure in which a launch has the GPU to itself, and where roofline.kernel_ms comes from) and
+`value_host_inclusive` (dgsqp_solve_batch from host buffers: H2D + solve + D2H + gather).
 """
 import argparse
+import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
 import numpy as np
 
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')     # one hardware queue per in-flight batch (HIP default: 4)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # BASELINE.json configs[1]
-    'dyn_curve_N25': dict(desc='2-agent dynamic-bicycle (Pacejka, rk4 M=10) curve track, N=25, fp64', kind='dyn', track='curve', N=25, reg=1e-3),
+    # BASELINE.json configs[1]: the reference's own dynamic-bicycle game (comparison_study_barc/exact_dynamic_game_dynamic.py) on the curve track
+    'dyn_curve_N25': dict(desc='2-agent dynamic-bicycle (Pacejka, rk4 M=10) curve track, N=25, game of exact_dynamic_game_dynamic.py (cost_setting 0), fp64', kind='dyn', track='curve', N=25, reg=1e-3),
+    # round 1's synthetic variant of it (costs / rate rows of curve.py on the Pacejka vehicle): a third of the scenarios diverge numerically
+    'dyn_curve_N25_stress': dict(desc='2-agent dynamic-bicycle curve track, N=25, curve.py costs and rate rows (round-1 definition), fp64', kind='dyn', track='curve', N=25, reg=1e-3, game_def='curve'),
     # the reference's own Monte-Carlo experiment (scripts/DGSQP_ALGAMES_monte_carlo_curve.py), kinematic bicycle
     'kb_curve_N25': dict(desc='2-agent kinematic-bicycle (euler) curve track, N=25, reg=0 (curve.py:161), fp64', kind='kb', track='curve', N=25, reg=0.0),
     'kb_chicane_N25': dict(desc='2-agent kinematic-bicycle (euler) chicane track, N=25, reg=1e-3 (chicane.py:164), fp64', kind='kb', track='chicane', N=25, reg=1e-3),
     # other Monte-Carlo scripts of the reference at their own sizes (not BASELINE's metric; for the DESIGN.md table)
     'kb_barc2_N15': dict(desc='2-agent kinematic-bicycle race on the L_track_barc circuit, N=15, reg=0 (DGSQP_comp_monte_carlo.py), fp64', kind='barc', M=2, N=15, reg=0.0),
+    'kb_barc3_N25': dict(desc='3-agent kinematic-bicycle race on the L_track_barc circuit, N=25, reg=0 (BASELINE configs[2] game), XL layout, fp64', kind='barc', M=3, N=25, reg=0.0),
     'merge_N20': dict(desc='3-car highway merge, kinematic unicycles rk3, N=20, reg=0 (DGSQP_merge_monte_carlo.py), big layout, fp64', kind='merge', N=20, reg=0.0),
     'kb_curve_N50': dict(desc='2-agent kinematic-bicycle curve track, N=50, reg=1e-3 (BASELINE configs[3] size on the curve track), XL layout, fp64', kind='kb', track='curve', N=50, reg=1e-3),
     'kb_curve3_N25': dict(desc='3-agent kinematic-bicycle curve track, N=25, reg=1e-3 (DGSQP_monte_carlo_agents.py M=3 N=25 = BASELINE configs[2] size), XL layout, fp64', kind='kb', track='curve', N=25, M=3, reg=1e-3),
@@ -44,7 +53,7 @@ def make_game(name, reg=None):
     w = WORKLOADS[name]
     reg = w['reg'] if reg is None else reg
     if w['kind'] == 'dyn':
-        return dynamic_racing_game(w['track'], N=w['N'], rk4_substeps=10, reg=reg)
+        return dynamic_racing_game(w['track'], N=w['N'], rk4_substeps=10, reg=reg, game_def=w.get('game_def', 'exact_dynamic'))
     if w['kind'] == 'barc':
         from dgsqp_amd.montecarlo import barc_racing_game
         return barc_racing_game(N=w['N'], M=w['M'], reg=reg)
@@ -60,149 +69,197 @@ def algorithmic_bytes_per_solve(d):
     return 8 * (d.n_q + d.n + d.n + d.n_c + (d.N + 1) * d.n_q + 3 + d.M) + 12
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (nothing in this process has
+    touched the GPU), relay rank 0's JSON line, exit with the worst return code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   DGSQP_RENDEZVOUS=os.path.join(os.environ.get('TMPDIR', '/tmp'), f'dgsqp_rccl_{port}_{os.getpid()}.id'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    sys.exit(max(abs(rc) for rc in rcs))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--batch', type=int, default=1024, help='scenarios per GPU per step')
+    ap.add_argument('--batch', type=int, default=1024, help='scenarios per GPU per step (--scaling weak) or in total per step (strong)')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--workload', default='dyn_curve_N25', choices=sorted(WORKLOADS))
-    ap.add_argument('--cpu-sample', type=int, default=16, help='scenarios timed on the host for cpu_baseline (0 disables)')
+    ap.add_argument('--cpu-sample', type=int, default=32, help='scenarios timed on the host for cpu_baseline (0 disables)')
     ap.add_argument('--pipeline', type=int, default=5,
                     help='independent batches in flight per GPU (each on its own handle / HIP stream); 1 = strictly one launch at a time')
+    ap.add_argument('--single-steps', type=int, default=3, help='extra one-launch-at-a-time steps behind value_single_launch / roofline.kernel_ms (0 disables)')
+    ap.add_argument('--host-steps', type=int, default=2, help='extra dgsqp_solve_batch calls from host buffers behind value_host_inclusive (0 disables)')
     ap.add_argument('--reg', type=float, default=None, help='DGSQPParams.reg (default: the value of the workload)')
+    ap.add_argument('--eig-floor', type=float, default=None, help='_nearestPD floor (default: the literal 1e-10, DGSQP.py:1293)')
+    ap.add_argument('--snap-active-bounds', action='store_true', help='implementation knob, see include/dgsqp.h (default: literal)')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus, sys.argv[1:])
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    import torch
-    import torch.distributed as dist
-    distributed = world > 1 or os.environ.get('DGSQP_BENCH_FORCE_DIST') == '1'   # the env knob lets a 1-GPU box exercise the RCCL path
-    if distributed:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    dev = torch.device('cuda', local_rank)
+    if args.gpus != world:
+        sys.stderr.write(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus} '
+                         f'or run `python bench.py --gpus {args.gpus}` without a launcher\n')
+        sys.exit(2)
 
     from dgsqp_amd import _ffi
     from dgsqp_amd.montecarlo import sample_scenarios
-    from dgsqp_amd.sharding import gather_stats, pack_stats, summarize
+    from dgsqp_amd.sharding import Communicator, padded_shard_size, shard_range, stats_from_records, summarize
     from dgsqp_amd.solver import DGSQP
-    import ctypes as C
 
     game = make_game(args.workload, args.reg)
-    solver = DGSQP(*game.solver_args(), print_method=None, device=local_rank)
-    d = solver.dims
-    B = args.batch
-    x0, u_tm = sample_scenarios(game, B, seed=1 + rank)          # rejection sampling happens before any timing
-    u_am = np.ascontiguousarray(solver._to_agent_major(u_tm))
-    lib, h = solver._lib, solver._h
-    # Steps are independent batches.  With --pipeline P > 1 they are issued round-robin on P handles (own stream, workspace and
-    # result buffers each) without waiting in between: the workgroups of step i+1 take over the compute units while step i
-    # drains its slowest scenarios.  Every step still solves its whole batch; all of them are complete at the closing fence.
+    mk = lambda: DGSQP(*game.solver_args(), print_method=None, device=local_rank, eig_floor=args.eig_floor,
+                       snap_active_bounds=args.snap_active_bounds)
     P = max(1, args.pipeline)
-    solvers = [solver] + [DGSQP(*game.solver_args(), print_method=None, device=local_rank) for _ in range(P - 1)]
+    n_batches = max(P, min(8, args.steps))             # distinct batches = handles (<= 8 hardware queues); steps cycle through them
+    solvers = [mk() for _ in range(n_batches)]
+    solver = solvers[0]
+    d = solver.dims
+    lib = solver._lib
+    comm = Communicator(solver, rank, world)          # RCCL communicator owned by handle 0 (world = 1: no peer needed)
+    if args.scaling == 'weak':
+        B_total, (lo, hi) = args.batch * world, (rank * args.batch, (rank + 1) * args.batch)
+    else:
+        B_total, (lo, hi) = args.batch, shard_range(args.batch, rank, world)
+    B = hi - lo
+    B_pad = padded_shard_size(B_total, world)
+    # rejection sampling + PID warm starts happen before any timing; batch j of rank r has its own seed
+    batches = []
+    for j in range(n_batches):
+        x0, u_tm = sample_scenarios(game, B, seed=1 + rank + 1000 * j)
+        batches.append((np.ascontiguousarray(x0), np.ascontiguousarray(solver._to_agent_major(u_tm))))
     handles = [sv._h for sv in solvers]
-    for hh in handles:
+    for hh, (x0, u_am) in zip(handles, batches):
         assert lib.dgsqp_stage_inputs(hh, B, _ffi.dptr(x0), _ffi.dptr(u_am)) == 0, lib.dgsqp_last_error(hh)
 
     tm = _ffi.TimingT()
-    for _ in range(args.warmup):
-        for hh in handles:
-            assert lib.dgsqp_solve_staged(hh, C.byref(tm)) == 0, lib.dgsqp_last_error(hh)
+    for w in range(args.warmup):
+        hh = handles[w % n_batches]
+        assert lib.dgsqp_solve_staged(hh, C.byref(tm)) == 0, lib.dgsqp_last_error(hh)
 
     def fence():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
+        for hh in handles:
+            assert lib.dgsqp_synchronize(hh) == 0
+        comm.barrier()
 
-    kernel_ms = []
-    busy = [False] * P
-    order = []                                        # handles in launch order (oldest first)
+    def run_steps(steps, in_flight):
+        """`steps` launches cycling through the staged batches, at most `in_flight` of them outstanding.  The next batch is started
+        when the previous launch has handed out its last scenario (its workgroups begin to exit and free compute units) -- not
+        earlier, or two launches would share the GPU from the start and both grow tails."""
+        kernel_ms, order, last = [], [], None
 
-    def wait(i):
-        assert lib.dgsqp_wait(handles[i], C.byref(tm)) == 0, lib.dgsqp_last_error(handles[i])
-        kernel_ms.append(tm.kernel_ms)            # HIP events around that launch on its own stream
-        busy[i] = False
-        order.remove(i)
+        def wait_oldest():
+            i = order.pop(0)
+            assert lib.dgsqp_wait(handles[i], C.byref(tm)) == 0, lib.dgsqp_last_error(handles[i])
+            kernel_ms.append(tm.kernel_ms)            # HIP events around that launch on its own stream
+        fence()
+        t0 = time.perf_counter()
+        for step in range(steps):
+            i = step % n_batches
+            if last is not None and in_flight > 1:
+                deadline = time.perf_counter() + 600.0           # never spin forever on a launch that died
+                while not lib.dgsqp_draining(handles[last]) and time.perf_counter() < deadline:
+                    time.sleep(0.0002)
+            while len(order) >= in_flight or i in order:
+                wait_oldest()
+            assert lib.dgsqp_launch_staged(handles[i]) == 0, lib.dgsqp_last_error(handles[i])
+            order.append(i)
+            last = i
+        while order:
+            wait_oldest()
+        fence()
+        elapsed = float(comm.allreduce_max([time.perf_counter() - t0])[0])
+        return elapsed, kernel_ms, last
 
-    fence()
-    t0 = time.perf_counter()
-    last = None
-    for step in range(args.steps):
-        # start the next batch when the previous launch has handed out its last scenario (its workgroups begin to exit and
-        # free compute units) -- not earlier, or two launches would share the GPU from the start and both grow tails
-        if last is not None and P > 1:
-            deadline = time.perf_counter() + 600.0           # never spin forever on a launch that died
-            while not lib.dgsqp_draining(handles[last]) and time.perf_counter() < deadline:
-                time.sleep(0.0002)
-        if all(busy):
-            wait(order[0])
-        i = busy.index(False)
-        assert lib.dgsqp_launch_staged(handles[i]) == 0, lib.dgsqp_last_error(handles[i])
-        busy[i] = True
-        order.append(i)
-        last = i
-    while order:
-        wait(order[0])
-    fence()
-    elapsed = time.perf_counter() - t0
-    h = handles[last]                                 # results of the last step
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # ---- the timed region of the contract: exactly K steps, fences on both sides, max over ranks
+    elapsed, kernel_ms_pipe, last = run_steps(args.steps, P)
+    value = B_total * args.steps / elapsed
+    # the single stats gather: the records of one step (batch 0, solved by handle 0, which owns the communicator)
+    rec = comm.gather_stats(B_pad)
+    stats = stats_from_records(rec)
 
-    # results of the last step + the single stats gather
-    out = dict(status=np.empty(B, np.int32), num_iters=np.empty(B, np.int32), qp_solves=np.empty(B, np.int32), cond=np.empty((B, 3)))
-    assert lib.dgsqp_fetch_results(h, None, None, None, _ffi.iptr(out['status']), _ffi.iptr(out['num_iters']),
-                                   _ffi.iptr(out['qp_solves']), _ffi.dptr(out['cond']), None) == 0
-    stats = gather_stats(pack_stats(out), device=dev)
-    kms = float(np.mean(kernel_ms))
-    if distributed:
-        t = torch.tensor([kms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        kms = float(t.item())
+    # ---- one launch at a time (no overlap): per-launch kernel time, single-launch throughput
+    single = None
+    if args.single_steps > 0:
+        e1, kms1, _ = run_steps(args.single_steps, 1)
+        kms = float(comm.allreduce_max([np.mean(kms1)])[0])
+        single = dict(value=B_total * args.single_steps / e1, kernel_ms=kms, ms_per_step=e1 / args.single_steps * 1e3)
+    else:
+        kms = float(comm.allreduce_max([np.mean(kernel_ms_pipe)])[0])
+
+    # ---- host-inclusive: H2D + solve + D2H of every output + the stats gather, from host buffers (SURVEY.md section 8d)
+    host = None
+    if args.host_steps > 0:
+        n, nc, nx = int(d.n), int(d.n_c), int((d.N + 1) * d.n_q)
+        ob = dict(u=np.empty((B, n)), l=np.empty((B, nc)), x=np.empty((B, nx)), st=np.empty(B, np.int32), it=np.empty(B, np.int32),
+                  qp=np.empty(B, np.int32), cond=np.empty((B, 3)), cost=np.empty((B, int(d.M))))
+        fence()
+        t0 = time.perf_counter()
+        for k in range(args.host_steps):
+            x0, u_am = batches[(k + 1) % n_batches]
+            rc = lib.dgsqp_solve_batch(handles[0], B, _ffi.dptr(x0), _ffi.dptr(u_am), _ffi.dptr(ob['u']), _ffi.dptr(ob['l']), _ffi.dptr(ob['x']),
+                                       _ffi.iptr(ob['st']), _ffi.iptr(ob['it']), _ffi.iptr(ob['qp']), _ffi.dptr(ob['cond']), _ffi.dptr(ob['cost']), C.byref(tm))
+            assert rc == 0, lib.dgsqp_last_error(handles[0])
+            comm.gather_stats(B_pad)
+        fence()
+        eh = float(comm.allreduce_max([time.perf_counter() - t0])[0])
+        host = dict(value=B_total * args.host_steps / eh, ms_per_step=eh / args.host_steps * 1e3)
 
     if rank == 0:
-        # HBM traffic from PMC counters is collected offline in separate rocprofv3 --pmc passes (gpurun refuses mixed runs)
-        # and so is the fp64 instruction mix (SQ counters, profiles/*_pmc_sq_*.json) behind the vector-ALU figure below
-        traffic, flop_per_solve = None, None
+        # HBM traffic comes from PMC counters collected in separate rocprofv3 --pmc passes (gpurun refuses mixed runs) and summarised
+        # under profiles/; so does the fp64 instruction mix (SQ counters) behind the vector-ALU figure.  Latest matching file wins.
+        traffic, flop_per_solve, traffic_src = None, None, None
         try:
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_*.json'))):
                 pm = json.load(open(f))
-                if pm.get('workload') == args.workload and pm.get('batch_per_gpu') == B:
-                    traffic = pm.get('traffic_bytes_per_launch', traffic)
+                if pm.get('workload') == args.workload and pm.get('batch_per_gpu') == B and pm.get('game_def', 'round1') == 'round2':
+                    if 'traffic_bytes_per_launch' in pm:
+                        traffic, traffic_src = pm['traffic_bytes_per_launch'], os.path.relpath(f, ROOT)
                     flop_per_solve = pm.get('fp64_flop_per_solve_upper_bound', flop_per_solve)
         except Exception:
             pass
-        total = B * world * args.steps
-        value = total / elapsed
         bytes_per_launch = algorithmic_bytes_per_solve(d) * B
         achieved = bytes_per_launch / (kms * 1e-3) / 1e9
         summ = summarize(stats)
         line = {
-            'metric': 'Monte-Carlo scenarios/sec (SQP solves/sec), 2-agent N=25' if args.workload in ('dyn_curve_N25', 'kb_curve_N25', 'kb_chicane_N25')
+            'metric': 'Monte-Carlo scenarios/sec (SQP solves/sec), 2-agent N=25' if args.workload.startswith(('dyn_curve_N25', 'kb_curve_N25', 'kb_chicane_N25'))
                       else 'Monte-Carlo scenarios/sec (SQP solves/sec)', 'value': value, 'unit': 'scenarios/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': args.workload, 'description': WORKLOADS[args.workload]['desc'], 'batch_per_gpu': B,
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': args.workload, 'description': WORKLOADS[args.workload]['desc'], 'batch_per_gpu': B, 'batch_total': B_total,
                        'n': int(d.n), 'n_c': int(d.n_c), 'parallelism': f'scenario-sharded x{world}',
-                       'sampler': {'circuit': 'scripts/DGSQP_comp_monte_carlo.py:365-382 (seed 1+rank), PID warm start',
-                                   'merge': 'scripts/DGSQP_merge_monte_carlo.py:421-480 (seed 1+rank), zero warm start'}.get(
-                                       game.sampler, 'scripts/DGSQP_ALGAMES_monte_carlo_curve.py:384-467 (seed 1+rank), PID warm start'),
-                       'layout': {0: 'lds', 1: 'big', 2: 'xl'}[int(d.layout)],
-                       'batches_in_flight': P, 'reg': float(game.params.reg), 'eig_floor': float(solver._cparams.eig_floor)},
+                       'sampler': {'circuit': 'scripts/DGSQP_comp_monte_carlo.py:365-382, PID warm start',
+                                   'merge': 'scripts/DGSQP_merge_monte_carlo.py:421-480, zero warm start'}.get(
+                                       game.sampler, 'scripts/DGSQP_ALGAMES_monte_carlo_curve.py:384-467, PID warm start') + ' (seed 1 + rank + 1000 * batch)',
+                       'distinct_batches': n_batches, 'layout': {0: 'lds', 1: 'big', 2: 'xl'}[int(d.layout)],
+                       'batches_in_flight': P, 'reg': float(game.params.reg), 'eig_floor': float(solver._cparams.eig_floor),
+                       'snap_active_bounds': int(solver._cparams.snap_active_bounds)},
+            'value_single_launch': single['value'] if single else None,
+            'value_host_inclusive': host['value'] if host else None,
             'mean_iters': summ['mean_iters_converged'], 'mean_iters_all': summ['mean_iters_all'],
             'mean_qp_solves': summ['mean_qp_solves_all'], 'converged_fraction': summ['converged'],
             'status_fractions': {k: summ[k] for k in ('conv_abs_tol', 'conv_rel_tol', 'max_it', 'diverged', 'qp_fail')},
             # The path is ALU/LDS-bound (state lives in LDS for the whole solve); the HBM figure is reported as the
             # contract asks and is expected to be a tiny fraction of peak (SURVEY.md section 8d).
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
-                         'traffic': traffic, 'kernel': 'dg_solve_kernel', 'kernel_ms': kms,
+                         'traffic': traffic, 'traffic_source': traffic_src, 'kernel': 'dg_solve_kernel', 'kernel_ms': kms,
+                         'kernel_ms_source': 'HIP events, launches one at a time' if single else 'HIP events, overlapping launches',
                          'algorithmic_bytes_per_solve': algorithmic_bytes_per_solve(d)},
         }
         if flop_per_solve is not None:
@@ -216,15 +273,14 @@ def main():
             oracle.build()
             ns = min(args.cpu_sample, B)
             cores = os.cpu_count() or 1
+            x0, u_am = batches[0]
             t1 = time.perf_counter()
             oracle.solve_batch(solver._problem, solver._cparams, x0[:ns], u_am[:ns], nthreads=min(cores, ns))
             dt = time.perf_counter() - t1
             line['cpu_baseline'] = {'value': ns / dt, 'unit': 'scenarios/s', 'cores': min(cores, ns), 'kind': 'port',
-                                    'sample': f'first {ns} scenarios of the same batch, oracle/dgsqp_oracle.cpp, {dt:.1f} s'}
+                                    'sample': f'first {ns} scenarios of batch 0, oracle/dgsqp_oracle.cpp (dense literal restatement, not CasADi+OSQP), {dt:.1f} s'}
         print(json.dumps(line), flush=True)
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+    comm.close()
 
 
 if __name__ == '__main__':

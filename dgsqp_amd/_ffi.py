@@ -73,6 +73,11 @@ class PidT(C.Structure):
     ]
 
 
+class StatRecordT(C.Structure):
+    _fields_ = [('status', C.c_int32), ('iters', C.c_int32), ('qp_solves', C.c_int32), ('rank', C.c_int32),
+                ('p_feas', C.c_double), ('comp', C.c_double), ('stat', C.c_double), ('cost', C.c_double * 3)]
+
+
 class DimsT(C.Structure):
     _fields_ = [('M', C.c_int32), ('N', C.c_int32), ('n_q', C.c_int32), ('n_u', C.c_int32), ('n', C.c_int32),
                 ('n_c', C.c_int32), ('n_dense', C.c_int32), ('lds_bytes', C.c_int32),
@@ -149,6 +154,18 @@ def load_library() -> C.CDLL:
     lib.dgsqp_fetch_iterate_log.restype = C.c_int
     lib.dgsqp_synchronize.argtypes = [H]
     lib.dgsqp_synchronize.restype = C.c_int
+    lib.dgsqp_comm_unique_id.argtypes = [C.c_char_p]
+    lib.dgsqp_comm_unique_id.restype = C.c_int
+    lib.dgsqp_comm_init.argtypes = [H, C.c_char_p, C.c_int, C.c_int]
+    lib.dgsqp_comm_init.restype = C.c_int
+    lib.dgsqp_comm_destroy.argtypes = [H]
+    lib.dgsqp_comm_destroy.restype = C.c_int
+    lib.dgsqp_gather_stats.argtypes = [H, C.c_int64, C.c_void_p]
+    lib.dgsqp_gather_stats.restype = C.c_int
+    lib.dgsqp_comm_barrier.argtypes = [H]
+    lib.dgsqp_comm_barrier.restype = C.c_int
+    lib.dgsqp_comm_allreduce_max.argtypes = [H, _PD, C.c_int]
+    lib.dgsqp_comm_allreduce_max.restype = C.c_int
     _LIB = lib
     return lib
 
@@ -157,7 +174,8 @@ EXPORTED_SYMBOLS = ['dgsqp_create', 'dgsqp_destroy', 'dgsqp_dims', 'dgsqp_plan',
                     'dgsqp_solve_batch', 'dgsqp_stage_inputs', 'dgsqp_solve_staged', 'dgsqp_fetch_results',
                     'dgsqp_evaluate_batch', 'dgsqp_qp_batch', 'dgsqp_set_trace', 'dgsqp_fetch_trace',
                     'dgsqp_pid_warm_start_batch', 'dgsqp_launch_staged', 'dgsqp_wait', 'dgsqp_draining',
-                    'dgsqp_set_iterate_log', 'dgsqp_fetch_iterate_log', 'dgsqp_synchronize']
+                    'dgsqp_set_iterate_log', 'dgsqp_fetch_iterate_log', 'dgsqp_synchronize', 'dgsqp_comm_unique_id', 'dgsqp_comm_init',
+                    'dgsqp_comm_destroy', 'dgsqp_gather_stats', 'dgsqp_comm_barrier', 'dgsqp_comm_allreduce_max']
 
 
 def dptr(a):

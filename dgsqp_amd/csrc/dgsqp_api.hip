@@ -148,6 +148,7 @@ struct DgEnvInit {
 } dg_env_init;
 }  // namespace
 
+struct dgsqp_comm_state;
 struct dgsqp_solver {
   int device = 0;
   DgProb hp;
@@ -169,6 +170,7 @@ struct dgsqp_solver {
   int64_t trace_launch_B = 0;                                             // scenarios of the launch that filled it
   double* d_itlog = nullptr; int itlog_cap = 0; int64_t itlog_B = 0, itlog_launch_B = 0;
   bool in_flight = false;       // a solve launch has been enqueued and not yet waited for
+  dgsqp_comm_state* comm = nullptr;   // RCCL communicator + record buffers (dgsqp_comm.h), owned by the handle
   std::string err;
 };
 static thread_local std::string g_create_err;
@@ -181,6 +183,8 @@ static thread_local std::string g_create_err;
       return DGSQP_E_DEVICE;                                                                 \
     }                                                                                        \
   } while (0)
+
+#include "dgsqp_comm.h"
 
 static void free_batch(dgsqp_solver* h) {
   void* ptrs[] = {h->d_x0, h->d_uws, h->d_u, h->d_l, h->d_x, h->d_cond, h->d_cost, h->d_status, h->d_iters, h->d_qps};
@@ -327,6 +331,7 @@ void dgsqp_destroy(dgsqp_handle_t h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream && h->in_flight) (void)hipStreamSynchronize(h->stream);
+  if (h->comm) (void)dgsqp_comm_destroy(h);
   { std::lock_guard<std::mutex> lk(g_reg_mutex); g_handles.erase(std::remove(g_handles.begin(), g_handles.end(), h), g_handles.end()); }
   free_batch(h);
   if (h->ws) (void)hipFree(h->ws);
@@ -674,6 +679,86 @@ int dgsqp_qp_batch(dgsqp_handle_t h, int64_t B, const double* x0, const double* 
   if (Qpd) HIPCHK(h, hipMemcpy(Qpd, dQ, sizeof(double) * B * n * n, hipMemcpyDeviceToHost));
   if (flag) HIPCHK(h, hipMemcpy(flag, df, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
   return DGSQP_OK;
+}
+
+// ---- RCCL communicator owned by the handle -----------------------------------------------------------------------------
+int dgsqp_comm_unique_id(char* out128) {
+  if (!out128) return DGSQP_E_ARG;
+  if (!g_rccl.load()) { g_create_err = g_rccl.err; return DGSQP_E_DEVICE; }
+  ncclUniqueId id;
+  if (g_rccl.GetUniqueId(&id) != ncclSuccess) { g_create_err = "ncclGetUniqueId failed"; return DGSQP_E_DEVICE; }
+  static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+  memcpy(out128, &id, 128);
+  return DGSQP_OK;
+}
+
+int dgsqp_comm_init(dgsqp_handle_t h, const char* id128, int rank, int world) {
+  if (!h || !id128 || world < 1 || rank < 0 || rank >= world) { if (h) h->err = "bad argument"; return DGSQP_E_ARG; }
+  if (h->comm) { h->err = "communicator already initialised"; return DGSQP_E_ARG; }
+  if (!g_rccl.load()) { h->err = g_rccl.err; return DGSQP_E_DEVICE; }
+  HIPCHK(h, hipSetDevice(h->device));
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  dgsqp_comm_state* c = new dgsqp_comm_state();
+  c->rank = rank; c->world = world;
+  ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+  if (r != ncclSuccess) { h->err = std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"); delete c; return DGSQP_E_DEVICE; }
+  if (hipMalloc(&c->d_red, sizeof(double) * 64) != hipSuccess) { g_rccl.CommDestroy(c->comm); delete c; h->err = "hipMalloc failed"; return DGSQP_E_NOMEM; }
+  h->comm = c;
+  return DGSQP_OK;
+}
+
+int dgsqp_comm_destroy(dgsqp_handle_t h) {
+  if (!h || !h->comm) return DGSQP_OK;
+  (void)hipSetDevice(h->device);
+  dgsqp_comm_state* c = h->comm;
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+  if (c->d_rec) (void)hipFree(c->d_rec);
+  if (c->d_all) (void)hipFree(c->d_all);
+  if (c->d_red) (void)hipFree(c->d_red);
+  delete c;
+  h->comm = nullptr;
+  return DGSQP_OK;
+}
+
+int dgsqp_gather_stats(dgsqp_handle_t h, int64_t B_pad, dgsqp_stat_record_t* out) {
+  if (!h || !out || !h->comm) { if (h) h->err = "dgsqp_comm_init first"; return DGSQP_E_ARG; }
+  if (B_pad < h->B || B_pad <= 0) { h->err = "B_pad must be at least this rank's batch size"; return DGSQP_E_ARG; }
+  HIPCHK(h, hipSetDevice(h->device));
+  { int rc = wait_idle(h); if (rc) return rc; }
+  dgsqp_comm_state* c = h->comm;
+  if (c->rec_cap < B_pad) {
+    if (c->d_rec) (void)hipFree(c->d_rec);
+    if (c->d_all) (void)hipFree(c->d_all);
+    c->d_rec = c->d_all = nullptr; c->rec_cap = 0;
+    HIPCHK(h, hipMalloc(&c->d_rec, sizeof(dgsqp_stat_record_t) * B_pad));
+    HIPCHK(h, hipMalloc(&c->d_all, sizeof(dgsqp_stat_record_t) * B_pad * c->world));
+    c->rec_cap = B_pad;
+  }
+  hipLaunchKernelGGL(dg_pack_stats_kernel, dim3((unsigned)((B_pad + 255) / 256)), dim3(256), 0, h->stream, h->B, B_pad, h->hp.M, c->rank,
+                     h->d_status, h->d_iters, h->d_qps, h->d_cond, h->d_cost, c->d_rec);
+  HIPCHK(h, hipGetLastError());
+  NCCLCHK(h, g_rccl.AllGather(c->d_rec, c->d_all, sizeof(dgsqp_stat_record_t) * B_pad, ncclChar, c->comm, h->stream));
+  HIPCHK(h, hipMemcpyAsync(out, c->d_all, sizeof(dgsqp_stat_record_t) * B_pad * c->world, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return DGSQP_OK;
+}
+
+int dgsqp_comm_allreduce_max(dgsqp_handle_t h, double* values, int count) {
+  if (!h || !values || count < 1 || count > 64 || !h->comm) { if (h) h->err = "bad argument / dgsqp_comm_init first"; return DGSQP_E_ARG; }
+  HIPCHK(h, hipSetDevice(h->device));
+  dgsqp_comm_state* c = h->comm;
+  HIPCHK(h, hipMemcpyAsync(c->d_red, values, sizeof(double) * count, hipMemcpyHostToDevice, h->stream));
+  NCCLCHK(h, g_rccl.AllReduce(c->d_red, c->d_red, count, ncclDouble, ncclMax, c->comm, h->stream));
+  HIPCHK(h, hipMemcpyAsync(values, c->d_red, sizeof(double) * count, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return DGSQP_OK;
+}
+
+int dgsqp_comm_barrier(dgsqp_handle_t h) {
+  double v = 0.0;
+  return dgsqp_comm_allreduce_max(h, &v, 1);
 }
 
 }  // extern "C"

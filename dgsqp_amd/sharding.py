@@ -1,15 +1,25 @@
 """Multi-GPU plumbing: the Monte-Carlo batch shards embarrassingly (every scenario is an independent
 ``solve()``, reference DGSQP/solvers/DGSQP.py:302-310), one process per GPU, no collective on the data
-path; the only exchange is ONE gather of a fixed-size per-scenario stats record for the convergence
-statistics (RCCL all_gather over xGMI when the backend is 'nccl', gloo in the CPU tests).
-
-torch.distributed is used as plumbing only and imported lazily, so the solver itself never needs torch.
+path; the only exchange is ONE all-gather of a fixed 64-byte per-scenario record for the convergence
+statistics -- ``ncclAllGather`` over xGMI issued by the HIP library itself (``dgsqp_gather_stats``,
+include/dgsqp.h; RCCL communicator owned by the solver handle).  No PyTorch anywhere: ranks find each
+other through the environment a launcher sets (RANK / LOCAL_RANK / WORLD_SIZE, e.g. ``torch.distributed.run``
+or ``bench.py --gpus N`` itself) and exchange the 128-byte ncclUniqueId through a file on the node.
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
+import time
+
 import numpy as np
 
+from . import _ffi
+
 STATS_FIELDS = ('status', 'num_iters', 'qp_solves', 'p_feas', 'comp', 'stat')
+RECORD_DTYPE = np.dtype([('status', np.int32), ('iters', np.int32), ('qp_solves', np.int32), ('rank', np.int32),
+                         ('p_feas', np.float64), ('comp', np.float64), ('stat', np.float64), ('cost', np.float64, (3,))])
+assert RECORD_DTYPE.itemsize == 64 == C.sizeof(_ffi.StatRecordT)
 
 
 def shard_range(B: int, rank: int, world: int):
@@ -19,32 +29,122 @@ def shard_range(B: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def padded_shard_size(B: int, world: int) -> int:
+    """Size of the largest shard = the per-rank record count of the (equal-count) all-gather."""
+    return -(-B // world)
+
+
 def pack_stats(res: dict) -> np.ndarray:
     """[B_local, 6] float64 record per scenario: status, iterations, QP solves, p_feas, comp, stat."""
     return np.column_stack([res['status'].astype(np.float64), res['num_iters'].astype(np.float64),
                             res['qp_solves'].astype(np.float64), res['cond']]).astype(np.float64)
 
 
-def gather_stats(local: np.ndarray, device=None) -> np.ndarray:
-    """all_gather of the per-scenario stats over the default process group; returns [B_total, 6] in rank order.
-    Shards may have different sizes: sizes are exchanged first, payloads are padded to the maximum."""
-    import torch
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return local
-    world = dist.get_world_size()
-    dev = device if device is not None else torch.device('cpu')
-    nloc = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
-    sizes = [torch.zeros_like(nloc) for _ in range(world)]
-    dist.all_gather(sizes, nloc)
-    sizes = [int(s.item()) for s in sizes]
-    nmax = max(sizes)
-    buf = torch.zeros((nmax, local.shape[1]), dtype=torch.float64, device=dev)
-    if local.shape[0]:
-        buf[:local.shape[0]] = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
-    out = [torch.zeros_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf)
-    return np.concatenate([o[:s].cpu().numpy() for o, s in zip(out, sizes)], axis=0)
+def records_from_results(res: dict, rank: int = 0) -> np.ndarray:
+    """Host-side construction of the 64-byte records (what ``dg_pack_stats_kernel`` builds on the device)."""
+    B = len(res['status'])
+    rec = np.zeros(B, RECORD_DTYPE)
+    rec['status'], rec['iters'], rec['qp_solves'], rec['rank'] = res['status'], res['num_iters'], res['qp_solves'], rank
+    rec['p_feas'], rec['comp'], rec['stat'] = res['cond'][:, 0], res['cond'][:, 1], res['cond'][:, 2]
+    if 'cost' in res:
+        m = min(3, res['cost'].shape[1])
+        rec['cost'][:, :m] = res['cost'][:, :m]
+    return rec
+
+
+def pad_records(rec: np.ndarray, B_pad: int) -> np.ndarray:
+    """Equal-count payload of the all-gather: padding rows carry status -1."""
+    out = np.zeros(B_pad, RECORD_DTYPE)
+    out['status'] = -1
+    out[:len(rec)] = rec
+    return out
+
+
+def stats_from_records(rec: np.ndarray) -> np.ndarray:
+    """Gathered records (rank order, padding rows status -1) -> [B_total, 6] float64 table ``summarize`` takes."""
+    rec = rec[rec['status'] >= 0]
+    return np.column_stack([rec['status'], rec['iters'], rec['qp_solves'], rec['p_feas'], rec['comp'], rec['stat']]).astype(np.float64)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# rendezvous: rank 0 publishes the ncclUniqueId in a file on the node, the others poll for it
+# ---------------------------------------------------------------------------------------------------------
+def rendezvous_path() -> str:
+    explicit = os.environ.get('DGSQP_RENDEZVOUS')
+    if explicit:
+        return explicit
+    tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
+    return os.path.join(os.environ.get('TMPDIR', '/tmp'), f'dgsqp_rccl_{tag}.id')
+
+
+def exchange_unique_id(rank: int, world: int, make_id, path: str = None, timeout: float = 120.0) -> bytes:
+    """Rank 0 calls ``make_id()`` (-> 128 bytes) and writes it atomically; the others wait for the file."""
+    path = path or rendezvous_path()
+    if rank == 0:
+        uid = bytes(make_id())
+        assert len(uid) == 128
+        tmp = f'{path}.{os.getpid()}.tmp'
+        with open(tmp, 'wb') as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid
+    deadline = time.time() + timeout
+    while time.time() < deadline:
+        try:
+            with open(path, 'rb') as f:
+                uid = f.read()
+            if len(uid) == 128:
+                return uid
+        except FileNotFoundError:
+            pass
+        time.sleep(0.01)
+    raise TimeoutError(f'rank {rank}: no ncclUniqueId at {path} after {timeout} s')
+
+
+class Communicator:
+    """The solver handle's RCCL communicator (one process per GPU).  ``world == 1`` needs no peer."""
+
+    def __init__(self, solver, rank: int, world: int, path: str = None):
+        self.solver, self.rank, self.world = solver, rank, world
+        self._lib, self._h = solver._lib, solver._h
+        self._path = path or rendezvous_path()
+
+        def make_id():
+            buf = C.create_string_buffer(128)
+            if self._lib.dgsqp_comm_unique_id(buf) != 0:
+                raise RuntimeError('dgsqp_comm_unique_id failed: ' + (self._lib.dgsqp_last_error(None) or b'').decode())
+            return buf.raw
+        uid = exchange_unique_id(rank, world, make_id, self._path) if world > 1 else make_id()
+        if self._lib.dgsqp_comm_init(self._h, uid, rank, world) != 0:
+            raise RuntimeError('dgsqp_comm_init failed: ' + self._lib.dgsqp_last_error(self._h).decode())
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(self._lib.dgsqp_last_error(self._h).decode())
+
+    def barrier(self):
+        self._check(self._lib.dgsqp_comm_barrier(self._h))
+
+    def allreduce_max(self, values) -> np.ndarray:
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        self._check(self._lib.dgsqp_comm_allreduce_max(self._h, _ffi.dptr(v), v.size))
+        return v
+
+    def gather_stats(self, B_pad: int) -> np.ndarray:
+        """ONE ncclAllGather of the 64-byte records of the handle's last solve; returns the [world * B_pad] record array."""
+        out = np.zeros(self.world * B_pad, RECORD_DTYPE)
+        self._check(self._lib.dgsqp_gather_stats(self._h, int(B_pad), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def close(self):
+        if self.world > 1:
+            self.barrier()
+        self._lib.dgsqp_comm_destroy(self._h)
+        if self.rank == 0 and self.world > 1:
+            try:
+                os.remove(self._path)
+            except OSError:
+                pass
 
 
 def summarize(stats: np.ndarray) -> dict:
@@ -58,6 +158,7 @@ def summarize(stats: np.ndarray) -> dict:
                max_it=float((status == 2).mean()) if len(status) else 0.0,
                diverged=float((status == 3).mean()) if len(status) else 0.0,
                qp_fail=float((status == 4).mean()) if len(status) else 0.0,
+               time_limit=float((status == 5).mean()) if len(status) else 0.0,
                mean_iters_all=float(stats[:, 1].mean()) if len(status) else 0.0,
                mean_qp_solves_all=float(stats[:, 2].mean()) if len(status) else 0.0)
     out['mean_iters_converged'] = float(stats[conv, 1].mean()) if conv.any() else float('nan')

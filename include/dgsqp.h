@@ -196,6 +196,14 @@ typedef struct {
   int32_t grid, block;
 } dgsqp_timing_t;
 
+/* Fixed 64-byte per-scenario record of the ONE collective of a sharded Monte-Carlo batch: what the
+   convergence statistics need (process_data_curve.py:44-53).  cost holds the first three agents' costs. */
+typedef struct {
+  int32_t status, iters, qp_solves, rank;
+  double p_feas, comp, stat;
+  double cost[3];
+} dgsqp_stat_record_t;
+
 typedef struct dgsqp_solver* dgsqp_handle_t;
 
 /* Build a solver for one game on one HIP device (one process per GPU).
@@ -295,6 +303,24 @@ int dgsqp_fetch_iterate_log(dgsqp_handle_t h, double* out, int64_t capacity_doub
 
 /* Wait for everything enqueued on the handle's stream (what a caller without a HIP runtime of its own uses as a fence). */
 int dgsqp_synchronize(dgsqp_handle_t h);
+
+
+/*
+ * Multi-GPU (one process per GPU, scenarios sharded, no data-path collective): the library owns the RCCL communicator.
+ *   dgsqp_comm_unique_id   rank 0: 128-byte ncclUniqueId to hand to the other ranks (file, socket, environment ...)
+ *   dgsqp_comm_init        every rank: ncclCommInitRank on the handle's device (collective call)
+ *   dgsqp_gather_stats     the ONE collective per batch: ncclAllGather over xGMI of the 64-byte records of the handle's last solve.
+ *                          B_pad = the largest shard (shards may differ by one scenario); out[world * B_pad] in rank order, padding
+ *                          rows carry status -1.  Every rank receives all records.
+ *   dgsqp_comm_barrier, dgsqp_comm_allreduce_max   fences / max-over-ranks of small host vectors for benchmark timing
+ * world = 1 works without any peer (and is what the single-GPU test exercises).
+ */
+int dgsqp_comm_unique_id(char* out128);
+int dgsqp_comm_init(dgsqp_handle_t h, const char* id128, int rank, int world);
+int dgsqp_comm_destroy(dgsqp_handle_t h);
+int dgsqp_gather_stats(dgsqp_handle_t h, int64_t B_pad, dgsqp_stat_record_t* out);
+int dgsqp_comm_barrier(dgsqp_handle_t h);
+int dgsqp_comm_allreduce_max(dgsqp_handle_t h, double* values, int count);
 
 #ifdef __cplusplus
 }

@@ -760,6 +760,28 @@ def test_large_batch_equals_small_batches(games):
             assert np.array_equal(big[key][lo:lo + 600], small[key]), (key, lo)
 
 
+def test_rccl_gather_single_rank(games):
+    """The library-owned RCCL communicator (dgsqp_comm_init / dgsqp_gather_stats, include/dgsqp.h) on one rank: ncclAllGather of the
+    64-byte records of the last solve, padding rows, barrier and max-reduction -- no PyTorch involved."""
+    from dgsqp_amd.montecarlo import sample_scenarios
+    from dgsqp_amd.sharding import Communicator, stats_from_records, pack_stats
+    from dgsqp_amd.solver import DGSQP
+    g = games['kb_curve_N10'][0]
+    s = DGSQP(*g.solver_args(), print_method=None)
+    x0, u = sample_scenarios(g, 37, seed=2)
+    res = s.solve_batch(x0, u)
+    comm = Communicator(s, 0, 1)
+    try:
+        comm.barrier()
+        assert np.array_equal(comm.allreduce_max([1.5, -2.0]), [1.5, -2.0])
+        rec = comm.gather_stats(40)
+        assert rec.shape == (40,) and (rec['status'][37:] == -1).all() and (rec['rank'] == 0).all()
+        assert np.array_equal(stats_from_records(rec), pack_stats(res))
+        assert np.array_equal(rec['cost'][:37, :2], res['cost'])
+    finally:
+        comm.close()
+
+
 def test_bench_line_contract():
     """bench.py prints ONE JSON line with the contract's keys, the roofline object and the CPU baseline (tiny batch)."""
     import json
@@ -774,8 +796,10 @@ def test_bench_line_contract():
     assert len(lines) == 1
     d = json.loads(lines[0])
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
-                'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+                'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'value_single_launch', 'value_host_inclusive'):
         assert key in d, key
+    assert 0 < d['value_host_inclusive'] and 0 < d['value_single_launch'] <= 1.5 * d['value']
+    assert d['config']['distinct_batches'] >= 2 and d['roofline']['kernel_ms_source'].endswith('one at a time')
     assert d['unit'] == 'scenarios/s' and d['n_gpus'] == 1 and d['steps'] == 3 and d['scaling'] == 'weak' and d['dtype'] == 'f64'
     assert d['config']['workload'] == 'kb_curve_N25' and d['config']['batch_per_gpu'] == 64
     r = d['roofline']

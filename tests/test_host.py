@@ -172,25 +172,37 @@ def test_shard_ranges_partition_the_batch():
 _GLOO_WORKER = r'''
 import os, sys, numpy as np
 sys.path.insert(0, sys.argv[1])
-import torch.distributed as dist
-from dgsqp_amd.sharding import shard_range, gather_stats, pack_stats, summarize
+import torch, torch.distributed as dist            # test-only transport: gloo stands in for the library's ncclAllGather
+from dgsqp_amd.sharding import (RECORD_DTYPE, exchange_unique_id, pad_records, padded_shard_size, records_from_results, shard_range,
+                                stats_from_records, pack_stats, summarize)
 from oracle import oracle
 from dgsqp_amd.montecarlo import kinematic_racing_game, sample_scenarios
 from dgsqp_amd.solver import build_problem, build_params
 dist.init_process_group('gloo')
 rank, world = dist.get_rank(), dist.get_world_size()
+# the rendezvous the RCCL communicator uses: rank 0 publishes 128 bytes in a file, the others poll for it
+uid = exchange_unique_id(rank, world, lambda: bytes(range(128)), path=sys.argv[2])
+assert uid == bytes(range(128))
 game = kinematic_racing_game('curve', N=10)
 P, par = build_problem(*game.solver_args()), build_params(game.params)
 B = 5
 x0, u = sample_scenarios(game, B, seed=4)
 lo, hi = shard_range(B, rank, world)
+B_pad = padded_shard_size(B, world)
 u_am = np.concatenate([u[:, :, 2 * a:2 * a + 2].reshape(B, -1) for a in range(2)], axis=1)
 res = oracle.solve_batch(P, par, x0[lo:hi], u_am[lo:hi])     # the CPU oracle stands in for the GPU solve here
-allstats = gather_stats(pack_stats(res))
+payload = pad_records(records_from_results(res, rank), B_pad)    # equal-count payload, exactly what dgsqp_gather_stats sends
+buf = torch.from_numpy(payload.view(np.uint8).copy())
+out = [torch.zeros_like(buf) for _ in range(world)]
+dist.all_gather(out, buf)
+rec = np.concatenate([o.numpy() for o in out]).view(RECORD_DTYPE)
+allstats = stats_from_records(rec)
 if rank == 0:
     full = oracle.solve_batch(P, par, x0, u_am)
+    assert rec.shape == (world * B_pad,) and (rec['status'] == -1).sum() == world * B_pad - B
     assert allstats.shape == (B, 6), allstats.shape
     assert np.array_equal(allstats, pack_stats(full))
+    assert np.array_equal(rec['rank'][rec['status'] >= 0], [0, 0, 0, 1, 1])
     s = summarize(allstats)
     assert s['n'] == B and 0 <= s['converged'] <= 1
     print('GLOO_OK', s['converged'])
@@ -200,15 +212,31 @@ dist.destroy_process_group()
 
 
 def test_two_process_gloo_shard_and_gather(tmp_path):
-    """world_size=2 over gloo: contiguous sharding + ONE all_gather of per-scenario stats == single-process result."""
+    """world_size=2: contiguous sharding (uneven: 3 + 2), the file rendezvous of the ncclUniqueId, and ONE equal-count all-gather
+    of the padded 64-byte records == the single-process result.  gloo is the transport in this CPU test only; on the GPU the
+    same payload goes through the library's ncclAllGather (tests/test_gpu.py::test_rccl_gather_single_rank)."""
     script = tmp_path / 'worker.py'
     script.write_text(_GLOO_WORKER)
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533')
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
-                          '--master-addr', '127.0.0.1', '--master-port', '29533', str(script), str(ROOT)],
+                          '--master-addr', '127.0.0.1', '--master-port', '29533', str(script), str(ROOT), str(tmp_path / 'uid')],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert 'GLOO_OK' in out.stdout
+
+
+def test_product_and_bench_do_not_use_torch():
+    """north_star: Python host code over a thin ctypes C-ABI, no PyTorch.  (torch.distributed.run may still be the LAUNCHER.)"""
+    import re
+    for f in [ROOT / 'bench.py'] + sorted((ROOT / 'dgsqp_amd').glob('*.py')):
+        src = f.read_text()
+        assert not re.search(r'^\s*(import torch|from torch)', src, re.M), f
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', '2'], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 2 and 'WORLD_SIZE=1' in out.stderr
 
 
 def test_multi_agent_sampler():
