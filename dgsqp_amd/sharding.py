@@ -114,8 +114,20 @@ class Communicator:
             if self._lib.dgsqp_comm_unique_id(buf) != 0:
                 raise RuntimeError('dgsqp_comm_unique_id failed: ' + (self._lib.dgsqp_last_error(None) or b'').decode())
             return buf.raw
-        uid = exchange_unique_id(rank, world, make_id, self._path) if world > 1 else make_id()
-        if self._lib.dgsqp_comm_init(self._h, uid, rank, world) != 0:
+        # RCCL prints a version banner on stdout when it initialises; callers such as bench.py own stdout (ONE JSON line), so
+        # the file descriptor is pointed at stderr for the duration of the initialisation.
+        import sys
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            uid = exchange_unique_id(rank, world, make_id, self._path) if world > 1 else make_id()
+            rc = self._lib.dgsqp_comm_init(self._h, uid, rank, world)
+            C.CDLL(None).fflush(None)         # RCCL writes through C stdio: flush its buffer while fd 1 still points at stderr
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        if rc != 0:
             raise RuntimeError('dgsqp_comm_init failed: ' + self._lib.dgsqp_last_error(self._h).decode())
 
     def _check(self, rc):

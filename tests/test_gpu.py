@@ -593,6 +593,34 @@ def test_xl_layout_three_agents_n150(oracle):
         assert rel(res['u'][b], ref['u'][b]) < 1e-6 and rel(res['l'][b], ref['l'][b]) < 1e-5
 
 
+@pytest.mark.parametrize('N,B', [(15, 24), (25, 12)])
+def test_three_agents_on_the_barc_circuit(oracle, N, B):
+    """BASELINE configs[2]'s own game: 3 kinematic bicycles on the L_track_barc circuit (DGSQP_comp_monte_carlo.py game with a
+    third car, 24 / 33 / 9 rows per stage, reg = 0), at the script's N = 15 (n = 90, LDS layout) and at BASELINE's N = 25
+    (n = 150, 825 rows, XL layout): stage quantities to 1e-11, control flow identical on the oracle-stable scenarios."""
+    from dgsqp_amd.montecarlo import barc_racing_game, sample_scenarios
+    from dgsqp_amd.solver import DGSQP, build_problem, build_params
+    g = barc_racing_game(N=N, M=3)
+    P, par = build_problem(*g.solver_args()), build_params(g.params, lsqr_tol=1e-13)
+    s = DGSQP(*g.solver_args(), print_method=None, lsqr_tol=1e-13)
+    assert (s.n, s.n_c_total) == (6 * N, 24 + 33 * (N - 1) + 9) and s.dims.layout == (0 if N == 15 else 2)
+    x0, u_tm = sample_scenarios(g, B, seed=0)
+    u = agent_major(u_tm)
+    rng = np.random.default_rng(1)
+    up = u + 0.01 * rng.standard_normal(u.shape)
+    l = np.maximum(0, rng.standard_normal((B, s.n_c_total)))
+    ev = s.evaluate_batch(x0[:2], up[:2], l[:2])
+    for b in range(2):
+        o = oracle.evaluate(P, x0[b], up[b], l[b], 1)
+        for key in ('x', 'q', 'g', 'G', 'Q'):
+            assert rel(ev[key][b], o[key]) < 1e-11, (key, b)
+    res = s.solve_batch(x0, u_tm)
+    ref = oracle.solve_batch(P, par, x0, u, nthreads=8)
+    same = assert_control_flow_parity(res, ref, stable_mask(oracle, P, par, x0, u, ref, K=2), f'barc3 N={N}', min_stable_same=0.7, max_conv_gap=0.15)
+    for b in np.where(same & (ref['status'] <= 1))[0]:
+        assert rel(res['u'][b], ref['u'][b]) < 1e-2, b
+
+
 def test_bfgs_hessian_option(oracle):
     """DGSQPParams.hessian_approximation = 'bfgs' (DGSQP.py:353-364, :535-557): exact Hessian at the first iteration, damped
     BFGS updates of the projected Hessian afterwards, against the oracle; more iterations than with exact Hessians."""
