@@ -162,7 +162,8 @@ __device__ inline void dyn_fc_pair(DynLane& Z, const double* q, double ua, doubl
   dq[6] = vlon;
   dq[7] = vx * se + vy * ce;
 }
-__device__ inline void dev_rollout_dyn_pair(const DgProb& D, int a, int role, clptr ub, clptr du, double alpha, lptr x) {
+typedef volatile __attribute__((address_space(3))) double vlds_d;
+__device__ inline void dev_rollout_dyn_pair(const DgProb& D, int a, int role, clptr ub, clptr du, double alpha, lptr x, lptr prog = nullptr) {
   const dgsqp_problem_t& P = D.P;
   const dgsqp_agent_t& ag = P.agents[a];
   const int nq = D.nq, qo = D.qoff[a];
@@ -215,6 +216,10 @@ __device__ inline void dev_rollout_dyn_pair(const DgProb& D, int a, int role, cl
     }
     if (role == 0)
       for (int i = 0; i < 8; i++) x[(k + 1) * nq + qo + i] = q[i];
+    if (prog) {      // fused rollout + derivative pass: x_{k+1} of every agent is in LDS, tell the other wavefronts
+      __threadfence_block();
+      if (threadIdx.x == 0) *(vlds_d*)prog = (double)(k + 1);
+    }
   }
 }
 // K trajectories x^(j) = rollout(ub + alpha_j du), alpha_j = alpha0 tau^j, j < K, on K * (lanes per trajectory) lanes of
@@ -360,6 +365,68 @@ __device__ __noinline__ void dev_dyn_derivs(const Ctx& c, clptr ue) {
           case DGSQP_INT_RK3: dev_taylor_item_nqa<DEG, DGSQP_INT_RK3>(c, D.nqa[a], a, k, dir, ue); break;
           default: dev_taylor_item_nqa<DEG, DGSQP_INT_RK2>(c, D.nqa[a], a, k, dir, ue); break;
         }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused rollout + derivative pass (dynamic bicycles under a multi-stage integrator).  The rollout is one dependent chain of
+// N x substeps x stages f_c evaluations on a handful of lanes of wavefront 0 (~1.7 M cycles at N = 25, rk4, M = 10) during
+// which the other seven wavefronts of the scenario would sit at a barrier; the derivative items of stage k need nothing but
+// x_k.  Wavefront 0 publishes the number of finished stages in an LDS slot; the other wavefronts pull 64-item tasks in
+// stage order from an LDS ticket and start on a task as soon as its last stage is there; wavefront 0 joins them when its
+// rollout is done.  The second-order items also deliver A_k, B_k, so a point evaluated this way needs no further derivative
+// pass (tag 2.0 in scal[DG_XVALID]) -- neither for a trial merit nor for the Hessian of the next linearisation at the same
+// point (the Taylor tensor does not depend on the multipliers).  Same arithmetic as dev_rollout + dev_dyn_derivs<2>.
+// ------------------------------------------------------------------------------------------------
+#define DG_PROG 54
+#define DG_TASK 53
+__device__ inline bool dev_can_fuse_rollout() {
+  const DgProb& D = dg_prob;
+  bool ok = D.P.integrator != DGSQP_INT_EULER && 2 * D.M <= 64;
+  for (int a = 0; a < D.M; a++) ok = ok && D.nqa[a] == 8 && D.ndir[a] == D.ndir[0];
+  return ok;
+}
+__device__ __noinline__ void dev_rollout_with_derivs(const Ctx& c, clptr ue, lptr x) {
+  const DgProb& D = dg_prob;
+  const DgLds& L = D.L;
+  lptr sc = LP(L.scal);
+  __syncthreads();
+  for (int i = TID; i < D.nq; i += NT) x[i] = c.x0[i];
+  if (TID == 0) { sc[DG_PROG] = 0.0; sc[DG_TASK] = 0.0; }
+  for (int a = 0; a < D.M; a++) {
+    const int nqa = D.nqa[a];
+    for (int it = TID; it < D.N * nqa; it += NT) {       // columns of x, y: identity (they never enter fc)
+      const int k = it / nqa, o = it % nqa;
+      lptr A = LP(L.e_A[a] + k * nqa * nqa);
+      A[o * nqa + 0] = (o == 0) ? 1.0 : 0.0;
+      A[o * nqa + 1] = (o == 1) ? 1.0 : 0.0;
+    }
+  }
+  __syncthreads();
+  const int wave = TID >> 6, lane = TID & 63;
+  if (wave == 0 && lane < 2 * D.M) dev_rollout_dyn_pair(D, lane >> 1, lane & 1, ue, nullptr, 0.0, x, sc + DG_PROG);
+  const int nd = D.ndir[0], per_agent = (D.N * nd + 63) >> 6, ntask = per_agent * D.M;
+  __attribute__((address_space(3))) unsigned int* ticket = (__attribute__((address_space(3))) unsigned int*)(sc + DG_TASK);
+  while (true) {
+    unsigned int t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if ((int)t >= ntask) break;
+    const int chunk = (int)t / D.M, a = (int)t % D.M;      // stage-major order, the agents alternate
+    const int last = chunk * 64 + 63;
+    const int kmax = last / nd < D.N - 1 ? last / nd : D.N - 1;
+    while ((int)*(vlds_d*)(sc + DG_PROG) < kmax) __builtin_amdgcn_s_sleep(8);
+    __threadfence_block();
+    const int it = chunk * 64 + lane;
+    if (it < D.N * nd) {
+      const int k = it / nd, dir = it % nd;
+      switch (D.P.integrator) {
+        case DGSQP_INT_RK4: dev_taylor_item_nqa<2, DGSQP_INT_RK4>(c, 8, a, k, dir, ue); break;
+        case DGSQP_INT_RK3: dev_taylor_item_nqa<2, DGSQP_INT_RK3>(c, 8, a, k, dir, ue); break;
+        default: dev_taylor_item_nqa<2, DGSQP_INT_RK2>(c, 8, a, k, dir, ue); break;
       }
     }
   }
@@ -970,12 +1037,17 @@ __device__ __noinline__ void dev_hessian_adjoint(const Ctx& c) {
 #define DG_XVALID 60
 #define DG_QP_NPREV 59   // scal slot: size of the saved active set (XL layout: 1 = the saved eigenvector basis is valid)
 // stage 1: trial input, trajectory and constraint values g (no derivatives)
-__device__ inline void dev_evaluate_point(const Ctx& c, clptr usrc, double alpha, clptr dusrc, clptr xsrc = nullptr) {
+// `fuse`: the caller will (most probably) need the derivatives at this point -- run the rollout fused with the second-order
+// derivative pass where that pays (dev_can_fuse_rollout).  Tag in scal[DG_XVALID]: 0 nothing valid, 1 trajectory valid,
+// 2 trajectory AND A_k, B_k, Taylor tensor valid for the input held in the EVAL scratch.
+__device__ inline void dev_evaluate_point(const Ctx& c, clptr usrc, double alpha, clptr dusrc, clptr xsrc = nullptr, bool fuse = false) {
   const DgProb& D = dg_prob;
   const DgLds& L = D.L;
   lptr ue = LP(L.e_ue);
   __syncthreads();
-  const bool tagged = LP(L.scal)[DG_XVALID] != 0.0;
+  const double tag = LP(L.scal)[DG_XVALID];
+  const bool tagged = tag != 0.0;
+  double newtag = 1.0;
   int differs = 0;
   for (int i = TID; i < D.n; i += NT) {
     const double v = dusrc ? step_u(usrc[i], alpha, dusrc[i]) : usrc[i];
@@ -986,16 +1058,26 @@ __device__ inline void dev_evaluate_point(const Ctx& c, clptr usrc, double alpha
     for (int i = TID; i < (D.N + 1) * D.nq; i += NT) LP(L.e_x)[i] = xsrc[i];
     __syncthreads();
   } else if (!tagged || __syncthreads_or(differs)) {
-    PROF_BEGIN(pt_); dev_rollout(c, ue, LP(L.e_x)); PROF_END(PH_ROLLOUT, pt_);
-  }
-  if (TID == 0) LP(L.scal)[DG_XVALID] = 1.0;
+    PROF_BEGIN(pt_);
+    if (fuse && dev_can_fuse_rollout()) { dev_rollout_with_derivs(c, ue, LP(L.e_x)); newtag = 2.0; }
+    else dev_rollout(c, ue, LP(L.e_x));
+    PROF_END(PH_ROLLOUT, pt_);
+  } else newtag = tag;          // same input as the one the scratch was computed for: everything that was valid still is
+  __syncthreads();
+  if (TID == 0) LP(L.scal)[DG_XVALID] = newtag;
   dev_constraint_values(c, ue);
 }
 // stage 2: derivatives at the point prepared by stage 1 -> q, packed G (and raw Q)
 __device__ inline void dev_evaluate_derivs(const Ctx& c, bool hessian) {
   const DgLds& L = dg_prob.L;
   lptr ue = LP(L.e_ue);
-  if (hessian) { PROF_BEGIN(pt_); dev_dyn_derivs<2>(c, ue); PROF_END(PH_DERIV2, pt_); }
+  __syncthreads();
+  const bool have = LP(L.scal)[DG_XVALID] == 2.0;       // A_k, B_k and the Taylor tensor of this very point are there already
+  if (have) {}
+  else if (hessian) {
+    PROF_BEGIN(pt_); dev_dyn_derivs<2>(c, ue); PROF_END(PH_DERIV2, pt_);
+    if (TID == 0 && LP(L.scal)[DG_XVALID] == 1.0) LP(L.scal)[DG_XVALID] = 2.0;
+  }
   else { PROF_BEGIN(pt_); dev_dyn_derivs<1>(c, ue); PROF_END(PH_DERIV1, pt_); }
   { PROF_BEGIN(pt_); dev_chains(c, ue); PROF_END(PH_CHAINS, pt_); }
   if (hessian) {
@@ -1009,10 +1091,12 @@ __device__ inline void dev_evaluate_derivs(const Ctx& c, bool hessian) {
 // a costate sweep, dev_phi_trial; q and the packed G are NOT refreshed -- every accepted point is re-linearised in full)
 __device__ inline void dev_evaluate_trial_derivs(const Ctx& c) {
   lptr ue = LP(dg_prob.L.e_ue);
+  __syncthreads();
+  if (LP(dg_prob.L.scal)[DG_XVALID] == 2.0) return;
   PROF_BEGIN(pt_); dev_dyn_derivs<1>(c, ue); PROF_END(PH_DERIV1, pt_);
 }
 __device__ inline void dev_evaluate(const Ctx& c, clptr usrc, double alpha, clptr dusrc, bool hessian, clptr xsrc = nullptr) {
-  dev_evaluate_point(c, usrc, alpha, dusrc, xsrc);
+  dev_evaluate_point(c, usrc, alpha, dusrc, xsrc, hessian);
   dev_evaluate_derivs(c, hessian);
 }
 

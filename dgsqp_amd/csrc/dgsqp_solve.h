@@ -1129,8 +1129,8 @@ __device__ inline int dev_watchdog(const Ctx& c, double mu, const LinScal& Sk) {
   const double phi_k = Sk.phi, dphi_k = Sk.dphi;
   int nqp = 0;
   dev_save_base(c);
-  // relaxed (full) step
-  dev_evaluate_point(c, lds + L.u, 1.0, lds + L.o_du);
+  // relaxed (full) step; most of them are accepted and re-linearised: roll out fused with the derivative pass
+  dev_evaluate_point(c, lds + L.u, 1.0, lds + L.o_du, nullptr, true);
   const double phi1 = dev_trial_merit(c, 1.0, Sk.S0 + Sk.S1, mu);
   dev_tr(c, 20, phi1);
   if (phi1 <= phi_k + beta * dphi_k) { dev_take_full_step(c); return 0; }
@@ -1145,7 +1145,7 @@ __device__ inline int dev_watchdog(const Ctx& c, double mu, const LinScal& Sk) {
     nqp++;
     if (flag != 0) { fail = true; break; }
     dev_step_scalars(c, S);
-    dev_evaluate_point(c, lds + L.u, 1.0, lds + L.o_du);
+    dev_evaluate_point(c, lds + L.u, 1.0, lds + L.o_du, nullptr, true);
     phi_n = dev_trial_merit(c, 1.0, S.S0 + S.S1, mu);
     dev_tr(c, 21, phi_n);
     if (phi_n > 1e6) break;                                   // merit_max; (u_t, l_t) not advanced

@@ -71,7 +71,7 @@ def stable_mask(oracle, P, par, x0, u_am, ref, K=3, seed=12345):
     return ok
 
 
-def assert_control_flow_parity(res, ref, stable, tag='', min_stable_same=0.95, max_conv_gap=0.05):
+def assert_control_flow_parity(res, ref, stable, tag='', min_stable_same=0.95, max_conv_gap=0.05, min_stable_frac=0.5):
     """Device vs oracle: identical (status, iterations, QP solves) on the scenarios the oracle itself reproduces under 1e-13
     perturbations (at most 1 in 20 of them may still fork: K re-runs do not find every fragile decision), converged
     fraction within ``max_conv_gap``.  Returns the mask of identical scenarios; prints the forks (pytest -s / on failure)."""
@@ -82,7 +82,7 @@ def assert_control_flow_parity(res, ref, stable, tag='', min_stable_same=0.95, m
            f'forks (scenario, stable?, device, oracle): ' +
            ', '.join(f'({b}, {bool(stable[b])}, {control_flow(res)[b].tolist()}, {control_flow(ref)[b].tolist()})' for b in forks))
     print(msg)
-    assert stable.mean() >= 0.5, msg
+    assert stable.mean() >= min_stable_frac, msg
     assert same[stable].mean() >= min_stable_same, msg
     assert abs(np.mean(res['status'] <= 1) - np.mean(ref['status'] <= 1)) <= max_conv_gap + 1.0 / len(same), msg
     return same

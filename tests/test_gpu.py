@@ -597,7 +597,9 @@ def test_xl_layout_three_agents_n150(oracle):
 def test_three_agents_on_the_barc_circuit(oracle, N, B):
     """BASELINE configs[2]'s own game: 3 kinematic bicycles on the L_track_barc circuit (DGSQP_comp_monte_carlo.py game with a
     third car, 24 / 33 / 9 rows per stage, reg = 0), at the script's N = 15 (n = 90, LDS layout) and at BASELINE's N = 25
-    (n = 150, 825 rows, XL layout): stage quantities to 1e-11, control flow identical on the oracle-stable scenarios."""
+    (n = 150, 825 rows, XL layout): stage quantities to 1e-11, control flow identical on the oracle-stable scenarios.  At N = 25
+    DG-SQP v1 itself fails on this game -- 11 of 12 scenarios end in infeasible QPs or at the iteration limit, on the oracle as on
+    the device, and only a third of the runs survive a 1e-13 perturbation of the oracle's inputs -- which is what the test pins."""
     from dgsqp_amd.montecarlo import barc_racing_game, sample_scenarios
     from dgsqp_amd.solver import DGSQP, build_problem, build_params
     g = barc_racing_game(N=N, M=3)
@@ -616,7 +618,8 @@ def test_three_agents_on_the_barc_circuit(oracle, N, B):
             assert rel(ev[key][b], o[key]) < 1e-11, (key, b)
     res = s.solve_batch(x0, u_tm)
     ref = oracle.solve_batch(P, par, x0, u, nthreads=8)
-    same = assert_control_flow_parity(res, ref, stable_mask(oracle, P, par, x0, u, ref, K=2), f'barc3 N={N}', min_stable_same=0.7, max_conv_gap=0.15)
+    same = assert_control_flow_parity(res, ref, stable_mask(oracle, P, par, x0, u, ref, K=2), f'barc3 N={N}', min_stable_same=0.7, max_conv_gap=0.15,
+                                      min_stable_frac=0.25)
     for b in np.where(same & (ref['status'] <= 1))[0]:
         assert rel(res['u'][b], ref['u'][b]) < 1e-2, b
 
