@@ -62,7 +62,10 @@ class ParamsT(C.Structure):
         ('lsqr_atol', C.c_double), ('lsqr_btol', C.c_double),
         ('qp_warm_start', C.c_int32), ('hessian_bfgs', C.c_int32),
         ('eig_floor', C.c_double), ('time_limit', C.c_double),
-        ('snap_active_bounds', C.c_int32), ('reserved_', C.c_int32),
+        ('snap_active_bounds', C.c_int32), ('variant', C.c_int32),
+        ('nms', C.c_int32), ('nms_frequency', C.c_int32), ('nms_memory_size', C.c_int32), ('merit_decrease_condition', C.c_int32),
+        ('reserved_', C.c_int32),
+        ('reg_decay', C.c_double), ('delta_decay', C.c_double), ('merit_decrease', C.c_double), ('merit_parameter', C.c_double),
     ]
 
 

@@ -14,6 +14,7 @@
 
 #include "dgsqp_solve.h"
 #include "dgsqp_xl.h"
+#include "dgsqp_solve_v2.h"
 
 
 // ------------------------------------------------------------------------------------------------
@@ -53,7 +54,8 @@ dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restric
 #ifdef DG_PROF
     const long long sc_t0 = clock64();
 #endif
-    dev_solve(c, (cgptr)u_ws + b * dg_prob.n, b, O);
+    if (dg_prob.par.variant == DGSQP_VARIANT_V2) dev_solve_v2(c, (cgptr)u_ws + b * dg_prob.n, b, O);
+    else dev_solve(c, (cgptr)u_ws + b * dg_prob.n, b, O);
 #ifdef DG_PROF
     if (TID == 0 && b < 16384) dg_prof_scn[b] = (unsigned long long)(clock64() - sc_t0);
 #endif
@@ -84,7 +86,7 @@ dg_evaluate_kernel(const DgProb* __restrict__ D, int64_t B, const double* __rest
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     c.x0 = (cgptr)x0 + b * dg_prob.nq;
     __syncthreads();
-    if (TID == 0) dg_lds[L.scal + DG_XVALID] = 0.0;
+    if (TID == 0) { dg_lds[L.scal + DG_XVALID] = 0.0; dg_lds[L.scal + DG_REG] = dg_prob.par.reg; }
     for (int i = TID; i < n; i += NT) dg_lds[L.u + i] = u[b * n + i];
     for (int r = TID; r < nc; r += NT) dg_lds[L.l + r] = l ? l[b * nc + r] : 0.0;
     __syncthreads();
@@ -124,7 +126,7 @@ dg_qp_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     c.x0 = (cgptr)x0 + b * dg_prob.nq;
     __syncthreads();
-    if (TID == 0) dg_lds[L.scal + DG_XVALID] = 0.0;
+    if (TID == 0) { dg_lds[L.scal + DG_XVALID] = 0.0; dg_lds[L.scal + DG_REG] = dg_prob.par.reg; }
     for (int i = TID; i < n; i += NT) dg_lds[L.u + i] = u[b * n + i];
     for (int r = TID; r < nc; r += NT) dg_lds[L.l + r] = l[b * nc + r];
     __syncthreads();

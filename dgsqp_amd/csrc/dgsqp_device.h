@@ -89,6 +89,10 @@ struct Ctx {
   gptr itlog;   // optional per-scenario iterate log: [0] = number of records, then records of (n + n_c) doubles (u, l):
   int itlog_cap;   // record 0 = (u_ws, dual start), record i = iterates after SQP iteration i (iter_data u_sol / l_sol, DGSQP.py:386-451)
 };
+// Regularisation added to the projected Hessian (DGSQP.py:238-239).  Constant in DG-SQP v1; v2 decays it from iteration to
+// iteration (DGSQP_v2.py:563,592), so it lives in an LDS scalar slot that dev_solve / dev_solve_v2 set per scenario.
+#define DG_REG 52
+__device__ inline double dev_reg() { const double r = LP(dg_prob.L.scal)[DG_REG]; return r > 0.0 ? r : 0.0; }
 // event log compared event-by-event with the oracle's (tests/test_gpu.py::test_event_trace_parity)
 __device__ inline void dev_tr(const Ctx& c, int code, double v) {
   if (c.trace && threadIdx.x == 0) {

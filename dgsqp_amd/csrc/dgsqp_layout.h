@@ -88,7 +88,7 @@ struct DgProb {
   int t2off[DGSQP_MAX_AGENTS];              // offset (doubles) of agent block in the Taylor tensor workspace
   int t2k[DGSQP_MAX_AGENTS];                // per-stage stride of that block = nqa*ndir
   int64_t t2_doubles;
-  int64_t ws_t2, ws_q, ws_base, ws_H, ws_tang, ws_Y, ws_P, ws_V, ws_R, ws_Vp, ws_xM, ws_xJ, ws_xR, ws_bfgs, ws_gd, ws_doubles; // global workspace layout (doubles): Taylor tensor, raw Q, watchdog backups,
+  int64_t ws_t2, ws_q, ws_base, ws_H, ws_tang, ws_Y, ws_P, ws_V, ws_R, ws_Vp, ws_xM, ws_xJ, ws_xR, ws_bfgs, ws_gd, ws_v2, ws_doubles; // global workspace layout (doubles): Taylor tensor, raw Q, watchdog backups,
                                                              // costate-contracted dynamics Hessians, tangent trajectories
   DgRow rows[DG_NCMAX];
   DgDense dense[DG_NDMAX];
@@ -120,13 +120,16 @@ static inline std::string dg_build_layout(DgProb& D) {
   D.ws_Vp = D.ws_R + (D.big == 2 ? matsz + 4 * D.n : 0);      // XL: eigenvectors of the scenario's previous _nearestPD (Jacobi warm start)
   D.ws_doubles = D.ws_Vp + (D.big == 2 ? matsz : 0);
   // matrices of the classical QP: M / its Cholesky factor, J, R (row-major n x n).  XL: the Jacobi buffers are reused
-  D.classic_qp = D.big == 2 || D.eig_floor + (D.par.reg > 0 ? D.par.reg : 0.0) < 1e-8;
+  D.classic_qp = D.big == 2 || D.eig_floor + (D.par.reg > 0 ? D.par.reg : 0.0) < 1e-8 ||
+                 (D.par.variant == DGSQP_VARIANT_V2 && D.eig_floor < 1e-8);      // v2: reg decays towards 0 during a solve (dgsqp_solve_v2.h)
   if (D.big == 2) { D.ws_xM = D.ws_R; D.ws_xJ = D.ws_P; D.ws_xR = D.ws_V; }
   else if (D.classic_qp) { D.ws_xM = D.ws_doubles; D.ws_xJ = D.ws_xM + (int64_t)D.n * D.n; D.ws_xR = D.ws_xJ + (int64_t)D.n * D.n; D.ws_doubles = D.ws_xR + (int64_t)D.n * D.n; }
   // hessian_approximation = 'bfgs': u of the previous iteration and d(u_prev, l) (2 n), the Hessian used at the top of the
   // previous iteration and its projection (n x n each)
   D.ws_bfgs = D.ws_doubles;
   if (D.par.hessian_bfgs) D.ws_doubles += 2 * (int64_t)D.n + 2 * (int64_t)D.n * D.n;
+  D.ws_v2 = D.ws_doubles;     // DG-SQP v2: three iteration records (checkpoint, latest, current) + (u, l) of the last m-step
+  if (D.par.variant == DGSQP_VARIANT_V2) D.ws_doubles += 3 * (2 * (int64_t)D.n + 2 * D.nc + 2) + D.n + D.nc;
   D.ws_gd = D.ws_doubles;
   if (D.gd_global) D.ws_doubles += D.ngd + DG_CHUNK;   // (chunked dots read up to one chunk past the last gradient)
   D.ws_doubles = (D.ws_doubles + 31) / 32 * 32;

@@ -300,7 +300,7 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
   if (TID == 0) { atomicAdd(&dg_prof[2 * PH_E_KNEG], (unsigned long long)kneg); atomicAdd(&dg_prof[2 * PH_E_KNEG + 1], 1ULL); }
 #endif
   // ---- 4a. M = B + reg I (this thread's slice, back into Br); the negative part is corrected batch by batch
-  const double reg = D.par.reg > 0 ? D.par.reg : 0.0;
+  const double reg = dev_reg();
 #pragma unroll
   for (int r = 0; r < RPT; r++) {
     const int i = hf + NH * r;
@@ -887,12 +887,29 @@ __device__ __noinline__ void dev_step_scalars(const Ctx& c, LinScal& S) {
   a1 = block_sum(a1, red); a2 = block_sum(a2, red); lGdu = block_sum(lGdu, red); dd = block_sum(dd, red);
   lg = block_sum(lg, red); lhg = block_sum(lhg, red); vio = block_sum(vio, red); s0 = block_sum(s0, red); ssum = block_sum(ssum, red);
   S.dstat = a1 + a2 + lg * (lGdu + (lhg - lg));
+  if (D.par.variant == DGSQP_VARIANT_V2) S.dstat = a1 + a2;     // d/d(u,l) of 1/2 |d|^2 along (du, dl)  (DGSQP_v2.py:1143-1145)
   S.vio = vio;
   S.S0 = s0;
   S.S1 = ssum - s0;
   S.phi = 0.5 * (dd + lg * lg);  // + mu*vio added by the caller
+  if (D.par.variant == DGSQP_VARIANT_V2) S.phi = 0.5 * dd;
   S.dphi = S.dstat;
   PROF_END(PH_MERIT, pt_m);
+}
+// DG-SQP v2's merit (DGSQP_v2.py:1141-1160, 'stat_l1'):  1/2 |d|^2 + mu sum(max(0, g))  -- no complementarity term, slacks
+// s = max(0, g) of the trial point itself.  |d|^2 and the violation are left in two scalar slots for the caller, which also
+// needs the value with mu = 1 (DGSQP_v2.py:754).
+#define DG_V2_DD 50
+#define DG_V2_VIO 51
+__device__ inline double dev_v2_trial_phi(const Ctx& c, double dd, double mu) {
+  const DgProb& D = dg_prob;
+  lptr lds = LP(0);
+  double v = 0;
+  for (int r = TID; r < D.nc; r += NT) v += fmax(lds[D.L.g + r], 0.0);
+  v = block_sum(v, lds + D.L.red);
+  if (TID == 0) { lds[D.L.scal + DG_V2_DD] = dd; lds[D.L.scal + DG_V2_VIO] = v; }
+  __syncthreads();
+  return 0.5 * dd + mu * v;
 }
 // merit of a trial point through q and the packed G (fallback when the packed-G area is too small to hold the trial
 // multipliers: games with hardly any state / obstacle rows): current (q, g, G) in LDS belong to the trial u
@@ -919,6 +936,7 @@ __device__ __noinline__ double dev_phi_trial_dense(const Ctx& c, double alpha, d
   dd = block_sum(dd, red); lg = block_sum(lg, red); sg = block_sum(sg, red);
   double phi = 0.5 * (dd + lg * lg);
   if (D.par.merit_function == DGSQP_MERIT_STAT_L1) phi += mu * (sg - sum_s);
+  if (D.par.variant == DGSQP_VARIANT_V2) phi = dev_v2_trial_phi(c, dd, mu);
   PROF_END(PH_MERIT, pt_m);
   return phi;
 }
@@ -973,6 +991,7 @@ __device__ __noinline__ double dev_phi_trial_adjoint(const Ctx& c, double alpha,
   dd = block_sum(dd, red); lg = block_sum(lg, red); sg = block_sum(sg, red);
   double phi = 0.5 * (dd + lg * lg);
   if (D.par.merit_function == DGSQP_MERIT_STAT_L1) phi += mu * (sg - sum_s);
+  if (D.par.variant == DGSQP_VARIANT_V2) phi = dev_v2_trial_phi(c, dd, mu);
   PROF_END(PH_MERIT, pt_m);
   return phi;
 }
@@ -1219,7 +1238,7 @@ __device__ __noinline__ void dev_bfgs_hessian(const Ctx& c) {
   __syncthreads();
   dev_evaluate(c, lds + L.u, 0.0, nullptr, false);
   dev_stat_vector(c, lds + L.l, lds + L.d);
-  const double reg = D.par.reg > 0 ? D.par.reg : 0.0;
+  const double reg = dev_reg();
   for (int i = TID; i < n; i += NT) { uprev[i] = lds[L.u + i] - up[i]; yv[i] = lds[L.d + i] - dm[i]; }   // uprev <- s
   __syncthreads();
   double a = 0, b = 0;
@@ -1253,7 +1272,7 @@ __device__ inline void dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
   lptr lds = LP(0);
   const int n = D.n, nc = D.nc;
   __syncthreads();
-  if (TID == 0) { lds[L.scal + DG_XVALID] = 0.0; lds[L.scal + DG_QP_NPREV] = 0.0; }
+  if (TID == 0) { lds[L.scal + DG_XVALID] = 0.0; lds[L.scal + DG_QP_NPREV] = 0.0; lds[L.scal + DG_REG] = D.par.reg; }
   for (int i = TID; i < n; i += NT) lds[L.u + i] = u_ws[i];
   for (int r = TID; r < nc; r += NT) lds[L.l + r] = 0.0;
   __syncthreads();

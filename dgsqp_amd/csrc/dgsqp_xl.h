@@ -173,7 +173,7 @@ __device__ __noinline__ bool dev_xl_psd_tri(const Ctx& c, gptr Qpd) {
   }
   XSYNC();
   // ---- M = B + sum_j (floor - lambda_j) v_j v_j^T + reg I
-  const double reg = D.par.reg > 0 ? D.par.reg : 0.0;
+  const double reg = dev_reg();
   for (int e = TID; e < n * n; e += NT) {
     const int i = e / n, k = e % n;
     double a = 0.5 * (Qg[(int64_t)i * n + k] + Qg[(int64_t)k * n + i]);
@@ -313,7 +313,7 @@ __device__ __noinline__ void dev_xl_psd_jacobi(const Ctx& c, gptr Qpd) {
     if (lane == 0) { const double lj = s / nv; lamv[j] = lj; lamv[n + j] = lj < 0.0 ? (D.eig_floor - lj) / nv : 0.0; }
   }
   __syncthreads();
-  const double reg = D.par.reg > 0 ? D.par.reg : 0.0;
+  const double reg = dev_reg();
   for (int e = TID; e < n * n; e += NT) {
     const int i = e / n, k = e % n;
     double a = 0.5 * (Qg[(int64_t)i * n + k] + Qg[(int64_t)k * n + i]);

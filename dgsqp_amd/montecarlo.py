@@ -21,7 +21,7 @@ from .dynamics import (CasadiDecoupledMultiAgentDynamicsModel, CasadiDynamicBicy
                        CasadiKinematicBicycleCombined, CasadiKinematicUnicycle, DynamicBicycleConfig,
                        KinematicBicycleConfig, MultiAgentModelConfig, UnicycleConfig)
 from .game import (CollisionAvoidance, GoalTrackingCost, InputRateLimits, LaneBoundaries, LaneHalfPlane, RacingCost)
-from .solver_types import DGSQPParams
+from .solver_types import DGSQPParams, DGSQPV2Params
 from .tracks import ChicaneTrack, CurveTrack, get_track
 from .types import (BodyAngularVelocity, BodyLinearVelocity, OrientationEuler, ParametricPose, Position,
                     VehicleActuation, VehicleState)
@@ -94,7 +94,7 @@ def kinematic_racing_game(track_kind='chicane', theta_deg=45, N=25, reg=1e-3, M=
                 name=f'kb_{track_kind}_N{N}')
 
 
-def dynamic_racing_game(track_kind='curve', theta_deg=45, N=25, reg=1e-3, rk4_substeps=10, game_def='exact_dynamic') -> Game:
+def dynamic_racing_game(track_kind='curve', theta_deg=45, N=25, reg=1e-3, rk4_substeps=10, game_def='exact_dynamic', solver='v1') -> Game:
     """BASELINE.json config 2: 2-agent dynamic-bicycle (Pacejka) race on the curve track (curve.py:140-146), rk4 with
     M=10 sub-steps (comparison_study_barc/globals.py:17-18), vehicle of exact_dynamic_game_dynamic.py:26-66.
 
@@ -106,9 +106,15 @@ def dynamic_racing_game(track_kind='curve', theta_deg=45, N=25, reg=1e-3, rk4_su
     (:68-95); rows per stage 8 / 13 / 5.  ``game_def='curve'`` is round 1's synthetic variant -- the costs, rate rows and
     radii of the kinematic curve.py game (progress weight 10, atan competition) on the Pacejka vehicle; a third of its
     scenarios drive the open-loop rollout into |dx/du| ~ 1e17 (profiles/r02_dyn_curve_divergence.txt), it is kept as a
-    stress case."""
+    stress case.  ``solver='v2'``: the DG-SQP v2 parameters of the reference's study (comparison_study_barc/globals.py:27-55:
+    reg 1e2 decaying by 0.95, nms with frequency / memory 10, 20 line-search trials, tolerance 1e-4, up to 500 m-steps);
+    ``reg`` is then ignored.  ``track_kind='barc'`` puts the game on the study's own L_track_barc circuit."""
     dt, half_width, M = 0.1, 1.0, 2
-    track = _track(track_kind, theta_deg, half_width)
+    if track_kind == 'barc':
+        track = get_track('L_track_barc')
+        half_width = track.half_width
+    else:
+        track = _track(track_kind, theta_deg, half_width)
     cfg = lambda: DynamicBicycleConfig(dt=dt, model_name='dynamic_bicycle', noise=False, discretization_method='rk4',
                                        simple_slip=False, tire_model='pacejka', mass=2.2187, yaw_inertia=0.02723,
                                        wheel_friction=0.9, pacejka_b_front=5.0, pacejka_b_rear=5.0,
@@ -117,8 +123,14 @@ def dynamic_racing_game(track_kind='curve', theta_deg=45, N=25, reg=1e-3, rk4_su
     joint = CasadiDecoupledMultiAgentDynamicsModel(0, models, MultiAgentModelConfig(
         dt=dt, discretization_method='rk4', use_mx=False, code_gen=False, verbose=False, compute_hessians=True,
         M=rk4_substeps))
-    params = DGSQPParams(solver_name='DGSQP', dt=dt, N=N, reg=reg, nonmono_ls=True, line_search_iters=50,
-                         sqp_iters=50, p_tol=1e-3, d_tol=1e-3, beta=0.01, tau=0.5, verbose=False)
+    if solver == 'v2':
+        params = DGSQPV2Params(solver_name='DGSQP', dt=dt, N=N, nms=True, nms_frequency=10, nms_memory_size=10, line_search_iters=20,
+                               sqp_iters=500, p_tol=1e-4, d_tol=1e-4, reg=1e2, reg_decay=0.95, delta_decay=0.99, merit_decrease=0.01,
+                               beta=0.01, tau=0.5, time_limit=600, verbose=False, merit_function='stat_l1',
+                               merit_decrease_condition='armijo', merit_parameter=None)
+    else:
+        params = DGSQPParams(solver_name='DGSQP', dt=dt, N=N, reg=reg, nonmono_ls=True, line_search_iters=50,
+                             sqp_iters=50, p_tol=1e-3, d_tol=1e-3, beta=0.01, tau=0.5, verbose=False)
     if game_def == 'exact_dynamic':
         r = 0.23
         cost = lambda: RacingCost(input_weight=(1.0, 1.0), input_rate_weight=(1.0, 1.0), comp_weights=(1.0, 5.0),
@@ -132,7 +144,8 @@ def dynamic_racing_game(track_kind='curve', theta_deg=45, N=25, reg=1e-3, rk4_su
     else:
         raise ValueError(game_def)
     return Game(joint, [cost() for _ in range(M)], rows, CollisionAvoidance([r] * M), _bounds(half_width, M), params, track,
-                half_width, 2 * r, name=f'dyn_{track_kind}_N{N}' + ('' if game_def == 'exact_dynamic' else '_' + game_def))
+                half_width, 2 * r, name=f'dyn_{track_kind}_N{N}' + ('' if game_def == 'exact_dynamic' else '_' + game_def) + ('_v2' if solver == 'v2' else ''),
+                sampler='circuit' if track_kind == 'barc' else 'first_segment')
 
 
 def barc_racing_game(N=15, M=2, reg=0.0) -> Game:

@@ -19,7 +19,7 @@ import numpy as np
 from . import _ffi
 from .dynamics import CasadiDecoupledMultiAgentDynamicsModel, INTEGRATORS
 from .game import CollisionAvoidance, GoalTrackingCost, InputRateLimits, LaneBoundaries, RacingCost
-from .solver_types import DGSQPParams
+from .solver_types import DGSQPParams, DGSQPV2Params
 from .types import VehiclePrediction, VehicleState
 
 
@@ -150,6 +150,8 @@ def build_params(params: DGSQPParams, eig_floor: Optional[float] = None, snap_ac
     with its classical (J = L^-T) active-set kernels; passing a larger floor (1e-6) is an explicit opt-in that keeps such games
     on the faster explicit-inverse kernels.  ``snap_active_bounds``: see include/dgsqp.h (default literal).
     ``lsqr_tol``: atol = btol of the LSQR dual start; ``None`` = scipy's defaults (1e-6), what ``DGSQP.py:324`` runs with."""
+    if isinstance(params, DGSQPV2Params):
+        return _build_params_v2(params, eig_floor, snap_active_bounds, lsqr_tol, qp_warm_start)
     if not params.conv_approx:
         raise NotImplementedError('conv_approx=False (IPOPT Newton step, DGSQP.py:204-228) is not on the Monte-Carlo path')
     if params.hessian_approximation not in ('none', 'bfgs'):
@@ -168,6 +170,38 @@ def build_params(params: DGSQPParams, eig_floor: Optional[float] = None, snap_ac
     p.time_limit = -1.0 if params.time_limit is None else float(params.time_limit)     # None -> no limit (DGSQP.py:64-67)
     p.eig_floor = 1e-10 if eig_floor is None else float(eig_floor)
     p.snap_active_bounds = int(bool(snap_active_bounds))
+    return p
+
+
+def _build_params_v2(params: DGSQPV2Params, eig_floor, snap_active_bounds, lsqr_tol, qp_warm_start) -> _ffi.ParamsT:
+    """DGSQPV2Params -> dgsqp_params_t for DG-SQP v2 (reference DGSQP/solvers/DGSQP_v2.py:66-222)."""
+    if params.merit_function != 'stat_l1':
+        raise NotImplementedError(f"merit_function {params.merit_function!r}: only 'stat_l1' (the setting of scripts/comparison_study_barc) is built; "
+                                  "'sum_obj_l1' (DGSQP_v2.py:1156-1159) needs the full cost gradients")
+    if params.merit_decrease_condition not in ('armijo', 'max'):
+        raise ValueError(f'merit_decrease_condition {params.merit_decrease_condition!r} not recognized')
+    if params.hessian_approximation != 'none':
+        raise ValueError(f'Hessian approximation method {params.hessian_approximation} not implmented')
+    if not 1 <= int(params.nms_memory_size) <= 16:
+        raise ValueError('nms_memory_size must be in 1..16')
+    p = _ffi.ParamsT()
+    p.variant = 1
+    p.tau, p.p_tol, p.d_tol, p.reg = params.tau, params.p_tol, params.d_tol, params.reg
+    p.beta = params.beta                   # (unused by v2's line search, which takes merit_decrease)
+    p.line_search_iters, p.sqp_iters, p.nonmono_ls = params.line_search_iters, params.sqp_iters, 0
+    p.merit_function = 0
+    p.rel_tol_req = 10                     # DGSQP_v2.py:84
+    p.lsqr_iter_lim = 0
+    p.lsqr_atol = p.lsqr_btol = 1e-6 if lsqr_tol is None else float(lsqr_tol)
+    p.qp_warm_start = int(bool(qp_warm_start))
+    p.hessian_bfgs = 0
+    p.time_limit = -1.0 if params.time_limit is None else float(params.time_limit)
+    p.eig_floor = 1e-10 if eig_floor is None else float(eig_floor)
+    p.snap_active_bounds = int(bool(snap_active_bounds))
+    p.nms, p.nms_frequency, p.nms_memory_size = int(bool(params.nms)), int(params.nms_frequency), int(params.nms_memory_size)
+    p.merit_decrease_condition = 0 if params.merit_decrease_condition == 'armijo' else 1
+    p.reg_decay, p.delta_decay, p.merit_decrease = float(params.reg_decay), float(params.delta_decay), float(params.merit_decrease)
+    p.merit_parameter = -1.0 if params.merit_parameter is None else float(params.merit_parameter)
     return p
 
 
@@ -443,6 +477,7 @@ class DGSQP(AbstractSolver):
             self.set_iterate_log(0)
         self.q_pred = res['x'][0]
         self.u_pred = res['u_pred'][0]
+        self._last_u_agent_major = res['u'][0]
         self.l_pred = res['l'][0]
         msg = res['msg'][0]
         cond = dict(p_feas=float(res['cond'][0, 0]), comp=float(res['cond'][0, 1]), stat=float(res['cond'][0, 2]))

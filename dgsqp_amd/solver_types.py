@@ -63,3 +63,46 @@ class DGSQPParams(ControllerConfig):
     debug_plot: bool = False
     pause_on_plot: bool = False
     local_pos: bool = False
+
+
+@dataclass
+class DGSQPV2Params(ControllerConfig):
+    """Reference DGSQP/solvers/solver_types.py:130-175 (field names and defaults identical)."""
+    N: int = 10
+    beta: float = 0.25
+    tau: float = 0.5
+    p_tol: float = 1e-4
+    d_tol: float = 1e-4
+    reg: float = 1e2
+    reg_decay: float = 0.95
+    line_search_iters: int = 50
+    nms: bool = True
+    nms_frequency: int = 5
+    nms_memory_size: int = 3
+    sqp_iters: int = 500
+    merit_function: str = 'stat_l1'
+    merit_parameter: float = None
+    merit_decrease: float = 0.01
+    merit_decrease_condition: str = 'armijo'
+    approximation_eval: str = 'always'
+    delta_decay: float = 0.95
+    verbose: bool = False
+    save_iter_data: bool = False
+    save_qp_data: bool = False
+    time_limit: float = None
+    code_gen: bool = False
+    jit: bool = False
+    opt_flag: str = 'O0'
+    enable_jacobians: bool = True
+    solver_name: str = 'DGSQP'
+    solver_dir: str = None
+    so_name: str = None
+    qp_interface: str = 'casadi'
+    qp_solver: str = 'osqp'
+    hessian_approximation: str = 'none'
+    debug: bool = False
+    debug_plot: bool = False
+    pause_on_plot: bool = False
+    save_plot: bool = False
+    show_ts: bool = False
+    local_pos: bool = False

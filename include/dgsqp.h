@@ -137,6 +137,10 @@ typedef struct {
   dgsqp_agent_t agents[DGSQP_MAX_AGENTS];
 } dgsqp_problem_t;
 
+#define DGSQP_VARIANT_V1 0
+#define DGSQP_VARIANT_V2 1
+#define DGSQP_DECREASE_ARMIJO 0
+#define DGSQP_DECREASE_MAX 1
 /* DGSQPParams (solver_types.py:91-127), numeric subset used by solve() */
 typedef struct {
   double beta, tau, p_tol, d_tol, reg;
@@ -166,7 +170,20 @@ typedef struct {
                              (sign random); the rows are linear, the next iterate inherits that residual and _get_mu switches
                              on the sign of sum(g - s) with threshold 0 (DGSQP.py:559-585) -- a coin flip in the reference
                              itself; 1 makes it deterministic (mu = 0 when nothing else is violated). */
+  int32_t variant;        /* DGSQP_VARIANT_V1: DGSQP/solvers/DGSQP.py (the fields above).  DGSQP_VARIANT_V2: DGSQP/solvers/DGSQP_v2.py
+                             :322-720 -- d-step / m-step non-monotone strategy with checkpoints, decaying regularisation, merit
+                             memory; p_tol/d_tol, reg (= reg_init), tau, line_search_iters, sqp_iters (counts m-steps), rel_tol_req
+                             (10), time_limit and the LSQR / QP knobs above keep their meaning; beta and nonmono_ls are unused */
+  /* DGSQPV2Params (solver_types.py:130-175) */
+  int32_t nms;                       /* non-monotone strategy on (d-steps / m-steps) */
+  int32_t nms_frequency;             /* m-step at the latest after this many d-steps (nms_mstep_frequency) */
+  int32_t nms_memory_size;           /* length of the merit memory (<= 16) */
+  int32_t merit_decrease_condition;  /* DGSQP_DECREASE_ARMIJO / DGSQP_DECREASE_MAX (DGSQP_v2.py:731-737) */
   int32_t reserved_;
+  double reg_decay;                  /* reg <- reg * reg_decay after every m-step / line-search step */
+  double delta_decay;                /* gamma: d-step radius decay */
+  double merit_decrease;             /* sigma */
+  double merit_parameter;            /* mu; < 0: adaptive (DGSQPV2Params.merit_parameter = None, _get_mu DGSQP_v2.py:665-690) */
 } dgsqp_params_t;
 
 /* PID lane follower used for the Monte-Carlo warm start (DGSQP/solvers/PID.py through

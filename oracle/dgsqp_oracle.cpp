@@ -1262,6 +1262,192 @@ static void solve_one(const dgsqp_problem_t& P, const dgsqp_params_t& par, const
   out.cond[0] = p_feas; out.cond[1] = comp; out.cond[2] = stat;
 }
 
+
+// -----------------------------------------------------------------------------
+// DG-SQP v2: solve (DGSQP_v2.py:322-720), _solve_qp (:253-284), _get_mu (:665-690), load_checkpoint (:692-712),
+// line_search (:727-755), merit functions 'stat_l1' (:1141-1160).  Trace codes as in v1; 40 carries 1.0 per iteration.
+// -----------------------------------------------------------------------------
+struct V2Rec { vec u, du, l, dl; double mu = 0; bool has_step = false; };
+static double v2_phi(const Layout& L, const vec& l, const vec& q, const vec& G, const vec& g, double mu) {
+  // f_phi = 1/2 |q + G'l|^2 + mu sum(s), s = max(0, g) supplied by every caller as max(0, g) of the same point
+  const int n = L.n, nc = L.nc;
+  double sq = 0, vio = 0;
+  for (int c = 0; c < n; c++) { double d = q[c]; for (int r = 0; r < nc; r++) d += G[(size_t)r * n + c] * l[r]; sq += d * d; }
+  for (int r = 0; r < nc; r++) vio += std::max(0.0, g[r]);
+  return 0.5 * sq + mu * vio;
+}
+static double v2_dstat(const Layout& L, const vec& du, const vec& l, const vec& dl, const Lin& k) {
+  // d/d(u,l) [1/2 |stat|^2] . (du, dl) = d'(Q du + G' dl) with the raw game Hessian Q (rows a of Duu L^a) at (u, l)
+  const int n = L.n, nc = L.nc;
+  double a = 0;
+  for (int i = 0; i < n; i++) {
+    double d = k.q[i], t = 0;
+    for (int r = 0; r < nc; r++) { d += k.G[(size_t)r * n + i] * l[r]; t += k.G[(size_t)r * n + i] * dl[r]; }
+    for (int j = 0; j < n; j++) t += k.Q[(size_t)i * n + j] * du[j];
+    a += d * t;
+  }
+  return a;
+}
+static bool v2_solve_qp(const Ctx& c, const Lin& k, double reg, vec& du, vec& lhat) {
+  vec Qpd;
+  nearest_pd(c.L.n, k.Q.data(), reg, Qpd, c.par.eig_floor);
+  du.assign(c.L.n, 0.0); lhat.assign(c.L.nc, 0.0);
+  return qp_gi(c.L.n, c.L.nc, Qpd.data(), k.q.data(), k.G.data(), k.g.data(), du.data(), lhat.data()) == 0;
+}
+static double v2_line_search(const Ctx& c, vec& u, const vec& du, vec& l, const vec& dl, double mu, const std::vector<double>& mem) {
+  const dgsqp_params_t& par = c.par;
+  const double sigma = par.merit_decrease;
+  double phi_b = 0, dphi_b = 0, memmax = *std::max_element(mem.begin(), mem.end());
+  if (par.merit_decrease_condition == DGSQP_DECREASE_ARMIJO) {
+    Lin b;
+    eval_lin(c, u, l, true, b);
+    double vio = 0;
+    for (int r = 0; r < c.L.nc; r++) vio += std::max(0.0, b.g[r]);
+    phi_b = v2_phi(c.L, l, b.q, b.G, b.g, mu);                       // s of the iterate = max(0, g) there
+    dphi_b = v2_dstat(c.L, du, l, dl, b) - mu * vio;
+  }
+  double a = 1.0, phi1 = 0;
+  vec ut, lt;
+  for (int i = 0; i < par.line_search_iters; i++) {
+    ut = axpy(u, a, du); lt = axpy(l, a, dl);
+    Lin t;
+    eval_lin(c, ut, lt, false, t);
+    const double phi = v2_phi(c.L, lt, t.q, t.G, t.g, mu);
+    const double R = par.merit_decrease_condition == DGSQP_DECREASE_MAX ? (1 - sigma * a) * memmax : phi_b + sigma * a * dphi_b;
+    ::tr(c, 30, a); ::tr(c, 31, phi);
+    phi1 = v2_phi(c.L, lt, t.q, t.G, t.g, 1.0);
+    if (phi <= R) break;
+    a *= par.tau;
+  }
+  u = ut; l = lt;
+  return phi1;
+}
+static void solve_one_v2(const dgsqp_problem_t& P, const dgsqp_params_t& par, const Layout& L, const double* x0, const double* u_ws, int literal, SolveOut& out, vec* trace = nullptr) {
+  Ctx c{P, par, L, x0, literal, trace};
+  const auto t_start = std::chrono::steady_clock::now();
+  vec u(u_ws, u_ws + L.n), l;
+  Eval ev0;
+  {
+    vec l0(L.nc, 0.0);
+    evaluate(P, L, u.data(), l0.data(), x0, false, literal, ev0);
+    dual_init(par, L, ev0, l);
+  }
+  out.l_init = l;
+  vec u_im1 = u, l_im1 = l;
+  std::vector<double> mem;                                     // deque(maxlen = nms_memory_size)
+  const size_t mem_size = (size_t)std::max(1, std::min(16, par.nms_memory_size));
+  auto mem_append = [&](double v) { if (mem.size() == mem_size) mem.erase(mem.begin()); mem.push_back(v); };
+  mem_append(v2_phi(L, l, ev0.q, ev0.G, ev0.g, 1.0));
+  double reg = par.reg, delta = 0, ckpt_delta = 0, ckpt_reg = reg;
+  int ckpt_counter = 0, ckpt_index = 0, sqp_it = 0, m_step_it = 0, rel_tol_its = 0, total_qp = 0, status = DGSQP_MAX_IT;
+  bool finished = false;
+  double p_feas = 0, comp = 0, stat = 0;
+  std::vector<V2Rec> iter_data;
+  while (true) {
+    Lin k;
+    eval_lin(c, u, l, true, k);
+    p_feas = 0; comp = 0; stat = 0;
+    double gmax = -INF;
+    for (int r = 0; r < L.nc; r++) { gmax = std::max(gmax, k.g[r]); comp = std::max(comp, std::fabs(k.g[r] * l[r])); }
+    p_feas = std::max(0.0, gmax);
+    for (int cc = 0; cc < L.n; cc++) { double d = k.q[cc]; for (int r = 0; r < L.nc; r++) d += k.G[(size_t)r * L.n + cc] * l[r]; stat = std::max(stat, std::fabs(d)); }
+    tr(c, 1, stat); tr(c, 2, p_feas); tr(c, 3, comp);
+    if (stat > 1e10) { finished = true; status = DGSQP_DIVERGED; }
+    if (p_feas < par.p_tol && comp < par.d_tol && stat < par.d_tol) { finished = true; status = DGSQP_CONV_ABS_TOL; }
+    if (m_step_it >= par.sqp_iters) { finished = true; status = DGSQP_MAX_IT; }
+    if (par.time_limit >= 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > par.time_limit) { finished = true; status = DGSQP_TIME_LIMIT; }
+    if (finished) { tr(c, 40, 0.0); break; }
+    V2Rec cur;
+    cur.u = u; cur.l = l;
+    vec du, lhat, dl;
+    const bool ok = v2_solve_qp(c, k, reg, du, lhat);
+    total_qp++;
+    bool d_step = false, m_step = false;
+    double mu = 0;
+    if (!ok) {
+      if (!par.nms || iter_data.empty()) { tr(c, 40, 1.0); status = DGSQP_QP_FAIL; break; }
+      m_step = true;
+      const int idx = std::min(ckpt_index, (int)iter_data.size() - 1);
+      cur = iter_data[idx];
+      u = cur.u; du = cur.du; l = cur.l; dl = cur.dl; mu = cur.mu;
+    } else {
+      dl.resize(L.nc);
+      for (int r = 0; r < L.nc; r++) dl[r] = lhat[r] - l[r];
+      double nrm = 0;
+      for (double e : du) nrm += e * e;
+      for (double e : dl) nrm += e * e;
+      nrm = std::sqrt(nrm);
+      if (sqp_it == 0) { delta = 20.0 * nrm; ckpt_delta = delta; }
+      if (par.nms) {
+        if (ckpt_counter >= par.nms_frequency) m_step = true;
+        else if (nrm < delta) d_step = true;
+        else m_step = true;
+      }
+      double vio = 0;
+      for (int r = 0; r < L.nc; r++) vio += std::max(0.0, k.g[r]);
+      if (par.merit_parameter < 0.0) {
+        const double d = v2_dstat(L, du, l, dl, k);
+        mu = vio > 0 ? std::fabs(d) / (0.5 * vio) : 0.0;
+      } else mu = par.merit_parameter;
+      tr(c, 10, nrm * nrm); tr(c, 11, mu);
+      cur.du = du; cur.dl = dl; cur.mu = mu; cur.has_step = true;
+    }
+    double phi_new = 0;
+    if (d_step) {
+      u = axpy(u, 1.0, du); l = axpy(l, 1.0, dl);
+      delta *= par.delta_decay;
+      ckpt_counter++;
+    }
+    if (m_step || (!d_step && !m_step)) {
+      bool accept = false;
+      if (m_step) {
+        m_step_it++;
+        vec un = axpy(u, 1.0, du), ln = axpy(l, 1.0, dl);
+        Lin t;
+        eval_lin(c, un, ln, false, t);
+        const double phi = v2_phi(L, ln, t.q, t.G, t.g, 1.0);
+        const double R = (1 - par.merit_decrease) * *std::max_element(mem.begin(), mem.end());
+        tr(c, 20, phi);
+        if (phi <= R) { accept = true; phi_new = phi; u = un; l = ln; }
+        else if (ckpt_index <= (int)iter_data.size() - 1) {
+          cur = iter_data[ckpt_index];
+          u = cur.u; du = cur.du; l = cur.l; dl = cur.dl; mu = cur.mu;
+          delta = ckpt_delta;
+          reg = ckpt_reg;
+        }
+      }
+      if (!accept) {
+        phi_new = v2_line_search(c, u, du, l, dl, mu, mem);
+        tr(c, 22, phi_new);
+      }
+      double du2 = 0, dl2 = 0;
+      for (int i = 0; i < L.n; i++) du2 += (u[i] - u_im1[i]) * (u[i] - u_im1[i]);
+      for (int i = 0; i < L.nc; i++) dl2 += (l[i] - l_im1[i]) * (l[i] - l_im1[i]);
+      if (std::sqrt(du2) < par.p_tol && std::sqrt(dl2) < par.d_tol) {
+        rel_tol_its++;
+        if (rel_tol_its >= par.rel_tol_req && p_feas < par.p_tol) { finished = true; status = DGSQP_CONV_REL_TOL; }
+      } else rel_tol_its = 0;
+      u_im1 = u; l_im1 = l;
+      reg *= par.reg_decay;
+      mem_append(phi_new);
+      if (m_step) { ckpt_counter = 0; ckpt_delta = delta; ckpt_reg = reg; ckpt_index = sqp_it + 1; }
+    }
+    tr(c, 40, 1.0);
+    iter_data.push_back(cur);
+    sqp_it++;
+  }
+  out.u = u; out.l = l;
+  rollout(P, L, u.data(), x0, out.x);
+  costs(P, L, u.data(), out.x, out.cost);
+  out.status = status; out.iters = sqp_it; out.qp_solves = total_qp;
+  out.cond[0] = p_feas; out.cond[1] = comp; out.cond[2] = stat;
+}
+
+static void solve_any(const dgsqp_problem_t& P, const dgsqp_params_t& par, const Layout& L, const double* x0, const double* u_ws, int literal, SolveOut& out, vec* trace = nullptr) {
+  if (par.variant == DGSQP_VARIANT_V2) solve_one_v2(P, par, L, x0, u_ws, literal, out, trace);
+  else solve_one(P, par, L, x0, u_ws, literal, out, trace);
+}
+
 // =============================================================================
 // C entry points (tests / bench cpu_baseline only)
 // =============================================================================
@@ -1386,7 +1572,7 @@ int oracle_solve_trace(const dgsqp_problem_t* P, const dgsqp_params_t* par, cons
   Layout L = make_layout(*P);
   SolveOut o;
   vec t;
-  solve_one(*P, *par, L, x0, u_ws, 0, o, &t);
+  solve_any(*P, *par, L, x0, u_ws, 0, o, &t);
   int np = (int)t.size() / 2;
   if (np > max_pairs) np = max_pairs;
   for (int i = 0; i < 2 * np; i++) trace_out[i] = t[i];
@@ -1402,7 +1588,7 @@ int oracle_solve_batch(const dgsqp_problem_t* P, const dgsqp_params_t* par, int6
   auto work = [&](int64_t b0, int64_t stride) {
     for (int64_t b = b0; b < B; b += stride) {
       SolveOut o;
-      solve_one(*P, *par, L, x0 + b * L.nq, u_ws + b * L.n, literal, o);
+      solve_any(*P, *par, L, x0 + b * L.nq, u_ws + b * L.n, literal, o);
       if (u_out) std::copy(o.u.begin(), o.u.end(), u_out + b * L.n);
       if (l_out) std::copy(o.l.begin(), o.l.end(), l_out + b * L.nc);
       if (x_out) std::copy(o.x.begin(), o.x.end(), x_out + b * (int64_t)(L.N + 1) * L.nq);

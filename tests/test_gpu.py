@@ -624,6 +624,57 @@ def test_three_agents_on_the_barc_circuit(oracle, N, B):
         assert rel(res['u'][b], ref['u'][b]) < 1e-2, b
 
 
+@pytest.mark.parametrize('kind', ['dyn', 'kb'])
+def test_dgsqp_v2_matches_oracle(oracle, kind):
+    """DG-SQP v2 (DGSQP_v2.py:322-720 -- d-steps / m-steps with checkpoints, decaying regularisation,
+    merit memory, merit without the complementarity term) on the device against the oracle's restatement: the dynamic-bicycle game
+    with the parameters of the reference's study (comparison_study_barc/globals.py) and a kinematic game with the default
+    DGSQPV2Params; event logs identical event by event, flags / iteration / QP counts identical, iterates within 1e-5."""
+    import copy
+    from dgsqp_amd import montecarlo as mc
+    from dgsqp_amd.solver import build_problem, build_params
+    from dgsqp_amd.solver_types import DGSQPV2Params
+    from dgsqp_amd.solver_v2 import DGSQP as DGSQPv2
+    if kind == 'dyn':
+        g = mc.dynamic_racing_game(N=10, rk4_substeps=3, solver='v2')
+    else:
+        g = mc.kinematic_racing_game('curve', N=12)           # DGSQPV2Params defaults: rejected m-steps, checkpoint loads, line searches
+        g.params = DGSQPV2Params(dt=0.1, N=12)
+    g.params.time_limit = None
+    P, par = build_problem(*g.solver_args()), build_params(g.params, lsqr_tol=1e-13)
+    assert par.variant == 1 and par.rel_tol_req == 10
+    s = DGSQPv2(*g.solver_args(), print_method=None, lsqr_tol=1e-13)
+    B = 10
+    x0, u_tm = mc.sample_scenarios(g, B, seed=2)
+    u = agent_major(u_tm)
+    s.set_trace(20000)
+    try:
+        res = s.solve_batch(x0, u_tm)
+        traces = s.fetch_trace(B)
+    finally:
+        s.set_trace(0)
+    ref = oracle.solve_batch(P, par, x0, u, nthreads=8)
+    same = assert_control_flow_parity(res, ref, stable_mask(oracle, P, par, x0, u, ref, K=2), f'v2 {kind}')
+    assert (ref['num_iters'] > 20).all() and (ref['status'] <= 2).all()          # v2 really iterates: reg starts at 100
+    assert (ref['status'] == 0).all() if kind == 'dyn' else (ref['status'] == 1).any()
+    for b in np.where(same)[0]:
+        assert rel(res['u'][b], ref['u'][b]) < 1e-5 and rel(res['l'][b], ref['l'][b]) < 1e-4, b
+    identical = 0
+    for b in range(4):
+        to = oracle.solve_trace(P, par, x0[b], u[b], max_pairs=60000)
+        tg = traces[b]
+        if len(to) == len(tg) and np.array_equal(to[:, 0], tg[:, 0]):
+            big = np.abs(to[:, 1]) > 1e-6
+            identical += int(np.all(np.abs(tg[big, 1] - to[big, 1]) <= 1e-5 * np.abs(to[big, 1])))
+    assert identical >= 3, identical
+    # the reference surface: solve() of the v2 class returns the v2 dictionary (DGSQP_v2.py:616-632)
+    states = s.joint_dynamics.qu2state(None, x0[0], None)
+    s.set_warm_start(u_tm[0])
+    info = s.solve(states)
+    assert {'primal_sol', 'dual_sol', 'x_pred', 'u_pred', 'conds', 'msg', 'num_iters', 'status'} <= set(info)
+    assert info['num_iters'] == int(res['num_iters'][0]) and np.array_equal(info['primal_sol'], res['u'][0])
+
+
 def test_bfgs_hessian_option(oracle):
     """DGSQPParams.hessian_approximation = 'bfgs' (DGSQP.py:353-364, :535-557): exact Hessian at the first iteration, damped
     BFGS updates of the projected Hessian afterwards, against the oracle; more iterations than with exact Hessians."""

@@ -351,3 +351,33 @@ def test_cpp_oracle_follows_the_numpy_loop(oracle, games):
             assert (code[s['msg']], s['num_iters'], s['qp_solves']) == (ref['status'][b], ref['num_iters'][b], ref['qp_solves'][b]), (kind, b)
             assert np.abs(s['l_init'] - ref['l_init'][b]).max() < 1e-3          # two LSQR implementations at tolerance 1e-6
             assert np.abs(s['u'] - ref['u'][b]).max() < tol * max(1.0, np.abs(ref['u'][b]).max()), (kind, b)
+
+
+def test_v2_restatement_invariants(oracle):
+    """Oracle restatement of DG-SQP v2 (DGSQP_v2.py:322-720).  With the parameters of the reference's study
+    (comparison_study_barc/globals.py:27-55) the regularisation has to decay from 100 before the steps grow: ~350 iterations, all
+    m-steps accepted, 'conv_abs_tol' with the measures below 1e-4, one QP per iteration.  With the DGSQPV2Params defaults
+    (frequency 5, memory 3) the kinematic game exercises the other branches: the m-step's merit test fails, the watchdog returns to
+    the checkpoint, the Armijo search along a heavily regularised step makes no progress and after rel_tol_req = 10 such m-steps
+    the solve ends with 'conv_rel_tol' (DGSQP_v2.py:549-556) -- 60 iterations = 10 x (5 d-steps + 1 m-step)."""
+    from dgsqp_amd import montecarlo as mc
+    from dgsqp_amd.solver import build_problem, build_params
+    from dgsqp_amd.solver_types import DGSQPV2Params
+    g = mc.kinematic_racing_game('curve', N=8)
+    g.params = DGSQPV2Params(dt=0.1, N=8)
+    P, par = build_problem(*g.solver_args()), build_params(g.params)
+    assert (par.variant, par.nms, par.nms_frequency, par.nms_memory_size, par.merit_decrease_condition) == (1, 1, 5, 3, 0)
+    assert (par.reg, par.reg_decay, par.delta_decay, par.merit_decrease, par.merit_parameter) == (100.0, 0.95, 0.95, 0.01, -1.0)
+    x0, u_tm = mc.sample_scenarios(g, 6, seed=3)
+    u = agent_major(u_tm)
+    res = oracle.solve_batch(P, par, x0, u, nthreads=6)
+    stalled = res['status'] == 1
+    assert stalled.sum() >= 3 and (res['num_iters'][stalled] == 60).all() and (res['cond'][stalled, 2] > 1e-2).all()
+    g.params = DGSQPV2Params(dt=0.1, N=8, nms=True, nms_frequency=10, nms_memory_size=10, line_search_iters=20, sqp_iters=500, reg=1e2,
+                             reg_decay=0.95, delta_decay=0.99, merit_decrease=0.01, beta=0.01, tau=0.5)
+    res = oracle.solve_batch(P, build_params(g.params), x0, u, nthreads=6)
+    assert (res['status'] == 0).all() and (res['num_iters'] > 200).all() and (res['cond'] < 1e-4).all()
+    assert (res['qp_solves'] == res['num_iters']).all()            # one QP per iteration; the final iteration only tests convergence
+    with pytest.raises(NotImplementedError):
+        g.params.merit_function = 'sum_obj_l1'
+        build_params(g.params)

@@ -26,7 +26,7 @@ def param_defaults():
     from DGSQP.solvers import solver_types as rst
     from DGSQP.dynamics import model_types as rmt
     sys.path.remove(str(ref))
-    out = {'DGSQPParams': defaults(rst.DGSQPParams), 'PIDParams': defaults(rst.PIDParams),
+    out = {'DGSQPParams': defaults(rst.DGSQPParams), 'DGSQPV2Params': defaults(rst.DGSQPV2Params), 'PIDParams': defaults(rst.PIDParams),
            'KinematicBicycleConfig': defaults(rmt.KinematicBicycleConfig),
            'DynamicBicycleConfig': defaults(rmt.DynamicBicycleConfig)}
     (GOLD / 'param_defaults.json').write_text(json.dumps(out, indent=1, sort_keys=True))
