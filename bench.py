@@ -36,6 +36,9 @@ WORKLOADS = {
     'dyn_curve_N25': dict(desc='2-agent dynamic-bicycle (Pacejka, rk4 M=10) curve track, N=25, game of exact_dynamic_game_dynamic.py (cost_setting 0), fp64', kind='dyn', track='curve', N=25, reg=1e-3),
     # round 1's synthetic variant of it (costs / rate rows of curve.py on the Pacejka vehicle): a third of the scenarios diverge numerically
     'dyn_curve_N25_stress': dict(desc='2-agent dynamic-bicycle curve track, N=25, curve.py costs and rate rows (round-1 definition), fp64', kind='dyn', track='curve', N=25, reg=1e-3, game_def='curve'),
+    # DG-SQP v2 on the dynamic-bicycle game, as the reference itself pairs them (comparison_study_barc: exact_dgsqp.py + globals.py), L_track_barc circuit
+    'dyn_barc_N25_v2': dict(desc='2-agent dynamic-bicycle (Pacejka, rk4 M=10) race on the L_track_barc circuit, N=25, DG-SQP v2 with the parameters of comparison_study_barc/globals.py, fp64', kind='dyn', track='barc', N=25, reg=None, solver='v2'),
+    'dyn_curve_N25_v2': dict(desc='2-agent dynamic-bicycle curve track, N=25, DG-SQP v2 (comparison_study_barc/globals.py parameters), fp64', kind='dyn', track='curve', N=25, reg=None, solver='v2'),
     # the reference's own Monte-Carlo experiment (scripts/DGSQP_ALGAMES_monte_carlo_curve.py), kinematic bicycle
     'kb_curve_N25': dict(desc='2-agent kinematic-bicycle (euler) curve track, N=25, reg=0 (curve.py:161), fp64', kind='kb', track='curve', N=25, reg=0.0),
     'kb_chicane_N25': dict(desc='2-agent kinematic-bicycle (euler) chicane track, N=25, reg=1e-3 (chicane.py:164), fp64', kind='kb', track='chicane', N=25, reg=1e-3),
@@ -53,7 +56,11 @@ def make_game(name, reg=None):
     w = WORKLOADS[name]
     reg = w['reg'] if reg is None else reg
     if w['kind'] == 'dyn':
-        return dynamic_racing_game(w['track'], N=w['N'], rk4_substeps=10, reg=reg, game_def=w.get('game_def', 'exact_dynamic'))
+        g = dynamic_racing_game(w['track'], N=w['N'], rk4_substeps=10, reg=reg if reg is not None else 1e-3, game_def=w.get('game_def', 'exact_dynamic'),
+                                solver=w.get('solver', 'v1'))
+        if w.get('solver') == 'v2':
+            g.params.time_limit = None          # wall-clock limits make a benchmark irreproducible; the study's 600 s is never reached here
+        return g
     if w['kind'] == 'barc':
         from dgsqp_amd.montecarlo import barc_racing_game
         return barc_racing_game(N=w['N'], M=w['M'], reg=reg)

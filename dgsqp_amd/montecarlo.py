@@ -425,7 +425,7 @@ def _sample_scenarios_circuit(game: Game, B: int, seed: int, max_rounds: int):
             xy = np.array([track.local_to_global((si, ei_, pi_))[:2] for si, ei_, pi_ in zip(s_, ey, ep)]).reshape(-1, 2)
             q = np.zeros((n, mdl.n_q))
             q[:, 0], q[:, 1], q[:, 2] = xy[:, 0], xy[:, 1], v
-            q[:, mdl.s_idx], q[:, mdl.ey_idx], q[:, 3] = s_, ey, ep
+            q[:, mdl.s_idx], q[:, mdl.ey_idx], q[:, 3 if mdl.model_id == 0 else 5] = s_, ey, ep      # e_psi: state 3 (kinematic) / 5 (dynamic)
             qw, uw = pid_warm_start(mdl, q, N, dt, du=du)
             q0.append(q); q_ws.append(qw); u_ws.append(uw)
         keep = np.ones(n, bool)

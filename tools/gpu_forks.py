@@ -31,7 +31,10 @@ res = s.solve_batch(x0, u_tm)
 traces = s.fetch_trace(B)
 s.set_trace(0)
 same = (res['status'] == gold['status']) & (res['num_iters'] == gold['num_iters']) & (res['qp_solves'] == gold['qp_solves'])
-print(f'{name}: identical {same.sum()}/{B}; converged device {np.mean(res["status"] <= 1):.3f} oracle {np.mean(gold["status"] <= 1):.3f}')
+stable = gold['stable'] if 'stable' in gold else np.ones(B, bool)
+print(f'{name}: identical {same.sum()}/{B}; oracle reproduces itself under 1e-13 input perturbations on {stable.sum()}/{B}; identical among those '
+      f'{same[stable].sum()}/{stable.sum()}; converged device {np.mean(res["status"] <= 1):.3f} oracle {np.mean(gold["status"] <= 1):.3f}')
+print('fork table: scenario | oracle-stable | device (status, iters, QPs) | oracle | first differing event | cause')
 names = {40: 'qp solves of the iteration', 1: 'stat', 2: 'p_feas', 3: 'comp', 10: '|du|^2', 11: 'mu', 12: 'phi', 13: 'dphi', 20: 'wd phi1', 21: 'wd phi_n', 22: 'wd phi_n2', 30: 'ls alpha', 31: 'ls phi'}
 u_am = agent_major(u_tm) if u_tm.shape[2] == 4 else np.concatenate([u_tm[:, :, 2 * a:2 * a + 2].reshape(B, -1) for a in range(u_tm.shape[2] // 2)], axis=1)
 for b in np.nonzero(~same)[0]:
@@ -41,6 +44,17 @@ for b in np.nonzero(~same)[0]:
     while k < min(len(to), len(tg)) and to[k, 0] == tg[k, 0] and abs(tg[k, 1] - to[k, 1]) <= tol * max(abs(to[k, 1]), 1e-9):
         k += 1
     it = int((to[:k, 0] == 1).sum()) - 1
+    # classification of the first differing event
+    ev = names.get(int(to[k, 0]), '?') if k < len(to) else 'end'
+    pf = [to[j, 1] for j in range(k, -1, -1) if j < len(to) and int(to[j, 0]) == 2][:1]
+    pfd = [tg[j, 1] for j in range(min(k, len(tg) - 1), -1, -1) if int(tg[j, 0]) == 2][:1]
+    if ev == 'mu' and pf and pfd and max(pf[0], pfd[0]) < 1e-12:
+        cause = 'mu switch: _get_mu tests sum(g - s) > 0 (threshold 0, DGSQP.py:559-585) on a rounding-level sum (p_feas %.1e / %.1e)' % (pf[0], pfd[0])
+    else:
+        st = [to[j, 1] for j in range(k, -1, -1) if j < len(to) and int(to[j, 0]) == 1][:1]
+        cause = 'rounding amplified over the iterations (values agree to %.0e at the fork; stat %.2g, p_feas %.2g at that iterate)' % (
+            abs(tg[k, 1] - to[k, 1]) / max(abs(to[k, 1]), 1e-300) if k < min(len(to), len(tg)) else float('nan'), st[0] if st else float('nan'), pf[0] if pf else float('nan'))
+    print(f'| {b} | {bool(stable[b])} | {(int(res["status"][b]), int(res["num_iters"][b]), int(res["qp_solves"][b]))} | {(int(gold["status"][b]), int(gold["num_iters"][b]), int(gold["qp_solves"][b]))} | event {k} = {ev} in SQP iteration {it} | {cause} |')
     print(f'scn {b}: device (status {res["status"][b]}, iters {res["num_iters"][b]}, qps {res["qp_solves"][b]}) oracle ({gold["status"][b]}, {gold["num_iters"][b]}, {gold["qp_solves"][b]}) | events dev {len(tg)} oracle {len(to)} | agree for {k} events (SQP iteration {it})')
     for j in range(max(0, k - 4), min(k + 3, max(len(to), len(tg)))):
         eo = f'{names.get(int(to[j, 0]), int(to[j, 0]))} {to[j, 1]:.10e}' if j < len(to) else '-'
