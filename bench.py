@@ -47,6 +47,7 @@ WORKLOADS = {
     'kb_barc3_N25': dict(desc='3-agent kinematic-bicycle race on the L_track_barc circuit, N=25, reg=0 (BASELINE configs[2] game), XL layout, fp64', kind='barc', M=3, N=25, reg=0.0),
     'merge_N20': dict(desc='3-car highway merge, kinematic unicycles rk3, N=20, reg=0 (DGSQP_merge_monte_carlo.py), big layout, fp64', kind='merge', N=20, reg=0.0),
     'kb_curve_N50': dict(desc='2-agent kinematic-bicycle curve track, N=50, reg=1e-3 (BASELINE configs[3] size on the curve track), XL layout, fp64', kind='kb', track='curve', N=50, reg=1e-3),
+    'kb_f1_N50': dict(desc='2-agent kinematic-bicycle race on the F1 track (cubic-spline centre line), N=50, reg=1e-3 (BASELINE configs[3] game), XL layout, fp64', kind='f1', N=50, reg=1e-3),
     'kb_curve3_N25': dict(desc='3-agent kinematic-bicycle curve track, N=25, reg=1e-3 (DGSQP_monte_carlo_agents.py M=3 N=25 = BASELINE configs[2] size), XL layout, fp64', kind='kb', track='curve', N=25, M=3, reg=1e-3),
 }
 
@@ -64,6 +65,9 @@ def make_game(name, reg=None):
     if w['kind'] == 'barc':
         from dgsqp_amd.montecarlo import barc_racing_game
         return barc_racing_game(N=w['N'], M=w['M'], reg=reg)
+    if w['kind'] == 'f1':
+        from dgsqp_amd.montecarlo import f1_racing_game
+        return f1_racing_game(N=w['N'], reg=reg)
     if w['kind'] == 'merge':
         from dgsqp_amd.montecarlo import merge_game
         return merge_game(N=w['N'], reg=reg)

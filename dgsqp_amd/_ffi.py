@@ -8,6 +8,7 @@ import ctypes as C
 import os
 import pathlib
 
+MAX_KNOTS = 1152
 MAX_AGENTS = 6
 MAX_SEGS = 16
 MAX_NQA = 8
@@ -51,6 +52,7 @@ class ProblemT(C.Structure):
         ('seg_s', C.c_double * (MAX_SEGS + 1)), ('seg_curv', C.c_double * MAX_SEGS),
         ('seg_ang', C.c_double * (MAX_SEGS + 1)),
         ('agents', AgentT * MAX_AGENTS),
+        ('track_kind', C.c_int32), ('n_knots', C.c_int32), ('spline', C.c_uint64),     # const double*: kept as an integer so that the POD stays copyable / picklable
     ]
 
 

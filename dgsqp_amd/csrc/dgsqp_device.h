@@ -402,6 +402,32 @@ __device__ inline void dev_track(const dgsqp_problem_t& P, const Ty<DEG>& s, dou
   psi = (s + (sbar - s.c[0] - tt[seg])) * tt[3 * S1 + seg] + tt[2 * S1 + seg];
 }
 
+// Cubic-spline centre line (CasadiBSplineTrack, casadi_bspline_track.py:122-149; BASELINE configs[3]'s F1 track): curvature
+// (x'y'' - y'x'') / (x'^2 + y'^2)^1.5 and tangent atan2(y', x') of the piecewise cubics x(s), y(s), evaluated in Taylor
+// arithmetic -- the derivatives of the curvature that fAd / fEd need (the fourth derivative of a cubic piece is 0) come out
+// of the propagation, no separate derivative tables.  The table (dg_prob.spl: knots, x coefficients, y coefficients) sits in
+// the per-device constant block; waypoints are close to equispaced, so the interval is found from a proportional guess.
+template <int DEG>
+__device__ inline void dev_track_spline(const dgsqp_problem_t& P, const Ty<DEG>& s, Ty<DEG>& curv, Ty<DEG>& psi) {
+  typedef Ty<DEG> T;
+  const int nk = P.n_knots;
+  const double* kn = dg_prob.spl;
+  const double sbar = wrap_s(s.c[0], P.track_L, dg_prob.inv_track_L);
+  int i = (int)(sbar * dg_prob.inv_track_L * (double)(nk - 1));
+  i = i < 0 ? 0 : (i > nk - 2 ? nk - 2 : i);
+  while (i > 0 && sbar < kn[i]) i--;
+  while (i < nk - 2 && sbar >= kn[i + 1]) i++;
+  const double* cx = dg_prob.spl + nk + 4 * i;
+  const double* cy = dg_prob.spl + nk + 4 * (nk - 1) + 4 * i;
+  const double x1 = cx[1], x2 = cx[2], x3 = cx[3], y1 = cy[1], y2 = cy[2], y3 = cy[3];
+  const T t = s + (sbar - s.c[0] - kn[i]);            // d sbar / d s = 1 (fmod)
+  const T dx = (t * (3.0 * x3) + 2.0 * x2) * t + x1, dy = (t * (3.0 * y3) + 2.0 * y2) * t + y1;
+  const T ddx = t * (6.0 * x3) + 2.0 * x2, ddy = t * (6.0 * y3) + 2.0 * y2;
+  const T n2 = dx * dx + dy * dy;
+  curv = (dx * ddy - dy * ddx) * ty_recip(n2 * ty_sqrt(n2));
+  psi = ty_atan2(dy, dx);
+}
+
 // kinematic bicycle in the Frenet frame (dynamics_models.py:1046-1070); q = [x,y,v,e_psi,s,e_y], u = [a, delta]
 // terms of f_c that depend on the (zero-order-hold) input only: evaluated once per stage, not once per rk sub-stage
 template <int DEG>
@@ -425,18 +451,20 @@ __device__ inline void dev_fc_kin(const dgsqp_problem_t& P, const dgsqp_agent_t&
   const T psidot = q[2] * sb * pre.ilr;
   T F = q[2] * (-ag.c_da) - q[2] * ty_abs(q[2]) * ag.c_dr - psidot * psidot * ag.c_s;
   if (ag.c_r != 0.0) F = F - ty_pow(ty_abs(q[2]), ag.p_r) * (q[2] / ty_sqrt(q[2] * q[2] + 1e-6)) * ag.c_r;
-  double c;
-  T psit;
-  dev_track(P, q[4], c, psit);
+  double c = 0.0;
+  T psit, cs;
+  const bool spl = P.track_kind == DGSQP_TRACK_SPLINE;     // uniform: the curvature is a Taylor value only on spline tracks
+  if (spl) dev_track_spline<DEG>(P, q[4], cs, psit);
+  else dev_track(P, q[4], c, psit);
   T s1, c1, s2, c2;
   ty_sincos(beta + psit + q[3], s1, c1);
   ty_sincos(beta + q[3], s2, c2);
-  const T inv = ty_recip(1.0 - q[5] * c);
+  const T inv = spl ? ty_recip(1.0 - q[5] * cs) : ty_recip(1.0 - q[5] * c);
   const T vlon = q[2] * c2 * inv;
   dq[0] = q[2] * c1;
   dq[1] = q[2] * s1;
   dq[2] = u[0] + F * pre.im;
-  dq[3] = psidot - vlon * c;
+  dq[3] = spl ? psidot - vlon * cs : psidot - vlon * c;
   dq[4] = vlon;
   dq[5] = q[2] * s2;
 }
@@ -446,9 +474,11 @@ template <int DEG>
 __device__ inline void dev_fc_dyn(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const Ty<DEG>* q, const Ty<DEG>* u, const FcPre<DEG>& pre, Ty<DEG>* dq) {
   typedef Ty<DEG> T;
   const T &vx = q[2], &vy = q[3], &w = q[4];
-  double c;
-  T psit;
-  dev_track(P, q[6], c, psit);
+  double c = 0.0;
+  T psit, cs;
+  const bool spl = P.track_kind == DGSQP_TRACK_SPLINE;
+  if (spl) dev_track_spline<DEG>(P, q[6], cs, psit);
+  else dev_track(P, q[6], c, psit);
   const T &sd = pre.s0, &cd = pre.c0;
   const T vyf = vy + w * ag.L_f;
   T af;
@@ -475,13 +505,13 @@ __device__ inline void dev_fc_dyn(const dgsqp_problem_t& P, const dgsqp_agent_t&
   T se, ce, st, ct;
   ty_sincos(q[5], se, ce);
   ty_sincos(q[5] + psit, st, ct);
-  const T vlon = (vx * ce - vy * se) * ty_recip(1.0 - q[7] * c);
+  const T vlon = (vx * ce - vy * se) * (spl ? ty_recip(1.0 - q[7] * cs) : ty_recip(1.0 - q[7] * c));
   dq[0] = vx * ct - vy * st;
   dq[1] = vy * ct + vx * st;
   dq[2] = ax + w * vy;
   dq[3] = ay - w * vx;
   dq[4] = (fyf * cd * ag.L_f - fyr * ag.L_r) * pre.iz;
-  dq[5] = w - vlon * c;
+  dq[5] = spl ? w - vlon * cs : w - vlon * c;
   dq[6] = vlon;
   dq[7] = vx * se + vy * ce;
 }

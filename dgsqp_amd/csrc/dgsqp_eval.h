@@ -231,7 +231,7 @@ __device__ __noinline__ void dev_rollout_multi(const Ctx& c, clptr ub, clptr du,
   // trajectory j lives at xs + j xstride for j < K1 and at xs2 + (j - K1) xstride beyond
   for (int i = TID; i < K * D.nq; i += NT) { const int j = i / D.nq; (j < K1 ? xs + j * xstride : xs2 + (j - K1) * xstride)[i % D.nq] = c.x0[i % D.nq]; }
   __syncthreads();
-  bool all_dyn = true;
+  bool all_dyn = D.P.track_kind == DGSQP_TRACK_ARCS;      // the pair rollout caches the arc segment of the track in registers
   for (int a = 0; a < D.M; a++) all_dyn = all_dyn && D.nqa[a] == 8;
   const int per = all_dyn ? 2 * D.M : D.M;
   if (TID < K * per) {
@@ -385,7 +385,7 @@ __device__ __noinline__ void dev_dyn_derivs(const Ctx& c, clptr ue) {
 #define DG_TASK 53
 __device__ inline bool dev_can_fuse_rollout() {
   const DgProb& D = dg_prob;
-  bool ok = D.P.integrator != DGSQP_INT_EULER && 2 * D.M <= 64;
+  bool ok = D.P.integrator != DGSQP_INT_EULER && 2 * D.M <= 64 && D.P.track_kind == DGSQP_TRACK_ARCS;
   for (int a = 0; a < D.M; a++) ok = ok && D.nqa[a] == 8 && D.ndir[a] == D.ndir[0];
   return ok;
 }

@@ -98,6 +98,7 @@ struct DgProb {
   int16_t stage_dense0[DG_NMAX + 2]; // first dense gradient of each stage
   DgTask dtask[DG_NTASKMAX];
   DgLds L;
+  double spl[9 * DGSQP_MAX_KNOTS];   // spline track (P.track_kind == DGSQP_TRACK_SPLINE): knots, x coefficients, y coefficients
 };
 
 #include <cmath>
@@ -227,6 +228,13 @@ static inline std::string dg_build_layout(DgProb& D) {
 static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_t& par, DgProb& D) {
   memset(&D, 0, sizeof(D));
   D.P = P; D.par = par;
+  D.P.spline = nullptr;          // the table is copied below; the host pointer is not part of the device description
+  if (P.track_kind == DGSQP_TRACK_SPLINE) {
+    if (P.n_knots < 3 || P.n_knots > DGSQP_MAX_KNOTS || !P.spline) return "bad spline track table (3 <= n_knots <= DGSQP_MAX_KNOTS)";
+    memcpy(D.spl, P.spline, sizeof(double) * (size_t)(9 * P.n_knots - 8));
+    for (int i = 0; i + 1 < P.n_knots; i++) if (!(P.spline[i + 1] > P.spline[i])) return "spline knots must increase";
+    if (P.spline[0] != 0.0 || fabs(P.spline[P.n_knots - 1] - P.track_L) > 1e-9 * P.track_L) return "spline knots must span [0, track_L]";
+  } else if (P.track_kind != DGSQP_TRACK_ARCS) return "unknown track kind";
   if (P.M < 1 || P.M > DGSQP_MAX_AGENTS) return "unsupported number of agents";
   if (P.N < 1 || P.N > DG_NMAX) return "unsupported horizon";
   if (P.N * P.M * DGSQP_NUA > 256) return "more than 256 decision variables are not supported yet";

@@ -172,6 +172,37 @@ def barc_racing_game(N=15, M=2, reg=0.0) -> Game:
                 name=f'kb_barc_M{M}_N{N}', sampler='circuit')
 
 
+def f1_racing_game(N=50, M=2, reg=1e-3, model='kinematic', rk4_substeps=10) -> Game:
+    """BASELINE.json config 4: head-to-head race on the F1 track (``f1_austin_tenth_scale``, a ``CasadiBSplineTrack`` in the
+    reference: track_lib.get_track :112-113, scripts/comparison_study_f1), long horizon N = 50.  Costs, rate limits, radii and
+    solver parameters are those of the circuit race DGSQP_comp_monte_carlo.py (as ``barc_racing_game``); lateral bounds
+    +-(half width - 0.1); ``model='dynamic'`` puts the Pacejka bicycle of the comparison studies on it (rk4)."""
+    dt = 0.1
+    track = get_track('f1_austin_tenth_scale')
+    H = track.half_width
+    if model == 'kinematic':
+        cfg = lambda: KinematicBicycleConfig(dt=dt, model_name='kinematic_bicycle', noise=False, discretization_method='euler',
+                                             wheel_dist_front=0.13, wheel_dist_rear=0.13, code_gen=False)
+        models = [CasadiKinematicBicycleCombined(0, cfg(), track=track) for _ in range(M)]
+        method, sub = 'euler', 1
+    else:
+        cfg = lambda: DynamicBicycleConfig(dt=dt, model_name='dynamic_bicycle', noise=False, discretization_method='rk4',
+                                           simple_slip=False, tire_model='pacejka', mass=2.2187, yaw_inertia=0.02723,
+                                           wheel_friction=0.9, pacejka_b_front=5.0, pacejka_b_rear=5.0,
+                                           pacejka_c_front=2.28, pacejka_c_rear=2.28, M=rk4_substeps)
+        models = [CasadiDynamicBicycleCombined(0, cfg(), track=track) for _ in range(M)]
+        method, sub = 'rk4', rk4_substeps
+    joint = CasadiDecoupledMultiAgentDynamicsModel(0, models, MultiAgentModelConfig(
+        dt=dt, discretization_method=method, use_mx=False, code_gen=False, verbose=False, compute_hessians=True, M=sub))
+    r = 0.2
+    params = DGSQPParams(solver_name='DGSQP', dt=dt, N=N, reg=reg, nonmono_ls=True, line_search_iters=50, sqp_iters=50,
+                         p_tol=1e-3, d_tol=1e-3, beta=0.01, tau=0.5, verbose=False, merit_function='stat_l1')
+    cost = lambda: RacingCost(input_weight=(0.1, 0.1), input_rate_weight=(1.0, 1.0), comp_weights=(0.0, 1.0), comp_type='atan')
+    return Game(joint, [cost() for _ in range(M)], [InputRateLimits((10.0, 4.5), (-10.0, -4.5)) for _ in range(M)],
+                CollisionAvoidance([r] * M), _bounds(H - 0.1, M), params, track, H - 0.1, 2 * r,
+                name=f'{"kb" if model == "kinematic" else "dyn"}_f1_M{M}_N{N}', sampler='circuit')
+
+
 _MERGE_GOAL_X = (4.0, 4.5, 4.25, 4.75, 5.25, 5.0)          # merge.py:85-87 for the first three cars
 _MERGE_X_NOM = (0.0, 0.5, 0.25, 1.0, 1.5, -0.35)          # merge.py:430,443,456: cars 1, 2 on the straight lane, car 3 on the ramp
 
@@ -213,12 +244,7 @@ def merge_game(N=20, reg=0.0, M=3) -> Game:
 # vectorised plant for the PID warm start
 # ---------------------------------------------------------------------------------------------
 def _track_lookup(track, s):
-    L, seg_s, seg_curv, ang = track.tables()
-    sb = np.fmod(np.fmod(s, L) + L, L)
-    idx = np.clip(np.searchsorted(seg_s, sb, side='right') - 1, 0, len(seg_curv) - 1)
-    curv = seg_curv[idx]
-    slope = (ang[idx + 1] - ang[idx]) / (seg_s[idx + 1] - seg_s[idx])
-    return curv, ang[idx] + slope * (sb - seg_s[idx])
+    return track.lookup(s)
 
 
 def _fc_batch(model, q, u):

@@ -63,6 +63,14 @@ def build_problem(joint_dynamics: CasadiDecoupledMultiAgentDynamicsModel,
     track = joint_dynamics.track
     if track is None:                       # global-frame models (unicycle): a one-segment placeholder table
         L, seg_s, seg_curv, seg_ang = 1.0, [0.0, 1.0], [0.0], [0.0, 0.0]
+    elif getattr(track, 'kind', 'arcs') == 'spline':      # CasadiBSplineTrack (F1): cubic-spline table, see include/dgsqp.h
+        table = track.spline_table()
+        if len(track.knots) > _ffi.MAX_KNOTS:
+            raise ValueError(f'spline track has {len(track.knots)} knots, limit is {_ffi.MAX_KNOTS}')
+        P.track_kind, P.n_knots = 1, len(track.knots)
+        P._spline_keepalive = table                       # the POD only borrows the host buffer
+        P.spline = table.ctypes.data
+        L, seg_s, seg_curv, seg_ang = track.track_length, [0.0, track.track_length], [0.0], [0.0, 0.0]
     else:
         L, seg_s, seg_curv, seg_ang = track.tables()
     n_segs = len(seg_curv)

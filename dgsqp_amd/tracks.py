@@ -124,6 +124,16 @@ class RadiusArclengthTrack:
     def get_halfwidth(self, s):
         return self.half_width
 
+    kind = 'arcs'
+
+    def lookup(self, s):
+        """Vectorised (curvature, tangent angle) at arclength s."""
+        L, seg_s, seg_curv, ang = self.tables()
+        sb = np.fmod(np.fmod(s, L) + L, L)
+        idx = np.clip(np.searchsorted(seg_s, sb, side='right') - 1, 0, len(seg_curv) - 1)
+        slope = (ang[idx + 1] - ang[idx]) / (seg_s[idx + 1] - seg_s[idx])
+        return seg_curv[idx], ang[idx] + slope * (sb - seg_s[idx])
+
     # ---- Frenet -> global (radius_arclength_track.py:752-807) --------------------------------
     def local_to_global(self, cl_coord):
         s, e_y, e_psi = cl_coord
@@ -218,8 +228,84 @@ _TRACK_DATA = {
 }
 
 
-def get_track(name: str) -> RadiusArclengthTrack:
+class CubicSplineTrack:
+    """Centre line given by cubic-spline interpolants x(s), y(s) through arclength-tagged waypoints -- the reference's
+    ``CasadiBSplineTrack`` (DGSQP/tracks/casadi_bspline_track.py:10-71) as the solver sees it:
+    curvature = (x'y'' - y'x'') / (x'^2 + y'^2)^1.5 (:122-135), tangent angle = atan2(y', x') (:137-149),
+    ``sbar = fmod(fmod(s, L) + L, L)``.  The interpolant is held as one cubic per waypoint interval (ascending powers of
+    ``s - s_i``); the table is produced by tools/make_f1_table.py with scipy's ``make_interp_spline(k=3)`` -- CasADi's
+    ``interpolant('bspline')`` satisfies the same interpolation conditions, its end conditions may differ (stated deviation)."""
+    kind = 'spline'
+
+    def __init__(self, knots, cx, cy, left_width, right_width, slack):
+        self.knots = np.asarray(knots, float)
+        self.cx, self.cy = np.asarray(cx, float), np.asarray(cy, float)
+        self.left_width_points, self.right_width_points = np.asarray(left_width, float), np.asarray(right_width, float)
+        self.track_width = float(np.mean(self.left_width_points + self.right_width_points))      # casadi_bspline_track.py:20-21
+        self.half_width = self.track_width / 2
+        self.slack = slack
+        self.track_length = float(self.knots[-1] - self.knots[0])
+        self.circuit = bool(np.allclose([self.cx[0, 0], self.cy[0, 0]], self._xy(self.knots[-1] - 1e-12), atol=1e-6))
+
+    def _sbar(self, s):
+        L = self.track_length
+        return np.fmod(np.fmod(s, L) + L, L)
+
+    def _piece(self, sb):
+        i = np.clip(np.searchsorted(self.knots, sb, side='right') - 1, 0, len(self.knots) - 2)
+        return i, sb - self.knots[i]
+
+    def _xy(self, s):
+        i, t = self._piece(self._sbar(np.asarray(s, float)))
+        return (((self.cx[i, 3] * t + self.cx[i, 2]) * t + self.cx[i, 1]) * t + self.cx[i, 0],
+                ((self.cy[i, 3] * t + self.cy[i, 2]) * t + self.cy[i, 1]) * t + self.cy[i, 0])
+
+    def _derivs(self, s):
+        i, t = self._piece(self._sbar(np.asarray(s, float)))
+        dx = (3 * self.cx[i, 3] * t + 2 * self.cx[i, 2]) * t + self.cx[i, 1]
+        dy = (3 * self.cy[i, 3] * t + 2 * self.cy[i, 2]) * t + self.cy[i, 1]
+        return dx, dy, 6 * self.cx[i, 3] * t + 2 * self.cx[i, 2], 6 * self.cy[i, 3] * t + 2 * self.cy[i, 2]
+
+    def lookup(self, s):
+        """Vectorised (curvature, tangent angle) at arclength s."""
+        dx, dy, ddx, ddy = self._derivs(s)
+        return (dx * ddy - dy * ddx) / np.power(dx ** 2 + dy ** 2, 1.5), np.arctan2(dy, dx)
+
+    def get_curvature(self, s):
+        return float(self.lookup(s)[0])
+
+    def get_tangent_angle(self, s):
+        return float(self.lookup(s)[1])
+
+    def get_halfwidth(self, s):
+        return self.half_width
+
+    def local_to_global(self, cl_coord):
+        """casadi_bspline_track.py:151-170: centre-line point plus e_y along the left normal, heading = tangent + e_psi."""
+        s, e_y, e_psi = cl_coord
+        x, y = self._xy(s)
+        dx, dy, _, _ = self._derivs(s)
+        nrm = np.hypot(dx, dy)
+        return float(x - e_y * dy / nrm), float(y + e_y * dx / nrm), float(np.arctan2(dy, dx) + e_psi)
+
+    def local_to_global_typed(self, state):
+        x, y, psi = self.local_to_global((state.p.s, state.p.x_tran, state.p.e_psi))
+        state.x.x, state.x.y, state.e.psi = x, y, psi
+
+    def spline_table(self):
+        """[knots (n), x coefficients (n-1) x 4, y coefficients (n-1) x 4] as the C-ABI takes it (dgsqp_problem_t.spline)."""
+        return np.ascontiguousarray(np.concatenate([self.knots - self.knots[0], self.cx.ravel(), self.cy.ravel()]))
+
+
+_SPLINE_TRACKS = {'f1_austin_tenth_scale': 'f1_austin_tenth_scale_spline.npz'}
+
+
+def get_track(name: str):
     key = name[:-4] if name.endswith('.npz') else name
+    if key in _SPLINE_TRACKS:
+        import pathlib
+        d = np.load(pathlib.Path(__file__).resolve().parent / 'track_data' / _SPLINE_TRACKS[key])
+        return CubicSplineTrack(d['knots'], d['cx'], d['cy'], d['left_width'], d['right_width'], float(d['slack']))
     if key not in _TRACK_DATA:
         raise ValueError('Chosen Track is unavailable: %s\n Available Tracks: %s' % (name, sorted(_TRACK_DATA)))
     d = _TRACK_DATA[key]

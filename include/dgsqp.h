@@ -135,8 +135,20 @@ typedef struct {
   double seg_curv[DGSQP_MAX_SEGS];
   double seg_ang[DGSQP_MAX_SEGS + 1];
   dgsqp_agent_t agents[DGSQP_MAX_AGENTS];
+  /* centre line of the Frenet-frame models.  DGSQP_TRACK_ARCS: the segment tables above (RadiusArclengthTrack: curvature
+     piecewise constant, tangent piecewise linear, radius_arclength_track.py:199-225).  DGSQP_TRACK_SPLINE: cubic-spline
+     interpolants x(s), y(s) (CasadiBSplineTrack, casadi_bspline_track.py:56-71): curvature (x'y'' - y'x'')/(x'^2 + y'^2)^1.5
+     (:122-135), tangent atan2(y', x') (:137-149), s wrapped into [0, track_L).  spline = [n_knots] knots (first one 0), then
+     [n_knots-1][4] coefficients of x and [n_knots-1][4] of y in ascending powers of (s - knot_i); caller-owned, copied by
+     dgsqp_create (n_knots <= DGSQP_MAX_KNOTS). */
+  int32_t track_kind;
+  int32_t n_knots;
+  const double* spline;
 } dgsqp_problem_t;
 
+#define DGSQP_TRACK_ARCS 0
+#define DGSQP_TRACK_SPLINE 1
+#define DGSQP_MAX_KNOTS 1152
 #define DGSQP_VARIANT_V1 0
 #define DGSQP_VARIANT_V2 1
 #define DGSQP_DECREASE_ARMIJO 0

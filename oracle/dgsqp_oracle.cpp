@@ -118,8 +118,28 @@ static Layout make_layout(const dgsqp_problem_t& P) {
 // -----------------------------------------------------------------------------
 // track functions (radius_arclength_track.py:199-225; CasADi pw_const/pw_lin)
 // -----------------------------------------------------------------------------
+// CasadiBSplineTrack (casadi_bspline_track.py:122-149): curvature and tangent of the cubic-spline centre line
 template <class T>
-static void track_eval(const dgsqp_problem_t& P, const T& s, double& curv, T& psi_t) {
+static void track_eval_spline(const dgsqp_problem_t& P, const T& s, T& curv, T& psi_t) {
+  using std::sqrt; using std::atan2;
+  const double L = P.track_L, sv = val(s);
+  const double sbar = std::fmod(std::fmod(sv, L) + L, L);
+  const int nk = P.n_knots;
+  const double* kn = P.spline;
+  int i = (int)(std::upper_bound(kn, kn + nk, sbar) - kn) - 1;
+  i = std::max(0, std::min(nk - 2, i));
+  const double* cx = P.spline + nk + 4 * (size_t)i;
+  const double* cy = P.spline + nk + 4 * (size_t)(nk - 1) + 4 * (size_t)i;
+  T t = s + (sbar - sv - kn[i]);                       // d sbar / d s = 1 (fmod)
+  T dx = (3.0 * cx[3] * t + 2.0 * cx[2]) * t + cx[1], dy = (3.0 * cy[3] * t + 2.0 * cy[2]) * t + cy[1];
+  T ddx = 6.0 * cx[3] * t + 2.0 * cx[2], ddy = 6.0 * cy[3] * t + 2.0 * cy[2];
+  T n2 = dx * dx + dy * dy;
+  curv = (dx * ddy - dy * ddx) / (n2 * sqrt(n2));
+  psi_t = atan2(dy, dx);
+}
+template <class T>
+static void track_eval(const dgsqp_problem_t& P, const T& s, T& curv, T& psi_t) {
+  if (P.track_kind == DGSQP_TRACK_SPLINE) { track_eval_spline(P, s, curv, psi_t); return; }
   const double L = P.track_L;
   const double sv = val(s);
   const double sbar = std::fmod(std::fmod(sv, L) + L, L);
@@ -127,7 +147,7 @@ static void track_eval(const dgsqp_problem_t& P, const T& s, double& curv, T& ps
   // pw_const(sbar, key_pts[1:-1,3], key_pts[1:,5]) = v0 + sum (v_{i+1}-v_i)*(t>=t_i)
   double c = P.seg_curv[0];
   for (int i = 0; i + 1 < ns; i++) c += (P.seg_curv[i + 1] - P.seg_curv[i]) * (sbar >= P.seg_s[i + 1] ? 1.0 : 0.0);
-  curv = c;
+  curv = T(c);
   // pw_lin(sbar, key_pts[:,3], abs_angs); d sbar / d s = 1 (fmod)
   T sb = s + (sbar - sv);
   auto lseg = [&](int i) -> T {
@@ -153,7 +173,7 @@ static void fc_kin(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const T* q
   T psidot = v / ag.L_r * sin(beta);
   T F_ext = -ag.c_da * v - ag.c_dr * v * ca_abs(v) - ag.c_s * (psidot * psidot);
   if (ag.c_r != 0.0) F_ext = F_ext - ag.c_r * powc(ca_abs(v), ag.p_r) * ca_sign(v);
-  double c; T psi_t;
+  T c; T psi_t;
   track_eval(P, s, c, psi_t);
   T den = 1.0 - ey * c;
   dq[0] = v * cos(beta + psi_t + epsi);
@@ -170,7 +190,7 @@ static void fc_dyn(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const T* q
   using std::sin; using std::cos; using std::atan; using std::atan2;
   const T &vx = q[2], &vy = q[3], &w = q[4], &epsi = q[5], &s = q[6], &ey = q[7];
   const T &ua = u[0], &us = u[1];
-  double c; T psi_t;
+  T c; T psi_t;
   track_eval(P, s, c, psi_t);
   T alpha_f, alpha_r;
   if (ag.simple_slip)
@@ -1489,10 +1509,9 @@ int oracle_dynamics(const dgsqp_problem_t* P, int agent, const double* q, const 
 
 int oracle_track(const dgsqp_problem_t* P, double s, double* curv, double* tangent, double* dtangent) {
   Jet::nv = 1;
-  Jet sj = Jet::var(s, 0), psi;
-  double c;
+  Jet sj = Jet::var(s, 0), psi, c;
   track_eval<Jet>(*P, sj, c, psi);
-  *curv = c; *tangent = psi.v; if (dtangent) *dtangent = psi.g[0];
+  *curv = c.v; *tangent = psi.v; if (dtangent) *dtangent = psi.g[0];
   return 0;
 }
 

@@ -675,6 +675,40 @@ def test_dgsqp_v2_matches_oracle(oracle, kind):
     assert info['num_iters'] == int(res['num_iters'][0]) and np.array_equal(info['primal_sol'], res['u'][0])
 
 
+@pytest.mark.parametrize('model,N,B', [('kinematic', 12, 16), ('dynamic', 8, 8), ('kinematic', 50, 4)])
+def test_f1_spline_track_game(oracle, model, N, B):
+    """BASELINE configs[3]'s game: two cars on the F1 track, a cubic-spline centre line (CasadiBSplineTrack,
+    casadi_bspline_track.py:56-71, :122-149) whose curvature has non-zero derivatives -- evaluated on the device in Taylor
+    arithmetic from the spline table.  Stage quantities to 1e-10, the PID warm start on the spline track, full solves against
+    the oracle; N = 50 is the configuration's horizon (n = 200, 1,050 rows, XL layout)."""
+    from dgsqp_amd import montecarlo as mc
+    from dgsqp_amd.solver import DGSQP, build_problem, build_params
+    g = mc.f1_racing_game(N=N, model=model, rk4_substeps=3)
+    P, par = build_problem(*g.solver_args()), build_params(g.params, lsqr_tol=1e-13)
+    s = DGSQP(*g.solver_args(), print_method=None, lsqr_tol=1e-13)
+    assert s.dims.layout == (2 if N == 50 else 0) and (N != 50 or (s.n, s.n_c_total) == (200, 1050))
+    x0, u_tm = mc.sample_scenarios(g, B, seed=0)
+    u = agent_major(u_tm)
+    rng = np.random.default_rng(1)
+    up = u + 0.02 * rng.standard_normal(u.shape)
+    l = np.maximum(0, rng.standard_normal((B, s.n_c_total)))
+    ev = s.evaluate_batch(x0[:3], up[:3], l[:3])
+    for b in range(3):
+        o = oracle.evaluate(P, x0[b], up[b], l[b], 1)
+        for key in ('x', 'q', 'g', 'G', 'Q'):
+            assert rel(ev[key][b], o[key]) < 1e-10, (key, b)
+    dev = s.pid_warm_start_batch(x0, du_max=(10.0, 4.5), want_trajectories=True)
+    models = g.joint_model.dynamics_models
+    ref_u = np.concatenate([mc.pid_warm_start(m, x0[:, a * m.n_q:(a + 1) * m.n_q], N, 0.1, du=(10.0, 4.5))[1] for a, m in enumerate(models)], axis=2)
+    assert np.abs(dev['u_ws'] - ref_u).max() < 1e-9
+    res = s.solve_batch(x0, u_tm)
+    ref = oracle.solve_batch(P, par, x0, u, nthreads=8)
+    same = assert_control_flow_parity(res, ref, stable_mask(oracle, P, par, x0, u, ref, K=2), f'f1 {model} N={N}', min_stable_same=0.9,
+                                      max_conv_gap=0.15, min_stable_frac=0.4)
+    for b in np.where(same & (ref['status'] <= 1))[0]:
+        assert rel(res['u'][b], ref['u'][b]) < 1e-5, b
+
+
 def test_bfgs_hessian_option(oracle):
     """DGSQPParams.hessian_approximation = 'bfgs' (DGSQP.py:353-364, :535-557): exact Hessian at the first iteration, damped
     BFGS updates of the projected Hessian afterwards, against the oracle; more iterations than with exact Hessians."""

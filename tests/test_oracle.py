@@ -382,3 +382,37 @@ def test_v2_restatement_invariants(oracle):
     with pytest.raises(NotImplementedError):
         g.params.merit_function = 'sum_obj_l1'
         build_params(g.params)
+
+
+def test_spline_track_game_derivatives(oracle):
+    """BASELINE configs[3]'s track: cubic-spline centre line (CasadiBSplineTrack, casadi_bspline_track.py:56-71, :122-149).  The
+    host class, the oracle's track function and its derivatives through the game: tangent / curvature agree between host and
+    oracle, d(tangent)/ds from the jets == finite differences, G and the game Hessian Q == finite differences of g and of the
+    Lagrangian gradients (the curvature now has non-zero first and second derivatives, unlike the arc tracks)."""
+    from dgsqp_amd import montecarlo as mc
+    from dgsqp_amd.solver import build_problem, build_params
+    for model in ('kinematic', 'dynamic'):
+        g = mc.f1_racing_game(N=6, model=model, rk4_substeps=2)
+        P = build_problem(*g.solver_args())
+        assert P.track_kind == 1 and P.n_knots == 1103 and abs(P.track_L - 550.8628177372308) < 1e-9
+        for s in (0.0, 10.3, 275.0, 550.5, 551.2, -3.0):
+            c, t, dt = oracle.track(P, s)
+            ch, th = g.track.lookup(np.array([s]))
+            assert abs(c - ch[0]) < 1e-12 and abs(t - th[0]) < 1e-12
+            h = 1e-6
+            if s not in (0.0,):          # (the interpolant is not periodic: its tangent jumps by 9e-7 at the seam s = 0 = L)
+                assert abs((oracle.track(P, s + h)[1] - oracle.track(P, s - h)[1]) / (2 * h) - dt) < 1e-7
+        x0, u_tm = mc.sample_scenarios(g, 2, seed=0)
+        u = agent_major(u_tm)[0] + 0.05 * np.random.default_rng(1).standard_normal(u_tm.shape[1] * u_tm.shape[2])
+        nc, n = oracle.dims(P)['nc'], u.size
+        l = np.abs(np.random.default_rng(0).standard_normal(nc))
+        ev = oracle.evaluate(P, x0[0], u, l, 1)
+        Gfd, Qfd, h = np.zeros((nc, n)), np.zeros((n, n)), 1e-6
+        for i in range(n):
+            up, um = u.copy(), u.copy()
+            up[i] += h; um[i] -= h
+            ep, em = oracle.evaluate(P, x0[0], up, l, 0), oracle.evaluate(P, x0[0], um, l, 0)
+            Gfd[:, i] = (ep['g'] - em['g']) / (2 * h)
+            Qfd[:, i] = ((ep['q'] + ep['G'].T @ l) - (em['q'] + em['G'].T @ l)) / (2 * h)
+        assert np.abs(Gfd - ev['G']).max() < 1e-6 * max(1.0, np.abs(ev['G']).max())
+        assert np.abs(Qfd - ev['Q']).max() < 1e-6 * max(1.0, np.abs(ev['Q']).max())
