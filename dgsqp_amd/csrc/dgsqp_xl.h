@@ -343,13 +343,16 @@ __device__ inline void xl_rot_cols(gptr X, int n, int rows, int ja, int jb, doub
 // ---- _solve_qp on the projected Hessian M held row-major in the scratch (ws_xM).  Also the QP of the smaller layouts when
 // M is too ill-conditioned for the explicit-inverse kernels (classic_qp, dgsqp_layout.h).
 // Out: du (L.o_du), lhat (L.o_lhat).  Returns 0 ok, 1 infeasible, 2 numerical failure / iteration limit.
-__device__ __noinline__ int dev_xl_qp(const Ctx& c) {
+// J (n x n, row stride js) lives in LDS -- in the slots of the packed P and R of the explicit-inverse kernels, which the classical
+// method does not use -- whenever the game has the LDS-resident layout (n <= ~100), otherwise in the workgroup's L2 scratch.
+template <class MP>
+__device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
   const DgProb& D = dg_prob;
   const DgLds& L = D.L;
   lptr lds = LP(0);
   const int n = D.n, nc = D.nc;
   const QpPtrs q = qp_ptrs(c);
-  gptr Lc = c.ws + D.ws_xM, J = c.ws + D.ws_xJ, R = c.ws + D.ws_xR;      // all row-major n x n
+  gptr Lc = c.ws + D.ws_xM, R = c.ws + D.ws_xR;      // row-major n x n
   lptr lhat = lds + L.o_lhat, x = q.xv, np = q.yv, dv = q.cvec, zv = q.wv, rv = q.rv, uu = q.lam, tv = q.tv, acc = q.rd;
   lds_d* scal = lds + L.scal;
   lds_d* red = lds + L.red;
@@ -385,40 +388,40 @@ __device__ __noinline__ int dev_xl_qp(const Ctx& c) {
   //      n passes over the matrix; beyond n = 160 the matrices of a full GPU no longer sit in L2 and one thread per column
   //      solving L^T y = e_col (reads only) is faster (measured at n = 200: 83 vs 107 scen/s).
   if (n <= 160) {
-    for (int e = TID; e < n * n; e += NT) J[e] = (e / n == e % n) ? 1.0 : 0.0;
+    for (int e = TID; e < n * n; e += NT) J[(e / n) * js + e % n] = (e / n == e % n) ? 1.0 : 0.0;
     XSYNC();
     for (int k = 0; k < n; k++) {
       const double dk = 1.0 / Lc[(int64_t)k * n + k];
-      for (int j = TID; j <= k; j += NT) J[(int64_t)j * n + k] *= dk;
+      for (int j = TID; j <= k; j += NT) J[j * js + k] *= dk;
       XSYNC();
       const int m = n - k - 1;
       for (int e = TID; e < m * (k + 1); e += NT) {
         const int i = k + 1 + e % m, j = e / m;                      // X[i][j] -= L[i][k] X[k][j]   (J[j][i] = X[i][j])
-        J[(int64_t)j * n + i] -= Lc[(int64_t)i * n + k] * J[(int64_t)j * n + k];
+        J[j * js + i] -= Lc[(int64_t)i * n + k] * J[j * js + k];
       }
       XSYNC();
     }
   } else {
     for (int col = TID; col < n; col += NT) {
-      for (int i = n - 1; i > col; i--) J[(int64_t)i * n + col] = 0.0;
+      for (int i = n - 1; i > col; i--) J[i * js + col] = 0.0;
       for (int i = col; i >= 0; i--) {
         double s0 = i == col ? 1.0 : 0.0, s1 = 0, s2 = 0, s3 = 0;      // independent accumulators: the loads overlap
         int k = i + 1;
         for (; k + 3 <= col; k += 4) {
-          s0 -= Lc[(int64_t)k * n + i] * J[(int64_t)k * n + col]; s1 -= Lc[(int64_t)(k + 1) * n + i] * J[(int64_t)(k + 1) * n + col];
-          s2 -= Lc[(int64_t)(k + 2) * n + i] * J[(int64_t)(k + 2) * n + col]; s3 -= Lc[(int64_t)(k + 3) * n + i] * J[(int64_t)(k + 3) * n + col];
+          s0 -= Lc[(int64_t)k * n + i] * J[k * js + col]; s1 -= Lc[(int64_t)(k + 1) * n + i] * J[(k + 1) * js + col];
+          s2 -= Lc[(int64_t)(k + 2) * n + i] * J[(k + 2) * js + col]; s3 -= Lc[(int64_t)(k + 3) * n + i] * J[(k + 3) * js + col];
         }
-        for (; k <= col; k++) s0 -= Lc[(int64_t)k * n + i] * J[(int64_t)k * n + col];
-        J[(int64_t)i * n + col] = ((s0 + s1) + (s2 + s3)) / Lc[(int64_t)i * n + i];
+        for (; k <= col; k++) s0 -= Lc[(int64_t)k * n + i] * J[k * js + col];
+        J[i * js + col] = ((s0 + s1) + (s2 + s3)) / Lc[(int64_t)i * n + i];
       }
     }
     XSYNC();
   }
   PROF_END(PH_Q_Y, px2);
   // ---- x = -M^-1 q = -J (J^T q)
-  for (int i = TID; i < n; i += NT) { double s = 0; for (int k = 0; k <= i; k++) s += J[(int64_t)k * n + i] * lds[L.q + k]; dv[i] = s; }
+  for (int i = TID; i < n; i += NT) { double s = 0; for (int k = 0; k <= i; k++) s += J[k * js + i] * lds[L.q + k]; dv[i] = s; }
   __syncthreads();
-  for (int i = TID; i < n; i += NT) { double s = 0; for (int k = i; k < n; k++) s += J[(int64_t)i * n + k] * dv[k]; x[i] = -s; }
+  for (int i = TID; i < n; i += NT) { double s = 0; for (int k = i; k < n; k++) s += J[i * js + k] * dv[k]; x[i] = -s; }
   __syncthreads();
   int iq = 0, ret = 2;
   auto row_slack = [&](int p) -> double {       // -(g_p + a_p . x), block-uniform; tv must hold a_p
@@ -473,7 +476,7 @@ __device__ __noinline__ int dev_xl_qp(const Ctx& c) {
     __syncthreads();
     // the same rotations on the columns of J: every thread carries its own row through the whole sequence
     for (int i = TID; i < n; i += NT) {
-      gptr Ji = J + (int64_t)i * n;
+      MP Ji = J + i * js;
       double carry = Ji[l];
       for (int k0 = l; k0 < iq; k0 += XL_RCH) {
         const int cnt = iq - k0 < XL_RCH ? iq - k0 : XL_RCH;
@@ -513,10 +516,10 @@ __device__ __noinline__ int dev_xl_qp(const Ctx& c) {
         double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
         int k = 0;
         for (; k + 3 < n; k += 4) {
-          s0 += J[(int64_t)k * n + i] * np[k]; s1 += J[(int64_t)(k + 1) * n + i] * np[k + 1];
-          s2 += J[(int64_t)(k + 2) * n + i] * np[k + 2]; s3 += J[(int64_t)(k + 3) * n + i] * np[k + 3];
+          s0 += J[k * js + i] * np[k]; s1 += J[(k + 1) * js + i] * np[k + 1];
+          s2 += J[(k + 2) * js + i] * np[k + 2]; s3 += J[(k + 3) * js + i] * np[k + 3];
         }
-        for (; k < n; k++) s0 += J[(int64_t)k * n + i] * np[k];
+        for (; k < n; k++) s0 += J[k * js + i] * np[k];
         dv[i] = (s0 + s1) + (s2 + s3);
       }
       __syncthreads();
@@ -524,10 +527,10 @@ __device__ __noinline__ int dev_xl_qp(const Ctx& c) {
         double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
         int k = iq;
         for (; k + 3 < n; k += 4) {
-          s0 += J[(int64_t)i * n + k] * dv[k]; s1 += J[(int64_t)i * n + k + 1] * dv[k + 1];
-          s2 += J[(int64_t)i * n + k + 2] * dv[k + 2]; s3 += J[(int64_t)i * n + k + 3] * dv[k + 3];
+          s0 += J[i * js + k] * dv[k]; s1 += J[i * js + k + 1] * dv[k + 1];
+          s2 += J[i * js + k + 2] * dv[k + 2]; s3 += J[i * js + k + 3] * dv[k + 3];
         }
-        for (; k < n; k++) s0 += J[(int64_t)i * n + k] * dv[k];
+        for (; k < n; k++) s0 += J[i * js + k] * dv[k];
         zv[i] = (s0 + s1) + (s2 + s3);
       }
       for (int i = TID; i < iq; i += NT) acc[i] = dv[i];
@@ -591,7 +594,7 @@ __device__ __noinline__ int dev_xl_qp(const Ctx& c) {
         }
         __syncthreads();
         for (int i = TID; i < n; i += NT) {
-          gptr Ji = J + (int64_t)i * n;
+          MP Ji = J + i * js;
           double carry = Ji[n - 1];
           for (int hi = n - 1; hi > iq; hi -= XL_RCH) {      // XL_RCH rotations per pass: their loads are issued together
             const int cnt = hi - iq < XL_RCH ? hi - iq : XL_RCH;
@@ -629,8 +632,8 @@ __device__ __noinline__ int dev_xl_qp(const Ctx& c) {
     __syncthreads();
     for (int k = TID; k < iq; k += NT) lhat[q.alist[k]] = uu[k];
     __syncthreads();
-    // the exact minimiser sits ON its active input bounds (same step in dev_qp and in the oracle)
-    for (int k = TID; k < iq; k += NT) {
+    // par.snap_active_bounds (default 0 = literal): put du exactly on its active input bounds (same knob in dev_qp and the oracle)
+    for (int k = TID; D.par.snap_active_bounds && k < iq; k += NT) {
       const int r = q.alist[k];
       const DgRow Rw = ld_row(r);
       if (uu[k] > 0.0 && Rw.type == DG_R_IN_UB) x[am_col(D, Rw.a, Rw.k, Rw.idx)] = -q.g[r];
@@ -640,6 +643,12 @@ __device__ __noinline__ int dev_xl_qp(const Ctx& c) {
   __syncthreads();
   PROF_END(PH_QP, pt_qp);
   return ret;
+}
+
+__device__ inline int dev_xl_qp(const Ctx& c) {
+  const DgProb& D = dg_prob;
+  if (D.big == 0) return dev_xl_qp_t<lptr>(c, LP(D.L.g_Bp), D.n + 1);     // P + R slots: n (n + 1) doubles
+  return dev_xl_qp_t<gptr>(c, c.ws + D.ws_xJ, D.n);
 }
 
 __device__ void dev_xl_psd(const Ctx& c, gptr Qpd) {
