@@ -16,10 +16,13 @@ python bench.py --workload kb_chicane_N25 --cpu-sample 0 > $O/bench_kb_chicane_N
 python bench.py --workload kb_barc2_N15 --cpu-sample 0 > $O/bench_kb_barc2_N15.json 2>> $O/bench.err
 python bench.py --workload merge_N20 --cpu-sample 0 > $O/bench_merge_N20.json 2>> $O/bench.err
 python bench.py --workload kb_curve3_N25 --steps 8 --cpu-sample 0 > $O/bench_kb_curve3_N25.json 2>> $O/bench.err
+python bench.py --workload kb_f1_N50 --batch 256 --steps 4 --pipeline 2 --single-steps 0 --host-steps 0 --cpu-sample 0 > $O/bench_kb_f1_N50_B256.json 2>> $O/bench.err
+python bench.py --workload kb_barc3_N25 --batch 512 --steps 4 --pipeline 2 --single-steps 0 --host-steps 0 --cpu-sample 0 > $O/bench_kb_barc3_N25_B512.json 2>> $O/bench.err
 python bench.py --workload kb_curve_N50 --batch 512 --steps 4 --pipeline 2 --single-steps 0 --host-steps 0 --cpu-sample 0 > $O/bench_kb_curve_N50_B512.json 2>> $O/bench.err
 python bench.py --workload dyn_curve_N25_v2 --batch 512 --steps 8 --single-steps 1 --host-steps 0 --cpu-sample 0 > $O/bench_dyn_curve_N25_v2_B512.json 2>> $O/bench.err
 python bench.py --workload dyn_barc_N25_v2 --batch 512 --steps 8 --single-steps 1 --host-steps 0 --cpu-sample 0 > $O/bench_dyn_barc_N25_v2_B512.json 2>> $O/bench.err
 # parity tables
+python -m pytest tests -m gpu -q -s 2>&1 | grep -E "identical|passed|failed" | cut -c1-2000 > $O/gpu_tests_parity_lines.txt
 python tools/gpu_forks.py dyn_curve_N25 > $O/forks_dyn_curve_N25.txt 2>&1
 python tools/gpu_forks.py kb_chicane_N15 > $O/forks_kb_chicane_N15.txt 2>&1
 python tools/gpu_forks.py kb_barc2_N15 > $O/forks_kb_barc2_N15.txt 2>&1
