@@ -103,12 +103,12 @@ def spawn_ranks(n, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=1024, help='scenarios per GPU per step (--scaling weak) or in total per step (strong)')
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--workload', default='dyn_curve_N25', choices=sorted(WORKLOADS))
-    ap.add_argument('--cpu-sample', type=int, default=256, help='scenarios timed on the host for cpu_baseline (0 disables)')
+    ap.add_argument('--cpu-sample', type=int, default=64, help='scenarios timed on the host for cpu_baseline (0 disables)')
     ap.add_argument('--pipeline', type=int, default=8,
                     help='independent batches in flight per GPU (each on its own handle / HIP stream); 1 = strictly one launch at a time')
     ap.add_argument('--single-steps', type=int, default=3, help='extra one-launch-at-a-time steps behind value_single_launch / roofline.kernel_ms (0 disables)')

@@ -7,6 +7,7 @@ cd $R
 nproc > $O/nproc.txt
 # bench lines
 python bench.py > $O/bench_dyn_curve_N25.json 2> $O/bench.err
+python bench.py --steps 20 --cpu-sample 0 > $O/bench_dyn_curve_N25_steps20.json 2>> $O/bench.err
 python bench.py --steps 10 --pipeline 5 --cpu-sample 0 > $O/bench_dyn_curve_N25_steps10_pipeline5.json 2>> $O/bench.err
 python bench.py --batch 4096 --steps 10 --cpu-sample 0 > $O/bench_dyn_curve_N25_B4096.json 2>> $O/bench.err
 python bench.py --workload dyn_curve_N25_stress --cpu-sample 0 > $O/bench_dyn_curve_N25_stress.json 2>> $O/bench.err
