@@ -9,6 +9,7 @@
 // per-workgroup HBM/L2 scratch.  All functions below are block-cooperative:
 // every thread of the workgroup calls them with identical arguments.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include "dgsqp_layout.h"
@@ -444,40 +445,42 @@ __device__ inline void dev_fc_pre_dyn(const dgsqp_agent_t& ag, const Ty<DEG>* u,
   pre.a0 = u[1];
   ty_sincos(u[1], pre.s0, pre.c0);
 }
-template <int DEG>
+// SPL: the track is a cubic spline (curvature is a Taylor value); a template parameter so that the arc-track instantiations --
+// the hot ones -- carry nothing of the spline path in their register allocation
+template <int DEG, bool SPL = false>
 __device__ inline void dev_fc_kin(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const Ty<DEG>* q, const Ty<DEG>* u, const FcPre<DEG>& pre, Ty<DEG>* dq) {
   typedef Ty<DEG> T;
   const T &beta = pre.a0, &sb = pre.s0, &cb = pre.c0;
   const T psidot = q[2] * sb * pre.ilr;
   T F = q[2] * (-ag.c_da) - q[2] * ty_abs(q[2]) * ag.c_dr - psidot * psidot * ag.c_s;
   if (ag.c_r != 0.0) F = F - ty_pow(ty_abs(q[2]), ag.p_r) * (q[2] / ty_sqrt(q[2] * q[2] + 1e-6)) * ag.c_r;
-  double c = 0.0;
-  T psit, cs;
-  const bool spl = P.track_kind == DGSQP_TRACK_SPLINE;     // uniform: the curvature is a Taylor value only on spline tracks
-  if (spl) dev_track_spline<DEG>(P, q[4], cs, psit);
+  typename std::conditional<SPL, T, double>::type c;
+  T psit;
+  constexpr bool spl = SPL;
+  if constexpr (spl) dev_track_spline<DEG>(P, q[4], c, psit);
   else dev_track(P, q[4], c, psit);
   T s1, c1, s2, c2;
   ty_sincos(beta + psit + q[3], s1, c1);
   ty_sincos(beta + q[3], s2, c2);
-  const T inv = spl ? ty_recip(1.0 - q[5] * cs) : ty_recip(1.0 - q[5] * c);
+  const T inv = ty_recip(1.0 - q[5] * c);
   const T vlon = q[2] * c2 * inv;
   dq[0] = q[2] * c1;
   dq[1] = q[2] * s1;
   dq[2] = u[0] + F * pre.im;
-  dq[3] = spl ? psidot - vlon * cs : psidot - vlon * c;
+  dq[3] = psidot - vlon * c;
   dq[4] = vlon;
   dq[5] = q[2] * s2;
 }
 
 // dynamic bicycle, Pacejka / linear tyres (dynamics_models.py:2008-2062); q = [x,y,vx,vy,w,e_psi,s,e_y]
-template <int DEG>
+template <int DEG, bool SPL = false>
 __device__ inline void dev_fc_dyn(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const Ty<DEG>* q, const Ty<DEG>* u, const FcPre<DEG>& pre, Ty<DEG>* dq) {
   typedef Ty<DEG> T;
   const T &vx = q[2], &vy = q[3], &w = q[4];
-  double c = 0.0;
-  T psit, cs;
-  const bool spl = P.track_kind == DGSQP_TRACK_SPLINE;
-  if (spl) dev_track_spline<DEG>(P, q[6], cs, psit);
+  typename std::conditional<SPL, T, double>::type c;
+  T psit;
+  constexpr bool spl = SPL;
+  if constexpr (spl) dev_track_spline<DEG>(P, q[6], c, psit);
   else dev_track(P, q[6], c, psit);
   const T &sd = pre.s0, &cd = pre.c0;
   const T vyf = vy + w * ag.L_f;
@@ -505,13 +508,13 @@ __device__ inline void dev_fc_dyn(const dgsqp_problem_t& P, const dgsqp_agent_t&
   T se, ce, st, ct;
   ty_sincos(q[5], se, ce);
   ty_sincos(q[5] + psit, st, ct);
-  const T vlon = (vx * ce - vy * se) * (spl ? ty_recip(1.0 - q[7] * cs) : ty_recip(1.0 - q[7] * c));
+  const T vlon = (vx * ce - vy * se) * ty_recip(1.0 - q[7] * c);
   dq[0] = vx * ct - vy * st;
   dq[1] = vy * ct + vx * st;
   dq[2] = ax + w * vy;
   dq[3] = ay - w * vx;
   dq[4] = (fyf * cd * ag.L_f - fyr * ag.L_r) * pre.iz;
-  dq[5] = spl ? w - vlon * cs : w - vlon * c;
+  dq[5] = w - vlon * c;
   dq[6] = vlon;
   dq[7] = vx * se + vy * ce;
 }
@@ -527,16 +530,16 @@ __device__ inline void dev_fc_uni(const Ty<DEG>* q, const Ty<DEG>* u, const FcPr
   dq[3] = u[1];
 }
 
-template <int DEG, int NQA>
+template <int DEG, int NQA, bool SPL = false>
 __device__ inline void dev_fc(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const Ty<DEG>* q, const Ty<DEG>* u, const FcPre<DEG>& pre, Ty<DEG>* dq) {
-  if constexpr (NQA == 8) dev_fc_dyn<DEG>(P, ag, q, u, pre, dq);
+  if constexpr (NQA == 8) dev_fc_dyn<DEG, SPL>(P, ag, q, u, pre, dq);
   else if constexpr (NQA == 4) dev_fc_uni<DEG>(q, u, pre, dq);
-  else dev_fc_kin<DEG>(P, ag, q, u, pre, dq);
+  else dev_fc_kin<DEG, SPL>(P, ag, q, u, pre, dq);
 }
 
 // one discrete step of the joint model's integrator (dynamics_models.py:88-99, :188-219).  The integrator is a template
 // parameter so that every instantiation keeps only the stage arrays it needs in registers (rk4: x, k-accumulator, k, t).
-template <int DEG, int NQA, int INTEG>
+template <int DEG, int NQA, int INTEG, bool SPL = false>
 __device__ inline void dev_fd_t(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const Ty<DEG>* q, const Ty<DEG>* u, Ty<DEG>* qn) {
   typedef Ty<DEG> T;
   T x[NQA], k1[NQA], k2[NQA], t[NQA];
@@ -547,7 +550,7 @@ __device__ inline void dev_fd_t(const dgsqp_problem_t& P, const dgsqp_agent_t& a
 #pragma unroll
   for (int i = 0; i < NQA; i++) x[i] = q[i];
   if constexpr (INTEG == DGSQP_INT_EULER) {
-    dev_fc<DEG, NQA>(P, ag, x, u, pre, k1);
+    dev_fc<DEG, NQA, SPL>(P, ag, x, u, pre, k1);
 #pragma unroll
     for (int i = 0; i < NQA; i++) qn[i] = x[i] + k1[i] * P.dt;
     return;
@@ -555,34 +558,34 @@ __device__ inline void dev_fd_t(const dgsqp_problem_t& P, const dgsqp_agent_t& a
   const double h = P.dt / P.substeps;
   for (int m = 0; m < P.substeps; m++) {
     if constexpr (INTEG == DGSQP_INT_RK4) {
-      dev_fc<DEG, NQA>(P, ag, x, u, pre, k1);
+      dev_fc<DEG, NQA, SPL>(P, ag, x, u, pre, k1);
 #pragma unroll
       for (int i = 0; i < NQA; i++) t[i] = x[i] + k1[i] * (h / 2);
-      dev_fc<DEG, NQA>(P, ag, t, u, pre, k2);
+      dev_fc<DEG, NQA, SPL>(P, ag, t, u, pre, k2);
 #pragma unroll
       for (int i = 0; i < NQA; i++) { t[i] = x[i] + k2[i] * (h / 2); k1[i] = k1[i] + k2[i] * 2.0; }
-      dev_fc<DEG, NQA>(P, ag, t, u, pre, k2);
+      dev_fc<DEG, NQA, SPL>(P, ag, t, u, pre, k2);
 #pragma unroll
       for (int i = 0; i < NQA; i++) { t[i] = x[i] + k2[i] * h; k1[i] = k1[i] + k2[i] * 2.0; }
-      dev_fc<DEG, NQA>(P, ag, t, u, pre, k2);
+      dev_fc<DEG, NQA, SPL>(P, ag, t, u, pre, k2);
 #pragma unroll
       for (int i = 0; i < NQA; i++) x[i] = x[i] + (k1[i] + k2[i]) * (h / 6.0);
     } else if constexpr (INTEG == DGSQP_INT_RK3) {
       T k3[NQA];
-      dev_fc<DEG, NQA>(P, ag, x, u, pre, k1);
+      dev_fc<DEG, NQA, SPL>(P, ag, x, u, pre, k1);
 #pragma unroll
       for (int i = 0; i < NQA; i++) { k1[i] = k1[i] * h; t[i] = x[i] + k1[i] * 0.5; }
-      dev_fc<DEG, NQA>(P, ag, t, u, pre, k2);
+      dev_fc<DEG, NQA, SPL>(P, ag, t, u, pre, k2);
 #pragma unroll
       for (int i = 0; i < NQA; i++) { k2[i] = k2[i] * h; t[i] = x[i] - k1[i] + k2[i] * 2.0; }
-      dev_fc<DEG, NQA>(P, ag, t, u, pre, k3);
+      dev_fc<DEG, NQA, SPL>(P, ag, t, u, pre, k3);
 #pragma unroll
       for (int i = 0; i < NQA; i++) x[i] = x[i] + (k1[i] + k2[i] * 4.0 + k3[i] * h) / 6.0;
     } else {
-      dev_fc<DEG, NQA>(P, ag, x, u, pre, k1);
+      dev_fc<DEG, NQA, SPL>(P, ag, x, u, pre, k1);
 #pragma unroll
       for (int i = 0; i < NQA; i++) t[i] = x[i] + k1[i] * h;
-      dev_fc<DEG, NQA>(P, ag, t, u, pre, k2);
+      dev_fc<DEG, NQA, SPL>(P, ag, t, u, pre, k2);
 #pragma unroll
       for (int i = 0; i < NQA; i++) x[i] = x[i] + (k1[i] + k2[i]) * (h / 2);
     }
@@ -590,13 +593,13 @@ __device__ inline void dev_fd_t(const dgsqp_problem_t& P, const dgsqp_agent_t& a
 #pragma unroll
   for (int i = 0; i < NQA; i++) qn[i] = x[i];
 }
-template <int DEG, int NQA>
+template <int DEG, int NQA, bool SPL = false>
 __device__ inline void dev_fd(const dgsqp_problem_t& P, const dgsqp_agent_t& ag, const Ty<DEG>* q, const Ty<DEG>* u, Ty<DEG>* qn) {
   switch (P.integrator) {   // uniform
-    case DGSQP_INT_EULER: dev_fd_t<DEG, NQA, DGSQP_INT_EULER>(P, ag, q, u, qn); break;
-    case DGSQP_INT_RK4: dev_fd_t<DEG, NQA, DGSQP_INT_RK4>(P, ag, q, u, qn); break;
-    case DGSQP_INT_RK3: dev_fd_t<DEG, NQA, DGSQP_INT_RK3>(P, ag, q, u, qn); break;
-    default: dev_fd_t<DEG, NQA, DGSQP_INT_RK2>(P, ag, q, u, qn); break;
+    case DGSQP_INT_EULER: dev_fd_t<DEG, NQA, DGSQP_INT_EULER, SPL>(P, ag, q, u, qn); break;
+    case DGSQP_INT_RK4: dev_fd_t<DEG, NQA, DGSQP_INT_RK4, SPL>(P, ag, q, u, qn); break;
+    case DGSQP_INT_RK3: dev_fd_t<DEG, NQA, DGSQP_INT_RK3, SPL>(P, ag, q, u, qn); break;
+    default: dev_fd_t<DEG, NQA, DGSQP_INT_RK2, SPL>(P, ag, q, u, qn); break;
   }
 }
 

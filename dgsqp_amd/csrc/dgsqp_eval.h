@@ -84,7 +84,7 @@ __device__ inline double dev_state_cost(const DgProb& D, int a, XP xk, bool term
 // ------------------------------------------------------------------------------------------------
 // trial input u + alpha du, written the same way everywhere so that equal points give bit-identical trajectories
 __device__ inline double step_u(double u, double alpha, double du) { return __builtin_fma(alpha, du, u); }
-template <int NQA>
+template <int NQA, bool SPL = false>
 __device__ inline void dev_rollout_agent(const DgProb& D, int a, clptr ub, clptr du, double alpha, lptr x) {
   typedef Ty<0> T;
   const int nq = D.nq, qo = D.qoff[a];
@@ -94,7 +94,7 @@ __device__ inline void dev_rollout_agent(const DgProb& D, int a, clptr ub, clptr
     const int i0 = am_col(D, a, k, 0);
     u[0].c[0] = du ? step_u(ub[i0], alpha, du[i0]) : ub[i0];
     u[1].c[0] = du ? step_u(ub[i0 + 1], alpha, du[i0 + 1]) : ub[i0 + 1];
-    dev_fd<0, NQA>(D.P, D.P.agents[a], q, u, qn);
+    dev_fd<0, NQA, SPL>(D.P, D.P.agents[a], q, u, qn);
     for (int i = 0; i < NQA; i++) { q[i] = qn[i]; x[(k + 1) * nq + qo + i] = qn[i].c[0]; }
   }
 }
@@ -240,6 +240,9 @@ __device__ __noinline__ void dev_rollout_multi(const Ctx& c, clptr ub, clptr du,
     for (int t = 0; t < j; t++) alpha *= tau;           // same products as the sequential alpha *= tau
     lptr x = j < K1 ? xs + j * xstride : xs2 + (j - K1) * xstride;
     if (all_dyn) dev_rollout_dyn_pair(D, w >> 1, w & 1, ub, du, alpha, x);
+    else if (D.P.track_kind == DGSQP_TRACK_SPLINE && D.nqa[w] != 4) {
+      if (D.nqa[w] == 8) dev_rollout_agent<8, true>(D, w, ub, du, alpha, x); else dev_rollout_agent<6, true>(D, w, ub, du, alpha, x);
+    }
     else if (D.nqa[w] == 8) dev_rollout_agent<8>(D, w, ub, du, alpha, x);
     else if (D.nqa[w] == 4) dev_rollout_agent<4>(D, w, ub, du, alpha, x);
     else dev_rollout_agent<6>(D, w, ub, du, alpha, x);
@@ -259,7 +262,7 @@ __device__ inline void dir_pair(int neff, int dir, int& i, int& j) {
   while (p >= neff - 1 - i) { p -= neff - 1 - i; i++; }
   j = i + 1 + p;
 }
-template <int DEG, int NQA, int INTEG>
+template <int DEG, int NQA, int INTEG, bool SPL = false>
 __device__ __forceinline__ void dev_taylor_item_impl(const Ctx& c, int a, int k, int dir, clptr ue) {
   const DgProb& D = dg_prob;
   const DgLds& L = D.L;
@@ -279,7 +282,7 @@ __device__ __forceinline__ void dev_taylor_item_impl(const Ctx& c, int a, int k,
 #pragma unroll
     for (int i = 0; i < 2; i++) u[i].c[1] = (NQA + i == zi || NQA + i == zj) ? 1.0 : 0.0;
   }
-  dev_fd_t<DEG, NQA, INTEG>(D.P, D.P.agents[a], q, u, out);
+  dev_fd_t<DEG, NQA, INTEG, SPL>(D.P, D.P.agents[a], q, u, out);
   if (dir < D.neff[a]) {
     const int z = D.effvar[a][dir];
     if (z < NQA) {
@@ -298,10 +301,12 @@ __device__ __forceinline__ void dev_taylor_item_impl(const Ctx& c, int a, int k,
 }
 // First-derivative items are compiled out of line, one instantiation per (model, integrator), which keeps their register
 // allocation tight (no spills for euler); the second-order items are inlined into their caller.
-template <int DEG, int NQA, int INTEG>
-__device__ __noinline__ void dev_taylor_item_ool(const Ctx& c, int a, int k, int dir, clptr ue) { dev_taylor_item_impl<DEG, NQA, INTEG>(c, a, k, dir, ue); }
+template <int DEG, int NQA, int INTEG, bool SPL = false>
+__device__ __noinline__ void dev_taylor_item_ool(const Ctx& c, int a, int k, int dir, clptr ue) { dev_taylor_item_impl<DEG, NQA, INTEG, SPL>(c, a, k, dir, ue); }
 template <int DEG, int NQA, int INTEG>
 __device__ __forceinline__ void dev_taylor_item(const Ctx& c, int a, int k, int dir, clptr ue) {
+  // games on a spline track: their own out-of-line instantiations (the arc-track ones keep their register allocation)
+  if (NQA != 4 && dg_prob.P.track_kind == DGSQP_TRACK_SPLINE) { dev_taylor_item_ool<DEG, NQA, INTEG, true>(c, a, k, dir, ue); return; }
   if constexpr (DEG >= 2 && NQA == 8 && INTEG != DGSQP_INT_EULER) dev_taylor_item_impl<DEG, NQA, INTEG>(c, a, k, dir, ue);
   else dev_taylor_item_ool<DEG, NQA, INTEG>(c, a, k, dir, ue);
 }

@@ -4,7 +4,7 @@
 // continuous model integrated with rk4 (10 sub-steps per dt by default), the same f_c the solver differentiates.
 #pragma once
 
-template <int NQA>
+template <int NQA, bool SPL = false>
 __device__ inline void dev_pid_agent(const DgProb& D, int a, cgptr q0, const dgsqp_pid_t& pid, gptr u_out, gptr q_out) {
   typedef Ty<0> T;
   const dgsqp_problem_t& P = D.P;
@@ -33,16 +33,16 @@ __device__ inline void dev_pid_agent(const DgProb& D, int a, cgptr q0, const dgs
     FcPre<0> pre;
     if constexpr (NQA == 8) dev_fc_pre_dyn<0>(ag, u, pre); else dev_fc_pre_kin<0>(ag, u, pre);
     for (int m = 0; m < pid.substeps; m++) {
-      dev_fc<0, NQA>(P, ag, q, u, pre, k1);
+      dev_fc<0, NQA, SPL>(P, ag, q, u, pre, k1);
 #pragma unroll
       for (int i = 0; i < NQA; i++) t[i] = q[i] + k1[i] * (h / 2);
-      dev_fc<0, NQA>(P, ag, t, u, pre, k2);
+      dev_fc<0, NQA, SPL>(P, ag, t, u, pre, k2);
 #pragma unroll
       for (int i = 0; i < NQA; i++) { t[i] = q[i] + k2[i] * (h / 2); k1[i] = k1[i] + k2[i] * 2.0; }
-      dev_fc<0, NQA>(P, ag, t, u, pre, k2);
+      dev_fc<0, NQA, SPL>(P, ag, t, u, pre, k2);
 #pragma unroll
       for (int i = 0; i < NQA; i++) { t[i] = q[i] + k2[i] * h; k1[i] = k1[i] + k2[i] * 2.0; }
-      dev_fc<0, NQA>(P, ag, t, u, pre, k2);
+      dev_fc<0, NQA, SPL>(P, ag, t, u, pre, k2);
 #pragma unroll
       for (int i = 0; i < NQA; i++) q[i] = q[i] + (k1[i] + k2[i]) * (h / 6.0);
     }
@@ -62,7 +62,8 @@ dg_pid_kernel(int64_t B, const double* __restrict__ q0, dgsqp_pid_t pid, double*
     cgptr q0a = (cgptr)q0 + b * D.nq + D.qoff[a];
     gptr uo = (gptr)u_ws + b * D.n;
     gptr qo = q_ws ? (gptr)q_ws + b * (int64_t)(D.N + 1) * D.nq + D.qoff[a] : nullptr;
-    if (D.nqa[a] == 8) dev_pid_agent<8>(D, a, q0a, pid, uo, qo); else dev_pid_agent<6>(D, a, q0a, pid, uo, qo);
+    if (D.P.track_kind == DGSQP_TRACK_SPLINE) { if (D.nqa[a] == 8) dev_pid_agent<8, true>(D, a, q0a, pid, uo, qo); else dev_pid_agent<6, true>(D, a, q0a, pid, uo, qo); }
+    else if (D.nqa[a] == 8) dev_pid_agent<8>(D, a, q0a, pid, uo, qo); else dev_pid_agent<6>(D, a, q0a, pid, uo, qo);
   }
 }
 // collide[b] = 1 if any two agents come closer than r_i + r_j at any stage of the warm-start trajectories
