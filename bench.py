@@ -6,7 +6,7 @@
 
 One "step" = one pass of the hot path (DGSQP.solve(), reference DGSQP/solvers/DGSQP.py:302-507) over one batch of synthetic
 random-initial-condition scenarios that is resident in HBM before the timed region starts (dgsqp_stage_inputs); consecutive
-steps solve DIFFERENT batches (own seed each, up to 8 distinct ones).  The timed region is exactly K steps between two fences
+steps solve DIFFERENT batches (own seed each; 2 x pipeline distinct ones, cycled).  The timed region is exactly K steps between two fences
 (library stream synchronisation + RCCL barrier), max over ranks.  Scenarios shard over the ranks with no data-path collective
 (--scaling weak: fixed batch per GPU; strong: fixed total batch); the only exchange is ONE ncclAllGather of the 64-byte
 per-scenario record, issued by the HIP library (dgsqp_gather_stats).  No PyTorch: the launcher only provides RANK / LOCAL_RANK /
@@ -24,7 +24,7 @@ import time
 
 import numpy as np
 
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')     # one hardware queue per in-flight batch (HIP default: 4)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')    # one hardware queue per in-flight batch (HIP default: 4; 32 fails on this stack)
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -109,8 +109,9 @@ def main():
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--workload', default='dyn_curve_N25', choices=sorted(WORKLOADS))
     ap.add_argument('--cpu-sample', type=int, default=64, help='scenarios timed on the host for cpu_baseline (0 disables)')
-    ap.add_argument('--pipeline', type=int, default=8,
+    ap.add_argument('--pipeline', type=int, default=12,
                     help='independent batches in flight per GPU (each on its own handle / HIP stream); 1 = strictly one launch at a time')
+    ap.add_argument('--batches', type=int, default=0, help='distinct staged batches = handles the steps cycle through (default: 2 x pipeline, so that a step never waits for the tail of the launch that used its handle before)')
     ap.add_argument('--single-steps', type=int, default=3, help='extra one-launch-at-a-time steps behind value_single_launch / roofline.kernel_ms (0 disables)')
     ap.add_argument('--host-steps', type=int, default=2, help='extra dgsqp_solve_batch calls from host buffers behind value_host_inclusive (0 disables)')
     ap.add_argument('--reg', type=float, default=None, help='DGSQPParams.reg (default: the value of the workload)')
@@ -137,7 +138,7 @@ def main():
     mk = lambda: DGSQP(*game.solver_args(), print_method=None, device=local_rank, eig_floor=args.eig_floor,
                        snap_active_bounds=args.snap_active_bounds)
     P = max(1, args.pipeline)
-    n_batches = max(P, min(8, args.steps))             # distinct batches = handles (<= 8 hardware queues); steps cycle through them
+    n_batches = args.batches if args.batches > 0 else max(P, min(2 * P, args.steps))     # distinct batches = handles; steps cycle through them
     solvers = [mk() for _ in range(n_batches)]
     solver = solvers[0]
     d = solver.dims
@@ -152,7 +153,7 @@ def main():
     # rejection sampling + PID warm starts happen before any timing; batch j of rank r has its own seed
     batches = []
     for j in range(n_batches):
-        x0, u_tm = sample_scenarios(game, B, seed=1 + rank + 1000 * j)
+        x0, u_tm = sample_scenarios(game, B, seed=1 + rank + 1000 * j, solver=solver if game.sampler == 'first_segment' and d.M == 2 else None)   # PID warm starts on the device where the sampler supports it
         batches.append((np.ascontiguousarray(x0), np.ascontiguousarray(solver._to_agent_major(u_tm))))
     handles = [sv._h for sv in solvers]
     for hh, (x0, u_am) in zip(handles, batches):

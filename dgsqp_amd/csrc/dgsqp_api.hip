@@ -146,7 +146,7 @@ dg_qp_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__
 // the user already chose a value.
 namespace {
 struct DgEnvInit {
-  DgEnvInit() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+  DgEnvInit() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 } dg_env_init;
 }  // namespace
 

@@ -38,7 +38,13 @@ for b in np.nonzero(~same)[0]:
     to = oracle.solve_trace(P, par, x0[b], u_am[b], max_pairs=60000)
     tg = traces[b]
     k = 0
-    while k < min(len(to), len(tg)) and to[k, 0] == tg[k, 0] and abs(tg[k, 1] - to[k, 1]) <= tol * max(abs(to[k, 1]), 1e-9):
+    def agree(k):          # p_feas / comp values at rounding level are noise on both sides, not a difference
+        if to[k, 0] != tg[k, 0]:
+            return False
+        if int(to[k, 0]) in (2, 3) and max(abs(to[k, 1]), abs(tg[k, 1])) < 1e-10:
+            return True
+        return abs(tg[k, 1] - to[k, 1]) <= tol * max(abs(to[k, 1]), 1e-9)
+    while k < min(len(to), len(tg)) and agree(k):
         k += 1
     it = int((to[:k, 0] == 1).sum()) - 1
     # classification of the first differing event
