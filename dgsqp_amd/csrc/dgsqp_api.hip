@@ -502,6 +502,72 @@ int dgsqp_solve_batch(dgsqp_handle_t h, int64_t B, const double* x0, const doubl
   return DGSQP_OK;
 }
 
+// fp32 boundary: widen / narrow on the device
+__global__ void dg_widen_kernel(int64_t n, const float* __restrict__ src, double* __restrict__ dst) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (double)src[i];
+}
+__global__ void dg_narrow_kernel(int64_t n, const double* __restrict__ src, float* __restrict__ dst) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (float)src[i];
+}
+
+int dgsqp_solve_batch_f32(dgsqp_handle_t h, int64_t B, const float* x0, const float* u_ws, float* u_out, float* l_out,
+                          float* x_out, int32_t* status, int32_t* iters, int32_t* qp_solves, float* cond, float* cost,
+                          dgsqp_timing_t* tm) {
+  if (!h || B < 0 || (B > 0 && (!x0 || !u_ws))) { if (h) h->err = "bad argument"; return DGSQP_E_ARG; }
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = wait_idle(h);
+  if (rc) return rc;
+  h->B = B;
+  if (B == 0) return DGSQP_OK;
+  rc = ensure_batch(h, B);
+  if (rc) return rc;
+  rc = ensure_ws(h, (size_t)grid_for(h, B));
+  if (rc) return rc;
+  const DgProb& D = h->hp;
+  const size_t nx = (size_t)(D.N + 1) * D.nq;
+  size_t big = (size_t)B * (D.nc > (int)nx ? (size_t)D.nc : nx);
+  if ((size_t)B * D.n > big) big = (size_t)B * D.n;
+  TmpBuf tb;
+  float* f = tb.alloc<float>(big);          // one single-precision staging buffer, reused for every array
+  if (!f) { h->err = "hipMalloc failed"; return DGSQP_E_NOMEM; }
+  HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+  auto in = [&](const float* src, double* dst, size_t cnt) -> int {
+    HIPCHK(h, hipMemcpyAsync(f, src, sizeof(float) * cnt, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(dg_widen_kernel, dim3(256), dim3(256), 0, h->stream, (int64_t)cnt, f, dst);
+    HIPCHK(h, hipGetLastError());
+    return DGSQP_OK;
+  };
+  if ((rc = in(x0, h->d_x0, (size_t)B * D.nq))) return rc;
+  if ((rc = in(u_ws, h->d_uws, (size_t)B * D.n))) return rc;
+  dgsqp_timing_t t2;
+  rc = dgsqp_solve_staged(h, &t2);
+  if (rc) return rc;
+  auto out = [&](const double* src, float* dst, size_t cnt) -> int {
+    if (!dst) return DGSQP_OK;
+    hipLaunchKernelGGL(dg_narrow_kernel, dim3(256), dim3(256), 0, h->stream, (int64_t)cnt, src, f);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(dst, f, sizeof(float) * cnt, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));       // f is reused by the next array
+    return DGSQP_OK;
+  };
+  if ((rc = out(h->d_u, u_out, (size_t)B * D.n))) return rc;
+  if ((rc = out(h->d_l, l_out, (size_t)B * D.nc))) return rc;
+  if ((rc = out(h->d_x, x_out, (size_t)B * nx))) return rc;
+  if ((rc = out(h->d_cond, cond, (size_t)B * 3))) return rc;
+  if ((rc = out(h->d_cost, cost, (size_t)B * D.M))) return rc;
+  rc = dgsqp_fetch_results(h, nullptr, nullptr, nullptr, status, iters, qp_solves, nullptr, nullptr);
+  if (rc) return rc;
+  HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (tm) {
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
+    *tm = t2;
+    tm->total_ms = ms;
+  }
+  return DGSQP_OK;
+}
+
 // Diagnostic build (-DDG_PROF) only: cycles spent on each scenario of the last launch.
 int dgsqp_prof_scn(unsigned long long* out, int n) {
 #ifdef DG_PROF

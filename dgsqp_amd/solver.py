@@ -337,9 +337,12 @@ class DGSQP(AbstractSolver):
         self.l_ws = l_ws
 
     # ---- batched entry point -------------------------------------------------------------------
-    def solve_batch(self, x0: np.ndarray, u_ws: np.ndarray) -> dict:
+    def solve_batch(self, x0: np.ndarray, u_ws: np.ndarray, dtype=np.float64) -> dict:
         """B independent ``solve()`` calls.  ``x0`` [B, n_q]; ``u_ws`` [B, N, n_u] (time-major,
-        as ``set_warm_start``) or [B, n] (agent-major)."""
+        as ``set_warm_start``) or [B, n] (agent-major).  ``dtype=np.float32``: single-precision arrays at the boundary
+        (``dgsqp_solve_batch_f32``: widened on the device, fp64 solve, results rounded to fp32)."""
+        if np.dtype(dtype) == np.float32:
+            return self._solve_batch_f32(x0, u_ws)
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         B = x0.shape[0]
         u_ws = np.asarray(u_ws, dtype=np.float64)
@@ -361,6 +364,33 @@ class DGSQP(AbstractSolver):
                                          _ffi.iptr(out['qp_solves']), _ffi.dptr(out['cond']), _ffi.dptr(out['cost']), C.byref(tm))
         if rc != 0:
             raise RuntimeError(f'dgsqp_solve_batch failed ({rc}): {self._lib.dgsqp_last_error(self._h).decode()}')
+        out['time'] = time.time() - t0
+        out['kernel_ms'] = tm.kernel_ms
+        out['msg'] = [_ffi.STATUS_MSG[s] for s in out['status']]
+        out['converged'] = out['status'] <= 1
+        out['u_pred'] = self._to_time_major(out['u'])
+        return out
+
+    def _solve_batch_f32(self, x0, u_ws) -> dict:
+        x0 = np.ascontiguousarray(x0, dtype=np.float32)
+        B = x0.shape[0]
+        u_ws = np.asarray(u_ws, dtype=np.float32)
+        if u_ws.ndim == 3:
+            u_ws = self._to_agent_major(u_ws)
+        u_ws = np.ascontiguousarray(u_ws, dtype=np.float32)
+        if x0.shape != (B, self.n_q) or u_ws.shape != (B, self.n):
+            raise RuntimeError(f'bad batch shapes x0 {x0.shape} u_ws {u_ws.shape}')
+        f32 = np.float32
+        out = dict(u=np.empty((B, self.n), f32), l=np.empty((B, self.n_c_total), f32), x=np.empty((B, self.N + 1, self.n_q), f32),
+                   status=np.empty(B, np.int32), num_iters=np.empty(B, np.int32), qp_solves=np.empty(B, np.int32),
+                   cond=np.empty((B, 3), f32), cost=np.empty((B, self.M), f32))
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        tm = _ffi.TimingT()
+        t0 = time.time()
+        rc = self._lib.dgsqp_solve_batch_f32(self._h, B, fp(x0), fp(u_ws), fp(out['u']), fp(out['l']), fp(out['x']), _ffi.iptr(out['status']),
+                                             _ffi.iptr(out['num_iters']), _ffi.iptr(out['qp_solves']), fp(out['cond']), fp(out['cost']), C.byref(tm))
+        if rc != 0:
+            raise RuntimeError(f'dgsqp_solve_batch_f32 failed ({rc}): {self._lib.dgsqp_last_error(self._h).decode()}')
         out['time'] = time.time() - t0
         out['kernel_ms'] = tm.kernel_ms
         out['msg'] = [_ffi.STATUS_MSG[s] for s in out['status']]

@@ -265,6 +265,15 @@ int dgsqp_solve_batch(dgsqp_handle_t h, int64_t B, const double* x0, const doubl
                       int32_t* iters, int32_t* qp_solves, double* cond, double* cost,
                       dgsqp_timing_t* timing);
 
+/* The same call with single-precision arrays at the boundary ("double / float selected by dtype"): x0, u_ws
+   are widened to fp64 on the device, the solve runs in fp64 -- there are no fp32 arithmetic kernels -- and u, l, x, cond,
+   cost are rounded to fp32 on the way out.  Halves the HBM / PCIe bytes of the batch, changes nothing else: on inputs that are
+   exactly representable in fp32 the integer outputs equal those of dgsqp_solve_batch. */
+int dgsqp_solve_batch_f32(dgsqp_handle_t h, int64_t B, const float* x0, const float* u_ws,
+                          float* u_out, float* l_out, float* x_out, int32_t* status,
+                          int32_t* iters, int32_t* qp_solves, float* cond, float* cost,
+                          dgsqp_timing_t* timing);
+
 /*
  * Device-resident variant used by bench.py: inputs are staged once with
  * dgsqp_stage_inputs(); dgsqp_solve_staged() runs only the solve kernel on

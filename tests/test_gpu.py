@@ -877,6 +877,24 @@ def test_large_batch_equals_small_batches(games):
             assert np.array_equal(big[key][lo:lo + 600], small[key]), (key, lo)
 
 
+def test_single_precision_boundary(games, solvers):
+    """float arrays at the boundary (dgsqp_solve_batch_f32).  Inputs exactly representable in fp32 give the very
+    same solve as the fp64 entry point -- identical status / iteration / QP counts -- and outputs that are the fp64 results rounded
+    to fp32 (the arithmetic stays fp64; fp32 kernels are not built)."""
+    from dgsqp_amd.montecarlo import sample_scenarios
+    g = games['kb_chicane_N15'][0]
+    s = solvers['kb_chicane_N15']
+    x0, u_tm = sample_scenarios(g, 40, seed=8)
+    x32, u32 = x0.astype(np.float32), u_tm.astype(np.float32)
+    r64 = s.solve_batch(x32.astype(np.float64), u32.astype(np.float64))
+    r32 = s.solve_batch(x32, u32, dtype=np.float32)
+    assert r32['u'].dtype == np.float32 and r32['l'].dtype == np.float32 and r32['x'].dtype == np.float32
+    for k in ('status', 'num_iters', 'qp_solves'):
+        assert np.array_equal(r32[k], r64[k]), k
+    for k in ('u', 'l', 'x', 'cond', 'cost'):
+        assert np.array_equal(r32[k], r64[k].astype(np.float32)), k
+
+
 def test_rccl_gather_single_rank(games):
     """The library-owned RCCL communicator (dgsqp_comm_init / dgsqp_gather_stats, include/dgsqp.h) on one rank: ncclAllGather of the
     64-byte records of the last solve, padding rows, barrier and max-reduction -- no PyTorch involved."""

@@ -108,7 +108,7 @@ def test_library_exports_every_declared_symbol():
     so = build()
     lib = ctypes.CDLL(str(so))
     header = (ROOT / 'include' / 'dgsqp.h').read_text()
-    declared = set(re.findall(r'\b(dgsqp_[a-z_]+)\s*\(', header))
+    declared = set(re.findall(r'\b(dgsqp_[a-z0-9_]+)\s*\(', header))
     assert declared == set(_ffi.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
