@@ -346,6 +346,151 @@ __device__ inline void xl_rot_cols(gptr X, int n, int rows, int ja, int jb, doub
 // Out: du (L.o_du), lhat (L.o_lhat).  Returns 0 ok, 1 infeasible, 2 numerical failure / iteration limit.
 // J (n x n, row stride js) lives in LDS -- in the slots of the packed P and R of the explicit-inverse kernels, which the classical
 // method does not use -- whenever the game has the LDS-resident layout (n <= ~100), otherwise in the workgroup's L2 scratch.
+// R (upper triangular) is kept column-major in the scratch: a column is what one step of a triangular solve and the append of a
+// row read / write, and it is contiguous.
+template <class MP> struct xl_mp { static constexpr bool lds = false; };
+template <> struct xl_mp<lptr> { static constexpr bool lds = true; };
+#define JSYNC() do { if constexpr (xl_mp<MP>::lds) __syncthreads(); else XSYNC(); } while (0)
+#define RU(i, k) R[(int64_t)(k) * n + (i)]
+
+// Wavefront 0: R r = b (back substitution) and R^T y = b (forward substitution), iq x iq.  Lane l owns rows l, l + 64, ...; the
+// columns of R are fetched BCH at a time (one L2 round trip per BCH steps), the pivots travel by readlane -- no barriers.
+template <int NS, int BCH>
+__device__ inline void xl_wave_backsub_t(cgptr R, int n, int iq, clptr b, lptr out) {
+  const int lane = TID & 63;
+  double a[NS];
+#pragma unroll
+  for (int s = 0; s < NS; s++) { const int i = lane + 64 * s; a[s] = i < iq ? b[i] : 0.0; }
+  for (int k0 = iq - 1; k0 >= 0; k0 -= BCH) {
+    double col[BCH][NS], dg[BCH];
+#pragma unroll
+    for (int t = 0; t < BCH; t++) {
+      const int k = k0 - t;
+      cgptr Rk = R + (int64_t)(k > 0 ? k : 0) * n;
+      dg[t] = k >= 0 ? Rk[k] : 1.0;
+#pragma unroll
+      for (int s = 0; s < NS; s++) { const int i = lane + 64 * s; col[t][s] = (k >= 0 && i < k) ? Rk[i] : 0.0; }
+    }
+#pragma unroll
+    for (int t = 0; t < BCH; t++) {
+      const int k = k0 - t;
+      if (k >= 0) {       // uniform
+        double piv = a[0];
+#pragma unroll
+        for (int s = 1; s < NS; s++) piv = (k >> 6) == s ? a[s] : piv;
+        const double rk = lane_bcast(piv, k & 63) / dg[t];
+        if (lane == 0) out[k] = rk;
+#pragma unroll
+        for (int s = 0; s < NS; s++) a[s] -= col[t][s] * rk;     // (rows >= k carry zeros)
+      }
+    }
+  }
+}
+template <int NS, int BCH>
+__device__ inline void xl_wave_fwdsub_t(cgptr R, int n, int iq, clptr b, lptr out) {
+  const int lane = TID & 63;
+  double y[NS];
+#pragma unroll
+  for (int s = 0; s < NS; s++) y[s] = 0.0;
+  for (int k0 = 0; k0 < iq; k0 += BCH) {
+    double col[BCH][NS], dg[BCH], bk[BCH];
+#pragma unroll
+    for (int t = 0; t < BCH; t++) {
+      const int k = k0 + t;
+      cgptr Rk = R + (int64_t)(k < iq ? k : 0) * n;
+      dg[t] = k < iq ? Rk[k] : 1.0;
+      bk[t] = k < iq ? b[k] : 0.0;
+#pragma unroll
+      for (int s = 0; s < NS; s++) { const int i = lane + 64 * s; col[t][s] = (k < iq && i < k) ? Rk[i] : 0.0; }
+    }
+#pragma unroll
+    for (int t = 0; t < BCH; t++) {
+      const int k = k0 + t;
+      if (k < iq) {       // uniform
+        double part = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; s++) part += col[t][s] * y[s];
+        const double yk = (bk[t] - wave_sum(part)) / dg[t];
+        if (lane == 0) out[k] = yk;
+#pragma unroll
+        for (int s = 0; s < NS; s++) if (lane + 64 * s == k) y[s] = yk;
+      }
+    }
+  }
+}
+__device__ inline void xl_wave_backsub(cgptr R, int n, int iq, clptr b, lptr out) {
+  if (iq <= 64) xl_wave_backsub_t<1, 8>(R, n, iq, b, out);
+  else if (iq <= 128) xl_wave_backsub_t<2, 8>(R, n, iq, b, out);
+  else xl_wave_backsub_t<4, 4>(R, n, iq, b, out);
+}
+__device__ inline void xl_wave_fwdsub(cgptr R, int n, int iq, clptr b, lptr out) {
+  if (iq <= 64) xl_wave_fwdsub_t<1, 8>(R, n, iq, b, out);
+  else if (iq <= 128) xl_wave_fwdsub_t<2, 8>(R, n, iq, b, out);
+  else xl_wave_fwdsub_t<4, 4>(R, n, iq, b, out);
+}
+// Thread (g, i) of the products with J: column / row i, the g-th part of the summation range (n <= 256: two to four parts).
+struct XlSplit { int G, g, i; };
+__device__ inline XlSplit xl_split(int n) {
+  const int npad = (n + 31) & ~31;
+  XlSplit S;
+  S.G = NT / npad; if (S.G > DG_NH) S.G = DG_NH;
+  S.g = TID / npad; S.i = TID - S.g * npad;
+  return S;
+}
+// out[i] = sum_{k0 <= k < k1} J[k][i] v[k]   (J^T v restricted to rows k0..k1-1): consecutive threads read consecutive addresses
+template <class MP>
+__device__ inline void xl_jt_mul(MP J, int js, int n, const XlSplit& S, int k0, int k1, clptr v, lptr out, lptr part) {
+  if (S.g < S.G && S.i < n) {
+    const int len = k1 - k0, ka = k0 + (S.g * len) / S.G, kb = k0 + ((S.g + 1) * len) / S.G;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
+    int k = ka;
+    for (; k + 7 < kb; k += 8) {
+      s0 += J[k * js + S.i] * v[k]; s1 += J[(k + 1) * js + S.i] * v[k + 1];
+      s2 += J[(k + 2) * js + S.i] * v[k + 2]; s3 += J[(k + 3) * js + S.i] * v[k + 3];
+      s4 += J[(k + 4) * js + S.i] * v[k + 4]; s5 += J[(k + 5) * js + S.i] * v[k + 5];
+      s6 += J[(k + 6) * js + S.i] * v[k + 6]; s7 += J[(k + 7) * js + S.i] * v[k + 7];
+    }
+    for (; k < kb; k++) s0 += J[k * js + S.i] * v[k];
+    s0 += s4; s1 += s5; s2 += s6; s3 += s7;
+    part[S.g * n + S.i] = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();
+  if (TID < n) { double s = part[TID]; for (int g = 1; g < S.G; g++) s += part[g * n + TID]; out[TID] = s; }
+  __syncthreads();
+}
+// out[i] = sum_{k0 <= k < k1} J[i][k] v[k]   (J v restricted to columns k0..k1-1).  LDS: the odd row stride keeps the row-per-thread
+// reads conflict-free.  Scratch: one wavefront per row, lanes along the row.
+template <class MP>
+__device__ inline void xl_j_mul(MP J, int js, int n, const XlSplit& S, int k0, int k1, clptr v, lptr out, lptr part) {
+  if constexpr (xl_mp<MP>::lds) {
+    if (S.g < S.G && S.i < n) {
+      const int len = k1 - k0, ka = k0 + (S.g * len) / S.G, kb = k0 + ((S.g + 1) * len) / S.G;
+      MP Ji = J + S.i * js;
+      double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+      int k = ka;
+      for (; k + 3 < kb; k += 4) { s0 += Ji[k] * v[k]; s1 += Ji[k + 1] * v[k + 1]; s2 += Ji[k + 2] * v[k + 2]; s3 += Ji[k + 3] * v[k + 3]; }
+      for (; k < kb; k++) s0 += Ji[k] * v[k];
+      part[S.g * n + S.i] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    if (TID < n) { double s = part[TID]; for (int g = 1; g < S.G; g++) s += part[g * n + TID]; out[TID] = s; }
+    __syncthreads();
+  } else {
+    const int lane = TID & 63;
+    for (int i0 = (TID >> 6) * 4; i0 < n; i0 += (NT / 64) * 4) {      // four rows at a time: their loads are in flight together
+      double s[4] = {0, 0, 0, 0};
+      for (int k = k0 + lane; k < k1; k += 64) {
+        const double vk = v[k];
+#pragma unroll
+        for (int r = 0; r < 4; r++) if (i0 + r < n) s[r] += J[(int64_t)(i0 + r) * js + k] * vk;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) { const double t = wave_sum(s[r]); if (lane == 0 && i0 + r < n) out[i0 + r] = t; }
+    }
+    __syncthreads();
+  }
+}
+
 template <class MP>
 __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
   const DgProb& D = dg_prob;
@@ -353,76 +498,60 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
   lptr lds = LP(0);
   const int n = D.n, nc = D.nc;
   const QpPtrs q = qp_ptrs(c);
-  gptr Lc = c.ws + D.ws_xM, R = c.ws + D.ws_xR;      // row-major n x n
+  cgptr Mx = c.ws + D.ws_xM;
+  gptr R = c.ws + D.ws_xR;      // column-major upper triangle (RU)
   lptr lhat = lds + L.o_lhat, x = q.xv, np = q.yv, dv = q.cvec, zv = q.wv, rv = q.rv, uu = q.lam, tv = q.tv, acc = q.rd;
+  lptr part = lds + L.p_part;
   lds_d* scal = lds + L.scal;
   lds_d* red = lds + L.red;
   const int NONE = 0x7fffffff;
   const double TOL = 1e-10;
+  const XlSplit S = xl_split(n);
+  const int tr = TID >> 5, tc = TID & 31;       // 16 row groups x 32 consecutive columns for the element-wise updates of J
   PROF_BEGIN(pt_qp);
   __syncthreads();
   for (int r = TID; r < nc; r += NT) { q.act[r] = 0; lhat[r] = 0.0; }
-  // ---- Cholesky M = L L^T in place (lower triangle), right-looking
+  // ---- J = L^-T with M = L L^T, inside J's storage: elimination M = L~ D L~^T by columns with the inverse of the unit factor
+  //      accumulated in place.  At step j the pivot vector holds row j left of the diagonal (= row j of X = L~^-1, final) and column j
+  //      below it (a_kj, the multipliers m_i = a_ij / d_j); row i > j becomes row_i - m_i * pivot vector on its whole prefix [0, i]:
+  //      left of j that is the forward substitution on the identity, right of j the Schur update, and (i, j) itself turns into -m_i.
+  //      Every element is independent: two barriers per column, all threads busy.  Then J[c][i] = X[i][c] / sqrt(d_i).
   PROF_BEGIN(px1);
-  if (TID == 0) scal[4] = 0.0;
-  __syncthreads();
+  for (int e = TID; e < n * n; e += NT) { const int i = e / n, k = e - i * n; if (k <= i) J[i * js + k] = Mx[(int64_t)i * n + k]; }
+  JSYNC();
+  bool bad = false;
   for (int j = 0; j < n; j++) {
-    const double djj = Lc[(int64_t)j * n + j];
-    if (!(djj > 0.0)) { if (TID == 0) scal[4] = 1.0; }
-    const double dd = sqrt(djj > 0.0 ? djj : 1.0);
+    const double djj = J[j * js + j];
+    if (!(djj > 0.0)) { bad = true; break; }       // (every thread reads the same pivot)
+    if (j == n - 1) break;
+    const double inv = 1.0 / djj;
+    for (int k = TID; k < n; k += NT) if (k != j) tv[k] = k < j ? J[j * js + k] : J[k * js + j];
     __syncthreads();
-    for (int i = j + 1 + TID; i < n; i += NT) Lc[(int64_t)i * n + j] /= dd;
-    if (TID == 0) Lc[(int64_t)j * n + j] = dd;
-    XSYNC();
-    const int m = n - j - 1;
-    for (int e = TID; e < m * m; e += NT) {
-      const int i = j + 1 + e / m, k = j + 1 + e % m;
-      if (k <= i) Lc[(int64_t)i * n + k] -= Lc[(int64_t)i * n + j] * Lc[(int64_t)k * n + j];
+    for (int i = j + 1 + tr; i < n; i += 16) {
+      const double m = tv[i] * inv;
+      MP Ji = J + (int64_t)i * js;
+#pragma unroll 4
+      for (int k = tc; k <= i; k += 32) Ji[k] = k == j ? -m : Ji[k] - m * tv[k];
     }
-    XSYNC();
+    JSYNC();
   }
-  if (scal[4] != 0.0) { if (TID == 0) scal[DG_QP_NPREV] = 0.0; __syncthreads(); PROF_END(PH_QP, pt_qp); return 2; }
+  if (bad) { if (TID == 0) scal[DG_QP_NPREV] = 0.0; __syncthreads(); PROF_END(PH_QP, pt_qp); return 2; }
   PROF_END(PH_Q_WARM, px1);
   PROF_BEGIN(px2);
-  // ---- J = L^-T (upper triangular).  Up to n = 160: (L^-1)^T by right-looking forward substitution on all unit vectors at
-  //      once -- step k scales row k of X = L^-1 (column k of J) and eliminates column k of L from the rows below.  That makes
-  //      n passes over the matrix; beyond n = 160 the matrices of a full GPU no longer sit in L2 and one thread per column
-  //      solving L^T y = e_col (reads only) is faster (measured at n = 200: 83 vs 107 scen/s).
-  if (n <= 160) {
-    for (int e = TID; e < n * n; e += NT) J[(e / n) * js + e % n] = (e / n == e % n) ? 1.0 : 0.0;
-    XSYNC();
-    for (int k = 0; k < n; k++) {
-      const double dk = 1.0 / Lc[(int64_t)k * n + k];
-      for (int j = TID; j <= k; j += NT) J[j * js + k] *= dk;
-      XSYNC();
-      const int m = n - k - 1;
-      for (int e = TID; e < m * (k + 1); e += NT) {
-        const int i = k + 1 + e % m, j = e / m;                      // X[i][j] -= L[i][k] X[k][j]   (J[j][i] = X[i][j])
-        J[j * js + i] -= Lc[(int64_t)i * n + k] * J[j * js + k];
-      }
-      XSYNC();
-    }
-  } else {
-    for (int col = TID; col < n; col += NT) {
-      for (int i = n - 1; i > col; i--) J[i * js + col] = 0.0;
-      for (int i = col; i >= 0; i--) {
-        double s0 = i == col ? 1.0 : 0.0, s1 = 0, s2 = 0, s3 = 0;      // independent accumulators: the loads overlap
-        int k = i + 1;
-        for (; k + 3 <= col; k += 4) {
-          s0 -= Lc[(int64_t)k * n + i] * J[k * js + col]; s1 -= Lc[(int64_t)(k + 1) * n + i] * J[(k + 1) * js + col];
-          s2 -= Lc[(int64_t)(k + 2) * n + i] * J[(k + 2) * js + col]; s3 -= Lc[(int64_t)(k + 3) * n + i] * J[(k + 3) * js + col];
-        }
-        for (; k <= col; k++) s0 -= Lc[(int64_t)k * n + i] * J[k * js + col];
-        J[i * js + col] = ((s0 + s1) + (s2 + s3)) / Lc[(int64_t)i * n + i];
-      }
-    }
-    XSYNC();
+  for (int j = TID; j < n; j += NT) tv[j] = 1.0 / sqrt(J[j * js + j]);
+  __syncthreads();
+  for (int i = tr; i < n; i += 16) {
+    const double ri = tv[i];
+    MP Ji = J + (int64_t)i * js;
+    for (int k = tc; k < i; k += 32) { J[k * js + i] = Ji[k] * ri; Ji[k] = 0.0; }
   }
+  for (int j = TID; j < n; j += NT) J[j * js + j] = tv[j];
+  JSYNC();
   PROF_END(PH_Q_Y, px2);
   // ---- x = -M^-1 q = -J (J^T q)
-  for (int i = TID; i < n; i += NT) { double s = 0; for (int k = 0; k <= i; k++) s += J[k * js + i] * lds[L.q + k]; dv[i] = s; }
-  __syncthreads();
-  for (int i = TID; i < n; i += NT) { double s = 0; for (int k = i; k < n; k++) s += J[i * js + k] * dv[k]; x[i] = -s; }
+  xl_jt_mul<MP>(J, js, n, S, 0, n, lds + L.q, dv, part);
+  xl_j_mul<MP>(J, js, n, S, 0, n, dv, x, part);
+  for (int i = TID; i < n; i += NT) x[i] = -x[i];
   __syncthreads();
   int iq = 0, ret = 2;
   auto row_slack = [&](int p) -> double {       // -(g_p + a_p . x), block-uniform; tv must hold a_p
@@ -430,12 +559,35 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
     for (int i = TID; i < n; i += NT) s += tv[i] * x[i];
     return -(q.g[p] + block_sum(s, red));
   };
+  // a_p into tv, n_p = -a_p into np, d = J^T n_p into dv (an input-bound / rate row has one or two unit coefficients: d is a row of J)
+  auto row_products = [&](int p) {
+    const DgRow Rw = ld_row(p);
+    __syncthreads();
+    if (Rw.dense < 0) {
+      const int c1 = am_col(D, Rw.a, Rw.k, Rw.idx);
+      const bool has0 = (Rw.type == DG_R_RATE_UB || Rw.type == DG_R_RATE_LB) && Rw.k > 0;
+      const double sgn = (Rw.type == DG_R_IN_UB || Rw.type == DG_R_RATE_UB) ? 1.0 : -1.0;
+      for (int i = TID; i < n; i += NT) {
+        double av = i == c1 ? sgn : 0.0;
+        if (has0 && i == c1 - DGSQP_NUA) av = -sgn;
+        tv[i] = av; np[i] = -av;
+        double dj = J[c1 * js + i];
+        if (has0) dj -= J[(c1 - DGSQP_NUA) * js + i];
+        dv[i] = -sgn * dj;
+      }
+      __syncthreads();
+    } else {
+      for (int col = TID; col < n; col += NT) { const double a = q.gdG ? g_row_coef<cgptr>(D, q.gdG, p, col) : g_row_coef<clptr>(D, q.gd, p, col); tv[col] = a; np[col] = -a; }
+      __syncthreads();
+      xl_jt_mul<MP>(J, js, n, S, 0, n, np, dv, part);
+    }
+  };
   auto drop = [&](int l) {   // remove the active constraint at position l, restore R upper triangular (rotations also on J)
     if (TID == 0) q.act[q.alist[l]] = 0;
     __syncthreads();
-    for (int i = TID; i < n; i += NT) {          // shift columns l+1.. of R one to the left (every thread owns its rows)
-      for (int k = l; k < iq - 1; k++) R[(int64_t)i * n + k] = R[(int64_t)i * n + k + 1];
-      R[(int64_t)i * n + iq - 1] = 0.0;
+    for (int i = TID; i < n; i += NT) {          // shift columns l+1.. of R one to the left (every thread owns its row)
+      for (int k = l; k < iq - 1; k++) RU(i, k) = RU(i, k + 1);
+      RU(i, iq - 1) = 0.0;
     }
     if (TID == 0) {
       for (int k = l; k < iq - 1; k++) { q.alist[k] = q.alist[k + 1]; uu[k] = uu[k + 1]; }
@@ -446,15 +598,15 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
     // Givens rotations of rows (k, k+1), k = l .. iq-1, restore the triangle.  Thread j owns column j of R and carries the
     // current value of row k in a register: it only ever touches its own column (no global fences), the coefficients of
     // rotation k come from the thread of column k through LDS.  The rows it needs are prefetched XL_RCH at a time.
-    lptr gc = acc, gs = lds + L.p_part;
+    lptr gc = acc, gs = part;
     {
       const int j2 = TID;
       const bool mine = j2 >= l && j2 < iq;
-      double ra = mine ? R[(int64_t)l * n + j2] : 0.0;
+      double ra = mine ? RU(l, j2) : 0.0;
       for (int k0 = l; k0 < iq; k0 += XL_RCH) {
         double rbv[XL_RCH];
 #pragma unroll
-        for (int t = 0; t < XL_RCH; t++) { const int k = k0 + t; rbv[t] = (mine && k < iq && j2 >= k) ? R[(int64_t)(k + 1) * n + j2] : 0.0; }
+        for (int t = 0; t < XL_RCH; t++) { const int k = k0 + t; rbv[t] = (mine && k < iq && j2 >= k) ? RU(k + 1, j2) : 0.0; }
 #pragma unroll
         for (int t = 0; t < XL_RCH; t++) {
           const int k = k0 + t;
@@ -466,18 +618,18 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
             __syncthreads();
             if (mine && j2 >= k) {
               const double cc = gc[k], s2 = gs[k];
-              R[(int64_t)k * n + j2] = cc * ra + s2 * rbv[t];
+              RU(k, j2) = cc * ra + s2 * rbv[t];
               ra = -s2 * ra + cc * rbv[t];
             }
           }
         }
       }
-      if (mine) R[(int64_t)iq * n + j2] = ra;
+      if (mine) RU(iq, j2) = ra;
     }
     __syncthreads();
     // the same rotations on the columns of J: every thread carries its own row through the whole sequence
     for (int i = TID; i < n; i += NT) {
-      MP Ji = J + i * js;
+      MP Ji = J + (int64_t)i * js;
       double carry = Ji[l];
       for (int k0 = l; k0 < iq; k0 += XL_RCH) {
         const int cnt = iq - k0 < XL_RCH ? iq - k0 : XL_RCH;
@@ -497,62 +649,32 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
     }
     XSYNC();
   };
-  // Append row p (d = J^T n_p is in dv) to the factorisation: Givens rotations zero d[iq+1..n-1] into d[iq], applied to J's columns;
-  // R gets the new column; p becomes active.
-  auto absorb = [&](int ip) {
-        // (coefficients by one thread -- the recurrence on d is sequential --, then every thread carries its own row of J
-        //  through the whole sequence: one pass over J instead of one barrier per rotation)
-        // Rotation j2 combines d[j2-1] with what the previous ones accumulated in d[j2], i.e. with the suffix norm
-        // h_j2 = |d[j2..n-1]|: c = d[j2-1] / h_{j2-1}, s = h_j2 / h_{j2-1}.  The suffix sums of squares are one short serial
-        // pass; the square roots and quotients are then computed by all threads at once.
-        lptr gc = acc, gs = lds + L.p_part;
-        if (TID == 0) {
-          double sfx = 0.0;
-          for (int k = n - 1; k >= iq; k--) { sfx += dv[k] * dv[k]; gs[k] = sfx; }
-        }
-        __syncthreads();
-        double rc[(256 + NT - 1) / NT], rs[(256 + NT - 1) / NT];
-        {
-          int slot = 0;
-          for (int j2 = iq + 1 + TID; j2 < n; j2 += NT, slot++) {
-            const double h0 = sqrt(gs[j2 - 1]), h1 = sqrt(gs[j2]);
-            rc[slot] = h0 != 0.0 ? dv[j2 - 1] / h0 : 1.0;
-            rs[slot] = h0 != 0.0 ? (j2 == n - 1 ? dv[n - 1] : h1) / h0 : 0.0;     // (the first rotation meets the signed d[n-1])
-          }
-        }
-        const double hfin = sqrt(gs[iq]);
-        __syncthreads();
-        {
-          int slot = 0;
-          for (int j2 = iq + 1 + TID; j2 < n; j2 += NT, slot++) { gc[j2] = rc[slot]; gs[j2] = rs[slot]; dv[j2] = 0.0; }
-          if (TID == 0) dv[iq] = hfin;
-        }
-        __syncthreads();
-        for (int i = TID; i < n; i += NT) {
-          MP Ji = J + i * js;
-          double carry = Ji[n - 1];
-          for (int hi = n - 1; hi > iq; hi -= XL_RCH) {      // XL_RCH rotations per pass: their loads are issued together
-            const int cnt = hi - iq < XL_RCH ? hi - iq : XL_RCH;
-            double ja[XL_RCH], out[XL_RCH];
-#pragma unroll
-            for (int t = 0; t < XL_RCH; t++) ja[t] = t < cnt ? Ji[hi - 1 - t] : 0.0;
-#pragma unroll
-            for (int t = 0; t < XL_RCH; t++) {
-              const int j2 = t < cnt ? hi - t : hi;              // (idle steps: identity)
-              const double cc = t < cnt ? gc[j2] : 1.0, s2 = t < cnt ? gs[j2] : 0.0;
-              out[t] = -s2 * ja[t] + cc * carry;
-              carry = t < cnt ? cc * ja[t] + s2 * carry : carry;
-            }
-#pragma unroll
-            for (int t = 0; t < XL_RCH; t++) if (t < cnt) Ji[hi - t] = out[t];
-          }
-          Ji[iq] = carry;
-        }
-        XSYNC();
-        for (int i = TID; i <= iq; i += NT) R[(int64_t)i * n + iq] = dv[i];
-        if (TID == 0) q.act[ip] = 1;
-        XSYNC();
-        iq++;
+  // Append row p (d = J^T n_p in dv, sig2 = |d[iq..n-1]|^2) to the factorisation: ONE Householder reflection H maps d2 = d[iq..] onto
+  // delta e_1; J2 <- J2 H = J2 - (beta J2 v) v^T with v = d2 - delta e_1, and J2 v = J2 d2 - delta J[:, iq] costs nothing when the
+  // step direction z = J2 d2 is at hand (have_z).  Every element of J2 is updated independently -- the rotation-by-rotation form of
+  // the textbook method is a serial chain per row.  R gets the column (d1, delta); p becomes active.
+  auto absorb = [&](int ip, bool have_z, double sig2) {
+    const double x0 = dv[iq];
+    const double tail2 = sig2 - x0 * x0;
+    double delta = x0, beta = 0.0, v0 = 0.0;
+    if (iq + 1 < n && tail2 > 0.0) { delta = x0 >= 0.0 ? -sqrt(sig2) : sqrt(sig2); v0 = x0 - delta; beta = -1.0 / (delta * v0); }
+    __syncthreads();        // (x0 is read)
+    if (beta != 0.0) {      // uniform
+      if (!have_z) xl_j_mul<MP>(J, js, n, S, iq, n, dv, zv, part);
+      for (int i = TID; i < n; i += NT) zv[i] = beta * (zv[i] - delta * J[i * js + iq]);
+      if (TID == 0) dv[iq] = v0;
+      __syncthreads();
+      for (int i = tr; i < n; i += 16) {
+        const double wi = zv[i];
+        MP Ji = J + (int64_t)i * js;
+#pragma unroll 4
+        for (int k = iq + tc; k < n; k += 32) Ji[k] -= wi * dv[k];
+      }
+    }
+    for (int i = TID; i < iq; i += NT) RU(i, iq) = dv[i];
+    if (TID == 0) { RU(iq, iq) = delta; q.act[ip] = 1; }
+    XSYNC();
+    iq++;
   };
   // ---- warm start (par.qp_warm_start): consecutive QPs of a scenario end on nearly the same active set.  Rebuild the factorisation
   // for the rows the previous QP ended with (skipping rows that have become dependent), take the minimiser on that set,
@@ -568,49 +690,27 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
     PROF_BEGIN(pxw);
     for (int jp = 0; jp < nprev && iq < n; jp++) {
       const int p = q.prev[jp];
-      for (int col = TID; col < n; col += NT) { const double a = q.gdG ? g_row_coef<cgptr>(D, q.gdG, p, col) : g_row_coef<clptr>(D, q.gd, p, col); np[col] = -a; }
-      __syncthreads();
-      double s_np = 0;
-      for (int i = TID; i < n; i += NT) {
-        double s0 = 0, s1 = 0;
-        int k = 0;
-        for (; k + 1 < n; k += 2) { s0 += J[k * js + i] * np[k]; s1 += J[(k + 1) * js + i] * np[k + 1]; }
-        for (; k < n; k++) s0 += J[k * js + i] * np[k];
-        dv[i] = s0 + s1;
-        s_np += np[i] * np[i];
-      }
-      __syncthreads();
-      double s_d2 = 0;
-      for (int k = iq + TID; k < n; k += NT) s_d2 += dv[k] * dv[k];
+      row_products(p);
+      double s_d2 = 0, s_np = 0;
+      for (int k = TID; k < n; k += NT) { if (k >= iq) s_d2 += dv[k] * dv[k]; s_np += np[k] * np[k]; }
       s_d2 = block_sum(s_d2, red); s_np = block_sum(s_np, red);
       if (!(s_d2 > 1e-12 * s_np)) continue;               // (numerically) dependent on the rows taken so far
       if (TID == 0) { q.alist[iq] = p; uu[iq] = 0.0; }
       __syncthreads();
-      absorb(p);
+      absorb(p, false, s_d2);
     }
     // c = J^T q  (dv)
-    for (int i = TID; i < n; i += NT) { double sacc = 0; for (int k = 0; k < n; k++) sacc += J[k * js + i] * lds[L.q + k]; dv[i] = sacc; }
-    __syncthreads();
+    xl_jt_mul<MP>(J, js, n, S, 0, n, lds + L.q, dv, part);
     for (int guard = 0; guard <= n && iq > 0; guard++) {
-      // forward substitution R^T y1 = g_W (rows of R are contiguous), then back substitution R u = y1 + c1
+      // forward substitution R^T y1 = g_W, then back substitution R u = y1 + c1 (wavefront 0)
       for (int k = TID; k < iq; k += NT) acc[k] = q.g[q.alist[k]];
       __syncthreads();
-      for (int k = 0; k < iq; k++) {
-        const double yk = acc[k] / R[(int64_t)k * n + k];
-        __syncthreads();
-        if (TID == 0) zv[k] = yk;
-        for (int i = k + 1 + TID; i < iq; i += NT) acc[i] -= R[(int64_t)k * n + i] * yk;
-        __syncthreads();
-      }
+      if (TID < 64) xl_wave_fwdsub(R, n, iq, acc, zv);
+      __syncthreads();
       for (int k = TID; k < iq; k += NT) acc[k] = zv[k] + dv[k];
       __syncthreads();
-      for (int k = iq - 1; k >= 0; k--) {
-        const double uk = acc[k] / R[(int64_t)k * n + k];
-        __syncthreads();
-        if (TID == 0) uu[k] = uk;
-        for (int i = TID; i < k; i += NT) acc[i] -= R[(int64_t)i * n + k] * uk;
-        __syncthreads();
-      }
+      if (TID < 64) xl_wave_backsub(R, n, iq, acc, uu);
+      __syncthreads();
       double umin = INFINITY, umax = 0.0; int kmin = NONE;
       for (int k = TID; k < iq; k += NT) { if (uu[k] < umin) { umin = uu[k]; kmin = k; } umax = fmax(umax, fabs(uu[k])); }
       { double bv; int bi; block_argmin(umin, kmin, red, bv, bi); umin = bv; kmin = bi; }
@@ -618,16 +718,12 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
       if (!(umin < -1e-10 * (1.0 + umax))) break;
       // drop the row with the most negative multiplier; J's rotations change c = J^T q as well: recompute it
       drop(kmin);
-      for (int i = TID; i < n; i += NT) { double sacc = 0; for (int k = 0; k < n; k++) sacc += J[k * js + i] * lds[L.q + k]; dv[i] = sacc; }
-      __syncthreads();
+      xl_jt_mul<MP>(J, js, n, S, 0, n, lds + L.q, dv, part);
     }
     // x = J1 y1 - J2 c2 ; multipliers clipped at 0 (rounding)
-    for (int i = TID; i < n; i += NT) {
-      double sacc = 0;
-      for (int k = 0; k < iq; k++) sacc += J[i * js + k] * zv[k];
-      for (int k = iq; k < n; k++) sacc -= J[i * js + k] * dv[k];
-      x[i] = sacc;
-    }
+    for (int k = TID; k < n; k += NT) np[k] = k < iq ? zv[k] : -dv[k];
+    __syncthreads();
+    xl_j_mul<MP>(J, js, n, S, 0, n, np, x, part);
     for (int k = TID; k < iq; k += NT) uu[k] = fmax(uu[k], 0.0);
     __syncthreads();
     PROF_END(PH_Q_WARM, pxw);
@@ -638,46 +734,23 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
     const int ip = qp_scan(q, TOL);
     PROF_END(PH_Q_SCAN, px3);
     if (ip == NONE) { ret = 0; break; }
-    for (int col = TID; col < n; col += NT) { const double a = q.gdG ? g_row_coef<cgptr>(D, q.gdG, ip, col) : g_row_coef<clptr>(D, q.gd, ip, col); tv[col] = a; np[col] = -a; }
+    PROF_BEGIN(px4a);
+    row_products(ip);
     if (TID == 0) { uu[iq] = 0.0; q.alist[iq] = ip; }
-    __syncthreads();
     double npnp;
     { double s = 0; for (int i = TID; i < n; i += NT) s += np[i] * np[i]; npnp = block_sum(s, red); }
     double sp = row_slack(ip);
+    PROF_END(PH_Q_DIR, px4a);
     int st = -1;          // -1 running, 0 constraint added, 1 infeasible, 2 iteration limit
+    bool have_d = true;   // dv = J^T n_p is current (row_products); after a drop J has changed
     for (int inner = 0; inner < 10 * (n + nc) && st < 0; inner++) {
       // step 2a: d = J^T np ; z = J2 d2 ; r = R^-1 d1
       PROF_BEGIN(px4);
-      for (int i = TID; i < n; i += NT) {
-        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        int k = 0;
-        for (; k + 3 < n; k += 4) {
-          s0 += J[k * js + i] * np[k]; s1 += J[(k + 1) * js + i] * np[k + 1];
-          s2 += J[(k + 2) * js + i] * np[k + 2]; s3 += J[(k + 3) * js + i] * np[k + 3];
-        }
-        for (; k < n; k++) s0 += J[k * js + i] * np[k];
-        dv[i] = (s0 + s1) + (s2 + s3);
-      }
+      if (!have_d) xl_jt_mul<MP>(J, js, n, S, 0, n, np, dv, part);
+      have_d = false;
+      xl_j_mul<MP>(J, js, n, S, iq, n, dv, zv, part);
+      if (TID < 64) xl_wave_backsub(R, n, iq, dv, rv);
       __syncthreads();
-      for (int i = TID; i < n; i += NT) {
-        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        int k = iq;
-        for (; k + 3 < n; k += 4) {
-          s0 += J[i * js + k] * dv[k]; s1 += J[i * js + k + 1] * dv[k + 1];
-          s2 += J[i * js + k + 2] * dv[k + 2]; s3 += J[i * js + k + 3] * dv[k + 3];
-        }
-        for (; k < n; k++) s0 += J[i * js + k] * dv[k];
-        zv[i] = (s0 + s1) + (s2 + s3);
-      }
-      for (int i = TID; i < iq; i += NT) acc[i] = dv[i];
-      __syncthreads();
-      for (int k = iq - 1; k >= 0; k--) {      // back substitution, column oriented
-        const double rk = acc[k] / R[(int64_t)k * n + k];
-        __syncthreads();
-        if (TID == 0) rv[k] = rk;
-        for (int i = TID; i < k; i += NT) acc[i] -= R[(int64_t)i * n + k] * rk;
-        __syncthreads();
-      }
       PROF_END(PH_Q_DIR, px4);
       // step 2b: step lengths
       double t1 = INFINITY; int lidx = NONE;
@@ -701,7 +774,7 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
       __syncthreads();
       PROF_BEGIN(px5);
       if (t == t2) {   // full step: add constraint ip
-        absorb(ip);
+        absorb(ip, true, znp);
         st = 0;
       } else {          // partial step: drop the blocking constraint, recompute the slack of ip
         drop(lidx);

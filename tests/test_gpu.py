@@ -496,7 +496,7 @@ def test_reg0_games_track_the_oracle(oracle, kind, opts):
     assert par.reg == 0.0 and par.eig_floor == pytest.approx(opts.get('eig_floor', 1e-10))
     s = DGSQP(*g.solver_args(), print_method=None, lsqr_tol=1e-13, **opts)
     literal = not opts
-    B = 48
+    B = 48 if kind == 'barc2' else 192      # (curve game: 48 scenarios leave ~37 oracle-stable ones, two forks more or less move the fraction by 5 points)
     x0, u_tm = sample_scenarios(g, B, seed=0 if kind == 'barc2' else 1)
     u = agent_major(u_tm)
     l0 = np.array([oracle.dual_init(P, par, x0[b], u[b]) for b in range(4)])

@@ -16,12 +16,26 @@ tol = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-6
 games = {'dyn_curve_N25': lambda: mc.dynamic_racing_game(N=25, rk4_substeps=10),
          'dyn_curve_N15': lambda: mc.dynamic_racing_game(N=15, rk4_substeps=4, game_def='curve'),
          'kb_chicane_N15': lambda: mc.kinematic_racing_game('chicane', N=15), 'kb_curve_N10': lambda: mc.kinematic_racing_game('curve', N=10),
-         'kb_barc2_N15': lambda: mc.barc_racing_game(N=15, M=2), 'merge_N8': lambda: mc.merge_game(N=8)}
+         'kb_barc2_N15': lambda: mc.barc_racing_game(N=15, M=2), 'merge_N8': lambda: mc.merge_game(N=8),
+         'kb_curve_reg0_N20': lambda: mc.kinematic_racing_game('curve', N=20, reg=0.0), 'merge_N20': lambda: mc.merge_game()}
 g = games[name]()
-gold = np.load(ROOT / 'tests' / 'golden' / f'{name}.npz')
+P, par = build_problem(*g.solver_args()), tight_lsqr(build_params(g.params))
+gpath = ROOT / 'tests' / 'golden' / f'{name}.npz'
+cache = os.environ.get('FORKS_CACHE')
+if gpath.exists():
+    gold = np.load(gpath)
+elif cache and os.path.exists(cache):
+    gold = np.load(cache)
+else:        # no fixture: the scenarios of the GPU test (seed 1), the oracle run here
+    from conftest import stable_mask
+    x0, u_tm = mc.sample_scenarios(g, int(os.environ.get('FORKS_B', '48')), seed=1)
+    ua = agent_major(u_tm) if u_tm.shape[2] == 4 else np.concatenate([u_tm[:, :, 2 * a:2 * a + 2].reshape(len(x0), -1) for a in range(u_tm.shape[2] // 2)], axis=1)
+    ref = oracle.solve_batch(P, par, x0, ua, nthreads=8)
+    gold = dict(x0=x0, u_ws=u_tm, status=ref['status'], num_iters=ref['num_iters'], qp_solves=ref['qp_solves'], stable=stable_mask(oracle, P, par, x0, ua, ref))
+    if cache:
+        np.savez(cache, **gold)
 x0, u_tm = gold['x0'], gold['u_ws']
 B = len(x0)
-P, par = build_problem(*g.solver_args()), tight_lsqr(build_params(g.params))
 s = DGSQP(*g.solver_args(), print_method=None, lsqr_tol=1e-13)
 s.set_trace(20000)
 res = s.solve_batch(x0, u_tm)
@@ -34,7 +48,7 @@ print(f'{name}: identical {same.sum()}/{B}; oracle reproduces itself under 1e-13
 print('fork table: scenario | oracle-stable | device (status, iters, QPs) | oracle | first differing event | cause')
 names = {40: 'qp solves of the iteration', 1: 'stat', 2: 'p_feas', 3: 'comp', 10: '|du|^2', 11: 'mu', 12: 'phi', 13: 'dphi', 20: 'wd phi1', 21: 'wd phi_n', 22: 'wd phi_n2', 30: 'ls alpha', 31: 'ls phi'}
 u_am = agent_major(u_tm) if u_tm.shape[2] == 4 else np.concatenate([u_tm[:, :, 2 * a:2 * a + 2].reshape(B, -1) for a in range(u_tm.shape[2] // 2)], axis=1)
-for b in np.nonzero(~same)[0]:
+for b in (np.nonzero(~same)[0] if not os.environ.get('FORKS_QUIET') else []):
     to = oracle.solve_trace(P, par, x0[b], u_am[b], max_pairs=60000)
     tg = traces[b]
     k = 0
