@@ -63,6 +63,7 @@ struct DgLds {
   int p_R, p_lam, p_c, p_w, p_r, p_y, p_t, p_alist, p_rd, p_yd2, p_yslot, p_yfree, p_dpart, p_act, p_part;
   // QP outputs that must survive trial evaluations
   int o_du, o_lhat;
+  int c_R;   // classical QP: the first DgProb.c_rcap columns of the triangular factor R, packed column-major (phase-multiplexed with e_xs2)
   // LSQR scratch
   int s_u, s_v, s_w, s_x, s_t;
   int total;  // doubles
@@ -77,6 +78,7 @@ struct DgProb {
   double eig_floor;    // value given to negative eigenvalues by _nearestPD (par.eig_floor, 1e-10 when not set)
   int uniform_nqa;
   int gd_global;    // the packed constraint gradients live in the global scratch (ws_gd) instead of LDS: XL games beyond n ~ 160
+  int c_rcap;       // columns of R (classical QP) that live in LDS; the rest in the global scratch
   int classic_qp;   // the QP runs the classical (J = L^-T) Goldfarb-Idnani kernels of dgsqp_xl.h: XL layout, or a projected Hessian
                     // whose smallest eigenvalue (eig_floor + reg) is below 1e-8 -- the literal reg = 0 formula
   int big;          // 2: XL layout (n > 128, dgsqp_xl.h).  1: the packed inverse P and the packed Householder reflectors live in the workgroup's global scratch (L2)
@@ -213,6 +215,17 @@ static inline std::string dg_build_layout(DgProb& D) {
   if (eig_end > tot) tot = eig_end;
   if (out_end > tot) tot = out_end;
   if (lsqr_end > tot) tot = lsqr_end;
+  // classical QP: as many columns of R as the arena still holds above the QP outputs (the trial trajectories of e_xs2 are dead
+  // while a QP runs); a triangular solve per added row reads R column by column -- from LDS that is 10x less latency than from L2
+  L.c_R = (out_end + 1) & ~1;
+  D.c_rcap = 0;
+  if (D.classic_qp) {
+    const int avail = DG_LDS_LIMIT / 8 - L.c_R;
+    int cap = 0;
+    while (cap < n && (cap + 1) * (cap + 2) / 2 <= avail) cap++;
+    D.c_rcap = cap;
+    if (L.c_R + cap * (cap + 1) / 2 > tot) tot = L.c_R + cap * (cap + 1) / 2;
+  }
   L.total = tot;
   if ((long)tot * 8 > DG_LDS_LIMIT && !D.big) { D.big = 1; return dg_build_layout(D); }   // (n > 128 starts at big = 2)
   if ((long)tot * 8 > DG_LDS_LIMIT && D.big == 2 && !D.gd_global) { D.gd_global = 1; return dg_build_layout(D); }

@@ -17,6 +17,16 @@
 #define XL_GRP 4     // ... handled four at a time (their four columns each stay in registers)
 #endif
 
+// Thread (g, i) of the products with J: column / row i, the g-th part of the summation range (n <= 256: two to four parts).
+struct XlSplit { int G, g, i; };
+__device__ inline XlSplit xl_split(int n) {
+  const int npad = (n + 31) & ~31;
+  XlSplit S;
+  S.G = NT / npad; if (S.G > DG_NH) S.G = DG_NH;
+  S.g = TID / npad; S.i = TID - S.g * npad;
+  return S;
+}
+
 // ---- _nearestPD through the tridiagonal form (the same algorithm as the fast layouts, written generically):
 //   Householder tridiagonalisation of B (block-wide, B and the reflectors in the L2 scratch), Sturm-count multisection
 //   for the NEGATIVE eigenvalues only, eigenvectors by twisted factorisation (one wavefront each), modified Gram-Schmidt,
@@ -24,6 +34,7 @@
 // Returns false (nothing written) when there are more than XL_KMAX negative eigenvalues: the Jacobi path takes over.
 #define XL_KMAX 32
 #define XL_RCH 16      // Givens rotations applied to a row of J per pass
+#define XL_SEG 8       // 16-column segments of a row of J one thread updates per pass (loads first, stores after)
 __device__ __noinline__ bool dev_xl_psd_tri(const Ctx& c, gptr Qpd) {
   const DgProb& D = dg_prob;
   const int n = D.n, lane = TID & 63, wave = TID >> 6;
@@ -35,6 +46,8 @@ __device__ __noinline__ bool dev_xl_psd_tri(const Ctx& c, gptr Qpd) {
   lptr strips = W + 6 * n + XL_KMAX + 16;                                            // 3 n per wavefront
   lds_d* red = lds + D.L.red;
   lds_d* scal = lds + D.L.scal;
+  lptr part = strips;                 // (the strips are free until the eigenvector phase; the QP scratch overlaps this workspace)
+  const XlSplit S = xl_split(n);
   if (TID == 0) { scal[DG_XVALID] = 0.0; scal[DG_XL_BASIS] = 0.0; }   // (Z overwrites the Jacobi warm-start basis)
   __syncthreads();
   PROF_BEGIN(pt_t);
@@ -59,22 +72,48 @@ __device__ __noinline__ bool dev_xl_psd_tri(const Ctx& c, gptr Qpd) {
     __syncthreads();
     for (int i = k + 1 + TID; i < n; i += NT) Vr[(int64_t)k * n + i] = vv[i];
     if (beta != 0.0) {
-      // p = beta B v (B symmetric: column i is read along rows, coalesced over i)
+      // p = beta B v (B symmetric: column i is read along rows, coalesced over i); thread (g, i) sums the g-th part of the rows
+      if (S.g < S.G && S.i > k && S.i < n) {
+        const int len = n - k - 1, ja = k + 1 + (S.g * len) / S.G, jb = k + 1 + ((S.g + 1) * len) / S.G;
+        cgptr pb = Bm + (int64_t)ja * n + S.i;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        int j = ja;
+        for (; j + 7 < jb; j += 8, pb += 8 * n) {
+          double b[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) b[u] = pb[u * n];
+          a0 += b[0] * vv[j] + b[4] * vv[j + 4]; a1 += b[1] * vv[j + 1] + b[5] * vv[j + 5];
+          a2 += b[2] * vv[j + 2] + b[6] * vv[j + 6]; a3 += b[3] * vv[j + 3] + b[7] * vv[j + 7];
+        }
+        for (; j < jb; j++, pb += n) a0 += pb[0] * vv[j];
+        part[S.g * n + S.i] = (a0 + a1) + (a2 + a3);
+      }
+      __syncthreads();
       double pvsum = 0;
       for (int i = k + 1 + TID; i < n; i += NT) {
-        double a0 = 0, a1 = 0;
-        int j = k + 1;
-        for (; j + 1 < n; j += 2) { a0 += Bm[(int64_t)j * n + i] * vv[j]; a1 += Bm[(int64_t)(j + 1) * n + i] * vv[j + 1]; }
-        if (j < n) a0 += Bm[(int64_t)j * n + i] * vv[j];
-        const double p = beta * (a0 + a1);
+        double a = part[i];
+        for (int g = 1; g < S.G; g++) a += part[g * n + i];
+        const double p = beta * a;
         pv[i] = p; pvsum += p * vv[i];
       }
       const double K = 0.5 * beta * block_sum(pvsum, red);
       for (int i = k + 1 + TID; i < n; i += NT) pv[i] -= K * vv[i];       // w
       __syncthreads();
-      for (int e = TID; e < m * m; e += NT) {
-        const int i = k + 1 + e / m, j = k + 1 + e % m;
-        Bm[(int64_t)i * n + j] -= vv[i] * pv[j] + pv[i] * vv[j];
+      // B -= v w^T + w v^T on the trailing block: thread (g, j) owns column j of the rows k + 1 + g, k + 1 + g + G, ...
+      if (S.g < S.G && S.i > k && S.i < n) {
+        const int j = S.i, G = S.G;
+        const double vj = vv[j], wj = pv[j];
+        int i = k + 1 + S.g;
+        gptr pb = Bm + (int64_t)i * n + j;
+        const int64_t rs = (int64_t)G * n;
+        for (; i + 7 * G < n; i += 8 * G, pb += 8 * rs) {      // eight rows per pass: their L2 round trips overlap
+          double b[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) b[u] = pb[u * rs];
+#pragma unroll
+          for (int u = 0; u < 8; u++) pb[u * rs] = b[u] - (vv[i + u * G] * wj + pv[i + u * G] * vj);
+        }
+        for (; i < n; i += G, pb += rs) pb[0] = pb[0] - (vv[i] * wj + pv[i] * vj);
       }
     }
     XSYNC();
@@ -351,12 +390,17 @@ __device__ inline void xl_rot_cols(gptr X, int n, int rows, int ja, int jb, doub
 template <class MP> struct xl_mp { static constexpr bool lds = false; };
 template <> struct xl_mp<lptr> { static constexpr bool lds = true; };
 #define JSYNC() do { if constexpr (xl_mp<MP>::lds) __syncthreads(); else XSYNC(); } while (0)
-#define RU(i, k) R[(int64_t)(k) * n + (i)]
+// R: column k holds rows 0..k.  The first `cap` columns are packed in LDS, the others sit column-major (stride n) in the scratch.
+struct XlR {
+  gptr G; lptr Lp; int cap, n;
+  __device__ inline double get(int i, int k) const { return k < cap ? Lp[((k * (k + 1)) >> 1) + i] : G[(int64_t)k * n + i]; }
+  __device__ inline void set(int i, int k, double v) const { if (k < cap) Lp[((k * (k + 1)) >> 1) + i] = v; else G[(int64_t)k * n + i] = v; }
+};
 
 // Wavefront 0: R r = b (back substitution) and R^T y = b (forward substitution), iq x iq.  Lane l owns rows l, l + 64, ...; the
-// columns of R are fetched BCH at a time (one L2 round trip per BCH steps), the pivots travel by readlane -- no barriers.
+// columns of R are fetched BCH at a time (one round trip per BCH steps), the pivots travel by readlane -- no barriers.
 template <int NS, int BCH>
-__device__ inline void xl_wave_backsub_t(cgptr R, int n, int iq, clptr b, lptr out) {
+__device__ inline void xl_wave_backsub_t(const XlR& R, int iq, clptr b, lptr out) {
   const int lane = TID & 63;
   double a[NS];
 #pragma unroll
@@ -365,11 +409,10 @@ __device__ inline void xl_wave_backsub_t(cgptr R, int n, int iq, clptr b, lptr o
     double col[BCH][NS], dg[BCH];
 #pragma unroll
     for (int t = 0; t < BCH; t++) {
-      const int k = k0 - t;
-      cgptr Rk = R + (int64_t)(k > 0 ? k : 0) * n;
-      dg[t] = k >= 0 ? Rk[k] : 1.0;
+      const int k = k0 - t, kk = k > 0 ? k : 0;
+      dg[t] = k >= 0 ? R.get(kk, kk) : 1.0;
 #pragma unroll
-      for (int s = 0; s < NS; s++) { const int i = lane + 64 * s; col[t][s] = (k >= 0 && i < k) ? Rk[i] : 0.0; }
+      for (int s = 0; s < NS; s++) { const int i = lane + 64 * s; col[t][s] = (k >= 0 && i < k) ? R.get(i, kk) : 0.0; }
     }
 #pragma unroll
     for (int t = 0; t < BCH; t++) {
@@ -387,7 +430,7 @@ __device__ inline void xl_wave_backsub_t(cgptr R, int n, int iq, clptr b, lptr o
   }
 }
 template <int NS, int BCH>
-__device__ inline void xl_wave_fwdsub_t(cgptr R, int n, int iq, clptr b, lptr out) {
+__device__ inline void xl_wave_fwdsub_t(const XlR& R, int iq, clptr b, lptr out) {
   const int lane = TID & 63;
   double y[NS];
 #pragma unroll
@@ -396,12 +439,11 @@ __device__ inline void xl_wave_fwdsub_t(cgptr R, int n, int iq, clptr b, lptr ou
     double col[BCH][NS], dg[BCH], bk[BCH];
 #pragma unroll
     for (int t = 0; t < BCH; t++) {
-      const int k = k0 + t;
-      cgptr Rk = R + (int64_t)(k < iq ? k : 0) * n;
-      dg[t] = k < iq ? Rk[k] : 1.0;
+      const int k = k0 + t, kk = k < iq ? k : 0;
+      dg[t] = k < iq ? R.get(kk, kk) : 1.0;
       bk[t] = k < iq ? b[k] : 0.0;
 #pragma unroll
-      for (int s = 0; s < NS; s++) { const int i = lane + 64 * s; col[t][s] = (k < iq && i < k) ? Rk[i] : 0.0; }
+      for (int s = 0; s < NS; s++) { const int i = lane + 64 * s; col[t][s] = (k < iq && i < k) ? R.get(i, kk) : 0.0; }
     }
 #pragma unroll
     for (int t = 0; t < BCH; t++) {
@@ -418,24 +460,15 @@ __device__ inline void xl_wave_fwdsub_t(cgptr R, int n, int iq, clptr b, lptr ou
     }
   }
 }
-__device__ inline void xl_wave_backsub(cgptr R, int n, int iq, clptr b, lptr out) {
-  if (iq <= 64) xl_wave_backsub_t<1, 8>(R, n, iq, b, out);
-  else if (iq <= 128) xl_wave_backsub_t<2, 8>(R, n, iq, b, out);
-  else xl_wave_backsub_t<4, 4>(R, n, iq, b, out);
+__device__ inline void xl_wave_backsub(const XlR& R, int iq, clptr b, lptr out) {
+  if (iq <= 64) xl_wave_backsub_t<1, 8>(R, iq, b, out);
+  else if (iq <= 128) xl_wave_backsub_t<2, 8>(R, iq, b, out);
+  else xl_wave_backsub_t<4, 4>(R, iq, b, out);
 }
-__device__ inline void xl_wave_fwdsub(cgptr R, int n, int iq, clptr b, lptr out) {
-  if (iq <= 64) xl_wave_fwdsub_t<1, 8>(R, n, iq, b, out);
-  else if (iq <= 128) xl_wave_fwdsub_t<2, 8>(R, n, iq, b, out);
-  else xl_wave_fwdsub_t<4, 4>(R, n, iq, b, out);
-}
-// Thread (g, i) of the products with J: column / row i, the g-th part of the summation range (n <= 256: two to four parts).
-struct XlSplit { int G, g, i; };
-__device__ inline XlSplit xl_split(int n) {
-  const int npad = (n + 31) & ~31;
-  XlSplit S;
-  S.G = NT / npad; if (S.G > DG_NH) S.G = DG_NH;
-  S.g = TID / npad; S.i = TID - S.g * npad;
-  return S;
+__device__ inline void xl_wave_fwdsub(const XlR& R, int iq, clptr b, lptr out) {
+  if (iq <= 64) xl_wave_fwdsub_t<1, 8>(R, iq, b, out);
+  else if (iq <= 128) xl_wave_fwdsub_t<2, 8>(R, iq, b, out);
+  else xl_wave_fwdsub_t<4, 4>(R, iq, b, out);
 }
 // out[i] = sum_{k0 <= k < k1} J[k][i] v[k]   (J^T v restricted to rows k0..k1-1): consecutive threads read consecutive addresses
 template <class MP>
@@ -499,7 +532,7 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
   const int n = D.n, nc = D.nc;
   const QpPtrs q = qp_ptrs(c);
   cgptr Mx = c.ws + D.ws_xM;
-  gptr R = c.ws + D.ws_xR;      // column-major upper triangle (RU)
+  const XlR R{c.ws + D.ws_xR, lds + L.c_R, D.c_rcap, n};
   lptr lhat = lds + L.o_lhat, x = q.xv, np = q.yv, dv = q.cvec, zv = q.wv, rv = q.rv, uu = q.lam, tv = q.tv, acc = q.rd;
   lptr part = lds + L.p_part;
   lds_d* scal = lds + L.scal;
@@ -507,7 +540,7 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
   const int NONE = 0x7fffffff;
   const double TOL = 1e-10;
   const XlSplit S = xl_split(n);
-  const int tr = TID >> 5, tc = TID & 31;       // 16 row groups x 32 consecutive columns for the element-wise updates of J
+  const int tr = TID >> 4, tc = TID & 15;       // 32 row groups x 16 consecutive columns for the element-wise updates of J
   PROF_BEGIN(pt_qp);
   __syncthreads();
   for (int r = TID; r < nc; r += NT) { q.act[r] = 0; lhat[r] = 0.0; }
@@ -520,30 +553,70 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
   for (int e = TID; e < n * n; e += NT) { const int i = e / n, k = e - i * n; if (k <= i) J[i * js + k] = Mx[(int64_t)i * n + k]; }
   JSYNC();
   bool bad = false;
+#ifdef DG_PROF
+  long long pa_ = 0, pb_ = 0, pc_ = 0;
+#endif
   for (int j = 0; j < n; j++) {
+#ifdef DG_PROF
+    long long p0_ = clock64();
+#endif
     const double djj = J[j * js + j];
     if (!(djj > 0.0)) { bad = true; break; }       // (every thread reads the same pivot)
     if (j == n - 1) break;
     const double inv = 1.0 / djj;
-    for (int k = TID; k < n; k += NT) if (k != j) tv[k] = k < j ? J[j * js + k] : J[k * js + j];
-    __syncthreads();
-    for (int i = j + 1 + tr; i < n; i += 16) {
-      const double m = tv[i] * inv;
-      MP Ji = J + (int64_t)i * js;
-#pragma unroll 4
-      for (int k = tc; k <= i; k += 32) Ji[k] = k == j ? -m : Ji[k] - m * tv[k];
+    for (int k = TID; k < n; k += NT) {
+      if (k < j) tv[k] = J[j * js + k];
+      else if (k > j) { const double akj = J[k * js + j]; tv[k] = akj; np[k] = akj * inv; }      // pivot vector / multipliers m_k
     }
+    __syncthreads();
+#ifdef DG_PROF
+    { const long long t_ = clock64(); pa_ += t_ - p0_; p0_ = t_; }
+#endif
+    for (int i = j + 1 + TID; i < n; i += NT) J[i * js + j] = -np[i];
+    // thread (g, k): column k != j of the rows i >= max(j + 1, k), i = j + 1 + g (mod G) -- its pivot-vector entry is loaded once, the
+    // multiplier of a row is a broadcast read; four rows per pass, loads first, stores after; no guards inside the loop
+    if (S.g < S.G && S.i < n && S.i != j) {
+      const int k = S.i, G = S.G;
+      const double pk = tv[k];
+      int i = j + 1 + S.g;
+      if (i < k) i += ((k - i + G - 1) / G) * G;
+      MP pj = J + (int64_t)i * js + k;
+      clptr pm = np + i;
+      const int rs = G * js;
+      if constexpr (!xl_mp<MP>::lds) {
+        for (; i + 7 * G < n; i += 8 * G, pj += 8 * rs, pm += 8 * G) {      // scratch: eight L2 round trips in flight
+          double a[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) a[u] = pj[u * rs];
+#pragma unroll
+          for (int u = 0; u < 8; u++) pj[u * rs] = a[u] - pm[u * G] * pk;
+        }
+      }
+      for (; i + 3 * G < n; i += 4 * G, pj += 4 * rs, pm += 4 * G) {
+        const double a0 = pj[0], a1 = pj[rs], a2 = pj[2 * rs], a3 = pj[3 * rs];
+        const double m0 = pm[0], m1 = pm[G], m2 = pm[2 * G], m3 = pm[3 * G];
+        pj[0] = a0 - m0 * pk; pj[rs] = a1 - m1 * pk; pj[2 * rs] = a2 - m2 * pk; pj[3 * rs] = a3 - m3 * pk;
+      }
+      for (; i < n; i += G, pj += rs, pm += G) pj[0] = pj[0] - pm[0] * pk;
+    }
+#ifdef DG_PROF
+    { const long long t_ = clock64(); pb_ += t_ - p0_; p0_ = t_; }
+#endif
     JSYNC();
+#ifdef DG_PROF
+    { const long long t_ = clock64(); pc_ += t_ - p0_; p0_ = t_; }
+#endif
   }
+  PROF_COUNT(PH_W_BUILD, pa_); PROF_COUNT(PH_W_MULT, pb_); PROF_COUNT(PH_W_X, pc_);
   if (bad) { if (TID == 0) scal[DG_QP_NPREV] = 0.0; __syncthreads(); PROF_END(PH_QP, pt_qp); return 2; }
   PROF_END(PH_Q_WARM, px1);
   PROF_BEGIN(px2);
   for (int j = TID; j < n; j += NT) tv[j] = 1.0 / sqrt(J[j * js + j]);
   __syncthreads();
-  for (int i = tr; i < n; i += 16) {
+  for (int i = tr; i < n; i += 32) {
     const double ri = tv[i];
     MP Ji = J + (int64_t)i * js;
-    for (int k = tc; k < i; k += 32) { J[k * js + i] = Ji[k] * ri; Ji[k] = 0.0; }
+    for (int k = tc; k < i; k += 16) { J[k * js + i] = Ji[k] * ri; Ji[k] = 0.0; }
   }
   for (int j = TID; j < n; j += NT) J[j * js + j] = tv[j];
   JSYNC();
@@ -585,28 +658,29 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
   auto drop = [&](int l) {   // remove the active constraint at position l, restore R upper triangular (rotations also on J)
     if (TID == 0) q.act[q.alist[l]] = 0;
     __syncthreads();
-    for (int i = TID; i < n; i += NT) {          // shift columns l+1.. of R one to the left (every thread owns its row)
-      for (int k = l; k < iq - 1; k++) RU(i, k) = RU(i, k + 1);
-      RU(i, iq - 1) = 0.0;
-    }
+    // R loses column l: new column j = old column j + 1 (rows 0..j+1, upper Hessenberg from column l on).  Rows above l are copied
+    // (thread = row, columns in ascending order: a thread only ever touches its own row)
+    for (int i = TID; i < l; i += NT)
+      for (int k = l; k < iq - 1; k++) R.set(i, k, R.get(i, k + 1));
     if (TID == 0) {
       for (int k = l; k < iq - 1; k++) { q.alist[k] = q.alist[k + 1]; uu[k] = uu[k + 1]; }
       q.alist[iq - 1] = q.alist[iq]; uu[iq - 1] = uu[iq]; uu[iq] = 0.0; q.alist[iq] = -1;
     }
     XSYNC();
     iq--;
-    // Givens rotations of rows (k, k+1), k = l .. iq-1, restore the triangle.  Thread j owns column j of R and carries the
-    // current value of row k in a register: it only ever touches its own column (no global fences), the coefficients of
-    // rotation k come from the thread of column k through LDS.  The rows it needs are prefetched XL_RCH at a time.
+    // Givens rotations of rows (k, k+1), k = l .. iq-1, restore the triangle.  Thread j builds NEW column j from OLD column j + 1 and
+    // carries the current value of row k in a register; the coefficients of rotation k come from the thread of column k through LDS.
+    // The rows it needs are prefetched XL_RCH at a time -- always before the step (and its barrier) in which the thread of the
+    // neighbouring column overwrites them.
     lptr gc = acc, gs = part;
     {
       const int j2 = TID;
       const bool mine = j2 >= l && j2 < iq;
-      double ra = mine ? RU(l, j2) : 0.0;
+      double ra = mine ? R.get(l, j2 + 1) : 0.0;
       for (int k0 = l; k0 < iq; k0 += XL_RCH) {
         double rbv[XL_RCH];
 #pragma unroll
-        for (int t = 0; t < XL_RCH; t++) { const int k = k0 + t; rbv[t] = (mine && k < iq && j2 >= k) ? RU(k + 1, j2) : 0.0; }
+        for (int t = 0; t < XL_RCH; t++) { const int k = k0 + t; rbv[t] = (mine && k < iq && j2 >= k) ? R.get(k + 1, j2 + 1) : 0.0; }
 #pragma unroll
         for (int t = 0; t < XL_RCH; t++) {
           const int k = k0 + t;
@@ -618,13 +692,12 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
             __syncthreads();
             if (mine && j2 >= k) {
               const double cc = gc[k], s2 = gs[k];
-              RU(k, j2) = cc * ra + s2 * rbv[t];
+              R.set(k, j2, cc * ra + s2 * rbv[t]);
               ra = -s2 * ra + cc * rbv[t];
             }
           }
         }
       }
-      if (mine) RU(iq, j2) = ra;
     }
     __syncthreads();
     // the same rotations on the columns of J: every thread carries its own row through the whole sequence
@@ -664,15 +737,31 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
       for (int i = TID; i < n; i += NT) zv[i] = beta * (zv[i] - delta * J[i * js + iq]);
       if (TID == 0) dv[iq] = v0;
       __syncthreads();
-      for (int i = tr; i < n; i += 16) {
-        const double wi = zv[i];
-        MP Ji = J + (int64_t)i * js;
-#pragma unroll 4
-        for (int k = iq + tc; k < n; k += 32) Ji[k] -= wi * dv[k];
+      if (S.g < S.G && S.i + iq < n) {     // thread (g, k): column k >= iq of the rows g, g + G, ...
+        const int k = S.i + iq, G = S.G, rs = G * js;
+        const double vk = dv[k];
+        int i = S.g;
+        MP pj = J + (int64_t)i * js + k;
+        clptr pw = zv + i;
+        if constexpr (!xl_mp<MP>::lds) {
+          for (; i + 7 * G < n; i += 8 * G, pj += 8 * rs, pw += 8 * G) {
+            double a[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) a[u] = pj[u * rs];
+#pragma unroll
+            for (int u = 0; u < 8; u++) pj[u * rs] = a[u] - pw[u * G] * vk;
+          }
+        }
+        for (; i + 3 * G < n; i += 4 * G, pj += 4 * rs, pw += 4 * G) {
+          const double a0 = pj[0], a1 = pj[rs], a2 = pj[2 * rs], a3 = pj[3 * rs];
+          const double w0 = pw[0], w1 = pw[G], w2 = pw[2 * G], w3 = pw[3 * G];
+          pj[0] = a0 - w0 * vk; pj[rs] = a1 - w1 * vk; pj[2 * rs] = a2 - w2 * vk; pj[3 * rs] = a3 - w3 * vk;
+        }
+        for (; i < n; i += G, pj += rs, pw += G) pj[0] = pj[0] - pw[0] * vk;
       }
     }
-    for (int i = TID; i < iq; i += NT) RU(i, iq) = dv[i];
-    if (TID == 0) { RU(iq, iq) = delta; q.act[ip] = 1; }
+    for (int i = TID; i < iq; i += NT) R.set(i, iq, dv[i]);
+    if (TID == 0) { R.set(iq, iq, delta); q.act[ip] = 1; }
     XSYNC();
     iq++;
   };
@@ -705,11 +794,11 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
       // forward substitution R^T y1 = g_W, then back substitution R u = y1 + c1 (wavefront 0)
       for (int k = TID; k < iq; k += NT) acc[k] = q.g[q.alist[k]];
       __syncthreads();
-      if (TID < 64) xl_wave_fwdsub(R, n, iq, acc, zv);
+      if (TID < 64) xl_wave_fwdsub(R, iq, acc, zv);
       __syncthreads();
       for (int k = TID; k < iq; k += NT) acc[k] = zv[k] + dv[k];
       __syncthreads();
-      if (TID < 64) xl_wave_backsub(R, n, iq, acc, uu);
+      if (TID < 64) xl_wave_backsub(R, iq, acc, uu);
       __syncthreads();
       double umin = INFINITY, umax = 0.0; int kmin = NONE;
       for (int k = TID; k < iq; k += NT) { if (uu[k] < umin) { umin = uu[k]; kmin = k; } umax = fmax(umax, fabs(uu[k])); }
@@ -749,7 +838,7 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
       if (!have_d) xl_jt_mul<MP>(J, js, n, S, 0, n, np, dv, part);
       have_d = false;
       xl_j_mul<MP>(J, js, n, S, iq, n, dv, zv, part);
-      if (TID < 64) xl_wave_backsub(R, n, iq, dv, rv);
+      if (TID < 64) xl_wave_backsub(R, iq, dv, rv);
       __syncthreads();
       PROF_END(PH_Q_DIR, px4);
       // step 2b: step lengths
