@@ -220,21 +220,27 @@ __device__ inline double horner(double p, double z, double C) {
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(z), "s"(C));
   return r;
 }
+// fdlibm kernels on the reduced argument: sin r = r + r^3 S(r^2), cos r = 1 - r^2/2 + r^4 C(r^2)
+__device__ inline double sin_poly(double z) {
+  double ps = horner(1.58969099521155010221e-10, z, -2.50507602534068634195e-08);
+  ps = horner(ps, z, 2.75573137070700676789e-06);
+  ps = horner(ps, z, -1.98412698298579493134e-04);
+  ps = horner(ps, z, 8.33333333332248946124e-03);
+  return horner(ps, z, -1.66666666666666324348e-01);
+}
+__device__ inline double cos_poly(double z) {
+  double pc = horner(-1.13596475577881948265e-11, z, 2.08757232129817482790e-09);
+  pc = horner(pc, z, -2.75573143513906633035e-07);
+  pc = horner(pc, z, 2.48015872894767294178e-05);
+  pc = horner(pc, z, -1.38888888888741095749e-03);
+  return horner(pc, z, 4.16666666666666019037e-02);
+}
 __device__ inline void dev_sincos(double x, double& so, double& co) {
   const double k = __builtin_rint(x * 0.63661977236758138);
   double r = __builtin_fma(-k, 1.5707963267948966, x);
   r = __builtin_fma(-k, 6.123233995736766e-17, r);
   const double z = r * r;
-  double ps = horner(1.58969099521155010221e-10, z, -2.50507602534068634195e-08);
-  ps = horner(ps, z, 2.75573137070700676789e-06);
-  ps = horner(ps, z, -1.98412698298579493134e-04);
-  ps = horner(ps, z, 8.33333333332248946124e-03);
-  ps = horner(ps, z, -1.66666666666666324348e-01);
-  double pc = horner(-1.13596475577881948265e-11, z, 2.08757232129817482790e-09);
-  pc = horner(pc, z, -2.75573143513906633035e-07);
-  pc = horner(pc, z, 2.48015872894767294178e-05);
-  pc = horner(pc, z, -1.38888888888741095749e-03);
-  pc = horner(pc, z, 4.16666666666666019037e-02);
+  const double ps = sin_poly(z), pc = cos_poly(z);
   const double sn = __builtin_fma(r * z, ps, r);
   const double cs = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
   const int q = (int)k;
@@ -244,8 +250,7 @@ __device__ inline void dev_sincos(double x, double& so, double& co) {
   co = __hiloint2double(__double2hiint(c1) ^ (((q + 1) & 2) << 30), __double2loint(c1));
 }
 // atan polynomial on the reduced argument t (|t| <= 7/16): t - t^3 P(t^2)
-__device__ inline double atan_poly_tail(double t, double hi, double lo) {
-  const double z = t * t;
+__device__ inline double atan_poly(double z) {
   double p = horner(1.62858201153657823623e-02, z, -3.65315727442169155270e-02);
   p = horner(p, z, 4.97687799461593236017e-02);
   p = horner(p, z, -5.83357013379057348645e-02);
@@ -255,7 +260,11 @@ __device__ inline double atan_poly_tail(double t, double hi, double lo) {
   p = horner(p, z, -1.11111104054623557880e-01);
   p = horner(p, z, 1.42857142725034663711e-01);
   p = horner(p, z, -1.99999999998764832476e-01);
-  p = horner(p, z, 3.33333333333329318027e-01);
+  return horner(p, z, 3.33333333333329318027e-01);
+}
+__device__ inline double atan_poly_tail(double t, double hi, double lo) {
+  const double z = t * t;
+  const double p = atan_poly(z);
   return hi + ((lo - t * z * p) + t);
 }
 // Argument reduction atan(t) = atan(k) + atan((t - k)/(1 + k t)), k in {0, 1/2, 1, 3/2, inf}, folded into ONE division.  The

@@ -107,9 +107,72 @@ struct DynLane {
   // per-lane constants of the pair rollout, loaded once (agent parameters are lane-dependent, i.e. vector loads otherwise)
   double L_f, L_r, Bc, Cc, Dc, lin, c_da, c_dr, c_r, p_r, inv_mass, inv_Iz, fr, ff, L, invL;
   int role, simple_slip, pacejka, nsegs;
+  double Ll, cdl, sdl, add;      // axle offset (+L_f / -L_r) and, per stage, the rotation into the wheel frame and the slip offset of this lane's axle
   // track segment currently containing s: [lo, hi), curvature, tangent angle at lo and its slope
   double lo, hi, curv, ang0, slope;
 };
+// Elementary functions of the scalar rollout.  Its ~10^3 sequential f_c evaluations run on a handful of lanes of ONE wavefront: the
+// instruction count of the chain is the latency of the rollout (and of every line-search trial).  On a car that is not spinning
+// every angle is small -- slip angles below atan(7/16), Pacejka arguments and heading errors below pi/4 -- and then the range
+// reductions are identities: when EVERY active lane is in that range (wave-uniform test, no divergence) the table look-up, the
+// quadrant selects and the unused cosine are skipped.  Same operations in the same order as the general path: bit-identical.
+__device__ inline double roll_atan_core(double num, double rcp, double hi, double lo) {
+  const double t = num * rcp, z = t * t;
+  const double p = atan_poly(z);
+  double e = __builtin_fma(-p, t * z, lo);
+  e = __builtin_fma(num, rcp, e);
+  return hi + e;
+}
+__device__ inline double roll_atan2(double y, double x) {
+  const double ay = __builtin_fabs(y), ax = __builtin_fabs(x);
+  const double y16 = 16.0 * ay;
+  if (__all(x > 0.0 && y16 < 7.0 * ax)) {
+    const double r = roll_atan_core(ay, fast_rcp(ax), 0.0, 0.0);
+    return y < 0.0 ? -r : r;
+  }
+  const int rid = (int)(y16 >= 7.0 * ax) + (int)(y16 >= 11.0 * ax) + (int)(y16 >= 19.0 * ax) + (int)(y16 >= 39.0 * ax);
+  clptr ta = LP(dg_prob.L.t_atan);
+  const double hi = ta[rid], lo = ta[5 + rid];
+  const bool big = rid == 4;
+  const double kk = 0.5 * (double)(big ? 0 : rid);
+  const double num = big ? -ax : __builtin_fma(-kk, ax, ay);
+  double den = big ? ay : __builtin_fma(kk, ay, ax);
+  den = den == 0.0 ? 1.0 : den;
+  double r = roll_atan_core(num, fast_rcp(den), hi, lo);
+  r = x < 0.0 ? (3.141592653589793 - r) + 1.2246467991473532e-16 : r;
+  return y < 0.0 ? -r : r;
+}
+__device__ inline double roll_atan(double x) {
+  const double ay = __builtin_fabs(x);
+  if (__all(ay < 0.4375)) {
+    const double r = roll_atan_core(ay, 1.0, 0.0, 0.0);
+    return x < 0.0 ? -r : r;
+  }
+  const int rid = (int)(ay >= 0.4375) + (int)(ay >= 0.6875) + (int)(ay >= 1.1875) + (int)(ay >= 2.4375);
+  clptr ta = LP(dg_prob.L.t_atan);
+  const double hi = ta[rid], lo = ta[5 + rid];
+  const bool big = rid == 4;
+  const double kk = 0.5 * (double)(big ? 0 : rid);
+  const double num = big ? -1.0 : ay - kk;
+  const double den = big ? ay : __builtin_fma(kk, ay, 1.0);
+  const double r = roll_atan_core(num, fast_rcp(den), hi, lo);
+  return x < 0.0 ? -r : r;
+}
+__device__ inline double roll_sin(double x) {
+  if (__all(__builtin_fabs(x) < 0.78)) { const double z = x * x; return __builtin_fma(x * z, sin_poly(z), x); }
+  double s_, c_;
+  dev_sincos(x, s_, c_);
+  return s_;
+}
+__device__ inline void roll_sincos(double x, double& so, double& co) {
+  if (__all(__builtin_fabs(x) < 0.78)) {
+    const double z = x * x;
+    so = __builtin_fma(x * z, sin_poly(z), x);
+    co = __builtin_fma(z * z, cos_poly(z), __builtin_fma(-0.5, z, 1.0));
+    return;
+  }
+  dev_sincos(x, so, co);
+}
 __device__ inline void dyn_lane_seek(DynLane& Z, double sbar) {
   constexpr int S1 = DGSQP_MAX_SEGS + 1;
   clptr tt = LP(dg_prob.L.t_track);
@@ -124,25 +187,18 @@ __device__ inline void dyn_fc_pair(DynLane& Z, const double* q, double ua, doubl
   if (!(sbar >= Z.lo && sbar < Z.hi)) dyn_lane_seek(Z, sbar);     // rare: s crossed a segment boundary
   const double c = Z.curv;
   const double psit = (q[6] + (sbar - q[6] - Z.lo)) * Z.slope + Z.ang0;
-  const double vyf = __builtin_fma(w, Z.L_f, vy);
-  // role 0: front axle and e_psi ; role 1: rear axle and e_psi + psi_t.  Even / odd lanes differ here, so the arms are
-  // evaluated for everybody and selected (a divergent branch costs more than the four extra multiplies)
-  const bool front = Z.role == 0, rot = front && !Z.simple_slip;
-  const double yF = __builtin_fma(vyf, cd, -vx * sd), xF = __builtin_fma(vx, cd, vyf * sd);
-  const double ay_ = rot ? yF : (front ? vyf : __builtin_fma(-w, Z.L_r, vy));
-  const double ax_ = rot ? xF : vx;
-  const double add = (front && Z.simple_slip) ? us : 0.0;
-  const double alpha = add - dev_atan2(ay_, ax_);
+  // role 0: front axle and e_psi ; role 1: rear axle and e_psi + psi_t.  Even / odd lanes differ only in per-lane constants: the axle
+  // offset, the rotation into the wheel frame (identity except for a steered front axle with the exact slip formula) and the offset
+  // of the simple slip formula -- no selects in the chain
+  const bool front = Z.role == 0;
+  const double vyl = __builtin_fma(w, Z.Ll, vy);
+  const double ay_ = __builtin_fma(vyl, Z.cdl, -vx * Z.sdl), ax_ = __builtin_fma(vx, Z.cdl, vyl * Z.sdl);
+  const double alpha = Z.add - roll_atan2(ay_, ax_);
   double F;
-  if (Z.pacejka) {
-    double sF, cF;
-    dev_sincos(Z.Cc * dev_atan(Z.Bc * alpha), sF, cF);
-    F = Z.Dc * sF;
-  } else {
-    F = alpha * Z.lin;
-  }
+  if (Z.pacejka) F = Z.Dc * roll_sin(Z.Cc * roll_atan(Z.Bc * alpha));
+  else F = alpha * Z.lin;
   double sa, ca;
-  dev_sincos(front ? q[5] : q[5] + psit, sa, ca);
+  roll_sincos(front ? q[5] : q[5] + psit, sa, ca);
   // exchange inside the pair: quad_perm [0,0,2,2] takes the even lane's value, [1,1,3,3] the odd lane's
   const double fyf = dpp_f64<0xA0>(F), fyr = dpp_f64<0xF5>(F);
   const double se = dpp_f64<0xA0>(sa), ce = dpp_f64<0xA0>(ca), st = dpp_f64<0xF5>(sa), ct = dpp_f64<0xF5>(ca);
@@ -169,7 +225,7 @@ __device__ inline void dev_rollout_dyn_pair(const DgProb& D, int a, int role, cl
   const int nq = D.nq, qo = D.qoff[a];
   DynLane Z;
   Z.role = role; Z.simple_slip = ag.simple_slip; Z.pacejka = ag.tire_model == 0; Z.nsegs = P.n_segs;
-  Z.L_f = ag.L_f; Z.L_r = ag.L_r;
+  Z.L_f = ag.L_f; Z.L_r = ag.L_r; Z.Ll = role == 0 ? ag.L_f : -ag.L_r;
   Z.Bc = role == 0 ? ag.pac_Bf : ag.pac_Br; Z.Cc = role == 0 ? ag.pac_Cf : ag.pac_Cr; Z.Dc = role == 0 ? ag.pac_Df : ag.pac_Dr;
   Z.lin = role == 0 ? ag.lin_Bf * ag.mass * ag.gravity * ag.L_r / (ag.L_f + ag.L_r) : ag.lin_Br * ag.mass * ag.gravity * ag.L_f / (ag.L_f + ag.L_r);
   Z.c_da = ag.c_da; Z.c_dr = ag.c_dr; Z.c_r = ag.c_r; Z.p_r = ag.p_r;
@@ -186,6 +242,8 @@ __device__ inline void dev_rollout_dyn_pair(const DgProb& D, int a, int role, cl
     const double ua = du ? step_u(ub[i0], alpha, du[i0]) : ub[i0], us = du ? step_u(ub[i0 + 1], alpha, du[i0 + 1]) : ub[i0 + 1];
     double sd, cd;
     dev_sincos(us, sd, cd);
+    const bool rot = role == 0 && !ag.simple_slip;
+    Z.cdl = rot ? cd : 1.0; Z.sdl = rot ? sd : 0.0; Z.add = (role == 0 && ag.simple_slip) ? us : 0.0;
     for (int m = 0; m < nsub; m++) {
       if (integ == DGSQP_INT_RK4) {
         dyn_fc_pair(Z, q, ua, us, sd, cd, k1);
