@@ -103,7 +103,7 @@ def spawn_ranks(n, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--steps', type=int, default=120, help='timed steps; the default is long enough (about 15 s) for the drain of the last launches -- one slowest scenario, ~0.7 s -- to weigh a few percent')
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=1024, help='scenarios per GPU per step (--scaling weak) or in total per step (strong)')
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
@@ -111,7 +111,7 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=64, help='scenarios timed on the host for cpu_baseline (0 disables)')
     ap.add_argument('--pipeline', type=int, default=12,
                     help='independent batches in flight per GPU (each on its own handle / HIP stream); 1 = strictly one launch at a time')
-    ap.add_argument('--batches', type=int, default=0, help='distinct staged batches = handles the steps cycle through (default: 2 x pipeline, so that a step never waits for the tail of the launch that used its handle before)')
+    ap.add_argument('--batches', type=int, default=0, help='distinct staged batches = handles the steps cycle through (default: 3 x pipeline, so that a step never waits for the tail of the launch that used its handle before)')
     ap.add_argument('--single-steps', type=int, default=3, help='extra one-launch-at-a-time steps behind value_single_launch / roofline.kernel_ms (0 disables)')
     ap.add_argument('--host-steps', type=int, default=2, help='extra dgsqp_solve_batch calls from host buffers behind value_host_inclusive (0 disables)')
     ap.add_argument('--reg', type=float, default=None, help='DGSQPParams.reg (default: the value of the workload)')
@@ -138,7 +138,7 @@ def main():
     mk = lambda: DGSQP(*game.solver_args(), print_method=None, device=local_rank, eig_floor=args.eig_floor,
                        snap_active_bounds=args.snap_active_bounds)
     P = max(1, args.pipeline)
-    n_batches = args.batches if args.batches > 0 else max(P, min(2 * P, args.steps))     # distinct batches = handles; steps cycle through them
+    n_batches = args.batches if args.batches > 0 else max(P, min(3 * P, args.steps))     # distinct batches = handles; steps cycle through them
     solvers = [mk() for _ in range(n_batches)]
     solver = solvers[0]
     d = solver.dims

@@ -104,6 +104,7 @@ struct DgProb {
 };
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -223,6 +224,7 @@ static inline std::string dg_build_layout(DgProb& D) {
     const int avail = DG_LDS_LIMIT / 8 - L.c_R;
     int cap = 0;
     while (cap < n && (cap + 1) * (cap + 2) / 2 <= avail) cap++;
+    if (const char* e = getenv("DGSQP_RCAP")) { const int lim = atoi(e); if (lim >= 0 && lim < cap) cap = lim; }   // test hook: force the LDS / scratch split of R
     D.c_rcap = cap;
     if (L.c_R + cap * (cap + 1) / 2 > tot) tot = L.c_R + cap * (cap + 1) / 2;
   }

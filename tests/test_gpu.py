@@ -519,6 +519,29 @@ def test_reg0_games_track_the_oracle(oracle, kind, opts):
         assert rel(res['u'][b], ref['u'][b]) < (1e-2 if literal else 1e-4), b
 
 
+def test_classical_qp_storage_split_of_the_triangular_factor(monkeypatch):
+    """The classical active-set QP keeps the leading columns of R in LDS and the rest in the scratch (dgsqp_layout.h: c_rcap).  Games of
+    this size never fill the LDS part, so the split is forced to 3 and to 0 columns: same arithmetic, different storage -- every
+    output must be bitwise identical.  Covers the LDS-resident J (n = 80), the L2-resident J of the big layout (merge, n = 120) and the
+    XL layout (3 agents, n = 150; warm-started QPs)."""
+    from dgsqp_amd.montecarlo import kinematic_racing_game, merge_game, sample_scenarios
+    from dgsqp_amd.solver import DGSQP
+    for g, B in ((kinematic_racing_game('curve', N=20, reg=0.0), 24), (merge_game(), 8), (kinematic_racing_game('curve', N=25, M=3), 6)):
+        x0, u_tm = sample_scenarios(g, B, seed=3)
+        runs = []
+        for cap in (None, '3', '0'):
+            if cap is None:
+                monkeypatch.delenv('DGSQP_RCAP', raising=False)
+            else:
+                monkeypatch.setenv('DGSQP_RCAP', cap)
+            s = DGSQP(*g.solver_args(), print_method=None)
+            runs.append(s.solve_batch(x0, u_tm))
+        assert (runs[0]['qp_solves'] > 0).all() and (runs[0]['status'] <= 1).mean() > 0.5
+        for r in runs[1:]:
+            for k in ('status', 'num_iters', 'qp_solves', 'u', 'l', 'cond'):
+                assert np.array_equal(r[k], runs[0][k]), k
+
+
 def test_big_layout_and_merge_game(oracle):
     """Games beyond the LDS-resident layout keep the packed inverse and the reflectors in the workgroup's L2 scratch
     (n up to 128): KB curve N=30 (n=120) and the three-car merge of scripts/DGSQP_merge_monte_carlo.py at its own

@@ -7,16 +7,16 @@ cd $R
 nproc > $O/nproc.txt
 # bench lines
 python bench.py > $O/bench_dyn_curve_N25.json 2> $O/bench.err
-python bench.py --steps 20 --cpu-sample 0 > $O/bench_dyn_curve_N25_steps20.json 2>> $O/bench.err
+python bench.py --steps 40 --batches 24 --cpu-sample 0 > $O/bench_dyn_curve_N25_steps40.json 2>> $O/bench.err
 python bench.py --steps 10 --pipeline 5 --cpu-sample 0 > $O/bench_dyn_curve_N25_steps10_pipeline5.json 2>> $O/bench.err
-python bench.py --batch 4096 --steps 10 --cpu-sample 0 > $O/bench_dyn_curve_N25_B4096.json 2>> $O/bench.err
+python bench.py --batch 4096 --steps 30 --cpu-sample 0 > $O/bench_dyn_curve_N25_B4096.json 2>> $O/bench.err
 python bench.py --workload dyn_curve_N25_stress --cpu-sample 0 > $O/bench_dyn_curve_N25_stress.json 2>> $O/bench.err
 python bench.py --workload kb_curve_N25 --cpu-sample 64 > $O/bench_kb_curve_N25.json 2>> $O/bench.err
 python bench.py --workload kb_curve_N25 --cpu-sample 0 --eig-floor 1e-6 --snap-active-bounds > $O/bench_kb_curve_N25_floor1e-6_snap.json 2>> $O/bench.err
 python bench.py --workload kb_chicane_N25 --cpu-sample 0 > $O/bench_kb_chicane_N25.json 2>> $O/bench.err
 python bench.py --workload kb_barc2_N15 --cpu-sample 0 > $O/bench_kb_barc2_N15.json 2>> $O/bench.err
 python bench.py --workload merge_N20 --cpu-sample 0 > $O/bench_merge_N20.json 2>> $O/bench.err
-python bench.py --workload kb_curve3_N25 --steps 8 --cpu-sample 0 > $O/bench_kb_curve3_N25.json 2>> $O/bench.err
+python bench.py --workload kb_curve3_N25 --steps 24 --cpu-sample 0 > $O/bench_kb_curve3_N25.json 2>> $O/bench.err
 python bench.py --workload kb_f1_N50 --batch 256 --steps 4 --pipeline 2 --single-steps 0 --host-steps 0 --cpu-sample 0 > $O/bench_kb_f1_N50_B256.json 2>> $O/bench.err
 python bench.py --workload kb_barc3_N25 --batch 512 --steps 4 --pipeline 2 --single-steps 0 --host-steps 0 --cpu-sample 0 > $O/bench_kb_barc3_N25_B512.json 2>> $O/bench.err
 python bench.py --workload kb_curve_N50 --batch 512 --steps 4 --pipeline 2 --single-steps 0 --host-steps 0 --cpu-sample 0 > $O/bench_kb_curve_N50_B512.json 2>> $O/bench.err
@@ -27,10 +27,12 @@ python -m pytest tests -m gpu -q -s 2>&1 | grep -E "identical|passed|failed" | c
 python tools/gpu_forks.py dyn_curve_N25 > $O/forks_dyn_curve_N25.txt 2>&1
 python tools/gpu_forks.py kb_chicane_N15 > $O/forks_kb_chicane_N15.txt 2>&1
 python tools/gpu_forks.py kb_barc2_N15 > $O/forks_kb_barc2_N15.txt 2>&1
+FORKS_B=192 python tools/gpu_forks.py kb_curve_reg0_N20 > $O/forks_kb_curve_reg0_N20.txt 2>&1
 # phase cycles (diagnostic build)
 if [ -f dgsqp_amd/csrc/libdgsqp_hip_prof.so ]; then
   DGSQP_HIP_LIB=dgsqp_amd/csrc/libdgsqp_hip_prof.so python tools/gpu_time.py dyn 25 1024 > $O/phase_cycles_dyn_curve_N25_B1024.txt 2>&1
   DGSQP_HIP_LIB=dgsqp_amd/csrc/libdgsqp_hip_prof.so python tools/gpu_time.py kbcurve 25 1024 > $O/phase_cycles_kb_curve_N25_B1024.txt 2>&1
+  DGSQP_HIP_LIB=dgsqp_amd/csrc/libdgsqp_hip_prof.so python tools/gpu_time.py agents3 25 512 > $O/phase_cycles_kb_curve3_N25_B512.txt 2>&1
 fi
 # rocprofv3: kernel trace + stats on launches issued one at a time (the HIP-event kernel_ms of the same run must agree)
 cd /tmp && export TMPDIR=/tmp
