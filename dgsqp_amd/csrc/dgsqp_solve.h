@@ -148,7 +148,7 @@ __device__ inline void twisted_eigvec(double dA, double dB, double eA, double eB
 // (RPT of them) of the symmetric matrix for the whole Householder reduction AND the Gauss-Jordan sweep; LDS
 // only carries the broadcast vectors (reflector v, w, pivot column) and the stored reflectors.
 template <int RPT>
-__device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
+__device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd, bool want_inverse) {
   const DgProb& D = dg_prob;
   const DgLds& L = D.L;
   lptr lds = LP(0);
@@ -409,6 +409,7 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
   }
   __syncthreads();
   PROF_END(PH_JACOBI, pt_t);
+  if (!want_inverse) return true;      // the classical QP works on M itself (written to Qpd above): no explicit inverse
   PROF_BEGIN(pt_s);
   // ---- 5. symmetric Gauss-Jordan sweep in registers: after all pivots the slice holds -M^-1
   lptr colA = tws, colB = tws + (NH * RPT + 4);  // pivot column, double buffered; padding rows stay zero
@@ -470,14 +471,14 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd) {
   return true;
 }
 
-__device__ inline void dev_psd_inverse(const Ctx& c, gptr Qpd) {
+__device__ inline void dev_psd_inverse(const Ctx& c, gptr Qpd, bool want_inverse = true) {
   if (TID == 0) LP(dg_prob.L.scal)[DG_XVALID] = 0.0;   // the EIG scratch overwrites the trajectory
   const int n = dg_prob.n;
   bool ok;
-  if (n <= 32) ok = dev_psd_inverse_tridiag<32 / DG_NH>(c, Qpd);
-  else if (n <= 64) ok = dev_psd_inverse_tridiag<64 / DG_NH>(c, Qpd);
-  else if (n <= 100) ok = dev_psd_inverse_tridiag<100 / DG_NH>(c, Qpd);
-  else ok = dev_psd_inverse_tridiag<128 / DG_NH>(c, Qpd);
+  if (n <= 32) ok = dev_psd_inverse_tridiag<32 / DG_NH>(c, Qpd, want_inverse);
+  else if (n <= 64) ok = dev_psd_inverse_tridiag<64 / DG_NH>(c, Qpd, want_inverse);
+  else if (n <= 100) ok = dev_psd_inverse_tridiag<100 / DG_NH>(c, Qpd, want_inverse);
+  else ok = dev_psd_inverse_tridiag<128 / DG_NH>(c, Qpd, want_inverse);
   (void)ok;  // n <= 128 is enforced by dgsqp_create
 }
 
@@ -1076,7 +1077,7 @@ __device__ inline int dev_linearize_and_qp(const Ctx& c, bool do_qp, double* con
   dev_qt_mul(c);
   if (dg_prob.big == 2) { dev_xl_psd(c, Qpd); return dev_xl_qp(c); }   // n > 128: dgsqp_xl.h
   if (dg_prob.classic_qp) {    // literal reg = 0 projection: condition ~1e12, classical active-set kernels on M itself
-    dev_psd_inverse(c, c.ws + dg_prob.ws_xM);
+    dev_psd_inverse(c, c.ws + dg_prob.ws_xM, false);
     if (Qpd) { for (int e = TID; e < dg_prob.n * dg_prob.n; e += NT) Qpd[e] = (c.ws + dg_prob.ws_xM)[e]; }
     return dev_xl_qp(c);
   }
@@ -1233,7 +1234,7 @@ __device__ __noinline__ void dev_bfgs_hessian(const Ctx& c) {
   for (int e = TID; e < n * n; e += NT) Qg[e] = Qk[e];
   __threadfence_block();
   __syncthreads();
-  if (D.big == 2) dev_xl_psd(c, Bm); else dev_psd_inverse(c, Bm);
+  if (D.big == 2) dev_xl_psd(c, Bm); else dev_psd_inverse(c, Bm, false);
   __threadfence_block();
   __syncthreads();
   dev_evaluate(c, lds + L.u, 0.0, nullptr, false);
@@ -1313,7 +1314,7 @@ __device__ inline void dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
     dev_qt_mul(c);
     int flag;
     if (D.big == 2) { dev_xl_psd(c, nullptr); flag = dev_xl_qp(c); }   // n > 128: dgsqp_xl.h
-    else if (D.classic_qp) { dev_psd_inverse(c, c.ws + D.ws_xM); flag = dev_xl_qp(c); }
+    else if (D.classic_qp) { dev_psd_inverse(c, c.ws + D.ws_xM, false); flag = dev_xl_qp(c); }
     else { dev_psd_inverse(c, nullptr); flag = dev_qp(c); }
     total_qp++;
     if (flag != 0) { dev_tr(c, 40, 1.0); dev_log_iterate(c); status = DGSQP_QP_FAIL; break; }

@@ -47,7 +47,7 @@ __device__ inline int v2_qp(const Ctx& c) {
   // the explicit-inverse kernels need eig_floor + reg >= 1e-8 (dgsqp_layout.h); reg decays towards 0 during a v2 solve
   if (D.classic_qp && D.eig_floor + dev_reg() < 1e-8) {
     if (TID == 0) LP(D.L.scal)[DG_QP_NPREV] = 0.0;      // the classical kernels reuse the QP scratch: no saved active set afterwards
-    dev_psd_inverse(c, c.ws + D.ws_xM);
+    dev_psd_inverse(c, c.ws + D.ws_xM, false);
     return dev_xl_qp(c);
   }
   dev_psd_inverse(c, nullptr);
