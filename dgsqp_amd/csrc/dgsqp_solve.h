@@ -236,9 +236,12 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd, boo
     if (beta != 0.0) {   // wave-uniform (all waves computed the same beta)
       // p_j = sum_i B[i][j] v_i over this thread's rows (B symmetric => column sums give the matvec)
       double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+      double vr[RPT];          // v on this thread's rows: read once, used by the product and by the rank-2 update below
+#pragma unroll
+      for (int r = R0; r < RPT; r++) vr[r] = vfw[hf + NH * r];
 #pragma unroll
       for (int r = R0; r < RPT; r++) {
-        const double vi = vfw[hf + NH * r];
+        const double vi = vr[r];
         if ((r & 3) == 0) s0 += Br[r] * vi; else if ((r & 3) == 1) s1 += Br[r] * vi; else if ((r & 3) == 2) s2 += Br[r] * vi; else s3 += Br[r] * vi;
       }
       if (colok) pp[hf * n + jc] = (s0 + s1) + (s2 + s3);
@@ -261,7 +264,7 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd, boo
 #pragma unroll
         for (int r = R0; r < RPT; r++) {
           const int i = hf + NH * r;
-          Br[r] -= vfw[i] * wj + wfw[i] * vj;
+          Br[r] -= vr[r] * wj + wfw[i] * vj;
         }
       }
     }
