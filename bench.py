@@ -6,7 +6,7 @@
 
 One "step" = one pass of the hot path (DGSQP.solve(), reference DGSQP/solvers/DGSQP.py:302-507) over one batch of synthetic
 random-initial-condition scenarios that is resident in HBM before the timed region starts (dgsqp_stage_inputs); consecutive
-steps solve DIFFERENT batches (own seed each; 2 x pipeline distinct ones, cycled).  The timed region is exactly K steps between two fences
+steps solve DIFFERENT batches (own seed each; 3 x pipeline distinct ones, cycled).  The timed region is exactly K steps between two fences
 (library stream synchronisation + RCCL barrier), max over ranks.  Scenarios shard over the ranks with no data-path collective
 (--scaling weak: fixed batch per GPU; strong: fixed total batch); the only exchange is ONE ncclAllGather of the 64-byte
 per-scenario record, issued by the HIP library (dgsqp_gather_stats).  No PyTorch: the launcher only provides RANK / LOCAL_RANK /

@@ -78,12 +78,16 @@ __device__ __noinline__ bool dev_xl_psd_tri(const Ctx& c, gptr Qpd) {
         cgptr pb = Bm + (int64_t)ja * n + S.i;
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         int j = ja;
-        for (; j + 7 < jb; j += 8, pb += 8 * n) {
-          double b[8];
+        for (; j + 15 < jb; j += 16, pb += 16 * n) {          // sixteen L2 round trips in flight
+          double b[16];
 #pragma unroll
-          for (int u = 0; u < 8; u++) b[u] = pb[u * n];
-          a0 += b[0] * vv[j] + b[4] * vv[j + 4]; a1 += b[1] * vv[j + 1] + b[5] * vv[j + 5];
-          a2 += b[2] * vv[j + 2] + b[6] * vv[j + 6]; a3 += b[3] * vv[j + 3] + b[7] * vv[j + 7];
+          for (int u = 0; u < 16; u++) b[u] = pb[u * n];
+#pragma unroll
+          for (int u = 0; u < 16; u += 4) { a0 += b[u] * vv[j + u]; a1 += b[u + 1] * vv[j + u + 1]; a2 += b[u + 2] * vv[j + u + 2]; a3 += b[u + 3] * vv[j + u + 3]; }
+        }
+        for (; j + 3 < jb; j += 4, pb += 4 * n) {
+          const double b0 = pb[0], b1 = pb[n], b2 = pb[2 * n], b3 = pb[3 * n];
+          a0 += b0 * vv[j]; a1 += b1 * vv[j + 1]; a2 += b2 * vv[j + 2]; a3 += b3 * vv[j + 3];
         }
         for (; j < jb; j++, pb += n) a0 += pb[0] * vv[j];
         part[S.g * n + S.i] = (a0 + a1) + (a2 + a3);
@@ -106,12 +110,19 @@ __device__ __noinline__ bool dev_xl_psd_tri(const Ctx& c, gptr Qpd) {
         int i = k + 1 + S.g;
         gptr pb = Bm + (int64_t)i * n + j;
         const int64_t rs = (int64_t)G * n;
-        for (; i + 7 * G < n; i += 8 * G, pb += 8 * rs) {      // eight rows per pass: their L2 round trips overlap
-          double b[8];
+        for (; i + 15 * G < n; i += 16 * G, pb += 16 * rs) {      // sixteen rows per pass: their L2 round trips overlap
+          double b[16];
 #pragma unroll
-          for (int u = 0; u < 8; u++) b[u] = pb[u * rs];
+          for (int u = 0; u < 16; u++) b[u] = pb[u * rs];
 #pragma unroll
-          for (int u = 0; u < 8; u++) pb[u * rs] = b[u] - (vv[i + u * G] * wj + pv[i + u * G] * vj);
+          for (int u = 0; u < 16; u++) pb[u * rs] = b[u] - (vv[i + u * G] * wj + pv[i + u * G] * vj);
+        }
+        for (; i + 3 * G < n; i += 4 * G, pb += 4 * rs) {
+          double b[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) b[u] = pb[u * rs];
+#pragma unroll
+          for (int u = 0; u < 4; u++) pb[u * rs] = b[u] - (vv[i + u * G] * wj + pv[i + u * G] * vj);
         }
         for (; i < n; i += G, pb += rs) pb[0] = pb[0] - (vv[i] * wj + pv[i] * vj);
       }
@@ -510,13 +521,21 @@ __device__ inline void xl_j_mul(MP J, int js, int n, const XlSplit& S, int k0, i
     __syncthreads();
   } else {
     const int lane = TID & 63;
-    for (int i0 = (TID >> 6) * 4; i0 < n; i0 += (NT / 64) * 4) {      // four rows at a time: their loads are in flight together
-      double s[4] = {0, 0, 0, 0};
-      for (int k = k0 + lane; k < k1; k += 64) {
-        const double vk = v[k];
+    // four rows per wavefront and pass, every load of the pass (4 rows x up to 4 chunks of 64 columns, n <= 256) issued before the
+    // first use: one L2 round trip per pass instead of one per chunk
+    for (int i0 = (TID >> 6) * 4; i0 < n; i0 += (NT / 64) * 4) {
+      double a[4][4], vk[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) if (i0 + r < n) s[r] += J[(int64_t)(i0 + r) * js + k] * vk;
+      for (int cidx = 0; cidx < 4; cidx++) {
+        const int k = k0 + lane + 64 * cidx;
+        const bool on = k < k1;
+        vk[cidx] = on ? v[k] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) a[r][cidx] = (on && i0 + r < n) ? J[(int64_t)(i0 + r) * js + k] : 0.0;
       }
+      double s[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) s[r] = (a[r][0] * vk[0] + a[r][1] * vk[1]) + (a[r][2] * vk[2] + a[r][3] * vk[3]);
 #pragma unroll
       for (int r = 0; r < 4; r++) { const double t = wave_sum(s[r]); if (lane == 0 && i0 + r < n) out[i0 + r] = t; }
     }
