@@ -73,7 +73,15 @@ def rendezvous_path() -> str:
     explicit = os.environ.get('DGSQP_RENDEZVOUS')
     if explicit:
         return explicit
-    tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
+    # the launcher (torch.distributed.run agent, or bench.py spawning its own ranks) is the common parent of all ranks: its pid plus its
+    # start time name this launch and no earlier one -- a file left behind by a crashed run can never be mistaken for this run's id
+    ppid = os.getppid()
+    try:
+        with open(f'/proc/{ppid}/stat') as f:
+            started = f.read().rsplit(')', 1)[1].split()[19]      # field 22 (starttime, clock ticks since boot)
+    except (OSError, IndexError):
+        started = '0'
+    tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{ppid}_{started}"
     return os.path.join(os.environ.get('TMPDIR', '/tmp'), f'dgsqp_rccl_{tag}.id')
 
 
