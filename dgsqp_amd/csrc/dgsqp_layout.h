@@ -252,6 +252,7 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   } else if (P.track_kind != DGSQP_TRACK_ARCS) return "unknown track kind";
   if (P.M < 1 || P.M > DGSQP_MAX_AGENTS) return "unsupported number of agents";
   if (P.N < 1 || P.N > DG_NMAX) return "unsupported horizon";
+  if (par.merit_function == DGSQP_MERIT_SUM_OBJ_L1 && par.variant != DGSQP_VARIANT_V2) return "merit function sum_obj_l1 belongs to DG-SQP v2";
   if (P.N * P.M * DGSQP_NUA > 256) return "more than 256 decision variables are not supported yet";
   if (P.n_segs < 1 || P.n_segs > DGSQP_MAX_SEGS) return "bad track table";
   D.M = P.M; D.N = P.N; D.nq = 0; D.nu = P.M * DGSQP_NUA;

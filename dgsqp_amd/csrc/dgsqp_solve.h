@@ -833,6 +833,7 @@ __device__ __noinline__ void dev_dual_init(const Ctx& c) {
 // ------------------------------------------------------------------------------------------------
 // quantities of one SQP linearisation needed by the merit function (DGSQP.py:949-979)
 // ------------------------------------------------------------------------------------------------
+#define DG_V2_OBJ 48       // scal slot, DG-SQP v2 merit 'sum_obj_l1': sum of the agents' costs at the current linearisation point
 struct LinScal {
   double phi, dphi;   // merit and its directional derivative at the base point (with the caller's mu)
   double S0, S1;      // sum(s), sum(ds) with s = min(0,g), ds = g + G du - s   (DGSQP.py:414-415)
@@ -892,11 +893,14 @@ __device__ __noinline__ void dev_step_scalars(const Ctx& c, LinScal& S) {
   lg = block_sum(lg, red); lhg = block_sum(lhg, red); vio = block_sum(vio, red); s0 = block_sum(s0, red); ssum = block_sum(ssum, red);
   S.dstat = a1 + a2 + lg * (lGdu + (lhg - lg));
   if (D.par.variant == DGSQP_VARIANT_V2) S.dstat = a1 + a2;     // d/d(u,l) of 1/2 |d|^2 along (du, dl)  (DGSQP_v2.py:1143-1145)
+  const bool sum_obj = D.par.variant == DGSQP_VARIANT_V2 && D.par.merit_function == DGSQP_MERIT_SUM_OBJ_L1;
+  if (sum_obj) S.dstat = a1;                                    // L.v holds Du(sum_a J^a) here: dobj = v . du  (DGSQP_v2.py:1152)
   S.vio = vio;
   S.S0 = s0;
   S.S1 = ssum - s0;
   S.phi = 0.5 * (dd + lg * lg);  // + mu*vio added by the caller
   if (D.par.variant == DGSQP_VARIANT_V2) S.phi = 0.5 * dd;
+  if (sum_obj) S.phi = lds[L.scal + DG_V2_OBJ];
   S.dphi = S.dstat;
   PROF_END(PH_MERIT, pt_m);
 }
@@ -905,9 +909,67 @@ __device__ __noinline__ void dev_step_scalars(const Ctx& c, LinScal& S) {
 // needs the value with mu = 1 (DGSQP_v2.py:754).
 #define DG_V2_DD 50
 #define DG_V2_VIO 51
+// DG-SQP v2, merit 'sum_obj_l1' (DGSQP_v2.py:1151-1152, 1161-1164): obj = sum_a J^a along the trajectory in the EVAL scratch (inputs
+// e_ue).  With `grad` the gradient of obj w.r.t. ALL inputs goes to L.v -- the slot of Q^T d, which this merit does not use --: stage
+// gradients of the summed cost, one costate sweep per agent block (the joint dynamics are block diagonal), B_t^T lam_{t+1} + the
+// direct input-cost terms.  Needs x, A_k, B_k of the point in the EVAL scratch, i.e. runs before the QP.
+__device__ __noinline__ double dev_v2_sum_obj(const Ctx& c, bool grad) {
+  const DgProb& D = dg_prob;
+  const DgLds& L = D.L;
+  lptr lds = LP(0);
+  const int nq = D.nq, N = D.N, M = D.M, n = D.n;
+  clptr x = lds + L.e_x, ue = lds + L.e_ue;
+  lptr Dxs = lds + L.e_Dxs;       // [k][nq]: d/dx_k of the summed stage cost (first agent slice of the costate scratch)
+  lptr lam = lds + L.e_lam;       // [k][nq]: costates of the summed cost
+  __syncthreads();
+  double part = 0;
+  for (int k = TID; k <= N; k += NT) {
+    double Dx[DGSQP_MAX_AGENTS * DGSQP_MAX_NQA];
+    for (int i = 0; i < nq; i++) Dx[i] = 0.0;
+    for (int a = 0; a < M; a++) part += dev_state_cost(D, a, x + k * nq, k == N, grad ? Dx : (double*)nullptr, (double*)nullptr);
+    if (grad) for (int i = 0; i < nq; i++) Dxs[k * nq + i] = Dx[i];
+  }
+  for (int i = TID; i < n; i += NT) {
+    const int a = i / (N * DGSQP_NUA), rem = i % (N * DGSQP_NUA), t = rem / DGSQP_NUA, j = rem % DGSQP_NUA;
+    const dgsqp_agent_t& ag = D.P.agents[a];
+    const double uk = ue[i], um = t > 0 ? ue[i - DGSQP_NUA] : 0.0;
+    part += 0.5 * ag.w_in[j] * uk * uk + 0.5 * ag.w_rate[j] * (uk - um) * (uk - um);
+  }
+  const double obj = block_sum(part, lds + L.red);
+  if (!grad) return obj;
+  __syncthreads();
+  if (TID < M) {
+    const int a = TID, nqa = D.nqa[a], qo = D.qoff[a];
+    double lk[DGSQP_MAX_NQA], nx[DGSQP_MAX_NQA];
+    for (int m = 0; m < nqa; m++) lk[m] = Dxs[N * nq + qo + m];
+    for (int k = N - 1; k >= 0; k--) {
+      for (int m = 0; m < nqa; m++) lam[(k + 1) * nq + qo + m] = lk[m];
+      clptr A = lds + L.e_A[a] + k * nqa * nqa;
+      for (int z = 0; z < nqa; z++) { double sacc = Dxs[k * nq + qo + z]; for (int o = 0; o < nqa; o++) sacc += A[o * nqa + z] * lk[o]; nx[z] = sacc; }
+      for (int m = 0; m < nqa; m++) lk[m] = nx[m];
+    }
+  }
+  __syncthreads();
+  for (int i = TID; i < n; i += NT) {
+    const int a = i / (N * DGSQP_NUA), rem = i % (N * DGSQP_NUA), t = rem / DGSQP_NUA, j = rem % DGSQP_NUA;
+    const dgsqp_agent_t& ag = D.P.agents[a];
+    const double uk = ue[i], um = t > 0 ? ue[i - DGSQP_NUA] : 0.0;
+    double sacc = ag.w_in[j] * uk + ag.w_rate[j] * (uk - um);
+    if (t + 1 < N) sacc -= ag.w_rate[j] * (ue[i + DGSQP_NUA] - uk);
+    const int nqa = D.nqa[a];
+    clptr B = lds + L.e_B[a] + t * nqa * DGSQP_NUA;
+    clptr lkp = lam + (t + 1) * nq + D.qoff[a];
+    for (int m = 0; m < nqa; m++) sacc += B[m * DGSQP_NUA + j] * lkp[m];
+    lds[L.v + i] = sacc;
+  }
+  if (TID == 0) lds[L.scal + DG_V2_OBJ] = obj;
+  __syncthreads();
+  return obj;
+}
 __device__ inline double dev_v2_trial_phi(const Ctx& c, double dd, double mu) {
   const DgProb& D = dg_prob;
   lptr lds = LP(0);
+  if (D.par.merit_function == DGSQP_MERIT_SUM_OBJ_L1) dd = 2.0 * dev_v2_sum_obj(c, false);      // (callers keep 1/2 dd: the objective part of the merit)
   double v = 0;
   for (int r = TID; r < D.nc; r += NT) v += fmax(lds[D.L.g + r], 0.0);
   v = block_sum(v, lds + D.L.red);

@@ -40,9 +40,13 @@ __device__ inline void v2_rec_copy(const Ctx& c, gptr dst, cgptr src) {
 }
 
 // _solve_qp with the current regularisation (DGSQP_v2.py:253-284) at the linearisation held in LDS
+// v = Q^T d for the directional derivative of 1/2 |d|^2 ('stat_l1'), or the gradient of the summed objective ('sum_obj_l1')
+__device__ inline void v2_merit_vector(const Ctx& c) {
+  if (dg_prob.par.merit_function == DGSQP_MERIT_SUM_OBJ_L1) (void)dev_v2_sum_obj(c, true); else dev_qt_mul(c);
+}
 __device__ inline int v2_qp(const Ctx& c) {
   const DgProb& D = dg_prob;
-  dev_qt_mul(c);
+  v2_merit_vector(c);
   if (D.big == 2) { dev_xl_psd(c, nullptr); return dev_xl_qp(c); }
   // the explicit-inverse kernels need eig_floor + reg >= 1e-8 (dgsqp_layout.h); reg decays towards 0 during a v2 solve
   if (D.classic_qp && D.eig_floor + dev_reg() < 1e-8) {
@@ -105,6 +109,7 @@ __device__ inline void dev_solve_v2(const Ctx& c, cgptr u_ws, int64_t b, const S
   const double t_start = timed ? dev_block_clock() : 0.0;
   // dual warm start and the first entry of the merit memory (DGSQP_v2.py:333-343)
   dev_evaluate(c, lds + L.u, 0.0, nullptr, false);
+  const double obj0 = par.merit_function == DGSQP_MERIT_SUM_OBJ_L1 ? dev_v2_sum_obj(c, false) : 0.0;      // (the dual start reuses the EVAL scratch)
   dev_dual_init(c);
   dev_log_iterate(c);
   dev_stat_vector(c, lds + L.l, lds + L.d);
@@ -122,7 +127,7 @@ __device__ inline void dev_solve_v2(const Ctx& c, cgptr u_ws, int64_t b, const S
     for (int i = TID; i < n; i += NT) dd += lds[L.d + i] * lds[L.d + i];
     for (int r = TID; r < nc; r += NT) vio += fmax(lds[L.g + r], 0.0);
     dd = block_sum(dd, lds + L.red); vio = block_sum(vio, lds + L.red);
-    mem_append(0.5 * dd + vio);                      // nms_initial_reference_factor = 1 (DGSQP_v2.py:213)
+    mem_append((par.merit_function == DGSQP_MERIT_SUM_OBJ_L1 ? obj0 : 0.5 * dd) + vio);      // nms_initial_reference_factor = 1 (DGSQP_v2.py:213)
   }
   for (int i = TID; i < n; i += NT) im1[i] = lds[L.u + i];
   for (int r = TID; r < nc; r += NT) im1[n + r] = lds[L.l + r];
@@ -214,7 +219,7 @@ __device__ inline void dev_solve_v2(const Ctx& c, cgptr u_ws, int64_t b, const S
           // base values of the Armijo test at the loaded point: _evaluate(hessian=True) there (DGSQP_v2.py:734-737)
           dev_evaluate(c, lds + L.u, 0.0, nullptr, true);
           dev_stat_vector(c, lds + L.l, lds + L.d);
-          dev_qt_mul(c);
+          v2_merit_vector(c);
           LinScal Sb;
           dev_step_scalars(c, Sb);
           phi_b = Sb.phi + mu * Sb.vio; dphi_b = Sb.dstat - mu * Sb.vio;

@@ -183,9 +183,8 @@ def build_params(params: DGSQPParams, eig_floor: Optional[float] = None, snap_ac
 
 def _build_params_v2(params: DGSQPV2Params, eig_floor, snap_active_bounds, lsqr_tol, qp_warm_start) -> _ffi.ParamsT:
     """DGSQPV2Params -> dgsqp_params_t for DG-SQP v2 (reference DGSQP/solvers/DGSQP_v2.py:66-222)."""
-    if params.merit_function != 'stat_l1':
-        raise NotImplementedError(f"merit_function {params.merit_function!r}: only 'stat_l1' (the setting of scripts/comparison_study_barc) is built; "
-                                  "'sum_obj_l1' (DGSQP_v2.py:1156-1159) needs the full cost gradients")
+    if params.merit_function not in ('stat_l1', 'sum_obj_l1'):
+        raise ValueError(f'Merit function option {params.merit_function} not recognized')      # (DGSQP_v2.py:1165-1166)
     if params.merit_decrease_condition not in ('armijo', 'max'):
         raise ValueError(f'merit_decrease_condition {params.merit_decrease_condition!r} not recognized')
     if params.hessian_approximation != 'none':
@@ -197,7 +196,7 @@ def _build_params_v2(params: DGSQPV2Params, eig_floor, snap_active_bounds, lsqr_
     p.tau, p.p_tol, p.d_tol, p.reg = params.tau, params.p_tol, params.d_tol, params.reg
     p.beta = params.beta                   # (unused by v2's line search, which takes merit_decrease)
     p.line_search_iters, p.sqp_iters, p.nonmono_ls = params.line_search_iters, params.sqp_iters, 0
-    p.merit_function = 0
+    p.merit_function = 0 if params.merit_function == 'stat_l1' else 2      # DGSQP_MERIT_STAT_L1 / DGSQP_MERIT_SUM_OBJ_L1
     p.rel_tol_req = 10                     # DGSQP_v2.py:84
     p.lsqr_iter_lim = 0
     p.lsqr_atol = p.lsqr_btol = 1e-6 if lsqr_tol is None else float(lsqr_tol)

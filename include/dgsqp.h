@@ -44,7 +44,7 @@ enum { DGSQP_INT_EULER = 0, DGSQP_INT_RK4 = 1, DGSQP_INT_RK3 = 2, DGSQP_INT_RK2 
 /* terminal competition cost shape */
 enum { DGSQP_COMP_ATAN = 0, DGSQP_COMP_LINEAR = 1 };
 /* merit function (DGSQP.py:971-978) */
-enum { DGSQP_MERIT_STAT_L1 = 0, DGSQP_MERIT_STAT = 1 };
+enum { DGSQP_MERIT_STAT_L1 = 0, DGSQP_MERIT_STAT = 1, DGSQP_MERIT_SUM_OBJ_L1 = 2 /* DG-SQP v2 only (DGSQP_v2.py:1161-1164) */ };
 
 /* per-scenario exit codes == reference `msg` strings (DGSQP.py:388,396,408,458,466,471) */
 enum {

@@ -522,6 +522,41 @@ static void cost_gradient(const dgsqp_problem_t& P, const Layout& L, const doubl
   }
 }
 
+// DG-SQP v2's merit 'sum_obj_l1' (DGSQP_v2.py:1151-1152,1161-1164): obj = sum_a J^a(u) and dobj = Du(obj) . du with the gradient of
+// EVERY agent's cost w.r.t. EVERY input (f_q above keeps only the agent's own rows): Du_J^a = Du_Jxu + Dx_Jxu Du_x, summed over a.
+static void sum_obj_terms(const dgsqp_problem_t& P, const Layout& L, const double* u, const Eval& ev, double& obj, vec* grad) {
+  const int nq = L.nq, n = L.n, N = L.N;
+  double J[DGSQP_MAX_AGENTS];
+  costs(P, L, u, ev.x, J);
+  obj = 0;
+  for (int a = 0; a < L.M; a++) obj += J[a];
+  if (!grad) return;
+  grad->assign(n, 0.0);
+  vec DxJ((size_t)(N + 1) * nq);
+  for (int a = 0; a < L.M; a++) {
+    const dgsqp_agent_t& ag = P.agents[a];
+    Jet::nv = nq;
+    vector<Jet> xj(nq);
+    for (int k = 0; k <= N; k++) {
+      for (int i = 0; i < nq; i++) xj[i] = Jet::var(ev.x[(size_t)k * nq + i], i);
+      Jet Jk = state_cost<Jet>(P, L, a, xj.data(), k == N);
+      for (int i = 0; i < nq; i++) DxJ[(size_t)k * nq + i] = Jk.g[i];
+    }
+    for (int k = 0; k < N; k++)
+      for (int j = 0; j < DGSQP_NUA; j++) {
+        const double uk = u[L.col(a, k, j)], um = k > 0 ? u[L.col(a, k - 1, j)] : 0.0;
+        double d = ag.w_in[j] * uk + ag.w_rate[j] * (uk - um);
+        if (k + 1 < N) d -= ag.w_rate[j] * (u[L.col(a, k + 1, j)] - uk);
+        (*grad)[L.col(a, k, j)] += d;
+      }
+    for (int c = 0; c < n; c++) {
+      double s = 0;
+      for (size_t r = 0; r < (size_t)(N + 1) * nq; r++) s += DxJ[r] * ev.Dux[r * n + c];
+      (*grad)[c] += s;
+    }
+  }
+}
+
 // One backward dynamic-programming sweep for the Hessian w.r.t. the input
 // sequence of a scalar function of the trajectory (DGSQP.py:679-727 for costs,
 // :828-877 for one constraint row).  `kstart` is the stage whose (Dx, Dxx)
@@ -1005,6 +1040,8 @@ static void dual_init(const dgsqp_params_t& par, const Layout& L, const Eval& ev
 // -----------------------------------------------------------------------------
 struct Lin {  // one SQP linearisation
   vec Q, q, G, g;
+  double obj = 0;   // DG-SQP v2, merit 'sum_obj_l1': sum of the agents' costs at this point ...
+  vec gobj;         // ... and its gradient w.r.t. ALL inputs (filled with the Hessian pass only)
 };
 static double f_phi(const Layout& L, const dgsqp_params_t& par, const vec& l, const vec& s, const vec& q, const vec& G, const vec& g, double mu) {
   const int n = L.n, nc = L.nc;
@@ -1065,6 +1102,7 @@ static void eval_lin(const Ctx& c, const vec& u, const vec& l, bool hessian, Lin
   out.q = ev.q; out.G = ev.G; out.g = ev.g;
   if (hessian) out.Q = ev.Q;
   if (xout) *xout = ev.x;
+  if (c.par.variant == DGSQP_VARIANT_V2 && c.par.merit_function == DGSQP_MERIT_SUM_OBJ_L1) sum_obj_terms(c.P, c.L, u.data(), ev, out.obj, hessian ? &out.gobj : nullptr);
 }
 // _solve_qp (DGSQP.py:232-266); returns false on failure ("None in du")
 static bool solve_qp(const Ctx& c, const Lin& k, vec& du, vec& lhat) {
@@ -1314,6 +1352,19 @@ static bool v2_solve_qp(const Ctx& c, const Lin& k, double reg, vec& du, vec& lh
   du.assign(c.L.n, 0.0); lhat.assign(c.L.nc, 0.0);
   return qp_gi(c.L.n, c.L.nc, Qpd.data(), k.q.data(), k.G.data(), k.g.data(), du.data(), lhat.data()) == 0;
 }
+// the merit of the chosen option at a point whose linearisation (q, G, g, obj) is `t`, multipliers lt; f_dphi_c along (du, dl) at k
+static double v2_merit(const Ctx& c, const Lin& t, const vec& lt, double mu) {
+  if (c.par.merit_function != DGSQP_MERIT_SUM_OBJ_L1) return v2_phi(c.L, lt, t.q, t.G, t.g, mu);
+  double vio = 0;
+  for (int r = 0; r < c.L.nc; r++) vio += std::max(0.0, t.g[r]);
+  return t.obj + mu * vio;
+}
+static double v2_dmerit_c(const Ctx& c, const vec& du, const vec& l, const vec& dl, const Lin& k) {
+  if (c.par.merit_function != DGSQP_MERIT_SUM_OBJ_L1) return v2_dstat(c.L, du, l, dl, k);
+  double d = 0;
+  for (int i = 0; i < c.L.n; i++) d += k.gobj[i] * du[i];
+  return d;
+}
 static double v2_line_search(const Ctx& c, vec& u, const vec& du, vec& l, const vec& dl, double mu, const std::vector<double>& mem) {
   const dgsqp_params_t& par = c.par;
   const double sigma = par.merit_decrease;
@@ -1323,8 +1374,8 @@ static double v2_line_search(const Ctx& c, vec& u, const vec& du, vec& l, const 
     eval_lin(c, u, l, true, b);
     double vio = 0;
     for (int r = 0; r < c.L.nc; r++) vio += std::max(0.0, b.g[r]);
-    phi_b = v2_phi(c.L, l, b.q, b.G, b.g, mu);                       // s of the iterate = max(0, g) there
-    dphi_b = v2_dstat(c.L, du, l, dl, b) - mu * vio;
+    phi_b = v2_merit(c, b, l, mu);                                   // s of the iterate = max(0, g) there
+    dphi_b = v2_dmerit_c(c, du, l, dl, b) - mu * vio;
   }
   double a = 1.0, phi1 = 0;
   vec ut, lt;
@@ -1332,10 +1383,10 @@ static double v2_line_search(const Ctx& c, vec& u, const vec& du, vec& l, const 
     ut = axpy(u, a, du); lt = axpy(l, a, dl);
     Lin t;
     eval_lin(c, ut, lt, false, t);
-    const double phi = v2_phi(c.L, lt, t.q, t.G, t.g, mu);
+    const double phi = v2_merit(c, t, lt, mu);
     const double R = par.merit_decrease_condition == DGSQP_DECREASE_MAX ? (1 - sigma * a) * memmax : phi_b + sigma * a * dphi_b;
     ::tr(c, 30, a); ::tr(c, 31, phi);
-    phi1 = v2_phi(c.L, lt, t.q, t.G, t.g, 1.0);
+    phi1 = v2_merit(c, t, lt, 1.0);
     if (phi <= R) break;
     a *= par.tau;
   }
@@ -1357,7 +1408,12 @@ static void solve_one_v2(const dgsqp_problem_t& P, const dgsqp_params_t& par, co
   std::vector<double> mem;                                     // deque(maxlen = nms_memory_size)
   const size_t mem_size = (size_t)std::max(1, std::min(16, par.nms_memory_size));
   auto mem_append = [&](double v) { if (mem.size() == mem_size) mem.erase(mem.begin()); mem.push_back(v); };
-  mem_append(v2_phi(L, l, ev0.q, ev0.G, ev0.g, 1.0));
+  if (par.merit_function == DGSQP_MERIT_SUM_OBJ_L1) {
+    double obj0 = 0, vio0 = 0;
+    sum_obj_terms(P, L, u.data(), ev0, obj0, nullptr);
+    for (int r = 0; r < L.nc; r++) vio0 += std::max(0.0, ev0.g[r]);
+    mem_append(obj0 + vio0);
+  } else mem_append(v2_phi(L, l, ev0.q, ev0.G, ev0.g, 1.0));
   double reg = par.reg, delta = 0, ckpt_delta = 0, ckpt_reg = reg;
   int ckpt_counter = 0, ckpt_index = 0, sqp_it = 0, m_step_it = 0, rel_tol_its = 0, total_qp = 0, status = DGSQP_MAX_IT;
   bool finished = false;
@@ -1406,7 +1462,7 @@ static void solve_one_v2(const dgsqp_problem_t& P, const dgsqp_params_t& par, co
       double vio = 0;
       for (int r = 0; r < L.nc; r++) vio += std::max(0.0, k.g[r]);
       if (par.merit_parameter < 0.0) {
-        const double d = v2_dstat(L, du, l, dl, k);
+        const double d = v2_dmerit_c(c, du, l, dl, k);
         mu = vio > 0 ? std::fabs(d) / (0.5 * vio) : 0.0;
       } else mu = par.merit_parameter;
       tr(c, 10, nrm * nrm); tr(c, 11, mu);
@@ -1425,7 +1481,7 @@ static void solve_one_v2(const dgsqp_problem_t& P, const dgsqp_params_t& par, co
         vec un = axpy(u, 1.0, du), ln = axpy(l, 1.0, dl);
         Lin t;
         eval_lin(c, un, ln, false, t);
-        const double phi = v2_phi(L, ln, t.q, t.G, t.g, 1.0);
+        const double phi = v2_merit(c, t, ln, 1.0);
         const double R = (1 - par.merit_decrease) * *std::max_element(mem.begin(), mem.end());
         tr(c, 20, phi);
         if (phi <= R) { accept = true; phi_new = phi; u = un; l = ln; }
@@ -1512,6 +1568,17 @@ int oracle_track(const dgsqp_problem_t* P, double s, double* curv, double* tange
   Jet sj = Jet::var(s, 0), psi, c;
   track_eval<Jet>(*P, sj, c, psi);
   *curv = c.v; *tangent = psi.v; if (dtangent) *dtangent = psi.g[0];
+  return 0;
+}
+
+// DG-SQP v2, merit 'sum_obj_l1': sum of the agents' costs at u and its gradient w.r.t. all inputs (test hook of sum_obj_terms)
+int oracle_sum_obj(const dgsqp_problem_t* P, const double* x0, const double* u, double* obj, double* grad) {
+  Layout L = make_layout(*P);
+  Eval ev;
+  vec lz(L.nc, 0.0), g;
+  evaluate(*P, L, u, lz.data(), x0, false, false, ev);
+  sum_obj_terms(*P, L, u, ev, *obj, grad ? &g : nullptr);
+  if (grad) std::copy(g.begin(), g.end(), grad);
   return 0;
 }
 

@@ -88,6 +88,14 @@ def evaluate(P, x0, u, l=None, hessian=1):
     return out
 
 
+def sum_obj(P, x0, u):
+    """(sum_a J^a(u), its gradient w.r.t. all inputs): the objective part of DG-SQP v2's merit 'sum_obj_l1'."""
+    d = dims(P)
+    obj, grad = C.c_double(0.0), np.zeros(d['n'])
+    lib().oracle_sum_obj(C.byref(P), _d(np.ascontiguousarray(x0, float)), _d(np.ascontiguousarray(u, float)), C.byref(obj), _d(grad))
+    return obj.value, grad
+
+
 def dual_init(P, par, x0, u):
     d = dims(P)
     l0 = np.zeros(d['nc'])

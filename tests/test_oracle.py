@@ -379,8 +379,23 @@ def test_v2_restatement_invariants(oracle):
     ok = res['status'] == 0
     assert ok.sum() >= 2 and (res['num_iters'][ok] > 200).all() and (res['cond'][ok] < 1e-4).all() and (res['status'] <= 1).all()
     assert (res['qp_solves'] == res['num_iters']).all()            # one QP per iteration; the final iteration only tests convergence
-    with pytest.raises(NotImplementedError):
-        g.params.merit_function = 'sum_obj_l1'
+    # merit 'sum_obj_l1' (DGSQP_v2.py:1151-1152, 1161-1164): sum of the agents' costs + mu * violation.  Its gradient (every agent's cost
+    # w.r.t. every input, through the dense Du_x) against central differences of the costs; a solve with it
+    obj, grad = oracle.sum_obj(P, x0[0], u[0])
+    assert obj == pytest.approx(oracle.evaluate(P, x0[0], u[0], hessian=0)['J'].sum(), rel=1e-14)
+    h, fd = 1e-6, np.zeros_like(grad)
+    for i in range(len(grad)):
+        e = np.zeros_like(grad); e[i] = h
+        fd[i] = (oracle.evaluate(P, x0[0], u[0] + e, hessian=0)['J'].sum() - oracle.evaluate(P, x0[0], u[0] - e, hessian=0)['J'].sum()) / (2 * h)
+    assert np.abs(grad - fd).max() < 1e-6 * max(1.0, np.abs(grad).max())
+    g.params.merit_function = 'sum_obj_l1'
+    par_obj = build_params(g.params)
+    assert par_obj.merit_function == 2 and par_obj.variant == 1
+    res_obj = oracle.solve_batch(P, par_obj, x0, u, nthreads=6)
+    assert (res_obj['status'] <= 2).all() and (res_obj['num_iters'] > 20).all()
+    assert not np.array_equal(res_obj['num_iters'], res['num_iters'])            # (a different merit: different paths)
+    with pytest.raises(ValueError):
+        g.params.merit_function = 'nope'
         build_params(g.params)
 
 
