@@ -6,7 +6,9 @@
 
 One "step" = one pass of the hot path (DGSQP.solve(), reference DGSQP/solvers/DGSQP.py:302-507) over one batch of synthetic
 random-initial-condition scenarios that is resident in HBM before the timed region starts (dgsqp_stage_inputs); consecutive
-steps solve DIFFERENT batches (own seed each; 3 x pipeline distinct ones, cycled).  The timed region is exactly K steps between two fences
+steps solve DIFFERENT batches (own seed each, (pipeline + 2) x group distinct ones, cycled) and are issued `--group` at a time: ONE
+launch solves the staged batches of a group from a shared ticket queue (dgsqp_launch_staged_group; own buffers per batch, results
+bit-identical to separate launches), `--pipeline` launches in flight.  The timed region is exactly K steps between two fences
 (library stream synchronisation + RCCL barrier), max over ranks.  Scenarios shard over the ranks with no data-path collective
 (--scaling weak: fixed batch per GPU; strong: fixed total batch); the only exchange is ONE ncclAllGather of the 64-byte
 per-scenario record, issued by the HIP library (dgsqp_gather_stats).  No PyTorch: the launcher only provides RANK / LOCAL_RANK /
@@ -109,9 +111,10 @@ def main():
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--workload', default='dyn_curve_N25', choices=sorted(WORKLOADS))
     ap.add_argument('--cpu-sample', type=int, default=64, help='scenarios timed on the host for cpu_baseline (0 disables)')
-    ap.add_argument('--pipeline', type=int, default=12,
-                    help='independent batches in flight per GPU (each on its own handle / HIP stream); 1 = strictly one launch at a time')
-    ap.add_argument('--batches', type=int, default=0, help='distinct staged batches = handles the steps cycle through (default: 3 x pipeline, so that a step never waits for the tail of the launch that used its handle before)')
+    ap.add_argument('--pipeline', type=int, default=6,
+                    help='launches in flight per GPU (each on its own HIP stream / hardware queue); 1 = strictly one launch at a time')
+    ap.add_argument('--group', type=int, default=8, help='staged batches (= steps) solved by ONE launch with a shared ticket queue (dgsqp_launch_staged_group)')
+    ap.add_argument('--batches', type=int, default=0, help='distinct staged batches = handles the steps cycle through (default: (pipeline + 2) x group, so that a group never waits for the tail of a launch that still holds its handles)')
     ap.add_argument('--single-steps', type=int, default=3, help='extra one-launch-at-a-time steps behind value_single_launch / roofline.kernel_ms (0 disables)')
     ap.add_argument('--host-steps', type=int, default=2, help='extra dgsqp_solve_batch calls from host buffers behind value_host_inclusive (0 disables)')
     ap.add_argument('--reg', type=float, default=None, help='DGSQPParams.reg (default: the value of the workload)')
@@ -138,7 +141,7 @@ def main():
     mk = lambda: DGSQP(*game.solver_args(), print_method=None, device=local_rank, eig_floor=args.eig_floor,
                        snap_active_bounds=args.snap_active_bounds)
     P = max(1, args.pipeline)
-    n_batches = args.batches if args.batches > 0 else max(P, min(3 * P, args.steps))     # distinct batches = handles; steps cycle through them
+    n_batches = args.batches if args.batches > 0 else max(P, min(max(3 * P, (P + 2) * max(1, args.group)), args.steps))     # distinct batches = handles; steps cycle through them
     solvers = [mk() for _ in range(n_batches)]
     solver = solvers[0]
     d = solver.dims
@@ -169,37 +172,64 @@ def main():
             assert lib.dgsqp_synchronize(hh) == 0
         comm.barrier()
 
-    def run_steps(steps, in_flight):
-        """`steps` launches cycling through the staged batches, at most `in_flight` of them outstanding.  The next batch is started
-        when the previous launch has handed out its last scenario (its workgroups begin to exit and free compute units) -- not
-        earlier, or two launches would share the GPU from the start and both grow tails."""
-        kernel_ms, order, last = [], [], None
+    def run_steps(steps, in_flight, group=1):
+        """`steps` steps (one staged batch each), issued `group` at a time: the batches of a group are solved by ONE launch with a shared
+        ticket queue (dgsqp_launch_staged_group; every batch keeps its own buffers, results are bit-identical to separate launches), at
+        most `in_flight` launches outstanding.  The next launch is started when the previous one has handed out its last scenario
+        (its workgroups begin to exit and free compute units) -- not earlier, or two launches would share the GPU from the start and
+        both grow tails.  A launch ends with its slowest scenario (up to ~1 s here, the balanced time of one batch is ~0.1 s), and the
+        hardware runs at most 16 launches side by side: launches are retired in the order they FINISH (dgsqp_finished), and fewer,
+        longer launches keep the compute units busier than many short ones."""
+        kernel_ms, flying, last = [], [], None     # flying: tuples of handle indices, leader first
 
-        def wait_oldest():
-            i = order.pop(0)
-            assert lib.dgsqp_wait(handles[i], C.byref(tm)) == 0, lib.dgsqp_last_error(handles[i])
-            kernel_ms.append(tm.kernel_ms)            # HIP events around that launch on its own stream
+        def busy():
+            return {i for grp in flying for i in grp}
+
+        def retire(grp):
+            flying.remove(grp)
+            for i in grp:
+                assert lib.dgsqp_wait(handles[i], C.byref(tm)) == 0, lib.dgsqp_last_error(handles[i])
+            kernel_ms.append(tm.kernel_ms)            # HIP events around that launch on its leader's stream
+
+        def retire_finished(block):
+            deadline = time.perf_counter() + 600.0
+            while True:
+                done = [grp for grp in flying if lib.dgsqp_finished(handles[grp[0]])]
+                for grp in done:
+                    retire(grp)
+                if done or not block or not flying or time.perf_counter() > deadline:
+                    return
+                time.sleep(0.0002)
         fence()
         t0 = time.perf_counter()
-        for step in range(steps):
-            i = step % n_batches
+        nxt, step = 0, 0
+        while step < steps:
+            gsz = min(group, steps - step)
             if last is not None and in_flight > 1:
                 deadline = time.perf_counter() + 600.0           # never spin forever on a launch that died
                 while not lib.dgsqp_draining(handles[last]) and time.perf_counter() < deadline:
                     time.sleep(0.0002)
-            while len(order) >= in_flight or i in order:
-                wait_oldest()
-            assert lib.dgsqp_launch_staged(handles[i]) == 0, lib.dgsqp_last_error(handles[i])
-            order.append(i)
-            last = i
-        while order:
-            wait_oldest()
+            retire_finished(block=False)
+            while len(flying) >= in_flight or n_batches - len(busy()) < gsz:
+                retire_finished(block=True)
+            grp, taken = [], busy()
+            while len(grp) < gsz:                     # the next staged batches whose handles are idle (round robin)
+                i, nxt = nxt, (nxt + 1) % n_batches
+                if i not in taken and i not in grp:
+                    grp.append(i)
+            arr = (C.c_void_p * gsz)(*[handles[i] for i in grp])
+            assert lib.dgsqp_launch_staged_group(arr, gsz) == 0, lib.dgsqp_last_error(handles[grp[0]])
+            flying.append(tuple(grp))
+            last = grp[0]
+            step += gsz
+        while flying:
+            retire(flying[0])
         fence()
         elapsed = float(comm.allreduce_max([time.perf_counter() - t0])[0])
         return elapsed, kernel_ms, last
 
     # ---- the timed region of the contract: exactly K steps, fences on both sides, max over ranks
-    elapsed, kernel_ms_pipe, last = run_steps(args.steps, P)
+    elapsed, kernel_ms_pipe, last = run_steps(args.steps, P, max(1, args.group))
     value = B_total * args.steps / elapsed
     # the single stats gather: the records of one step (batch 0, solved by handle 0, which owns the communicator)
     rec = comm.gather_stats(B_pad)
@@ -259,8 +289,8 @@ def main():
                        'sampler': {'circuit': 'scripts/DGSQP_comp_monte_carlo.py:365-382, PID warm start',
                                    'merge': 'scripts/DGSQP_merge_monte_carlo.py:421-480, zero warm start'}.get(
                                        game.sampler, 'scripts/DGSQP_ALGAMES_monte_carlo_curve.py:384-467, PID warm start') + ' (seed 1 + rank + 1000 * batch)',
-                       'distinct_batches': n_batches, 'layout': {0: 'lds', 1: 'big', 2: 'xl'}[int(d.layout)],
-                       'batches_in_flight': P, 'reg': float(game.params.reg), 'eig_floor': float(solver._cparams.eig_floor),
+                       'distinct_batches': n_batches, 'batches_per_launch': max(1, args.group), 'layout': {0: 'lds', 1: 'big', 2: 'xl'}[int(d.layout)],
+                       'launches_in_flight': P, 'batches_in_flight': P * max(1, args.group), 'reg': float(game.params.reg), 'eig_floor': float(solver._cparams.eig_floor),
                        'snap_active_bounds': int(solver._cparams.snap_active_bounds)},
             'value_single_launch': single['value'] if single else None,
             'value_host_inclusive': host['value'] if host else None,

@@ -160,6 +160,10 @@ def load_library() -> C.CDLL:
     _PF = C.POINTER(C.c_float)
     lib.dgsqp_solve_batch_f32.argtypes = [H, C.c_int64, _PF, _PF, _PF, _PF, _PF, _PI, _PI, _PI, _PF, _PF, C.POINTER(TimingT)]
     lib.dgsqp_solve_batch_f32.restype = C.c_int
+    lib.dgsqp_launch_staged_group.argtypes = [C.POINTER(H), C.c_int]
+    lib.dgsqp_launch_staged_group.restype = C.c_int
+    lib.dgsqp_finished.argtypes = [H]
+    lib.dgsqp_finished.restype = C.c_int
     lib.dgsqp_synchronize.argtypes = [H]
     lib.dgsqp_synchronize.restype = C.c_int
     lib.dgsqp_comm_unique_id.argtypes = [C.c_char_p]
@@ -182,7 +186,7 @@ EXPORTED_SYMBOLS = ['dgsqp_create', 'dgsqp_destroy', 'dgsqp_dims', 'dgsqp_plan',
                     'dgsqp_solve_batch', 'dgsqp_stage_inputs', 'dgsqp_solve_staged', 'dgsqp_fetch_results',
                     'dgsqp_evaluate_batch', 'dgsqp_qp_batch', 'dgsqp_set_trace', 'dgsqp_fetch_trace',
                     'dgsqp_pid_warm_start_batch', 'dgsqp_launch_staged', 'dgsqp_wait', 'dgsqp_draining',
-                    'dgsqp_set_iterate_log', 'dgsqp_fetch_iterate_log', 'dgsqp_synchronize', 'dgsqp_solve_batch_f32', 'dgsqp_comm_unique_id', 'dgsqp_comm_init',
+                    'dgsqp_set_iterate_log', 'dgsqp_fetch_iterate_log', 'dgsqp_synchronize', 'dgsqp_finished', 'dgsqp_launch_staged_group', 'dgsqp_solve_batch_f32', 'dgsqp_comm_unique_id', 'dgsqp_comm_init',
                     'dgsqp_comm_destroy', 'dgsqp_gather_stats', 'dgsqp_comm_barrier', 'dgsqp_comm_allreduce_max']
 
 

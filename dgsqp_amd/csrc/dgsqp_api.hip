@@ -17,6 +17,10 @@
 #include "dgsqp_solve_v2.h"
 
 
+// one staged batch of a grouped launch: its inputs and its outputs
+struct DgBatch { const double* x0; const double* u_ws; SolveOutPtrs O; };
+#define DG_GROUP_MAX 64
+
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
@@ -26,7 +30,7 @@ __global__ void __launch_bounds__(DG_BLOCK)
 dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__ x0, const double* __restrict__ u_ws,
                 SolveOutPtrs O, double* __restrict__ ws_all, unsigned long long* __restrict__ ticket,
                 double* __restrict__ trace, int trace_cap, unsigned int* __restrict__ drained,
-                double* __restrict__ itlog, int itlog_cap) {
+                double* __restrict__ itlog, int itlog_cap, const DgBatch* __restrict__ group, int group_n) {
   Ctx c;
   c.trace_cap = trace_cap;
   c.itlog_cap = itlog_cap;
@@ -40,12 +44,17 @@ dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restric
     __syncthreads();
     if (TID == 0) dg_lds[dg_prob.L.scal + 63] = (double)atomicAdd(ticket, 1ULL);
     __syncthreads();
-    const int64_t b = (int64_t)dg_lds[dg_prob.L.scal + 63];
-    if (b >= B) {
+    int64_t b = (int64_t)dg_lds[dg_prob.L.scal + 63];
+    if (b >= B * (group ? group_n : 1)) {
       // the queue is empty: from now on this launch only drains.  Tell the host (mapped, fine-grained memory) so that it
       // can start the next independent batch on the compute units that become free.
       if (drained && TID == 0) { __hip_atomic_store(drained, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
       break;
+    }
+    if (group) {        // grouped launch (dgsqp_launch_staged_group): ticket -> (staged batch, scenario); every batch has its own buffers
+      const int64_t gi = b / B;
+      b -= gi * B;
+      x0 = group[gi].x0; u_ws = group[gi].u_ws; O = group[gi].O;
     }
     c.x0 = (cgptr)x0 + b * dg_prob.nq;
     c.trace = trace ? (gptr)trace + b * (int64_t)(1 + 2 * trace_cap) : nullptr;
@@ -172,6 +181,9 @@ struct dgsqp_solver {
   int64_t trace_launch_B = 0;                                             // scenarios of the launch that filled it
   double* d_itlog = nullptr; int itlog_cap = 0; int64_t itlog_B = 0, itlog_launch_B = 0;
   bool in_flight = false;       // a solve launch has been enqueued and not yet waited for
+  dgsqp_solver* group_leader = nullptr;   // set while this handle's batch is being solved by another handle's grouped launch
+  DgBatch* d_group = nullptr;             // leader: device table of the group's batches (DG_GROUP_MAX entries)
+  std::vector<DgBatch> group_host;
   dgsqp_comm_state* comm = nullptr;   // RCCL communicator + record buffers (dgsqp_comm.h), owned by the handle
   std::string err;
 };
@@ -231,10 +243,13 @@ struct DgResident { bool valid = false; std::vector<unsigned char> bytes; };
 DgResident g_resident[64];
 std::vector<dgsqp_solver*> g_handles;
 }  // namespace
+// the stream the handle's solve in flight runs on: its own, or the leader's for a member of a grouped launch
+static hipStream_t active_stream(const dgsqp_solver* h) { return h->group_leader ? h->group_leader->stream : h->stream; }
 static int wait_idle(dgsqp_solver* h) {
   if (h->in_flight) {
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(active_stream(h)));
     h->in_flight = false;
+    h->group_leader = nullptr;
   }
   return DGSQP_OK;
 }
@@ -245,7 +260,7 @@ static int upload_problem(dgsqp_solver* h) {
   if (r.valid && r.bytes.size() == sizeof(DgProb) && memcmp(r.bytes.data(), &h->hp, sizeof(DgProb)) == 0) return DGSQP_OK;
   for (dgsqp_solver* o : g_handles)
     if (o->device == h->device && o->in_flight) {
-      if (hipStreamSynchronize(o->stream) != hipSuccess) { h->err = "hipStreamSynchronize of a launch in flight failed"; return DGSQP_E_DEVICE; }
+      if (hipStreamSynchronize(active_stream(o)) != hipSuccess) { h->err = "hipStreamSynchronize of a launch in flight failed"; return DGSQP_E_DEVICE; }
       // (o stays marked in flight: its owner still has to collect it with dgsqp_wait)
     }
   HIPCHK(h, hipMemcpyToSymbolAsync(HIP_SYMBOL(dg_prob), &h->hp, sizeof(DgProb), 0, hipMemcpyHostToDevice, h->stream));
@@ -332,7 +347,10 @@ int dgsqp_create(const dgsqp_problem_t* prob, const dgsqp_params_t* par, int dev
 void dgsqp_destroy(dgsqp_handle_t h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
-  if (h->stream && h->in_flight) (void)hipStreamSynchronize(h->stream);
+  if (h->stream && h->in_flight) (void)hipStreamSynchronize(active_stream(h));
+  (void)hipStreamSynchronize(h->stream);
+  { std::lock_guard<std::mutex> lk(g_reg_mutex); for (dgsqp_solver* o : g_handles) if (o->group_leader == h) { o->group_leader = nullptr; o->in_flight = false; } }
+  if (h->d_group) (void)hipFree(h->d_group);
   if (h->comm) (void)dgsqp_comm_destroy(h);
   { std::lock_guard<std::mutex> lk(g_reg_mutex); g_handles.erase(std::remove(g_handles.begin(), g_handles.end(), h), g_handles.end()); }
   free_batch(h);
@@ -425,7 +443,7 @@ int dgsqp_launch_staged(dgsqp_handle_t h) {
     h->itlog_launch_B = h->B;
   }
   *h->drained_host = 0u;
-  hipLaunchKernelGGL(dg_solve_kernel, dim3(grid), dim3(DG_BLOCK), h->lds_bytes, h->stream, h->dp, h->B, h->d_x0, h->d_uws, O, h->ws, h->ticket, trace, h->trace_cap, h->drained_dev, itlog, h->itlog_cap);
+  hipLaunchKernelGGL(dg_solve_kernel, dim3(grid), dim3(DG_BLOCK), h->lds_bytes, h->stream, h->dp, h->B, h->d_x0, h->d_uws, O, h->ws, h->ticket, trace, h->trace_cap, h->drained_dev, itlog, h->itlog_cap, (const DgBatch*)nullptr, 0);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
   h->launched_grid = grid;
@@ -433,20 +451,68 @@ int dgsqp_launch_staged(dgsqp_handle_t h) {
   return DGSQP_OK;
 }
 
+int dgsqp_launch_staged_group(const dgsqp_handle_t* hs, int count) {
+  if (!hs || count < 1 || count > DG_GROUP_MAX || !hs[0]) return DGSQP_E_ARG;
+  dgsqp_solver* L = hs[0];
+  if (count == 1) return dgsqp_launch_staged(L);
+  HIPCHK(L, hipSetDevice(L->device));
+  for (int i = 0; i < count; i++) {
+    dgsqp_solver* h = hs[i];
+    if (!h) { L->err = "null handle in the group"; return DGSQP_E_ARG; }
+    for (int j = 0; j < i; j++) if (hs[j] == h) { L->err = "a handle appears twice in the group"; return DGSQP_E_ARG; }
+    if (h->device != L->device || h->B != L->B || L->B <= 0 || memcmp(&h->hp, &L->hp, sizeof(DgProb)) != 0) {
+      L->err = "grouped launch: every handle must hold a staged batch of the same size, of the same game, on the same device"; return DGSQP_E_ARG;
+    }
+    if (h->trace_cap > 0 || h->itlog_cap > 0) { L->err = "grouped launch: event / iterate logs are per single launch"; return DGSQP_E_ARG; }
+    const int rcw = wait_idle(h);
+    if (rcw) return rcw;
+  }
+  const int grid = grid_for(L, L->B * count);
+  { const int rce = ensure_ws(L, (size_t)grid); if (rce) return rce; }
+  if (!L->d_group) HIPCHK(L, hipMalloc(&L->d_group, sizeof(DgBatch) * DG_GROUP_MAX));
+  L->group_host.resize(count);
+  for (int i = 0; i < count; i++) {
+    dgsqp_solver* h = hs[i];
+    L->group_host[i] = DgBatch{h->d_x0, h->d_uws, SolveOutPtrs{h->d_u, h->d_l, h->d_x, h->d_cond, h->d_cost, h->d_status, h->d_iters, h->d_qps}};
+  }
+  std::unique_lock<std::mutex> game_lock(g_reg_mutex);
+  { int rcu = upload_problem(L); if (rcu) return rcu; }
+  HIPCHK(L, hipMemcpyAsync(L->d_group, L->group_host.data(), sizeof(DgBatch) * count, hipMemcpyHostToDevice, L->stream));
+  HIPCHK(L, hipMemsetAsync(L->ticket, 0, sizeof(unsigned long long), L->stream));
+  HIPCHK(L, hipEventRecord(L->ev[0], L->stream));
+  *L->drained_host = 0u;
+  SolveOutPtrs O0 = L->group_host[0].O;
+  hipLaunchKernelGGL(dg_solve_kernel, dim3(grid), dim3(DG_BLOCK), L->lds_bytes, L->stream, L->dp, L->B, L->d_x0, L->d_uws, O0, L->ws, L->ticket,
+                     (double*)nullptr, 0, L->drained_dev, (double*)nullptr, 0, (const DgBatch*)L->d_group, count);
+  HIPCHK(L, hipGetLastError());
+  HIPCHK(L, hipEventRecord(L->ev[1], L->stream));
+  for (int i = 0; i < count; i++) { hs[i]->launched_grid = grid; hs[i]->in_flight = true; hs[i]->group_leader = i == 0 ? nullptr : L; }
+  return DGSQP_OK;
+}
+
 int dgsqp_draining(dgsqp_handle_t h) {
   if (!h) return 1;
-  return h->launched_grid == 0 || __atomic_load_n(h->drained_host, __ATOMIC_RELAXED) != 0u;
+  const dgsqp_solver* L = h->group_leader ? h->group_leader : h;
+  return h->launched_grid == 0 || __atomic_load_n(L->drained_host, __ATOMIC_RELAXED) != 0u;
+}
+
+int dgsqp_finished(dgsqp_handle_t h) {
+  if (!h || !h->in_flight || h->launched_grid == 0) return 1;
+  if (hipSetDevice(h->device) != hipSuccess) return 1;
+  return hipEventQuery((h->group_leader ? h->group_leader : h)->ev[1]) != hipErrorNotReady;
 }
 
 int dgsqp_wait(dgsqp_handle_t h, dgsqp_timing_t* tm) {
   if (!h) return DGSQP_E_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   if (tm) memset(tm, 0, sizeof(*tm));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  dgsqp_solver* L = h->group_leader ? h->group_leader : h;     // (a member of a grouped launch reports the group's kernel)
+  HIPCHK(h, hipStreamSynchronize(L->stream));
   h->in_flight = false;
+  h->group_leader = nullptr;
   if (tm && h->launched_grid > 0) {
     float ms = 0;
-    HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+    HIPCHK(h, hipEventElapsedTime(&ms, L->ev[0], L->ev[1]));
     tm->kernel_ms = ms; tm->total_ms = ms; tm->grid = h->launched_grid; tm->block = DG_BLOCK;
   }
   return DGSQP_OK;
@@ -465,6 +531,7 @@ int dgsqp_fetch_results(dgsqp_handle_t h, double* u_out, double* l_out, double* 
   const DgProb& D = h->hp;
   const int64_t B = h->B;
   if (B == 0) return DGSQP_OK;
+  if (h->group_leader) { const int rcw = wait_idle(h); if (rcw) return rcw; }      // (solved on the leader's stream)
   if (u_out) HIPCHK(h, hipMemcpyAsync(u_out, h->d_u, sizeof(double) * B * D.n, hipMemcpyDeviceToHost, h->stream));
   if (l_out) HIPCHK(h, hipMemcpyAsync(l_out, h->d_l, sizeof(double) * B * D.nc, hipMemcpyDeviceToHost, h->stream));
   if (x_out) HIPCHK(h, hipMemcpyAsync(x_out, h->d_x, sizeof(double) * B * (D.N + 1) * D.nq, hipMemcpyDeviceToHost, h->stream));

@@ -288,10 +288,20 @@ int dgsqp_solve_staged(dgsqp_handle_t h, dgsqp_timing_t* timing);
    device (the kernels read the game from one per-device constant block). */
 int dgsqp_launch_staged(dgsqp_handle_t h);
 int dgsqp_wait(dgsqp_handle_t h, dgsqp_timing_t* timing);
+/* ONE launch over the staged batches of `count` handles (same game, same batch size, same device; at most 64): the scenarios of all
+   of them share one ticket queue, every batch keeps its own input and output buffers, results are bit-identical to separate
+   launches.  A launch ends with its slowest scenario, so few long launches keep the compute units busier than many short ones; the
+   number of launches in flight is bounded by the hardware queues (16 here).  hs[0] leads: its stream, workspace and events are
+   used; every handle of the group is in flight until ITS dgsqp_wait / dgsqp_fetch_results (which wait for the group's kernel).
+   Event and iterate logs are not available in grouped launches. */
+int dgsqp_launch_staged_group(const dgsqp_handle_t* hs, int count);
 /* 1 once the handle's last launch has handed out its last scenario (it only drains from then on, compute units are
    becoming free) or when nothing is in flight; 0 while scenarios are still queued.  Polled by bench.py to start the next
    independent batch on another handle at exactly that moment. */
 int dgsqp_draining(dgsqp_handle_t h);
+/* 1 once the launch of dgsqp_launch_staged has completed (or nothing is in flight), 0 while it runs; never blocks.  A batch ends
+   with its slowest scenario: a caller that keeps several launches in flight retires whichever has finished, not the oldest. */
+int dgsqp_finished(dgsqp_handle_t h);
 int dgsqp_fetch_results(dgsqp_handle_t h, double* u_out, double* l_out, double* x_out,
                         int32_t* status, int32_t* iters, int32_t* qp_solves, double* cond,
                         double* cost);

@@ -409,6 +409,44 @@ def test_concurrent_launches_on_two_handles(games):
         assert np.array_equal(u, ref['u']) and np.array_equal(l, ref['l'])
 
 
+def test_grouped_launch_of_three_staged_batches(games):
+    """dgsqp_launch_staged_group: ONE launch over the staged batches of three handles (shared ticket queue, own buffers) gives every
+    batch bit-identical results to its own launch; members are in flight until their own wait, mismatched groups are refused."""
+    import ctypes as C
+    from dgsqp_amd import _ffi
+    from dgsqp_amd.montecarlo import sample_scenarios
+    from dgsqp_amd.solver import DGSQP
+    g, P, par = games['kb_chicane_N15']
+    solvers = [DGSQP(*g.solver_args(), print_method=None) for _ in range(3)]
+    lib = solvers[0]._lib
+    data = [sample_scenarios(g, 150, seed=50 + j) for j in range(3)]
+    refs = [s_.solve_batch(x_, u_) for s_, (x_, u_) in zip(solvers, data)]
+    for s_, (x_, u_) in zip(solvers, data):
+        u_am = np.ascontiguousarray(s_._to_agent_major(u_))
+        assert lib.dgsqp_stage_inputs(s_._h, x_.shape[0], _ffi.dptr(np.ascontiguousarray(x_)), _ffi.dptr(u_am)) == 0
+    arr = (C.c_void_p * 3)(*[s_._h for s_ in solvers])
+    assert lib.dgsqp_launch_staged_group(arr, 3) == 0, lib.dgsqp_last_error(solvers[0]._h)
+    tm = _ffi.TimingT()
+    assert lib.dgsqp_wait(solvers[2]._h, C.byref(tm)) == 0 and tm.kernel_ms > 0 and tm.grid > 0        # a member reports the group's kernel
+    assert lib.dgsqp_finished(solvers[1]._h) == 1 and lib.dgsqp_draining(solvers[0]._h) == 1
+    for s_, ref in zip(solvers, refs):                         # (fetching waits for the group where dgsqp_wait has not been called)
+        B = ref['u'].shape[0]
+        u = np.empty((B, s_.n)); l = np.empty((B, s_.n_c_total)); st = np.empty(B, np.int32); it = np.empty(B, np.int32); qs = np.empty(B, np.int32)
+        assert lib.dgsqp_fetch_results(s_._h, _ffi.dptr(u), _ffi.dptr(l), None, _ffi.iptr(st), _ffi.iptr(it), _ffi.iptr(qs), None, None) == 0
+        assert np.array_equal(st, ref['status']) and np.array_equal(it, ref['num_iters']) and np.array_equal(qs, ref['qp_solves'])
+        assert np.array_equal(u, ref['u']) and np.array_equal(l, ref['l'])
+    # a handle twice / batches of different sizes: refused, nothing launched
+    bad = (C.c_void_p * 2)(solvers[0]._h, solvers[0]._h)
+    assert lib.dgsqp_launch_staged_group(bad, 2) != 0
+    x_, u_ = sample_scenarios(g, 20, seed=60)
+    assert lib.dgsqp_stage_inputs(solvers[1]._h, 20, _ffi.dptr(np.ascontiguousarray(x_)), _ffi.dptr(np.ascontiguousarray(solvers[1]._to_agent_major(u_)))) == 0
+    bad = (C.c_void_p * 2)(solvers[0]._h, solvers[1]._h)
+    assert lib.dgsqp_launch_staged_group(bad, 2) != 0
+    # the solvers are still usable on their own
+    again = solvers[1].solve_batch(*data[1])
+    assert np.array_equal(again['u'], refs[1]['u'])
+
+
 @pytest.mark.parametrize('comp_type', ['atan', 'linear'])
 def test_blocking_and_obstacle_cost_terms(oracle, comp_type):
     """Cost terms of scripts/DGSQP_monte_carlo_ablation.py:229-262 that the preset games leave at zero weight: blocking

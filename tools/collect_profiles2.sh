@@ -38,10 +38,10 @@ for f in sorted(glob.glob(f'{D}/{P}_bench_*.json')):
         continue
     c = d['config']
     fmt = lambda v: '—' if v is None else f'{v:,.0f}'
-    rows.append(f"| `{os.path.basename(f)}` | {c['workload']} | {c['layout']} | {c['batch_per_gpu']} | {d['steps']} / {c['batches_in_flight']} | {fmt(d['value'])} | {fmt(d.get('value_single_launch'))} | "
+    rows.append(f"| `{os.path.basename(f)}` | {c['workload']} | {c['layout']} | {c['batch_per_gpu']} | {d['steps']} / {c.get('batches_per_launch', 1)} x {c.get('launches_in_flight', c['batches_in_flight'])} | {fmt(d['value'])} | {fmt(d.get('value_single_launch'))} | "
                 f"{fmt(d.get('value_host_inclusive'))} | {d['converged_fraction']:.3f} | {d['mean_iters']:.1f} | {d['mean_qp_solves']:.1f} | {d['roofline']['kernel_ms']:.0f} | "
                 f"{('%.1f (%d threads)' % (d['cpu_baseline']['value'], d['cpu_baseline']['cores'])) if 'cpu_baseline' in d else '—'} |")
-print('| file | workload | layout | B per GPU | steps / in flight | scen/s | one launch at a time | host-inclusive | converged | mean iters (conv.) | mean QPs | kernel ms (one at a time) | CPU oracle scen/s |')
+print('| file | workload | layout | B per GPU | steps / batches per launch x launches in flight | scen/s | one launch at a time | host-inclusive | converged | mean iters (conv.) | mean QPs | kernel ms (one at a time) | CPU oracle scen/s |')
 print('|---|---|---|---|---|---|---|---|---|---|---|---|---|')
 print('\n'.join(rows))
 for w in ('dyn_curve_N25', 'kb_curve_N25'):
