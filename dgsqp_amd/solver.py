@@ -212,6 +212,52 @@ def _build_params_v2(params: DGSQPV2Params, eig_floor, snap_active_bounds, lsqr_
     return p
 
 
+def solve_batches(solvers, batches) -> list:
+    """Several Monte-Carlo batches of the SAME game and size in ONE launch (``dgsqp_launch_staged_group``): ``solvers`` are DGSQP
+    objects of that game (one per batch: every batch keeps its own device buffers), ``batches`` the matching ``(x0, u_ws)`` pairs as
+    ``solve_batch`` takes them.  A launch ends with its slowest scenario; grouping lets the workgroups that are done with one batch
+    go on with the next instead of idling behind that tail.  Returns one ``solve_batch``-style dictionary per batch, bit-identical
+    to separate ``solve_batch`` calls."""
+    if len(solvers) != len(batches) or not solvers:
+        raise ValueError('one solver per batch')
+    lib = solvers[0]._lib
+    staged = []
+    for s, (x0, u_ws) in zip(solvers, batches):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        u_ws = np.asarray(u_ws, dtype=np.float64)
+        if u_ws.ndim == 3:
+            u_ws = s._to_agent_major(u_ws)
+        u_ws = np.ascontiguousarray(u_ws)
+        B = x0.shape[0]
+        if x0.shape != (B, s.n_q) or u_ws.shape != (B, s.n):
+            raise RuntimeError(f'bad batch shapes x0 {x0.shape} u_ws {u_ws.shape}')
+        if lib.dgsqp_stage_inputs(s._h, B, _ffi.dptr(x0), _ffi.dptr(u_ws)) != 0:
+            raise RuntimeError('dgsqp_stage_inputs failed: ' + lib.dgsqp_last_error(s._h).decode())
+        staged.append(B)
+    t0 = time.time()
+    arr = (C.c_void_p * len(solvers))(*[s._h for s in solvers])
+    if lib.dgsqp_launch_staged_group(arr, len(solvers)) != 0:
+        raise RuntimeError('dgsqp_launch_staged_group failed: ' + lib.dgsqp_last_error(solvers[0]._h).decode())
+    tm = _ffi.TimingT()
+    outs = []
+    for s, B in zip(solvers, staged):
+        if lib.dgsqp_wait(s._h, C.byref(tm)) != 0:
+            raise RuntimeError('dgsqp_wait failed: ' + lib.dgsqp_last_error(s._h).decode())
+        out = dict(u=np.empty((B, s.n)), l=np.empty((B, s.n_c_total)), x=np.empty((B, s.N + 1, s.n_q)), status=np.empty(B, np.int32),
+                   num_iters=np.empty(B, np.int32), qp_solves=np.empty(B, np.int32), cond=np.empty((B, 3)), cost=np.empty((B, s.M)))
+        rc = lib.dgsqp_fetch_results(s._h, _ffi.dptr(out['u']), _ffi.dptr(out['l']), _ffi.dptr(out['x']), _ffi.iptr(out['status']),
+                                     _ffi.iptr(out['num_iters']), _ffi.iptr(out['qp_solves']), _ffi.dptr(out['cond']), _ffi.dptr(out['cost']))
+        if rc != 0:
+            raise RuntimeError('dgsqp_fetch_results failed: ' + lib.dgsqp_last_error(s._h).decode())
+        out['time'] = time.time() - t0
+        out['kernel_ms'] = tm.kernel_ms
+        out['msg'] = [_ffi.STATUS_MSG[v] for v in out['status']]
+        out['converged'] = out['status'] <= 1
+        out['u_pred'] = s._to_time_major(out['u'])
+        outs.append(out)
+    return outs
+
+
 def plan(P: _ffi.ProblemT, par: _ffi.ParamsT) -> dict:
     """What ``dgsqp_create`` would build for this game (host only, no GPU): dimensions, LDS bytes, scratch bytes and the
     layout (0 LDS-resident, 1 big, 2 XL); raises ``ValueError`` with the library's reason for unsupported games."""

@@ -445,6 +445,12 @@ def test_grouped_launch_of_three_staged_batches(games):
     # the solvers are still usable on their own
     again = solvers[1].solve_batch(*data[1])
     assert np.array_equal(again['u'], refs[1]['u'])
+    # the Python front end of the same call
+    from dgsqp_amd.solver import solve_batches
+    outs = solve_batches(solvers, data)
+    for o, ref in zip(outs, refs):
+        for k in ('status', 'num_iters', 'qp_solves', 'u', 'l', 'x', 'cond', 'cost'):
+            assert np.array_equal(o[k], ref[k]), k
 
 
 @pytest.mark.parametrize('comp_type', ['atan', 'linear'])
