@@ -14,6 +14,7 @@ for W in dyn_curve_N25 kb_curve_N25; do
   cp $(ls -t $G/pmc_fetch_$W/runc/*_counter_collection.csv | head -1) $D/${P}_pmc_fetch_$W.csv
   cp $(ls -t $G/pmc_write_$W/runc/*_counter_collection.csv | head -1) $D/${P}_pmc_write_$W.csv
   cp $(ls -t $G/pmc_sq_$W/runc/*_counter_collection.csv | head -1) $D/${P}_pmc_sq_$W.csv
+  [ -d $G/pmc_f64_$W ] && cp $(ls -t $G/pmc_f64_$W/runc/*_counter_collection.csv | head -1) $D/${P}_pmc_f64_$W.csv
   python $R/tools/pmc_summary.py $D/${P}_pmc_fetch_$W.csv $D/${P}_pmc_write_$W.csv $W 1024 $D/${P}_pmc_$W.json > /dev/null
   python - $D/${P}_pmc_$W.json $D/${P}_pmc_sq_$W.csv <<'PY'
 import csv, json, sys, collections
@@ -23,6 +24,18 @@ for r in csv.DictReader(open(sys.argv[2])):
     if r['Kernel_Name'].startswith('dg_solve_kernel'): t[r['Counter_Name']] += float(r['Counter_Value'])
 wc = t['SQ_WAVE_CYCLES'] or 1.0
 d['game_def'] = 'round2'
+import os
+f64 = sys.argv[2].replace('_pmc_sq_', '_pmc_f64_')
+if os.path.exists(f64):
+    u = collections.defaultdict(float); launches = set()
+    for r in csv.DictReader(open(f64)):
+        if r['Kernel_Name'].startswith('dg_solve_kernel'):
+            u[r['Counter_Name']] += float(r['Counter_Value']); launches.add(r['Dispatch_Id'])
+    nl = max(1, len(launches))
+    flop = 64.0 * (2 * u['SQ_INSTS_VALU_FMA_F64'] + u['SQ_INSTS_VALU_MUL_F64'] + u['SQ_INSTS_VALU_ADD_F64'] + u['SQ_INSTS_VALU_TRANS_F64']) / nl
+    d['fp64_flop_per_launch_upper_bound'] = flop
+    d['fp64_flop_per_solve_upper_bound'] = flop / d.get('batch_per_gpu', 1024)
+    d['fp64_share_of_valu_instructions'] = (u['SQ_INSTS_VALU_FMA_F64'] + u['SQ_INSTS_VALU_MUL_F64'] + u['SQ_INSTS_VALU_ADD_F64'] + u['SQ_INSTS_VALU_TRANS_F64']) / max(u['SQ_INSTS_VALU'], 1.0)
 d['sq_wave_cycle_shares'] = {'waiting (SQ_WAIT_ANY)': t['SQ_WAIT_ANY'] / wc, 'issue stalls (SQ_WAIT_INST_ANY)': t['SQ_WAIT_INST_ANY'] / wc, 'issuing (SQ_ACTIVE_INST_ANY)': t['SQ_ACTIVE_INST_ANY'] / wc}
 json.dump(d, open(sys.argv[1], 'w'), indent=1)
 PY

@@ -43,5 +43,6 @@ for w in dyn_curve_N25 kb_curve_N25; do
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$w -- python3 $R/bench.py --workload $w --steps 2 --warmup 0 --group 1 --pipeline 1 --single-steps 0 --host-steps 0 --cpu-sample 0 > $O/pmc_fetch_$w.json 2> $O/pmc_fetch_$w.err
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$w -- python3 $R/bench.py --workload $w --steps 2 --warmup 0 --group 1 --pipeline 1 --single-steps 0 --host-steps 0 --cpu-sample 0 > $O/pmc_write_$w.json 2> $O/pmc_write_$w.err
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_sq_$w -- python3 $R/bench.py --workload $w --steps 2 --warmup 0 --group 1 --pipeline 1 --single-steps 0 --host-steps 0 --cpu-sample 0 > $O/pmc_sq_$w.json 2> $O/pmc_sq_$w.err
+  rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU --output-format csv -d $O/pmc_f64_$w -- python3 $R/bench.py --workload $w --steps 2 --warmup 0 --group 1 --pipeline 1 --single-steps 0 --host-steps 0 --cpu-sample 0 > $O/pmc_f64_$w.json 2> $O/pmc_f64_$w.err
 done
 find $O -name "*.csv" | head -40
