@@ -14,6 +14,7 @@ python bench.py --group 1 --steps 10 --pipeline 5 --cpu-sample 0 > $O/bench_dyn_
 python bench.py --batch 4096 --steps 32 --group 4 --pipeline 4 --cpu-sample 0 > $O/bench_dyn_curve_N25_B4096.json 2>> $O/bench.err
 python bench.py --workload dyn_curve_N25_stress --cpu-sample 0 > $O/bench_dyn_curve_N25_stress.json 2>> $O/bench.err
 python bench.py --workload kb_curve_N25 --cpu-sample 64 > $O/bench_kb_curve_N25.json 2>> $O/bench.err
+python bench.py --workload kb_curve_N25 --steps 240 --cpu-sample 0 --single-steps 0 --host-steps 0 > $O/bench_kb_curve_N25_steps240.json 2>> $O/bench.err
 python bench.py --workload kb_curve_N25 --cpu-sample 0 --eig-floor 1e-6 --snap-active-bounds > $O/bench_kb_curve_N25_floor1e-6_snap.json 2>> $O/bench.err
 python bench.py --workload kb_chicane_N25 --cpu-sample 0 > $O/bench_kb_chicane_N25.json 2>> $O/bench.err
 python bench.py --workload kb_barc2_N15 --cpu-sample 0 > $O/bench_kb_barc2_N15.json 2>> $O/bench.err
