@@ -1007,6 +1007,7 @@ def test_bench_line_contract():
     assert d['config']['distinct_batches'] >= 2 and d['roofline']['kernel_ms_source'].endswith('one at a time')
     assert d['unit'] == 'scenarios/s' and d['n_gpus'] == 1 and d['steps'] == 3 and d['scaling'] == 'weak' and d['dtype'] == 'f64'
     assert d['config']['workload'] == 'kb_curve_N25' and d['config']['batch_per_gpu'] == 64
+    assert d['config']['launches_in_flight'] == 2 and d['config']['batches_per_launch'] >= 1      # (steps are issued in grouped launches)
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-15 and r['kernel_ms'] > 0
     c = d['cpu_baseline']
