@@ -254,7 +254,7 @@ def test_statistical_parity_at_default_lsqr_tolerance(oracle, games):
     ref2 = oracle.solve_batch(P, par2, x0, agent_major(u_tm), nthreads=8)
     stable = (ref2['status'] == ref['status']) & (ref2['num_iters'] == ref['num_iters']) & (ref2['qp_solves'] == ref['qp_solves'])
     stable &= stable_mask(oracle, P, par, x0, agent_major(u_tm), ref, K=2)
-    assert_control_flow_parity(res, ref, stable, 'kb_chicane_N15 at scipy LSQR tolerance', min_stable_same=0.85, max_conv_gap=0.08)
+    assert_control_flow_parity(res, ref, stable, 'kb_chicane_N15 at scipy LSQR tolerance', min_stable_same=0.95, max_conv_gap=0.05)
     both = conv_g & conv_r & (res['status'] == 0) & (ref['status'] == 0)
     assert abs(res['num_iters'][both].mean() - ref['num_iters'][both].mean()) <= 0.1 * ref['num_iters'][both].mean()
     for b in np.where(both)[0]:          # converged to the same equilibrium
@@ -686,7 +686,7 @@ def test_three_agents_on_the_barc_circuit(oracle, N, B):
             assert rel(ev[key][b], o[key]) < 1e-11, (key, b)
     res = s.solve_batch(x0, u_tm)
     ref = oracle.solve_batch(P, par, x0, u, nthreads=8)
-    same = assert_control_flow_parity(res, ref, stable_mask(oracle, P, par, x0, u, ref, K=2), f'barc3 N={N}', min_stable_same=0.7, max_conv_gap=0.15,
+    same = assert_control_flow_parity(res, ref, stable_mask(oracle, P, par, x0, u, ref, K=2), f'barc3 N={N}', min_stable_same=0.85, max_conv_gap=0.15,
                                       min_stable_frac=0.25)
     for b in np.where(same & (ref['status'] <= 1))[0]:
         assert rel(res['u'][b], ref['u'][b]) < 1e-2, b
