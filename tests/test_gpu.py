@@ -987,6 +987,31 @@ def test_rccl_gather_single_rank(games):
         comm.close()
 
 
+def test_monte_carlo_example_script(tmp_path):
+    """examples/monte_carlo_curve.py -- the DG-SQP leg of scripts/DGSQP_ALGAMES_monte_carlo_curve.py on the library: grouped launches
+    plus a ragged remainder give the results of one plain solve_batch, and the pickle has the layout process_data_curve.py reads."""
+    import pathlib
+    import pickle
+    import subprocess
+    import sys
+    from dgsqp_amd.montecarlo import kinematic_racing_game, sample_scenarios
+    from dgsqp_amd.solver import DGSQP
+    root = pathlib.Path(__file__).resolve().parent.parent
+    out_file = tmp_path / 'data_curve.pkl'
+    out = subprocess.run([sys.executable, str(root / 'examples' / 'monte_carlo_curve.py'), '--num-mc', '150', '--N', '12', '--batch', '64',
+                          '--seed', '5', '--out', str(out_file)], capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert out.returncode == 0, out.stderr[-2000:]
+    data = pickle.load(open(out_file, 'rb'))
+    recs = data['sqgames']
+    assert len(recs) == 150 and {'solve_info', 'params', 'init'} <= set(recs[0])
+    g = kinematic_racing_game('curve', N=12, reg=0.0)
+    x0, u_ws = sample_scenarios(g, 150, seed=5)
+    ref = DGSQP(*g.solver_args(), print_method=None).solve_batch(x0, u_ws)
+    assert [r['solve_info']['num_iters'] for r in recs] == list(ref['num_iters'])
+    assert [r['solve_info']['status'] for r in recs] == list(ref['status'] <= 1)
+    assert all(np.array_equal(r['solve_info']['iter_data'][0]['u_sol'], ref['u'][b]) for b, r in enumerate(recs))
+
+
 def test_bench_line_contract():
     """bench.py prints ONE JSON line with the contract's keys, the roofline object and the CPU baseline (tiny batch)."""
     import json
