@@ -6,7 +6,7 @@
 
 One "step" = one pass of the hot path (DGSQP.solve(), reference DGSQP/solvers/DGSQP.py:302-507) over one batch of synthetic
 random-initial-condition scenarios that is resident in HBM before the timed region starts (dgsqp_stage_inputs); consecutive
-steps solve DIFFERENT batches (own seed each, (pipeline + 2) x group distinct ones, cycled) and are issued `--group` at a time: ONE
+steps solve DIFFERENT batches (own seed each, (pipeline + 1) x group distinct ones, cycled) and are issued `--group` at a time: ONE
 launch solves the staged batches of a group from a shared ticket queue (dgsqp_launch_staged_group; own buffers per batch, results
 bit-identical to separate launches), `--pipeline` launches in flight.  The timed region is exactly K steps between two fences
 (library stream synchronisation + RCCL barrier), max over ranks.  Scenarios shard over the ranks with no data-path collective
@@ -111,10 +111,10 @@ def main():
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--workload', default='dyn_curve_N25', choices=sorted(WORKLOADS))
     ap.add_argument('--cpu-sample', type=int, default=64, help='scenarios timed on the host for cpu_baseline (0 disables)')
-    ap.add_argument('--pipeline', type=int, default=6,
+    ap.add_argument('--pipeline', type=int, default=5,
                     help='launches in flight per GPU (each on its own HIP stream / hardware queue); 1 = strictly one launch at a time')
-    ap.add_argument('--group', type=int, default=8, help='staged batches (= steps) solved by ONE launch with a shared ticket queue (dgsqp_launch_staged_group)')
-    ap.add_argument('--batches', type=int, default=0, help='distinct staged batches = handles the steps cycle through (default: (pipeline + 2) x group, so that a group never waits for the tail of a launch that still holds its handles)')
+    ap.add_argument('--group', type=int, default=12, help='staged batches (= steps) solved by ONE launch with a shared ticket queue (dgsqp_launch_staged_group)')
+    ap.add_argument('--batches', type=int, default=0, help='distinct staged batches = handles the steps cycle through (default: (pipeline + 1) x group, so that a group never waits for the tail of a launch that still holds its handles)')
     ap.add_argument('--single-steps', type=int, default=3, help='extra one-launch-at-a-time steps behind value_single_launch / roofline.kernel_ms (0 disables)')
     ap.add_argument('--host-steps', type=int, default=2, help='extra dgsqp_solve_batch calls from host buffers behind value_host_inclusive (0 disables)')
     ap.add_argument('--reg', type=float, default=None, help='DGSQPParams.reg (default: the value of the workload)')
@@ -141,7 +141,7 @@ def main():
     mk = lambda: DGSQP(*game.solver_args(), print_method=None, device=local_rank, eig_floor=args.eig_floor,
                        snap_active_bounds=args.snap_active_bounds)
     P = max(1, args.pipeline)
-    n_batches = args.batches if args.batches > 0 else max(P, min(max(3 * P, (P + 2) * max(1, args.group)), args.steps))     # distinct batches = handles; steps cycle through them
+    n_batches = args.batches if args.batches > 0 else max(P, min(max(3 * P, (P + 1) * max(1, args.group)), args.steps))     # distinct batches = handles; steps cycle through them
     solvers = [mk() for _ in range(n_batches)]
     solver = solvers[0]
     d = solver.dims
