@@ -37,6 +37,7 @@ struct DgDense {    // one distinct dense gradient: d x^a_k[idx] / du   or the o
 
 // Dot products with the dense gradients are cut into chunks of <= DG_CHUNK contiguous entries (one lane each, all loads
 // issued together): gd[p0 .. p0+len) . v[v0 .. v0+len)
+#define DG_XL_KMAX 64     // XL layout: negative eigenvalues the tridiagonal _nearestPD handles (beyond: one-sided Jacobi, ~5x slower)
 #define DG_CHUNK 16
 struct DgTask {
   int32_t p0;
@@ -161,7 +162,7 @@ static inline std::string dg_build_layout(DgProb& D) {
   const int npk = n * (n + 1) / 2;
   const int rpt = (n <= 32 ? 32 : (n <= 64 ? 64 : (n <= 100 ? 100 : 128))) / DG_NH;
   if (!D.big) { L.g_Bp = take(npk); L.g_V = take(npk); } else { L.g_Bp = L.g_V = -1; }
-  L.g_tw = D.big == 2 ? take(6 * n + 32 + 16 + (DG_BLOCK / 64) * 3 * n + 16)   // d, e, tau, v, w, e^2, lambda, per-wavefront strips
+  L.g_tw = D.big == 2 ? take(6 * n + DG_XL_KMAX + 16 + (DG_BLOCK / 64) * 3 * n + 16)   // d, e, tau, v, w, e^2, lambda, per-wavefront strips
                       : take((5 + DG_NH) * n + 16 + DG_PSD_KMAX * n /* Z */ + 3 * (DG_NH * rpt + 4)
                              + 2 * (DG_BLOCK / 64) * (DG_NH * rpt + 4) /* per-wavefront copies of the reflector v and of w */);
   // per-wavefront strips of the twisted factorisation (3 n doubles each): the packed-P slot is free until the sweep writes

@@ -32,7 +32,7 @@ __device__ inline XlSplit xl_split(int n) {
 //   for the NEGATIVE eigenvalues only, eigenvectors by twisted factorisation (one wavefront each), modified Gram-Schmidt,
 //   back-transformation, M = B + sum_j (floor - lambda_j) v_j v_j^T + reg I.
 // Returns false (nothing written) when there are more than XL_KMAX negative eigenvalues: the Jacobi path takes over.
-#define XL_KMAX 32
+#define XL_KMAX DG_XL_KMAX
 #define XL_RCH 16      // Givens rotations applied to a row of J per pass
 #define XL_SEG 8       // 16-column segments of a row of J one thread updates per pass (loads first, stores after)
 __device__ __noinline__ bool dev_xl_psd_tri(const Ctx& c, gptr Qpd) {

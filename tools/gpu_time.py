@@ -8,6 +8,8 @@ which, N, B = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 M = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 if which == 'agents3':      # XL layout: scripts/DGSQP_monte_carlo_agents.py at M=3, N=25
     game = kinematic_racing_game('curve', N=N, M=3)
+elif which == 'kbcurve50':    # XL layout at n = 200 (BASELINE configs[3]'s size on the curve track)
+    game = kinematic_racing_game('curve', N=N)
 elif which.startswith('kb'):  # reg as in the scripts: curve.py:161 reg=0, chicane.py:164 reg=1e-3
     game = kinematic_racing_game('curve' if which == 'kbcurve' else 'chicane', N=N, reg=0.0 if which == 'kbcurve' else 1e-3)
 else:
