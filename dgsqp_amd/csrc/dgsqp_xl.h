@@ -189,13 +189,24 @@ __device__ __noinline__ bool dev_xl_psd_tri(const Ctx& c, gptr Qpd) {
   }
   XSYNC();
   PROF_END(PH_E_BIS, pe1);
-  // ---- modified Gram-Schmidt (close eigenvalues give nearly parallel vectors), block-wide
+  // ---- orthonormalisation (close eigenvalues give nearly parallel vectors): classical Gram-Schmidt applied twice per vector -- all the
+  //      projections of vector j at once (one wavefront per earlier vector for the dot products, then one pass over z_j), instead of
+  //      one block-wide step per PAIR as modified Gram-Schmidt needs: with up to 64 vectors that is 128 steps, not 2,016
+  lptr dots = strips;        // (the strips are free again: XL_KMAX coefficients)
   for (int j = 0; j < kneg; j++) {
-    for (int i = 0; i < j; i++) {
-      double dsum = 0;
-      for (int t = TID; t < n; t += NT) dsum += Z[(int64_t)j * n + t] * Z[(int64_t)i * n + t];
-      const double dt = block_sum(dsum, red);
-      for (int t = TID; t < n; t += NT) Z[(int64_t)j * n + t] -= dt * Z[(int64_t)i * n + t];
+    for (int pass = 0; pass < 2 && j > 0; pass++) {
+      for (int i = wave; i < j; i += NT / 64) {
+        double dsum = 0;
+        for (int t = lane; t < n; t += 64) dsum += Z[(int64_t)j * n + t] * Z[(int64_t)i * n + t];
+        dsum = wave_sum(dsum);
+        if (lane == 0) dots[i] = dsum;
+      }
+      __syncthreads();
+      for (int t = TID; t < n; t += NT) {
+        double zt = Z[(int64_t)j * n + t];
+        for (int i = 0; i < j; i++) zt -= dots[i] * Z[(int64_t)i * n + t];
+        Z[(int64_t)j * n + t] = zt;
+      }
       XSYNC();
     }
     double nsum = 0;
