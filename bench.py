@@ -48,6 +48,8 @@ WORKLOADS = {
     'kb_barc2_N15': dict(desc='2-agent kinematic-bicycle race on the L_track_barc circuit, N=15, reg=0 (DGSQP_comp_monte_carlo.py), fp64', kind='barc', M=2, N=15, reg=0.0),
     'kb_barc3_N25': dict(desc='3-agent kinematic-bicycle race on the L_track_barc circuit, N=25, reg=0 (BASELINE configs[2] game), XL layout, fp64', kind='barc', M=3, N=25, reg=0.0),
     'merge_N20': dict(desc='3-car highway merge, kinematic unicycles rk3, N=20, reg=0 (DGSQP_merge_monte_carlo.py), big layout, fp64', kind='merge', N=20, reg=0.0),
+    # BASELINE configs[4]: six cars, N = 25 (n = 300, 1,587 rows, 837 distinct dense gradients): XL kernels, tables read from the constant block
+    'merge6_N25': dict(desc='6-car highway merge, kinematic unicycles rk3, N=25, reg=0 (DGSQP_merge_monte_carlo.py with six cars = BASELINE configs[4] game), XL layout, fp64', kind='merge', N=25, M=6, reg=0.0),
     'kb_curve_N50': dict(desc='2-agent kinematic-bicycle curve track, N=50, reg=1e-3 (BASELINE configs[3] size on the curve track), XL layout, fp64', kind='kb', track='curve', N=50, reg=1e-3),
     'kb_f1_N50': dict(desc='2-agent kinematic-bicycle race on the F1 track (cubic-spline centre line), N=50, reg=1e-3 (BASELINE configs[3] game), XL layout, fp64', kind='f1', N=50, reg=1e-3),
     'kb_curve3_N25': dict(desc='3-agent kinematic-bicycle curve track, N=25, reg=1e-3 (DGSQP_monte_carlo_agents.py M=3 N=25 = BASELINE configs[2] size), XL layout, fp64', kind='kb', track='curve', N=25, M=3, reg=1e-3),
@@ -72,7 +74,7 @@ def make_game(name, reg=None):
         return f1_racing_game(N=w['N'], reg=reg)
     if w['kind'] == 'merge':
         from dgsqp_amd.montecarlo import merge_game
-        return merge_game(N=w['N'], reg=reg)
+        return merge_game(N=w['N'], reg=reg, M=w.get('M', 3))
     return kinematic_racing_game(w['track'], N=w['N'], reg=reg, M=w.get('M', 2))
 
 
@@ -82,24 +84,54 @@ def algorithmic_bytes_per_solve(d):
     return 8 * (d.n_q + d.n + d.n + d.n_c + (d.N + 1) * d.n_q + 3 + d.M) + 12
 
 
-def spawn_ranks(n, argv):
+def spawn_ranks(n, argv, script=None, timeout=3600.0):
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (nothing in this process has
-    touched the GPU), relay rank 0's JSON line, exit with the worst return code."""
+    touched the GPU), relay rank 0's JSON line, exit with the worst return code.  Every spawn has its own rendezvous file (port +
+    pid + time, unlinked before the ranks start) and its own launch tag; a rank that dies takes the others down with it
+    instead of leaving them in ncclCommInitRank for ever.  `script`: what to run as a rank (tests substitute a stub)."""
     import socket
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
+    rdv = os.path.join(os.environ.get('TMPDIR', '/tmp'), f'dgsqp_rccl_{port}_{os.getpid()}_{time.time_ns()}.id')
+    for stale in (rdv,):
+        try:
+            os.remove(stale)
+        except OSError:
+            pass
     procs = []
+    tag = f'{os.getpid()}_{port}_{time.time_ns()}'
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                   DGSQP_RENDEZVOUS=os.path.join(os.environ.get('TMPDIR', '/tmp'), f'dgsqp_rccl_{port}_{os.getpid()}.id'))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                   DGSQP_RENDEZVOUS=rdv, DGSQP_LAUNCH_TAG=tag)
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
+    # rank 0's stdout is read by a thread so that the liveness loop below never blocks on a full pipe
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + timeout
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs) or time.time() > deadline:
+            failed = True
+            time.sleep(2.0)                 # (let the others notice a broken collective by themselves first)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                # exact PIDs we started
+            break
+        time.sleep(0.05)
     rcs = [p.wait() for p in procs]
-    sys.stdout.write(out.decode())
+    reader.join(10.0)
+    sys.stdout.write(b''.join(c for c in chunks if c).decode())
     sys.stdout.flush()
-    sys.exit(max(abs(rc) for rc in rcs))
+    try:
+        os.remove(rdv)
+    except OSError:
+        pass
+    worst = max(abs(rc) for rc in rcs)
+    sys.exit(worst if worst else (1 if failed else 0))
 
 
 def main():
@@ -197,9 +229,12 @@ def main():
                 done = [grp for grp in flying if lib.dgsqp_finished(handles[grp[0]])]
                 for grp in done:
                     retire(grp)
-                if done or not block or not flying or time.perf_counter() > deadline:
+                if done or not block or not flying:
                     return
+                if time.perf_counter() > deadline:
+                    raise RuntimeError('bench.py: a launch did not finish within 600 s')
                 time.sleep(0.0002)
+        group = max(1, min(group, n_batches))         # a group can never hold more batches than there are handles
         fence()
         t0 = time.perf_counter()
         nxt, step = 0, 0

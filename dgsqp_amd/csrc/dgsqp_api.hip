@@ -183,7 +183,10 @@ struct dgsqp_solver {
   bool in_flight = false;       // a solve launch has been enqueued and not yet waited for
   dgsqp_solver* group_leader = nullptr;   // set while this handle's batch is being solved by another handle's grouped launch
   DgBatch* d_group = nullptr;             // leader: device table of the group's batches (DG_GROUP_MAX entries)
-  std::vector<DgBatch> group_host;
+  DgBatch* group_host = nullptr;          // ... and its pinned host image (the source of an asynchronous copy)
+  unsigned long long launch_gen = 0;      // leader: counts its launches; members remember the generation they belong to
+  unsigned long long group_gen = 0;       // member: launch_gen of the leader's launch that solves this handle's batch
+  float last_ms = 0.0f;                   // kernel time of the last completed launch that solved this handle's batch (HIP events)
   dgsqp_comm_state* comm = nullptr;   // RCCL communicator + record buffers (dgsqp_comm.h), owned by the handle
   std::string err;
 };
@@ -245,9 +248,23 @@ std::vector<dgsqp_solver*> g_handles;
 }  // namespace
 // the stream the handle's solve in flight runs on: its own, or the leader's for a member of a grouped launch
 static hipStream_t active_stream(const dgsqp_solver* h) { return h->group_leader ? h->group_leader->stream : h->stream; }
+// kernel time of h's completed launch (events ev[0], ev[1] of the stream it ran on)
+static void record_last_ms(dgsqp_solver* h, dgsqp_solver* leader) {
+  float ms = 0.0f;
+  if (h->launched_grid > 0 && hipEventElapsedTime(&ms, leader->ev[0], leader->ev[1]) == hipSuccess) h->last_ms = ms;
+}
+// The members of a grouped launch led by L whose kernel has completed (L's stream is synchronised): they leave the group
+// with the kernel time of THAT launch.  Called before L's events are re-recorded by its next launch, so that a member's
+// later dgsqp_wait / dgsqp_finished never looks at the events of an unrelated kernel.
+static void release_members(dgsqp_solver* L) {
+  for (dgsqp_solver* o : g_handles)
+    if (o->group_leader == L && o->group_gen == L->launch_gen) { record_last_ms(o, L); o->in_flight = false; o->group_leader = nullptr; }
+}
 static int wait_idle(dgsqp_solver* h) {
   if (h->in_flight) {
-    HIPCHK(h, hipStreamSynchronize(active_stream(h)));
+    dgsqp_solver* L = h->group_leader ? h->group_leader : h;
+    HIPCHK(h, hipStreamSynchronize(L->stream));
+    record_last_ms(h, L);
     h->in_flight = false;
     h->group_leader = nullptr;
   }
@@ -351,6 +368,7 @@ void dgsqp_destroy(dgsqp_handle_t h) {
   (void)hipStreamSynchronize(h->stream);
   { std::lock_guard<std::mutex> lk(g_reg_mutex); for (dgsqp_solver* o : g_handles) if (o->group_leader == h) { o->group_leader = nullptr; o->in_flight = false; } }
   if (h->d_group) (void)hipFree(h->d_group);
+  if (h->group_host) (void)hipHostFree(h->group_host);
   if (h->comm) (void)dgsqp_comm_destroy(h);
   { std::lock_guard<std::mutex> lk(g_reg_mutex); g_handles.erase(std::remove(g_handles.begin(), g_handles.end(), h), g_handles.end()); }
   free_batch(h);
@@ -415,10 +433,9 @@ int dgsqp_launch_staged(dgsqp_handle_t h) {
   const int grid = grid_for(h, h->B);
   SolveOutPtrs O{h->d_u, h->d_l, h->d_x, h->d_cond, h->d_cost, h->d_status, h->d_iters, h->d_qps};
   std::unique_lock<std::mutex> game_lock(g_reg_mutex);
+  if (hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "hipStreamSynchronize failed"; return DGSQP_E_DEVICE; }
+  release_members(h);        // (members of an earlier grouped launch led by h: that kernel is done, its events are about to be reused)
   { int rcu = upload_problem(h); if (rcu) return rcu; }
-  h->in_flight = true;
-  HIPCHK(h, hipMemsetAsync(h->ticket, 0, sizeof(unsigned long long), h->stream));
-  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
   double* trace = nullptr;
   if (h->trace_cap > 0) {
     if (h->trace_B < h->B) {
@@ -442,12 +459,15 @@ int dgsqp_launch_staged(dgsqp_handle_t h) {
     itlog = h->d_itlog;
     h->itlog_launch_B = h->B;
   }
+  HIPCHK(h, hipMemsetAsync(h->ticket, 0, sizeof(unsigned long long), h->stream));
+  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
   *h->drained_host = 0u;
   hipLaunchKernelGGL(dg_solve_kernel, dim3(grid), dim3(DG_BLOCK), h->lds_bytes, h->stream, h->dp, h->B, h->d_x0, h->d_uws, O, h->ws, h->ticket, trace, h->trace_cap, h->drained_dev, itlog, h->itlog_cap, (const DgBatch*)nullptr, 0);
   HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+  h->launch_gen++;
   h->launched_grid = grid;
-  h->in_flight = true;
+  h->in_flight = true;       // (only now: an error return above leaves the handle idle)
+  HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
   return DGSQP_OK;
 }
 
@@ -470,14 +490,16 @@ int dgsqp_launch_staged_group(const dgsqp_handle_t* hs, int count) {
   const int grid = grid_for(L, L->B * count);
   { const int rce = ensure_ws(L, (size_t)grid); if (rce) return rce; }
   if (!L->d_group) HIPCHK(L, hipMalloc(&L->d_group, sizeof(DgBatch) * DG_GROUP_MAX));
-  L->group_host.resize(count);
+  if (!L->group_host) HIPCHK(L, hipHostMalloc((void**)&L->group_host, sizeof(DgBatch) * DG_GROUP_MAX, hipHostMallocDefault));
   for (int i = 0; i < count; i++) {
     dgsqp_solver* h = hs[i];
     L->group_host[i] = DgBatch{h->d_x0, h->d_uws, SolveOutPtrs{h->d_u, h->d_l, h->d_x, h->d_cond, h->d_cost, h->d_status, h->d_iters, h->d_qps}};
   }
   std::unique_lock<std::mutex> game_lock(g_reg_mutex);
+  if (hipStreamSynchronize(L->stream) != hipSuccess) { L->err = "hipStreamSynchronize failed"; return DGSQP_E_DEVICE; }
+  release_members(L);
   { int rcu = upload_problem(L); if (rcu) return rcu; }
-  HIPCHK(L, hipMemcpyAsync(L->d_group, L->group_host.data(), sizeof(DgBatch) * count, hipMemcpyHostToDevice, L->stream));
+  HIPCHK(L, hipMemcpyAsync(L->d_group, L->group_host, sizeof(DgBatch) * count, hipMemcpyHostToDevice, L->stream));
   HIPCHK(L, hipMemsetAsync(L->ticket, 0, sizeof(unsigned long long), L->stream));
   HIPCHK(L, hipEventRecord(L->ev[0], L->stream));
   *L->drained_host = 0u;
@@ -485,8 +507,9 @@ int dgsqp_launch_staged_group(const dgsqp_handle_t* hs, int count) {
   hipLaunchKernelGGL(dg_solve_kernel, dim3(grid), dim3(DG_BLOCK), L->lds_bytes, L->stream, L->dp, L->B, L->d_x0, L->d_uws, O0, L->ws, L->ticket,
                      (double*)nullptr, 0, L->drained_dev, (double*)nullptr, 0, (const DgBatch*)L->d_group, count);
   HIPCHK(L, hipGetLastError());
+  L->launch_gen++;
+  for (int i = 0; i < count; i++) { hs[i]->launched_grid = grid; hs[i]->in_flight = true; hs[i]->group_leader = i == 0 ? nullptr : L; hs[i]->group_gen = L->launch_gen; }
   HIPCHK(L, hipEventRecord(L->ev[1], L->stream));
-  for (int i = 0; i < count; i++) { hs[i]->launched_grid = grid; hs[i]->in_flight = true; hs[i]->group_leader = i == 0 ? nullptr : L; }
   return DGSQP_OK;
 }
 
@@ -499,22 +522,15 @@ int dgsqp_draining(dgsqp_handle_t h) {
 int dgsqp_finished(dgsqp_handle_t h) {
   if (!h || !h->in_flight || h->launched_grid == 0) return 1;
   if (hipSetDevice(h->device) != hipSuccess) return 1;
-  return hipEventQuery((h->group_leader ? h->group_leader : h)->ev[1]) != hipErrorNotReady;
+  return hipEventQuery((h->group_leader ? h->group_leader : h)->ev[1]) != hipErrorNotReady;      // (a member whose leader has moved on was released: not in flight)
 }
 
 int dgsqp_wait(dgsqp_handle_t h, dgsqp_timing_t* tm) {
   if (!h) return DGSQP_E_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   if (tm) memset(tm, 0, sizeof(*tm));
-  dgsqp_solver* L = h->group_leader ? h->group_leader : h;     // (a member of a grouped launch reports the group's kernel)
-  HIPCHK(h, hipStreamSynchronize(L->stream));
-  h->in_flight = false;
-  h->group_leader = nullptr;
-  if (tm && h->launched_grid > 0) {
-    float ms = 0;
-    HIPCHK(h, hipEventElapsedTime(&ms, L->ev[0], L->ev[1]));
-    tm->kernel_ms = ms; tm->total_ms = ms; tm->grid = h->launched_grid; tm->block = DG_BLOCK;
-  }
+  { const int rc = wait_idle(h); if (rc) return rc; }           // (a member of a grouped launch waits for, and reports, the group's kernel)
+  if (tm && h->launched_grid > 0) { tm->kernel_ms = h->last_ms; tm->total_ms = h->last_ms; tm->grid = h->launched_grid; tm->block = DG_BLOCK; }
   return DGSQP_OK;
 }
 
@@ -531,7 +547,7 @@ int dgsqp_fetch_results(dgsqp_handle_t h, double* u_out, double* l_out, double* 
   const DgProb& D = h->hp;
   const int64_t B = h->B;
   if (B == 0) return DGSQP_OK;
-  if (h->group_leader) { const int rcw = wait_idle(h); if (rcw) return rcw; }      // (solved on the leader's stream)
+  { const int rcw = wait_idle(h); if (rcw) return rcw; }      // (a member of a grouped launch was solved on its leader's stream)
   if (u_out) HIPCHK(h, hipMemcpyAsync(u_out, h->d_u, sizeof(double) * B * D.n, hipMemcpyDeviceToHost, h->stream));
   if (l_out) HIPCHK(h, hipMemcpyAsync(l_out, h->d_l, sizeof(double) * B * D.nc, hipMemcpyDeviceToHost, h->stream));
   if (x_out) HIPCHK(h, hipMemcpyAsync(x_out, h->d_x, sizeof(double) * B * (D.N + 1) * D.nq, hipMemcpyDeviceToHost, h->stream));
@@ -541,7 +557,6 @@ int dgsqp_fetch_results(dgsqp_handle_t h, double* u_out, double* l_out, double* 
   if (cond) HIPCHK(h, hipMemcpyAsync(cond, h->d_cond, sizeof(double) * B * 3, hipMemcpyDeviceToHost, h->stream));
   if (cost) HIPCHK(h, hipMemcpyAsync(cost, h->d_cost, sizeof(double) * B * D.M, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  h->in_flight = false;
   return DGSQP_OK;
 }
 
@@ -704,8 +719,10 @@ int dgsqp_fetch_iterate_log(dgsqp_handle_t h, double* out, int64_t capacity_doub
 int dgsqp_synchronize(dgsqp_handle_t h) {
   if (!h) return DGSQP_E_ARG;
   HIPCHK(h, hipSetDevice(h->device));
+  // A member of a grouped launch is solved on its LEADER's stream: wait for that kernel first (and leave the group), then for
+  // whatever is queued on the handle's own stream (copies, the stats gather).
+  { const int rc = wait_idle(h); if (rc) return rc; }
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  h->in_flight = false;
   return DGSQP_OK;
 }
 

@@ -34,13 +34,16 @@ __constant__ DgProb dg_prob;
 // inside sequential loops, where a constant-memory vector load would cost a global-memory round trip each time.
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 static_assert(sizeof(DgRow) == 8 && sizeof(DgDense) == 16, "table entries are moved as 64-bit words");
+// (DgProb.tab_const: games whose vectors nearly fill the arena read the tables from the constant block itself)
 __device__ inline DgRow ld_row(int r) {
+  if (dg_prob.tab_const) return dg_prob.rows[r];
   const unsigned long long w = ((const lds_u64*)LP(dg_prob.L.t_rows))[r];
   DgRow R;
   __builtin_memcpy(&R, &w, 8);
   return R;
 }
 __device__ inline DgDense ld_dense(int d) {
+  if (dg_prob.tab_const) return dg_prob.dense[d];
   const lds_u64* p = (const lds_u64*)LP(dg_prob.L.t_dense) + 2 * d;
   const unsigned long long w[2] = {p[0], p[1]};
   DgDense R;
@@ -48,6 +51,7 @@ __device__ inline DgDense ld_dense(int d) {
   return R;
 }
 __device__ inline DgTask ld_task(int t) {
+  if (dg_prob.tab_const) return dg_prob.dtask[t];
   const unsigned long long w = ((const lds_u64*)LP(dg_prob.L.t_task))[t];
   DgTask R;
   __builtin_memcpy(&R, &w, 8);
@@ -59,9 +63,9 @@ __device__ inline void dev_load_tables() {
   lds_u64* td = (lds_u64*)LP(D.L.t_dense);
   const unsigned long long* sr = (const unsigned long long*)D.rows;
   const unsigned long long* sd = (const unsigned long long*)D.dense;
-  for (int r = threadIdx.x; r < D.nc; r += DG_BLOCK) tr[r] = sr[r];
-  for (int d = threadIdx.x; d < 2 * D.ndense; d += DG_BLOCK) td[d] = sd[d];
-  {
+  if (!D.tab_const) for (int r = threadIdx.x; r < D.nc; r += DG_BLOCK) tr[r] = sr[r];
+  if (!D.tab_const) for (int d = threadIdx.x; d < 2 * D.ndense; d += DG_BLOCK) td[d] = sd[d];
+  if (!D.tab_const) {
     lds_u64* tk = (lds_u64*)LP(D.L.t_task);
     const unsigned long long* sk = (const unsigned long long*)D.dtask;
     for (int t = threadIdx.x; t < D.ntask; t += DG_BLOCK) tk[t] = sk[t];

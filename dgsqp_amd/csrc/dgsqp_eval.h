@@ -637,13 +637,15 @@ __device__ inline int dev_block_of(const DgProb& D, int xi) {
 }
 
 // generic (mixed-model) variant: run-time block offsets, arrays end up in scratch memory
-template <int NQA>
+// KG: the compact state-Hessian columns are read from the global scratch (DgProb.tab_const)
+template <int NQA, bool KG = false>
 __device__ __noinline__ void dev_hessian_row_generic(const Ctx& c, int row, int a, int k0, int j0) {
   const DgProb& D = dg_prob;
   const DgLds& L = D.L;
   lptr lds = LP(0);
   const int nq = D.nq, n = D.n, N = D.N, M = D.M;
-  clptr Kc = lds + L.e_K;
+  typename std::conditional<KG, cgptr, clptr>::type Kc;
+  if constexpr (KG) Kc = c.ws + D.ws_K; else Kc = lds + L.e_K;
   cgptr Hg = c.ws + D.ws_H;
   gptr tang = c.ws + D.ws_tang;
   gptr Qrow = c.ws + D.ws_q + (int64_t)row * n;
@@ -679,7 +681,7 @@ __device__ __noinline__ void dev_hessian_row_generic(const Ctx& c, int row, int 
   // mu_N = L_xx,N dx_N  (v holds dx_N)
   for (int i = 0; i < nq; i++) mu[i] = 0.0;
   {
-    clptr K = Kc + (a * (N + 1) + N) * M * 5;
+    const auto K = Kc + (a * (N + 1) + N) * M * 5;
     for (int b = 0; b < M; b++) {
       const int qb = D.qoff[b];
       mu[qb + 0] += K[b * 5 + 0] * v[0] + K[b * 5 + 1] * v[1];
@@ -739,7 +741,7 @@ __device__ __noinline__ void dev_hessian_row_generic(const Ctx& c, int row, int 
         }
       }
       if (t > k0) {
-        clptr K = Kc + (a * (N + 1) + t) * M * 5;
+        const auto K = Kc + (a * (N + 1) + t) * M * 5;
         for (int b = 0; b < M; b++) {
           const int qb = D.qoff[b];
           nm[qb + 0] += K[b * 5 + 0] * v[0] + K[b * 5 + 1] * v[1];
@@ -965,10 +967,12 @@ __device__ __noinline__ void dev_costates(const Ctx& c, clptr lm) {
       } else Dx[D.qoff[R.a] + R.idx] -= lr;
     }
     for (int i = 0; i < nq; i++) Dxs[(a * (N + 1) + k) * nq + i] = Dx[i];
-    for (int i = 0; i < M * 5; i++) Kc[(a * (N + 1) + k) * M * 5 + i] = Kl[i];
+    if (D.tab_const) { gptr Kg = c.ws + D.ws_K; for (int i = 0; i < M * 5; i++) Kg[(a * (N + 1) + k) * M * 5 + i] = Kl[i]; }
+    else for (int i = 0; i < M * 5; i++) Kc[(a * (N + 1) + k) * M * 5 + i] = Kl[i];
   }
+  if (D.tab_const) __threadfence_block();
   __syncthreads();
-  // ---- 1. costates: one wavefront per agent, lane = state component
+  // ---- 1. costates: one wavefront per agent, lane = state component (in place where e_Dxs shares e_lam's slot)
   {
     const int a = TID >> 6, i = TID & 63;
     if (a < M) {
@@ -1057,7 +1061,11 @@ __device__ __noinline__ void dev_hessian_adjoint(const Ctx& c) {
   // ---- 3. one lane per row of Q
   for (int row = TID; row < n; row += NT) {
     const int a = row / (N * DGSQP_NUA), rem = row % (N * DGSQP_NUA), k0 = rem / DGSQP_NUA, j0 = rem % DGSQP_NUA;
-    if (!D.uniform_nqa) {
+    if (D.tab_const) {
+      if (D.nqa[a] == 8) dev_hessian_row_generic<8, true>(c, row, a, k0, j0);
+      else if (D.nqa[a] == 4) dev_hessian_row_generic<4, true>(c, row, a, k0, j0);
+      else dev_hessian_row_generic<6, true>(c, row, a, k0, j0);
+    } else if (!D.uniform_nqa) {
       if (D.nqa[a] == 8) dev_hessian_row_generic<8>(c, row, a, k0, j0);
       else if (D.nqa[a] == 4) dev_hessian_row_generic<4>(c, row, a, k0, j0);
       else dev_hessian_row_generic<6>(c, row, a, k0, j0);

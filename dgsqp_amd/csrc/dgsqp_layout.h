@@ -9,7 +9,8 @@
 
 #define DG_NMAX 64        // horizon limit
 #define DG_NCMAX 2048     // inequality rows limit
-#define DG_NDMAX 512      // distinct dense gradients limit
+#define DG_NVARMAX 320     // decision variables limit (XL kernels: five 64-lane registers per column)
+#define DG_NDMAX 1024     // distinct dense gradients limit (6-car merge, N = 25: 837)
 #define DG_MAXEFF 8       // effective variables of one agent's dynamics (dyn bicycle: 6 states + 2 inputs)
 #define DG_MAXDIR 36      // MAXEFF*(MAXEFF+1)/2 Taylor directions
 #ifndef DG_BLOCK
@@ -44,7 +45,7 @@ struct DgTask {
   uint16_t v0;
   uint8_t len, pad_;
 };
-#define DG_NTASKMAX 1536
+#define DG_NTASKMAX 3072
 
 // LDS arena, offsets in doubles
 struct DgLds {
@@ -65,8 +66,9 @@ struct DgLds {
   // QP outputs that must survive trial evaluations
   int o_du, o_lhat;
   int c_R;   // classical QP: the first DgProb.c_rcap columns of the triangular factor R, packed column-major (phase-multiplexed with e_xs2)
-  // LSQR scratch
-  int s_u, s_v, s_w, s_x, s_t;
+  // LSQR scratch (s_yd2 / s_dpart: the dense-dot scratch of the dual start -- the QP's p_yd2 / p_dpart except in the
+  // 'tables in constant memory' layout, where the dual start has its own behind its vectors and may overlap the QP outputs)
+  int s_u, s_v, s_w, s_x, s_t, s_yd2, s_dpart;
   int total;  // doubles
 };
 
@@ -79,6 +81,9 @@ struct DgProb {
   double eig_floor;    // value given to negative eigenvalues by _nearestPD (par.eig_floor, 1e-10 when not set)
   int uniform_nqa;
   int gd_global;    // the packed constraint gradients live in the global scratch (ws_gd) instead of LDS: XL games beyond n ~ 160
+  int tab_const;    // the row / dense-gradient / task tables are read from this constant block instead of LDS copies, the compact
+                    // state-Hessian columns (e_K) live in the global scratch (ws_K) and the stage gradients share the costates'
+                    // slot: games whose vectors alone nearly fill the arena (6 agents, N = 25: n = 300, 1,587 rows, 837 gradients)
   int c_rcap;       // columns of R (classical QP) that live in LDS; the rest in the global scratch
   int classic_qp;   // the QP runs the classical (J = L^-T) Goldfarb-Idnani kernels of dgsqp_xl.h: XL layout, or a projected Hessian
                     // whose smallest eigenvalue (eig_floor + reg) is below 1e-8 -- the literal reg = 0 formula
@@ -91,7 +96,7 @@ struct DgProb {
   int t2off[DGSQP_MAX_AGENTS];              // offset (doubles) of agent block in the Taylor tensor workspace
   int t2k[DGSQP_MAX_AGENTS];                // per-stage stride of that block = nqa*ndir
   int64_t t2_doubles;
-  int64_t ws_t2, ws_q, ws_base, ws_H, ws_tang, ws_Y, ws_P, ws_V, ws_R, ws_Vp, ws_xM, ws_xJ, ws_xR, ws_bfgs, ws_gd, ws_v2, ws_doubles; // global workspace layout (doubles): Taylor tensor, raw Q, watchdog backups,
+  int64_t ws_t2, ws_q, ws_base, ws_H, ws_tang, ws_Y, ws_P, ws_V, ws_R, ws_Vp, ws_xM, ws_xJ, ws_xR, ws_bfgs, ws_gd, ws_v2, ws_K, ws_doubles; // global workspace layout (doubles): Taylor tensor, raw Q, watchdog backups,
                                                              // costate-contracted dynamics Hessians, tangent trajectories
   DgRow rows[DG_NCMAX];
   DgDense dense[DG_NDMAX];
@@ -137,6 +142,8 @@ static inline std::string dg_build_layout(DgProb& D) {
   if (D.par.variant == DGSQP_VARIANT_V2) D.ws_doubles += 3 * (2 * (int64_t)D.n + 2 * D.nc + 2) + D.n + D.nc;
   D.ws_gd = D.ws_doubles;
   if (D.gd_global) D.ws_doubles += D.ngd + DG_CHUNK;   // (chunked dots read up to one chunk past the last gradient)
+  D.ws_K = D.ws_doubles;
+  if (D.tab_const) D.ws_doubles += (int64_t)D.M * (D.N + 1) * D.M * 5;
   D.ws_doubles = (D.ws_doubles + 31) / 32 * 32;
   // ---- LDS arena
   DgLds& L = D.L;
@@ -148,14 +155,18 @@ static inline std::string dg_build_layout(DgProb& D) {
   L.gd = take(D.gd_global ? (nc > 2 ? nc : 2) : D.ngd);   // gd_global: only the nc-vector the trial merits keep there
   L.yd = take(nd); L.red = take(64); L.scal = take(64);
   L.w_prev = take((n + 2) / 2 + 1); L.w_prevlam = take(n + 1);   // final active set of the previous QP of this scenario (warm start)
-  L.t_rows = take(nc); L.t_dense = take(2 * nd); L.t_task = take(D.ntask); L.t_track = take(4 * (DGSQP_MAX_SEGS + 1)); L.t_atan = take(10);
+  if (D.tab_const) { L.t_rows = L.t_dense = L.t_task = o; }
+  else { L.t_rows = take(nc); L.t_dense = take(2 * nd); L.t_task = take(D.ntask); }
+  L.t_track = take(4 * (DGSQP_MAX_SEGS + 1)); L.t_atan = take(10);
   L.scr = o;
   // EVAL
   o = L.scr;
   L.e_x = take((N + 1) * nq); L.e_ue = take(n);
   for (int a = 0; a < D.M; a++) { L.e_A[a] = take(N * D.nqa[a] * D.nqa[a]); L.e_B[a] = take(N * D.nqa[a] * DGSQP_NUA); }
   L.e_dJ = take((N + 1) * nq);
-  L.e_lam = take(D.M * (N + 1) * nq); L.e_Dxs = take(D.M * (N + 1) * nq); L.e_K = take(D.M * (N + 1) * D.M * 5);
+  L.e_lam = take(D.M * (N + 1) * nq);
+  if (D.tab_const) { L.e_Dxs = L.e_lam; L.e_K = o; }      // costate recursion in place; e_K in the global scratch
+  else { L.e_Dxs = take(D.M * (N + 1) * nq); L.e_K = take(D.M * (N + 1) * D.M * 5); }
   int eval_end = o;
   // EIG: packed P, packed Householder reflectors, tridiagonal workspace
   o = L.scr;
@@ -174,7 +185,7 @@ static inline std::string dg_build_layout(DgProb& D) {
   o = L.scr + (D.big ? 0 : ((npk + 1) & ~1));
   L.p_R = D.big == 2 ? -1 : take(npk); L.p_lam = take(n + 1); L.p_c = take(n + 1); L.p_w = take(n + 1); L.p_r = take(n + 1);
   L.p_y = take(n); L.p_t = take(n); L.p_alist = take((n + 2) / 2 + 1); L.p_rd = take(n + 1);
-  {   // the dual start borrows p_yd2 / p_dpart while its own vectors (5 of length n_c) sit at L.scr: keep them apart
+  if (!D.tab_const) {   // the dual start borrows p_yd2 / p_dpart while its own vectors (5 of length n_c) sit at L.scr: keep them apart
     const int lsqr_size = 4 * ((nc + 1) & ~1) + (((nc > n ? nc : n) + 1) & ~1);
     if (o < L.scr + lsqr_size) o = L.scr + lsqr_size;
   }
@@ -187,8 +198,10 @@ static inline std::string dg_build_layout(DgProb& D) {
   // LSQR
   o = L.scr;
   L.s_u = take(nc); L.s_v = take(nc); L.s_w = take(nc); L.s_x = take(nc); L.s_t = take(nc > n ? nc : n);
+  if (D.tab_const) { L.s_yd2 = take(nd); L.s_dpart = take(D.ntask); }       // (the QP outputs are dead during the dual start)
+  else { L.s_yd2 = L.p_yd2; L.s_dpart = L.p_dpart; }
   const int lsqr_end = o;
-  if (L.p_yd2 < lsqr_end || L.p_dpart < lsqr_end) return "internal layout error: the dual start's borrowed QP scratch overlaps its vectors";
+  if (L.s_yd2 < L.s_t + (nc > n ? nc : n) || L.s_dpart < L.s_t + (nc > n ? nc : n)) return "internal layout error: the dual start's dot scratch overlaps its vectors";
   {
     // give the speculative rollouts the scratch the EIG / QP phases need anyway (the arena does not grow for them)
     int tot0 = eig_end > out_end ? eig_end : out_end;
@@ -232,6 +245,7 @@ static inline std::string dg_build_layout(DgProb& D) {
   L.total = tot;
   if ((long)tot * 8 > DG_LDS_LIMIT && !D.big) { D.big = 1; return dg_build_layout(D); }   // (n > 128 starts at big = 2)
   if ((long)tot * 8 > DG_LDS_LIMIT && D.big == 2 && !D.gd_global) { D.gd_global = 1; return dg_build_layout(D); }
+  if ((long)tot * 8 > DG_LDS_LIMIT && D.big == 2 && !D.tab_const) { D.tab_const = 1; return dg_build_layout(D); }
   if ((long)tot * 8 > DG_LDS_LIMIT) {
     char buf[160];
     snprintf(buf, sizeof buf, "problem needs %ld B of LDS per scenario (limit %d): n=%d n_c=%d", (long)tot * 8, DG_LDS_LIMIT, n, nc);
@@ -254,7 +268,7 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   if (P.M < 1 || P.M > DGSQP_MAX_AGENTS) return "unsupported number of agents";
   if (P.N < 1 || P.N > DG_NMAX) return "unsupported horizon";
   if (par.merit_function == DGSQP_MERIT_SUM_OBJ_L1 && par.variant != DGSQP_VARIANT_V2) return "merit function sum_obj_l1 belongs to DG-SQP v2";
-  if (P.N * P.M * DGSQP_NUA > 256) return "more than 256 decision variables are not supported yet";
+  if (P.N * P.M * DGSQP_NUA > DG_NVARMAX) return "more than 320 decision variables are not supported yet";
   if (P.n_segs < 1 || P.n_segs > DGSQP_MAX_SEGS) return "bad track table";
   D.M = P.M; D.N = P.N; D.nq = 0; D.nu = P.M * DGSQP_NUA;
   int t2 = 0;

@@ -723,9 +723,9 @@ __device__ int dev_xl_qp(const Ctx& c);
 __device__ inline void dev_ggt_mul(const Ctx& c, clptr vin, lptr vout, lptr tmpn) {
   const DgProb& D = dg_prob;
   gt_mul(c, vin, tmpn);
-  lptr dd2 = LP(D.L.p_yd2);     // QP scratch, idle during the dual start
-  if (D.gd_global) qp_dense_dots<cgptr>(D, dev_gd_global(c), tmpn, LP(D.L.p_dpart), dd2);
-  else qp_dense_dots<clptr>(D, LP(D.L.gd), tmpn, LP(D.L.p_dpart), dd2);
+  lptr dd2 = LP(D.L.s_yd2);     // QP scratch, idle during the dual start (its own copy in the tab_const layout)
+  if (D.gd_global) qp_dense_dots<cgptr>(D, dev_gd_global(c), tmpn, LP(D.L.s_dpart), dd2);
+  else qp_dense_dots<clptr>(D, LP(D.L.gd), tmpn, LP(D.L.s_dpart), dd2);
   for (int r = TID; r < D.nc; r += NT) vout[r] = qpw_row_dot(D, ld_row(r), tmpn, dd2);
   __syncthreads();
 }

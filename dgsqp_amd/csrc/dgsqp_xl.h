@@ -1,4 +1,4 @@
-// XL layout (128 < n <= 192): _nearestPD + _solve_qp for games whose matrices do not fit the LDS-resident layouts
+// XL layout (128 < n <= 320): _nearestPD + _solve_qp for games whose matrices do not fit the LDS-resident layouts
 // (BASELINE configs[2]: 3 agents, N=25, n=150; scripts/DGSQP_monte_carlo_agents.py at its M=3, N=25 setting).
 // Every n x n matrix lives in the workgroup's global scratch (L2); the kernels are plain block-wide loops -- a correct,
 // unoptimised path with the same semantics as the fast one:
@@ -11,8 +11,9 @@
 
 #define XSYNC() do { __threadfence_block(); __syncthreads(); } while (0)
 #define DG_XL_BASIS 49   // scal slot: the saved eigenvector basis of the Jacobi _nearestPD is valid (XL layout)
-#define XL_NV 4      // registers per lane for one column (n <= 256)
-#define XL_MAXP 16   // pairs of one tournament round per wavefront (128 pairs / 8 wavefronts)
+#define XL_NV 5      // registers per lane for one column (n <= 320 = DG_NVARMAX)
+#define XL_MAXP 20   // pairs of one tournament round per wavefront (160 pairs / 8 wavefronts)
+static_assert(64 * XL_NV >= DG_NVARMAX && XL_MAXP * (DG_BLOCK / 64) * 2 >= DG_NVARMAX, "XL kernels: register tiling must cover DG_NVARMAX columns");
 #ifndef XL_GRP
 #define XL_GRP 4     // ... handled four at a time (their four columns each stay in registers)
 #endif
@@ -485,12 +486,14 @@ __device__ inline void xl_wave_fwdsub_t(const XlR& R, int iq, clptr b, lptr out)
 __device__ inline void xl_wave_backsub(const XlR& R, int iq, clptr b, lptr out) {
   if (iq <= 64) xl_wave_backsub_t<1, 8>(R, iq, b, out);
   else if (iq <= 128) xl_wave_backsub_t<2, 8>(R, iq, b, out);
-  else xl_wave_backsub_t<4, 4>(R, iq, b, out);
+  else if (iq <= 256) xl_wave_backsub_t<4, 4>(R, iq, b, out);
+  else xl_wave_backsub_t<5, 4>(R, iq, b, out);
 }
 __device__ inline void xl_wave_fwdsub(const XlR& R, int iq, clptr b, lptr out) {
   if (iq <= 64) xl_wave_fwdsub_t<1, 8>(R, iq, b, out);
   else if (iq <= 128) xl_wave_fwdsub_t<2, 8>(R, iq, b, out);
-  else xl_wave_fwdsub_t<4, 4>(R, iq, b, out);
+  else if (iq <= 256) xl_wave_fwdsub_t<4, 4>(R, iq, b, out);
+  else xl_wave_fwdsub_t<5, 4>(R, iq, b, out);
 }
 // out[i] = sum_{k0 <= k < k1} J[k][i] v[k]   (J^T v restricted to rows k0..k1-1): consecutive threads read consecutive addresses
 template <class MP>
@@ -533,7 +536,7 @@ __device__ inline void xl_j_mul(MP J, int js, int n, const XlSplit& S, int k0, i
   } else {
     const int lane = TID & 63;
     // four rows per wavefront and pass, every load of the pass (4 rows x up to 4 chunks of 64 columns, n <= 256) issued before the
-    // first use: one L2 round trip per pass instead of one per chunk
+    // first use: one L2 round trip per pass instead of one per chunk.  Columns beyond 256 (n <= 320) ride in a fifth chunk.
     for (int i0 = (TID >> 6) * 4; i0 < n; i0 += (NT / 64) * 4) {
       double a[4][4], vk[4];
 #pragma unroll
@@ -547,6 +550,13 @@ __device__ inline void xl_j_mul(MP J, int js, int n, const XlSplit& S, int k0, i
       double s[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) s[r] = (a[r][0] * vk[0] + a[r][1] * vk[1]) + (a[r][2] * vk[2] + a[r][3] * vk[3]);
+      if (k1 - k0 > 256) {       // uniform
+        const int k = k0 + lane + 256;
+        const bool on = k < k1;
+        const double v5 = on ? v[k] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) s[r] += ((on && i0 + r < n) ? J[(int64_t)(i0 + r) * js + k] : 0.0) * v5;
+      }
 #pragma unroll
       for (int r = 0; r < 4; r++) { const double t = wave_sum(s[r]); if (lane == 0 && i0 + r < n) out[i0 + r] = t; }
     }

@@ -29,6 +29,29 @@ def shard_range(B: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_indices(B: int, rank: int, world: int, mode: str = 'contiguous') -> np.ndarray:
+    """Scenario indices owned by ``rank``.  ``contiguous``: the block of ``shard_range``.  ``interleaved``: rank, rank + world,
+    rank + 2 world, ... (iteration counts that correlate with the sample index -- e.g. a sampler that
+    sweeps a parameter -- then spread evenly over the ranks instead of loading one of them).  Both give every rank the same
+    number of scenarios up to one, the largest being ``padded_shard_size``."""
+    if mode == 'contiguous':
+        lo, hi = shard_range(B, rank, world)
+        return np.arange(lo, hi)
+    if mode == 'interleaved':
+        return np.arange(rank, B, world)
+    raise ValueError(f'unknown shard mode {mode!r}')
+
+
+def unshard(parts, B: int, world: int, mode: str = 'contiguous') -> np.ndarray:
+    """Inverse of ``shard_indices`` for per-rank result arrays (rank order): the array in the original scenario order."""
+    first = np.asarray(parts[0])
+    out = np.empty((B,) + first.shape[1:], first.dtype)
+    for r, part in enumerate(parts):
+        idx = shard_indices(B, r, world, mode)
+        out[idx] = np.asarray(part)[:len(idx)]
+    return out
+
+
 def padded_shard_size(B: int, world: int) -> int:
     """Size of the largest shard = the per-rank record count of the (equal-count) all-gather."""
     return -(-B // world)
@@ -69,6 +92,23 @@ def stats_from_records(rec: np.ndarray) -> np.ndarray:
 # ---------------------------------------------------------------------------------------------------------
 # rendezvous: rank 0 publishes the ncclUniqueId in a file on the node, the others poll for it
 # ---------------------------------------------------------------------------------------------------------
+_COMM_SEQ = 0      # communicators this process has built: every rank builds them in the same order, so the number names one rendezvous
+
+
+def launch_tag() -> bytes:
+    """16 bytes naming THIS launch (the common parent of the ranks: pid + start time): written in front of the id, checked by
+    the readers -- a file left behind by another launch under the same path is never taken for this launch's id."""
+    import hashlib
+    ppid = os.getppid()
+    try:
+        with open(f'/proc/{ppid}/stat') as f:
+            started = f.read().rsplit(')', 1)[1].split()[19]
+    except (OSError, IndexError):
+        started = '0'
+    key = os.environ.get('DGSQP_LAUNCH_TAG') or f"{ppid}_{started}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}"
+    return hashlib.blake2s(key.encode(), digest_size=16).digest()
+
+
 def rendezvous_path() -> str:
     explicit = os.environ.get('DGSQP_RENDEZVOUS')
     if explicit:
@@ -85,28 +125,34 @@ def rendezvous_path() -> str:
     return os.path.join(os.environ.get('TMPDIR', '/tmp'), f'dgsqp_rccl_{tag}.id')
 
 
-def exchange_unique_id(rank: int, world: int, make_id, path: str = None, timeout: float = 120.0) -> bytes:
-    """Rank 0 calls ``make_id()`` (-> 128 bytes) and writes it atomically; the others wait for the file."""
-    path = path or rendezvous_path()
+def exchange_unique_id(rank: int, world: int, make_id, path: str = None, timeout: float = 120.0, seq: int = 0) -> bytes:
+    """Rank 0 calls ``make_id()`` (-> 128 bytes) and publishes [launch tag (16 bytes), sequence number (8), id (128)] atomically
+    (stale files are unlinked first); the others wait for a file that carries THIS launch's tag and THIS rendezvous' number."""
+    path = (path or rendezvous_path()) + (f'.{seq}' if seq else '')
+    head = launch_tag() + int(seq).to_bytes(8, 'little')
     if rank == 0:
         uid = bytes(make_id())
         assert len(uid) == 128
+        try:
+            os.remove(path)
+        except OSError:
+            pass
         tmp = f'{path}.{os.getpid()}.tmp'
         with open(tmp, 'wb') as f:
-            f.write(uid)
+            f.write(head + uid)
         os.replace(tmp, path)
         return uid
     deadline = time.time() + timeout
     while time.time() < deadline:
         try:
             with open(path, 'rb') as f:
-                uid = f.read()
-            if len(uid) == 128:
-                return uid
+                blob = f.read()
+            if len(blob) == 152 and blob[:24] == head:
+                return blob[24:]
         except FileNotFoundError:
             pass
         time.sleep(0.01)
-    raise TimeoutError(f'rank {rank}: no ncclUniqueId at {path} after {timeout} s')
+    raise TimeoutError(f'rank {rank}: no ncclUniqueId of this launch at {path} after {timeout} s')
 
 
 class Communicator:
@@ -115,6 +161,8 @@ class Communicator:
     def __init__(self, solver, rank: int, world: int, path: str = None):
         self.solver, self.rank, self.world = solver, rank, world
         self._lib, self._h = solver._lib, solver._h
+        global _COMM_SEQ
+        self._seq, _COMM_SEQ = _COMM_SEQ, _COMM_SEQ + 1
         self._path = path or rendezvous_path()
 
         def make_id():
@@ -129,7 +177,7 @@ class Communicator:
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            uid = exchange_unique_id(rank, world, make_id, self._path) if world > 1 else make_id()
+            uid = exchange_unique_id(rank, world, make_id, self._path, seq=self._seq) if world > 1 else make_id()
             rc = self._lib.dgsqp_comm_init(self._h, uid, rank, world)
             C.CDLL(None).fflush(None)         # RCCL writes through C stdio: flush its buffer while fd 1 still points at stderr
         finally:
@@ -162,7 +210,7 @@ class Communicator:
         self._lib.dgsqp_comm_destroy(self._h)
         if self.rank == 0 and self.world > 1:
             try:
-                os.remove(self._path)
+                os.remove(self._path + (f'.{self._seq}' if self._seq else ''))
             except OSError:
                 pass
 

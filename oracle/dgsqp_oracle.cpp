@@ -801,6 +801,70 @@ static void nearest_pd(int n, const double* Qin, double reg, vec& out, double fl
 // Goldfarb-Idnani dual active set.  Returns 0 ok, 1 infeasible, 2 numerical failure.
 // lam = multipliers of G x <= -g (>= 0), i.e. CasADi's lam_a.
 // -----------------------------------------------------------------------------
+// KKT polish on the final active set A (iq rows): the dual method above reaches the optimal active set, but on the literal reg = 0
+// projection (eigenvalues floored at 1e-10, condition 1e12..1e13) its iterates start from x = -H^-1 c, of size 1e10 |c| along the
+// floored directions, and cancel back to O(1): the point it ends on carries relative errors up to 0.5 (tools/reg0_qp_study.py,
+// profiles/r03_reg0_qp_study.txt), although the minimiser itself is perfectly well determined -- the active rows pin those
+// directions.  What the reference returns is OSQP's POLISHED point: the solution of the KKT system of the active set
+// (osqp/src/polish.c: [H A'; A 0] regularised by delta = 1e-6 and iteratively refined).  Here: the same system, dense LU with
+// partial pivoting, two steps of iterative refinement.  The polished point replaces the iterate when it is primal and dual
+// feasible to the method's own tolerance; otherwise the iterate is kept (OSQP's "polish unsuccessful").  Returns 1 when taken.
+static bool qp_polish_enabled = false;     // (switched on together with the device-side polish)
+static int qp_kkt_polish(int n, int m, const double* H, const double* c, const double* G, const double* g, const int* A, int iq,
+                         double* x, double* lamA) {
+  const int s = n + iq;
+  vec K((size_t)s * s, 0.0), K0, rhs(s), sol(s), res(s);
+  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) K[(size_t)i * s + j] = H[(size_t)i * n + j];
+  for (int k = 0; k < iq; k++)
+    for (int j = 0; j < n; j++) { const double a = G[(size_t)A[k] * n + j]; K[(size_t)(n + k) * s + j] = a; K[(size_t)j * s + n + k] = a; }
+  for (int i = 0; i < n; i++) rhs[i] = -c[i];
+  for (int k = 0; k < iq; k++) rhs[n + k] = -g[A[k]];
+  K0 = K;
+  vector<int> piv(s);
+  for (int k = 0; k < s; k++) {       // LU with partial pivoting (lowest index on ties), L below the diagonal
+    int p = k; double best = std::fabs(K[(size_t)k * s + k]);
+    for (int i = k + 1; i < s; i++) { const double v = std::fabs(K[(size_t)i * s + k]); if (v > best) { best = v; p = i; } }
+    piv[k] = p;
+    if (!(best > 0.0)) return 0;
+    if (p != k) for (int j = 0; j < s; j++) std::swap(K[(size_t)k * s + j], K[(size_t)p * s + j]);
+    const double inv = 1.0 / K[(size_t)k * s + k];
+    for (int i = k + 1; i < s; i++) {
+      const double l = K[(size_t)i * s + k] * inv;
+      K[(size_t)i * s + k] = l;
+      if (l != 0.0) for (int j = k + 1; j < s; j++) K[(size_t)i * s + j] -= l * K[(size_t)k * s + j];
+    }
+  }
+  auto lu_solve = [&](vec& b) {        // in place
+    for (int k = 0; k < s; k++) if (piv[k] != k) std::swap(b[k], b[piv[k]]);      // P b (whole rows were swapped: P A = L U)
+    for (int k = 0; k < s; k++) for (int i = k + 1; i < s; i++) b[i] -= K[(size_t)i * s + k] * b[k];
+    for (int k = s - 1; k >= 0; k--) { double t = b[k]; for (int j = k + 1; j < s; j++) t -= K[(size_t)k * s + j] * b[j]; b[k] = t / K[(size_t)k * s + k]; }
+  };
+  sol = rhs;
+  lu_solve(sol);
+  for (int it = 0; it < 2; it++) {     // iterative refinement with fp64 residuals
+    for (int i = 0; i < s; i++) { double t = rhs[i]; for (int j = 0; j < s; j++) t -= K0[(size_t)i * s + j] * sol[j]; res[i] = t; }
+    lu_solve(res);
+    for (int i = 0; i < s; i++) sol[i] += res[i];
+  }
+  for (int i = 0; i < s; i++) if (!std::isfinite(sol[i])) return 0;
+  // accept only a primal / dual feasible point (tolerances of the active-set loop, relative for the multipliers)
+  double lmax = 0.0, lmin = 0.0;
+  for (int k = 0; k < iq; k++) { lmax = std::max(lmax, std::fabs(sol[n + k])); lmin = std::min(lmin, sol[n + k]); }
+  if (getenv("ORACLE_QP_DEBUG")) fprintf(stderr, "polish: s=%d lmin %g lmax %g\n", s, lmin, lmax);
+  if (lmin < -1e-9 * (1.0 + lmax)) return 0;
+  vector<char> act(m, 0);
+  for (int k = 0; k < iq; k++) act[A[k]] = 1;
+  for (int i = 0; i < m; i++) {
+    if (act[i]) continue;
+    double v = g[i];
+    for (int j = 0; j < n; j++) v += G[(size_t)i * n + j] * sol[j];
+    if (v > 1e-9) { if (getenv("ORACLE_QP_DEBUG")) fprintf(stderr, "polish: row %d violated %g\n", i, v); return 0; }
+  }
+  for (int i = 0; i < n; i++) x[i] = sol[i];
+  for (int k = 0; k < iq; k++) lamA[k] = std::max(sol[n + k], 0.0);
+  return 1;
+}
+
 static int qp_gi(int n, int m, const double* H, const double* c, const double* G, const double* g, double* x, double* lam) {
   vec Lc((size_t)n * n, 0.0);
   for (int j = 0; j < n; j++) {  // Cholesky H = L L'
@@ -846,6 +910,7 @@ static int qp_gi(int n, int m, const double* H, const double* c, const double* G
       if (s < ss) { ss = s; ip = i; }
     }
     if (ip < 0) {
+      if (qp_polish_enabled && iq > 0) (void)qp_kkt_polish(n, m, H, c, G, g, A.data(), iq, x, uu.data());
       for (int i = 0; i < m; i++) lam[i] = 0.0;
       for (int k = 0; k < iq; k++) lam[A[k]] = uu[k];
       return 0;
@@ -1629,6 +1694,7 @@ int oracle_eigh(int n, const double* A, double* s, double* U) {
   return 0;
 }
 
+void oracle_set_qp_polish(int on) { qp_polish_enabled = on != 0; }
 int oracle_qp(int n, int m, const double* H, const double* c, const double* G, const double* g, double* x, double* lam) {
   return qp_gi(n, m, H, c, G, g, x, lam);
 }

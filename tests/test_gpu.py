@@ -661,6 +661,47 @@ def test_xl_layout_three_agents_n150(oracle):
         assert rel(res['u'][b], ref['u'][b]) < 1e-6 and rel(res['l'][b], ref['l'][b]) < 1e-5
 
 
+def test_six_agent_merge_n300(oracle):
+    """BASELINE configs[4]'s game at its own size: six cars on the highway merge (DGSQP_merge_monte_carlo.py:66-74, 253-261, 316-342
+    generalised to six cars), N = 25: n = 300 decision variables, 36 / 63 / 39 rows per stage = 1,587 rows, 837 distinct dense
+    gradients (31,200 doubles, in the L2 scratch), tables read from the constant block, XL kernels with five registers per column.
+    Stage quantities to 1e-11, _nearestPD + QP against the oracle, full solves identical in (status, iterations, QP solves)."""
+    from dgsqp_amd.montecarlo import merge_game, sample_scenarios
+    from dgsqp_amd.solver import DGSQP, build_problem, build_params
+    g = merge_game(N=25, M=6)
+    P, par = build_problem(*g.solver_args()), tight_lsqr(build_params(g.params))
+    s = DGSQP(*g.solver_args(), print_method=None, lsqr_tol=1e-13)
+    assert (s.n, s.n_c_total, s.dims.n_dense, s.dims.layout) == (300, 1587, 837, 2) and s.dims.lds_bytes <= 163840
+    B = 8
+    x0, u_tm = sample_scenarios(g, B, seed=1)
+    u = agent_major(u_tm)
+    rng = np.random.default_rng(1)
+    up = u + 0.05 * rng.standard_normal(u.shape)
+    l = np.maximum(0, rng.standard_normal((B, s.n_c_total)))
+    ev = s.evaluate_batch(x0[:3], up[:3], l[:3])
+    for b in range(3):
+        o = oracle.evaluate(P, x0[b], up[b], l[b], 1)
+        for key in ('x', 'q', 'g', 'G', 'Q'):
+            assert rel(ev[key][b], o[key]) < 1e-11, (key, b)
+        assert rel(ev['l0'][b], oracle.dual_init(P, par, x0[b], up[b])) < 1e-6, b
+    l0 = np.array([oracle.dual_init(P, par, x0[b], u[b]) for b in range(2)])
+    qp = s.qp_batch(x0[:2], u[:2], l0)
+    for b in range(2):
+        o = oracle.evaluate(P, x0[b], u[b], l0[b], 1)
+        Qpd = oracle.nearest_pd(o['Q'], par.reg, par.eig_floor)
+        du, lam, flag = oracle.qp(Qpd, o['q'], o['G'], o['g'])
+        assert qp['flag'][b] == flag == 0 and np.abs(qp['Qpd'][b] - Qpd).max() < 1e-10 * np.abs(o['Q']).max()
+        assert np.array_equal(qp['lhat'][b] > 0, lam > 0), b
+        # (reg = 0, literal floor: condition 1e12 -- the step agrees to the accuracy either side solves that QP to)
+        assert rel(qp['du'][b], du) < 1e-4, (b, rel(qp['du'][b], du))
+    res = s.solve_batch(x0, u_tm)
+    ref = oracle.solve_batch(P, par, x0, u, nthreads=8)
+    same = assert_control_flow_parity(res, ref, stable_mask(oracle, P, par, x0, u, ref, K=1), g.name, min_stable_same=0.9)
+    assert (res['status'] <= 1).all() and same.sum() >= B - 1
+    for b in np.where(same & (ref['status'] <= 1))[0]:
+        assert rel(res['u'][b], ref['u'][b]) < 1e-2 and rel(res['x'][b], ref['x'][b]) < 1e-3, b
+
+
 @pytest.mark.parametrize('N,B', [(15, 24), (25, 12)])
 def test_three_agents_on_the_barc_circuit(oracle, N, B):
     """BASELINE configs[2]'s own game: 3 kinematic bicycles on the L_track_barc circuit (DGSQP_comp_monte_carlo.py game with a
