@@ -112,17 +112,20 @@ def spawn_ranks(n, argv, script=None, timeout=3600.0):
     reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
     reader.start()
     deadline = time.time() + timeout
-    failed = False
+    failed, killed = False, set()
     while any(p.poll() is None for p in procs):
         if any(p.poll() not in (None, 0) for p in procs) or time.time() > deadline:
             failed = True
             time.sleep(2.0)                 # (let the others notice a broken collective by themselves first)
             for p in procs:
                 if p.poll() is None:
+                    killed.add(p.pid)
                     p.kill()                # exact PIDs we started
             break
         time.sleep(0.05)
-    rcs = [p.wait() for p in procs]
+    rcs = [0 if p.pid in killed else p.wait() for p in procs]      # (the code of the rank that failed, not of the ones taken down after it)
+    for p in procs:
+        p.wait()
     reader.join(10.0)
     sys.stdout.write(b''.join(c for c in chunks if c).decode())
     sys.stdout.flush()
@@ -149,6 +152,9 @@ def main():
     ap.add_argument('--batches', type=int, default=0, help='distinct staged batches = handles the steps cycle through (default: (pipeline + 1) x group, so that a group never waits for the tail of a launch that still holds its handles)')
     ap.add_argument('--single-steps', type=int, default=3, help='extra one-launch-at-a-time steps behind value_single_launch / roofline.kernel_ms (0 disables)')
     ap.add_argument('--host-steps', type=int, default=2, help='extra dgsqp_solve_batch calls from host buffers behind value_host_inclusive (0 disables)')
+    ap.add_argument('--coop', choices=('auto', 'off'), default='auto',
+                    help='cooperative line search (dgsqp_set_cooperative): auto = in the LAST launch of the timed region and in launches that run alone -- idle '
+                         'workgroups evaluate line-search trials of the scenarios still solving; results are bit-identical; off = never')
     ap.add_argument('--reg', type=float, default=None, help='DGSQPParams.reg (default: the value of the workload)')
     ap.add_argument('--eig-floor', type=float, default=None, help='_nearestPD floor (default: the literal 1e-10, DGSQP.py:1293)')
     ap.add_argument('--snap-active-bounds', action='store_true', help='implementation knob, see include/dgsqp.h (default: literal)')
@@ -191,6 +197,8 @@ def main():
         x0, u_tm = sample_scenarios(game, B, seed=1 + rank + 1000 * j, solver=solver if game.sampler == 'first_segment' and d.M == 2 else None)   # PID warm starts on the device where the sampler supports it
         batches.append((np.ascontiguousarray(x0), np.ascontiguousarray(solver._to_agent_major(u_tm))))
     handles = [sv._h for sv in solvers]
+    for hh in handles:
+        lib.dgsqp_set_cooperative(hh, 1 if args.coop == 'auto' else 0)
     for hh, (x0, u_am) in zip(handles, batches):
         assert lib.dgsqp_stage_inputs(hh, B, _ffi.dptr(x0), _ffi.dptr(u_am)) == 0, lib.dgsqp_last_error(hh)
 
@@ -253,18 +261,28 @@ def main():
                 if i not in taken and i not in grp:
                     grp.append(i)
             arr = (C.c_void_p * gsz)(*[handles[i] for i in grp])
+            # the last launch of the region (and any launch that runs alone) is cooperative: nothing else is waiting for the compute
+            # units its idle workgroups keep while they help the slowest scenarios
+            coop = args.coop == 'auto' and (step + gsz >= steps or in_flight == 1)
+            lib.dgsqp_set_cooperative(handles[grp[0]], 2 if coop else 0)
             assert lib.dgsqp_launch_staged_group(arr, gsz) == 0, lib.dgsqp_last_error(handles[grp[0]])
+            lib.dgsqp_set_cooperative(handles[grp[0]], 1 if args.coop == 'auto' else 0)
             flying.append(tuple(grp))
             last = grp[0]
             step += gsz
         while flying:
             retire(flying[0])
+        mine = time.perf_counter() - t0           # this rank's own time up to its last launch (before the closing fence)
         fence()
         elapsed = float(comm.allreduce_max([time.perf_counter() - t0])[0])
+        per_rank = np.zeros(max(world, 1))
+        per_rank[rank] = mine
+        run_steps.per_rank = comm.allreduce_max(per_rank).tolist() if world <= 64 else None
         return elapsed, kernel_ms, last
 
     # ---- the timed region of the contract: exactly K steps, fences on both sides, max over ranks
     elapsed, kernel_ms_pipe, last = run_steps(args.steps, P, max(1, args.group))
+    elapsed_per_rank = run_steps.per_rank
     value = B_total * args.steps / elapsed
     # the single stats gather: the records of one step (batch 0, solved by handle 0, which owns the communicator)
     rec = comm.gather_stats(B_pad)
@@ -325,8 +343,9 @@ def main():
                                    'merge': 'scripts/DGSQP_merge_monte_carlo.py:421-480, zero warm start'}.get(
                                        game.sampler, 'scripts/DGSQP_ALGAMES_monte_carlo_curve.py:384-467, PID warm start') + ' (seed 1 + rank + 1000 * batch)',
                        'distinct_batches': n_batches, 'batches_per_launch': max(1, args.group), 'layout': {0: 'lds', 1: 'big', 2: 'xl'}[int(d.layout)],
-                       'launches_in_flight': P, 'batches_in_flight': P * max(1, args.group), 'reg': float(game.params.reg), 'eig_floor': float(solver._cparams.eig_floor),
+                       'launches_in_flight': P, 'batches_in_flight': P * max(1, args.group), 'cooperative_line_search': args.coop, 'reg': float(game.params.reg), 'eig_floor': float(solver._cparams.eig_floor),
                        'snap_active_bounds': int(solver._cparams.snap_active_bounds)},
+            'elapsed_s_per_rank': elapsed_per_rank,        # each rank's own time for its K steps: load imbalance between the shards shows here
             'value_single_launch': single['value'] if single else None,
             'value_host_inclusive': host['value'] if host else None,
             'mean_iters': summ['mean_iters_converged'], 'mean_iters_all': summ['mean_iters_all'],
@@ -348,14 +367,21 @@ def main():
         if world == 1 and args.cpu_sample > 0:
             from oracle import oracle            # checker/baseline only: the CPU restatement, NOT CasADi+OSQP
             oracle.build()
-            ns = min(args.cpu_sample, B)
             cores = os.cpu_count() or 1
+            # a THROUGHPUT, not the time of the slowest scenario: 8 scenarios per core by default, handed out dynamically; plus one core alone
+            ns = min(args.cpu_sample if args.cpu_sample != 64 else 8 * cores, B)
             x0, u_am = batches[0]
             t1 = time.perf_counter()
             oracle.solve_batch(solver._problem, solver._cparams, x0[:ns], u_am[:ns], nthreads=min(cores, ns))
             dt = time.perf_counter() - t1
+            n1 = min(4, ns)
+            t1 = time.perf_counter()
+            oracle.solve_batch(solver._problem, solver._cparams, x0[:n1], u_am[:n1], nthreads=1)
+            dt1 = time.perf_counter() - t1
             line['cpu_baseline'] = {'value': ns / dt, 'unit': 'scenarios/s', 'cores': min(cores, ns), 'kind': 'port',
-                                    'sample': f'first {ns} scenarios of batch 0, oracle/dgsqp_oracle.cpp (dense literal restatement, not CasADi+OSQP), {dt:.1f} s'}
+                                    'value_one_core': n1 / dt1,
+                                    'sample': f'first {ns} scenarios of batch 0 over {min(cores, ns)} threads (dynamic hand-out), {dt:.1f} s; first {n1} on one core, {dt1:.1f} s; '
+                                              f'oracle/dgsqp_oracle.cpp (dense literal restatement, not CasADi+OSQP)'}
         print(json.dumps(line), flush=True)
     comm.close()
 

@@ -164,6 +164,10 @@ def load_library() -> C.CDLL:
     lib.dgsqp_launch_staged_group.restype = C.c_int
     lib.dgsqp_finished.argtypes = [H]
     lib.dgsqp_finished.restype = C.c_int
+    lib.dgsqp_set_cooperative.argtypes = [H, C.c_int]
+    lib.dgsqp_set_cooperative.restype = C.c_int
+    lib.dgsqp_coop_stats.argtypes = [H, C.POINTER(C.c_uint64)]
+    lib.dgsqp_coop_stats.restype = C.c_int
     lib.dgsqp_synchronize.argtypes = [H]
     lib.dgsqp_synchronize.restype = C.c_int
     lib.dgsqp_comm_unique_id.argtypes = [C.c_char_p]
@@ -187,7 +191,8 @@ EXPORTED_SYMBOLS = ['dgsqp_create', 'dgsqp_destroy', 'dgsqp_dims', 'dgsqp_plan',
                     'dgsqp_evaluate_batch', 'dgsqp_qp_batch', 'dgsqp_set_trace', 'dgsqp_fetch_trace',
                     'dgsqp_pid_warm_start_batch', 'dgsqp_launch_staged', 'dgsqp_wait', 'dgsqp_draining',
                     'dgsqp_set_iterate_log', 'dgsqp_fetch_iterate_log', 'dgsqp_synchronize', 'dgsqp_finished', 'dgsqp_launch_staged_group', 'dgsqp_solve_batch_f32', 'dgsqp_comm_unique_id', 'dgsqp_comm_init',
-                    'dgsqp_comm_destroy', 'dgsqp_gather_stats', 'dgsqp_comm_barrier', 'dgsqp_comm_allreduce_max']
+                    'dgsqp_comm_destroy', 'dgsqp_gather_stats', 'dgsqp_comm_barrier', 'dgsqp_comm_allreduce_max',
+                    'dgsqp_set_cooperative', 'dgsqp_coop_stats']
 
 
 def dptr(a):

@@ -30,8 +30,13 @@ __global__ void __launch_bounds__(DG_BLOCK)
 dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__ x0, const double* __restrict__ u_ws,
                 SolveOutPtrs O, double* __restrict__ ws_all, unsigned long long* __restrict__ ticket,
                 double* __restrict__ trace, int trace_cap, unsigned int* __restrict__ drained,
-                double* __restrict__ itlog, int itlog_cap, const DgBatch* __restrict__ group, int group_n) {
+                double* __restrict__ itlog, int itlog_cap, const DgBatch* __restrict__ group, int group_n,
+                DgCoop* coop, double* coop_payload, int coop_start, int coop_verify) {
   Ctx c;
+  c.coop = coop;
+  c.coop_start = coop_start; c.coop_verify = coop_verify;
+  c.coop_payload = coop ? coop_payload + (size_t)blockIdx.x * 2 * (2 * dg_prob.n + 2 * dg_prob.nc) : nullptr;
+  c.coop_total = (unsigned long long)(B * (group ? group_n : 1));
   c.trace_cap = trace_cap;
   c.itlog_cap = itlog_cap;
   c.ws = (gptr)ws_all + (int64_t)blockIdx.x * dg_prob.ws_doubles;
@@ -40,6 +45,7 @@ dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restric
   const unsigned long long wall0 = wall_clock64();
 #endif
   dev_load_tables();
+  if (TID == 0) dg_lds[dg_prob.L.scal + DG_COOP_FLIP] = 0.0;
   while (true) {
     __syncthreads();
     if (TID == 0) dg_lds[dg_prob.L.scal + 63] = (double)atomicAdd(ticket, 1ULL);
@@ -49,6 +55,8 @@ dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restric
       // the queue is empty: from now on this launch only drains.  Tell the host (mapped, fine-grained memory) so that it
       // can start the next independent batch on the compute units that become free.
       if (drained && TID == 0) { __hip_atomic_store(drained, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+      // cooperative launches: stay and evaluate line-search trials for the workgroups that are still solving
+      if (coop) dev_coop_help(c);
       break;
     }
     if (group) {        // grouped launch (dgsqp_launch_staged_group): ticket -> (staged batch, scenario); every batch has its own buffers
@@ -65,6 +73,7 @@ dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restric
 #endif
     if (dg_prob.par.variant == DGSQP_VARIANT_V2) dev_solve_v2(c, (cgptr)u_ws + b * dg_prob.n, b, O);
     else dev_solve(c, (cgptr)u_ws + b * dg_prob.n, b, O);
+    if (coop && TID == 0) { __threadfence(); __hip_atomic_fetch_add(&coop->finished, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 #ifdef DG_PROF
     if (TID == 0 && b < 16384) dg_prof_scn[b] = (unsigned long long)(clock64() - sc_t0);
 #endif
@@ -87,6 +96,7 @@ dg_evaluate_kernel(const DgProb* __restrict__ D, int64_t B, const double* __rest
                    const double* __restrict__ l, double* q, double* g, double* G, double* Q, double* x, double* l0,
                    double* __restrict__ ws_all) {
   Ctx c;
+  c.coop = nullptr; c.coop_payload = nullptr; c.coop_total = 0; c.coop_start = 0; c.coop_verify = 0;
   c.ws = (gptr)ws_all + (int64_t)blockIdx.x * dg_prob.ws_doubles;
   c.trace = nullptr; c.trace_cap = 0; c.itlog = nullptr; c.itlog_cap = 0;
   const DgLds& L = dg_prob.L;
@@ -124,6 +134,7 @@ __global__ void __launch_bounds__(DG_BLOCK)
 dg_qp_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__ x0, const double* __restrict__ u,
              const double* __restrict__ l, double* du, double* lhat, double* Qpd, int32_t* flag, double* __restrict__ ws_all) {
   Ctx c;
+  c.coop = nullptr; c.coop_payload = nullptr; c.coop_total = 0; c.coop_start = 0; c.coop_verify = 0;
   c.ws = (gptr)ws_all + (int64_t)blockIdx.x * dg_prob.ws_doubles;
   c.trace = nullptr; c.trace_cap = 0; c.itlog = nullptr; c.itlog_cap = 0;
   const DgLds& L = dg_prob.L;
@@ -187,6 +198,11 @@ struct dgsqp_solver {
   unsigned long long launch_gen = 0;      // leader: counts its launches; members remember the generation they belong to
   unsigned long long group_gen = 0;       // member: launch_gen of the leader's launch that solves this handle's batch
   float last_ms = 0.0f;                   // kernel time of the last completed launch that solved this handle's batch (HIP events)
+  DgCoop* d_coop = nullptr;           // cooperative line search: job slots (2 per workgroup) ...
+  double* d_coop_payload = nullptr;   // ... and the base points their owners publish
+  size_t coop_bytes = 0;
+  int coop_mode = 1;                  // 0 off, 1 synchronous calls only (nothing else is waiting for the compute units), 2 every launch
+  bool coop_next_sync = false;        // (set by the synchronous entry points around their launch)
   dgsqp_comm_state* comm = nullptr;   // RCCL communicator + record buffers (dgsqp_comm.h), owned by the handle
   std::string err;
 };
@@ -286,6 +302,25 @@ static int upload_problem(dgsqp_solver* h) {
   r.valid = true;
   return DGSQP_OK;
 }
+// Cooperative line search for the launch about to be enqueued?  Helpers keep their compute units until the launch's last
+// scenario is done: right when nothing else waits for them (synchronous calls), wrong in a pipeline of launches -- the caller
+// says so (dgsqp_set_cooperative).  Needs the whole grid resident (it is: at most one workgroup per compute unit).
+// (development knobs: DGSQP_COOP_START = rejected trials after which a line search is offered to helpers, default 4;
+//  DGSQP_COOP_VERIFY = 1: owners re-evaluate every helper value and count differing bits -- dgsqp_coop_stats)
+static int coop_start_trials() { const char* e = getenv("DGSQP_COOP_START"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }
+static int coop_verify_mode() { const char* e = getenv("DGSQP_COOP_VERIFY"); return e && atoi(e) != 0; }
+static bool coop_for_launch(dgsqp_solver* h, int grid) {
+  if (!h->d_coop || grid > h->num_cu * 2 + 2 || h->trace_cap > 0) return false;
+  // Worth it only where a trial point is expensive: its rollout is a dependent chain of N x substeps x stages evaluations of f_c on
+  // a handful of lanes (dynamic bicycle, rk4, M = 10: 1,000; measured 1,045 -> 735 ms for a 1,024-scenario batch).  For the euler
+  // games (25 evaluations) a helper needs as long to find and load a job as the owner to evaluate the trial itself (measured: 409 ->
+  // 450 ms), so those launches stay plain.
+  const dgsqp_problem_t& P = h->hp.P;
+  const int stages = P.integrator == DGSQP_INT_RK4 ? 4 : (P.integrator == DGSQP_INT_RK3 ? 3 : (P.integrator == DGSQP_INT_RK2 ? 2 : 1));
+  const int chain = P.N * (P.integrator == DGSQP_INT_EULER ? 1 : P.substeps * stages);
+  if (chain < 200 && !getenv("DGSQP_COOP_FORCE")) return false;
+  return h->coop_mode == 2 || (h->coop_mode == 1 && h->coop_next_sync);
+}
 static int grid_for(dgsqp_solver* h, int64_t B) {
   int64_t g = (int64_t)h->max_grid;
   if (B < g) g = B;
@@ -347,6 +382,9 @@ int dgsqp_create(const dgsqp_problem_t* prob, const dgsqp_params_t* par, int dev
   if (hipHostMalloc((void**)&h->drained_host, sizeof(unsigned int), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return fail("hipHostMalloc(flag) failed");
   *h->drained_host = 1u;
   if (hipHostGetDevicePointer((void**)&h->drained_dev, h->drained_host, 0) != hipSuccess) return fail("hipHostGetDevicePointer failed");
+  h->coop_bytes = sizeof(DgCoop) + sizeof(DgCoopJob) * 2 * (size_t)(h->num_cu * 2 + 2);
+  if (hipMalloc((void**)&h->d_coop, h->coop_bytes) != hipSuccess) return fail("hipMalloc(coop) failed");
+  if (hipMalloc((void**)&h->d_coop_payload, sizeof(double) * 2 * (2 * (size_t)h->hp.n + 2 * (size_t)h->hp.nc) * (size_t)(h->num_cu * 2 + 2)) != hipSuccess) return fail("hipMalloc(coop payload) failed");
   const void* kernels[] = {(const void*)dg_solve_kernel, (const void*)dg_evaluate_kernel, (const void*)dg_qp_kernel};
   for (const void* k : kernels) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
@@ -375,6 +413,8 @@ void dgsqp_destroy(dgsqp_handle_t h) {
   if (h->ws) (void)hipFree(h->ws);
   if (h->dp) (void)hipFree(h->dp);
   if (h->ticket) (void)hipFree(h->ticket);
+  if (h->d_coop) (void)hipFree(h->d_coop);
+  if (h->d_coop_payload) (void)hipFree(h->d_coop_payload);
   if (h->drained_host) (void)hipHostFree(h->drained_host);
   if (h->d_trace) (void)hipFree(h->d_trace);
   if (h->d_itlog) (void)hipFree(h->d_itlog);
@@ -460,9 +500,12 @@ int dgsqp_launch_staged(dgsqp_handle_t h) {
     h->itlog_launch_B = h->B;
   }
   HIPCHK(h, hipMemsetAsync(h->ticket, 0, sizeof(unsigned long long), h->stream));
+  const bool coop = coop_for_launch(h, grid);
+  if (coop) HIPCHK(h, hipMemsetAsync(h->d_coop, 0, h->coop_bytes, h->stream));
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
   *h->drained_host = 0u;
-  hipLaunchKernelGGL(dg_solve_kernel, dim3(grid), dim3(DG_BLOCK), h->lds_bytes, h->stream, h->dp, h->B, h->d_x0, h->d_uws, O, h->ws, h->ticket, trace, h->trace_cap, h->drained_dev, itlog, h->itlog_cap, (const DgBatch*)nullptr, 0);
+  hipLaunchKernelGGL(dg_solve_kernel, dim3(grid), dim3(DG_BLOCK), h->lds_bytes, h->stream, h->dp, h->B, h->d_x0, h->d_uws, O, h->ws, h->ticket, trace, h->trace_cap, h->drained_dev, itlog, h->itlog_cap, (const DgBatch*)nullptr, 0,
+                     coop ? h->d_coop : (DgCoop*)nullptr, h->d_coop_payload, coop_start_trials(), coop_verify_mode());
   HIPCHK(h, hipGetLastError());
   h->launch_gen++;
   h->launched_grid = grid;
@@ -501,11 +544,14 @@ int dgsqp_launch_staged_group(const dgsqp_handle_t* hs, int count) {
   { int rcu = upload_problem(L); if (rcu) return rcu; }
   HIPCHK(L, hipMemcpyAsync(L->d_group, L->group_host, sizeof(DgBatch) * count, hipMemcpyHostToDevice, L->stream));
   HIPCHK(L, hipMemsetAsync(L->ticket, 0, sizeof(unsigned long long), L->stream));
+  const bool coop = coop_for_launch(L, grid);
+  if (coop) HIPCHK(L, hipMemsetAsync(L->d_coop, 0, L->coop_bytes, L->stream));
   HIPCHK(L, hipEventRecord(L->ev[0], L->stream));
   *L->drained_host = 0u;
   SolveOutPtrs O0 = L->group_host[0].O;
   hipLaunchKernelGGL(dg_solve_kernel, dim3(grid), dim3(DG_BLOCK), L->lds_bytes, L->stream, L->dp, L->B, L->d_x0, L->d_uws, O0, L->ws, L->ticket,
-                     (double*)nullptr, 0, L->drained_dev, (double*)nullptr, 0, (const DgBatch*)L->d_group, count);
+                     (double*)nullptr, 0, L->drained_dev, (double*)nullptr, 0, (const DgBatch*)L->d_group, count,
+                     coop ? L->d_coop : (DgCoop*)nullptr, L->d_coop_payload, coop_start_trials(), coop_verify_mode());
   HIPCHK(L, hipGetLastError());
   L->launch_gen++;
   for (int i = 0; i < count; i++) { hs[i]->launched_grid = grid; hs[i]->in_flight = true; hs[i]->group_leader = i == 0 ? nullptr : L; hs[i]->group_gen = L->launch_gen; }
@@ -535,9 +581,29 @@ int dgsqp_wait(dgsqp_handle_t h, dgsqp_timing_t* tm) {
 }
 
 int dgsqp_solve_staged(dgsqp_handle_t h, dgsqp_timing_t* tm) {
+  if (!h) return DGSQP_E_ARG;
+  h->coop_next_sync = true;          // the caller waits for this launch: idle workgroups help with its line searches
   const int rc = dgsqp_launch_staged(h);
+  h->coop_next_sync = false;
   if (rc != DGSQP_OK) return rc;
   return dgsqp_wait(h, tm);
+}
+
+int dgsqp_set_cooperative(dgsqp_handle_t h, int mode) {
+  if (!h || mode < 0 || mode > 2) return DGSQP_E_ARG;
+  h->coop_mode = mode;
+  return DGSQP_OK;
+}
+
+int dgsqp_coop_stats(dgsqp_handle_t h, uint64_t* out4 /* six values */) {
+  if (!h || !out4 || !h->d_coop) return DGSQP_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  { const int rc = wait_idle(h); if (rc) return rc; }
+  DgCoop hdr;
+  HIPCHK(h, hipMemcpy(&hdr, h->d_coop, sizeof(DgCoop) - sizeof(DgCoopJob), hipMemcpyDeviceToHost));
+  out4[0] = hdr.helped; out4[1] = hdr.timeouts; out4[2] = hdr.finished; out4[3] = hdr.idle;
+  out4[4] = hdr.used; out4[5] = hdr.mismatches;
+  return DGSQP_OK;
 }
 
 int dgsqp_fetch_results(dgsqp_handle_t h, double* u_out, double* l_out, double* x_out, int32_t* status, int32_t* iters,

@@ -86,7 +86,46 @@ __device__ inline void dev_load_tables() {
   __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Cooperative line search (dgsqp_solve.h: dev_line_search / dev_coop_help).  A launch ends with its slowest scenario -- 50
+// iterations of failing 50-trial line searches, 0.7 s alone while the balanced share of a 1,024-scenario batch is 0.09 s.  The
+// trial points of one line search are independent evaluations, so workgroups that find the ticket queue empty stay as HELPERS:
+// they poll the job slots of the workgroups still solving, claim trial indices, evaluate them with the very same device
+// functions (bit-identical merits) and hand the values back; the owner replays the sequential accept / reject logic on them.
+// ------------------------------------------------------------------------------------------------
+#define DG_COOP_PHI 64
+struct DgCoopJob {
+  unsigned int seq;               // odd: open (published with release semantics), even: closed
+  unsigned int active;            // helpers currently working on this job (the slot is reused only when 0)
+  unsigned long long claimed;     // bit j: trial j is taken (owner or helper), atomic OR
+  unsigned long long ready;       // bit j: its result is in phi_out / pruned
+  unsigned long long pruned;      // bit j: rejected by the derivative-free bound (no merit value)
+  int lo, iters;                  // helpers take trials [lo, iters) first, then lo-1 .. 1
+  double mu, phi, dphi, S0, S1;   // the Armijo test's constants
+  const double* x0;               // the scenario's initial state
+  double* payload;                // u[n], du[n], l[nc], lhat[nc] of the base point
+  double phi_out[DG_COOP_PHI];
+};
+struct DgCoop {
+  unsigned int idle;              // helper workgroups currently polling
+  unsigned int timeouts;          // owner waits that gave up (diagnostic: must stay 0)
+  unsigned long long finished;    // scenarios completed by this launch
+  unsigned int open;              // job slots currently open: the one word idle helpers poll
+  unsigned int pad0_;
+  unsigned long long helped;      // trials evaluated by helpers (diagnostic)
+  unsigned int pad1_;
+  unsigned int mismatches;        // verify mode: helper values whose bits differ from the owner's own evaluation (must stay 0)
+  unsigned long long used;        // helper values the owners consumed (diagnostic)
+  unsigned long long pad_[2];
+  DgCoopJob jobs[1];              // 2 per workgroup of the grid (double buffered)
+};
+
 struct Ctx {
+  DgCoop* coop;    // cooperative line search of this launch (null: off)
+  double* coop_payload;   // this workgroup's two payload buffers (2 x (2 n + 2 n_c) doubles)
+  unsigned long long coop_total;   // scenarios of this launch (helpers leave when that many are finished)
+  int coop_start;  // a line search is offered to helpers once this many of its trials have been rejected (short ones stay private)
+  int coop_verify; // diagnostic: the owner evaluates every trial itself as well and counts helper values that differ in their bits
   gptr ws;      // this workgroup's global workspace
   cgptr x0;
   gptr trace;   // optional per-scenario event log: [0] = number of (code, value) pairs, then the pairs

@@ -1072,6 +1072,147 @@ __device__ inline double dev_trial_merit(const Ctx& c, double alpha, double sum_
   return dev_phi_trial_dense(c, alpha, sum_s, mu);
 }
 
+// ---- cooperative line search (dgsqp_device.h: DgCoop) ----------------------------------------------------------------------
+#define DG_COOP_FLIP 57      // scal slot: which of the workgroup's two job slots its next line search uses
+#define DG_BCAST 58          // scal slot: one 64-bit word handed from thread 0 to the workgroup
+#define AT_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+// one value read by thread 0 and handed to the whole workgroup (control flow must stay uniform)
+__device__ inline unsigned long long dev_bcast_u64(unsigned long long v) {
+  lptr sc = LP(dg_prob.L.scal);
+  __syncthreads();
+  if (TID == 0) ((__attribute__((address_space(3))) unsigned long long*)sc)[DG_BCAST] = v;
+  __syncthreads();
+  return ((__attribute__((address_space(3))) unsigned long long*)sc)[DG_BCAST];
+}
+// The derivative-free part of the merit exceeds the Armijo bound: the trial is rejected from its constraint values alone.
+__device__ inline bool dev_trial_pruned(const Ctx& c, double alpha, double mu, double phi, double dphi, double S0, double S1) {
+  const DgProb& D = dg_prob;
+  const DgLds& L = D.L;
+  lptr lds = LP(0);
+  double lg = 0, sg = 0;
+  for (int r = TID; r < D.nc; r += NT) {
+    const double gr = lds[L.g + r];
+    lg += (lds[L.l + r] + alpha * (lds[L.o_lhat + r] - lds[L.l + r])) * gr;
+    sg += gr;
+  }
+  lg = block_sum(lg, lds + L.red); sg = block_sum(sg, lds + L.red);
+  double lb = 0.5 * lg * lg;
+  if (D.par.merit_function == DGSQP_MERIT_STAT_L1) lb += mu * (sg - (S0 + alpha * S1));
+  const double bound = phi + D.par.beta * alpha * dphi;
+  PROF_COUNT(PH_C_TRIALS, lb > bound + 1e-9 * (fabs(bound) + fabs(lb)) ? 1 : 0);
+  return lb > bound + 1e-9 * (fabs(bound) + fabs(lb));
+}
+// Helper side: evaluate trial j of `job` exactly as its owner would (own rollout of that one trajectory).  The base point is in
+// this workgroup's LDS (loaded by dev_coop_help).
+__device__ __noinline__ void dev_coop_trial(const Ctx& c, DgCoopJob* job, int j) {
+  const DgProb& D = dg_prob;
+  const DgLds& L = D.L;
+  lptr lds = LP(0);
+  const int xsz = ((D.N + 1) * D.nq + 1) & ~1;
+  double alpha = 1.0;
+  for (int t = 0; t < j; t++) alpha *= D.par.tau;            // the owner's alpha *= tau, j times
+  const double mu = AT_LOAD(&job->mu), phi = AT_LOAD(&job->phi), dphi = AT_LOAD(&job->dphi), S0 = AT_LOAD(&job->S0), S1 = AT_LOAD(&job->S1);
+  const int iters = __hip_atomic_load(&job->iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  dev_rollout_multi(c, lds + L.u, lds + L.o_du, alpha, D.par.tau, 1, lds + L.e_xs, xsz, D.ls_spec1, lds + L.e_xs2);
+  dev_evaluate_point(c, lds + L.u, alpha, lds + L.o_du, lds + L.e_xs);
+  bool pruned = false;
+  if (j + 1 < iters) pruned = dev_trial_pruned(c, alpha, mu, phi, dphi, S0, S1);
+  double phit = 0.0;
+  if (!pruned) phit = dev_trial_merit(c, alpha, S0 + alpha * S1, mu);
+  __syncthreads();
+  if (TID == 0) {
+    job->phi_out[j] = phit;
+    if (pruned) __hip_atomic_fetch_or(&job->pruned, 1ull << j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    __hip_atomic_fetch_or(&job->ready, 1ull << j, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&c.coop->helped, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+}
+// A workgroup that found the ticket queue empty: help the line searches of the workgroups still solving until every scenario of
+// the launch is done.
+__device__ __noinline__ void dev_coop_help(Ctx& c) {
+  const DgProb& D = dg_prob;
+  const DgLds& L = D.L;
+  lptr lds = LP(0);
+  DgCoop* co = c.coop;
+  const int njobs = 2 * (int)gridDim.x;
+  const int NONE = 0x7fffffff;
+  if (TID == 0) __hip_atomic_fetch_add(&co->idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int start = (2 * (int)blockIdx.x + 2) % njobs;
+  unsigned long long spins = 0;
+  while (true) {
+    {
+      // one word to poll while nothing is on offer (hundreds of workgroups may be idle: they must not hammer the memory system)
+      const unsigned long long w = dev_bcast_u64(TID == 0 ? ((unsigned long long)(AT_LOAD(&co->finished) >= c.coop_total) << 32) | (unsigned long long)AT_LOAD(&co->open) : 0ull);
+      if (w >> 32) break;
+      if ((w & 0xffffffffull) == 0ull) {
+        for (int t = 0; t < 8; t++) __builtin_amdgcn_s_sleep(127);
+        if (++spins > (1ull << 24)) break;
+        continue;
+      }
+    }
+    // every thread looks at some job slots: open, with a trial nobody has taken?  Helpers take [lo, iters) upwards, then
+    // lo-1 .. 1 downwards (trial 0 is always the owner's).  The nearest such slot after `start` wins.
+    double key = 1e300; int slot = NONE;
+    for (int sl = TID; sl < njobs; sl += NT) {
+      DgCoopJob* jb = &co->jobs[sl];
+      const unsigned int sq = __hip_atomic_load(&jb->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      if (!(sq & 1u)) continue;
+      const int lo = __hip_atomic_load(&jb->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), iters = __hip_atomic_load(&jb->iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long cl = AT_LOAD(&jb->claimed);
+      const unsigned long long all = iters >= 64 ? ~0ull : ((1ull << iters) - 1ull);
+      if ((cl & all) == all || lo < 1 || iters > DG_COOP_PHI) continue;
+      if ((cl >> lo) == (all >> lo)) continue;            // nothing left in [lo, iters): the trials below lo are the owner's
+      const double k2 = (double)((sl - start + njobs) % njobs);
+      if (k2 < key) { key = k2; slot = sl; }
+    }
+    double kb; int sb;
+    block_argmin(key, slot, lds + L.red, kb, sb);
+    unsigned long long pick = ~0ull;        // (slot << 8) | trial, ~0: nothing
+    if (sb != NONE && TID == 0) {
+      DgCoopJob* jb = &co->jobs[sb];
+      const unsigned int sq = __hip_atomic_load(&jb->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      if (sq & 1u) {
+        __hip_atomic_fetch_add(&jb->active, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = __hip_atomic_load(&jb->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == sq;     // still the job we looked at: its fields are stable while `active` is held
+        int cand = -1;
+        if (ok) {
+          const int lo = __hip_atomic_load(&jb->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), iters = __hip_atomic_load(&jb->iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int tries = 0; tries < 64 && cand < 0; tries++) {
+            const unsigned long long cl = AT_LOAD(&jb->claimed);
+            int j2 = -1;
+            for (int j = lo; j < iters; j++) if (!((cl >> j) & 1ull)) { j2 = j; break; }
+            if (j2 < 0) break;
+            if (!((__hip_atomic_fetch_or(&jb->claimed, 1ull << j2, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) >> j2) & 1ull)) cand = j2;
+          }
+        }
+        if (cand >= 0) pick = ((unsigned long long)sb << 8) | (unsigned long long)cand;
+        else __hip_atomic_fetch_sub(&jb->active, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    pick = dev_bcast_u64(pick);
+    if (pick == ~0ull) { __builtin_amdgcn_s_sleep(127); if (++spins > (1ull << 24)) break; continue; }
+    DgCoopJob* job = &co->jobs[pick >> 8];
+    const int j = (int)(pick & 255ull);
+    start = (int)(pick >> 8);
+    // base point of the job into this workgroup's LDS (its owner does not touch the payload while `active` is held)
+    __threadfence();
+    {
+      const double* pl = (const double*)__hip_atomic_load((unsigned long long*)&job->payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = TID; i < D.n; i += NT) { lds[L.u + i] = pl[i]; lds[L.o_du + i] = pl[D.n + i]; }
+      for (int r = TID; r < D.nc; r += NT) { lds[L.l + r] = pl[2 * D.n + r]; lds[L.o_lhat + r] = pl[2 * D.n + D.nc + r]; }
+      if (TID == 0) lds[L.scal + DG_XVALID] = 0.0;
+      c.x0 = (cgptr)(const double*)__hip_atomic_load((unsigned long long*)&job->x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    dev_coop_trial(c, job, j);
+    if (TID == 0) __hip_atomic_fetch_sub(&job->active, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (TID == 0) __hip_atomic_fetch_sub(&co->idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+}
+
 // _line_search_3 (DGSQP.py:1057-1081) from the base (u, du, l, lhat) held in LDS.  On return u and l hold
 // the LAST trial point; returns its merit.
 __device__ inline double dev_line_search(const Ctx& c, double mu, double phi, double dphi, double S0, double S1) {
@@ -1080,13 +1221,90 @@ __device__ inline double dev_line_search(const Ctx& c, double mu, double phi, do
   lptr lds = LP(0);
   double alpha = 1.0, phit = 0.0;
   const int K = D.ls_spec, xsz = ((D.N + 1) * D.nq + 1) & ~1;
-  for (int i = 0; i < D.par.line_search_iters; i++) {
+  const int iters = D.par.line_search_iters;
+  // ---- cooperative mode: once `start` trials have been rejected the remaining ones are offered to idle workgroups, if there are
+  // any (never while an event trace is recorded: it lists every trial).  Short searches -- the common case -- stay private.
+  DgCoopJob* job = nullptr;
+  const bool coop_ok = c.coop && !c.trace && K > 1 && iters > K && iters <= DG_COOP_PHI && D.ngd >= D.nc;
+  const int C = 4;                       // the owner claims its own next trials in chunks of C, the helpers work upwards from `lo`
+  int lo = iters;
+  bool verify = false;
+  unsigned long long mine = ~0ull;      // trials this workgroup evaluates itself (bit mask); without a job: all of them
+  int rolled = -1;                       // block of K trials whose trajectories are in the speculation slots
+  for (int i = 0; i < iters; i++) {
+    if (coop_ok && !job && i > 0) {
+      if (i == c.coop_start && i + C < iters && dev_bcast_u64(TID == 0 ? (unsigned long long)AT_LOAD(&c.coop->idle) : 0ull) > 0ull) {
+        const int flip = (int)lds[L.scal + DG_COOP_FLIP];
+        DgCoopJob* jb = &c.coop->jobs[2 * (int)blockIdx.x + flip];
+        // the slot was closed two line searches ago; a helper may still be finishing a trial of that job (rare): then go alone
+        if (dev_bcast_u64(TID == 0 ? (unsigned long long)__hip_atomic_load(&jb->active, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : 0ull) == 0ull) {
+          job = jb;
+          lo = i + C;
+          verify = c.coop_verify != 0;
+          double* pl = c.coop_payload + (size_t)flip * (2 * D.n + 2 * D.nc);
+          for (int t = TID; t < D.n; t += NT) { pl[t] = lds[L.u + t]; pl[D.n + t] = lds[L.o_du + t]; }
+          for (int r = TID; r < D.nc; r += NT) { pl[2 * D.n + r] = lds[L.l + r]; pl[2 * D.n + D.nc + r] = lds[L.o_lhat + r]; }
+          __threadfence();
+          __syncthreads();
+          if (TID == 0) {
+            lds[L.scal + DG_COOP_FLIP] = (double)(1 - flip);
+            job->claimed = (1ull << lo) - 1ull; job->ready = 0ull; job->pruned = 0ull;        // trials below lo are the owner's
+            job->lo = lo; job->iters = iters;
+            job->mu = mu; job->phi = phi; job->dphi = dphi; job->S0 = S0; job->S1 = S1;
+            job->x0 = (const double*)c.x0; job->payload = pl;
+            __threadfence();
+            __hip_atomic_store(&job->seq, job->seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);     // even -> odd: open
+            __hip_atomic_fetch_add(&c.coop->open, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          __syncthreads();
+        }
+      }
+    }
+    bool have_h = false, h_pruned = false;     // a helper's value for this trial
+    double h_phi = 0.0;
+    if (job && i >= lo) {
+      // claim the next chunk of trials the helpers have not taken yet; the others arrive through the job slot
+      if ((i - lo) % C == 0) {
+        unsigned long long want = 0ull;
+        for (int j = i; j < i + C && j < iters; j++) want |= 1ull << j;
+        const unsigned long long prev = dev_bcast_u64(TID == 0 ? __hip_atomic_fetch_or(&job->claimed, want, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) : 0ull);
+        mine = (mine & ~want) | (want & ~prev);
+      }
+      if (!((mine >> i) & 1ull)) {       // a helper has this trial: wait for its value
+        unsigned long long rdy = 0ull, spins = 0ull;
+        while (true) {
+          rdy = dev_bcast_u64(TID == 0 ? __hip_atomic_load(&job->ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : 0ull);
+          if (((rdy >> i) & 1ull) || ++spins > (1ull << 17)) break;
+          __builtin_amdgcn_s_sleep(32);
+        }
+        if ((rdy >> i) & 1ull) {
+          __threadfence();
+          h_pruned = (dev_bcast_u64(TID == 0 ? AT_LOAD(&job->pruned) : 0ull) >> i) & 1ull;
+          h_phi = __longlong_as_double((long long)dev_bcast_u64(TID == 0 ? (unsigned long long)__double_as_longlong(AT_LOAD(&job->phi_out[i])) : 0ull));
+          have_h = true;
+          if (TID == 0) __hip_atomic_fetch_add(&c.coop->used, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (!verify) {
+            if (h_pruned) { alpha *= D.par.tau; continue; }
+            phit = h_phi;
+            if (phit <= phi + D.par.beta * alpha * dphi) break;
+            if (i + 1 < iters) alpha *= D.par.tau;
+            continue;
+          }
+        } else {
+          if (TID == 0) __hip_atomic_fetch_add(&c.coop->timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          mine |= 1ull << i;              // gave up waiting (diagnostic counter): evaluate it here -- same value
+        }
+      }
+    }
     if (K > 1) {
-      // trial step sizes are known in advance: roll the next K of them out concurrently, then test them in order
-      if (i % K == 0) {
+      // trial step sizes are known in advance: roll the K of a block out concurrently (one instruction stream), test them in order
+      if (rolled != i / K) {
         PROF_BEGIN(pt_);
-        const int left = D.par.line_search_iters - i;
-        dev_rollout_multi(c, lds + L.u, lds + L.o_du, alpha, D.par.tau, left < K ? left : K, lds + L.e_xs, xsz, D.ls_spec1, lds + L.e_xs2);
+        const int b0 = (i / K) * K, left = iters - b0;
+        double ab = 1.0;
+        for (int t = 0; t < b0; t++) ab *= D.par.tau;       // alpha of trial b0: the same products as the running alpha *= tau
+        dev_rollout_multi(c, lds + L.u, lds + L.o_du, ab, D.par.tau, left < K ? left : K, lds + L.e_xs, xsz, D.ls_spec1, lds + L.e_xs2);
+        rolled = i / K;
         PROF_END(PH_ROLLOUT, pt_);
       }
       const int jt = i % K;
@@ -1096,26 +1314,24 @@ __device__ inline double dev_line_search(const Ctx& c, double mu, double phi, do
     // derivatives.  When the other two alone exceed the Armijo bound the trial is rejected from the constraint values (the
     // decision cannot differ; a relative margin covers rounding).  Never for the last allowed trial (its merit is returned)
     // and not while an event trace is recorded (the trace lists every trial's merit).
-    if (!c.trace && i + 1 < D.par.line_search_iters) {
-      double lg = 0, sg = 0;
-      for (int r = TID; r < D.nc; r += NT) {
-        const double gr = lds[L.g + r];
-        lg += (lds[L.l + r] + alpha * (lds[L.o_lhat + r] - lds[L.l + r])) * gr;
-        sg += gr;
+    if (!c.trace && i + 1 < iters) {
+      if (dev_trial_pruned(c, alpha, mu, phi, dphi, S0, S1)) {
+        if (have_h && !h_pruned && TID == 0) __hip_atomic_fetch_add(&c.coop->mismatches, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        alpha *= D.par.tau; continue;
       }
-      lg = block_sum(lg, lds + L.red); sg = block_sum(sg, lds + L.red);
-      double lb = 0.5 * lg * lg;
-      if (D.par.merit_function == DGSQP_MERIT_STAT_L1) lb += mu * (sg - (S0 + alpha * S1));
-      const double bound = phi + D.par.beta * alpha * dphi;
-      PROF_COUNT(PH_C_TRIALS, lb > bound + 1e-9 * (fabs(bound) + fabs(lb)) ? 1 : 0);
-      if (lb > bound + 1e-9 * (fabs(bound) + fabs(lb))) { alpha *= D.par.tau; continue; }
     }
     phit = dev_trial_merit(c, alpha, S0 + alpha * S1, mu);
+    if (have_h && (h_pruned || __double_as_longlong(h_phi) != __double_as_longlong(phit)) && TID == 0)
+      __hip_atomic_fetch_add(&c.coop->mismatches, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     dev_tr(c, 30, alpha); dev_tr(c, 31, phit);
     if (phit <= phi + D.par.beta * alpha * dphi) break;
-    if (i + 1 < D.par.line_search_iters) alpha *= D.par.tau;
+    if (i + 1 < iters) alpha *= D.par.tau;
   }
   __syncthreads();
+  if (job && TID == 0) {
+    __hip_atomic_store(&job->seq, job->seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);     // odd -> even: closed
+    __hip_atomic_fetch_sub(&c.coop->open, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
   for (int i = TID; i < D.n; i += NT) lds[L.u + i] = step_u(lds[L.u + i], alpha, lds[L.o_du + i]);
   for (int r = TID; r < D.nc; r += NT) lds[L.l + r] += alpha * (lds[L.o_lhat + r] - lds[L.l + r]);
   __syncthreads();

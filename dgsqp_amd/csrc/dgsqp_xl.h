@@ -914,6 +914,60 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
     if (st < 0) st = 2;
     if (st != 0) { ret = st; break; }
   }
+  // ---- polish: the KKT point of the final active set W.  The dual method reaches the optimal active set, but its iterate is an
+  // accumulation that starts at x = -M^-1 q -- of size 1e10 |q| along the directions _nearestPD floored at 1e-10 -- and cancels
+  // back to O(1): on the literal reg = 0 projection the point it ends on is off by up to 0.5 |x| (tools/reg0_qp_study.py), while the
+  // minimiser itself is well determined (the active rows pin those directions; the KKT matrix has condition ~1e7).  The reference
+  // returns OSQP's POLISHED point, the solution of the KKT system of the active set (DGSQP.py:186, osqp polish); the oracle solves
+  // that system by dense LU.  Here: two steps of iterative refinement with fp64 residuals, the factorisation at hand (J^T M J = I to
+  // ~1e-4, J^T N = [R; 0] to ~1e-10) as the approximate inverse -- each step gains four or more digits:
+  //     r1 = -(q + M x + A_W^T u),  r2 = -(g_W + A_W x);   R^T y1 = -r2,  y2 = J2^T r1;   dx = J [y1; y2],  du = R^-1 (y1 - J1^T r1).
+  // The polished point is kept when it is primal and dual feasible to 1e-9 (else the iterate stands: OSQP's "polish unsuccessful").
+  if (ret == 0 && iq > 0) {
+    PROF_BEGIN(pxp);
+    lptr xb = tv, ub = acc, r1 = np, rhs2 = zv, y1 = rv;
+    __syncthreads();
+    for (int i = TID; i < n; i += NT) xb[i] = x[i];
+    for (int k = TID; k < iq; k += NT) ub[k] = uu[k];
+    for (int pass = 0; pass < 2; pass++) {
+      __syncthreads();
+      for (int k = TID; k < iq; k += NT) lhat[q.alist[k]] = uu[k];        // (lhat is zero elsewhere)
+      __syncthreads();
+      gt_mul(c, lhat, r1);                                                  // A_W^T u
+      xl_jt_mul<cgptr>(Mx, n, n, S, 0, n, x, dv, part);                     // M x (M symmetric)
+      if (q.gdG) qp_dense_dots<cgptr>(D, q.gdG, x, q.dpart, q.ddx); else qp_dense_dots<clptr>(D, q.gd, x, q.dpart, q.ddx);
+      for (int i = TID; i < n; i += NT) r1[i] = -(lds[L.q + i] + dv[i] + r1[i]);
+      for (int k = TID; k < iq; k += NT) { const int r = q.alist[k]; rhs2[k] = q.g[r] + qpw_row_dot(D, ld_row(r), x, q.ddx); }      // = -r2
+      __syncthreads();
+      xl_jt_mul<MP>(J, js, n, S, 0, n, r1, dv, part);                       // [J1^T r1; J2^T r1]
+      if (TID < 64) xl_wave_fwdsub(R, iq, rhs2, y1);
+      __syncthreads();
+      for (int k = TID; k < iq; k += NT) { rhs2[k] = y1[k] - dv[k]; dv[k] = y1[k]; }
+      __syncthreads();
+      xl_j_mul<MP>(J, js, n, S, 0, n, dv, r1, part);                        // dx
+      if (TID < 64) xl_wave_backsub(R, iq, rhs2, y1);                       // du
+      __syncthreads();
+      for (int i = TID; i < n; i += NT) x[i] += r1[i];
+      for (int k = TID; k < iq; k += NT) uu[k] += y1[k];
+    }
+    __syncthreads();
+    double lmin = 0.0, lmax = 0.0;
+    for (int k = TID; k < iq; k += NT) { lmin = fmin(lmin, uu[k]); lmax = fmax(lmax, fabs(uu[k])); }
+    lmin = -block_max(-lmin, red); lmax = block_max(lmax, red);
+    bool keep = lmin >= -1e-9 * (1.0 + lmax);
+    for (int i = TID; i < n; i += NT) keep = keep && (x[i] == x[i]);
+    keep = !__syncthreads_or(!keep) && qp_scan(q, 1e-9) == NONE;
+    if (!keep) {
+      for (int i = TID; i < n; i += NT) x[i] = xb[i];
+      for (int k = TID; k < iq; k += NT) uu[k] = ub[k];
+    } else {
+      for (int k = TID; k < iq; k += NT) uu[k] = fmax(uu[k], 0.0);
+    }
+    PROF_COUNT(PH_C_MWARM, keep ? 1 : 0);
+    __syncthreads();
+    for (int k = TID; k < iq; k += NT) lhat[q.alist[k]] = 0.0;
+    PROF_END(PH_Q_REFINE, pxp);
+  }
   if (ret == 0) {
     __syncthreads();
     for (int k = TID; k < iq; k += NT) { lhat[q.alist[k]] = uu[k]; q.prev[k] = q.alist[k]; }

@@ -459,6 +459,19 @@ class DGSQP(AbstractSolver):
             raise RuntimeError(f'event log truncated: {int(raw[:, 0].max())} events, capacity {cap} (set_trace with a larger value)')
         return [raw[b, 1:1 + 2 * int(raw[b, 0])].reshape(-1, 2) for b in range(B)]
 
+    def set_cooperative(self, mode: int):
+        """Cooperative line search (include/dgsqp.h: dgsqp_set_cooperative): 0 never, 1 synchronous calls only (default), 2 every
+        launch.  Results are bit-identical in every mode; only the time a launch spends behind its slowest scenario changes."""
+        if self._lib.dgsqp_set_cooperative(self._h, int(mode)) != 0:
+            raise ValueError(f'bad cooperative mode {mode}')
+
+    def coop_stats(self) -> dict:
+        """Counters of the last cooperative launch: trials evaluated by helper workgroups, owner waits that gave up (must be 0)."""
+        out = (C.c_uint64 * 6)()
+        if self._lib.dgsqp_coop_stats(self._h, out) != 0:
+            raise RuntimeError(self._lib.dgsqp_last_error(self._h).decode())
+        return dict(helped=int(out[0]), timeouts=int(out[1]), finished=int(out[2]), idle=int(out[3]), used=int(out[4]), mismatches=int(out[5]))
+
     def set_iterate_log(self, records_per_scenario: int):
         """Keep (u, l) after every SQP iteration of subsequent solves (what ``solve()`` reports in ``iter_data``); 0 disables."""
         self._itlog_cap = int(records_per_scenario)

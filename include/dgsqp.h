@@ -295,6 +295,17 @@ int dgsqp_wait(dgsqp_handle_t h, dgsqp_timing_t* timing);
    used; every handle of the group is in flight until ITS dgsqp_wait / dgsqp_fetch_results (which wait for the group's kernel).
    Event and iterate logs are not available in grouped launches. */
 int dgsqp_launch_staged_group(const dgsqp_handle_t* hs, int count);
+/* Cooperative line search.  A launch ends with its slowest scenario (dozens of failing 50-trial line searches) while most
+   workgroups have long run out of scenarios.  In a cooperative launch those workgroups stay and evaluate line-search trial points
+   for the ones still solving (the very same device code: results are bit-identical to a non-cooperative launch); they keep their
+   compute units until the launch's last scenario is done.  mode 0: never; 1 (default): in the synchronous calls only
+   (dgsqp_solve_batch, dgsqp_solve_staged -- nothing else is waiting for the compute units); 2: every launch of this handle, also
+   the asynchronous ones -- for the LAST launch of a pipeline.  The leader's setting governs a grouped launch. */
+int dgsqp_set_cooperative(dgsqp_handle_t h, int mode);
+/* Diagnostic: counters of the handle's last cooperative launch -- out6 = {trials evaluated by helpers, owner waits that gave up
+   (must be 0), scenarios finished, helpers still registered (0 after the launch), helper values the owners consumed, helper values
+   whose bits differed from the owner's own evaluation (verify mode, environment DGSQP_COOP_VERIFY=1; must be 0)}. */
+int dgsqp_coop_stats(dgsqp_handle_t h, uint64_t* out6);
 /* 1 once the handle's last launch has handed out its last scenario (it only drains from then on, compute units are
    becoming free) or when nothing is in flight; 0 while scenarios are still queued.  Polled by bench.py to start the next
    independent batch on another handle at exactly that moment. */

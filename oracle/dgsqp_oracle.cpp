@@ -35,6 +35,7 @@
 #include <cstring>
 #include <limits>
 #include <thread>
+#include <atomic>
 #include <vector>
 
 #include "../include/dgsqp.h"
@@ -809,7 +810,8 @@ static void nearest_pd(int n, const double* Qin, double reg, vec& out, double fl
 // (osqp/src/polish.c: [H A'; A 0] regularised by delta = 1e-6 and iteratively refined).  Here: the same system, dense LU with
 // partial pivoting, two steps of iterative refinement.  The polished point replaces the iterate when it is primal and dual
 // feasible to the method's own tolerance; otherwise the iterate is kept (OSQP's "polish unsuccessful").  Returns 1 when taken.
-static bool qp_polish_enabled = false;     // (switched on together with the device-side polish)
+static bool qp_polish_enabled = true;
+static std::atomic<long> qp_polish_stats[4];   // QPs polished, rejected on a negative multiplier, rejected on a violated row, singular
 static int qp_kkt_polish(int n, int m, const double* H, const double* c, const double* G, const double* g, const int* A, int iq,
                          double* x, double* lamA) {
   const int s = n + iq;
@@ -825,7 +827,7 @@ static int qp_kkt_polish(int n, int m, const double* H, const double* c, const d
     int p = k; double best = std::fabs(K[(size_t)k * s + k]);
     for (int i = k + 1; i < s; i++) { const double v = std::fabs(K[(size_t)i * s + k]); if (v > best) { best = v; p = i; } }
     piv[k] = p;
-    if (!(best > 0.0)) return 0;
+    if (!(best > 0.0)) { qp_polish_stats[3]++; return 0; }
     if (p != k) for (int j = 0; j < s; j++) std::swap(K[(size_t)k * s + j], K[(size_t)p * s + j]);
     const double inv = 1.0 / K[(size_t)k * s + k];
     for (int i = k + 1; i < s; i++) {
@@ -850,18 +852,18 @@ static int qp_kkt_polish(int n, int m, const double* H, const double* c, const d
   // accept only a primal / dual feasible point (tolerances of the active-set loop, relative for the multipliers)
   double lmax = 0.0, lmin = 0.0;
   for (int k = 0; k < iq; k++) { lmax = std::max(lmax, std::fabs(sol[n + k])); lmin = std::min(lmin, sol[n + k]); }
-  if (getenv("ORACLE_QP_DEBUG")) fprintf(stderr, "polish: s=%d lmin %g lmax %g\n", s, lmin, lmax);
-  if (lmin < -1e-9 * (1.0 + lmax)) return 0;
+  if (lmin < -1e-9 * (1.0 + lmax)) { qp_polish_stats[1]++; return 0; }
   vector<char> act(m, 0);
   for (int k = 0; k < iq; k++) act[A[k]] = 1;
   for (int i = 0; i < m; i++) {
     if (act[i]) continue;
     double v = g[i];
     for (int j = 0; j < n; j++) v += G[(size_t)i * n + j] * sol[j];
-    if (v > 1e-9) { if (getenv("ORACLE_QP_DEBUG")) fprintf(stderr, "polish: row %d violated %g\n", i, v); return 0; }
+    if (v > 1e-9) { qp_polish_stats[2]++; return 0; }
   }
   for (int i = 0; i < n; i++) x[i] = sol[i];
   for (int k = 0; k < iq; k++) lamA[k] = std::max(sol[n + k], 0.0);
+  qp_polish_stats[0]++;
   return 1;
 }
 
@@ -1695,6 +1697,7 @@ int oracle_eigh(int n, const double* A, double* s, double* U) {
 }
 
 void oracle_set_qp_polish(int on) { qp_polish_enabled = on != 0; }
+void oracle_qp_polish_stats(long* out4, int reset) { for (int i = 0; i < 4; i++) { out4[i] = qp_polish_stats[i]; if (reset) qp_polish_stats[i] = 0; } }
 int oracle_qp(int n, int m, const double* H, const double* c, const double* G, const double* g, double* x, double* lam) {
   return qp_gi(n, m, H, c, G, g, x, lam);
 }
@@ -1737,8 +1740,9 @@ int oracle_solve_batch(const dgsqp_problem_t* P, const dgsqp_params_t* par, int6
                        double* u_out, double* l_out, double* x_out, int32_t* status, int32_t* iters, int32_t* qp_solves,
                        double* cond, double* cost, double* l_init, int literal, int nthreads) {
   Layout L = make_layout(*P);
-  auto work = [&](int64_t b0, int64_t stride) {
-    for (int64_t b = b0; b < B; b += stride) {
+  std::atomic<int64_t> next{0};       // dynamic hand-out: iteration counts vary 1..50+, a static partition would time the unluckiest thread
+  auto work = [&](int64_t, int64_t) {
+    for (int64_t b = next++; b < B; b = next++) {
       SolveOut o;
       solve_any(*P, *par, L, x0 + b * L.nq, u_ws + b * L.n, literal, o);
       if (u_out) std::copy(o.u.begin(), o.u.end(), u_out + b * L.n);

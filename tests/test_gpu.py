@@ -661,6 +661,40 @@ def test_xl_layout_three_agents_n150(oracle):
         assert rel(res['u'][b], ref['u'][b]) < 1e-6 and rel(res['l'][b], ref['l'][b]) < 1e-5
 
 
+def test_cooperative_line_search_is_bit_identical(games):
+    """Workgroups that run out of scenarios evaluate line-search trial points for the ones still solving (dgsqp_set_cooperative;
+    default in the synchronous calls).  Same device functions, same reductions: every output of a cooperative launch equals the
+    non-cooperative one bit for bit; helpers did evaluate trials; no owner ever gave up waiting for one."""
+    from dgsqp_amd.montecarlo import sample_scenarios
+    from dgsqp_amd.solver import DGSQP
+    import os
+    for name, B, force in (('dyn_curve_N25', 768, False), ('kb_chicane_N25', 768, True)):      # (euler games stay plain unless forced: helping does not pay there)
+        g = games[name][0]
+        s = DGSQP(*g.solver_args(), print_method=None)
+        x0, u_tm = sample_scenarios(g, B, seed=5)
+        s.set_cooperative(0)
+        ref = s.solve_batch(x0, u_tm)
+        s.set_cooperative(1)
+        os.environ['DGSQP_COOP_VERIFY'] = '1'            # owners re-evaluate every value a helper hands them and count differing bits
+        if force:
+            os.environ['DGSQP_COOP_FORCE'] = '1'
+        try:
+            chk = s.solve_batch(x0, u_tm)
+            st_chk = s.coop_stats()
+            os.environ.pop('DGSQP_COOP_VERIFY')
+            res = s.solve_batch(x0, u_tm)
+            st = s.coop_stats()
+        finally:
+            os.environ.pop('DGSQP_COOP_VERIFY', None)
+            os.environ.pop('DGSQP_COOP_FORCE', None)
+        print(name, 'kernel ms alone', ref['kernel_ms'], 'cooperative', res['kernel_ms'], st, 'verify run', st_chk)
+        for r in (res, chk):
+            for k in ('status', 'num_iters', 'qp_solves', 'u', 'l', 'x', 'cond', 'cost'):
+                assert np.array_equal(r[k], ref[k], equal_nan=True), (name, k)      # (NaN iterates of qp_fail / diverged runs are outputs too)
+        assert st['timeouts'] == 0 and st['idle'] == 0 and st['finished'] == B and st['helped'] > 0 and st['used'] > 0, st
+        assert st_chk['mismatches'] == 0 and st_chk['used'] > 0, st_chk
+
+
 def test_six_agent_merge_n300(oracle):
     """BASELINE configs[4]'s game at its own size: six cars on the highway merge (DGSQP_merge_monte_carlo.py:66-74, 253-261, 316-342
     generalised to six cars), N = 25: n = 300 decision variables, 36 / 63 / 39 rows per stage = 1,587 rows, 837 distinct dense

@@ -4,6 +4,7 @@ import os
 import pathlib
 import re
 import subprocess
+import time
 import sys
 
 import numpy as np
@@ -167,6 +168,82 @@ def test_shard_ranges_partition_the_batch():
             assert spans[0][0] == 0 and spans[-1][1] == B
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_interleaved_shards_partition_the_batch():
+    """interleaved assignment (rank, rank + world, ...) next to the contiguous blocks; both partition the batch,
+    sizes differ by at most one, and ``unshard`` restores the scenario order."""
+    from dgsqp_amd.sharding import padded_shard_size, shard_indices, unshard
+    for mode in ('contiguous', 'interleaved'):
+        for B in (0, 1, 7, 1024, 1025):
+            for w in (1, 2, 3, 8):
+                parts = [shard_indices(B, r, w, mode) for r in range(w)]
+                assert sorted(np.concatenate(parts).tolist()) == list(range(B))
+                assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1 and max(len(p) for p in parts) == (padded_shard_size(B, w) if B else 0)
+                vals = np.arange(B) * 10.0
+                assert np.array_equal(unshard([vals[p] for p in parts], B, w, mode), vals)
+    assert shard_indices(10, 1, 4, 'interleaved').tolist() == [1, 5, 9]
+    with pytest.raises(ValueError):
+        shard_indices(4, 0, 2, 'striped')
+
+
+_RANK_STUB = r'''
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+from dgsqp_amd.sharding import exchange_unique_id, rendezvous_path
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+assert os.environ['LOCAL_RANK'] == os.environ['RANK'] and os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0
+mode = sys.argv[2]
+# two rendezvous in a row (communicator re-built in the same launch): the second must not pick up the first one's file
+for seq in (0, 1):
+    uid = exchange_unique_id(rank, world, lambda: bytes([seq + 1]) * 128, seq=seq, timeout=30.0)
+    assert uid == bytes([seq + 1]) * 128, (rank, seq, uid[:4])
+if mode == 'fail' and rank == 1:
+    sys.exit(7)
+if mode == 'fail':
+    time.sleep(60)            # a rank stuck in a collective whose peer died: the launcher must take it down
+if rank == 0:
+    print('{"stub": "ok", "world": %d}' % world, flush=True)
+'''
+
+
+def test_spawn_ranks_environment_rendezvous_and_exit_codes(tmp_path):
+    """`bench.py --gpus N` without a launcher: every rank gets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, a rendezvous file of its own
+    (a stale file of an earlier launch under the same name is ignored: wrong launch tag), rank 0's line is relayed, the worst exit
+    code is returned, and a dead rank takes the stuck ones down.  Stub ranks: no GPU needed."""
+    import importlib.util
+    stub = tmp_path / 'rank_stub.py'
+    stub.write_text(_RANK_STUB)
+    driver = tmp_path / 'driver.py'
+    driver.write_text(f'''
+import sys
+sys.path.insert(0, {str(ROOT)!r})
+import bench
+bench.spawn_ranks(int(sys.argv[1]), [{str(ROOT)!r}, sys.argv[2]], script={str(stub)!r}, timeout=120.0)
+''')
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    ok = subprocess.run([sys.executable, str(driver), '3', 'ok'], env=env, capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0 and '"stub": "ok", "world": 3' in ok.stdout, ok.stdout + ok.stderr
+    assert not list(tmp_path.glob('dgsqp_rccl_*.id')), 'rendezvous file left behind'
+    t0 = time.time()
+    bad = subprocess.run([sys.executable, str(driver), '2', 'fail'], env=env, capture_output=True, text=True, timeout=300)
+    assert bad.returncode == 7 and time.time() - t0 < 45, (bad.returncode, bad.stderr[-500:])
+
+
+def test_rendezvous_ignores_a_stale_file(tmp_path):
+    """A file left by a crashed run under an explicit DGSQP_RENDEZVOUS carries another launch's tag: readers wait for THIS launch's."""
+    from dgsqp_amd import sharding
+    path = str(tmp_path / 'uid')
+    os.environ['DGSQP_LAUNCH_TAG'] = 'old-launch'
+    try:
+        assert sharding.exchange_unique_id(0, 2, lambda: b'a' * 128, path=path) == b'a' * 128
+        os.environ['DGSQP_LAUNCH_TAG'] = 'new-launch'
+        with pytest.raises(TimeoutError):
+            sharding.exchange_unique_id(1, 2, None, path=path, timeout=0.3)
+        assert sharding.exchange_unique_id(0, 2, lambda: b'b' * 128, path=path) == b'b' * 128
+        assert sharding.exchange_unique_id(1, 2, None, path=path, timeout=5.0) == b'b' * 128
+    finally:
+        os.environ.pop('DGSQP_LAUNCH_TAG', None)
 
 
 _GLOO_WORKER = r'''

@@ -18,7 +18,8 @@ GAMES = {'dyn_curve_N25': (lambda: mc.dynamic_racing_game(N=25, rk4_substeps=10)
          'kb_curve_N25': (lambda: mc.kinematic_racing_game('curve', N=25, reg=0.0), 1),
          'kb_chicane_N25': (lambda: mc.kinematic_racing_game('chicane', N=25), 1),
          'kb_chicane_N15': (lambda: mc.kinematic_racing_game('chicane', N=15), 1),
-         'kb_barc2_N15': (lambda: mc.barc_racing_game(N=15, M=2), 0)}
+         'kb_barc2_N15': (lambda: mc.barc_racing_game(N=15, M=2), 0),
+         'merge_N20': (lambda: mc.merge_game(N=20), 1)}
 CODE = {'conv_abs_tol': 0, 'conv_rel_tol': 1, 'max_it': 2, 'diverged': 3, 'exception': 4}
 
 
@@ -29,7 +30,13 @@ def one(args):
     x0, uws = mc.sample_scenarios(g, B_, seed=GAMES[name][1])
     u = np.concatenate([uws[:, :, 2 * a:2 * a + 2].reshape(B_, -1) for a in range(uws.shape[2] // 2)], axis=1)
     r = pyref.PyRef(P, par, qp='osqp')
-    s = r.solve(x0[b], u[b])
+    try:
+        with np.errstate(all='ignore'):
+            s = r.solve(x0[b], u[b])
+    except (ValueError, FloatingPointError, np.linalg.LinAlgError):
+        # a diverging run fed inf / NaN into the KKT solve: the reference's run would die with an exception here too
+        n_, nc_ = oracle.dims(P)['n'], oracle.dims(P)['nc']
+        s = dict(msg='exception', num_iters=0, qp_solves=len(r.qp_log), u=np.full(n_, np.nan), l=np.full(nc_, np.nan))
     log = np.array(r.qp_log).reshape(-1, 3)
     return (CODE[s['msg']], s['num_iters'], s['qp_solves'], s['u'], s['l'], int((log[:, 2] != 1).sum()), int((log[:, 0] != 1).sum()), float(min(0.0, s['l'].min())))
 

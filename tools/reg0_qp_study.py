@@ -10,6 +10,7 @@ Stage `cpu`  (anywhere): the oracle's answer on the same inputs (its own project
                dev_vs_orc   |du_dev - du_orc| / |du|                    what the parity tests see
                dev_err      |du_dev - x*(M_dev)| / |x*|                 error of the device's QP solver on ITS matrix
                orc_err      |du_orc - x*(M_orc)| / |x*|                 error of the oracle's QP solver on ITS matrix
+               raw_err      the same for the oracle's dual active-set iterate WITHOUT the KKT polish (what rounds 1-2 compared against)
                cross        |x*(M_dev) - x*(M_orc)| / |x*|              what the two fp64 projections alone are responsible for
 Usage: python tools/reg0_qp_study.py gpu out.npz [game] [B] [iters]   |   python tools/reg0_qp_study.py cpu out.npz [n_exact]
 """
@@ -110,14 +111,20 @@ def stage_cpu(path, n_exact=40):
         if flag != 0:
             continue
         nrm = max(np.linalg.norm(du_o), 1e-300)
-        rows.append(dict(k=k, o=o, M_orc=M_orc, du_o=du_o, lam_o=lam_o, dev_vs_orc=np.linalg.norm(d['du'][k] - du_o) / nrm,
+        oracle.lib().oracle_set_qp_polish(0)             # the dual active-set iterate as it stands, without the KKT polish (rounds 1-2)
+        du_raw = oracle.qp(M_orc, o['q'], o['G'], o['g'])[0]
+        oracle.lib().oracle_set_qp_polish(1)
+        rows.append(dict(k=k, o=o, M_orc=M_orc, du_o=du_o, lam_o=lam_o, du_raw=du_raw, dev_vs_orc=np.linalg.norm(d['du'][k] - du_o) / nrm,
                          dM=np.abs(d['Qpd'][k] - M_orc).max(), same_set=bool(np.array_equal(d['lhat'][k] > 0, lam_o > 0))))
     dv = np.array([r['dev_vs_orc'] for r in rows])
     print(f'{name}: {len(rows)} feasible QPs; |du_dev - du_orc|/|du|: median {np.median(dv):.2e}, 90 % {np.quantile(dv, 0.9):.2e}, max {dv.max():.2e}; '
           f'same active set on {np.mean([r["same_set"] for r in rows]):.3f}; max |M_dev - M_orc| {max(r["dM"] for r in rows):.2e}')
     order = np.argsort(-dv)
     pick = list(order[:n_exact // 2]) + list(order[len(order) // 2:len(order) // 2 + n_exact - n_exact // 2])     # the worst and a band around the median
-    print('   QP  scen iter | dev_vs_orc | dev_err    orc_err    cross      | lam_min(M) cond(M)  | sets: dev = orc?  exact(M_dev) = exact(M_orc)?')
+    raw = np.array([np.linalg.norm(r['du_raw'] - r['du_o']) / max(np.linalg.norm(r['du_o']), 1e-300) for r in rows])
+    print(f'   unpolished oracle iterate vs its polished point, |.|/|du|: median {np.median(raw):.2e}, 90 % {np.quantile(raw, 0.9):.2e}, max {raw.max():.2e} '
+          f'(share above 1e-5: {np.mean(raw > 1e-5):.3f})')
+    print('   QP  scen iter | dev_vs_orc | dev_err    orc_err    raw_err    cross      | lam_min(M) cond(M)  | sets: dev = orc?  exact(M_dev) = exact(M_orc)?')
     summ = []
     for idx in pick:
         r = rows[idx]
@@ -132,8 +139,9 @@ def stage_cpu(path, n_exact=40):
         xd, xo = ed[0], eo[0]
         nx = max(np.linalg.norm(xo), 1e-300)
         e_dev, e_orc, cross = np.linalg.norm(d['du'][k] - xd) / nx, np.linalg.norm(r['du_o'] - xo) / nx, np.linalg.norm(xd - xo) / nx
+        e_raw = np.linalg.norm(r['du_raw'] - xo) / nx
         summ.append((r['dev_vs_orc'], e_dev, e_orc, cross))
-        print(f'{k:5d} {d["scenario"][k]:5d} {d["iteration"][k]:4d} | {r["dev_vs_orc"]:.2e}   | {e_dev:.2e}   {e_orc:.2e}   {cross:.2e}   | {w[0]:.2e}   {w[-1] / w[0]:.1e} | '
+        print(f'{k:5d} {d["scenario"][k]:5d} {d["iteration"][k]:4d} | {r["dev_vs_orc"]:.2e}   | {e_dev:.2e}   {e_orc:.2e}   {e_raw:.2e}   {cross:.2e}   | {w[0]:.2e}   {w[-1] / w[0]:.1e} | '
               f'{r["same_set"]}  {set(ed[1]) == set(eo[1])}')
     if summ:
         a = np.array(summ)
