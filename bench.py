@@ -314,6 +314,29 @@ def main():
         fence()
         eh = float(comm.allreduce_max([time.perf_counter() - t0])[0])
         host = dict(value=B_total * args.host_steps / eh, ms_per_step=eh / args.host_steps * 1e3)
+        # ... and the same for a GROUP of batches handed over together: H2D of every batch, ONE cooperative launch over all of them, D2H of
+        # every output (what a Monte-Carlo driver with more than one batch in hand would call)
+        G = max(1, min(args.group, n_batches))
+        obs = [dict(u=np.empty((B, n)), l=np.empty((B, nc)), x=np.empty((B, nx)), st=np.empty(B, np.int32), it=np.empty(B, np.int32),
+                    qp=np.empty(B, np.int32), cond=np.empty((B, 3)), cost=np.empty((B, int(d.M)))) for _ in range(G)]
+        fence()
+        t0 = time.perf_counter()
+        for k in range(G):
+            x0, u_am = batches[k]
+            assert lib.dgsqp_stage_inputs(handles[k], B, _ffi.dptr(x0), _ffi.dptr(u_am)) == 0, lib.dgsqp_last_error(handles[k])
+        lib.dgsqp_set_cooperative(handles[0], 2 if args.coop == 'auto' else 0)
+        arr = (C.c_void_p * G)(*handles[:G])
+        assert lib.dgsqp_launch_staged_group(arr, G) == 0, lib.dgsqp_last_error(handles[0])
+        lib.dgsqp_set_cooperative(handles[0], 1 if args.coop == 'auto' else 0)
+        for k in range(G):
+            o = obs[k]
+            rc = lib.dgsqp_fetch_results(handles[k], _ffi.dptr(o['u']), _ffi.dptr(o['l']), _ffi.dptr(o['x']), _ffi.iptr(o['st']), _ffi.iptr(o['it']),
+                                         _ffi.iptr(o['qp']), _ffi.dptr(o['cond']), _ffi.dptr(o['cost']))
+            assert rc == 0, lib.dgsqp_last_error(handles[k])
+        comm.gather_stats(B_pad)
+        fence()
+        eg = float(comm.allreduce_max([time.perf_counter() - t0])[0])
+        host['grouped'] = dict(value=B_total * G / eg, batches=G, ms=eg * 1e3)
 
     if rank == 0:
         # HBM traffic comes from PMC counters collected in separate rocprofv3 --pmc passes (gpurun refuses mixed runs) and summarised
@@ -321,9 +344,9 @@ def main():
         traffic, flop_per_solve, traffic_src = None, None, None
         try:
             import glob
-            for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_*.json'))):
+            for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r03_pmc_*.json'))):      # this round's kernels only
                 pm = json.load(open(f))
-                if pm.get('workload') == args.workload and pm.get('batch_per_gpu') == B and pm.get('game_def', 'round1') == 'round2':
+                if pm.get('workload') == args.workload and pm.get('batch_per_gpu') == B:
                     if 'traffic_bytes_per_launch' in pm:
                         traffic, traffic_src = pm['traffic_bytes_per_launch'], os.path.relpath(f, ROOT)
                     flop_per_solve = pm.get('fp64_flop_per_solve_upper_bound', flop_per_solve)
@@ -348,6 +371,8 @@ def main():
             'elapsed_s_per_rank': elapsed_per_rank,        # each rank's own time for its K steps: load imbalance between the shards shows here
             'value_single_launch': single['value'] if single else None,
             'value_host_inclusive': host['value'] if host else None,
+            'value_host_inclusive_grouped': host['grouped']['value'] if host else None,      # H2D + one launch + D2H of `batches_per_launch` batches
+            'host_inclusive_grouped_batches': host['grouped']['batches'] if host else None,
             'mean_iters': summ['mean_iters_converged'], 'mean_iters_all': summ['mean_iters_all'],
             'mean_qp_solves': summ['mean_qp_solves_all'], 'converged_fraction': summ['converged'],
             'status_fractions': {k: summ[k] for k in ('conv_abs_tol', 'conv_rel_tol', 'max_it', 'diverged', 'qp_fail')},

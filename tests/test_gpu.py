@@ -97,17 +97,15 @@ def test_solve_matches_golden_fixtures(solvers, name):
     gold = np.load(GOLD / f'{name}.npz')
     s = solvers[name]
     res = s.solve_batch(gold['x0'], gold['u_ws'])
-    # reg = 0 games run the literal 1e-10 floor: a QP of condition 1e12 that neither side solves beyond ~1e-4, and without the
-    # active-bound snap the sign of the +-1e-15 residual on active input bounds (which switches mu) is implementation-defined:
-    # agreement there is statistical; the opt-in settings are held to the strict bar in
-    # test_reg0_games_track_the_oracle.
-    reg0 = name in ('kb_barc2_N15', 'merge_N8')
-    same = assert_control_flow_parity(res, gold, gold['stable'], name, min_stable_same=0.9 if reg0 else 0.95, max_conv_gap=0.1 if reg0 else 0.05)
+    # (reg = 0 games -- kb_barc2_N15, merge_N8 -- run the literal 1e-10 floor and are held to the same bar since both sides polish
+    # their QPs, round 3)
+    same = assert_control_flow_parity(res, gold, gold['stable'], name, min_stable_same=0.95, max_conv_gap=0.05)
+    assert same.mean() >= 0.85            # an absolute floor next to the stable-subset one
     for b in np.where(same & (gold['status'] <= 1))[0]:
-        assert rel(res['u'][b], gold['u'][b]) < (1e-2 if reg0 else 1e-5), b
+        assert rel(res['u'][b], gold['u'][b]) < 1e-5, b
         if gold['status'][b] == 0:
-            assert rel(res['l'][b], gold['l'][b]) < (1e-2 if reg0 else 1e-5), b
-            assert rel(res['cost'][b], gold['cost'][b]) < (1e-3 if reg0 else 1e-8), b
+            assert rel(res['l'][b], gold['l'][b]) < 1e-5, b
+            assert rel(res['cost'][b], gold['cost'][b]) < 1e-8, b
 
 
 def test_baseline_config1_dyn_curve_N25_parity(solvers):
@@ -124,28 +122,30 @@ def test_baseline_config1_dyn_curve_N25_parity(solvers):
         assert rel(res['l'][b], gold['l'][b]) < 1e-5, b
 
 
-@pytest.mark.parametrize('name', ['dyn_curve_N25', 'kb_curve_N25', 'kb_chicane_N25'])
+@pytest.mark.parametrize('name', ['dyn_curve_N25', 'kb_curve_N25', 'kb_chicane_N25', 'kb_barc2_N15', 'merge_N20'])
 def test_convergence_statistics_against_the_restated_osqp_loop(name):
     """north_star: "matching reference convergence rate".  The yardstick is the line-by-line numpy restatement of the
     reference loop with the restated OSQP as its QP (oracle/pyref.py + oracle/osqp_restate.py; scipy lsqr at its default
-    tolerance, numpy eigh), run in the build container on the first scenarios of the sampler and committed.  OSQP's polished
-    points carry 1e-3..1e-6 errors (and occasionally negative multipliers), so paths differ; the Monte-Carlo statistics the
-    reference reports (process_data_curve.py:99-110) must agree: converged fraction within 15 points (two standard errors of
-    the difference of two proportions on the 48 / 32 committed scenarios), same converged flag on >= 85 % of the scenarios, mean
-    iterations of the commonly converged within 2."""
+    tolerance, numpy eigh), run in the build container on the first 256 scenarios of each sampler and committed
+    (tools/ref_stats.py, profiles/r03_pyref_osqp_vs_oracle.txt).  OSQP stops ADMM at 1e-3 and its polish is accepted on residuals
+    alone (negative multipliers included), so individual paths differ; the Monte-Carlo statistics the reference reports
+    (process_data_curve.py:99-110) must agree: converged fraction within 5 points, same converged flag on >= 90 % of the scenarios,
+    mean iterations of the commonly converged within 0.5."""
     from dgsqp_amd import montecarlo as mc
     from dgsqp_amd.solver import DGSQP
     ref = np.load(GOLD / f'pyref_osqp_{name}.npz')
     g = {'dyn_curve_N25': lambda: mc.dynamic_racing_game(N=25, rk4_substeps=10), 'kb_curve_N25': lambda: mc.kinematic_racing_game('curve', N=25, reg=0.0),
-         'kb_chicane_N25': lambda: mc.kinematic_racing_game('chicane', N=25)}[name]()
+         'kb_chicane_N25': lambda: mc.kinematic_racing_game('chicane', N=25), 'kb_barc2_N15': lambda: mc.barc_racing_game(N=15, M=2),
+         'merge_N20': lambda: mc.merge_game(N=20)}[name]()
+    assert len(ref['status']) >= 256
     res = DGSQP(*g.solver_args(), print_method=None).solve_batch(ref['x0'], ref['u_ws'])      # all defaults: literal formulas, scipy's LSQR tolerance
     cd, cr = res['status'] <= 1, ref['status'] <= 1
     both = cd & cr
     print(name, 'converged device', cd.mean(), 'restated-OSQP loop', cr.mean(), 'same flag', np.mean(cd == cr),
           'mean iters (commonly converged)', res['num_iters'][both].mean(), ref['num_iters'][both].mean())
-    assert abs(cd.mean() - cr.mean()) <= 0.15
-    assert np.mean(cd == cr) >= 0.85
-    assert abs(res['num_iters'][both].mean() - ref['num_iters'][both].mean()) <= 2.0
+    assert abs(cd.mean() - cr.mean()) <= 0.05
+    assert np.mean(cd == cr) >= 0.90
+    assert abs(res['num_iters'][both].mean() - ref['num_iters'][both].mean()) <= 0.5
 
 
 def test_event_trace_parity(oracle, games, solvers):
@@ -530,9 +530,11 @@ def test_model_and_integrator_variants(oracle, kind, method, msub, over):
                                        ('barc2', dict(eig_floor=1e-6, snap_active_bounds=True)), ('kb_curve_reg0', dict(eig_floor=1e-6, snap_active_bounds=True))])
 def test_reg0_games_track_the_oracle(oracle, kind, opts):
     """reg = 0 (curve.py:161, comp.py:169): _nearestPD leaves the clamped eigenvalues at the floor.  Default = the literal 1e-10
-    (DGSQP.py:1293; condition ~1e12, classical J = L^-T active-set kernels on the device -- the oracle's own algorithm; neither
-    side solves that QP to better than ~1e-4); opt-in = floor 1e-6 with the active-bound snap (explicit-inverse kernels).  Either
-    way device and oracle take the same parameters and must agree on the scenarios the oracle itself reproduces."""
+    (DGSQP.py:1293; condition ~1e12..1e13, classical J = L^-T active-set kernels on the device); opt-in = floor 1e-6 with the
+    active-bound snap (explicit-inverse kernels).  Since round 3 both sides return the POLISHED point -- the KKT point of the final
+    active set, as OSQP's polish does for the reference: the dual method's own iterate is off by up to 0.5 |du| on these QPs, the
+    polished points are exact to ~1e-10 (profiles/r03_reg0_qp_study.txt, checked against 60-digit KKT solves).  Device and oracle
+    must agree on >= 95 % of the scenarios the oracle itself reproduces, converged fractions within 2 points, iterates to 1e-5."""
     from dgsqp_amd.montecarlo import barc_racing_game, kinematic_racing_game, sample_scenarios
     from dgsqp_amd.solver import DGSQP, build_problem, build_params
     g = barc_racing_game(N=15, M=2) if kind == 'barc2' else kinematic_racing_game('curve', N=20, reg=0.0)
@@ -552,15 +554,17 @@ def test_reg0_games_track_the_oracle(oracle, kind, opts):
         du, lam, flag = oracle.qp(Qpd, o['q'], o['G'], o['g'])
         obj = lambda z: 0.5 * z @ Qpd @ z + o['q'] @ z
         assert qp['flag'][b] == flag == 0 and (o['G'] @ qp['du'][b] + o['g']).max() < 1e-4
-        assert abs(obj(qp['du'][b]) - obj(du)) < (1e-3 if literal else 1e-6) * max(1.0, abs(obj(du)))
+        assert abs(obj(qp['du'][b]) - obj(du)) < 1e-6 * max(1.0, abs(obj(du)))
+        assert rel(qp['du'][b], du) < 1e-6, (b, rel(qp['du'][b], du))
     res = s.solve_batch(x0, u_tm)
     ref = oracle.solve_batch(P, par, x0, u, nthreads=8)
     same = assert_control_flow_parity(res, ref, stable_mask(oracle, P, par, x0, u, ref), f'{kind} {opts}',
-                                      min_stable_same=0.85 if literal else 0.95, max_conv_gap=0.1)
+                                      min_stable_same=0.95, max_conv_gap=0.02)
     ok = same & (ref['status'] <= 1)
     assert ok.sum() >= B // 3
-    for b in np.where(ok)[0]:
-        assert rel(res['u'][b], ref['u'][b]) < (1e-2 if literal else 1e-4), b
+    worst = max(rel(res['u'][b], ref['u'][b]) for b in np.where(ok)[0])
+    print(f'{kind} {opts}: largest relative difference of a converged iterate {worst:.2e}')
+    assert worst < 1e-5
 
 
 def test_classical_qp_storage_split_of_the_triangular_factor(monkeypatch):
@@ -612,9 +616,8 @@ def test_big_layout_and_merge_game(oracle):
                 assert rel(ev[key][b], o[key]) < 1e-11, (g.name, key, b)
         res = s.solve_batch(x0, u_tm)
         ref = oracle.solve_batch(P, par, x0, u, nthreads=8)
-        same = assert_control_flow_parity(res, ref, stable_mask(oracle, P, par, x0, u, ref, K=2), g.name,
-                                          min_stable_same=0.9 if g.params.reg == 0.0 else 0.95)     # (reg = 0: literal floor, no snap -- see the golden test)
-        tol = 1e-2 if g.params.reg == 0.0 else 1e-5         # (reg = 0: literal 1e-10 floor, see test_reg0_games_track_the_oracle)
+        same = assert_control_flow_parity(res, ref, stable_mask(oracle, P, par, x0, u, ref, K=2), g.name, min_stable_same=0.95)
+        tol = 1e-5
         for b in np.where(same & (ref['status'] <= 1))[0]:
             assert rel(res['u'][b], ref['u'][b]) < tol and rel(res['l'][b], ref['l'][b]) < 10 * tol, (g.name, b)
         if M >= 3:
@@ -727,16 +730,16 @@ def test_six_agent_merge_n300(oracle):
         assert qp['flag'][b] == flag == 0 and np.abs(qp['Qpd'][b] - Qpd).max() < 1e-10 * np.abs(o['Q']).max()
         assert np.array_equal(qp['lhat'][b] > 0, lam > 0), b
         # (reg = 0, literal floor: condition 1e12 -- the step agrees to the accuracy either side solves that QP to)
-        assert rel(qp['du'][b], du) < 1e-4, (b, rel(qp['du'][b], du))
+        assert rel(qp['du'][b], du) < 1e-6, (b, rel(qp['du'][b], du))
     res = s.solve_batch(x0, u_tm)
     ref = oracle.solve_batch(P, par, x0, u, nthreads=8)
-    same = assert_control_flow_parity(res, ref, stable_mask(oracle, P, par, x0, u, ref, K=1), g.name, min_stable_same=0.9)
+    same = assert_control_flow_parity(res, ref, stable_mask(oracle, P, par, x0, u, ref, K=1), g.name, min_stable_same=0.95)
     assert (res['status'] <= 1).all() and same.sum() >= B - 1
     for b in np.where(same & (ref['status'] <= 1))[0]:
-        assert rel(res['u'][b], ref['u'][b]) < 1e-2 and rel(res['x'][b], ref['x'][b]) < 1e-3, b
+        assert rel(res['u'][b], ref['u'][b]) < 1e-5 and rel(res['x'][b], ref['x'][b]) < 1e-6, b
 
 
-@pytest.mark.parametrize('N,B', [(15, 24), (25, 12)])
+@pytest.mark.parametrize('N,B', [(15, 24), (25, 48)])
 def test_three_agents_on_the_barc_circuit(oracle, N, B):
     """BASELINE configs[2]'s own game: 3 kinematic bicycles on the L_track_barc circuit (DGSQP_comp_monte_carlo.py game with a
     third car, 24 / 33 / 9 rows per stage, reg = 0), at the script's N = 15 (n = 90, LDS layout) and at BASELINE's N = 25
@@ -760,11 +763,15 @@ def test_three_agents_on_the_barc_circuit(oracle, N, B):
         for key in ('x', 'q', 'g', 'G', 'Q'):
             assert rel(ev[key][b], o[key]) < 1e-11, (key, b)
     res = s.solve_batch(x0, u_tm)
-    ref = oracle.solve_batch(P, par, x0, u, nthreads=8)
-    same = assert_control_flow_parity(res, ref, stable_mask(oracle, P, par, x0, u, ref, K=2), f'barc3 N={N}', min_stable_same=0.85, max_conv_gap=0.15,
-                                      min_stable_frac=0.25)
+    import os
+    ref = oracle.solve_batch(P, par, x0, u, nthreads=min(B, os.cpu_count() or 8))
+    stable = stable_mask(oracle, P, par, x0, u, ref, K=2)
+    same = assert_control_flow_parity(res, ref, stable, f'barc3 N={N}', min_stable_same=0.95, max_conv_gap=0.05, min_stable_frac=0.25)
+    assert stable.sum() >= 16            # (that many oracle-stable scenarios back the parity claim)
+    # (XL layout, reg = 0, n = 150: identical control flow over ~40 iterations of condition-1e12 QPs; measured 1.6e-4 on the one scenario
+    # that converges at N = 25)
     for b in np.where(same & (ref['status'] <= 1))[0]:
-        assert rel(res['u'][b], ref['u'][b]) < 1e-2, b
+        assert rel(res['u'][b], ref['u'][b]) < (1e-3 if N == 25 else 1e-5), b
 
 
 @pytest.mark.parametrize('kind', ['dyn', 'kb', 'kb_sum_obj'])
@@ -821,7 +828,7 @@ def test_dgsqp_v2_matches_oracle(oracle, kind):
     assert info['num_iters'] == int(res['num_iters'][0]) and np.array_equal(info['primal_sol'], res['u'][0])
 
 
-@pytest.mark.parametrize('model,N,B', [('kinematic', 12, 16), ('dynamic', 8, 8), ('kinematic', 50, 4)])
+@pytest.mark.parametrize('model,N,B', [('kinematic', 12, 16), ('dynamic', 8, 8), ('kinematic', 50, 40)])
 def test_f1_spline_track_game(oracle, model, N, B):
     """BASELINE configs[3]'s game: two cars on the F1 track, a cubic-spline centre line (CasadiBSplineTrack,
     casadi_bspline_track.py:56-71, :122-149) whose curvature has non-zero derivatives -- evaluated on the device in Taylor
@@ -848,9 +855,11 @@ def test_f1_spline_track_game(oracle, model, N, B):
     ref_u = np.concatenate([mc.pid_warm_start(m, x0[:, a * m.n_q:(a + 1) * m.n_q], N, 0.1, du=(10.0, 4.5))[1] for a, m in enumerate(models)], axis=2)
     assert np.abs(dev['u_ws'] - ref_u).max() < 1e-9
     res = s.solve_batch(x0, u_tm)
-    ref = oracle.solve_batch(P, par, x0, u, nthreads=8)
-    same = assert_control_flow_parity(res, ref, stable_mask(oracle, P, par, x0, u, ref, K=2), f'f1 {model} N={N}', min_stable_same=0.9,
-                                      max_conv_gap=0.15, min_stable_frac=0.4)
+    import os
+    ref = oracle.solve_batch(P, par, x0, u, nthreads=min(B, os.cpu_count() or 8))
+    stable = stable_mask(oracle, P, par, x0, u, ref, K=2)
+    same = assert_control_flow_parity(res, ref, stable, f'f1 {model} N={N}', min_stable_same=0.95, max_conv_gap=0.05, min_stable_frac=0.4)
+    assert N != 50 or stable.sum() >= 16            # (that many oracle-stable scenarios back the parity claim at the configuration's own horizon)
     for b in np.where(same & (ref['status'] <= 1))[0]:
         assert rel(res['u'][b], ref['u'][b]) < 1e-5, b
 
