@@ -393,8 +393,8 @@ def main():
             from oracle import oracle            # checker/baseline only: the CPU restatement, NOT CasADi+OSQP
             oracle.build()
             cores = os.cpu_count() or 1
-            # a THROUGHPUT, not the time of the slowest scenario: 8 scenarios per core by default, handed out dynamically; plus one core alone
-            ns = min(args.cpu_sample if args.cpu_sample != 64 else 8 * cores, B)
+            # a THROUGHPUT over at least as many scenarios as hardware threads, handed out dynamically (not the time of the slowest one); plus one core alone
+            ns = min(args.cpu_sample if args.cpu_sample != 64 else max(64, cores), B)       # default: one scenario per hardware thread (bounded: 15-30 s)
             x0, u_am = batches[0]
             t1 = time.perf_counter()
             oracle.solve_batch(solver._problem, solver._cparams, x0[:ns], u_am[:ns], nthreads=min(cores, ns))

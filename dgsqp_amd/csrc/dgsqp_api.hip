@@ -89,6 +89,7 @@ dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restric
 }
 
 #include "dgsqp_pid.h"
+#include "dgsqp_sampler.h"
 
 // Test hook: one _evaluate(hessian=True) (+ dual init) per scenario, results expanded to dense arrays.
 __global__ void __launch_bounds__(DG_BLOCK)
@@ -862,6 +863,65 @@ int dgsqp_pid_warm_start_batch(dgsqp_handle_t h, int64_t B, const double* q0, co
   HIPCHK(h, hipMemcpy(u_ws, du, sizeof(double) * B * D.n, hipMemcpyDeviceToHost));
   if (q_ws) HIPCHK(h, hipMemcpy(q_ws, dq, sizeof(double) * B * nx, hipMemcpyDeviceToHost));
   if (collide) HIPCHK(h, hipMemcpy(collide, dc, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+  return DGSQP_OK;
+}
+
+int dgsqp_sample_batch(dgsqp_handle_t h, int64_t B, const dgsqp_sampler_t* spec, const dgsqp_pid_t* pid, double* x0_out,
+                       double* u_ws_out, int64_t* candidates, int stage) {
+  if (!h || B < 0 || !spec || spec->kind < 0 || spec->kind > DGSQP_SAMPLER_MERGE) { if (h) h->err = "bad argument"; return DGSQP_E_ARG; }
+  const DgProb& D = h->hp;
+  const bool merge = spec->kind == DGSQP_SAMPLER_MERGE;
+  if (!merge && (!pid || pid->substeps < 1 || spec->n_key < 2 || spec->n_key > DGSQP_MAX_SEGS + 1)) { h->err = "bad sampler description"; return DGSQP_E_ARG; }
+  if (spec->kind == DGSQP_SAMPLER_FIRST_SEGMENT && D.M != 2) { h->err = "the first-segment sampler places two cars"; return DGSQP_E_ARG; }
+  for (int a = 0; a < D.M; a++)
+    if ((D.nqa[a] == 4) != merge) { h->err = "sampler and vehicle model do not fit (merge: unicycles; the others: Frenet-frame models)"; return DGSQP_E_ARG; }
+  if (candidates) *candidates = 0;
+  if (B == 0) return DGSQP_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  { int rc = wait_idle(h); if (rc) return rc; }
+  { int rc = ensure_batch(h, B); if (rc) return rc; }
+  { int rc = ensure_ws(h, (size_t)grid_for(h, B)); if (rc) return rc; }
+  const int64_t nround = std::max<int64_t>(256, std::min<int64_t>(2 * B, 1 << 16));        // candidates per round
+  const size_t nx = (size_t)(D.N + 1) * D.nq;
+  TmpBuf tb;
+  double* dq0 = tb.alloc<double>(nround * D.nq); double* du = tb.alloc<double>(nround * D.n); double* dq = tb.alloc<double>(nround * nx);
+  int32_t* dok = tb.alloc<int32_t>(nround); int32_t* dcol = tb.alloc<int32_t>(nround); int32_t* dpos = tb.alloc<int32_t>(nround); int32_t* dcnt = tb.alloc<int32_t>(1);
+  if (!dq0 || !du || !dq || !dok || !dcol || !dpos || !dcnt) { h->err = "hipMalloc failed"; return DGSQP_E_NOMEM; }
+  std::unique_lock<std::mutex> game_lock(g_reg_mutex);
+  { int rcu = upload_problem(h); if (rcu) return rcu; }
+  int64_t have = 0;
+  unsigned long long c0 = 0;
+  for (int round = 0; have < B; round++) {
+    if (round > 10000) { h->err = "sampler did not produce enough collision-free scenarios"; return DGSQP_E_ARG; }
+    hipLaunchKernelGGL(dg_sample_place_kernel, dim3((unsigned)((nround + 255) / 256)), dim3(256), 0, h->stream, nround, c0, *spec, dq0, dok);
+    HIPCHK(h, hipGetLastError());
+    if (merge) {
+      hipLaunchKernelGGL(dg_sample_zero_rollout_kernel, dim3((unsigned)((nround * D.M + 255) / 256)), dim3(256), 0, h->stream, nround, dq0, dq);
+    } else {
+      int grid = (int)((nround * D.M + DG_BLOCK - 1) / DG_BLOCK);
+      if (grid > 4 * h->num_cu) grid = 4 * h->num_cu;
+      hipLaunchKernelGGL(dg_pid_kernel, dim3(grid), dim3(DG_BLOCK), (size_t)D.L.scr * sizeof(double), h->stream, nround, dq0, *pid, du, dq);
+    }
+    HIPCHK(h, hipGetLastError());
+    hipLaunchKernelGGL(dg_collide_kernel, dim3((unsigned)((nround + 255) / 256)), dim3(256), 0, h->stream, nround, dq, dcol);
+    hipLaunchKernelGGL(dg_sample_scan_kernel, dim3(1), dim3(1024), 0, h->stream, nround, dok, dcol, dpos, dcnt);
+    hipLaunchKernelGGL(dg_sample_gather_kernel, dim3(1024), dim3(128), 0, h->stream, nround, have, B, dpos, dq0, merge ? (const double*)nullptr : du, h->d_x0, h->d_uws);
+    HIPCHK(h, hipGetLastError());
+    int32_t cnt = 0;
+    HIPCHK(h, hipMemcpyAsync(&cnt, dcnt, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (have + cnt >= B && candidates) {
+      // index after the (B - have)-th accepted candidate of this round
+      std::vector<int32_t> pos((size_t)nround);
+      HIPCHK(h, hipMemcpy(pos.data(), dpos, sizeof(int32_t) * nround, hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < nround; i++) if (pos[i] == (int32_t)(B - have - 1)) { *candidates = (int64_t)(c0 + i + 1); break; }
+    }
+    have += cnt;
+    c0 += (unsigned long long)nround;
+  }
+  if (x0_out) HIPCHK(h, hipMemcpy(x0_out, h->d_x0, sizeof(double) * B * D.nq, hipMemcpyDeviceToHost));
+  if (u_ws_out) HIPCHK(h, hipMemcpy(u_ws_out, h->d_uws, sizeof(double) * B * D.n, hipMemcpyDeviceToHost));
+  h->B = stage ? B : 0;          // (the staging buffers were used either way: without `stage` nothing is left staged)
   return DGSQP_OK;
 }
 

@@ -81,6 +81,9 @@ struct DgProb {
   double eig_floor;    // value given to negative eigenvalues by _nearestPD (par.eig_floor, 1e-10 when not set)
   int uniform_nqa;
   int gd_global;    // the packed constraint gradients live in the global scratch (ws_gd) instead of LDS: XL games beyond n ~ 160
+  int xl_pack;      // XL layout: the symmetric matrix of the Householder tridiagonalisation lives in LDS as a packed lower triangle
+                    // (n (n + 1) / 2 doubles next to the per-step vectors: n <= ~160) instead of the L2 scratch; the packed constraint
+                    // gradients move to the scratch to make room (gd_global)
   int tab_const;    // the row / dense-gradient / task tables are read from this constant block instead of LDS copies, the compact
                     // state-Hessian columns (e_K) live in the global scratch (ws_K) and the stage gradients share the costates'
                     // slot: games whose vectors alone nearly fill the arena (6 agents, N = 25: n = 300, 1,587 rows, 837 gradients)
@@ -173,7 +176,8 @@ static inline std::string dg_build_layout(DgProb& D) {
   const int npk = n * (n + 1) / 2;
   const int rpt = (n <= 32 ? 32 : (n <= 64 ? 64 : (n <= 100 ? 100 : 128))) / DG_NH;
   if (!D.big) { L.g_Bp = take(npk); L.g_V = take(npk); } else { L.g_Bp = L.g_V = -1; }
-  L.g_tw = D.big == 2 ? take(6 * n + DG_XL_KMAX + 16 + (DG_BLOCK / 64) * 3 * n + 16)   // d, e, tau, v, w, e^2, lambda, per-wavefront strips
+  const int xl_strips = (DG_BLOCK / 64) * 3 * n + 16, xl_packed = npk + DG_NH * n + 16;     // (the packed matrix + the partial sums of its products share the strips' slot)
+  L.g_tw = D.big == 2 ? take(6 * n + DG_XL_KMAX + 16 + (D.xl_pack && xl_packed > xl_strips ? xl_packed : xl_strips))   // d, e, tau, v, w, e^2, lambda, per-wavefront strips
                       : take((5 + DG_NH) * n + 16 + DG_PSD_KMAX * n /* Z */ + 3 * (DG_NH * rpt + 4)
                              + 2 * (DG_BLOCK / 64) * (DG_NH * rpt + 4) /* per-wavefront copies of the reflector v and of w */);
   // per-wavefront strips of the twisted factorisation (3 n doubles each): the packed-P slot is free until the sweep writes
@@ -244,6 +248,7 @@ static inline std::string dg_build_layout(DgProb& D) {
   }
   L.total = tot;
   if ((long)tot * 8 > DG_LDS_LIMIT && !D.big) { D.big = 1; return dg_build_layout(D); }   // (n > 128 starts at big = 2)
+  if ((long)tot * 8 > DG_LDS_LIMIT && D.big == 2 && D.xl_pack) { D.xl_pack = 0; D.gd_global = 0; return dg_build_layout(D); }   // no room for the packed matrix: the plain XL layout
   if ((long)tot * 8 > DG_LDS_LIMIT && D.big == 2 && !D.gd_global) { D.gd_global = 1; return dg_build_layout(D); }
   if ((long)tot * 8 > DG_LDS_LIMIT && D.big == 2 && !D.tab_const) { D.tab_const = 1; return dg_build_layout(D); }
   if ((long)tot * 8 > DG_LDS_LIMIT) {
@@ -386,6 +391,7 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   }
   D.t2_doubles = t2;
   D.big = D.n > 128 ? 2 : 0;   // XL layout: every matrix of the PSD / QP phases in the global scratch, generic (slow) kernels
+  if (D.big == 2 && D.n <= 176 && !getenv("DGSQP_XL_NOPACK")) { D.xl_pack = 1; D.gd_global = 1; }       // (tried first; dg_build_layout falls back when the arena overflows)
   return dg_build_layout(D);
 }
 

@@ -52,6 +52,88 @@ __device__ __noinline__ bool dev_xl_psd_tri(const Ctx& c, gptr Qpd) {
   if (TID == 0) { scal[DG_XVALID] = 0.0; scal[DG_XL_BASIS] = 0.0; }   // (Z overwrites the Jacobi warm-start basis)
   __syncthreads();
   PROF_BEGIN(pt_t);
+  if (D.xl_pack) {
+    // ---- Householder tridiagonalisation with the matrix in LDS (packed lower triangle, row i at i (i + 1) / 2): the same reduction as
+    // the loop below, whose every step pays three dependent L2 round trips (column, product, rank-2 update) -- 2.4 of the 9 Mcycles of
+    // a QP iteration at n = 150.  Thread (g, i) owns row i and the g-th part of its column range, in the product and in the update.
+    lptr Bp = strips, part2 = strips + n * (n + 1) / 2;
+    for (int e = TID; e < n * n; e += NT) {
+      const int i = e / n, k = e - i * n;
+      if (k <= i) Bp[i * (i + 1) / 2 + k] = 0.5 * (Qg[(int64_t)i * n + k] + Qg[(int64_t)k * n + i]);
+    }
+    __syncthreads();
+    for (int k = 0; k + 2 < n; k++) {
+      double s2 = 0;
+      for (int i = k + 1 + TID; i < n; i += NT) { const double x = Bp[i * (i + 1) / 2 + k]; vv[i] = x; s2 += x * x; }
+      const double nrm2 = block_sum(s2, red);
+      const double x0 = vv[k + 1];
+      const double tail2 = nrm2 - x0 * x0;
+      double alpha, beta;
+      if (!(tail2 > 0.0)) { alpha = x0; beta = 0.0; }
+      else { alpha = x0 >= 0 ? -sqrt(nrm2) : sqrt(nrm2); const double v0 = x0 - alpha; beta = 2.0 / (tail2 + v0 * v0); }
+      __syncthreads();
+      if (TID == 0) { dv[k] = Bp[k * (k + 1) / 2 + k]; ev[k] = alpha; tau[k] = beta; if (beta != 0.0) vv[k + 1] = x0 - alpha; }
+      __syncthreads();
+      for (int i = k + 1 + TID; i < n; i += NT) Vr[(int64_t)k * n + i] = vv[i];
+      if (beta != 0.0) {
+        const bool on = S.g < S.G && S.i > k && S.i < n;
+        if (on) {      // p_i = sum_j B(i, j) v_j over the g-th part of j in (k, n): row i up to the diagonal, column i below it
+          const int i = S.i, len = n - k - 1, ja = k + 1 + (S.g * len) / S.G, jb = k + 1 + ((S.g + 1) * len) / S.G;
+          clptr row = Bp + i * (i + 1) / 2;
+          double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+          int j = ja;
+          const int jm = jb < i + 1 ? jb : i + 1;
+          for (; j + 7 < jm; j += 8) {       // eight LDS reads of the matrix in flight (and eight broadcast reads of v)
+            double b[8], w[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { b[u] = row[j + u]; w[u] = vv[j + u]; }
+            a0 += b[0] * w[0] + b[4] * w[4]; a1 += b[1] * w[1] + b[5] * w[5]; a2 += b[2] * w[2] + b[6] * w[6]; a3 += b[3] * w[3] + b[7] * w[7];
+          }
+          for (; j < jm; j++) a0 += row[j] * vv[j];
+          for (; j + 7 < jb; j += 8) {
+            double b[8], w[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { b[u] = Bp[(j + u) * (j + u + 1) / 2 + i]; w[u] = vv[j + u]; }
+            a0 += b[0] * w[0] + b[4] * w[4]; a1 += b[1] * w[1] + b[5] * w[5]; a2 += b[2] * w[2] + b[6] * w[6]; a3 += b[3] * w[3] + b[7] * w[7];
+          }
+          for (; j < jb; j++) a0 += Bp[j * (j + 1) / 2 + i] * vv[j];
+          part2[S.g * n + i] = (a0 + a1) + (a2 + a3);
+        }
+        __syncthreads();
+        double pvsum = 0;
+        for (int i = k + 1 + TID; i < n; i += NT) {
+          double a = part2[i];
+          for (int g = 1; g < S.G; g++) a += part2[g * n + i];
+          const double pq = beta * a;
+          pv[i] = pq; pvsum += pq * vv[i];
+        }
+        const double K = 0.5 * beta * block_sum(pvsum, red);
+        for (int i = k + 1 + TID; i < n; i += NT) pv[i] -= K * vv[i];       // w
+        __syncthreads();
+        if (on) {      // B(i, j) -= v_i w_j + w_i v_j on the g-th part of row i's columns (k, i]
+          const int i = S.i, len = i - k, ja = k + 1 + (S.g * len) / S.G, jb = k + 1 + ((S.g + 1) * len) / S.G;
+          lptr row = Bp + i * (i + 1) / 2;
+          const double vi = vv[i], wi = pv[i];
+          int j = ja;
+          for (; j + 7 < jb; j += 8) {       // loads first, stores after
+            double b[8], wj[8], vj[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { b[u] = row[j + u]; wj[u] = pv[j + u]; vj[u] = vv[j + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) row[j + u] = b[u] - (vi * wj[u] + wi * vj[u]);
+          }
+          for (; j < jb; j++) row[j] -= vi * pv[j] + wi * vv[j];
+        }
+      }
+      __syncthreads();
+    }
+    if (TID == 0) {
+      dv[n - 2] = Bp[(n - 2) * (n - 1) / 2 + n - 2]; dv[n - 1] = Bp[(n - 1) * n / 2 + n - 1];
+      ev[n - 2] = Bp[(n - 1) * n / 2 + n - 2]; ev[n - 1] = 0.0; tau[n - 2] = 0.0; tau[n - 1] = 0.0;
+    }
+    __threadfence_block();
+    __syncthreads();
+  } else {
   for (int e = TID; e < n * n; e += NT) {
     const int i = e / n, k = e % n;
     Bm[e] = 0.5 * (Qg[(int64_t)i * n + k] + Qg[(int64_t)k * n + i]);
@@ -135,6 +217,7 @@ __device__ __noinline__ bool dev_xl_psd_tri(const Ctx& c, gptr Qpd) {
     ev[n - 2] = Bm[(int64_t)(n - 1) * n + n - 2]; ev[n - 1] = 0.0; tau[n - 2] = 0.0; tau[n - 1] = 0.0;
   }
   __syncthreads();
+  }
   PROF_END(PH_E_TRI, pt_t);
   // ---- negative eigenvalues of T
   double tn = 0;

@@ -215,14 +215,19 @@ def _build_params_v2(params: DGSQPV2Params, eig_floor, snap_active_bounds, lsqr_
 def solve_batches(solvers, batches) -> list:
     """Several Monte-Carlo batches of the SAME game and size in ONE launch (``dgsqp_launch_staged_group``): ``solvers`` are DGSQP
     objects of that game (one per batch: every batch keeps its own device buffers), ``batches`` the matching ``(x0, u_ws)`` pairs as
-    ``solve_batch`` takes them.  A launch ends with its slowest scenario; grouping lets the workgroups that are done with one batch
+    ``solve_batch`` takes them -- or the batch size alone for a batch that is staged on the device already (``sample_batch(stage=True)``:
+    sampling, solve and results never pass through host arrays in between).  A launch ends with its slowest scenario; grouping lets the workgroups that are done with one batch
     go on with the next instead of idling behind that tail.  Returns one ``solve_batch``-style dictionary per batch, bit-identical
     to separate ``solve_batch`` calls."""
     if len(solvers) != len(batches) or not solvers:
         raise ValueError('one solver per batch')
     lib = solvers[0]._lib
     staged = []
-    for s, (x0, u_ws) in zip(solvers, batches):
+    for s, bt in zip(solvers, batches):
+        if isinstance(bt, (int, np.integer)):          # already staged on the device (DGSQP.sample_batch(..., stage=True)): just its size
+            staged.append(int(bt))
+            continue
+        x0, u_ws = bt
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         u_ws = np.asarray(u_ws, dtype=np.float64)
         if u_ws.ndim == 3:
@@ -236,7 +241,10 @@ def solve_batches(solvers, batches) -> list:
         staged.append(B)
     t0 = time.time()
     arr = (C.c_void_p * len(solvers))(*[s._h for s in solvers])
-    if lib.dgsqp_launch_staged_group(arr, len(solvers)) != 0:
+    lib.dgsqp_set_cooperative(solvers[0]._h, 2)        # the caller waits for this launch: idle workgroups help with its line searches
+    rc = lib.dgsqp_launch_staged_group(arr, len(solvers))
+    lib.dgsqp_set_cooperative(solvers[0]._h, 1)
+    if rc != 0:
         raise RuntimeError('dgsqp_launch_staged_group failed: ' + lib.dgsqp_last_error(solvers[0]._h).decode())
     tm = _ffi.TimingT()
     outs = []
@@ -549,6 +557,34 @@ class DGSQP(AbstractSolver):
         out = dict(u_ws=np.ascontiguousarray(u_tm), collide=col.astype(bool))
         if want_trajectories:
             out['q_ws'] = q_ws
+        return out
+
+    def sample_batch(self, game, B: int, seed: int = 1, u_max=(2.1, 0.436), du_max=None, substeps=10, stage=False, fetch=True):
+        """The game's rejection sampler on the device (``dgsqp_sample_batch``; counter-based random numbers, mirrored bit for bit
+        by ``dgsqp_amd.sampler``): placement, PID warm start (zero inputs for the merge), collision rejection, the first ``B``
+        accepted candidates in candidate order.  ``stage=True`` leaves the batch staged on the handle (``solve_staged`` next);
+        ``fetch=False`` skips the copy to the host.  Returns dict(x0, u_ws [B, N, n_u] time-major, candidates)."""
+        from . import sampler as smp
+        spec = smp.sampler_spec(game, seed)
+        pid = _ffi.PidT()
+        pid.kp_v, pid.kp_s, pid.ki_s, pid.ey_gain, pid.ei_max = 1.0, 1.0, 0.005, 5.0, 100.0
+        if du_max is None:
+            rl = game.agent_constraints[0] if game.agent_constraints else None
+            du_max = (10.0, 4.5) if (rl is None or not hasattr(rl, 'rate_max')) else tuple(rl.rate_max)
+        pid.u_max[0], pid.u_max[1] = float(u_max[0]), float(u_max[1])
+        pid.du_max[0], pid.du_max[1] = float(du_max[0]), float(du_max[1])
+        pid.substeps = int(substeps)
+        x0 = np.empty((B, self.n_q)) if fetch else None
+        u_am = np.empty((B, self.n)) if fetch else None
+        used = C.c_int64(0)
+        rc = self._lib.dgsqp_sample_batch(self._h, int(B), C.byref(spec), C.byref(pid), _ffi.dptr(x0), _ffi.dptr(u_am), C.byref(used), 1 if stage else 0)
+        if rc != 0:
+            raise RuntimeError(f'dgsqp_sample_batch failed ({rc}): {self._lib.dgsqp_last_error(self._h).decode()}')
+        out = dict(candidates=int(used.value))
+        if fetch:
+            nua = self.n_u // self.M
+            out['x0'] = x0
+            out['u_ws'] = np.ascontiguousarray(u_am.reshape(B, self.M, self.N, nua).transpose(0, 2, 1, 3).reshape(B, self.N, self.n_u))
         return out
 
     # ---- reference single-scenario surface -----------------------------------------------------

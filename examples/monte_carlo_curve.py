@@ -25,21 +25,36 @@ def main():
     ap.add_argument('--batch', type=int, default=1024, help='scenarios per batch; up to 8 batches share one launch')
     ap.add_argument('--seed', type=int, default=1)
     ap.add_argument('--out', default=None, help='pickle in the layout process_data_curve.py reads')
+    ap.add_argument('--host-sampler', action='store_true', help="the scripts' sequential numpy draws (np.random.default_rng(seed), curve.py:384-467) "
+                    'instead of the counter-based sampler on the device')
     args = ap.parse_args()
 
     game = kinematic_racing_game('curve', N=args.N, reg=0.0)                       # curve.py:161: reg = 0
-    x0, u_ws = sample_scenarios(game, args.num_mc, seed=args.seed)                 # rejection sampling + PID warm starts
     bounds = list(range(0, args.num_mc, args.batch)) + [args.num_mc]
-    chunks = [(x0[a:b], u_ws[a:b]) for a, b in zip(bounds[:-1], bounds[1:])]
-    full = [c for c in chunks if len(c[0]) == args.batch]
-    solvers = [DGSQP(*game.solver_args(), print_method=None) for _ in range(max(1, min(8, len(full))))]
+    sizes = [b - a for a, b in zip(bounds[:-1], bounds[1:])]
+    nfull = sum(1 for n in sizes if n == args.batch)
+    solvers = [DGSQP(*game.solver_args(), print_method=None) for _ in range(max(1, min(8, nfull)))]
     t0 = time.time()
     results = []
-    for i in range(0, len(full), len(solvers)):                                     # groups of equal-sized batches: one launch each
-        grp = full[i:i + len(solvers)]
-        results += solve_batches(solvers[:len(grp)], grp)
-    for c in chunks[len(full):]:                                                     # the ragged remainder on its own
-        results.append(solvers[0].solve_batch(*c))
+    if args.host_sampler:
+        x0, u_ws = sample_scenarios(game, args.num_mc, seed=args.seed)             # rejection sampling + PID warm starts on the host
+        chunks = [(x0[a:b], u_ws[a:b]) for a, b in zip(bounds[:-1], bounds[1:])]
+        for i in range(0, nfull, len(solvers)):                                     # groups of equal-sized batches: one launch each
+            grp = chunks[i:min(i + len(solvers), nfull)]
+            results += solve_batches(solvers[:len(grp)], grp)
+        for c in chunks[nfull:]:                                                     # the ragged remainder on its own
+            results.append(solvers[0].solve_batch(*c))
+    else:
+        # batch j: the device sampler with seed + j (placement, PID warm start, collision rejection, compaction), left staged on its
+        # handle; the group is solved by one launch; only the results come back
+        for i in range(0, len(sizes), len(solvers)):
+            grp = sizes[i:i + len(solvers)]
+            for j, (sv, n) in enumerate(zip(solvers, grp)):
+                sv.sample_batch(game, n, seed=args.seed + i + j, stage=True, fetch=False)
+            same = [k for k, n in enumerate(grp) if n == grp[0]]
+            results += solve_batches([solvers[k] for k in same], [grp[k] for k in same])
+            for k in range(len(same), len(grp)):                                     # (a ragged last batch)
+                results += solve_batches([solvers[k]], [grp[k]])
     wall = time.time() - t0
     res = {k: np.concatenate([r[k] for r in results]) for k in ('u', 'l', 'x', 'status', 'num_iters', 'qp_solves', 'cond', 'cost')}
     res['msg'] = sum((r['msg'] for r in results), [])

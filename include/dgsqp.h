@@ -345,6 +345,35 @@ int dgsqp_pid_warm_start_batch(dgsqp_handle_t h, int64_t B, const double* q0, co
                                double* q_ws, int32_t* collide);
 
 /*
+ * Rejection samplers of the Monte-Carlo scripts on the device (row (f) of the hot-path scope): random placement, PID warm start
+ * (zero inputs for the merge), collision check along the warm start, accepted candidates kept in candidate order.  The random
+ * numbers are counter-based (Philox4x32-10): uniform k of candidate c depends on (seed, c, k) only, so the host mirror
+ * (dgsqp_amd/sampler.py) reproduces the stream bit for bit whatever the round sizes.
+ *   DGSQP_SAMPLER_FIRST_SEGMENT  scripts/DGSQP_ALGAMES_monte_carlo_chicane.py:384-404, _curve.py (two cars)
+ *   DGSQP_SAMPLER_INDEPENDENT    scripts/DGSQP_monte_carlo_agents.py:262-308 (M cars)
+ *   DGSQP_SAMPLER_CIRCUIT        scripts/DGSQP_comp_monte_carlo.py:365-382 (M cars on a closed track)
+ *   DGSQP_SAMPLER_MERGE          scripts/DGSQP_merge_monte_carlo.py:429-473 (unicycles, zero warm start)
+ * key_pts: the arc track's key points (x, y, psi, cumulative length, segment length, signed curvature of the segment ENDING
+ * there), n_key = segments + 1 (radius_arclength_track.py:361-408).
+ */
+enum { DGSQP_SAMPLER_FIRST_SEGMENT = 0, DGSQP_SAMPLER_INDEPENDENT = 1, DGSQP_SAMPLER_CIRCUIT = 2, DGSQP_SAMPLER_MERGE = 3 };
+typedef struct {
+  int32_t kind;
+  int32_t n_key;
+  uint64_t seed;
+  double half_width;   /* placement range of e_y */
+  double obs_d;        /* obstacle distance of the relative placements */
+  double seg0_len;     /* length of the first track segment */
+  double x_nom[DGSQP_MAX_AGENTS];   /* merge: nominal x of every car (merge.py:430,443,456) */
+  double key_pts[DGSQP_MAX_SEGS + 1][6];
+} dgsqp_sampler_t;
+/* Draw until B scenarios are accepted: x0_out [B][n_q], u_ws_out [B][n] agent-major (host, either may be NULL).  stage != 0: the
+   batch also becomes the handle's staged input (as after dgsqp_stage_inputs) -- sampling, solve and statistics never leave the
+   device.  *candidates (may be NULL) = candidates consumed, i.e. the index after the last accepted one. */
+int dgsqp_sample_batch(dgsqp_handle_t h, int64_t B, const dgsqp_sampler_t* spec, const dgsqp_pid_t* pid, double* x0_out,
+                       double* u_ws_out, int64_t* candidates, int stage);
+
+/*
  * Test hook: event log of the SQP state machine (convergence measures, merit values, step lengths,
  * watchdog branches) of every scenario of the next solve calls; compared event-by-event with the
  * oracle's log.  Layout per scenario: [count, (code, value) x pairs_per_scenario].  0 disables.

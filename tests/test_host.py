@@ -118,12 +118,13 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header():
     """ctypes mirrors and the C structs agree in size (checked by compiling a tiny C program)."""
     from dgsqp_amd import _ffi
-    src = '#include <stdio.h>\n#include "dgsqp.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(dgsqp_agent_t), sizeof(dgsqp_problem_t), sizeof(dgsqp_params_t), sizeof(dgsqp_dims_t), sizeof(dgsqp_timing_t), sizeof(dgsqp_pid_t));return 0;}\n'
+    src = '#include <stdio.h>\n#include "dgsqp.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(dgsqp_agent_t), sizeof(dgsqp_problem_t), sizeof(dgsqp_params_t), sizeof(dgsqp_dims_t), sizeof(dgsqp_timing_t), sizeof(dgsqp_pid_t), sizeof(dgsqp_sampler_t));return 0;}\n'
     exe = pathlib.Path('/tmp/dgsqp_sizeof')
     subprocess.run(['gcc', '-x', 'c', '-', '-I', str(ROOT / 'include'), '-o', str(exe)], input=src.encode(), check=True)
     sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    from dgsqp_amd.sampler import SamplerT
     assert sizes == [ctypes.sizeof(_ffi.AgentT), ctypes.sizeof(_ffi.ProblemT), ctypes.sizeof(_ffi.ParamsT),
-                     ctypes.sizeof(_ffi.DimsT), ctypes.sizeof(_ffi.TimingT), ctypes.sizeof(_ffi.PidT)]
+                     ctypes.sizeof(_ffi.DimsT), ctypes.sizeof(_ffi.TimingT), ctypes.sizeof(_ffi.PidT), ctypes.sizeof(SamplerT)]
 
 
 def _has_gpu():
@@ -168,6 +169,37 @@ def test_shard_ranges_partition_the_batch():
             assert spans[0][0] == 0 and spans[-1][1] == B
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_philox_known_answers_and_counter_based_sampler():
+    """The device sampler's random numbers (csrc/dgsqp_sampler.h) are Philox4x32-10; its numpy restatement reproduces the
+    published known-answer vectors of the generator (Random123 kat_vectors: zero / all-ones / digits-of-pi counters and keys).
+    The sampler built on it is a pure function of (seed, candidate): the accepted scenarios do not depend on how the candidates are
+    chunked, obey the placement rules of the scripts, and every one of them is collision-free along its warm start."""
+    from dgsqp_amd import sampler as smp
+    from dgsqp_amd.montecarlo import kinematic_racing_game, merge_game, barc_racing_game
+    hexs = lambda ctr, key: [int(v) for v in smp.philox4x32_10(np.array([ctr], np.uint32), key)[0]]
+    assert hexs([0, 0, 0, 0], (0, 0)) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert hexs([0xffffffff] * 4, (0xffffffff, 0xffffffff)) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert hexs([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], (0xa4093822, 0x299f31d0)) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    u = smp.uniform(7, np.arange(20000), 3)
+    assert u.min() >= 0.0 and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.01 and abs(u.var() - 1 / 12) < 0.005
+    assert not np.array_equal(u, smp.uniform(8, np.arange(20000), 3)) and not np.array_equal(u, smp.uniform(7, np.arange(20000), 2))
+    g = kinematic_racing_game('curve', N=10)
+    x0a, ua, ca = smp.sample_scenarios_counter(g, 40, seed=3, chunk=64)
+    x0b, ub, cb = smp.sample_scenarios_counter(g, 40, seed=3, chunk=500)
+    assert ca == cb and np.array_equal(x0a, x0b) and np.array_equal(ua, ub)
+    assert x0a.shape == (40, 12) and ua.shape == (40, 10, 4) and ca >= 40
+    assert np.all(x0a[:, 4] >= 0.1) and np.all(np.abs(x0a[:, [5, 11]]) <= g.half_width) and np.all((x0a[:, [2, 8]] >= 2) & (x0a[:, [2, 8]] < 3))
+    d = np.hypot(x0a[:, 10] - x0a[:, 4], x0a[:, 11] - x0a[:, 5])
+    assert np.allclose(d, 1.2 * g.obs_d, atol=1e-12)                       # car 2 sits 1.2 obstacle distances from car 1 (chicane.py:396-399)
+    assert np.all(np.linalg.norm(x0a[:, :2] - x0a[:, 6:8], axis=1) >= g.obs_d)
+    gm = merge_game(N=6)
+    xm, um, cm = smp.sample_scenarios_counter(gm, 6, seed=1, chunk=16)
+    assert xm.shape == (6, 12) and not um.any() and np.all(np.abs(xm[:, [2, 6, 10]] - 0.3) <= 0.3 * 0.03 + 1e-12)
+    gc = barc_racing_game(N=6, M=3)
+    xc, uc, cc = smp.sample_scenarios_counter(gc, 6, seed=0, chunk=16)
+    assert xc.shape == (6, 18) and np.all(np.abs(xc[:, [5, 11, 17]]) <= gc.half_width + 1e-12) and np.all(np.abs(xc[:, [3, 9, 15]]) <= 5 * np.pi / 180 + 1e-12)
 
 
 def test_interleaved_shards_partition_the_batch():
