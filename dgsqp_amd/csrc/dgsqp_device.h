@@ -100,7 +100,8 @@ struct DgCoopJob {
   unsigned long long claimed;     // bit j: trial j is taken (owner or helper), atomic OR
   unsigned long long ready;       // bit j: its result is in phi_out / pruned
   unsigned long long pruned;      // bit j: rejected by the derivative-free bound (no merit value)
-  int lo, iters;                  // helpers take trials [lo, iters) first, then lo-1 .. 1
+  int lo, iters;                  // helpers take trials [lo, iters), lowest first ...
+  int pos, window;                // ... but none beyond pos + window, pos = the trial its owner is at (bounds the work wasted when the search ends early)
   double mu, phi, dphi, S0, S1;   // the Armijo test's constants
   const double* x0;               // the scenario's initial state
   double* payload;                // u[n], du[n], l[nc], lhat[nc] of the base point
@@ -125,6 +126,7 @@ struct Ctx {
   double* coop_payload;   // this workgroup's two payload buffers (2 x (2 n + 2 n_c) doubles)
   unsigned long long coop_total;   // scenarios of this launch (helpers leave when that many are finished)
   int coop_start;  // a line search is offered to helpers once this many of its trials have been rejected (short ones stay private)
+  int coop_window; // helpers run at most this many trials ahead of the owner
   int coop_verify; // diagnostic: the owner evaluates every trial itself as well and counts helper values that differ in their bits
   gptr ws;      // this workgroup's global workspace
   cgptr x0;

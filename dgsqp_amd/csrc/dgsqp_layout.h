@@ -65,6 +65,7 @@ struct DgLds {
   int p_R, p_lam, p_c, p_w, p_r, p_y, p_t, p_alist, p_rd, p_yd2, p_yslot, p_yfree, p_dpart, p_act, p_part;
   // QP outputs that must survive trial evaluations
   int o_du, o_lhat;
+  int x_el;  // XL layout with xl_el: packed lower triangle of the QP's elimination M = L~ D L~^T (overlaps the QP outputs and c_R, dead until J is built)
   int c_R;   // classical QP: the first DgProb.c_rcap columns of the triangular factor R, packed column-major (phase-multiplexed with e_xs2)
   // LSQR scratch (s_yd2 / s_dpart: the dense-dot scratch of the dual start -- the QP's p_yd2 / p_dpart except in the
   // 'tables in constant memory' layout, where the dual start has its own behind its vectors and may overlap the QP outputs)
@@ -84,6 +85,8 @@ struct DgProb {
   int xl_pack;      // XL layout: the symmetric matrix of the Householder tridiagonalisation lives in LDS as a packed lower triangle
                     // (n (n + 1) / 2 doubles next to the per-step vectors: n <= ~160) instead of the L2 scratch; the packed constraint
                     // gradients move to the scratch to make room (gd_global)
+  int xl_el;        // XL layout: the elimination that builds J = L^-T runs on a packed lower triangle in LDS (L.x_el) and J is written to
+                    // the scratch once, instead of n passes over the L2-resident J
   int tab_const;    // the row / dense-gradient / task tables are read from this constant block instead of LDS copies, the compact
                     // state-Hessian columns (e_K) live in the global scratch (ws_K) and the stage gradients share the costates'
                     // slot: games whose vectors alone nearly fill the arena (6 agents, N = 25: n = 300, 1,587 rows, 837 gradients)
@@ -189,7 +192,7 @@ static inline std::string dg_build_layout(DgProb& D) {
   o = L.scr + (D.big ? 0 : ((npk + 1) & ~1));
   L.p_R = D.big == 2 ? -1 : take(npk); L.p_lam = take(n + 1); L.p_c = take(n + 1); L.p_w = take(n + 1); L.p_r = take(n + 1);
   L.p_y = take(n); L.p_t = take(n); L.p_alist = take((n + 2) / 2 + 1); L.p_rd = take(n + 1);
-  if (!D.tab_const) {   // the dual start borrows p_yd2 / p_dpart while its own vectors (5 of length n_c) sit at L.scr: keep them apart
+  if (!D.tab_const && D.big != 2) {   // the dual start borrows p_yd2 / p_dpart while its own vectors (5 of length n_c) sit at L.scr: keep them apart
     const int lsqr_size = 4 * ((nc + 1) & ~1) + (((nc > n ? nc : n) + 1) & ~1);
     if (o < L.scr + lsqr_size) o = L.scr + lsqr_size;
   }
@@ -202,7 +205,7 @@ static inline std::string dg_build_layout(DgProb& D) {
   // LSQR
   o = L.scr;
   L.s_u = take(nc); L.s_v = take(nc); L.s_w = take(nc); L.s_x = take(nc); L.s_t = take(nc > n ? nc : n);
-  if (D.tab_const) { L.s_yd2 = take(nd); L.s_dpart = take(D.ntask); }       // (the QP outputs are dead during the dual start)
+  if (D.tab_const || D.big == 2) { L.s_yd2 = take(nd); L.s_dpart = take(D.ntask); }       // (the QP outputs are dead during the dual start)
   else { L.s_yd2 = L.p_yd2; L.s_dpart = L.p_dpart; }
   const int lsqr_end = o;
   if (L.s_yd2 < L.s_t + (nc > n ? nc : n) || L.s_dpart < L.s_t + (nc > n ? nc : n)) return "internal layout error: the dual start's dot scratch overlaps its vectors";
@@ -236,6 +239,11 @@ static inline std::string dg_build_layout(DgProb& D) {
   if (lsqr_end > tot) tot = lsqr_end;
   // classical QP: as many columns of R as the arena still holds above the QP outputs (the trial trajectories of e_xs2 are dead
   // while a QP runs); a triangular solve per added row reads R column by column -- from LDS that is 10x less latency than from L2
+  // XL, packed elimination: from the end of the QP scratch to the end of the arena (over the QP outputs and the R columns: all dead
+  // until J = L^-T has been built)
+  L.x_el = (qp_end + 1) & ~1;
+  D.xl_el = D.big == 2 && D.xl_pack && L.x_el + npk + 2 <= DG_LDS_LIMIT / 8 && !getenv("DGSQP_XL_NOEL");
+  if (D.xl_el && L.x_el + npk + 2 > tot) tot = L.x_el + npk + 2;       // (the triangle is part of the arena whatever R gets)
   L.c_R = (out_end + 1) & ~1;
   D.c_rcap = 0;
   if (D.classic_qp) {

@@ -1159,7 +1159,10 @@ __device__ __noinline__ void dev_coop_help(Ctx& c) {
       DgCoopJob* jb = &co->jobs[sl];
       const unsigned int sq = __hip_atomic_load(&jb->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
       if (!(sq & 1u)) continue;
-      const int lo = __hip_atomic_load(&jb->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), iters = __hip_atomic_load(&jb->iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int lo = __hip_atomic_load(&jb->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int iters = __hip_atomic_load(&jb->iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      { const int lim = __hip_atomic_load(&jb->pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + __hip_atomic_load(&jb->window, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (lim < iters) iters = lim; }
+      if (iters <= lo) continue;
       const unsigned long long cl = AT_LOAD(&jb->claimed);
       const unsigned long long all = iters >= 64 ? ~0ull : ((1ull << iters) - 1ull);
       if ((cl & all) == all || lo < 1 || iters > DG_COOP_PHI) continue;
@@ -1178,7 +1181,9 @@ __device__ __noinline__ void dev_coop_help(Ctx& c) {
         bool ok = __hip_atomic_load(&jb->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == sq;     // still the job we looked at: its fields are stable while `active` is held
         int cand = -1;
         if (ok) {
-          const int lo = __hip_atomic_load(&jb->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), iters = __hip_atomic_load(&jb->iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int lo = __hip_atomic_load(&jb->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          int iters = __hip_atomic_load(&jb->iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          { const int lim = __hip_atomic_load(&jb->pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + __hip_atomic_load(&jb->window, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (lim < iters) iters = lim; }
           for (int tries = 0; tries < 64 && cand < 0; tries++) {
             const unsigned long long cl = AT_LOAD(&jb->claimed);
             int j2 = -1;
@@ -1249,7 +1254,7 @@ __device__ inline double dev_line_search(const Ctx& c, double mu, double phi, do
           if (TID == 0) {
             lds[L.scal + DG_COOP_FLIP] = (double)(1 - flip);
             job->claimed = (1ull << lo) - 1ull; job->ready = 0ull; job->pruned = 0ull;        // trials below lo are the owner's
-            job->lo = lo; job->iters = iters;
+            job->lo = lo; job->iters = iters; job->pos = i; job->window = c.coop_window;
             job->mu = mu; job->phi = phi; job->dphi = dphi; job->S0 = S0; job->S1 = S1;
             job->x0 = (const double*)c.x0; job->payload = pl;
             __threadfence();
@@ -1260,6 +1265,7 @@ __device__ inline double dev_line_search(const Ctx& c, double mu, double phi, do
         }
       }
     }
+    if (job && TID == 0) __hip_atomic_store(&job->pos, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bool have_h = false, h_pruned = false;     // a helper's value for this trial
     double h_phi = 0.0;
     if (job && i >= lo) {

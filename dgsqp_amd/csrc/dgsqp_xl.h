@@ -666,7 +666,58 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
   const int tr = TID >> 4, tc = TID & 15;       // 32 row groups x 16 consecutive columns for the element-wise updates of J
   PROF_BEGIN(pt_qp);
   __syncthreads();
-  for (int r = TID; r < nc; r += NT) { q.act[r] = 0; lhat[r] = 0.0; }
+  for (int r = TID; r < nc; r += NT) q.act[r] = 0;
+  bool bad = false;
+  if constexpr (!xl_mp<MP>::lds) {
+  if (D.xl_el) {
+    // ---- the same elimination on a packed lower triangle in LDS (row i at i (i + 1) / 2; the region overlaps the QP outputs and the
+    // LDS columns of R, all dead until J exists): two LDS-latency barriers per column instead of two L2 round trips, then ONE pass
+    // writes J = L^-T (upper triangular at this point) to the scratch.
+    PROF_BEGIN(pxe);
+    lptr X = lds + L.x_el;
+    for (int e = TID; e < n * n; e += NT) { const int i = e / n, k = e - i * n; if (k <= i) X[i * (i + 1) / 2 + k] = Mx[(int64_t)i * n + k]; }
+    __syncthreads();
+    for (int j = 0; j < n; j++) {
+      const double djj = X[j * (j + 1) / 2 + j];
+      if (!(djj > 0.0)) { bad = true; break; }
+      if (j == n - 1) break;
+      const double inv = 1.0 / djj;
+      for (int k = TID; k < n; k += NT) {
+        if (k < j) tv[k] = X[j * (j + 1) / 2 + k];
+        else if (k > j) { const double akj = X[k * (k + 1) / 2 + j]; tv[k] = akj; np[k] = akj * inv; }
+      }
+      __syncthreads();
+      for (int i = j + 1 + TID; i < n; i += NT) X[i * (i + 1) / 2 + j] = -np[i];
+      if (S.g < S.G && S.i < n && S.i != j) {       // thread (g, k): column k of the rows i >= max(j + 1, k), i = j + 1 + g (mod G)
+        const int k = S.i, G = S.G;
+        const double pk = tv[k];
+        int i = j + 1 + S.g;
+        if (i < k) i += ((k - i + G - 1) / G) * G;
+        for (; i + 3 * G < n; i += 4 * G) {
+          const int i1 = i + G, i2 = i + 2 * G, i3 = i + 3 * G;
+          lptr p0 = X + i * (i + 1) / 2 + k, p1 = X + i1 * (i1 + 1) / 2 + k, p2 = X + i2 * (i2 + 1) / 2 + k, p3 = X + i3 * (i3 + 1) / 2 + k;
+          const double a0 = *p0, a1 = *p1, a2 = *p2, a3 = *p3, m0 = np[i], m1 = np[i1], m2 = np[i2], m3 = np[i3];
+          *p0 = a0 - m0 * pk; *p1 = a1 - m1 * pk; *p2 = a2 - m2 * pk; *p3 = a3 - m3 * pk;
+        }
+        for (; i < n; i += G) X[i * (i + 1) / 2 + k] -= np[i] * pk;
+      }
+      __syncthreads();
+    }
+    if (!bad) {
+      for (int j = TID; j < n; j += NT) tv[j] = 1.0 / sqrt(X[j * (j + 1) / 2 + j]);
+      __syncthreads();
+      for (int e = TID; e < n * n; e += NT) {       // J[a][b] = X[b][a] / sqrt(d_b) above the diagonal, 1 / sqrt(d_a) on it, 0 below
+        const int a = e / n, b2 = e - a * n;
+        J[e] = a < b2 ? X[b2 * (b2 + 1) / 2 + a] * tv[b2] : (a == b2 ? tv[a] : 0.0);
+      }
+    }
+    XSYNC();
+    PROF_END(PH_Q_WARM, pxe);
+  }
+  }
+  for (int r = TID; r < nc; r += NT) lhat[r] = 0.0;          // (after the packed elimination: its triangle overlaps the QP outputs)
+  const bool el_done = !xl_mp<MP>::lds && D.xl_el;
+  if (!el_done) {
   // ---- J = L^-T with M = L L^T, inside J's storage: elimination M = L~ D L~^T by columns with the inverse of the unit factor
   //      accumulated in place.  At step j the pivot vector holds row j left of the diagonal (= row j of X = L~^-1, final) and column j
   //      below it (a_kj, the multipliers m_i = a_ij / d_j); row i > j becomes row_i - m_i * pivot vector on its whole prefix [0, i]:
@@ -675,7 +726,6 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
   PROF_BEGIN(px1);
   for (int e = TID; e < n * n; e += NT) { const int i = e / n, k = e - i * n; if (k <= i) J[i * js + k] = Mx[(int64_t)i * n + k]; }
   JSYNC();
-  bool bad = false;
 #ifdef DG_PROF
   long long pa_ = 0, pb_ = 0, pc_ = 0;
 #endif
@@ -731,7 +781,7 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
 #endif
   }
   PROF_COUNT(PH_W_BUILD, pa_); PROF_COUNT(PH_W_MULT, pb_); PROF_COUNT(PH_W_X, pc_);
-  if (bad) { if (TID == 0) scal[DG_QP_NPREV] = 0.0; __syncthreads(); PROF_END(PH_QP, pt_qp); return 2; }
+  if (!bad) {
   PROF_END(PH_Q_WARM, px1);
   PROF_BEGIN(px2);
   for (int j = TID; j < n; j += NT) tv[j] = 1.0 / sqrt(J[j * js + j]);
@@ -744,6 +794,9 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
   for (int j = TID; j < n; j += NT) J[j * js + j] = tv[j];
   JSYNC();
   PROF_END(PH_Q_Y, px2);
+  }
+  }
+  if (bad) { if (TID == 0) scal[DG_QP_NPREV] = 0.0; __syncthreads(); PROF_END(PH_QP, pt_qp); return 2; }
   // ---- x = -M^-1 q = -J (J^T q)
   xl_jt_mul<MP>(J, js, n, S, 0, n, lds + L.q, dv, part);
   xl_j_mul<MP>(J, js, n, S, 0, n, dv, x, part);
