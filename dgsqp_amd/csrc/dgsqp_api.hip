@@ -31,10 +31,10 @@ dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restric
                 SolveOutPtrs O, double* __restrict__ ws_all, unsigned long long* __restrict__ ticket,
                 double* __restrict__ trace, int trace_cap, unsigned int* __restrict__ drained,
                 double* __restrict__ itlog, int itlog_cap, const DgBatch* __restrict__ group, int group_n,
-                DgCoop* coop, double* coop_payload, int coop_start, int coop_verify, int coop_window) {
+                DgCoop* coop, double* coop_payload, int coop_start, int coop_verify, int coop_window, int coop_helpers) {
   Ctx c;
   c.coop = coop;
-  c.coop_start = coop_start; c.coop_verify = coop_verify; c.coop_window = coop_window;
+  c.coop_start = coop_start; c.coop_verify = coop_verify; c.coop_window = coop_window; c.coop_helpers = coop_helpers;
   c.coop_payload = coop ? coop_payload + (size_t)blockIdx.x * 2 * (2 * dg_prob.n + 2 * dg_prob.nc) : nullptr;
   c.coop_total = (unsigned long long)(B * (group ? group_n : 1));
   c.trace_cap = trace_cap;
@@ -97,7 +97,7 @@ dg_evaluate_kernel(const DgProb* __restrict__ D, int64_t B, const double* __rest
                    const double* __restrict__ l, double* q, double* g, double* G, double* Q, double* x, double* l0,
                    double* __restrict__ ws_all) {
   Ctx c;
-  c.coop = nullptr; c.coop_payload = nullptr; c.coop_total = 0; c.coop_start = 0; c.coop_verify = 0; c.coop_window = 0;
+  c.coop = nullptr; c.coop_payload = nullptr; c.coop_total = 0; c.coop_start = 0; c.coop_verify = 0; c.coop_window = 0; c.coop_helpers = 0;
   c.ws = (gptr)ws_all + (int64_t)blockIdx.x * dg_prob.ws_doubles;
   c.trace = nullptr; c.trace_cap = 0; c.itlog = nullptr; c.itlog_cap = 0;
   const DgLds& L = dg_prob.L;
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(DG_BLOCK)
 dg_qp_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__ x0, const double* __restrict__ u,
              const double* __restrict__ l, double* du, double* lhat, double* Qpd, int32_t* flag, double* __restrict__ ws_all) {
   Ctx c;
-  c.coop = nullptr; c.coop_payload = nullptr; c.coop_total = 0; c.coop_start = 0; c.coop_verify = 0; c.coop_window = 0;
+  c.coop = nullptr; c.coop_payload = nullptr; c.coop_total = 0; c.coop_start = 0; c.coop_verify = 0; c.coop_window = 0; c.coop_helpers = 0;
   c.ws = (gptr)ws_all + (int64_t)blockIdx.x * dg_prob.ws_doubles;
   c.trace = nullptr; c.trace_cap = 0; c.itlog = nullptr; c.itlog_cap = 0;
   const DgLds& L = dg_prob.L;
@@ -310,17 +310,17 @@ static int upload_problem(dgsqp_solver* h) {
 //  DGSQP_COOP_VERIFY = 1: owners re-evaluate every helper value and count differing bits -- dgsqp_coop_stats)
 static int coop_start_trials() { const char* e = getenv("DGSQP_COOP_START"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }
 static int coop_window_trials() { const char* e = getenv("DGSQP_COOP_WINDOW"); const int v = e ? atoi(e) : 64; return v < 1 ? 1 : v; }
+static int coop_max_helpers() { const char* e = getenv("DGSQP_COOP_HELPERS"); const int v = e ? atoi(e) : 64; return v < 1 ? 1 : v; }
 static int coop_verify_mode() { const char* e = getenv("DGSQP_COOP_VERIFY"); return e && atoi(e) != 0; }
 static bool coop_for_launch(dgsqp_solver* h, int grid) {
   if (!h->d_coop || grid > h->num_cu * 2 + 2 || h->trace_cap > 0) return false;
-  // Worth it only where a trial point is expensive: its rollout is a dependent chain of N x substeps x stages evaluations of f_c on
-  // a handful of lanes (dynamic bicycle, rk4, M = 10: 1,000; measured 1,045 -> 735 ms for a 1,024-scenario batch).  For the euler
-  // games (25 evaluations) a helper needs as long to find and load a job as the owner to evaluate the trial itself (measured: 409 ->
-  // 450 ms), so those launches stay plain.
+  // (development knob DGSQP_COOP_MIN_CHAIN: only for games whose rollout is a dependent chain of at least that many evaluations of f_c,
+  // N x substeps x stages.  With all idle workgroups helping, the euler games lost -- 409 -> 450 ms --; with the helpers capped at 64
+  // they gain as well -- 362 -> 345 ms --, so the default is 0.)
   const dgsqp_problem_t& P = h->hp.P;
   const int stages = P.integrator == DGSQP_INT_RK4 ? 4 : (P.integrator == DGSQP_INT_RK3 ? 3 : (P.integrator == DGSQP_INT_RK2 ? 2 : 1));
   const int chain = P.N * (P.integrator == DGSQP_INT_EULER ? 1 : P.substeps * stages);
-  if (chain < 200 && !getenv("DGSQP_COOP_FORCE")) return false;
+  { const char* e = getenv("DGSQP_COOP_MIN_CHAIN"); if (chain < (e ? atoi(e) : 0)) return false; }
   return h->coop_mode == 2 || (h->coop_mode == 1 && h->coop_next_sync);
 }
 static int grid_for(dgsqp_solver* h, int64_t B) {
@@ -507,7 +507,7 @@ int dgsqp_launch_staged(dgsqp_handle_t h) {
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
   *h->drained_host = 0u;
   hipLaunchKernelGGL(dg_solve_kernel, dim3(grid), dim3(DG_BLOCK), h->lds_bytes, h->stream, h->dp, h->B, h->d_x0, h->d_uws, O, h->ws, h->ticket, trace, h->trace_cap, h->drained_dev, itlog, h->itlog_cap, (const DgBatch*)nullptr, 0,
-                     coop ? h->d_coop : (DgCoop*)nullptr, h->d_coop_payload, coop_start_trials(), coop_verify_mode(), coop_window_trials());
+                     coop ? h->d_coop : (DgCoop*)nullptr, h->d_coop_payload, coop_start_trials(), coop_verify_mode(), coop_window_trials(), coop_max_helpers());
   HIPCHK(h, hipGetLastError());
   h->launch_gen++;
   h->launched_grid = grid;
@@ -553,7 +553,7 @@ int dgsqp_launch_staged_group(const dgsqp_handle_t* hs, int count) {
   SolveOutPtrs O0 = L->group_host[0].O;
   hipLaunchKernelGGL(dg_solve_kernel, dim3(grid), dim3(DG_BLOCK), L->lds_bytes, L->stream, L->dp, L->B, L->d_x0, L->d_uws, O0, L->ws, L->ticket,
                      (double*)nullptr, 0, L->drained_dev, (double*)nullptr, 0, (const DgBatch*)L->d_group, count,
-                     coop ? L->d_coop : (DgCoop*)nullptr, L->d_coop_payload, coop_start_trials(), coop_verify_mode(), coop_window_trials());
+                     coop ? L->d_coop : (DgCoop*)nullptr, L->d_coop_payload, coop_start_trials(), coop_verify_mode(), coop_window_trials(), coop_max_helpers());
   HIPCHK(L, hipGetLastError());
   L->launch_gen++;
   for (int i = 0; i < count; i++) { hs[i]->launched_grid = grid; hs[i]->in_flight = true; hs[i]->group_leader = i == 0 ? nullptr : L; hs[i]->group_gen = L->launch_gen; }

@@ -127,6 +127,7 @@ struct Ctx {
   unsigned long long coop_total;   // scenarios of this launch (helpers leave when that many are finished)
   int coop_start;  // a line search is offered to helpers once this many of its trials have been rejected (short ones stay private)
   int coop_window; // helpers run at most this many trials ahead of the owner
+  int coop_helpers; // at most this many idle workgroups evaluate trials; the others sleep until the launch ends
   int coop_verify; // diagnostic: the owner evaluates every trial itself as well and counts helper values that differ in their bits
   gptr ws;      // this workgroup's global workspace
   cgptr x0;

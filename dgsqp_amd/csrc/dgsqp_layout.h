@@ -87,6 +87,7 @@ struct DgProb {
                     // gradients move to the scratch to make room (gd_global)
   int xl_el;        // XL layout: the elimination that builds J = L^-T runs on a packed lower triangle in LDS (L.x_el) and J is written to
                     // the scratch once, instead of n passes over the L2-resident J
+  int xl_noblock;   // (development knob, environment DGSQP_XL_NOBLOCK: the XL warm start re-absorbs its rows one at a time)
   int tab_const;    // the row / dense-gradient / task tables are read from this constant block instead of LDS copies, the compact
                     // state-Hessian columns (e_K) live in the global scratch (ws_K) and the stage gradients share the costates'
                     // slot: games whose vectors alone nearly fill the arena (6 agents, N = 25: n = 300, 1,587 rows, 837 gradients)
@@ -399,6 +400,7 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   }
   D.t2_doubles = t2;
   D.big = D.n > 128 ? 2 : 0;   // XL layout: every matrix of the PSD / QP phases in the global scratch, generic (slow) kernels
+  D.xl_noblock = getenv("DGSQP_XL_NOBLOCK") ? 1 : 0;
   if (D.big == 2 && D.n <= 176 && !getenv("DGSQP_XL_NOPACK")) { D.xl_pack = 1; D.gd_global = 1; }       // (tried first; dg_build_layout falls back when the arena overflows)
   return dg_build_layout(D);
 }

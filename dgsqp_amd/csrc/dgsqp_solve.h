@@ -1138,10 +1138,20 @@ __device__ __noinline__ void dev_coop_help(Ctx& c) {
   DgCoop* co = c.coop;
   const int njobs = 2 * (int)gridDim.x;
   const int NONE = 0x7fffffff;
-  if (TID == 0) __hip_atomic_fetch_add(&co->idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // The first `coop_helpers` workgroups to run out of scenarios help; the others only wait for the launch to end: a failing line search
+  // has at most 48 trials on offer, and 250 workgroups evaluating trials nobody will need keep the whole chip under load -- its clock
+  // sags and the scenarios still solving, serial chains all of them, run slower than in a plain launch's quiet tail.
+  const unsigned int rank = (unsigned int)dev_bcast_u64(TID == 0 ? (unsigned long long)__hip_atomic_fetch_add(&co->idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull);
+  const bool passive = (int)rank >= c.coop_helpers;
   int start = (2 * (int)blockIdx.x + 2) % njobs;
   unsigned long long spins = 0;
   while (true) {
+    if (passive) {
+      if (dev_bcast_u64(TID == 0 ? (unsigned long long)(AT_LOAD(&co->finished) >= c.coop_total) : 0ull)) break;
+      for (int t = 0; t < 32; t++) __builtin_amdgcn_s_sleep(127);
+      if (++spins > (1ull << 22)) break;
+      continue;
+    }
     {
       // one word to poll while nothing is on offer (hundreds of workgroups may be idle: they must not hammer the memory system)
       const unsigned long long w = dev_bcast_u64(TID == 0 ? ((unsigned long long)(AT_LOAD(&co->finished) >= c.coop_total) << 32) | (unsigned long long)AT_LOAD(&co->open) : 0ull);
@@ -1276,13 +1286,12 @@ __device__ inline double dev_line_search(const Ctx& c, double mu, double phi, do
         const unsigned long long prev = dev_bcast_u64(TID == 0 ? __hip_atomic_fetch_or(&job->claimed, want, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) : 0ull);
         mine = (mine & ~want) | (want & ~prev);
       }
-      if (!((mine >> i) & 1ull)) {       // a helper has this trial: wait for its value
-        unsigned long long rdy = 0ull, spins = 0ull;
-        while (true) {
-          rdy = dev_bcast_u64(TID == 0 ? __hip_atomic_load(&job->ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : 0ull);
-          if (((rdy >> i) & 1ull) || ++spins > (1ull << 17)) break;
-          __builtin_amdgcn_s_sleep(32);
-        }
+      if (!((mine >> i) & 1ull)) {
+        // A helper has taken this trial.  Its value is used if it is there; the owner never WAITS for one: a helper needs a rollout of
+        // its own (1.8 Mcycles) for what costs the owner 0.3 M on top of the block's rollout, so waiting loses whenever the search ends
+        // within a few more trials (measured: twelve bench batches 596 -> 624 ms with waiting).  A search that fails runs into the
+        // helpers' values after ~7 trials of its own and takes the other 40 from them.
+        const unsigned long long rdy = dev_bcast_u64(TID == 0 ? __hip_atomic_load(&job->ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : 0ull);
         if ((rdy >> i) & 1ull) {
           __threadfence();
           h_pruned = (dev_bcast_u64(TID == 0 ? AT_LOAD(&job->pruned) : 0ull) >> i) & 1ull;
@@ -1296,10 +1305,7 @@ __device__ inline double dev_line_search(const Ctx& c, double mu, double phi, do
             if (i + 1 < iters) alpha *= D.par.tau;
             continue;
           }
-        } else {
-          if (TID == 0) __hip_atomic_fetch_add(&c.coop->timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          mine |= 1ull << i;              // gave up waiting (diagnostic counter): evaluate it here -- same value
-        }
+        } else mine |= 1ull << i;         // not there yet: evaluate it here -- same value
       }
     }
     if (K > 1) {

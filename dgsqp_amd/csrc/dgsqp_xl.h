@@ -953,7 +953,97 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
   const int nprev = (D.par.qp_warm_start && D.big == 2) ? (int)scal[DG_QP_NPREV] : 0;
   if (nprev > 0) {
     PROF_BEGIN(pxw);
-    for (int jp = 0; jp < nprev && iq < n; jp++) {
+    int jp0 = 0;
+    if constexpr (!xl_mp<MP>::lds) {
+      // Blocked form (J in the scratch).  Re-absorbing the guessed rows one at a time costs three L2 passes over J per row (J^T n_p, the
+      // step direction, the reflection): 1.7 of the 8 Mcycles of a QP iteration at n = 150.  The reflections only depend on
+      // D = J^T N_W, so: (A) D for the first mb rows into LDS (a row of J for a box / rate row, one product for a dense row), (B)
+      // Householder QR of D there, column by column with the dependence test of the sequential path -- R and the reflectors --,
+      // (C) ONE pass over J applying the reflectors to every row (one wavefront per row, reflectors from LDS).  Same arithmetic
+      // as the loop below up to the order of the sums; rows beyond the LDS capacity go through that loop afterwards.
+      const int mcap = (L.o_du - L.x_el) / n;
+      const int mb = nprev < mcap ? nprev : mcap;
+      if (mb >= 4 && !D.xl_noblock) {
+        lptr Dl = lds + L.x_el, betas = zv, refc = rv, npn = acc;
+        const int lane = TID & 63, wave = TID >> 6;
+        for (int j = 0; j < mb; j++) {                    // (A) dense rows, one product each
+          const int p = q.prev[j];
+          if (ld_row(p).dense < 0) continue;              // uniform
+          row_products(p);
+          double sn = 0;
+          for (int k = TID; k < n; k += NT) { sn += np[k] * np[k]; Dl[j * n + k] = dv[k]; }
+          sn = block_sum(sn, red);
+          if (TID == 0) npn[j] = sn;
+        }
+        __syncthreads();
+        for (int e = TID; e < mb * n; e += NT) {          // (A) box / rate rows: d = -+ (row c1 of J - row c1 - 2)
+          const int j = e / n, i = e - j * n;
+          const DgRow Rw = ld_row(q.prev[j]);
+          if (Rw.dense >= 0) continue;
+          const int c1 = am_col(D, Rw.a, Rw.k, Rw.idx);
+          const bool has0 = (Rw.type == DG_R_RATE_UB || Rw.type == DG_R_RATE_LB) && Rw.k > 0;
+          const double sgn = (Rw.type == DG_R_IN_UB || Rw.type == DG_R_RATE_UB) ? 1.0 : -1.0;
+          double dj = J[(int64_t)c1 * js + i];
+          if (has0) dj -= J[(int64_t)(c1 - DGSQP_NUA) * js + i];
+          Dl[e] = -sgn * dj;
+          if (i == 0) npn[j] = has0 ? 2.0 : 1.0;
+        }
+        __syncthreads();
+        for (int j = 0; j < mb && iq < n; j++) {          // (B) QR of D in LDS
+          lptr d = Dl + j * n;
+          double s2 = 0;
+          for (int k = iq + TID; k < n; k += NT) s2 += d[k] * d[k];
+          const double s_d2 = block_sum(s2, red);
+          if (!(s_d2 > 1e-12 * npn[j])) continue;         // (numerically) dependent on the rows taken so far
+          const double x0 = d[iq];
+          const double tail2 = s_d2 - x0 * x0;
+          double delta = x0, beta = 0.0, v0 = 0.0;
+          if (iq + 1 < n && tail2 > 0.0) { delta = x0 >= 0.0 ? -sqrt(s_d2) : sqrt(s_d2); v0 = x0 - delta; beta = -1.0 / (delta * v0); }
+          __syncthreads();
+          for (int i = TID; i < iq; i += NT) R.set(i, iq, d[i]);
+          if (TID == 0) {
+            const int p = q.prev[j];
+            R.set(iq, iq, delta); q.act[p] = 1; q.alist[iq] = p; uu[iq] = 0.0;
+            if (beta != 0.0) d[iq] = v0;
+            betas[iq] = beta; refc[iq] = (double)j;
+          }
+          __syncthreads();
+          if (beta != 0.0)
+            for (int cc = j + 1 + wave; cc < mb; cc += NT / 64) {      // the reflection on the later columns, one wavefront each
+              lptr dc = Dl + cc * n;
+              double t = 0;
+              for (int k = iq + lane; k < n; k += 64) t += d[k] * dc[k];
+              t = beta * wave_sum(t);
+              for (int k = iq + lane; k < n; k += 64) dc[k] -= t * d[k];
+            }
+          iq++;
+          __syncthreads();
+        }
+        const int iqb = iq;
+        for (int i = wave; i < n; i += NT / 64) {          // (C) J <- J H_0 ... H_{iqb-1}, row by row
+          MP Ji = J + (int64_t)i * js;
+          double r[XL_NV];
+#pragma unroll
+          for (int h = 0; h < XL_NV; h++) { const int k = lane + 64 * h; r[h] = k < n ? Ji[k] : 0.0; }
+          for (int t = 0; t < iqb; t++) {
+            const double bt = betas[t];
+            if (bt == 0.0) continue;
+            clptr v = Dl + (int)refc[t] * n;
+            double vk[XL_NV], ds = 0;
+#pragma unroll
+            for (int h = 0; h < XL_NV; h++) { const int k = lane + 64 * h; vk[h] = (k >= t && k < n) ? v[k] : 0.0; ds += r[h] * vk[h]; }
+            ds = bt * wave_sum(ds);
+#pragma unroll
+            for (int h = 0; h < XL_NV; h++) r[h] -= ds * vk[h];
+          }
+#pragma unroll
+          for (int h = 0; h < XL_NV; h++) { const int k = lane + 64 * h; if (k < n) Ji[k] = r[h]; }
+        }
+        XSYNC();
+        jp0 = mb;
+      }
+    }
+    for (int jp = jp0; jp < nprev && iq < n; jp++) {
       const int p = q.prev[jp];
       row_products(p);
       double s_d2 = 0, s_np = 0;

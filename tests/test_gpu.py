@@ -701,7 +701,7 @@ def test_cooperative_line_search_is_bit_identical(games):
     from dgsqp_amd.montecarlo import sample_scenarios
     from dgsqp_amd.solver import DGSQP
     import os
-    for name, B, force in (('dyn_curve_N25', 768, False), ('kb_chicane_N25', 768, True)):      # (euler games stay plain unless forced: helping does not pay there)
+    for name, B, force in (('dyn_curve_N25', 768, False), ('kb_chicane_N25', 768, False)):
         g = games[name][0]
         s = DGSQP(*g.solver_args(), print_method=None)
         x0, u_tm = sample_scenarios(g, B, seed=5)

@@ -8,11 +8,13 @@ D=$R/profiles
 P=r03
 if [ ! -f $G/steps.txt ]; then echo "no $G/steps.txt: run tools/measure_round3.sh on the GPU box first" >&2; exit 1; fi
 BAD=$(awk '$2 != 0 {print $1}' $G/steps.txt)
-if [ -n "$BAD" ]; then echo "measurement steps failed: $BAD -- nothing copied" >&2; [ "${ALLOW_FAILED:-0}" = 1 ] || exit 1; fi
+if [ -n "$BAD" ]; then
+  if [ "${ALLOW_FAILED:-0}" = 1 ]; then echo "measurement steps failed: $BAD -- copying the others (ALLOW_FAILED=1)" >&2; else echo "measurement steps failed: $BAD -- nothing copied" >&2; exit 1; fi
+fi
 ok() { grep -q "^$1 0$" $G/steps.txt; }
 cp $G/steps.txt $D/${P}_measure_steps.txt
 for f in $G/bench_*.json; do python3 -c "import json,sys; json.load(open('$f'))" && cp $f $D/${P}_$(basename $f); done
-for f in $G/forks_*.txt $G/phase_cycles_*.txt $G/tail_composition_*.txt $G/gpu_tests_parity_lines.txt; do
+for f in $G/forks_*.txt $G/phase_cycles_*.txt $G/tail_composition_*.txt $G/coop_line_search_*.txt $G/gpu_tests_parity_lines.txt; do
   [ -f $f ] || continue
   if grep -q "Traceback" $f; then echo "traceback in $f -- not copied" >&2; exit 1; fi
   cp $f $D/${P}_$(basename $f)
