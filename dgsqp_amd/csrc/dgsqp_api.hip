@@ -31,9 +31,12 @@ dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restric
                 SolveOutPtrs O, double* __restrict__ ws_all, unsigned long long* __restrict__ ticket,
                 double* __restrict__ trace, int trace_cap, unsigned int* __restrict__ drained,
                 double* __restrict__ itlog, int itlog_cap, const DgBatch* __restrict__ group, int group_n,
-                DgCoop* coop, double* coop_payload, int coop_start, int coop_verify, int coop_window, int coop_helpers) {
+                DgCoop* coop, double* coop_payload, int coop_start, int coop_verify, int coop_window, int coop_helpers, DgPark park) {
   Ctx c;
   c.coop = coop;
+  c.park = park;
+  if (!coop) c.park.entries = nullptr;
+  c.ticket = ticket;
   c.coop_start = coop_start; c.coop_verify = coop_verify; c.coop_window = coop_window; c.coop_helpers = coop_helpers;
   c.coop_payload = coop ? coop_payload + (size_t)blockIdx.x * 2 * (2 * dg_prob.n + 2 * dg_prob.nc) : nullptr;
   c.coop_total = (unsigned long long)(B * (group ? group_n : 1));
@@ -46,19 +49,31 @@ dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restric
 #endif
   dev_load_tables();
   if (TID == 0) dg_lds[dg_prob.L.scal + DG_COOP_FLIP] = 0.0;
+  if (coop && TID == 0) { unsigned long long zero = 0ull; __hip_atomic_compare_exchange_strong(&coop->t_first, &zero, wall_clock64(), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   while (true) {
     __syncthreads();
     if (TID == 0) dg_lds[dg_prob.L.scal + 63] = (double)atomicAdd(ticket, 1ULL);
     __syncthreads();
     int64_t b = (int64_t)dg_lds[dg_prob.L.scal + 63];
+    const DgParkEntry* resume = nullptr;
     if (b >= B * (group ? group_n : 1)) {
       // the queue is empty: from now on this launch only drains.  Tell the host (mapped, fine-grained memory) so that it
       // can start the next independent batch on the compute units that become free.
       if (drained && TID == 0) { __hip_atomic_store(drained, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-      // cooperative launches: stay and evaluate line-search trials for the workgroups that are still solving
-      if (coop) dev_coop_help(c);
-      break;
+      if (!coop) break;
+      // cooperative launches: resume a deferred scenario, the one that has cost the most so far first; with none waiting, stay and
+      // evaluate line-search trials for the workgroups that are still solving (until a deferred scenario turns up or the launch ends)
+      const long long slot = dev_park_pop(c);
+      if (slot < 0) {
+        if (dev_coop_help(c)) continue;
+        break;
+      }
+      dev_park_load(c, (unsigned int)slot);
+      resume = &c.park.entries[slot];
+      b = (int64_t)resume->ticket;
+      if (TID == 0) c.park.entries[slot].t_resume = wall_clock64() - AT_LOAD(&coop->t_first);
     }
+    const int64_t tk = b;
     if (group) {        // grouped launch (dgsqp_launch_staged_group): ticket -> (staged batch, scenario); every batch has its own buffers
       const int64_t gi = b / B;
       b -= gi * B;
@@ -66,16 +81,26 @@ dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restric
     }
     c.x0 = (cgptr)x0 + b * dg_prob.nq;
     c.trace = trace ? (gptr)trace + b * (int64_t)(1 + 2 * trace_cap) : nullptr;
-    if (c.trace && TID == 0) c.trace[0] = 0.0;
+    if (c.trace && TID == 0 && !resume) c.trace[0] = 0.0;
     c.itlog = itlog ? (gptr)itlog + b * (1 + (int64_t)itlog_cap * (dg_prob.n + dg_prob.nc)) : nullptr;
 #ifdef DG_PROF
     const long long sc_t0 = clock64();
 #endif
+    bool deferred = false;
+    int its = 0;
     if (dg_prob.par.variant == DGSQP_VARIANT_V2) dev_solve_v2(c, (cgptr)u_ws + b * dg_prob.n, b, O);
-    else dev_solve(c, (cgptr)u_ws + b * dg_prob.n, b, O);
-    if (coop && TID == 0) { __threadfence(); __hip_atomic_fetch_add(&coop->finished, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+    else deferred = dev_solve(c, (cgptr)u_ws + b * dg_prob.n, b, O, resume, (long long)tk, c.park.entries ? dev_bcast_u64(TID == 0 ? wall_clock64() : 0ull) : 0ull, &its);
+    if (resume && TID == 0) {
+      DgParkEntry* e = &c.park.entries[resume - c.park.entries];
+      e->t_done = wall_clock64() - AT_LOAD(&coop->t_first); e->final_its = its; e->final_qps = O.qp_solves ? O.qp_solves[b] : 0;
+    }
+    if (coop && !deferred && TID == 0) {
+      __threadfence();
+      __hip_atomic_fetch_add(&coop->done_iters, (unsigned long long)its, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&coop->finished, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #ifdef DG_PROF
-    if (TID == 0 && b < 16384) dg_prof_scn[b] = (unsigned long long)(clock64() - sc_t0);
+    if (TID == 0 && tk < 16384) dg_prof_scn[tk] = (resume ? dg_prof_scn[tk] : 0ull) + (unsigned long long)(clock64() - sc_t0);
 #endif
   }
 #ifdef DG_PROF
@@ -204,6 +229,11 @@ struct dgsqp_solver {
   size_t coop_bytes = 0;
   int coop_mode = 1;                  // 0 off, 1 synchronous calls only (nothing else is waiting for the compute units), 2 every launch
   bool coop_next_sync = false;        // (set by the synchronous entry points around their launch)
+  DgParkEntry* d_park = nullptr;      // deferral of long scenarios (cooperative launches): entries ...
+  double* d_park_store = nullptr;     // ... and their slots (LDS image + scratch image each)
+  size_t park_cap = 0;
+  int defer_min_it = 8;               // 0: off
+  double defer_factor = 2.0;
   dgsqp_comm_state* comm = nullptr;   // RCCL communicator + record buffers (dgsqp_comm.h), owned by the handle
   std::string err;
 };
@@ -323,6 +353,42 @@ static bool coop_for_launch(dgsqp_solver* h, int grid) {
   { const char* e = getenv("DGSQP_COOP_MIN_CHAIN"); if (chain < (e ? atoi(e) : 0)) return false; }
   return h->coop_mode == 2 || (h->coop_mode == 1 && h->coop_next_sync);
 }
+// Deferral of long scenarios for the cooperative launch about to be enqueued on h's stream (DgPark, dgsqp_device.h): a quarter of
+// the launch's scenarios may be deferred at a time (bounded by 16 GB of slots).  Off for launches that give every scenario its own
+// workgroup, for DG-SQP v2 and while logs are recorded.  (development knobs: DGSQP_DEFER = 0 switches it off, DGSQP_DEFER_MIN_IT,
+// DGSQP_DEFER_FACTOR override dgsqp_set_deferral.)
+static int park_for_launch(dgsqp_solver* h, bool coop, int grid, int64_t total, DgPark* out) {
+  memset(out, 0, sizeof(*out));
+  int min_it = h->defer_min_it;
+  double factor = h->defer_factor;
+  { const char* e = getenv("DGSQP_DEFER"); if (e && atoi(e) == 0) min_it = 0; }
+  { const char* e = getenv("DGSQP_DEFER_MIN_IT"); if (e) min_it = atoi(e); }
+  { const char* e = getenv("DGSQP_DEFER_FACTOR"); if (e) factor = atof(e); }
+  if (!coop || min_it <= 0 || total <= (int64_t)grid || h->hp.par.variant == DGSQP_VARIANT_V2 || h->trace_cap > 0 || h->itlog_cap > 0) return DGSQP_OK;
+  const size_t slot = (size_t)h->hp.L.total + (size_t)h->hp.ws_doubles;
+  double frac = 0.25;
+  { const char* e = getenv("DGSQP_DEFER_CAP_FRAC"); if (e) frac = atof(e); }
+  size_t cap = (size_t)((double)total * (frac > 0.0 && frac <= 1.0 ? frac : 0.25) + 1.0);
+  const size_t max_slots = (size_t)(16ull << 30) / (slot * sizeof(double));
+  if (cap > max_slots) cap = max_slots;
+  if (cap < 1) return DGSQP_OK;
+  if (cap > h->park_cap) {
+    if (h->d_park) (void)hipFree(h->d_park);
+    if (h->d_park_store) (void)hipFree(h->d_park_store);
+    h->d_park = nullptr; h->d_park_store = nullptr; h->park_cap = 0;
+    HIPCHK(h, hipMalloc((void**)&h->d_park, sizeof(DgParkEntry) * cap));
+    if (hipMalloc((void**)&h->d_park_store, sizeof(double) * slot * cap) != hipSuccess) {      // no room: solve without deferral
+      (void)hipGetLastError();
+      (void)hipFree(h->d_park); h->d_park = nullptr;
+      return DGSQP_OK;
+    }
+    h->park_cap = cap;
+  }
+  HIPCHK(h, hipMemsetAsync(h->d_park, 0, sizeof(DgParkEntry) * cap, h->stream));
+  out->entries = h->d_park; out->store = h->d_park_store; out->cap = (unsigned int)cap;
+  out->min_it = min_it; out->factor_x16 = (int)(factor * 16.0 + 0.5); out->slot_doubles = slot;
+  return DGSQP_OK;
+}
 static int grid_for(dgsqp_solver* h, int64_t B) {
   int64_t g = (int64_t)h->max_grid;
   if (B < g) g = B;
@@ -417,6 +483,8 @@ void dgsqp_destroy(dgsqp_handle_t h) {
   if (h->ticket) (void)hipFree(h->ticket);
   if (h->d_coop) (void)hipFree(h->d_coop);
   if (h->d_coop_payload) (void)hipFree(h->d_coop_payload);
+  if (h->d_park) (void)hipFree(h->d_park);
+  if (h->d_park_store) (void)hipFree(h->d_park_store);
   if (h->drained_host) (void)hipHostFree(h->drained_host);
   if (h->d_trace) (void)hipFree(h->d_trace);
   if (h->d_itlog) (void)hipFree(h->d_itlog);
@@ -504,10 +572,12 @@ int dgsqp_launch_staged(dgsqp_handle_t h) {
   HIPCHK(h, hipMemsetAsync(h->ticket, 0, sizeof(unsigned long long), h->stream));
   const bool coop = coop_for_launch(h, grid);
   if (coop) HIPCHK(h, hipMemsetAsync(h->d_coop, 0, h->coop_bytes, h->stream));
+  DgPark park;
+  { const int rcp = park_for_launch(h, coop, grid, h->B, &park); if (rcp) return rcp; }
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
   *h->drained_host = 0u;
   hipLaunchKernelGGL(dg_solve_kernel, dim3(grid), dim3(DG_BLOCK), h->lds_bytes, h->stream, h->dp, h->B, h->d_x0, h->d_uws, O, h->ws, h->ticket, trace, h->trace_cap, h->drained_dev, itlog, h->itlog_cap, (const DgBatch*)nullptr, 0,
-                     coop ? h->d_coop : (DgCoop*)nullptr, h->d_coop_payload, coop_start_trials(), coop_verify_mode(), coop_window_trials(), coop_max_helpers());
+                     coop ? h->d_coop : (DgCoop*)nullptr, h->d_coop_payload, coop_start_trials(), coop_verify_mode(), coop_window_trials(), coop_max_helpers(), park);
   HIPCHK(h, hipGetLastError());
   h->launch_gen++;
   h->launched_grid = grid;
@@ -548,12 +618,14 @@ int dgsqp_launch_staged_group(const dgsqp_handle_t* hs, int count) {
   HIPCHK(L, hipMemsetAsync(L->ticket, 0, sizeof(unsigned long long), L->stream));
   const bool coop = coop_for_launch(L, grid);
   if (coop) HIPCHK(L, hipMemsetAsync(L->d_coop, 0, L->coop_bytes, L->stream));
+  DgPark park;
+  { const int rcp = park_for_launch(L, coop, grid, L->B * count, &park); if (rcp) return rcp; }
   HIPCHK(L, hipEventRecord(L->ev[0], L->stream));
   *L->drained_host = 0u;
   SolveOutPtrs O0 = L->group_host[0].O;
   hipLaunchKernelGGL(dg_solve_kernel, dim3(grid), dim3(DG_BLOCK), L->lds_bytes, L->stream, L->dp, L->B, L->d_x0, L->d_uws, O0, L->ws, L->ticket,
                      (double*)nullptr, 0, L->drained_dev, (double*)nullptr, 0, (const DgBatch*)L->d_group, count,
-                     coop ? L->d_coop : (DgCoop*)nullptr, L->d_coop_payload, coop_start_trials(), coop_verify_mode(), coop_window_trials(), coop_max_helpers());
+                     coop ? L->d_coop : (DgCoop*)nullptr, L->d_coop_payload, coop_start_trials(), coop_verify_mode(), coop_window_trials(), coop_max_helpers(), park);
   HIPCHK(L, hipGetLastError());
   L->launch_gen++;
   for (int i = 0; i < count; i++) { hs[i]->launched_grid = grid; hs[i]->in_flight = true; hs[i]->group_leader = i == 0 ? nullptr : L; hs[i]->group_gen = L->launch_gen; }
@@ -595,6 +667,41 @@ int dgsqp_set_cooperative(dgsqp_handle_t h, int mode) {
   if (!h || mode < 0 || mode > 2) return DGSQP_E_ARG;
   h->coop_mode = mode;
   return DGSQP_OK;
+}
+
+int dgsqp_set_deferral(dgsqp_handle_t h, int min_iters, double factor) {
+  if (!h || min_iters < 0 || !(factor >= 0.0) || factor > 1000.0) return DGSQP_E_ARG;
+  h->defer_min_it = min_iters;
+  h->defer_factor = factor;
+  return DGSQP_OK;
+}
+
+int dgsqp_deferral_stats(dgsqp_handle_t h, uint64_t* out2) {
+  if (!h || !out2 || !h->d_coop) return DGSQP_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  { const int rc = wait_idle(h); if (rc) return rc; }
+  DgCoop hdr;
+  HIPCHK(h, hipMemcpy(&hdr, h->d_coop, sizeof(DgCoop) - sizeof(DgCoopJob), hipMemcpyDeviceToHost));
+  out2[0] = hdr.park_pushed < h->park_cap ? hdr.park_pushed : (uint64_t)h->park_cap;
+  out2[1] = hdr.park_resumed;
+  return DGSQP_OK;
+}
+
+int dgsqp_deferral_log(dgsqp_handle_t h, uint64_t* out, int64_t cap_rows) {
+  if (!h || !out || cap_rows < 0) return -1;
+  if (hipSetDevice(h->device) != hipSuccess || wait_idle(h) != DGSQP_OK || !h->d_park) return 0;
+  uint64_t st[2];
+  if (dgsqp_deferral_stats(h, st) != DGSQP_OK) return -1;
+  const int64_t n = (int64_t)st[0] < cap_rows ? (int64_t)st[0] : cap_rows;
+  std::vector<DgParkEntry> e((size_t)n);
+  if (n > 0 && hipMemcpy(e.data(), h->d_park, sizeof(DgParkEntry) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  for (int64_t i = 0; i < n; i++) {
+    uint64_t* r = out + 11 * i;
+    memcpy(r + 8, e[i].cond, sizeof(double) * 3);
+    r[0] = (uint64_t)e[i].ticket; r[1] = (uint64_t)e[i].sqp_it; r[2] = (uint64_t)e[i].total_qp; r[3] = e[i].key;
+    r[4] = e[i].t_park; r[5] = e[i].t_resume; r[6] = e[i].t_done; r[7] = ((uint64_t)(uint32_t)e[i].final_qps << 32) | (uint32_t)e[i].final_its;
+  }
+  return (int)n;
 }
 
 int dgsqp_coop_stats(dgsqp_handle_t h, uint64_t* out4 /* six values */) {

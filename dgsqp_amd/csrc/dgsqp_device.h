@@ -117,8 +117,38 @@ struct DgCoop {
   unsigned int pad1_;
   unsigned int mismatches;        // verify mode: helper values whose bits differ from the owner's own evaluation (must stay 0)
   unsigned long long used;        // helper values the owners consumed (diagnostic)
-  unsigned long long pad_[2];
+  // deferral of long scenarios (DgPark below)
+  unsigned int park_pushed;       // slots handed out
+  unsigned int park_avail;        // deferred scenarios nobody has resumed yet: polled by idle workgroups next to `open`
+  unsigned long long done_iters;  // SQP iterations of the scenarios finished so far (their mean sets the deferral threshold)
+  unsigned long long park_resumed;   // (diagnostic)
+  unsigned long long t_first;     // 100 MHz counter when the launch's first workgroup started (diagnostic time base)
   DgCoopJob jobs[1];              // 2 per workgroup of the grid (double buffered)
+};
+// Deferral of long scenarios (scheduling only; cooperative launches).  A launch cannot end before its slowest scenario, and nothing in a
+// scenario's inputs tells how long it will run; what does is its own history.  A scenario still iterating after ~twice the mean
+// iteration count of the launch's finished scenarios is DEFERRED while fresh tickets remain: its workgroup stores the scenario's whole
+// state -- the LDS arena and the workgroup's scratch -- in a slot and takes the next ticket.  Once the queue is empty the deferred
+// scenarios are resumed, the ones that have cost the most so far first (longest processing time first), by whichever workgroup is
+// free, from the stored image: the same instructions on the same data as an uninterrupted solve, bit for bit.  The long scenarios of
+// the launch's LAST batches thus start their long tails while the chip still has other work, not after it.
+struct DgParkEntry {
+  unsigned int state;             // 0 empty, 1 stored (published with release semantics), 2 taken
+  int sqp_it, rel_tol_its, total_qp;     // dev_solve's loop variables
+  long long ticket;               // the scenario (ticket of the launch)
+  unsigned long long key;         // 100 MHz ticks spent on it so far: resumed in descending order
+  unsigned long long t_park, t_resume, t_done;   // diagnostic (dgsqp_deferral_log): 100 MHz ticks since the launch's first ticket
+  int final_its, final_qps;
+  double cond[3];                 // convergence measures of its last iteration before it was set aside (diagnostic)
+};
+struct DgPark {
+  DgParkEntry* entries;           // null: no deferral
+  double* store;                  // cap slots of slot_doubles (LDS image, then scratch image)
+  unsigned int cap;
+  int min_it;                     // never defer before this many iterations ...
+  int factor_x16;                 // ... nor before factor x mean iterations of the finished scenarios (fixed point, 1/16)
+  int pad_;
+  unsigned long long slot_doubles;
 };
 
 struct Ctx {
@@ -129,6 +159,8 @@ struct Ctx {
   int coop_window; // helpers run at most this many trials ahead of the owner
   int coop_helpers; // at most this many idle workgroups evaluate trials; the others sleep until the launch ends
   int coop_verify; // diagnostic: the owner evaluates every trial itself as well and counts helper values that differ in their bits
+  DgPark park;     // deferral of long scenarios (entries == null: off)
+  const unsigned long long* ticket;   // the launch's ticket counter (deferral only while fresh tickets remain)
   gptr ws;      // this workgroup's global workspace
   cgptr x0;
   gptr trace;   // optional per-scenario event log: [0] = number of (code, value) pairs, then the pairs

@@ -40,6 +40,11 @@ struct DgDense {    // one distinct dense gradient: d x^a_k[idx] / du   or the o
 // issued together): gd[p0 .. p0+len) . v[v0 .. v0+len)
 #define DG_XL_KMAX 64     // XL layout: negative eigenvalues the tridiagonal _nearestPD handles (beyond: one-sided Jacobi, ~5x slower)
 #define DG_CHUNK 16
+// Storage of the dual method's inverse Cholesky factor T (upper triangular, dgsqp_solve.h: qpt_solve): column j = 8a + b holds its
+// rows 0..j followed by zeros up to row 8(a + 1) - 1, plus one unused entry; it starts at dg_tcol(j).  The zeros make groups of eight
+// rows / columns of the triangle rectangular (no per-element masks in the products); the extra entry skews the column starts over
+// the LDS banks.  dg_tcol(n) entries hold n columns.
+__host__ __device__ inline int dg_tcol(int j) { const int a = j >> 3, b = j & 7; return 8 * (a + 1) * (4 * a + b) + j; }
 struct DgTask {
   int32_t p0;
   uint16_t v0;
@@ -62,7 +67,7 @@ struct DgLds {
   // EIG scratch
   int g_Bp, g_V, g_tw, g_strip;  // packed P / packed Householder reflectors / tridiagonal workspace
   // QP scratch (P shares g_Bp)
-  int p_R, p_lam, p_c, p_w, p_r, p_y, p_t, p_alist, p_rd, p_yd2, p_yslot, p_yfree, p_dpart, p_act, p_part;
+  int p_R, p_lam, p_c, p_w, p_r, p_y, p_t, p_alist, p_rd, p_yd2, p_yslot, p_yfree, p_dpart, p_act, p_part, p_xu;
   // QP outputs that must survive trial evaluations
   int o_du, o_lhat;
   int x_el;  // XL layout with xl_el: packed lower triangle of the QP's elimination M = L~ D L~^T (overlaps the QP outputs and c_R, dead until J is built)
@@ -191,13 +196,15 @@ static inline std::string dg_build_layout(DgProb& D) {
   const int eig_end = o;
   // QP (P aliases Bp)
   o = L.scr + (D.big ? 0 : ((npk + 1) & ~1));
-  L.p_R = D.big == 2 ? -1 : take(npk); L.p_lam = take(n + 1); L.p_c = take(n + 1); L.p_w = take(n + 1); L.p_r = take(n + 1);
+  L.p_R = D.big == 2 ? -1 : take(D.classic_qp ? npk : dg_tcol(n));   // (the dual method's inverse factor T: padded columns, dg_tcol)
+  L.p_lam = take(n + 1); L.p_c = take(n + 9); L.p_w = take(n + 9); L.p_r = take(n + 9);   // (c, w are read in groups of eight: zero tail)
   L.p_y = take(n); L.p_t = take(n); L.p_alist = take((n + 2) / 2 + 1); L.p_rd = take(n + 1);
   if (!D.tab_const && D.big != 2) {   // the dual start borrows p_yd2 / p_dpart while its own vectors (5 of length n_c) sit at L.scr: keep them apart
     const int lsqr_size = 4 * ((nc + 1) & ~1) + (((nc > n ? nc : n) + 1) & ~1);
     if (o < L.scr + lsqr_size) o = L.scr + lsqr_size;
   }
   L.p_yd2 = take(nd); L.p_yslot = take((n + 2) / 2 + 1); L.p_yfree = take((n + 2) / 2 + 1); L.p_dpart = take(D.ntask); L.p_act = take(nc / 8 + 2); L.p_part = take(DG_NH * n);
+  L.p_xu = L.p_rd;     // unconstrained minimiser of the QP, x = x_u - Y lam at every point of the dual method (the slot the reciprocal diagonal of the Cholesky factor had)
   const int qp_end = o;
   // QP outputs live past the end of both the QP and EVAL scratch
   o = qp_end > eval_end ? qp_end : eval_end;

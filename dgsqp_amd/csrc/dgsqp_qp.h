@@ -1,14 +1,18 @@
 // QP sub-problem of one SQP iteration.
 //
 // _solve_qp (DGSQP.py:232-266):  min 1/2 x'Bx + q'x  s.t.  G x <= -g,  with P = B^-1 packed in LDS.
-// Dual active-set method (Goldfarb & Idnani 1983) in range-space form.  The problem is small (n <= 128 unknowns, a few
-// dozen active rows) and a step is a chain of short dependent operations, so the work is split by its nature:
-//   * block-wide phases (all wavefronts): scan for the most violated row, y = P a_p, dots with the dense gradients;
-//   * wavefront-0 sections without any block barrier: triangular solves with the Cholesky factor R of the Schur
-//     complement A P A^T (v_readlane broadcasts, rows in blocks of four), step lengths, updates, Givens deletions.
+// Dual active-set method (Goldfarb & Idnani 1983) in range-space form.  The problem is small (n <= 128 unknowns, up to n
+// active rows) and a step is a chain of short dependent operations, so the work is split by its nature:
+//   * block-wide phases (all wavefronts): the primal point x = x_u - Y lam, the scan for the most violated row, y = P a_p, dots
+//     with the dense gradients;
+//   * wavefront-0 sections without any block barrier: the step direction in the multipliers, r = S^-1 A_W y through the inverse
+//     Cholesky factor T of the Schur complement S = A_W P A_W^T (two lane-parallel products, qpt_solve), step lengths, updates of T
+//     (a bordering column per added row, column rotations per removed one, qpt_drop).
 // Vector element i lives in lane i & 63 of wavefront 0 (two registers per lane for n > 64).  For every active row j the
-// vector y_j = P a_j is kept (global scratch, L2 resident), so the primal step direction is  Y r - y  instead of a
-// second product with P, and the final iterative refinement needs no product with P either.
+// vector y_j = P a_j is kept (global scratch, L2 resident).  The primal point is a function of the multipliers,
+// x = -P (q + A_W^T lam) = x_u - Y lam: inside the wavefront-0 section only the violation of row p is tracked (it falls by t delta
+// per primal step), x itself is rebuilt block-wide once per added row -- a thrashing solve takes tens of thousands of steps, and a
+// product with Y per step (one wavefront reading m columns from L2) was three quarters of their cost.
 // The result is the KKT point OSQP(polish=True) returns when its polish succeeds.
 #pragma once
 
@@ -86,12 +90,12 @@ __device__ inline void qpw_ymul(cgptr Y, int n, int m, int lane, clptr cf, const
 
 // state of the active-set iteration kept in wavefront 0's registers between the block-wide phases
 struct QpwState {
-  double x0, x1;   // current primal point (elements lane, lane + 64)
+  double x0, x1;   // primal point (elements lane, lane + 64): only where a section updates it itself (warm start, polish)
   int m, nfree;    // active rows, free Y slots
   int ill;         // a row was accepted or rejected on a curvature below 1e-9 of its unprojected value (reg = 0 regime)
 };
 struct QpPtrs {
-  lptr xv, R, lam, cvec, wv, rv, rd, yv, tv, ddx, ddy, dpart, scal, prevlam;
+  lptr xv, R, lam, cvec, wv, rv, rd, yv, tv, ddx, ddy, dpart, scal, prevlam, xu, part;   // (R: the slot of the inverse factor T)
   lds_i_t *alist, *yslot, *yfree, *prev;
   lds_b_t* act;
   clptr gd, g, Pp;
@@ -106,7 +110,7 @@ __device__ inline QpPtrs qp_ptrs(const Ctx& c) {
   QpPtrs q;
   q.xv = lds + L.o_du; q.R = lds + L.p_R; q.lam = lds + L.p_lam; q.cvec = lds + L.p_c; q.wv = lds + L.p_w; q.rv = lds + L.p_r;
   q.rd = lds + L.p_rd; q.yv = lds + L.p_y; q.tv = lds + L.p_t; q.ddx = lds + L.yd; q.ddy = lds + L.p_yd2; q.dpart = lds + L.p_dpart;
-  q.scal = lds + L.scal; q.prevlam = lds + L.w_prevlam;
+  q.scal = lds + L.scal; q.prevlam = lds + L.w_prevlam; q.xu = lds + L.p_xu; q.part = lds + L.p_part;
   q.alist = (lds_i_t*)(lds + L.p_alist); q.yslot = (lds_i_t*)(lds + L.p_yslot); q.yfree = (lds_i_t*)(lds + L.p_yfree);
   q.prev = (lds_i_t*)(lds + L.w_prev); q.act = (lds_b_t*)(lds + L.p_act);
   q.gd = lds + L.gd; q.gdG = D.gd_global ? c.ws + D.ws_gd : nullptr; q.g = lds + L.g; q.Pp = lds + (D.big ? 0 : L.g_Bp); q.PpG = c.ws + D.ws_P;
@@ -135,6 +139,38 @@ __device__ inline void qp_row_products(const Ctx& c, const QpPtrs& q, int p) {
   }
   qp_dense_dots(D, q.gd, q.yv, q.dpart, q.ddy);
 }
+// All wavefronts: xv = x_u - Y lam for the m active rows (slots in yslot).  Thread = element i x quarter of the columns: every
+// thread has its loads from L2 in flight together; the four partial sums meet in LDS.
+__device__ inline void qp_x_from_lambda(const QpPtrs& q, int m) {
+  const DgProb& D = dg_prob;
+  const int n = D.n;
+  constexpr int NSEG = NT / 128;
+  const int i = TID & 127, sg = TID >> 7;
+  __syncthreads();
+  if (i < n) {
+    const int len = (m + NSEG - 1) / NSEG;
+    const int j0 = sg * len, j1 = (j0 + len < m) ? j0 + len : m;
+    double a[4] = {0, 0, 0, 0};
+    int j = j0;
+    for (; j + 7 < j1; j += 8) {
+      double yv[8], lv[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) { yv[k] = q.Y[(int64_t)q.yslot[j + k] * n + i]; lv[k] = q.lam[j + k]; }
+#pragma unroll
+      for (int k = 0; k < 8; k++) a[k & 3] = __builtin_fma(yv[k], lv[k], a[k & 3]);
+    }
+    for (; j < j1; j++) a[0] = __builtin_fma(q.Y[(int64_t)q.yslot[j] * n + i], q.lam[j], a[0]);
+    q.part[sg * n + i] = (a[0] + a[1]) + (a[2] + a[3]);
+  }
+  __syncthreads();
+  if (TID < n) {
+    double s = 0;
+#pragma unroll
+    for (int g = 0; g < NSEG; g++) s += q.part[g * n + TID];
+    q.xv[TID] = q.xu[TID] - s;
+  }
+  __syncthreads();
+}
 // All wavefronts: most violated inactive row at the point held in xv (lowest index on ties); NONE if the point is feasible.
 __device__ inline int qp_scan(const QpPtrs& q, double tol) {
   const DgProb& D = dg_prob;
@@ -153,21 +189,19 @@ __device__ inline int qp_scan(const QpPtrs& q, double tol) {
 }
 // wavefront 0: append row p (whose y is in yv, a_p in tv, w in wv) to the factorisation
 __device__ inline void qpw_append(const QpPtrs& q, QpwState& S, int n, int lane, int p, double delta, double lam_p) {
+  // (r = T w of the step that made p active is in rv: the new column of T is (-r / rho; 1 / rho), rho^2 = delta)
   const int m = S.m;
-  if (lane < m) q.R[tri(m, lane)] = q.wv[lane];
-  if (lane + 64 < m) q.R[tri(m, lane + 64)] = q.wv[lane + 64];
+  const double ird = 1.0 / sqrt(delta);
+  qpt_put_column(q.R, m, lane, lane < m ? -q.rv[lane] * ird : 0.0, lane + 64 < m ? -q.rv[lane + 64] * ird : 0.0, ird);
   const int slot = q.yfree[S.nfree - 1];
   if (lane < n) q.Y[(int64_t)slot * n + lane] = q.yv[lane];
   if (lane + 64 < n) q.Y[(int64_t)slot * n + lane + 64] = q.yv[lane + 64];
-  if (lane == 0) {
-    const double sd = sqrt(delta);
-    q.R[tri(m, m)] = sd; q.rd[m] = 1.0 / sd; q.alist[m] = p; q.lam[m] = lam_p; q.act[p] = 1; q.yslot[m] = slot;
-  }
+  if (lane == 0) { q.alist[m] = p; q.lam[m] = lam_p; q.act[p] = 1; q.yslot[m] = slot; }
   S.nfree--; S.m++;
 }
 __device__ inline void qpw_remove(const QpPtrs& q, QpwState& S, int lane, int jd) {
   const int freed = q.yslot[jd];
-  qpw_drop(q.R, q.rd, q.alist, q.yslot, q.lam, q.act, S.m, jd, lane);
+  qpt_drop(q.R, q.alist, q.yslot, q.lam, q.act, S.m, jd, lane, q.wv, q.rv);
   if (lane == 0) q.yfree[S.nfree] = freed;
   S.nfree++; S.m--;
 }
@@ -183,14 +217,21 @@ __device__ inline int qpw_add_constraint(const QpPtrs& q, QpwState& S, int lane,
   const double app = wave_sum(t0 * y0 + t1 * y1), apap = wave_sum(t0 * t0 + t1 * t1);
   const double gp = q.g[p];
   double lp = 0.0;
+  (void)npk;
+  // a_p.x - b_p  (b = -g), > 0, at the point the scan looked at; every primal step x += t z lowers it by t delta (a_p.z = -delta)
+  double viol = wave_sum(t0 * (okA ? q.xv[lane] : 0.0) + t1 * (okB ? q.xv[lane + 64] : 0.0)) + gp;
   for (int inner = 0; inner < 4 * (n + D.nc); inner++) {
-    // ---- step 2a: directions.  c = A_A y ; R^T w = c ; r = R^-1 w
+    // ---- step 2a: directions.  c = A_A y ; w = T^T c ; r = T w
     PROF_BEGIN(pq3);
     const int m = S.m;
+    PROF_BEGIN(pqa);
     for (int j = lane; j < m; j += 64) q.cvec[j] = qpw_row_dot(D, ld_row(q.alist[j]), q.yv, q.ddy);
-    const double viol = wave_sum(t0 * S.x0 + t1 * S.x1) + gp;   // a_p.x - b_p  (b = -g), > 0
+    PROF_END(PH_W_BUILD, pqa);
+    PROF_COUNT(PH_C_MBUILD, m);
     double r0, r1;
-    const double ww = qpw_solve(q.R, q.rd, m, npk, lane, q.cvec, q.wv, q.rv, r0, r1);
+    PROF_BEGIN(pqb);
+    const double ww = qpt_solve(q.R, m, lane, q.cvec, q.wv, q.rv, r0, r1);
+    PROF_END(PH_W_MULT, pqb);
     // ---- step 2b: step lengths.  t1 keeps the multipliers >= 0, t2 makes constraint p active
     double ta = INFINITY; int jd = NONE;
     if (lane < m && r0 > 0) { ta = q.lam[lane] / r0; jd = lane; }
@@ -203,23 +244,20 @@ __device__ inline int qpw_add_constraint(const QpPtrs& q, QpwState& S, int lane,
     // the explicit primal direction z = Y r - y decides: for an independent row -a_p.z reproduces delta, for a dependent
     // one both are unrelated noise.
     bool indep = m < n && delta > 3e-15 * app && delta > 1e-18 * apap;
-    double z0 = 0.0, z1 = 0.0;
-    if (indep) {
+    if (indep && !(delta > 1e-9 * app)) {
       double d0, d1;
       qpw_ymul(q.Y, n, m, lane, q.rv, q.yslot, d0, d1);
-      z0 = d0 - y0; z1 = d1 - y1;
-      if (!(delta > 1e-9 * app)) {
-        S.ill = 1;
-        const double dz = -wave_sum(t0 * z0 + t1 * z1);
-        indep = __builtin_fabs(delta - dz) <= 0.3 * delta;
-      }
+      const double z0 = d0 - y0, z1 = d1 - y1;
+      S.ill = 1;
+      const double dz = -wave_sum(t0 * z0 + t1 * z1);
+      indep = __builtin_fabs(delta - dz) <= 0.3 * delta;
     }
     const double tb = indep ? viol / delta : INFINITY;
     const double t = fmin(ta, tb);
     PROF_END(PH_Q_DIR, pq3);
     if (!(t < INFINITY)) return 1;
     PROF_BEGIN(pq4);
-    if (indep) { S.x0 += t * z0; S.x1 += t * z1; }   // x += t z
+    if (indep) viol -= t * delta;                    // x += t z, z = Y r - y
     if (lane < m) q.lam[lane] -= t * r0;
     if (lane + 64 < m) q.lam[lane + 64] -= t * r1;
     lp += t;
@@ -262,11 +300,12 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
   for (int r = TID; r < nc; r += NT) { q.act[r] = 0; lhat[r] = 0.0; }
   if (TID == 0) q.scal[2] = 0.0;   // set when the active-set loop meets the ill-conditioned regime
   for (int i = TID; i < n; i += NT) q.yfree[i] = n - 1 - i;     // stack of free Y slots (top = lowest index)
-  dev_p_mul(c, lds + L.q, q.xv, -1.0);  // unconstrained minimiser x = -P q
+  dev_p_mul(c, lds + L.q, q.xu, -1.0);  // unconstrained minimiser x_u = -P q
+  for (int i = TID; i < n; i += NT) q.xv[i] = q.xu[i];
   __syncthreads();
   QpwState S;
   S.m = 0; S.nfree = n; S.ill = 0;
-  S.x0 = (w0 && okA) ? q.xv[lane] : 0.0; S.x1 = (w0 && okB) ? q.xv[lane + 64] : 0.0;
+  S.x0 = 0.0; S.x1 = 0.0;
 
   // ---- warm start from the final active set W of this scenario's previous QP.  (x(W'), W') with x(W') the minimiser on
   // the rows W' held as equalities and multipliers >= 0 is a valid S-pair for any independent subset W' of W, so the
@@ -277,8 +316,8 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
     // (a) y_j = P a_j for the first NB guessed rows, straight into Y slot j: box / rate rows are column copies (one
     //     wavefront per row), dense rows go through the block-wide product.
     int NB = nprev < 48 ? nprev : 48;
-    { int cap = (int)sqrt((double)npk) - 1; if (NB > cap) NB = cap; if (NB < 0) NB = 0; }
-    lptr Sb = q.R + NB * (NB + 1) / 2;     // S = A Y (packed by rows) lives behind the part of R the batch can fill
+    while (NB > 0 && dg_tcol(NB) + NB * (NB + 1) / 2 > dg_tcol(n)) NB--;
+    lptr Sb = q.R + dg_tcol(NB);           // S = A Y (packed by rows) lives behind the part of T the batch can fill
     for (int jj = TID >> 6; jj < NB; jj += NT / 64) {
       const DgRow Rw = ld_row(q.prev[jj]);
       if (Rw.dense >= 0) continue;
@@ -349,16 +388,15 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
         const int rowj = j * (j + 1) / 2;
         for (int k = lane; k < m; k += 64) q.cvec[k] = Sb[rowj + q.yslot[k]];
         const double app = Sb[rowj + j], apap = q.tv[j];
-        double wa, wb;
-        const double ww = qpw_fwd(q.R, q.rd, m, npk, lane, q.cvec, q.wv, wa, wb);
+        double ra, rb;
+        const double ww = qpt_solve(q.R, m, lane, q.cvec, q.wv, q.rv, ra, rb);
         const double delta = app - ww;
         if (m < n && delta > 1e-11 * app && delta > 1e-18 * apap) {   // conservative: a skipped guess is found again by the main loop
-          if (lane < m) q.R[tri(m, lane)] = wa;
-          if (lane + 64 < m) q.R[tri(m, lane + 64)] = wb;
+          const double ird = 1.0 / sqrt(delta);
+          qpt_put_column(q.R, m, lane, -ra * ird, -rb * ird, ird);
           if (lane == 0) {
             const int p = q.prev[j];
-            const double sd = sqrt(delta);
-            q.R[tri(m, m)] = sd; q.rd[m] = 1.0 / sd; q.alist[m] = p; q.lam[m] = q.prevlam[j]; q.act[p] = 1; q.yslot[m] = j;
+            q.alist[m] = p; q.lam[m] = q.prevlam[j]; q.act[p] = 1; q.yslot[m] = j;
           }
           S.m++;
         }
@@ -385,8 +423,8 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
         const double t0 = okA ? q.tv[lane] : 0.0, t1 = okB ? q.tv[lane + 64] : 0.0;
         const double y0 = okA ? q.yv[lane] : 0.0, y1 = okB ? q.yv[lane + 64] : 0.0;
         const double app = wave_sum(t0 * y0 + t1 * y1), apap = wave_sum(t0 * t0 + t1 * t1);
-        double wa, wb;
-        const double ww = qpw_fwd(q.R, q.rd, m, npk, lane, q.cvec, q.wv, wa, wb);
+        double ra, rb;
+        const double ww = qpt_solve(q.R, m, lane, q.cvec, q.wv, q.rv, ra, rb);
         const double delta = app - ww;
         if (m < n && delta > 1e-11 * app && delta > 1e-18 * apap) qpw_append(q, S, n, lane, p, delta, q.prevlam[jj]);
       }
@@ -402,7 +440,7 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
       while (S.m > 0) {
         const int m = S.m;
         double r0, r1;
-        (void)qpw_solve(q.R, q.rd, m, npk, lane, q.cvec, q.wv, q.rv, r0, r1);   // rv = l_eq
+        (void)qpt_solve(q.R, m, lane, q.cvec, q.wv, q.rv, r0, r1);   // rv = l_eq
         const double l0 = lane < m ? q.lam[lane] : 0.0, l1 = lane + 64 < m ? q.lam[lane + 64] : 0.0;
         double t = INFINITY; int jd = NONE;
         if (lane < m && r0 < 0.0) { t = l0 > 0.0 ? l0 / (l0 - r0) : 0.0; jd = lane; }
@@ -421,15 +459,10 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
         if (lane + 64 >= jd && lane + 65 < m) q.cvec[lane + 64] = cb;
       }
       PROF_COUNT(PH_C_MWARM, S.m);
-      if (S.m > 0) {   // x = x_unc - Y l
-        double d0, d1;
-        qpw_ymul(q.Y, n, S.m, lane, q.lam, q.yslot, d0, d1);
-        S.x0 -= d0; S.x1 -= d1;
-        if (okA) q.xv[lane] = S.x0;
-        if (okB) q.xv[lane + 64] = S.x1;
-      }
+      if (lane == 0) q.scal[1] = (double)S.m;
     }
     __syncthreads();
+    qp_x_from_lambda(q, (int)q.scal[1]);     // x = x_u - Y l
     PROF_END(PH_Q_WARM, pqw);
   }
 
@@ -456,28 +489,18 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
       PROF_END(PH_Q_Y, pq2);
       if (w0) {
         const int st = qpw_add_constraint(q, S, lane, p);
-        if (okA) q.xv[lane] = S.x0;
-        if (okB) q.xv[lane + 64] = S.x1;
-        if (lane == 0) { q.scal[0] = (double)st; q.scal[2] = (double)S.ill; }
+        if (lane == 0) { q.scal[0] = (double)st; q.scal[1] = (double)S.m; q.scal[2] = (double)S.ill; }
       }
       __syncthreads();
       if (q.scal[0] != 0.0) { ret = 1; break; }
+      PROF_BEGIN(pq7);
+      qp_x_from_lambda(q, (int)q.scal[1]);
+      PROF_END(PH_Q_STEP, pq7);
     }
     if (ret != 0 || (round > 0 && added == 0)) break;
     PROF_BEGIN(pq6);
-    // With reg = 0 (P spans ten decades) the increments of x carry absolute errors of 1e-6 and a legitimate row can be
-    // taken for a dependent one: put x back on the stationarity manifold of the multipliers, x = -P (q + A^T lam).
-    if (added > 0 && q.scal[2] != 0.0) {
-      dev_p_mul(c, lds + L.q, q.yv, -1.0);
-      if (w0) {
-        double d0, d1;
-        qpw_ymul(q.Y, n, S.m, lane, q.lam, q.yslot, d0, d1);
-        S.x0 = (okA ? q.yv[lane] : 0.0) - d0; S.x1 = (okB ? q.yv[lane + 64] : 0.0) - d1;
-        if (okA) q.xv[lane] = S.x0;
-        if (okB) q.xv[lane + 64] = S.x1;
-      }
-      __syncthreads();
-    }
+    // (x sits on the stationarity manifold of the multipliers, x = -P (q + A^T lam), by construction: qp_x_from_lambda)
+    if (w0) { S.x0 = okA ? q.xv[lane] : 0.0; S.x1 = okB ? q.xv[lane + 64] : 0.0; }
     // Iterative refinement on the active set: P is an explicit inverse, so the active rows hold to ~1e-12 only; two
     // projection steps  x <- x - Y S^-1 (A x - b),  lam <- lam + S^-1 (A x - b)  (Y = P A^T) bring them to rounding level.
     for (int pass = 0; pass < 2; pass++) {
@@ -486,7 +509,7 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
         const int m = S.m;
         for (int j = lane; j < m; j += 64) q.cvec[j] = q.g[q.alist[j]] + qpw_row_dot(D, ld_row(q.alist[j]), q.xv, q.ddx);
         double r0, r1;
-        (void)qpw_solve(q.R, q.rd, m, npk, lane, q.cvec, q.wv, q.rv, r0, r1);
+        (void)qpt_solve(q.R, m, lane, q.cvec, q.wv, q.rv, r0, r1);
         double d0, d1;
         qpw_ymul(q.Y, n, m, lane, q.rv, q.yslot, d0, d1);
         S.x0 -= d0; S.x1 -= d1;

@@ -556,158 +556,162 @@ __device__ inline double g_row_coef(const DgProb& D, GP gd, int r, int col) {
   }
 }
 
-// wavefront-0 helpers: solve (R^T R) r = c for the packed triangular factor R of order m (<= 128); rd holds 1/R_ii.
-// Lane j keeps entries j and j+64 in registers; pivots are broadcast with v_readlane.  Rows are processed in blocks of
-// four: the 4 reciprocal diagonals and the 4x2 matrix entries of a block are read from LDS up front (independent of the
-// recurrence), so that the sequential part of a step is readlane -> mul -> fma.
-#define QP_NPK_CLAMP(ix) ((ix) < npk ? (ix) : npk - 1)
-__device__ inline double qpw_fwd(clptr R, clptr rd, int m, int npk, int lane, clptr cvec, lptr wv, double& w0o, double& w1o) {
-  double c0 = lane < m ? cvec[lane] : 0.0, c1 = lane + 64 < m ? cvec[lane + 64] : 0.0;
-  double w0 = 0, w1 = 0;
-  const int rowA = lane * (lane + 1) / 2, rowB = (lane + 64) * (lane + 65) / 2;
-  int i = 0;
-  if (m <= 64) {   // common case: one register per lane
-    for (; i + 3 < m; i += 4) {
-      double d[4], a[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) { d[k] = rd[i + k]; a[k] = R[QP_NPK_CLAMP(rowA + i + k)]; }
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int ii = i + k;
-        const double wi = lane_bcast(c0, ii) * d[k];
-        w0 = lane == ii ? wi : w0;
-        c0 -= (lane > ii && lane < m) ? a[k] * wi : 0.0;
-      }
-    }
-  }
-  for (; i + 3 < m; i += 4) {
-    double d[4], a[4], b[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      d[k] = rd[i + k];
-      a[k] = R[QP_NPK_CLAMP(rowA + i + k)];
-      b[k] = R[QP_NPK_CLAMP(rowB + i + k)];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int ii = i + k;
-      const double wi = lane_bcast(ii < 64 ? c0 : c1, ii & 63) * d[k];
-      if (lane == (ii & 63)) { if (ii < 64) w0 = wi; else w1 = wi; }
-      c0 -= (lane > ii && lane < m) ? a[k] * wi : 0.0;
-      c1 -= (lane + 64 > ii && lane + 64 < m) ? b[k] * wi : 0.0;
-    }
-  }
-  for (; i < m; i++) {
-    const double wi = lane_bcast(i < 64 ? c0 : c1, i & 63) * rd[i];
-    if (lane == (i & 63)) { if (i < 64) w0 = wi; else w1 = wi; }
-    if (lane > i && lane < m) c0 -= R[rowA + i] * wi;
-    if (lane + 64 > i && lane + 64 < m) c1 -= R[rowB + i] * wi;
-  }
-  if (lane < m) wv[lane] = w0;
-  if (lane + 64 < m) wv[lane + 64] = w1;
-  w0o = w0; w1o = w1;
-  return wave_sum(w0 * w0 + w1 * w1);
-}
-// Writes w = R^-T c to wv, r = R^-1 w to rv and returns |w|^2 to every lane.
-__device__ inline double qpw_solve(clptr R, clptr rd, int m, int npk, int lane, clptr cvec, lptr wv, lptr rv,
-                                       double& r0_out, double& r1_out) {
+// wavefront-0 helpers of the dual active-set QP (dgsqp_qp.h).  The Schur complement S = A_W P A_W^T of the active rows is held
+// through the INVERSE of its Cholesky factor, T = R^-1 (S = R^T R; upper triangular), so that  w = R^-T c = T^T c  and
+// r = R^-1 w = T w  are two lane-parallel products (column sums, row sums: m independent multiply-adds per lane) instead of two
+// triangular solves of m dependent steps each -- the active-set loop of a thrashing scenario runs tens of thousands of them.
+// Adding a row borders R by (w; rho): T gets the column (-r / rho; 1 / rho), r = T w -- both at hand.  Removing row jd: the Givens
+// rotations that restore the triangle of R after its column jd is deleted act on the COLUMNS of T; they are the rotations that sweep
+// row jd of T into the last column, so their angles follow from that row alone (running norms), every row of T is then transformed
+// independently (lane = row), and T' is what remains without row jd and the last column.
+// Storage: columns padded with zeros to a multiple of eight rows (dg_tcol, dgsqp_layout.h) -- a group of eight rows of a column, or
+// of eight columns at a row, is then either entirely inside (entries or zeros) or entirely outside the lane's part of the triangle:
+// one execution mask per group, no masks or address clamps per element, neighbouring entries read in pairs.
+typedef __attribute__((address_space(3))) int lds_i_t;
+typedef __attribute__((address_space(3))) unsigned char lds_b_t;
+#define QPT_U 8
+// Writes w = T^T c to wv, r = T w to rv (lane j holds entries j and j + 64) and returns |w|^2 to every lane.  cvec / wv must be
+// readable (finite values or zeros) up to the next multiple of eight beyond m: both are zero-filled here.
+__device__ inline double qpt_solve(clptr T, int m_, int lane, lptr cvec, lptr wv, lptr rv, double& r0_out, double& r1_out) {
+  const int m = __builtin_amdgcn_readfirstlane(m_);       // (uniform by construction; says so to the compiler: scalar loops and branches)
+  const bool two = m > 64;
+  const int m1 = two ? 64 : m;                 // rows / columns of the first half
+  const int m8 = (m + 7) & ~7;
+  const int la = lane < m ? lane : 0, lb = lane + 64 < m ? lane + 64 : 64;
+  const int colA = dg_tcol(la), colB = dg_tcol(lb);
+  if (lane >= m && lane < m8) cvec[lane] = 0.0;
+  if (lane + 64 >= m && lane + 64 < m8) cvec[lane + 64] = 0.0;
   double w0, w1;
-  const double ww = qpw_fwd(R, rd, m, npk, lane, cvec, wv, w0, w1);
-  double r0 = 0, r1 = 0;
-  int j = m - 1;
-  if (m <= 64) {
-    for (; j >= 3; j -= 4) {
-      double d[4], a[4];
+  {
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    // rows i < m1 in groups of eight: column `lane` takes part while i <= lane (its zeros cover the rest of its last group),
+    // column lane + 64 in every group
+    for (int i = 0; i < m1; i += QPT_U) {
+      double cc[QPT_U];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int jj = j - k;
-        d[k] = rd[jj];
-        a[k] = R[jj * (jj + 1) / 2 + (lane < jj ? lane : jj)];
+      for (int k = 0; k < QPT_U; k++) cc[k] = cvec[i + k];
+      if (la >= i) {
+        double ta[QPT_U];
+#pragma unroll
+        for (int k = 0; k < QPT_U; k++) ta[k] = T[colA + i + k];
+#pragma unroll
+        for (int k = 0; k < QPT_U; k++) a[k & 3] = __builtin_fma(ta[k], cc[k], a[k & 3]);
       }
+      if (two) {
+        double tb[QPT_U];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int jj = j - k;
-        const double rj = lane_bcast(w0, jj) * d[k];
-        r0 = lane == jj ? rj : r0;
-        w0 -= lane < jj ? a[k] * rj : 0.0;
+        for (int k = 0; k < QPT_U; k++) tb[k] = T[colB + i + k];
+#pragma unroll
+        for (int k = 0; k < QPT_U; k++) b[k & 3] = __builtin_fma(tb[k], cc[k], b[k & 3]);
       }
     }
-  }
-  for (; j >= 3; j -= 4) {
-    double d[4], a[4], b[4];
+    // rows i >= 64: only columns lane + 64 >= i
+    if (two)
+      for (int i = 64; i < m; i += QPT_U) {
+        if (lb >= i) {
+          double tb[QPT_U], cc[QPT_U];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int jj = j - k, base = jj * (jj + 1) / 2;
-      d[k] = rd[jj];
-      a[k] = R[base + (lane < jj ? lane : jj)];
-      b[k] = R[base + (lane + 64 < jj ? lane + 64 : jj)];
-    }
+          for (int k = 0; k < QPT_U; k++) { cc[k] = cvec[i + k]; tb[k] = T[colB + i + k]; }
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int jj = j - k;
-      const double rj = lane_bcast(jj < 64 ? w0 : w1, jj & 63) * d[k];
-      if (lane == (jj & 63)) { if (jj < 64) r0 = rj; else r1 = rj; }
-      w0 -= lane < jj ? a[k] * rj : 0.0;
-      w1 -= lane + 64 < jj ? b[k] * rj : 0.0;
-    }
+          for (int k = 0; k < QPT_U; k++) b[k & 3] = __builtin_fma(tb[k], cc[k], b[k & 3]);
+        }
+      }
+    w0 = lane < m ? (a[0] + a[1]) + (a[2] + a[3]) : 0.0;
+    w1 = lane + 64 < m ? (b[0] + b[1]) + (b[2] + b[3]) : 0.0;
   }
-  for (; j >= 0; j--) {
-    const double rj = lane_bcast(j < 64 ? w0 : w1, j & 63) * rd[j];
-    if (lane == (j & 63)) { if (j < 64) r0 = rj; else r1 = rj; }
-    if (lane < j) w0 -= R[tri(j, lane)] * rj;
-    if (lane + 64 < j) w1 -= R[tri(j, lane + 64)] * rj;
+  if (lane < m8) wv[lane] = w0;
+  if (lane + 64 < m8) wv[lane + 64] = w1;
+  const double ww = wave_sum(w0 * w0 + w1 * w1);
+  double r0, r1;
+  {
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    // columns j in groups of eight (beyond m: w = 0 against zeros or entries of T's slot -- every column < m8 <= 8 ceil(n / 8) is inside
+    // it): row `lane` takes part while lane < j + 8 (the columns' zeros cover the rows below their diagonal inside the group)
+    for (int j = 0; j < m; j += QPT_U) {
+      const int base = dg_tcol(j), stride = 8 * ((j >> 3) + 1) + 1;
+      const int last = m - 1 - j;      // columns beyond m - 1 (last group only) hold whatever was there: read column m - 1 instead, w = 0 there
+      double wj[QPT_U];
+#pragma unroll
+      for (int k = 0; k < QPT_U; k++) wj[k] = wv[j + k];
+      if (la < j + QPT_U) {
+        double ta[QPT_U];
+#pragma unroll
+        for (int k = 0; k < QPT_U; k++) ta[k] = T[base + (k < last ? k : last) * stride + la];
+#pragma unroll
+        for (int k = 0; k < QPT_U; k++) a[k & 3] = __builtin_fma(ta[k], wj[k], a[k & 3]);
+      }
+      if (two && j >= 64 && lb < j + QPT_U) {
+        double tb[QPT_U];
+#pragma unroll
+        for (int k = 0; k < QPT_U; k++) tb[k] = T[base + (k < last ? k : last) * stride + lb];
+#pragma unroll
+        for (int k = 0; k < QPT_U; k++) b[k & 3] = __builtin_fma(tb[k], wj[k], b[k & 3]);
+      }
+    }
+    r0 = lane < m ? (a[0] + a[1]) + (a[2] + a[3]) : 0.0;
+    r1 = lane + 64 < m ? (b[0] + b[1]) + (b[2] + b[3]) : 0.0;
   }
   if (lane < m) rv[lane] = r0;
   if (lane + 64 < m) rv[lane + 64] = r1;
   r0_out = r0; r1_out = r1;
   return ww;
 }
-
-// wavefront-0 helper: remove active constraint jd (column deletion in R followed by Givens rotations)
-typedef __attribute__((address_space(3))) int lds_i_t;
-typedef __attribute__((address_space(3))) unsigned char lds_b_t;
-__device__ inline void qpw_drop(lptr R, lptr rd, lds_i_t* alist, lds_i_t* yslot, lptr lam, lds_b_t* act, int m, int jd, int lane) {
-    const int mn = m - 1;
-    const int ca = lane, cb = lane + 64;
-    const bool sa = ca >= jd && ca < mn, sb = cb >= jd && cb < mn;
-    if (lane == 0) act[alist[jd]] = 0;
-    // old diagonals become the sub-diagonal of the shifted columns
-    double suba = sa ? R[tri(ca + 1, ca + 1)] : 0.0, subb = sb ? R[tri(cb + 1, cb + 1)] : 0.0;
-    const int ala = sa ? alist[ca + 1] : 0, alb = sb ? alist[cb + 1] : 0;
-    const int ysa = sa ? yslot[ca + 1] : 0, ysb = sb ? yslot[cb + 1] : 0;
-    const double lma = sa ? lam[ca + 1] : 0.0, lmb = sb ? lam[cb + 1] : 0.0;
-    for (int i = 0; i < mn; i++) {  // row-synchronous shift: new column cc <- old column cc+1, rows 0..cc
-      double ta = 0, tb = 0;
-      const bool da = sa && i <= ca, db = sb && i <= cb;
-      if (da) ta = R[tri(ca + 1, i)];
-      if (db) tb = R[tri(cb + 1, i)];
-      if (da) R[tri(ca, i)] = ta;
-      if (db) R[tri(cb, i)] = tb;
-    }
-    if (sa) { alist[ca] = ala; lam[ca] = lma; yslot[ca] = ysa; }
-    if (sb) { alist[cb] = alb; lam[cb] = lmb; yslot[cb] = ysb; }
-    for (int k = jd; k < mn; k++) {
-      double dk = 0;
-      if (lane == (k & 63)) dk = R[tri(k, k)];
-      dk = lane_bcast(dk, k & 63);
-      const double sub = lane_bcast(k < 64 ? suba : subb, k & 63);
-      const double h = sqrt(dk * dk + sub * sub);     // entries of a Cholesky factor: no overflow concern
-      const double ih = h > 0 ? 1.0 / h : 0.0;
-      const double cs = h > 0 ? dk * ih : 1.0, sn = sub * ih;
-      if (lane == (k & 63)) { R[tri(k, k)] = h; rd[k] = ih; }
-      if (ca > k && ca < mn) {
-        const double ra = R[tri(ca, k)];
-        if (ca == k + 0) {}
-        const double rb = R[tri(ca, k + 1)];
-        R[tri(ca, k)] = cs * ra + sn * rb;
-        R[tri(ca, k + 1)] = -sn * ra + cs * rb;
-      }
-      if (cb > k && cb < mn) {
-        const double ra = R[tri(cb, k)], rb = R[tri(cb, k + 1)];
-        R[tri(cb, k)] = cs * ra + sn * rb;
-        R[tri(cb, k + 1)] = -sn * ra + cs * rb;
-      }
-    }
+// column m of T (m rows before): the entries v_i (lane i and i + 64 hold v0, v1), the diagonal d, zeros down to the end of the group
+__device__ inline void qpt_put_column(lptr T, int m, int lane, double v0, double v1, double d) {
+  const int base = dg_tcol(m), pend = 8 * ((m >> 3) + 1);
+  if (lane < pend) T[base + lane] = lane < m ? v0 : (lane == m ? d : 0.0);
+  if (lane + 64 < pend) T[base + lane + 64] = lane + 64 < m ? v1 : (lane + 64 == m ? d : 0.0);
+}
+// inclusive prefix sum over the 64 lanes of a wavefront
+__device__ inline double wave_prefix_sum(double v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const double t = __shfl_up(v, d); if (lane >= d) v += t; }
+  return v;
+}
+// remove active constraint jd (m rows before): bookkeeping arrays shift down, T is rotated (see above).  cs / sn: two scratch vectors
+// of m doubles in LDS.
+__device__ inline void qpt_drop(lptr T, lds_i_t* alist, lds_i_t* yslot, lptr lam, lds_b_t* act, int m_, int jd_, int lane, lptr cs, lptr sn) {
+  const int m = __builtin_amdgcn_readfirstlane(m_), jd = __builtin_amdgcn_readfirstlane(jd_);
+  const int mn = m - 1;
+  const int ca = lane, cb = lane + 64;
+  const bool sa = ca >= jd && ca < mn, sb = cb >= jd && cb < mn;
+  if (lane == 0) act[alist[jd]] = 0;
+  const int ala = sa ? alist[ca + 1] : 0, alb = sb ? alist[cb + 1] : 0;
+  const int ysa = sa ? yslot[ca + 1] : 0, ysb = sb ? yslot[cb + 1] : 0;
+  const double lma = sa ? lam[ca + 1] : 0.0, lmb = sb ? lam[cb + 1] : 0.0;
+  // rotation k (jd <= k < mn) mixes the running column (row-jd entry a_k) with old column k + 1 (row-jd entry e_{k+1}):
+  // a_jd = e_jd, a_{k+1} = sqrt(a_k^2 + e_{k+1}^2) = sqrt(sum_{i=jd..k+1} e_i^2);  c_k = e_{k+1} / a_{k+1},  s_k = a_k / a_{k+1}
+  const double ea = (ca >= jd && ca < m) ? T[dg_tcol(ca) + jd] : 0.0, eb = (cb >= jd && cb < m) ? T[dg_tcol(cb) + jd] : 0.0;
+  const double pa = wave_prefix_sum(ea * ea, lane);
+  const double pb = wave_prefix_sum(eb * eb, lane) + lane_bcast(pa, 63);
+  // a_k for k = lane / lane + 64 (the first one keeps its sign)
+  const double aa = ca == jd ? ea : sqrt(pa), ab = cb == jd ? eb : sqrt(pb);
+  // rotation k needs e_{k+1} and a_{k+1}: lane k + 1 publishes c_k, s_k needs a_k from lane k -- go through LDS
+  if (ca > jd && ca < m) cs[ca - 1] = ea / aa;          // c_{ca-1} = e_ca / a_ca
+  if (cb > jd && cb < m) cs[cb - 1] = eb / ab;
+  if (ca >= jd && ca < mn) sn[ca] = aa;                  // a_k, divided by a_{k+1} below
+  if (cb >= jd && cb < mn) sn[cb] = ab;
+  if (ca > jd && ca < m) sn[ca - 1] = sn[ca - 1] / aa;   // (same lane order within the wavefront: the store above is visible)
+  if (cb > jd && cb < m) sn[cb - 1] = sn[cb - 1] / ab;
+  // rows: lane handles old rows ca and cb (row jd itself disappears)
+  const bool ra = ca < m && ca != jd, rb = cb < m && cb != jd;
+  const int na = ca < jd ? ca : ca - 1, nb = cb < jd ? cb : cb - 1;      // their new indices
+  const int cjd = dg_tcol(jd);
+  double runa = (ra && ca <= jd) ? T[cjd + ca] : 0.0, runb = (rb && cb <= jd) ? T[cjd + cb] : 0.0;
+  for (int k = jd; k < mn; k++) {
+    const double c_ = cs[k], s_ = sn[k];
+    const int base = dg_tcol(k + 1), dst = dg_tcol(k);
+    const bool ia = ra && ca <= k + 1, ib = rb && cb <= k + 1;
+    const double ba = ia ? T[base + ca] : 0.0, bb = ib ? T[base + cb] : 0.0;
+    // new column k = s col_{k+1} - c run  (the sign that keeps the diagonal positive);  run <- s run + c col_{k+1}
+    if (ia) T[dst + na] = s_ * ba - c_ * runa;
+    if (ib) T[dst + nb] = s_ * bb - c_ * runb;
+    runa = s_ * runa + c_ * ba;
+    runb = s_ * runb + c_ * bb;
+  }
+  // (the zeros below the diagonals stay: new column k has k + 1 entries like the old one)
+  if (sa) { alist[ca] = ala; lam[ca] = lma; yslot[ca] = ysa; }
+  if (sb) { alist[cb] = alb; lam[cb] = lmb; yslot[cb] = ysb; }
 }
 
 #include "dgsqp_qp.h"
@@ -1131,7 +1135,8 @@ __device__ __noinline__ void dev_coop_trial(const Ctx& c, DgCoopJob* job, int j)
 }
 // A workgroup that found the ticket queue empty: help the line searches of the workgroups still solving until every scenario of
 // the launch is done.
-__device__ __noinline__ void dev_coop_help(Ctx& c) {
+// Returns 1 when a deferred scenario is waiting to be resumed (the caller takes it), 0 when the launch is over.
+__device__ __noinline__ int dev_coop_help(Ctx& c) {
   const DgProb& D = dg_prob;
   const DgLds& L = D.L;
   lptr lds = LP(0);
@@ -1145,15 +1150,19 @@ __device__ __noinline__ void dev_coop_help(Ctx& c) {
   const bool passive = (int)rank >= c.coop_helpers;
   int start = (2 * (int)blockIdx.x + 2) % njobs;
   unsigned long long spins = 0;
+  int ret = 0;
   while (true) {
     if (passive) {
-      if (dev_bcast_u64(TID == 0 ? (unsigned long long)(AT_LOAD(&co->finished) >= c.coop_total) : 0ull)) break;
+      const unsigned long long w = dev_bcast_u64(TID == 0 ? ((unsigned long long)(AT_LOAD(&co->finished) >= c.coop_total) << 32) | (unsigned long long)AT_LOAD(&co->park_avail) : 0ull);
+      if (w & 0xffffffffull) { ret = 1; break; }
+      if (w >> 32) break;
       for (int t = 0; t < 32; t++) __builtin_amdgcn_s_sleep(127);
       if (++spins > (1ull << 22)) break;
       continue;
     }
     {
-      // one word to poll while nothing is on offer (hundreds of workgroups may be idle: they must not hammer the memory system)
+      // two words to poll while nothing is on offer (hundreds of workgroups may be idle: they must not hammer the memory system)
+      if (dev_bcast_u64(TID == 0 ? (unsigned long long)AT_LOAD(&co->park_avail) : 0ull)) { ret = 1; break; }
       const unsigned long long w = dev_bcast_u64(TID == 0 ? ((unsigned long long)(AT_LOAD(&co->finished) >= c.coop_total) << 32) | (unsigned long long)AT_LOAD(&co->open) : 0ull);
       if (w >> 32) break;
       if ((w & 0xffffffffull) == 0ull) {
@@ -1226,6 +1235,7 @@ __device__ __noinline__ void dev_coop_help(Ctx& c) {
   }
   if (TID == 0) __hip_atomic_fetch_sub(&co->idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
+  return ret;
 }
 
 // _line_search_3 (DGSQP.py:1057-1081) from the base (u, du, l, lhat) held in LDS.  On return u and l hold
@@ -1560,24 +1570,145 @@ struct SolveOutPtrs {
   double *u, *l, *x, *cond, *cost;
   int32_t *status, *iters, *qp_solves;
 };
-__device__ inline void dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const SolveOutPtrs& O) {
+// ---- deferral of long scenarios (DgPark, dgsqp_device.h) ----
+// A slot for this scenario, or -1: not yet long enough, no fresh ticket left (nothing to make room for), or no slot free.  Block-uniform.
+__device__ inline long long dev_park_reserve(const Ctx& c, int sqp_it) {
+  if (!c.park.entries || sqp_it < c.park.min_it) return -1;
+  long long r = -1;
+  if (TID == 0) {
+    DgCoop* co = c.coop;
+    const unsigned long long fin = AT_LOAD(&co->finished), di = AT_LOAD(&co->done_iters);
+    const bool long_enough = fin < 32ull || (unsigned long long)sqp_it * 16ull * fin >= (unsigned long long)c.park.factor_x16 * di;
+    if (long_enough && AT_LOAD(c.ticket) < c.coop_total) {
+      const unsigned int idx = __hip_atomic_fetch_add(&co->park_pushed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (idx < c.park.cap) r = (long long)idx;
+    }
+  }
+  return (long long)dev_bcast_u64((unsigned long long)r);
+}
+// the scenario's state -- LDS arena, workgroup scratch, loop variables -- into slot idx
+__device__ __noinline__ void dev_park_store(const Ctx& c, unsigned int idx, int sqp_it, int rel_tol_its, int total_qp, long long ticket, unsigned long long key, const double* cond) {
+  const DgProb& D = dg_prob;
+  double* slot = c.park.store + (size_t)idx * c.park.slot_doubles;
+  __syncthreads();
+  for (int i = TID; i < D.L.total; i += NT) slot[i] = dg_lds[i];
+  {
+    cgptr w = c.ws;
+    double* sw = slot + D.L.total;
+    const int64_t nw = D.ws_doubles;
+    int64_t i = TID;
+    for (; i + 7 * NT < nw; i += 8 * NT) {
+      double t[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) t[k] = w[i + k * NT];
+#pragma unroll
+      for (int k = 0; k < 8; k++) sw[i + k * NT] = t[k];
+    }
+    for (; i < nw; i += NT) sw[i] = w[i];
+  }
+  __threadfence();
+  __syncthreads();
+  if (TID == 0) {
+    DgParkEntry* e = &c.park.entries[idx];
+    e->sqp_it = sqp_it; e->rel_tol_its = rel_tol_its; e->total_qp = total_qp; e->ticket = ticket; e->key = key;
+    e->t_park = wall_clock64() - AT_LOAD(&c.coop->t_first);
+    for (int i = 0; i < 3; i++) e->cond[i] = cond[i];
+    __threadfence();
+    __hip_atomic_store(&e->state, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&c.coop->park_avail, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+}
+// ... and back (the workgroup's own line-search slot toggle survives: it belongs to the workgroup, not to the scenario)
+__device__ __noinline__ void dev_park_load(const Ctx& c, unsigned int idx) {
+  const DgProb& D = dg_prob;
+  const double* slot = c.park.store + (size_t)idx * c.park.slot_doubles;
+  __threadfence();
+  __syncthreads();
+  const double flip = dg_lds[D.L.scal + DG_COOP_FLIP];
+  __syncthreads();
+  for (int i = TID; i < D.L.total; i += NT) dg_lds[i] = slot[i];
+  {
+    gptr w = c.ws;
+    const double* sw = slot + D.L.total;
+    const int64_t nw = D.ws_doubles;
+    int64_t i = TID;
+    for (; i + 7 * NT < nw; i += 8 * NT) {
+      double t[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) t[k] = sw[i + k * NT];
+#pragma unroll
+      for (int k = 0; k < 8; k++) w[i + k * NT] = t[k];
+    }
+    for (; i < nw; i += NT) w[i] = sw[i];
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (TID == 0) dg_lds[D.L.scal + DG_COOP_FLIP] = flip;
+  __syncthreads();
+}
+// The deferred scenario that has cost the most so far, or -1 when none is waiting.  Block-uniform.
+__device__ __noinline__ long long dev_park_pop(const Ctx& c) {
+  if (!c.park.entries) return -1;
+  const DgProb& D = dg_prob;
+  lptr lds = LP(0);
+  DgCoop* co = c.coop;
+  const int NONE = 0x7fffffff;
+  for (int tries = 0; tries < 64; tries++) {
+    const unsigned long long w = dev_bcast_u64(TID == 0 ? ((unsigned long long)AT_LOAD(&co->park_avail) << 32) | (unsigned long long)AT_LOAD(&co->park_pushed) : 0ull);
+    if ((w >> 32) == 0ull) return -1;
+    unsigned int np = (unsigned int)(w & 0xffffffffull);
+    if (np > c.park.cap) np = c.park.cap;
+    double key = 1e300; int slot = NONE;
+    for (unsigned int sl = TID; sl < np; sl += NT) {
+      DgParkEntry* e = &c.park.entries[sl];
+      if (__hip_atomic_load(&e->state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1u) continue;
+      const double k2 = -(double)AT_LOAD(&e->key);
+      if (k2 < key) { key = k2; slot = (int)sl; }
+    }
+    double kb; int sb;
+    block_argmin(key, slot, lds + D.L.red, kb, sb);
+    if (sb == NONE) continue;            // (an entry counted in park_avail whose state is not visible yet, or somebody else took the last one)
+    unsigned long long got = 0ull;
+    if (TID == 0) {
+      unsigned int expect = 1u;
+      if (__hip_atomic_compare_exchange_strong(&c.park.entries[sb].state, &expect, 2u, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_fetch_sub(&co->park_avail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&co->park_resumed, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        got = 1ull;
+      }
+    }
+    if (dev_bcast_u64(got)) return (long long)sb;
+  }
+  return -1;
+}
+
+// Returns true when the scenario was DEFERRED (its state is in a slot; nothing was written to the outputs), false when it is done.
+// resume: the entry of a deferred scenario whose state dev_park_load has just put back.  iters_out: SQP iterations of a finished solve.
+__device__ inline bool dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const SolveOutPtrs& O, const DgParkEntry* resume = nullptr,
+                                 long long ticket = 0, unsigned long long ticks0 = 0ull, int* iters_out = nullptr) {
   const DgProb& D = dg_prob;
   const DgLds& L = D.L;
   lptr lds = LP(0);
   const int n = D.n, nc = D.nc;
   __syncthreads();
-  if (TID == 0) { lds[L.scal + DG_XVALID] = 0.0; lds[L.scal + DG_QP_NPREV] = 0.0; lds[L.scal + DG_REG] = D.par.reg; }
-  for (int i = TID; i < n; i += NT) lds[L.u + i] = u_ws[i];
-  for (int r = TID; r < nc; r += NT) lds[L.l + r] = 0.0;
-  __syncthreads();
   const bool timed = D.par.time_limit >= 0.0;              // < 0: no limit (DGSQPParams.time_limit = None -> inf, DGSQP.py:64-67)
-  const double t_start = timed ? dev_block_clock() : 0.0;  // solve_start (DGSQP.py:304): before the dual start
-  // dual warm start
-  dev_evaluate(c, lds + L.u, 0.0, nullptr, false);
-  dev_dual_init(c);
-  if (TID == 0) lds[L.scal + DG_ITREC] = 0.0;
-  dev_log_iterate(c);                                      // record 0: (u_ws, dual start) = solve_info['init']
+  double t_start = 0.0;
   int sqp_it = 0, rel_tol_its = 0, status = DGSQP_MAX_IT, total_qp = 0;
+  if (!resume) {
+    if (TID == 0) { lds[L.scal + DG_XVALID] = 0.0; lds[L.scal + DG_QP_NPREV] = 0.0; lds[L.scal + DG_REG] = D.par.reg; }
+    for (int i = TID; i < n; i += NT) lds[L.u + i] = u_ws[i];
+    for (int r = TID; r < nc; r += NT) lds[L.l + r] = 0.0;
+    __syncthreads();
+    t_start = timed ? dev_block_clock() : 0.0;             // solve_start (DGSQP.py:304): before the dual start
+    // dual warm start
+    dev_evaluate(c, lds + L.u, 0.0, nullptr, false);
+    dev_dual_init(c);
+    if (TID == 0) lds[L.scal + DG_ITREC] = 0.0;
+    dev_log_iterate(c);                                    // record 0: (u_ws, dual start) = solve_info['init']
+  } else {
+    sqp_it = resume->sqp_it; rel_tol_its = resume->rel_tol_its; total_qp = resume->total_qp;
+  }
   double cond[3] = {0, 0, 0};
   const bool l1 = D.par.merit_function == DGSQP_MERIT_STAT_L1;
   while (true) {
@@ -1642,7 +1773,16 @@ __device__ inline void dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
     sqp_it++;
     if (sqp_it >= D.par.sqp_iters) { status = DGSQP_MAX_IT; break; }
     if (timed && (dev_block_clock() - t_start) * 1e-8 > D.par.time_limit) { status = DGSQP_TIME_LIMIT; break; }   // block-uniform
+    if (!resume && !timed) {      // (a wall-clock limit counts the time spent waiting: such solves are never deferred)
+      const long long slot = dev_park_reserve(c, sqp_it);
+      if (slot >= 0) {
+        const unsigned long long now = dev_bcast_u64(TID == 0 ? wall_clock64() : 0ull);
+        dev_park_store(c, (unsigned int)slot, sqp_it, rel_tol_its, total_qp, ticket, now - ticks0, cond);
+        return true;
+      }
+    }
   }
+  if (iters_out) *iters_out = sqp_it;
   // outputs: q_pred = evaluate_dynamics(u, x0) (DGSQP.py:476), cost = f_J (:492)
   __syncthreads();
   lds_d* ue = lds + L.e_ue;
@@ -1659,4 +1799,5 @@ __device__ inline void dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
     if (O.cond) for (int i = 0; i < 3; i++) O.cond[b * 3 + i] = cond[i];
   }
   __syncthreads();
+  return false;
 }

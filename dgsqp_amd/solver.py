@@ -480,6 +480,30 @@ class DGSQP(AbstractSolver):
             raise RuntimeError(self._lib.dgsqp_last_error(self._h).decode())
         return dict(helped=int(out[0]), timeouts=int(out[1]), finished=int(out[2]), idle=int(out[3]), used=int(out[4]), mismatches=int(out[5]))
 
+    def set_deferral(self, min_iters: int = 8, factor: float = 2.0):
+        """Deferral of long scenarios in cooperative launches (include/dgsqp.h: dgsqp_set_deferral): a scenario still iterating after
+        max(min_iters, factor x mean iterations of the finished ones) is set aside while fresh scenarios wait and resumed, bit for
+        bit, once the queue is empty.  min_iters = 0 switches it off."""
+        if self._lib.dgsqp_set_deferral(self._h, int(min_iters), float(factor)) != 0:
+            raise ValueError(f'bad deferral setting {min_iters}, {factor}')
+
+    def deferral_stats(self) -> dict:
+        out = (C.c_uint64 * 2)()
+        if self._lib.dgsqp_deferral_stats(self._h, out) != 0:
+            raise RuntimeError(self._lib.dgsqp_last_error(self._h).decode())
+        return dict(deferred=int(out[0]), resumed=int(out[1]))
+
+    def deferral_log(self, max_rows: int = 1 << 16) -> np.ndarray:
+        """Rows (ticket, iterations, QPs, cost in 100 MHz ticks when set aside, ticks since launch start when set aside / resumed /
+        finished, final iterations, final QPs, the three convergence measures when set aside) of the last cooperative launch's deferred
+        scenarios (diagnostic), as float64."""
+        out = np.zeros((max_rows, 11), np.uint64)
+        n = self._lib.dgsqp_deferral_log(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), max_rows)
+        if n < 0:
+            raise RuntimeError('dgsqp_deferral_log failed')
+        r = out[:n, :8].astype(np.int64)
+        return np.column_stack([r[:, :7], r[:, 7] & 0xffffffff, r[:, 7] >> 32, out[:n, 8:].copy().view(np.float64)])
+
     def set_iterate_log(self, records_per_scenario: int):
         """Keep (u, l) after every SQP iteration of subsequent solves (what ``solve()`` reports in ``iter_data``); 0 disables."""
         self._itlog_cap = int(records_per_scenario)

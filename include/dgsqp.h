@@ -306,6 +306,22 @@ int dgsqp_set_cooperative(dgsqp_handle_t h, int mode);
    (must be 0), scenarios finished, helpers still registered (0 after the launch), helper values the owners consumed, helper values
    whose bits differed from the owner's own evaluation (verify mode, environment DGSQP_COOP_VERIFY=1; must be 0)}. */
 int dgsqp_coop_stats(dgsqp_handle_t h, uint64_t* out6);
+/* Deferral of long scenarios (cooperative launches; scheduling only, results are bit-identical).  Nothing in a scenario's inputs
+   tells how long its solve will run; its own history does.  A scenario still iterating after max(min_iters, factor x the mean
+   iteration count of the launch's finished scenarios) SQP iterations is set aside while fresh scenarios remain in the queue -- its
+   workgroup stores the LDS arena and its scratch in a slot and takes the next ticket -- and resumed from that image once the queue
+   is empty, the scenarios that have cost the most so far first.  The long solves of a launch's last batches thereby run while the
+   chip still has other work.  Defaults: min_iters 8, factor 2.0; min_iters 0 switches it off.  Never applied with a wall-clock
+   limit (dgsqp_params_t.time_limit >= 0), to DG-SQP v2, while logs are recorded, or in non-cooperative launches. */
+int dgsqp_set_deferral(dgsqp_handle_t h, int32_t min_iters, double factor);
+/* Diagnostic: out2 = {scenarios deferred, scenarios resumed} of the handle's last cooperative launch (equal after the launch). */
+int dgsqp_deferral_stats(dgsqp_handle_t h, uint64_t* out2);
+/* Diagnostic: one row of 11 values per deferred scenario of the handle's last cooperative launch, at most cap_rows rows --
+   {ticket, SQP iterations and QP solves when it was set aside, 100 MHz ticks it had cost by then (the resume order's key), ticks since
+   the launch's start when it was set aside / resumed / finished, (QP solves << 32) | iterations at the end, and -- as the bits of three doubles -- the convergence measures (constraint violation,
+   complementarity, stationarity) of its last iteration before it was set aside}.  Returns the number of
+   rows written, negative on error. */
+int dgsqp_deferral_log(dgsqp_handle_t h, uint64_t* out, int64_t cap_rows);
 /* 1 once the handle's last launch has handed out its last scenario (it only drains from then on, compute units are
    becoming free) or when nothing is in flight; 0 while scenarios are still queued.  Polled by bench.py to start the next
    independent batch on another handle at exactly that moment. */
