@@ -148,7 +148,9 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=64, help='scenarios timed on the host for cpu_baseline (0 disables)')
     ap.add_argument('--pipeline', type=int, default=5,
                     help='launches in flight per GPU (each on its own HIP stream / hardware queue); 1 = strictly one launch at a time')
-    ap.add_argument('--group', type=int, default=12, help='staged batches (= steps) solved by ONE launch with a shared ticket queue (dgsqp_launch_staged_group)')
+    ap.add_argument('--group', type=int, default=0, help='staged batches (= steps) solved by ONE launch with a shared ticket queue (dgsqp_launch_staged_group); '
+                    '0 = auto: all of them in one cooperative launch when the timed region has at most 24 steps (a launch ends behind its slowest scenarios once, and its '
+                    'deferral of long scenarios sees the whole job), otherwise 12 per launch, pipelined')
     ap.add_argument('--batches', type=int, default=0, help='distinct staged batches = handles the steps cycle through (default: (pipeline + 1) x group, so that a group never waits for the tail of a launch that still holds its handles)')
     ap.add_argument('--single-steps', type=int, default=3, help='extra one-launch-at-a-time steps behind value_single_launch / roofline.kernel_ms (0 disables)')
     ap.add_argument('--host-steps', type=int, default=2, help='extra dgsqp_solve_batch calls from host buffers behind value_host_inclusive (0 disables)')
@@ -179,6 +181,8 @@ def main():
     mk = lambda: DGSQP(*game.solver_args(), print_method=None, device=local_rank, eig_floor=args.eig_floor,
                        snap_active_bounds=args.snap_active_bounds)
     P = max(1, args.pipeline)
+    if args.group <= 0:
+        args.group = args.steps if args.steps <= 24 else 12
     n_batches = args.batches if args.batches > 0 else max(P, min(max(3 * P, (P + 1) * max(1, args.group)), args.steps))     # distinct batches = handles; steps cycle through them
     solvers = [mk() for _ in range(n_batches)]
     solver = solvers[0]

@@ -1016,8 +1016,9 @@ __device__ __noinline__ void dev_hessian_adjoint(const Ctx& c) {
   //         e_i / e_i+e_j Taylor coefficients: H_ii = 2 c_i, H_ij = c_ij - c_i - c_j)
   // (a) cv[a][k][b][dir] = sum_o lam^a_{k+1}[b,o] T2[b][k][o][dir], once per direction (coalesced over dir), kept in the
   //     LDS area of the speculative line-search trajectories (idle here)
-  lptr cvb = lds + L.e_xs;
-  const int cvcap = (L.o_du - L.e_xs);
+  const int cv0 = D.lsqr_keeps_eval ? L.s_u : L.e_xs;      // (the dual start's vectors, where they sit right above the evaluation arrays, are idle too)
+  lptr cvb = lds + cv0;
+  const int cvcap = (L.o_du - cv0);
   int ndmax = 0;
   for (int b = 0; b < M; b++) ndmax = D.ndir[b] > ndmax ? D.ndir[b] : ndmax;
   const bool use_cv = M * N * M * ndmax <= cvcap;

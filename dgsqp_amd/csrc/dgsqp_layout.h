@@ -101,6 +101,8 @@ struct DgProb {
                     // whose smallest eigenvalue (eig_floor + reg) is below 1e-8 -- the literal reg = 0 formula
   int big;          // 2: XL layout (n > 128, dgsqp_xl.h).  1: the packed inverse P and the packed Householder reflectors live in the workgroup's global scratch (L2)
                     // instead of LDS: games whose LDS-resident layout exceeds the 160 KB arena
+  int lsqr_keeps_eval;  // the dual start's vectors sit ABOVE the evaluation arrays (not over them): the trajectory, A_k, B_k and the Taylor
+                    // tensor of the start point survive the dual start and serve the first linearisation
   int ls_spec;      // trial step sizes of _line_search_3 rolled out concurrently (speculation width)
   int ls_spec1;     // how many of them live in the first LDS segment (e_xs); the rest in e_xs2  // every agent uses the same vehicle model (statically indexed fast paths)
   int neff[DGSQP_MAX_AGENTS], ndir[DGSQP_MAX_AGENTS];
@@ -210,8 +212,14 @@ static inline std::string dg_build_layout(DgProb& D) {
   o = qp_end > eval_end ? qp_end : eval_end;
   L.o_du = take(n); L.o_lhat = take(nc);
   const int out_end = o;
-  // LSQR
-  o = L.scr;
+  // LSQR: over the evaluation arrays -- or above them when the EIG / QP scratch reaches further anyway (LDS-resident layout): the
+  // evaluation of the start point then survives the dual start
+  {
+    const int lsqr_size = 4 * ((nc + 1) & ~1) + (((nc > n ? nc : n) + 1) & ~1);
+    const int reach = eig_end > out_end ? eig_end : out_end;
+    D.lsqr_keeps_eval = (!D.big && !D.tab_const && eval_end + lsqr_size <= reach && eval_end + lsqr_size <= L.p_yd2 && !getenv("DGSQP_LSQR_LOW")) ? 1 : 0;
+  }
+  o = D.lsqr_keeps_eval ? eval_end : L.scr;
   L.s_u = take(nc); L.s_v = take(nc); L.s_w = take(nc); L.s_x = take(nc); L.s_t = take(nc > n ? nc : n);
   if (D.tab_const || D.big == 2) { L.s_yd2 = take(nd); L.s_dpart = take(D.ntask); }       // (the QP outputs are dead during the dual start)
   else { L.s_yd2 = L.p_yd2; L.s_dpart = L.p_dpart; }

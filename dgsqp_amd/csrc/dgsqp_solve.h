@@ -740,7 +740,7 @@ __device__ inline void dev_sym_ortho(double a, double b, double& cs, double& sn,
   else { const double tau = b / a; cs = ((a > 0) - (a < 0)) / sqrt(1 + tau * tau); sn = cs * tau; r = a / cs; }
 }
 __device__ __noinline__ void dev_dual_init(const Ctx& c) {
-  if (TID == 0) LP(dg_prob.L.scal)[DG_XVALID] = 0.0;   // the LSQR vectors overwrite the trajectory
+  if (TID == 0 && !dg_prob.lsqr_keeps_eval) LP(dg_prob.L.scal)[DG_XVALID] = 0.0;   // the LSQR vectors overwrite the trajectory
   const DgProb& D = dg_prob;
   const DgLds& L = D.L;
   lptr lds = LP(0);
@@ -1683,6 +1683,26 @@ __device__ __noinline__ long long dev_park_pop(const Ctx& c) {
   return -1;
 }
 
+// The trajectory of the final u for the outputs: it is still in the evaluation scratch when u is, bit for bit, the point evaluated
+// last (an exit at the convergence test, or right after a line search / full step whose last trial is the new iterate) and nothing
+// has overwritten it since (tag in scal[DG_XVALID]); otherwise one more rollout.
+__device__ inline void dev_final_rollout(const Ctx& c) {
+  const DgProb& D = dg_prob;
+  const DgLds& L = D.L;
+  lptr lds = LP(0);
+  lptr ue = lds + L.e_ue;
+  const bool tagged = lds[L.scal + DG_XVALID] != 0.0;
+  int differs = 0;
+  if (tagged)
+    for (int i = TID; i < D.n; i += NT) differs |= (__double_as_longlong(lds[L.u + i]) != __double_as_longlong(ue[i]));
+  if (!tagged || __syncthreads_or(differs)) {
+    __syncthreads();
+    for (int i = TID; i < D.n; i += NT) ue[i] = lds[L.u + i];
+    dev_rollout(c, ue, lds + L.e_x);
+  }
+  __syncthreads();
+}
+
 // Returns true when the scenario was DEFERRED (its state is in a slot; nothing was written to the outputs), false when it is done.
 // resume: the entry of a deferred scenario whose state dev_park_load has just put back.  iters_out: SQP iterations of a finished solve.
 __device__ inline bool dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const SolveOutPtrs& O, const DgParkEntry* resume = nullptr,
@@ -1701,8 +1721,10 @@ __device__ inline bool dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
     for (int r = TID; r < nc; r += NT) lds[L.l + r] = 0.0;
     __syncthreads();
     t_start = timed ? dev_block_clock() : 0.0;             // solve_start (DGSQP.py:304): before the dual start
-    // dual warm start
-    dev_evaluate(c, lds + L.u, 0.0, nullptr, false);
+    // dual warm start.  Where the evaluation survives it (DgProb.lsqr_keeps_eval) the rollout is fused with the second-order derivative
+    // pass the first linearisation needs anyway: one pass instead of rollout + first derivatives here and a fused pass there.
+    dev_evaluate_point(c, lds + L.u, 0.0, nullptr, nullptr, D.lsqr_keeps_eval != 0);
+    dev_evaluate_derivs(c, false);
     dev_dual_init(c);
     if (TID == 0) lds[L.scal + DG_ITREC] = 0.0;
     dev_log_iterate(c);                                    // record 0: (u_ws, dual start) = solve_info['init']
@@ -1786,8 +1808,7 @@ __device__ inline bool dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
   // outputs: q_pred = evaluate_dynamics(u, x0) (DGSQP.py:476), cost = f_J (:492)
   __syncthreads();
   lds_d* ue = lds + L.e_ue;
-  for (int i = TID; i < n; i += NT) ue[i] = lds[L.u + i];
-  dev_rollout(c, ue, lds + L.e_x);
+  dev_final_rollout(c);
   if (O.cost) dev_costs(c, ue, O.cost + b * D.M);
   if (O.u) for (int i = TID; i < n; i += NT) O.u[b * n + i] = lds[L.u + i];
   if (O.l) for (int r = TID; r < nc; r += NT) O.l[b * nc + r] = lds[L.l + r];

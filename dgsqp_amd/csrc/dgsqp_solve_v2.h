@@ -256,8 +256,7 @@ __device__ inline void dev_solve_v2(const Ctx& c, cgptr u_ws, int64_t b, const S
   // outputs
   __syncthreads();
   lds_d* ue = lds + L.e_ue;
-  for (int i = TID; i < n; i += NT) ue[i] = lds[L.u + i];
-  dev_rollout(c, ue, lds + L.e_x);
+  dev_final_rollout(c);
   if (O.cost) dev_costs(c, ue, O.cost + b * D.M);
   if (O.u) for (int i = TID; i < n; i += NT) O.u[b * n + i] = lds[L.u + i];
   if (O.l) for (int r = TID; r < nc; r += NT) O.l[b * nc + r] = lds[L.l + r];

@@ -728,6 +728,37 @@ def test_cooperative_line_search_is_bit_identical(games):
         assert st_chk['mismatches'] == 0 and st_chk['used'] > 0, st_chk
 
 
+def test_deferral_of_long_scenarios_is_bit_identical(games):
+    """Cooperative launches set scenarios that iterate much longer than the others aside while fresh ones wait (LDS arena + scratch
+    stored in HBM) and resume them, most expensive first, once the queue is empty (dgsqp_set_deferral).  Scheduling only: every
+    output equals the plain launch bit for bit, in a grouped launch and in a single one; every deferred scenario was resumed."""
+    from dgsqp_amd.montecarlo import sample_scenarios
+    from dgsqp_amd.solver import DGSQP, solve_batches
+    keys = ('status', 'num_iters', 'qp_solves', 'u', 'l', 'x', 'cond', 'cost')
+    for name, B, G in (('dyn_curve_N25', 640, 3), ('kb_chicane_N25', 768, 1), ('kb_barc2_N15', 512, 2)):
+        g = games[name][0]
+        solvers = [DGSQP(*g.solver_args(), print_method=None) for _ in range(G)]
+        batches = [sample_scenarios(g, B, seed=11 + i) for i in range(G)]
+        ref = []
+        for s, (x0, u) in zip(solvers, batches):
+            s.set_cooperative(0)
+            ref.append(s.solve_batch(x0, u))
+            s.set_cooperative(1)
+        for min_it, factor in ((0, 2.0), (8, 2.0), (4, 0.5)):
+            solvers[0].set_deferral(min_it, factor)
+            res = solve_batches(solvers, batches)
+            st = solvers[0].deferral_stats()
+            print(name, 'deferral', (min_it, factor), st, 'kernel ms', res[0]['kernel_ms'], 'plain launches', [round(r['kernel_ms'], 1) for r in ref])
+            for r, r0 in zip(res, ref):
+                for k in keys:
+                    assert np.array_equal(r[k], r0[k], equal_nan=True), (name, min_it, factor, k)
+            assert st['deferred'] == st['resumed']
+            assert (st['deferred'] > 0) == (min_it > 0), st
+        log = solvers[0].deferral_log()
+        assert len(log) == st['deferred'] and (log[:, 6] >= log[:, 5]).all() and (log[:, 5] >= log[:, 4]).all()     # set aside <= resumed <= finished
+        solvers[0].set_deferral(8, 2.0)
+
+
 def test_six_agent_merge_n300(oracle):
     """BASELINE configs[4]'s game at its own size: six cars on the highway merge (DGSQP_merge_monte_carlo.py:66-74, 253-261, 316-342
     generalised to six cars), N = 25: n = 300 decision variables, 36 / 63 / 39 rows per stage = 1,587 rows, 837 distinct dense
