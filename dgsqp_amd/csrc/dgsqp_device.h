@@ -136,7 +136,7 @@ struct DgParkEntry {
   unsigned int state;             // 0 empty, 1 stored (published with release semantics), 2 taken
   int sqp_it, rel_tol_its, total_qp;     // dev_solve's loop variables
   long long ticket;               // the scenario (ticket of the launch)
-  unsigned long long key;         // 100 MHz ticks spent on it so far: resumed in descending order
+  unsigned long long key;         // 100 MHz ticks spent on it so far x (1 + 2 log10(1 + stationarity)): resumed in descending order
   unsigned long long t_park, t_resume, t_done;   // diagnostic (dgsqp_deferral_log): 100 MHz ticks since the launch's first ticket
   int final_its, final_qps;
   double cond[3];                 // convergence measures of its last iteration before it was set aside (diagnostic)

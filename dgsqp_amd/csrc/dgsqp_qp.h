@@ -224,14 +224,9 @@ __device__ inline int qpw_add_constraint(const QpPtrs& q, QpwState& S, int lane,
     // ---- step 2a: directions.  c = A_A y ; w = T^T c ; r = T w
     PROF_BEGIN(pq3);
     const int m = S.m;
-    PROF_BEGIN(pqa);
     for (int j = lane; j < m; j += 64) q.cvec[j] = qpw_row_dot(D, ld_row(q.alist[j]), q.yv, q.ddy);
-    PROF_END(PH_W_BUILD, pqa);
-    PROF_COUNT(PH_C_MBUILD, m);
     double r0, r1;
-    PROF_BEGIN(pqb);
     const double ww = qpt_solve(q.R, m, lane, q.cvec, q.wv, q.rv, r0, r1);
-    PROF_END(PH_W_MULT, pqb);
     // ---- step 2b: step lengths.  t1 keeps the multipliers >= 0, t2 makes constraint p active
     double ta = INFINITY; int jd = NONE;
     if (lane < m && r0 > 0) { ta = q.lam[lane] / r0; jd = lane; }

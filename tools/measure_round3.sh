@@ -21,7 +21,8 @@ step bench_dyn_curve_N25_default $O/bench_dyn_curve_N25.json python bench.py --c
 step bench_dyn_curve_N25_coop_off $O/bench_dyn_curve_N25_driver_coop_off.json python bench.py --gpus 1 --steps 20 --warmup 5 --coop off --cpu-sample 0
 step bench_dyn_single12_coop $O/bench_dyn_curve_N25_single12.json python bench.py --steps 1 --warmup 0 --single-steps 12 --host-steps 0 --cpu-sample 0
 step bench_dyn_single12_plain $O/bench_dyn_curve_N25_single12_coop_off.json python bench.py --steps 1 --warmup 0 --single-steps 12 --host-steps 0 --cpu-sample 0 --coop off
-step bench_dyn_group20 $O/bench_dyn_curve_N25_driver_group20.json python bench.py --gpus 1 --steps 20 --warmup 5 --group 20 --pipeline 1 --cpu-sample 0 --single-steps 0 --host-steps 0
+step bench_dyn_group12 $O/bench_dyn_curve_N25_driver_group12.json python bench.py --gpus 1 --steps 20 --warmup 5 --group 12 --pipeline 5 --cpu-sample 0 --single-steps 0 --host-steps 0
+step bench_dyn_defer_off $O/bench_dyn_curve_N25_driver_deferral_off.json env DGSQP_DEFER=0 python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --single-steps 0 --host-steps 0
 step bench_dyn_B4096 $O/bench_dyn_curve_N25_B4096.json python bench.py --batch 4096 --steps 32 --group 4 --pipeline 4 --cpu-sample 0
 step bench_kb_curve_N25 $O/bench_kb_curve_N25.json python bench.py --workload kb_curve_N25
 step bench_kb_chicane_N25 $O/bench_kb_chicane_N25.json python bench.py --workload kb_chicane_N25 --cpu-sample 0
@@ -37,6 +38,8 @@ step bench_dyn_curve_N25_v2 $O/bench_dyn_curve_N25_v2_B512.json python bench.py 
 python -m pytest tests -m gpu -q -s 2>&1 | grep -E "identical|largest relative|converged device|kernel ms alone|passed|failed" | cut -c1-2000 > $O/gpu_tests_parity_lines.txt
 echo "gpu_tests ${PIPESTATUS[0]}" >> $O/steps.txt
 step coop_debug $O/coop_line_search_dyn_curve_N25_B1024.txt python tools/gpu_coop_debug.py dyn_curve_N25 1024 1
+step defer_debug $O/deferral_dyn_curve_N25_20x1024.txt python tools/gpu_defer_debug.py dyn_curve_N25 1024 20
+step defer_timeline $O/deferral_timeline_dyn_curve_N25_20x1024.txt python tools/gpu_defer_timeline.py dyn_curve_N25 1024 20 8 2.0
 step forks_dyn $O/forks_dyn_curve_N25.txt python tools/gpu_forks.py dyn_curve_N25
 FORKS_B=192 step forks_kb_curve_reg0 $O/forks_kb_curve_reg0_N20.txt python tools/gpu_forks.py kb_curve_reg0_N20
 # ---- phase cycles, tail composition (diagnostic build, built beforehand in the build container: tools/build_prof.sh)
@@ -46,6 +49,7 @@ if [ -f dgsqp_amd/csrc/libdgsqp_hip_prof.so ]; then
   step phase_kb $O/phase_cycles_kb_curve_N25_B1024.txt python tools/gpu_time.py kbcurve 25 1024
   step phase_agents3 $O/phase_cycles_kb_curve3_N25_B512.txt python tools/gpu_time.py agents3 25 512
   step tail_dyn $O/tail_composition_dyn_curve_N25.txt python tools/gpu_tail_profile.py dyn_curve_N25 1 4
+  step slowest_dyn $O/slowest_scenarios_dyn_curve_N25.txt python tools/gpu_scn_profile.py dyn_curve_N25 23:739 9:596 10:339
   unset DGSQP_HIP_LIB
 else
   echo "prof_library_missing 1" >> $O/steps.txt
