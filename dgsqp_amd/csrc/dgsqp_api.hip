@@ -231,7 +231,8 @@ struct dgsqp_solver {
   bool coop_next_sync = false;        // (set by the synchronous entry points around their launch)
   DgParkEntry* d_park = nullptr;      // deferral of long scenarios (cooperative launches): entries ...
   double* d_park_store = nullptr;     // ... and their slots (LDS image + scratch image each)
-  size_t park_cap = 0;
+  size_t park_cap = 0;                // slots allocated
+  size_t park_last_cap = 0;           // slots the last launch could use
   int defer_min_it = 8;               // 0: off
   double defer_factor = 2.0;
   dgsqp_comm_state* comm = nullptr;   // RCCL communicator + record buffers (dgsqp_comm.h), owned by the handle
@@ -369,22 +370,24 @@ static int park_for_launch(dgsqp_solver* h, bool coop, int grid, int64_t total, 
   double frac = 0.25;
   { const char* e = getenv("DGSQP_DEFER_CAP_FRAC"); if (e) frac = atof(e); }
   size_t cap = (size_t)((double)total * (frac > 0.0 && frac <= 1.0 ? frac : 0.25) + 1.0);
+  // The slots are allocated ONCE per handle, at its first deferring launch, for 4,096 scenarios (2.7 GB at configs[1]) or what 16 GB
+  // hold: a launch never pays for an allocation that depends on its own size (a hipMalloc of gigabytes takes tens of milliseconds).
+  size_t slots = 4096;
   const size_t max_slots = (size_t)(16ull << 30) / (slot * sizeof(double));
-  if (cap > max_slots) cap = max_slots;
+  if (slots > max_slots) slots = max_slots;
+  if (cap > slots) cap = slots;
   if (cap < 1) return DGSQP_OK;
-  if (cap > h->park_cap) {
-    if (h->d_park) (void)hipFree(h->d_park);
-    if (h->d_park_store) (void)hipFree(h->d_park_store);
-    h->d_park = nullptr; h->d_park_store = nullptr; h->park_cap = 0;
-    HIPCHK(h, hipMalloc((void**)&h->d_park, sizeof(DgParkEntry) * cap));
-    if (hipMalloc((void**)&h->d_park_store, sizeof(double) * slot * cap) != hipSuccess) {      // no room: solve without deferral
+  if (h->park_cap == 0) {
+    HIPCHK(h, hipMalloc((void**)&h->d_park, sizeof(DgParkEntry) * slots));
+    if (hipMalloc((void**)&h->d_park_store, sizeof(double) * slot * slots) != hipSuccess) {      // no room: solve without deferral
       (void)hipGetLastError();
       (void)hipFree(h->d_park); h->d_park = nullptr;
       return DGSQP_OK;
     }
-    h->park_cap = cap;
+    h->park_cap = slots;
   }
   HIPCHK(h, hipMemsetAsync(h->d_park, 0, sizeof(DgParkEntry) * cap, h->stream));
+  h->park_last_cap = cap;
   out->entries = h->d_park; out->store = h->d_park_store; out->cap = (unsigned int)cap;
   out->min_it = min_it; out->factor_x16 = (int)(factor * 16.0 + 0.5); out->slot_doubles = slot;
   return DGSQP_OK;
@@ -682,7 +685,7 @@ int dgsqp_deferral_stats(dgsqp_handle_t h, uint64_t* out2) {
   { const int rc = wait_idle(h); if (rc) return rc; }
   DgCoop hdr;
   HIPCHK(h, hipMemcpy(&hdr, h->d_coop, sizeof(DgCoop) - sizeof(DgCoopJob), hipMemcpyDeviceToHost));
-  out2[0] = hdr.park_pushed < h->park_cap ? hdr.park_pushed : (uint64_t)h->park_cap;
+  out2[0] = hdr.park_pushed < h->park_last_cap ? hdr.park_pushed : (uint64_t)h->park_last_cap;
   out2[1] = hdr.park_resumed;
   return DGSQP_OK;
 }
