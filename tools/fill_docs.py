@@ -4,6 +4,8 @@ import json, pathlib, re, subprocess, sys
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 P = ROOT / 'profiles'
 f = lambda v: '—' if v is None else f'{v:,.0f}'
+out = subprocess.run(['bash', str(ROOT / 'tools' / 'collect_profiles3.sh')], capture_output=True, text=True)      # (first: the rows below read what it copies)
+assert out.returncode == 0, out.stderr
 def L(name):
     return json.load(open(P / f'r03_bench_{name}.json'))
 def cpu(d):
@@ -23,9 +25,9 @@ rows = ['| workload (fp64) | layout | scen/s (`value`) | one launch at a time | 
         row('KB race BARC circuit N=15, reg=0', 'LDS, classical', L('kb_barc2_N15')),
         row('3-car merge N=20, reg=0', 'big, classical', L('merge_N20')),
         row('3-agent KB curve N=25 (configs[2] size)', 'XL, packed LDS matrices, blocked warm start', L('kb_curve3_N25'), ' (round 2: 2,622)'),
-        row('3-agent BARC circuit N=25 (**configs[2]** game), B=512', 'XL, packed', L('kb_barc3_N25_B512'), ' (round 2: 474; 460–590 between runs)'),
-        row('2-agent F1 track N=50 (**configs[3]** game), B=256', 'XL', L('kb_f1_N50_B256')),
-        row('2-agent KB curve N=50 (n = 200), B=512', 'XL', L('kb_curve_N50_B512')),
+        row('3-agent BARC circuit N=25 (**configs[2]** game), B=512', 'XL, packed', L('kb_barc3_N25_B512'), ' (round 2: 474; as 4 launches of 4 batches: 460–590 between runs)'),
+        row('2-agent F1 track N=50 (**configs[3]** game), B=256', 'XL', L('kb_f1_N50_B256'), ' (as 4 launches of 4 batches: 109)'),
+        row('2-agent KB curve N=50 (n = 200), B=512', 'XL', L('kb_curve_N50_B512'), ' (as 4 launches of 4 batches: 459)'),
         row('**configs[4]** 6-car merge N=25 (n = 300, 1,587 rows), B=256', 'XL, tables in constant memory', L('merge6_N25_B256')),
         row('dynamic bicycle curve N=25, DG-SQP v2 (study parameters), B=512', 'LDS', L('dyn_curve_N25_v2_B512'))]
 # the generic row() bolds nothing; fix the first data row by hand
@@ -38,8 +40,6 @@ def put(path, name, text):
     s = s[:s.index(a) + len(a)] + '\n' + text + '\n' + s[s.index(b):]
     path.write_text(s)
 put(ROOT / 'DESIGN.md', 'bench', '\n'.join(rows))
-out = subprocess.run(['bash', str(ROOT / 'tools' / 'collect_profiles3.sh')], capture_output=True, text=True)
-assert out.returncode == 0, out.stderr
 lines = out.stdout.splitlines()
 i = [k for k, l in enumerate(lines) if l.startswith('| file |')][0]
 j = [k for k, l in enumerate(lines) if l.startswith('grouped schedule')][0]
