@@ -229,10 +229,7 @@ struct dgsqp_solver {
   size_t coop_bytes = 0;
   int coop_mode = 1;                  // 0 off, 1 synchronous calls only (nothing else is waiting for the compute units), 2 every launch
   bool coop_next_sync = false;        // (set by the synchronous entry points around their launch)
-  DgParkEntry* d_park = nullptr;      // deferral of long scenarios (cooperative launches): entries ...
-  double* d_park_store = nullptr;     // ... and their slots (LDS image + scratch image each)
-  size_t park_cap = 0;                // slots allocated
-  size_t park_last_cap = 0;           // slots the last launch could use
+  size_t park_last_cap = 0;           // deferral of long scenarios: slots the handle's last launch could use (0: it did not defer)
   int defer_min_it = 8;               // 0: off
   double defer_factor = 2.0;
   dgsqp_comm_state* comm = nullptr;   // RCCL communicator + record buffers (dgsqp_comm.h), owned by the handle
@@ -293,6 +290,17 @@ std::mutex g_reg_mutex;
 struct DgResident { bool valid = false; std::vector<unsigned char> bytes; };
 DgResident g_resident[64];
 std::vector<dgsqp_solver*> g_handles;
+// Deferral of long scenarios: ONE pool of slots per device, taken by the cooperative launch that defers (such launches run when
+// nothing else waits for the compute units; a second one that finds the pool busy simply does not defer).  Allocated at the first
+// deferring launch on the device -- 4,096 slots or what 16 GB hold -- and kept: no launch pays for an allocation of its own.
+struct DgParkPool {
+  DgParkEntry* entries = nullptr;
+  double* store = nullptr;
+  size_t slots = 0, slot_doubles = 0;
+  dgsqp_solver* owner = nullptr;            // handle whose launch uses the pool ...
+  unsigned long long owner_gen = 0;         // ... and which of its launches
+};
+DgParkPool g_park[64];
 }  // namespace
 // the stream the handle's solve in flight runs on: its own, or the leader's for a member of a grouped launch
 static hipStream_t active_stream(const dgsqp_solver* h) { return h->group_leader ? h->group_leader->stream : h->stream; }
@@ -360,6 +368,7 @@ static bool coop_for_launch(dgsqp_solver* h, int grid) {
 // DGSQP_DEFER_FACTOR override dgsqp_set_deferral.)
 static int park_for_launch(dgsqp_solver* h, bool coop, int grid, int64_t total, DgPark* out) {
   memset(out, 0, sizeof(*out));
+  h->park_last_cap = 0;
   int min_it = h->defer_min_it;
   double factor = h->defer_factor;
   { const char* e = getenv("DGSQP_DEFER"); if (e && atoi(e) == 0) min_it = 0; }
@@ -370,25 +379,29 @@ static int park_for_launch(dgsqp_solver* h, bool coop, int grid, int64_t total, 
   double frac = 0.25;
   { const char* e = getenv("DGSQP_DEFER_CAP_FRAC"); if (e) frac = atof(e); }
   size_t cap = (size_t)((double)total * (frac > 0.0 && frac <= 1.0 ? frac : 0.25) + 1.0);
-  // The slots are allocated ONCE per handle, at its first deferring launch, for 4,096 scenarios (2.7 GB at configs[1]) or what 16 GB
-  // hold: a launch never pays for an allocation that depends on its own size (a hipMalloc of gigabytes takes tens of milliseconds).
-  size_t slots = 4096;
-  const size_t max_slots = (size_t)(16ull << 30) / (slot * sizeof(double));
-  if (slots > max_slots) slots = max_slots;
-  if (cap > slots) cap = slots;
-  if (cap < 1) return DGSQP_OK;
-  if (h->park_cap == 0) {
-    HIPCHK(h, hipMalloc((void**)&h->d_park, sizeof(DgParkEntry) * slots));
-    if (hipMalloc((void**)&h->d_park_store, sizeof(double) * slot * slots) != hipSuccess) {      // no room: solve without deferral
+  DgParkPool& pool = g_park[h->device & 63];      // (g_reg_mutex is held by the launch functions)
+  if (pool.owner && pool.owner != h && pool.owner->in_flight && pool.owner->launch_gen == pool.owner_gen) return DGSQP_OK;   // busy: no deferral
+  if (pool.slots == 0 || pool.slot_doubles < slot) {
+    if (pool.entries) (void)hipFree(pool.entries);
+    if (pool.store) (void)hipFree(pool.store);
+    pool = DgParkPool();
+    size_t slots = 4096;
+    const size_t max_slots = (size_t)(16ull << 30) / (slot * sizeof(double));
+    if (slots > max_slots) slots = max_slots;
+    if (slots < 1) return DGSQP_OK;
+    HIPCHK(h, hipMalloc((void**)&pool.entries, sizeof(DgParkEntry) * slots));
+    if (hipMalloc((void**)&pool.store, sizeof(double) * slot * slots) != hipSuccess) {      // no room: solve without deferral
       (void)hipGetLastError();
-      (void)hipFree(h->d_park); h->d_park = nullptr;
+      (void)hipFree(pool.entries); pool.entries = nullptr;
       return DGSQP_OK;
     }
-    h->park_cap = slots;
+    pool.slots = slots; pool.slot_doubles = slot;
   }
-  HIPCHK(h, hipMemsetAsync(h->d_park, 0, sizeof(DgParkEntry) * cap, h->stream));
+  if (cap > pool.slots) cap = pool.slots;
+  HIPCHK(h, hipMemsetAsync(pool.entries, 0, sizeof(DgParkEntry) * cap, h->stream));
+  pool.owner = h; pool.owner_gen = h->launch_gen + 1;      // (the launch about to be enqueued)
   h->park_last_cap = cap;
-  out->entries = h->d_park; out->store = h->d_park_store; out->cap = (unsigned int)cap;
+  out->entries = pool.entries; out->store = pool.store; out->cap = (unsigned int)cap;
   out->min_it = min_it; out->factor_x16 = (int)(factor * 16.0 + 0.5); out->slot_doubles = slot;
   return DGSQP_OK;
 }
@@ -486,8 +499,21 @@ void dgsqp_destroy(dgsqp_handle_t h) {
   if (h->ticket) (void)hipFree(h->ticket);
   if (h->d_coop) (void)hipFree(h->d_coop);
   if (h->d_coop_payload) (void)hipFree(h->d_coop_payload);
-  if (h->d_park) (void)hipFree(h->d_park);
-  if (h->d_park_store) (void)hipFree(h->d_park_store);
+  {
+    std::lock_guard<std::mutex> lk(g_reg_mutex);
+    DgParkPool& pool = g_park[h->device & 63];
+    if (pool.owner == h) pool.owner = nullptr;
+    if (g_handles.empty()) {          // last handle of the process: the pools go as well
+      for (DgParkPool& pl : g_park) {
+        if (pl.entries || pl.store) {
+          // (the pool's memory belongs to the device it was allocated on)
+          if (pl.entries) (void)hipFree(pl.entries);
+          if (pl.store) (void)hipFree(pl.store);
+          pl = DgParkPool();
+        }
+      }
+    }
+  }
   if (h->drained_host) (void)hipHostFree(h->drained_host);
   if (h->d_trace) (void)hipFree(h->d_trace);
   if (h->d_itlog) (void)hipFree(h->d_itlog);
@@ -692,12 +718,15 @@ int dgsqp_deferral_stats(dgsqp_handle_t h, uint64_t* out2) {
 
 int dgsqp_deferral_log(dgsqp_handle_t h, uint64_t* out, int64_t cap_rows) {
   if (!h || !out || cap_rows < 0) return -1;
-  if (hipSetDevice(h->device) != hipSuccess || wait_idle(h) != DGSQP_OK || !h->d_park) return 0;
+  if (hipSetDevice(h->device) != hipSuccess || wait_idle(h) != DGSQP_OK) return 0;
+  std::lock_guard<std::mutex> lk(g_reg_mutex);
+  const DgParkPool& pool = g_park[h->device & 63];
+  if (!pool.entries || pool.owner != h) return 0;        // (another launch has used the device's pool since)
   uint64_t st[2];
   if (dgsqp_deferral_stats(h, st) != DGSQP_OK) return -1;
   const int64_t n = (int64_t)st[0] < cap_rows ? (int64_t)st[0] : cap_rows;
   std::vector<DgParkEntry> e((size_t)n);
-  if (n > 0 && hipMemcpy(e.data(), h->d_park, sizeof(DgParkEntry) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (n > 0 && hipMemcpy(e.data(), pool.entries, sizeof(DgParkEntry) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
   for (int64_t i = 0; i < n; i++) {
     uint64_t* r = out + 11 * i;
     memcpy(r + 8, e[i].cond, sizeof(double) * 3);

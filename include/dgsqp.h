@@ -312,7 +312,10 @@ int dgsqp_coop_stats(dgsqp_handle_t h, uint64_t* out6);
    workgroup stores the LDS arena and its scratch in a slot and takes the next ticket -- and resumed from that image once the queue
    is empty, the scenarios that have cost the most so far first.  The long solves of a launch's last batches thereby run while the
    chip still has other work.  Defaults: min_iters 8, factor 2.0; min_iters 0 switches it off.  Never applied with a wall-clock
-   limit (dgsqp_params_t.time_limit >= 0), to DG-SQP v2, while logs are recorded, or in non-cooperative launches. */
+   limit (dgsqp_params_t.time_limit >= 0), to DG-SQP v2, while logs are recorded, or in non-cooperative launches.  The slots
+   (LDS image + scratch image per scenario, 4,096 of them or what 16 GB hold) are one pool per device, allocated at the first
+   deferring launch; a cooperative launch that finds the pool in use by another launch in flight simply does not defer.  Nothing is
+   deferred before 32 scenarios of the launch have finished nor when fewer than two rounds of fresh scenarios remain. */
 int dgsqp_set_deferral(dgsqp_handle_t h, int32_t min_iters, double factor);
 /* Diagnostic: out2 = {scenarios deferred, scenarios resumed} of the handle's last cooperative launch (equal after the launch). */
 int dgsqp_deferral_stats(dgsqp_handle_t h, uint64_t* out2);
