@@ -15,7 +15,7 @@ ok() { grep -q "^$1 0$" $G/steps.txt; }
 cp $G/steps.txt $D/${P}_measure_steps.txt
 for f in $G/bench_*.json; do python3 -c "import json,sys; json.load(open('$f'))" && cp $f $D/${P}_$(basename $f); done
 rm -f $D/${P}_bench_dyn_curve_N25_driver_group20.json      # (superseded: the driver's command itself now issues its 20 steps as one launch)
-for f in $G/forks_*.txt $G/phase_cycles_*.txt $G/tail_composition_*.txt $G/coop_line_search_*.txt $G/deferral_*.txt $G/slowest_scenarios_*.txt $G/gpu_tests_parity_lines.txt; do
+for f in $G/forks_*.txt $G/phase_cycles_*.txt $G/tail_composition_*.txt $G/coop_line_search_*.txt $G/deferral_*.txt $G/slowest_scenarios_*.txt $G/device_vs_oracle_*.txt $G/gpu_tests_parity_lines.txt; do
   [ -f $f ] || continue
   if grep -q "Traceback" $f; then echo "traceback in $f -- not copied" >&2; exit 1; fi
   cp $f $D/${P}_$(basename $f)

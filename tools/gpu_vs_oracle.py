@@ -7,13 +7,7 @@ from dgsqp_amd.solver import DGSQP
 from oracle import oracle
 which, N, B = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 game = kinematic_racing_game('curve' if which == 'kbcurve' else 'chicane', N=N, reg=0.0 if which == 'kbcurve' else 1e-3) if which.startswith('kb') else dynamic_racing_game(N=N, rk4_substeps=10)   # reg of curve.py:161 / chicane.py:164
-import dgsqp_amd.solver as sv
-if os.environ.get('TIGHT'):
-    _o = sv.build_params
-    def _bp(p):
-        q = _o(p); q.lsqr_atol = q.lsqr_btol = 1e-13; return q
-    sv.build_params = _bp
-s = DGSQP(*game.solver_args(), print_method=None)
+s = DGSQP(*game.solver_args(), print_method=None, **({'lsqr_tol': 1e-13} if os.environ.get('TIGHT') else {}))     # TIGHT: converged LSQR dual start (conftest.tight_lsqr)
 x0, uws = sample_scenarios(game, B, seed=1)
 res = s.solve_batch(x0, uws)
 oracle.build()
@@ -31,3 +25,5 @@ relu = [np.abs(res['u'][i] - o['u'][i]).max() / max(1e-300, np.abs(o['u'][i]).ma
 print('identical & converged:', int(conv.sum()), 'max rel |du| among them', max(relu) if relu else None, 'median', float(np.median(relu)) if relu else None)
 print('mean iters gpu', res['num_iters'].mean(), 'oracle', o['num_iters'].mean())
 print('gpu conv', np.mean(res['status'] <= 1), 'oracle conv', np.mean(o['status'] <= 1))
+same_conv = (res['status'] <= 1) == (o['status'] <= 1)
+print('same converged flag:', same_conv.mean(), '| iterations within 1 among the commonly converged:', float(np.mean(np.abs(res['num_iters'] - o['num_iters'])[(res['status'] <= 1) & (o['status'] <= 1)] <= 1)))

@@ -37,6 +37,8 @@ step bench_dyn_curve_N25_v2 $O/bench_dyn_curve_N25_v2_B512.json python bench.py 
 # ---- parity tables
 python -m pytest tests -m gpu -q -s 2>&1 | grep -E "identical|largest relative|converged device|kernel ms alone|passed|failed" | cut -c1-2000 > $O/gpu_tests_parity_lines.txt
 echo "gpu_tests ${PIPESTATUS[0]}" >> $O/steps.txt
+TIGHT=1 step vs_oracle_dyn $O/device_vs_oracle_dyn_curve_N25_B512.txt python tools/gpu_vs_oracle.py dyn 25 512
+TIGHT=1 step vs_oracle_chicane $O/device_vs_oracle_kb_chicane_N25_B512.txt python tools/gpu_vs_oracle.py kbchicane 25 512
 step coop_debug $O/coop_line_search_dyn_curve_N25_B1024.txt python tools/gpu_coop_debug.py dyn_curve_N25 1024 1
 step defer_debug $O/deferral_dyn_curve_N25_20x1024.txt python tools/gpu_defer_debug.py dyn_curve_N25 1024 20
 step defer_timeline $O/deferral_timeline_dyn_curve_N25_20x1024.txt python tools/gpu_defer_timeline.py dyn_curve_N25 1024 20 8 2.0
