@@ -29,7 +29,8 @@ rows = ['| workload (fp64) | layout | scen/s (`value`) | one launch at a time | 
         row('2-agent F1 track N=50 (**configs[3]** game), B=256', 'XL', L('kb_f1_N50_B256'), ' (as 4 launches of 4 batches: 109)'),
         row('2-agent KB curve N=50 (n = 200), B=512', 'XL', L('kb_curve_N50_B512'), ' (as 4 launches of 4 batches: 459)'),
         row('**configs[4]** 6-car merge N=25 (n = 300, 1,587 rows), B=256', 'XL, tables in constant memory', L('merge6_N25_B256')),
-        row('dynamic bicycle curve N=25, DG-SQP v2 (study parameters), B=512', 'LDS', L('dyn_curve_N25_v2_B512'))]
+        row('dynamic bicycle curve N=25, DG-SQP v2 (study parameters), B=512, 8 steps (bound by single solves of ~10 s)', 'LDS', L('dyn_curve_N25_v2_B512')),
+        row('same, 48 steps (8 batches per launch, 3 launches in flight)', 'LDS', L('dyn_curve_N25_v2_B512_steps48'))]
 # the generic row() bolds nothing; fix the first data row by hand
 d0 = L('dyn_curve_N25_driver_steps20_warmup5')
 rows[2] = row('**configs[1]** 2-agent dynamic bicycle curve N=25, rk4 M=10, reg 1e-3 — **driver command, 20 steps**', 'LDS', d0).replace(f"| LDS | {f(d0['value'])} |", f"| LDS | **{f(d0['value'])}** |")

@@ -33,6 +33,7 @@ step bench_kb_barc3_N25 $O/bench_kb_barc3_N25_B512.json python bench.py --worklo
 step bench_kb_f1_N50 $O/bench_kb_f1_N50_B256.json python bench.py --workload kb_f1_N50 --batch 256 --steps 16 --single-steps 0 --host-steps 0 --cpu-sample 0
 step bench_kb_curve_N50 $O/bench_kb_curve_N50_B512.json python bench.py --workload kb_curve_N50 --batch 512 --steps 16 --single-steps 0 --host-steps 0 --cpu-sample 0
 step bench_merge6_N25 $O/bench_merge6_N25_B256.json python bench.py --workload merge6_N25 --batch 256 --steps 16 --pipeline 2 --group 4 --single-steps 1 --host-steps 0 --cpu-sample 16
+step bench_dyn_curve_N25_v2_steps48 $O/bench_dyn_curve_N25_v2_B512_steps48.json python bench.py --workload dyn_curve_N25_v2 --batch 512 --steps 48 --group 8 --pipeline 3 --single-steps 0 --host-steps 0 --cpu-sample 0
 step bench_dyn_curve_N25_v2 $O/bench_dyn_curve_N25_v2_B512.json python bench.py --workload dyn_curve_N25_v2 --batch 512 --steps 8 --group 4 --pipeline 2 --single-steps 1 --host-steps 0 --cpu-sample 0
 # ---- parity tables
 python -m pytest tests -m gpu -q -s 2>&1 | grep -E "identical|largest relative|converged device|kernel ms alone|passed|failed" | cut -c1-2000 > $O/gpu_tests_parity_lines.txt
