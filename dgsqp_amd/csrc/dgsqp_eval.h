@@ -1011,7 +1011,10 @@ __device__ __noinline__ void dev_hessian_adjoint(const Ctx& c) {
   gptr Qg = c.ws + D.ws_q;
   const gptr T2base = c.ws + D.ws_t2;
   constexpr int EE = DG_MAXEFF * DG_MAXEFF;
+  PROF_BEGIN(ph0);
   dev_costates(c, lds + L.l);
+  PROF_END(PH_H_COST, ph0);
+  PROF_BEGIN(ph1);
   // ---- 2. H[a][k][b] = sum_o lam^a_{k+1}[b,o] * Hessian of f^b_{k,o} in effective variables (interpolated from the
   //         e_i / e_i+e_j Taylor coefficients: H_ii = 2 c_i, H_ij = c_ij - c_i - c_j)
   // (a) cv[a][k][b][dir] = sum_o lam^a_{k+1}[b,o] T2[b][k][o][dir], once per direction (coalesced over dir), kept in the
@@ -1059,6 +1062,8 @@ __device__ __noinline__ void dev_hessian_adjoint(const Ctx& c) {
     Hg[it] = h;
   }
   __syncthreads();
+  PROF_END(PH_H_CONTR, ph1);
+  PROF_BEGIN(ph2);
   // ---- 3. one lane per row of Q
   for (int row = TID; row < n; row += NT) {
     const int a = row / (N * DGSQP_NUA), rem = row % (N * DGSQP_NUA), k0 = rem / DGSQP_NUA, j0 = rem % DGSQP_NUA;
@@ -1097,6 +1102,7 @@ __device__ __noinline__ void dev_hessian_adjoint(const Ctx& c) {
     }
   }
   __syncthreads();
+  PROF_END(PH_H_ROWS, ph2);
 }
 
 // ------------------------------------------------------------------------------------------------
