@@ -66,7 +66,7 @@ class ParamsT(C.Structure):
         ('eig_floor', C.c_double), ('time_limit', C.c_double),
         ('snap_active_bounds', C.c_int32), ('variant', C.c_int32),
         ('nms', C.c_int32), ('nms_frequency', C.c_int32), ('nms_memory_size', C.c_int32), ('merit_decrease_condition', C.c_int32),
-        ('reserved_', C.c_int32),
+        ('qp_method', C.c_int32),
         ('reg_decay', C.c_double), ('delta_decay', C.c_double), ('merit_decrease', C.c_double), ('merit_parameter', C.c_double),
     ]
 
@@ -147,6 +147,8 @@ def load_library() -> C.CDLL:
     lib.dgsqp_evaluate_batch.restype = C.c_int
     lib.dgsqp_qp_batch.argtypes = [H, C.c_int64, _PD, _PD, _PD, _PD, _PD, _PD, _PI]
     lib.dgsqp_qp_batch.restype = C.c_int
+    lib.dgsqp_qp_batch_info.argtypes = [H, C.c_int64, _PD, _PD, _PD, _PD, _PD, _PD, _PI, _PD]
+    lib.dgsqp_qp_batch_info.restype = C.c_int
     lib.dgsqp_pid_warm_start_batch.argtypes = [H, C.c_int64, _PD, C.POINTER(PidT), _PD, _PD, _PI]
     lib.dgsqp_pid_warm_start_batch.restype = C.c_int
     lib.dgsqp_set_trace.argtypes = [H, C.c_int]
@@ -196,7 +198,7 @@ def load_library() -> C.CDLL:
 
 EXPORTED_SYMBOLS = ['dgsqp_create', 'dgsqp_destroy', 'dgsqp_dims', 'dgsqp_plan', 'dgsqp_last_error', 'dgsqp_backend_info',
                     'dgsqp_solve_batch', 'dgsqp_stage_inputs', 'dgsqp_solve_staged', 'dgsqp_fetch_results',
-                    'dgsqp_evaluate_batch', 'dgsqp_qp_batch', 'dgsqp_set_trace', 'dgsqp_fetch_trace',
+                    'dgsqp_evaluate_batch', 'dgsqp_qp_batch', 'dgsqp_qp_batch_info', 'dgsqp_set_trace', 'dgsqp_fetch_trace',
                     'dgsqp_pid_warm_start_batch', 'dgsqp_launch_staged', 'dgsqp_wait', 'dgsqp_draining',
                     'dgsqp_set_iterate_log', 'dgsqp_fetch_iterate_log', 'dgsqp_synchronize', 'dgsqp_finished', 'dgsqp_launch_staged_group', 'dgsqp_solve_batch_f32', 'dgsqp_comm_unique_id', 'dgsqp_comm_init',
                     'dgsqp_comm_destroy', 'dgsqp_gather_stats', 'dgsqp_comm_barrier', 'dgsqp_comm_allreduce_max',

@@ -158,7 +158,7 @@ dg_evaluate_kernel(const DgProb* __restrict__ D, int64_t B, const double* __rest
 // Test hook: _solve_qp at the linearisation point (u, l).
 __global__ void __launch_bounds__(DG_BLOCK)
 dg_qp_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__ x0, const double* __restrict__ u,
-             const double* __restrict__ l, double* du, double* lhat, double* Qpd, int32_t* flag, double* __restrict__ ws_all) {
+             const double* __restrict__ l, double* du, double* lhat, double* Qpd, int32_t* flag, double* info8, double* __restrict__ ws_all) {
   Ctx c;
   c.coop = nullptr; c.coop_payload = nullptr; c.coop_total = 0; c.coop_start = 0; c.coop_verify = 0; c.coop_window = 0; c.coop_helpers = 0;
   c.ws = (gptr)ws_all + (int64_t)blockIdx.x * dg_prob.ws_doubles;
@@ -180,6 +180,7 @@ dg_qp_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__
     if (du) for (int i = TID; i < n; i += NT) du[b * n + i] = dg_lds[L.o_du + i];
     if (lhat) for (int r = TID; r < nc; r += NT) lhat[b * nc + r] = dg_lds[L.o_lhat + r];
     if (flag && TID == 0) flag[b] = f;
+    if (info8 && TID < 8) info8[b * 8 + TID] = dg_prob.osqp ? dg_lds[L.scal + DG_OSQP_INFO + TID] : 0.0;
     __syncthreads();
   }
 }
@@ -1067,6 +1068,11 @@ int dgsqp_sample_batch(dgsqp_handle_t h, int64_t B, const dgsqp_sampler_t* spec,
 
 int dgsqp_qp_batch(dgsqp_handle_t h, int64_t B, const double* x0, const double* u, const double* l, double* du_out,
                    double* lhat, double* Qpd, int32_t* flag) {
+  return dgsqp_qp_batch_info(h, B, x0, u, l, du_out, lhat, Qpd, flag, nullptr);
+}
+
+int dgsqp_qp_batch_info(dgsqp_handle_t h, int64_t B, const double* x0, const double* u, const double* l, double* du_out,
+                        double* lhat, double* Qpd, int32_t* flag, double* info8) {
   if (!h || B < 0 || !x0 || !u || !l) { if (h) h->err = "bad argument"; return DGSQP_E_ARG; }
   if (B == 0) return DGSQP_OK;
   HIPCHK(h, hipSetDevice(h->device));
@@ -1081,14 +1087,15 @@ int dgsqp_qp_batch(dgsqp_handle_t h, int64_t B, const double* x0, const double* 
   double* dx0 = tb.alloc<double>(B * D.nq); double* du = tb.alloc<double>(B * n); double* dl = tb.alloc<double>(B * nc);
   double* ddu = du_out ? tb.alloc<double>(B * n) : nullptr; double* dlh = lhat ? tb.alloc<double>(B * nc) : nullptr;
   double* dQ = Qpd ? tb.alloc<double>(B * n * n) : nullptr; int32_t* df = flag ? tb.alloc<int32_t>(B) : nullptr;
-  if (!dx0 || !du || !dl || (du_out && !ddu) || (lhat && !dlh) || (Qpd && !dQ) || (flag && !df)) { h->err = "hipMalloc failed"; return DGSQP_E_NOMEM; }
+  double* dinfo = info8 ? tb.alloc<double>(B * 8) : nullptr;
+  if (!dx0 || !du || !dl || (du_out && !ddu) || (lhat && !dlh) || (Qpd && !dQ) || (flag && !df) || (info8 && !dinfo)) { h->err = "hipMalloc failed"; return DGSQP_E_NOMEM; }
   HIPCHK(h, hipMemcpy(dx0, x0, sizeof(double) * B * D.nq, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(du, u, sizeof(double) * B * n, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(dl, l, sizeof(double) * B * nc, hipMemcpyHostToDevice));
   std::unique_lock<std::mutex> game_lock(g_reg_mutex);
   { int rcu = upload_problem(h); if (rcu) return rcu; }
   h->in_flight = true;
-  hipLaunchKernelGGL(dg_qp_kernel, dim3(grid), dim3(DG_BLOCK), h->lds_bytes, h->stream, h->dp, B, dx0, du, dl, ddu, dlh, dQ, df, h->ws);
+  hipLaunchKernelGGL(dg_qp_kernel, dim3(grid), dim3(DG_BLOCK), h->lds_bytes, h->stream, h->dp, B, dx0, du, dl, ddu, dlh, dQ, df, dinfo, h->ws);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->in_flight = false;
@@ -1096,6 +1103,7 @@ int dgsqp_qp_batch(dgsqp_handle_t h, int64_t B, const double* x0, const double* 
   if (lhat) HIPCHK(h, hipMemcpy(lhat, dlh, sizeof(double) * B * nc, hipMemcpyDeviceToHost));
   if (Qpd) HIPCHK(h, hipMemcpy(Qpd, dQ, sizeof(double) * B * n * n, hipMemcpyDeviceToHost));
   if (flag) HIPCHK(h, hipMemcpy(flag, df, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+  if (info8) HIPCHK(h, hipMemcpy(info8, dinfo, sizeof(double) * B * 8, hipMemcpyDeviceToHost));
   return DGSQP_OK;
 }
 

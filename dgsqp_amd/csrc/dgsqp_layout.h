@@ -70,6 +70,10 @@ struct DgLds {
   int p_R, p_lam, p_c, p_w, p_r, p_y, p_t, p_alist, p_rd, p_yd2, p_yslot, p_yfree, p_dpart, p_act, p_part, p_xu;
   // QP outputs that must survive trial evaluations
   int o_du, o_lhat;
+  int a_z, a_y, a_E, a_dy, a_w;  // qp_method = OSQP (dgsqp_osqp.h): the ADMM's n_c-vectors z, y, E (row scaling), delta y, a work vector -- inside the
+                                 // slot of the active-set factor T (p_R), which only the polish needs
+  int a_sw;                      // pivot-column buffers of the Gauss-Jordan sweep (2 (NH RPT + 4) doubles): the QP's partial-sum slot where that is large enough
+  int a_tail;                    // ... and five n-vectors of the polish at the end of that slot (T keeps room for DgProb.osqp_namax active rows)
   int x_el;  // XL layout with xl_el: packed lower triangle of the QP's elimination M = L~ D L~^T (overlaps the QP outputs and c_R, dead until J is built)
   int c_R;   // classical QP: the first DgProb.c_rcap columns of the triangular factor R, packed column-major (phase-multiplexed with e_xs2)
   // LSQR scratch (s_yd2 / s_dpart: the dense-dot scratch of the dual start -- the QP's p_yd2 / p_dpart except in the
@@ -97,6 +101,9 @@ struct DgProb {
                     // state-Hessian columns (e_K) live in the global scratch (ws_K) and the stage gradients share the costates'
                     // slot: games whose vectors alone nearly fill the arena (6 agents, N = 25: n = 300, 1,587 rows, 837 gradients)
   int c_rcap;       // columns of R (classical QP) that live in LDS; the rest in the global scratch
+  int osqp;         // par.qp_method == DGSQP_QP_OSQP: the QP is OSQP's ADMM + polish (dgsqp_osqp.h) on the explicit-inverse layout, whatever reg
+  int osqp_nacap;   // (layout search: the T slot is sized for this many active rows -- n unless the arena overflows)
+  int osqp_namax;   // ... whose polish handles at most this many active rows (what the T slot holds next to the polish vectors)
   int classic_qp;   // the QP runs the classical (J = L^-T) Goldfarb-Idnani kernels of dgsqp_xl.h: XL layout, or a projected Hessian
                     // whose smallest eigenvalue (eig_floor + reg) is below 1e-8 -- the literal reg = 0 formula
   int big;          // 2: XL layout (n > 128, dgsqp_xl.h).  1: the packed inverse P and the packed Householder reflectors live in the workgroup's global scratch (L2)
@@ -146,7 +153,10 @@ static inline std::string dg_build_layout(DgProb& D) {
   // matrices of the classical QP: M / its Cholesky factor, J, R (row-major n x n).  XL: the Jacobi buffers are reused
   D.classic_qp = D.big == 2 || D.eig_floor + (D.par.reg > 0 ? D.par.reg : 0.0) < 1e-8 ||
                  (D.par.variant == DGSQP_VARIANT_V2 && D.eig_floor < 1e-8);      // v2: reg decays towards 0 during a solve (dgsqp_solve_v2.h)
-  if (D.big == 2) { D.ws_xM = D.ws_R; D.ws_xJ = D.ws_P; D.ws_xR = D.ws_V; }
+  // OSQP: ADMM adds sigma = 1e-6 and the polish delta = 1e-6 to the projected Hessian, so its explicit inverses are well conditioned
+  // whatever reg is; it needs the projected Hessian M itself (n x n, row-major) in the scratch; W = Gs^T Gs borrows the Y slot
+  if (D.osqp) { D.classic_qp = 0; D.ws_xM = D.ws_doubles; D.ws_xJ = D.ws_xR = D.ws_xM; D.ws_doubles = D.ws_xM + (int64_t)D.n * D.n; }
+  else if (D.big == 2) { D.ws_xM = D.ws_R; D.ws_xJ = D.ws_P; D.ws_xR = D.ws_V; }
   else if (D.classic_qp) { D.ws_xM = D.ws_doubles; D.ws_xJ = D.ws_xM + (int64_t)D.n * D.n; D.ws_xR = D.ws_xJ + (int64_t)D.n * D.n; D.ws_doubles = D.ws_xR + (int64_t)D.n * D.n; }
   // hessian_approximation = 'bfgs': u of the previous iteration and d(u_prev, l) (2 n), the Hessian used at the top of the
   // previous iteration and its projection (n x n each)
@@ -198,7 +208,20 @@ static inline std::string dg_build_layout(DgProb& D) {
   const int eig_end = o;
   // QP (P aliases Bp)
   o = L.scr + (D.big ? 0 : ((npk + 1) & ~1));
-  L.p_R = D.big == 2 ? -1 : take(D.classic_qp ? npk : dg_tcol(n));   // (the dual method's inverse factor T: padded columns, dg_tcol)
+  {
+    int tslot = D.classic_qp ? npk : dg_tcol(n);   // (the dual method's inverse factor T: padded columns, dg_tcol)
+    const int ncp = (nc + 1) & ~1, np = (n + 1) & ~1;
+    if (D.osqp) tslot = dg_tcol(D.osqp_nacap < n ? D.osqp_nacap : n) + (D.osqp_nacap < n ? 5 * np : 0);
+    if (D.osqp && tslot < 5 * ncp + 5 * np) tslot = 5 * ncp + 5 * np;
+    L.p_R = D.big == 2 ? -1 : take(tslot);
+    if (D.osqp) {
+      L.a_z = L.p_R; L.a_y = L.a_z + ncp; L.a_E = L.a_y + ncp; L.a_dy = L.a_E + ncp; L.a_w = L.a_dy + ncp;
+      L.a_tail = L.p_R + ((tslot - 5 * np) & ~1);
+      int na = 0;
+      while (na < n && dg_tcol(na + 1) <= L.a_tail - L.p_R) na++;
+      D.osqp_namax = na;
+    }
+  }
   L.p_lam = take(n + 1); L.p_c = take(n + 9); L.p_w = take(n + 9); L.p_r = take(n + 9);   // (c, w are read in groups of eight: zero tail)
   L.p_y = take(n); L.p_t = take(n); L.p_alist = take((n + 2) / 2 + 1); L.p_rd = take(n + 1);
   if (!D.tab_const && D.big != 2) {   // the dual start borrows p_yd2 / p_dpart while its own vectors (5 of length n_c) sit at L.scr: keep them apart
@@ -206,6 +229,10 @@ static inline std::string dg_build_layout(DgProb& D) {
     if (o < L.scr + lsqr_size) o = L.scr + lsqr_size;
   }
   L.p_yd2 = take(nd); L.p_yslot = take((n + 2) / 2 + 1); L.p_yfree = take((n + 2) / 2 + 1); L.p_dpart = take(D.ntask); L.p_act = take(nc / 8 + 2); L.p_part = take(DG_NH * n);
+  if (D.osqp) {
+    const int need = 2 * (DG_NH * rpt + 4);
+    L.a_sw = DG_NH * n >= need ? L.p_part : take(need);
+  }
   L.p_xu = L.p_rd;     // unconstrained minimiser of the QP, x = x_u - Y lam at every point of the dual method (the slot the reciprocal diagonal of the Cholesky factor had)
   const int qp_end = o;
   // QP outputs live past the end of both the QP and EVAL scratch
@@ -272,6 +299,7 @@ static inline std::string dg_build_layout(DgProb& D) {
   }
   L.total = tot;
   if ((long)tot * 8 > DG_LDS_LIMIT && !D.big) { D.big = 1; return dg_build_layout(D); }   // (n > 128 starts at big = 2)
+  if ((long)tot * 8 > DG_LDS_LIMIT && D.osqp && D.big == 1 && D.osqp_nacap > 24) { D.osqp_nacap -= 8; return dg_build_layout(D); }   // OSQP: a smaller T slot (polish of fewer active rows)
   if ((long)tot * 8 > DG_LDS_LIMIT && D.big == 2 && D.xl_pack) { D.xl_pack = 0; D.gd_global = 0; return dg_build_layout(D); }   // no room for the packed matrix: the plain XL layout
   if ((long)tot * 8 > DG_LDS_LIMIT && D.big == 2 && !D.gd_global) { D.gd_global = 1; return dg_build_layout(D); }
   if ((long)tot * 8 > DG_LDS_LIMIT && D.big == 2 && !D.tab_const) { D.tab_const = 1; return dg_build_layout(D); }
@@ -298,6 +326,8 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   if (P.N < 1 || P.N > DG_NMAX) return "unsupported horizon";
   if (par.merit_function == DGSQP_MERIT_SUM_OBJ_L1 && par.variant != DGSQP_VARIANT_V2) return "merit function sum_obj_l1 belongs to DG-SQP v2";
   if (P.N * P.M * DGSQP_NUA > DG_NVARMAX) return "more than 320 decision variables are not supported yet";
+  if (par.qp_method != DGSQP_QP_ACTIVE_SET && par.qp_method != DGSQP_QP_OSQP) return "unknown qp_method";
+  if (par.qp_method == DGSQP_QP_OSQP && P.N * P.M * DGSQP_NUA > 128) return "qp_method OSQP supports up to 128 decision variables (the XL layout has no ADMM kernels yet)";
   if (P.n_segs < 1 || P.n_segs > DGSQP_MAX_SEGS) return "bad track table";
   D.M = P.M; D.N = P.N; D.nq = 0; D.nu = P.M * DGSQP_NUA;
   int t2 = 0;
@@ -414,6 +444,8 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
     D.ntask = nt;
   }
   D.t2_doubles = t2;
+  D.osqp = par.qp_method == DGSQP_QP_OSQP ? 1 : 0;
+  D.osqp_nacap = D.n;
   D.big = D.n > 128 ? 2 : 0;   // XL layout: every matrix of the PSD / QP phases in the global scratch, generic (slow) kernels
   D.xl_noblock = getenv("DGSQP_XL_NOBLOCK") ? 1 : 0;
   if (D.big == 2 && D.n <= 176 && !getenv("DGSQP_XL_NOPACK")) { D.xl_pack = 1; D.gd_global = 1; }       // (tried first; dg_build_layout falls back when the arena overflows)

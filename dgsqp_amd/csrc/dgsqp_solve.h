@@ -144,6 +144,53 @@ __device__ inline void twisted_eigvec(double dA, double dB, double eA, double eB
   const double nr = 1.0 / wave_max(fmax(__builtin_fabs(zA), __builtin_fabs(zB)));
   zA *= nr; zB *= nr;
 }
+// Symmetric Gauss-Jordan sweep of an SPD matrix held in registers (thread (jc = TID & 127, hf = TID >> 7) owns column jc, rows
+// hf + NH r): after all n pivots the slice holds -A^-1 (SPD => no pivoting).  tws: 2 (NH RPT + 4) doubles of LDS for the
+// published pivot column (double buffered).  One barrier per pivot.
+template <int RPT>
+__device__ __forceinline__ void spd_sweep_regs(double (&Br)[RPT], lptr tws, int n) {
+  constexpr int NH = DG_NH;
+  const int jc = TID & 127, hf = TID >> 7;
+  const bool colok = jc < n;
+  lptr colA = tws, colB = tws + (NH * RPT + 4);  // pivot column, double buffered; padding rows stay zero
+  for (int i = TID; i < 2 * (NH * RPT + 4); i += NT) colA[i] = 0.0;
+  __syncthreads();
+  if (jc == 0) {
+#pragma unroll
+    for (int r = 0; r < RPT; r++) colA[hf + NH * r] = Br[r];
+  }
+  __syncthreads();
+  for (int k = 0; k < n; k++) {
+    clptr colk = (k & 1) ? colB : colA;
+    lptr coln = (k & 1) ? colA : colB;
+    const double dinv = fast_rcp(colk[k]);
+    const double rj = colok ? colk[jc] * dinv : 0.0;
+    const bool pc = jc == k;
+    const double rowv = pc ? -dinv : rj;   // new row k:  a_kj/d, pivot -1/d
+    // Straight-line update (selects on registers only, every LDS read unconditional so they can be batched):
+    //   general  a_ij - a_ik a_kj/d ;  column k  a_ik/d ;  row k  a_kj/d ;  pivot -1/d
+    double ci[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; r++) ci[r] = colk[hf + NH * r];
+    if (!pc) {
+#pragma unroll
+      for (int r = 0; r < RPT; r++) Br[r] = fma(-ci[r], rj, Br[r]);      // general entry
+    } else {
+#pragma unroll
+      for (int r = 0; r < RPT; r++) Br[r] = ci[r] * dinv;                // pivot column (4 threads per step)
+    }
+    if (hf == (k & (NH - 1))) {      // pivot row: one register (index k / NH, wave-uniform) of these threads
+      const int rs = k / NH;
+#pragma unroll
+      for (int r = 0; r < RPT; r++) Br[r] = (r == rs) ? rowv : Br[r];
+    }
+    if (jc == k + 1) {   // the next pivot column is final as soon as this update is done
+#pragma unroll
+      for (int r = 0; r < RPT; r++) coln[hf + NH * r] = Br[r];
+    }
+    __syncthreads();
+  }
+}
 // Register-resident layout: thread (jc = TID & 127, hf = TID >> 7) owns column jc, rows hf, hf+2, hf+4, ...
 // (RPT of them) of the symmetric matrix for the whole Householder reduction AND the Gauss-Jordan sweep; LDS
 // only carries the broadcast vectors (reflector v, w, pivot column) and the stored reflectors.
@@ -415,44 +462,7 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd, boo
   if (!want_inverse) return true;      // the classical QP works on M itself (written to Qpd above): no explicit inverse
   PROF_BEGIN(pt_s);
   // ---- 5. symmetric Gauss-Jordan sweep in registers: after all pivots the slice holds -M^-1
-  lptr colA = tws, colB = tws + (NH * RPT + 4);  // pivot column, double buffered; padding rows stay zero
-  for (int i = TID; i < 2 * (NH * RPT + 4); i += NT) colA[i] = 0.0;
-  __syncthreads();
-  if (jc == 0) {
-#pragma unroll
-    for (int r = 0; r < RPT; r++) colA[hf + NH * r] = Br[r];
-  }
-  __syncthreads();
-  for (int k = 0; k < n; k++) {
-    clptr colk = (k & 1) ? colB : colA;
-    lptr coln = (k & 1) ? colA : colB;
-    const double dinv = fast_rcp(colk[k]);
-    const double rj = colok ? colk[jc] * dinv : 0.0;
-    const bool pc = jc == k;
-    const double rowv = pc ? -dinv : rj;   // new row k:  a_kj/d, pivot -1/d
-    // Straight-line update (selects on registers only, every LDS read unconditional so they can be batched):
-    //   general  a_ij - a_ik a_kj/d ;  column k  a_ik/d ;  row k  a_kj/d ;  pivot -1/d
-    double ci[RPT];
-#pragma unroll
-    for (int r = 0; r < RPT; r++) ci[r] = colk[hf + NH * r];
-    if (!pc) {
-#pragma unroll
-      for (int r = 0; r < RPT; r++) Br[r] = fma(-ci[r], rj, Br[r]);      // general entry
-    } else {
-#pragma unroll
-      for (int r = 0; r < RPT; r++) Br[r] = ci[r] * dinv;                // pivot column (4 threads per step)
-    }
-    if (hf == (k & (NH - 1))) {      // pivot row: one register (index k / NH, wave-uniform) of these threads
-      const int rs = k / NH;
-#pragma unroll
-      for (int r = 0; r < RPT; r++) Br[r] = (r == rs) ? rowv : Br[r];
-    }
-    if (jc == k + 1) {   // the next pivot column is final as soon as this update is done
-#pragma unroll
-      for (int r = 0; r < RPT; r++) coln[hf + NH * r] = Br[r];
-    }
-    __syncthreads();
-  }
+  spd_sweep_regs<RPT>(Br, tws, n);
   if (big) {
     gptr Pp = c.ws + D.ws_P;
 #pragma unroll
@@ -715,6 +725,7 @@ __device__ inline void qpt_drop(lptr T, lds_i_t* alist, lds_i_t* yslot, lptr lam
 }
 
 #include "dgsqp_qp.h"
+#include "dgsqp_osqp.h"
 __device__ void dev_xl_psd(const Ctx& c, gptr Qpd);   // XL layout (n > 128), dgsqp_xl.h
 __device__ int dev_xl_qp(const Ctx& c);
 
@@ -1378,6 +1389,11 @@ __device__ inline int dev_linearize_and_qp(const Ctx& c, bool do_qp, double* con
   }
   if (!do_qp) return 0;
   dev_qt_mul(c);
+  if (dg_prob.osqp) {          // OSQP's arithmetic (dgsqp_osqp.h) on the projected Hessian M itself
+    dev_psd_inverse(c, c.ws + dg_prob.ws_xM, false);
+    if (Qpd) { for (int e = TID; e < dg_prob.n * dg_prob.n; e += NT) Qpd[e] = (c.ws + dg_prob.ws_xM)[e]; }
+    return dev_qp_osqp(c);
+  }
   if (dg_prob.big == 2) { dev_xl_psd(c, Qpd); return dev_xl_qp(c); }   // n > 128: dgsqp_xl.h
   if (dg_prob.classic_qp) {    // literal reg = 0 projection: condition ~1e12, classical active-set kernels on M itself
     dev_psd_inverse(c, c.ws + dg_prob.ws_xM, false);
@@ -1415,7 +1431,8 @@ __device__ inline void dev_take_full_step(const Ctx& c) {  // u += du ; l = lhat
 }
 
 // _watchdog_line_search_4 (DGSQP.py:1174-1288; branch order of SURVEY.md A.7).  Base point and step
-// (u_k, du_k, l_k, lhat_k) are in LDS on entry; returns the number of extra QP solves.
+// (u_k, du_k, l_k, lhat_k) are in LDS on entry; returns the number of extra QP solves (negated when, with qp_method OSQP, one of them
+// was reported infeasible: the solve ends there).
 // One reading of the 100 MHz constant-rate counter for the whole workgroup (thread 0 reads, everybody gets the same value),
 // so that wall-clock decisions (time_limit, DGSQP.py:470 and :1243-1247) are uniform across the 8 wavefronts of a scenario.
 #define DG_CLOCK 56
@@ -1466,6 +1483,7 @@ __device__ inline int dev_watchdog(const Ctx& c, double mu, const LinScal& Sk) {
   for (int t = 0; t < 5; t++) {
     const int flag = dev_linearize_and_qp(c, true, nullptr, nullptr);
     nqp++;
+    if (flag != 0 && D.osqp) return -nqp;      // OSQP reported infeasibility: the reference's NaN step ends the solve (DGSQP.py:566-585)
     if (flag != 0) { fail = true; break; }
     dev_step_scalars(c, S);
     dev_evaluate_point(c, lds + L.u, 1.0, lds + L.o_du, nullptr, true);
@@ -1480,6 +1498,7 @@ __device__ inline int dev_watchdog(const Ctx& c, double mu, const LinScal& Sk) {
   {
     const int flag = dev_linearize_and_qp(c, true, nullptr, nullptr);
     nqp++;
+    if (flag != 0 && D.osqp) return -nqp;
     if (flag != 0) fail = true;
     else {
       dev_step_scalars(c, S);
@@ -1494,6 +1513,7 @@ __device__ inline int dev_watchdog(const Ctx& c, double mu, const LinScal& Sk) {
     else if (phi_n > phi_k) fail = true;
     else {
       const int flag = dev_linearize_and_qp(c, true, nullptr, nullptr);
+      if (flag != 0 && D.osqp) return -(nqp + 1);
       if (flag != 0) {
         dev_restore_base(c);
         dev_line_search(c, mu, phi_k, dphi_k, Sk.S0, Sk.S1);
@@ -1762,7 +1782,8 @@ __device__ inline bool dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
     if (cond[0] < D.par.p_tol && cond[1] < D.par.d_tol && cond[2] < D.par.d_tol) { dev_tr(c, 40, 0.0); dev_log_iterate(c); status = DGSQP_CONV_ABS_TOL; break; }
     dev_qt_mul(c);
     int flag;
-    if (D.big == 2) { dev_xl_psd(c, nullptr); flag = dev_xl_qp(c); }   // n > 128: dgsqp_xl.h
+    if (D.osqp) { dev_psd_inverse(c, c.ws + D.ws_xM, false); flag = dev_qp_osqp(c); }
+    else if (D.big == 2) { dev_xl_psd(c, nullptr); flag = dev_xl_qp(c); }   // n > 128: dgsqp_xl.h
     else if (D.classic_qp) { dev_psd_inverse(c, c.ws + D.ws_xM, false); flag = dev_xl_qp(c); }
     else { dev_psd_inverse(c, nullptr); flag = dev_qp(c); }
     total_qp++;
@@ -1780,8 +1801,14 @@ __device__ inline bool dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
       dev_tr(c, 10, d2); dev_tr(c, 11, mu); dev_tr(c, 12, S.phi); dev_tr(c, 13, S.dphi);
     }
     dev_save_base(c);  // also u_im1 / l_im1 of the relative-tolerance test
-    if (D.par.nonmono_ls) total_qp += dev_watchdog(c, mu, S);
-    else dev_line_search(c, mu, S.phi, S.dphi, S.S0, S.S1);
+    if (D.par.nonmono_ls) {
+      const int wq = dev_watchdog(c, mu, S);
+      if (wq < 0) {     // (qp_method OSQP only) a QP inside the watchdog was infeasible
+        total_qp += -wq;
+        dev_tr(c, 40, (double)(total_qp - qp_before)); dev_log_iterate(c); status = DGSQP_QP_FAIL; break;
+      }
+      total_qp += wq;
+    } else dev_line_search(c, mu, S.phi, S.dphi, S.S0, S.S1);
     // relative-tolerance exit (DGSQP.py:454-462)
     double du2 = 0, dl2 = 0;
     cgptr bk = c.ws + D.ws_base;

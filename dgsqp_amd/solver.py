@@ -151,15 +151,36 @@ def build_problem(joint_dynamics: CasadiDecoupledMultiAgentDynamicsModel,
     return P
 
 
+QP_METHODS = {'active_set': 0, 'osqp': 1}
+
+
+def resolve_qp_method(params, qp_method: Optional[str]) -> int:
+    """How ``_solve_qp`` (DGSQP.py:232-266) is computed on the device -- ``dgsqp_params_t.qp_method``.
+
+    The reference hands the QP to ``ca.conic('qp', params.qp_solver, ...)`` (DGSQP.py:183-201): 'osqp' (its default, ADMM + polish:
+    an approximate KKT point), or one of the exact solvers 'qrqp' / 'qpoases' / 'cplex' (active-set / simplex: THE KKT point).
+    Here ``'active_set'`` is the exact dual active-set method, ``'osqp'`` the restatement of OSQP's own arithmetic
+    (csrc/dgsqp_osqp.h).  ``qp_method=None`` picks by ``params.qp_solver``: the exact solvers map to 'active_set'; 'osqp' maps to
+    'active_set' as well -- the KKT point OSQP's polish aims at, the faster kernels -- unless the caller opts into
+    ``qp_method='osqp'`` to follow the reference's own iterates."""
+    if qp_method is None:
+        if params.qp_solver not in ('osqp', 'qrqp', 'qpoases', 'cplex'):
+            raise ValueError(f'Unsupported QP solver {params.qp_solver}')       # (superscs: a conic splitting solver, not restated)
+        return QP_METHODS['active_set']
+    if qp_method not in QP_METHODS:
+        raise ValueError(f'qp_method must be one of {sorted(QP_METHODS)}')
+    return QP_METHODS[qp_method]
+
+
 def build_params(params: DGSQPParams, eig_floor: Optional[float] = None, snap_active_bounds: bool = False,
-                 lsqr_tol: Optional[float] = None, qp_warm_start: bool = True) -> _ffi.ParamsT:
+                 lsqr_tol: Optional[float] = None, qp_warm_start: bool = True, qp_method: Optional[str] = None) -> _ffi.ParamsT:
     """``eig_floor``: value ``_nearestPD`` gives to negative eigenvalues; ``None`` = the reference's literal 1e-10
     (DGSQP.py:1293).  At ``reg = 0`` (curve.py, comp.py, merge.py) that leaves a QP of condition 1e12, which the device solves
     with its classical (J = L^-T) active-set kernels; passing a larger floor (1e-6) is an explicit opt-in that keeps such games
     on the faster explicit-inverse kernels.  ``snap_active_bounds``: see include/dgsqp.h (default literal).
     ``lsqr_tol``: atol = btol of the LSQR dual start; ``None`` = scipy's defaults (1e-6), what ``DGSQP.py:324`` runs with."""
     if isinstance(params, DGSQPV2Params):
-        return _build_params_v2(params, eig_floor, snap_active_bounds, lsqr_tol, qp_warm_start)
+        return _build_params_v2(params, eig_floor, snap_active_bounds, lsqr_tol, qp_warm_start, qp_method)
     if not params.conv_approx:
         raise NotImplementedError('conv_approx=False (IPOPT Newton step, DGSQP.py:204-228) is not on the Monte-Carlo path')
     if params.hessian_approximation not in ('none', 'bfgs'):
@@ -178,10 +199,11 @@ def build_params(params: DGSQPParams, eig_floor: Optional[float] = None, snap_ac
     p.time_limit = -1.0 if params.time_limit is None else float(params.time_limit)     # None -> no limit (DGSQP.py:64-67)
     p.eig_floor = 1e-10 if eig_floor is None else float(eig_floor)
     p.snap_active_bounds = int(bool(snap_active_bounds))
+    p.qp_method = resolve_qp_method(params, qp_method)
     return p
 
 
-def _build_params_v2(params: DGSQPV2Params, eig_floor, snap_active_bounds, lsqr_tol, qp_warm_start) -> _ffi.ParamsT:
+def _build_params_v2(params: DGSQPV2Params, eig_floor, snap_active_bounds, lsqr_tol, qp_warm_start, qp_method=None) -> _ffi.ParamsT:
     """DGSQPV2Params -> dgsqp_params_t for DG-SQP v2 (reference DGSQP/solvers/DGSQP_v2.py:66-222)."""
     if params.merit_function not in ('stat_l1', 'sum_obj_l1'):
         raise ValueError(f'Merit function option {params.merit_function} not recognized')      # (DGSQP_v2.py:1165-1166)
@@ -209,6 +231,7 @@ def _build_params_v2(params: DGSQPV2Params, eig_floor, snap_active_bounds, lsqr_
     p.merit_decrease_condition = 0 if params.merit_decrease_condition == 'armijo' else 1
     p.reg_decay, p.delta_decay, p.merit_decrease = float(params.reg_decay), float(params.delta_decay), float(params.merit_decrease)
     p.merit_parameter = -1.0 if params.merit_parameter is None else float(params.merit_parameter)
+    p.qp_method = resolve_qp_method(params, qp_method)
     return p
 
 
@@ -315,9 +338,11 @@ class DGSQP(AbstractSolver):
                  eig_floor: Optional[float] = None,
                  snap_active_bounds: bool = False,
                  lsqr_tol: Optional[float] = None,
-                 qp_warm_start: bool = True):
+                 qp_warm_start: bool = True,
+                 qp_method: Optional[str] = None):
         """``eig_floor``, ``snap_active_bounds``: implementation knobs, see ``build_params``; the defaults are the reference's
-        literal formulas (``_nearestPD`` floor 1e-10, DGSQP.py:1293; no adjustment of the QP step)."""
+        literal formulas (``_nearestPD`` floor 1e-10, DGSQP.py:1293; no adjustment of the QP step).  ``qp_method``: 'active_set'
+        (exact KKT point) or 'osqp' (OSQP's own ADMM + polish arithmetic), see ``resolve_qp_method``."""
         self.joint_dynamics = joint_dynamics
         self.M = joint_dynamics.n_a
         self.print_method = (lambda s: None) if print_method is None else print_method
@@ -333,7 +358,7 @@ class DGSQP(AbstractSolver):
 
         self._problem = build_problem(joint_dynamics, costs, agent_constraints, shared_constraints, bounds, params)
         self._cparams = build_params(params, eig_floor=eig_floor, snap_active_bounds=snap_active_bounds, lsqr_tol=lsqr_tol,
-                                     qp_warm_start=qp_warm_start)
+                                     qp_warm_start=qp_warm_start, qp_method=qp_method)
         _, _, self.n, n_c = problem_dims(self._problem)
         self.n_c_total = n_c
 
@@ -549,12 +574,12 @@ class DGSQP(AbstractSolver):
         l = np.ascontiguousarray(l, dtype=np.float64)
         B = x0.shape[0]
         out = dict(du=np.empty((B, self.n)), lhat=np.empty((B, self.n_c_total)), Qpd=np.empty((B, self.n, self.n)),
-                   flag=np.empty(B, np.int32))
-        rc = self._lib.dgsqp_qp_batch(self._h, B, _ffi.dptr(x0), _ffi.dptr(u), _ffi.dptr(l), _ffi.dptr(out['du']),
-                                      _ffi.dptr(out['lhat']), _ffi.dptr(out['Qpd']), _ffi.iptr(out['flag']))
+                   flag=np.empty(B, np.int32), info=np.zeros((B, 8)))
+        rc = self._lib.dgsqp_qp_batch_info(self._h, B, _ffi.dptr(x0), _ffi.dptr(u), _ffi.dptr(l), _ffi.dptr(out['du']),
+                                           _ffi.dptr(out['lhat']), _ffi.dptr(out['Qpd']), _ffi.iptr(out['flag']), _ffi.dptr(out['info']))
         if rc != 0:
             raise RuntimeError(f'dgsqp_qp_batch failed ({rc}): {self._lib.dgsqp_last_error(self._h).decode()}')
-        return out
+        return out           # info: OSQP's diagnostics with qp_method='osqp' (include/dgsqp.h: dgsqp_qp_batch_info), zeros otherwise
 
     def pid_warm_start_batch(self, q0, u_max=(2.1, 0.436), du_max=(10.0, 4.5), substeps=10, want_trajectories=False):
         """PID lane-follower warm start of a batch on the device (chicane.py:411-447 with PID.py; collision check

@@ -151,6 +151,8 @@ typedef struct {
 #define DGSQP_MAX_KNOTS 1152
 #define DGSQP_VARIANT_V1 0
 #define DGSQP_VARIANT_V2 1
+#define DGSQP_QP_ACTIVE_SET 0
+#define DGSQP_QP_OSQP 1
 #define DGSQP_DECREASE_ARMIJO 0
 #define DGSQP_DECREASE_MAX 1
 /* DGSQPParams (solver_types.py:91-127), numeric subset used by solve() */
@@ -191,7 +193,14 @@ typedef struct {
   int32_t nms_frequency;             /* m-step at the latest after this many d-steps (nms_mstep_frequency) */
   int32_t nms_memory_size;           /* length of the merit memory (<= 16) */
   int32_t merit_decrease_condition;  /* DGSQP_DECREASE_ARMIJO / DGSQP_DECREASE_MAX (DGSQP_v2.py:731-737) */
-  int32_t reserved_;
+  int32_t qp_method;                 /* how _solve_qp (DGSQP.py:232-266) is computed.  DGSQP_QP_ACTIVE_SET (0, default): the exact KKT point of
+                                        the strictly convex QP -- dual active-set method + polish -- i.e. what OSQP(polish=True) returns when its
+                                        polish succeeds.  DGSQP_QP_OSQP (1): OSQP's own arithmetic as the reference runs it through CasADi's
+                                        conic plugin (DGSQP.py:183-201, :246-249): Ruiz equilibration, ADMM to eps 1e-3, adaptive rho, polish
+                                        accepted on residuals alone -- the iterate the reference's loop actually continues from (1e-3 .. 1e-6
+                                        off the exact KKT point, occasionally negative multipliers); n <= 128.  A primal / dual infeasible
+                                        QP ends the solve with DGSQP_QP_FAIL wherever it occurs (the reference's NaN step raises in _get_mu
+                                        one iteration later, DGSQP.py:566-585) */
   double reg_decay;                  /* reg <- reg * reg_decay after every m-step / line-search step */
   double delta_decay;                /* gamma: d-step radius decay */
   double merit_decrease;             /* sigma */
@@ -355,6 +364,12 @@ int dgsqp_evaluate_batch(dgsqp_handle_t h, int64_t B, const double* x0, const do
  */
 int dgsqp_qp_batch(dgsqp_handle_t h, int64_t B, const double* x0, const double* u,
                    const double* l, double* du, double* lhat, double* Qpd, int32_t* flag);
+/* The same hook with OSQP's diagnostics when the handle runs qp_method = DGSQP_QP_OSQP (zeros otherwise): info8 [B][8] = {OSQP status
+   (1 solved, 2 solved inaccurate, -2 iteration limit, -3 primal infeasible, -4 dual infeasible, -10 non-finite data), ADMM iterations,
+   polish (1 accepted, -1 rejected, 0 not attempted), final rho, rho updates, active rows handed to the polish, primal and dual residual
+   of the ADMM iterate} -- what tests compare with the CPU restatements of OSQP (oracle/osqp.hpp, oracle/osqp_restate.py). */
+int dgsqp_qp_batch_info(dgsqp_handle_t h, int64_t B, const double* x0, const double* u,
+                        const double* l, double* du, double* lhat, double* Qpd, int32_t* flag, double* info8);
 
 /* Warm start of a Monte-Carlo batch (row (f) of the hot-path scope): for every scenario and agent roll the PID lane follower
    out from q0[B][n_q] over the horizon with the agent's own continuous model (rk4).  u_ws[B][n] agent-major (what

@@ -40,6 +40,7 @@
 
 #include "../include/dgsqp.h"
 #include "jet.hpp"
+#include "osqp.hpp"
 
 thread_local int Jet::nv = 0;
 
@@ -1161,6 +1162,8 @@ struct Ctx {
   const double* x0;
   int literal;
   vec* trace;  // optional event log (code, value) pairs, compared event-by-event with the device trace
+  mutable bool qp_dead = false;   // qp_method = DGSQP_QP_OSQP: a QP inside the watchdog was primal / dual infeasible.  The reference carries the
+                                  // NaN step on and raises in _get_mu at the next iteration (DGSQP.py:566-585): the solve ends with DGSQP_QP_FAIL
 };
 static inline void tr(const Ctx& c, int code, double v) { if (c.trace) { c.trace->push_back((double)code); c.trace->push_back(v); } }
 static void eval_lin(const Ctx& c, const vec& u, const vec& l, bool hessian, Lin& out, vec* xout = nullptr) {
@@ -1176,6 +1179,12 @@ static bool solve_qp(const Ctx& c, const Lin& k, vec& du, vec& lhat) {
   vec Qpd;
   nearest_pd(c.L.n, k.Q.data(), c.par.reg, Qpd, c.par.eig_floor);   // eig_floor: 1e-10 in the reference (DGSQP.py:1293)
   du.assign(c.L.n, 0.0); lhat.assign(c.L.nc, 0.0);
+  if (c.par.qp_method == DGSQP_QP_OSQP) {   // OSQP's own arithmetic (oracle/osqp.hpp): uba = -g, NaN answer when infeasible
+    vec uba(c.L.nc);
+    for (int r = 0; r < c.L.nc; r++) uba[r] = -k.g[r];
+    const osqp_restate::Info info = osqp_restate::conic(c.L.n, c.L.nc, Qpd.data(), k.q.data(), k.G.data(), uba.data(), du.data(), lhat.data());
+    return !(info.status == osqp_restate::PRIMAL_INFEASIBLE || info.status == osqp_restate::DUAL_INFEASIBLE || info.status == osqp_restate::NAN_DATA);
+  }
   if (qp_gi(c.L.n, c.L.nc, Qpd.data(), k.q.data(), k.G.data(), k.g.data(), du.data(), lhat.data()) != 0) return false;
   // NOT in the reference, default off (par.snap_active_bounds = 0).  The exact minimiser sits ON its active input bounds;
   // the active-set iterations leave them at rounding distance (+-1e-15); these rows are linear in u, the next iterate
@@ -1241,6 +1250,7 @@ static void watchdog_4(const Ctx& c, double mu, const vec& u_k, const vec& du_k,
     eval_lin(c, u_t, l_t, true, lt);
     bool ok = solve_qp(c, lt, du, lhat);
     qp_solves++;
+    if (!ok && c.par.qp_method == DGSQP_QP_OSQP) { c.qp_dead = true; u_out = u_t; l_out = l_t; return; }
     if (!ok) { fail = true; break; }
     step_vectors(c.L, lt, du, l_t, lhat, dl, s, ds);
     u_n = axpy(u_t, 1.0, du); l_n = lhat; vec s_n = axpy(s, 1.0, ds);
@@ -1256,6 +1266,7 @@ static void watchdog_4(const Ctx& c, double mu, const vec& u_k, const vec& du_k,
   eval_lin(c, u_t, l_t, true, lt);
   bool ok = solve_qp(c, lt, du, lhat);
   qp_solves++;
+  if (!ok && c.par.qp_method == DGSQP_QP_OSQP) { c.qp_dead = true; u_out = u_t; l_out = l_t; return; }
   if (!ok) fail = true;
   else {
     step_vectors(c.L, lt, du, l_t, lhat, dl, s, ds);
@@ -1270,6 +1281,7 @@ static void watchdog_4(const Ctx& c, double mu, const vec& u_k, const vec& du_k,
       eval_lin(c, u_n, l_n, true, l2);
       vec du2, lhat2;
       if (!solve_qp(c, l2, du2, lhat2)) {
+        if (c.par.qp_method == DGSQP_QP_OSQP) { qp_solves++; c.qp_dead = true; u_out = u_n; l_out = l_n; return; }
         double ph; line_search_3(c, mu, u_k, du_k, l_k, dl_k, s_k, ds_k, lin_k, u_out, l_out, ph);
         return;
       }
@@ -1362,6 +1374,7 @@ static void solve_one(const dgsqp_problem_t& P, const dgsqp_params_t& par, const
       int nqp = 0; vec un, ln;
       watchdog_4(c, mu, u, du, l, dl, s, ds, k, un, ln, nqp);
       u = un; l = ln; total_qp += nqp;
+      if (c.qp_dead) { tr(c, 40, (double)(total_qp - qp_before)); status = DGSQP_QP_FAIL; break; }
     } else {
       vec un, ln; double ph;
       line_search_3(c, mu, u, du, l, dl, s, ds, k, un, ln, ph);
@@ -1417,6 +1430,12 @@ static bool v2_solve_qp(const Ctx& c, const Lin& k, double reg, vec& du, vec& lh
   vec Qpd;
   nearest_pd(c.L.n, k.Q.data(), reg, Qpd, c.par.eig_floor);
   du.assign(c.L.n, 0.0); lhat.assign(c.L.nc, 0.0);
+  if (c.par.qp_method == DGSQP_QP_OSQP) {
+    vec uba(c.L.nc);
+    for (int r = 0; r < c.L.nc; r++) uba[r] = -k.g[r];
+    const osqp_restate::Info info = osqp_restate::conic(c.L.n, c.L.nc, Qpd.data(), k.q.data(), k.G.data(), uba.data(), du.data(), lhat.data());
+    return !(info.status == osqp_restate::PRIMAL_INFEASIBLE || info.status == osqp_restate::DUAL_INFEASIBLE || info.status == osqp_restate::NAN_DATA);
+  }
   return qp_gi(c.L.n, c.L.nc, Qpd.data(), k.q.data(), k.G.data(), k.g.data(), du.data(), lhat.data()) == 0;
 }
 // the merit of the chosen option at a point whose linearisation (q, G, g, obj) is `t`, multipliers lt; f_dphi_c along (du, dl) at k
@@ -1700,6 +1719,15 @@ void oracle_set_qp_polish(int on) { qp_polish_enabled = on != 0; }
 void oracle_qp_polish_stats(long* out4, int reset) { for (int i = 0; i < 4; i++) { out4[i] = qp_polish_stats[i]; if (reset) qp_polish_stats[i] = 0; } }
 int oracle_qp(int n, int m, const double* H, const double* c, const double* G, const double* g, double* x, double* lam) {
   return qp_gi(n, m, H, c, G, g, x, lam);
+}
+// OSQP as the reference poses it (DGSQP.py:246): min 1/2 x'Hx + c'x s.t. G x <= -g.  info8 = {status, iters, polished, rho, rho updates,
+// active rows of the polish, primal residual, dual residual of the ADMM iterate}
+int oracle_osqp(int n, int m, const double* H, const double* c, const double* G, const double* g, double* x, double* lam, double* info8) {
+  vec uba(m);
+  for (int r = 0; r < m; r++) uba[r] = -g[r];
+  const osqp_restate::Info info = osqp_restate::conic(n, m, H, c, G, uba.data(), x, lam);
+  if (info8) { info8[0] = info.status; info8[1] = info.iters; info8[2] = info.polished; info8[3] = info.rho; info8[4] = info.rho_updates; info8[5] = info.n_active; info8[6] = info.pri_res; info8[7] = info.dua_res; }
+  return info.status;
 }
 
 int oracle_lsqr(int m, int n, const double* A, const double* b, double atol, double btol, int iter_lim, double* x, int32_t* itn) {

@@ -22,7 +22,7 @@ _PI = C.POINTER(C.c_int32)
 def build(force: bool = False) -> pathlib.Path:
     so = _HERE / 'liboracle.so'
     src = _HERE / 'dgsqp_oracle.cpp'
-    if force or not so.exists() or so.stat().st_mtime < max(src.stat().st_mtime, (_HERE / 'jet.hpp').stat().st_mtime):
+    if force or not so.exists() or so.stat().st_mtime < max(src.stat().st_mtime, (_HERE / 'jet.hpp').stat().st_mtime, (_HERE / 'osqp.hpp').stat().st_mtime):
         subprocess.check_call(['make', '-C', str(_HERE), 'liboracle.so'])
     return so
 
@@ -124,6 +124,16 @@ def qp(H, c, G, g):
     x, lam = np.zeros(n), np.zeros(m)
     flag = lib().oracle_qp(C.c_int(n), C.c_int(m), _d(H), _d(c), _d(G), _d(g), _d(x), _d(lam))
     return x, lam, flag
+
+
+def osqp(H, c, G, g):
+    """The C++ restatement of OSQP (oracle/osqp.hpp) on  min 1/2 x'Hx + c'x  s.t.  G x <= -g.  Returns (x, lam, info)."""
+    H, c, G, g = (np.ascontiguousarray(a, float) for a in (H, c, G, g))
+    n, m = H.shape[0], G.shape[0]
+    x, lam, info = np.zeros(n), np.zeros(m), np.zeros(8)
+    lib().oracle_osqp(C.c_int(n), C.c_int(m), _d(H), _d(c), _d(G), _d(g), _d(x), _d(lam), _d(info))
+    return x, lam, dict(status=int(info[0]), iters=int(info[1]), polished=int(info[2]), rho=info[3], rho_updates=int(info[4]),
+                        n_active=int(info[5]), pri_res=info[6], dua_res=info[7])
 
 
 def lsqr(A, b, atol=1e-6, btol=1e-6, iter_lim=0):
