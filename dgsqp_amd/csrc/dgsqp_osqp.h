@@ -304,7 +304,8 @@ __device__ inline void osqp_at_active(const DgProb& D, clptr gd, const lds_i_t* 
 // ------------------------------------------------------------------------------------------------
 // _solve_qp core with OSQP's arithmetic.  In: M (scratch, ws_xM), q, g, packed G.  Out: du (L.o_du), lhat (L.o_lhat).
 // Returns 0 when OSQP hands back a point (solved, solved inaccurate, or the iteration limit: the reference continues from whatever
-// OSQP returns), 1 when it reports primal / dual infeasibility or non-finite data (NaN answer: DGSQP.py:566-585 raises).
+// OSQP returns), 1 when it reports primal / dual infeasibility or non-finite data, or when the point is not finite (a NaN step:
+// DGSQP.py:566-585 raises).
 // ------------------------------------------------------------------------------------------------
 __device__ __noinline__ int dev_qp_osqp(const Ctx& c) {
   const DgProb& D = dg_prob;
@@ -334,6 +335,7 @@ __device__ __noinline__ int dev_qp_osqp(const Ctx& c) {
     }
   }
   // ---- Ruiz equilibration (section 5.1; OSQP scale_data()): 10 passes
+  PROF_BEGIN(po1);
   for (int j = TID; j < n; j += NT) { o.Dv[j] = 1.0; o.EI[j] = 1.0; }
   for (int r = TID; r < nc; r += NT) o.E[r] = 1.0;
   double cc = 1.0;
@@ -369,8 +371,11 @@ __device__ __noinline__ int dev_qp_osqp(const Ctx& c) {
     cc *= 1.0 / fmax(ct, qn);
   }
   const double cinv = 1.0 / cc;
+  PROF_END(PH_O_SCALE, po1);
   // ---- W = Gs' Gs (once), K(rho) and its inverse
+  PROF_BEGIN(po2);
   osqp_build_w(D, o);
+  PROF_END(PH_O_W, po2);
   double rho = 0.1;
   int rho_updates = 0;
   auto rho_I = [&](int j, double r) { return o.EI[j] * OSQP_INFTY > OSQP_INFTY * OSQP_MIN_SCALING ? OSQP_RHO_MIN : r; };   // "loose" row: both bounds beyond 1e26 after scaling
@@ -378,7 +383,10 @@ __device__ __noinline__ int dev_qp_osqp(const Ctx& c) {
     __syncthreads();
     for (int j = TID; j < n; j += NT) { const double aI = o.EI[j] * o.Dv[j]; o.tmp[j] = sigma + rho_I(j, r) * aI * aI; }
     __syncthreads();
-    return dev_osqp_inverse(c, o, o.Dv, o.tmp, cc, r);
+    PROF_BEGIN(po3);
+    const bool okk = dev_osqp_inverse(c, o, o.Dv, o.tmp, cc, r);
+    PROF_END(PH_O_KINV, po3);
+    return okk;
   };
   bool spd = build_kinv(rho);
   for (int j = TID; j < n; j += NT) { o.x[j] = 0.0; o.dx[j] = 0.0; }
@@ -422,6 +430,7 @@ __device__ __noinline__ int dev_qp_osqp(const Ctx& c) {
     ad_pr = v[3] / (fmax(fmax(v[4], v[7]), fmax(v[5], v[7])) + 1e-10);
     ad_dr = u[4] / (fmax(u[5], fmax(u[6], u[7])) + 1e-10);
   };
+  PROF_BEGIN(po4);
   for (int it = 1; !stopped && it <= max_iter; it++) {
     iters = it;
     // (1) right-hand side and the reduced solve
@@ -446,6 +455,7 @@ __device__ __noinline__ int dev_qp_osqp(const Ctx& c) {
     __syncthreads();
     if (it % check_every != 0) continue;
     // ---- termination (section 3.4) every 25 iterations; the same products serve the rho adaptation (section 5.2)
+    PROF_BEGIN(po5);
     // primal infeasibility certificate (uses delta y, which the residual products overwrite)
     bool pinf = false;
     {
@@ -472,6 +482,7 @@ __device__ __noinline__ int dev_qp_osqp(const Ctx& c) {
     }
     residual_vectors();
     residuals();
+    PROF_END(PH_O_CHECK, po5);
     if (pri_res <= eps_p && dua_res <= eps_d) { status = OSQP_SOLVED; break; }
     if (pinf) { status = OSQP_PRIMAL_INFEASIBLE; break; }
     {
@@ -515,6 +526,8 @@ __device__ __noinline__ int dev_qp_osqp(const Ctx& c) {
       }
     }
   }
+  PROF_END(PH_O_ADMM, po4);
+  PROF_COUNT(PH_O_ITERS, iters);
   if (status == OSQP_MAX_ITER) {      // iteration limit: OSQP re-checks with 10x the tolerances ("solved inaccurate")
     residual_vectors();
     residuals();
@@ -554,8 +567,12 @@ __device__ __noinline__ int dev_qp_osqp(const Ctx& c) {
       // Hu^-1 = (c M + delta D^-2)^-1 into the packed-P slot (the ADMM's K^-1 is dead)
       for (int j = TID; j < n; j += NT) o.tmp[j] = delta / (o.Dv[j] * o.Dv[j]);
       __syncthreads();
+      PROF_BEGIN(po6);
       ok = dev_osqp_inverse(c, o, nullptr, o.tmp, cc, 0.0);
+      PROF_END(PH_O_PINV, po6);
     }
+    PROF_COUNT(PH_O_NACT, na);
+    PROF_BEGIN(po7);
     if (ok) {
       // inverse Cholesky factor T of S = A Hu^-1 A' + delta E^-2, one bordering step per active row (dgsqp_qp.h machinery)
       for (int r = TID; r < nc; r += NT) q.act[r] = 0;
@@ -586,6 +603,8 @@ __device__ __noinline__ int dev_qp_osqp(const Ctx& c) {
       __threadfence_block();
       __syncthreads();
     }
+    PROF_END(PH_O_PROWS, po7);
+    PROF_BEGIN(po8);
     if (ok) {
       const int m = na;
       QpPtrs q2 = q;
@@ -645,13 +664,18 @@ __device__ __noinline__ int dev_qp_osqp(const Ctx& c) {
         polished = 1;
       } else polished = -1;
     } else polished = -1;
+    PROF_END(PH_O_PSOLVE, po8);
   }
   __syncthreads();
   if (TID == 0) {
     o.scal[DG_OSQP_INFO] = (double)status; o.scal[DG_OSQP_INFO + 1] = (double)iters; o.scal[DG_OSQP_INFO + 2] = (double)polished; o.scal[DG_OSQP_INFO + 3] = rho;
     o.scal[DG_OSQP_INFO + 4] = (double)rho_updates; o.scal[DG_OSQP_INFO + 5] = (double)na; o.scal[DG_OSQP_INFO + 6] = pri_res; o.scal[DG_OSQP_INFO + 7] = dua_res;
   }
-  __syncthreads();
+  // a non-finite answer (an ADMM run that overflowed before its iteration limit) is a NaN step as well
+  int nonfinite = 0;
+  for (int j = TID; j < n; j += NT) nonfinite |= !(__builtin_fabs(du[j]) < INFINITY);
+  for (int r = TID; r < nc; r += NT) nonfinite |= !(__builtin_fabs(lhat[r]) < INFINITY);
+  nonfinite = __syncthreads_or(nonfinite);
   PROF_END(PH_QP, pt_qp);
-  return (status == OSQP_PRIMAL_INFEASIBLE || status == OSQP_DUAL_INFEASIBLE || status == OSQP_NAN_DATA) ? 1 : 0;
+  return (nonfinite || status == OSQP_PRIMAL_INFEASIBLE || status == OSQP_DUAL_INFEASIBLE || status == OSQP_NAN_DATA) ? 1 : 0;
 }

@@ -1183,7 +1183,12 @@ static bool solve_qp(const Ctx& c, const Lin& k, vec& du, vec& lhat) {
     vec uba(c.L.nc);
     for (int r = 0; r < c.L.nc; r++) uba[r] = -k.g[r];
     const osqp_restate::Info info = osqp_restate::conic(c.L.n, c.L.nc, Qpd.data(), k.q.data(), k.G.data(), uba.data(), du.data(), lhat.data());
-    return !(info.status == osqp_restate::PRIMAL_INFEASIBLE || info.status == osqp_restate::DUAL_INFEASIBLE || info.status == osqp_restate::NAN_DATA);
+    // a non-finite answer -- the NaNs OSQP stores for an infeasible QP, or an ADMM run that overflowed before its iteration limit --
+    // is a NaN step: _get_mu raises on it (DGSQP.py:566-585)
+    bool finite = true;
+    for (double e : du) finite = finite && std::isfinite(e);
+    for (double e : lhat) finite = finite && std::isfinite(e);
+    return finite && !(info.status == osqp_restate::PRIMAL_INFEASIBLE || info.status == osqp_restate::DUAL_INFEASIBLE || info.status == osqp_restate::NAN_DATA);
   }
   if (qp_gi(c.L.n, c.L.nc, Qpd.data(), k.q.data(), k.G.data(), k.g.data(), du.data(), lhat.data()) != 0) return false;
   // NOT in the reference, default off (par.snap_active_bounds = 0).  The exact minimiser sits ON its active input bounds;
@@ -1434,7 +1439,12 @@ static bool v2_solve_qp(const Ctx& c, const Lin& k, double reg, vec& du, vec& lh
     vec uba(c.L.nc);
     for (int r = 0; r < c.L.nc; r++) uba[r] = -k.g[r];
     const osqp_restate::Info info = osqp_restate::conic(c.L.n, c.L.nc, Qpd.data(), k.q.data(), k.G.data(), uba.data(), du.data(), lhat.data());
-    return !(info.status == osqp_restate::PRIMAL_INFEASIBLE || info.status == osqp_restate::DUAL_INFEASIBLE || info.status == osqp_restate::NAN_DATA);
+    // a non-finite answer -- the NaNs OSQP stores for an infeasible QP, or an ADMM run that overflowed before its iteration limit --
+    // is a NaN step: _get_mu raises on it (DGSQP.py:566-585)
+    bool finite = true;
+    for (double e : du) finite = finite && std::isfinite(e);
+    for (double e : lhat) finite = finite && std::isfinite(e);
+    return finite && !(info.status == osqp_restate::PRIMAL_INFEASIBLE || info.status == osqp_restate::DUAL_INFEASIBLE || info.status == osqp_restate::NAN_DATA);
   }
   return qp_gi(c.L.n, c.L.nc, Qpd.data(), k.q.data(), k.G.data(), k.g.data(), du.data(), lhat.data()) == 0;
 }

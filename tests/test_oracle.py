@@ -353,6 +353,66 @@ def test_cpp_oracle_follows_the_numpy_loop(oracle, games):
             assert np.abs(s['u'] - ref['u'][b]).max() < tol * max(1.0, np.abs(ref['u'][b]).max()), (kind, b)
 
 
+def test_cpp_osqp_follows_the_numpy_restatement(oracle, games):
+    """oracle/osqp.hpp (the OSQP the C++ oracle solves its QPs with when qp_method = 1, and the checker of the device's ADMM kernel)
+    is the statement-by-statement C++ twin of oracle/osqp_restate.py: same status, ADMM iteration count, rho, polish verdict, and
+    x / lambda to rounding level -- on random strictly convex QPs, on an infeasible one (NaN answer), and on QPs of two games
+    (reg = 1e-3 and the literal reg = 0 projection) at the start point of four scenarios each."""
+    from dgsqp_amd.montecarlo import sample_scenarios
+    from oracle import osqp_restate
+    rng = np.random.default_rng(11)
+
+    def both(H, q, G, g, tol=1e-8):
+        xn, ln, inn = osqp_restate.conic(H, q, G, -g)
+        xc, lc, ic = oracle.osqp(H, q, G, g)
+        assert (ic['status'], ic['iters'], ic['polished']) == (inn['status'], inn['iters'], inn['polished'])
+        if inn['status'] in (osqp_restate.PRIMAL_INFEASIBLE, osqp_restate.DUAL_INFEASIBLE):
+            assert np.isnan(xc).all() and np.isnan(lc).all()
+            return inn
+        assert abs(ic['rho'] - inn['rho']) <= 1e-9 * inn['rho']
+        assert np.abs(xc - xn).max() <= tol * max(1.0, np.abs(xn).max()) and np.abs(lc - ln).max() <= tol * max(1.0, np.abs(ln).max())
+        return inn
+    for trial in range(6):
+        n, m = 10, 24
+        A = rng.standard_normal((n, n))
+        both(A @ A.T + 0.1 * np.eye(n), rng.standard_normal(n), rng.standard_normal((m, n)), -rng.random(m) - 0.05)
+    inn = both(np.eye(2), np.zeros(2), np.array([[1.0, 0.0], [-1.0, 0.0]]), np.array([1.0, 1.0]))
+    assert inn['status'] == osqp_restate.PRIMAL_INFEASIBLE
+    x, lam, info = oracle.osqp(np.array([[np.nan, 0.0], [0.0, 1.0]]), np.zeros(2), np.eye(2), -np.ones(2))      # non-finite data: NaN answer
+    assert info['status'] == -10 and np.isnan(x).all()
+    seen_rho_update = 0
+    for name in ('kb_chicane_N15', 'kb_barc2_N15'):
+        g, P, par = games[name]
+        x0, u_tm = sample_scenarios(g, 4, seed=5)
+        u = agent_major(u_tm)
+        for b in range(4):
+            l0 = oracle.dual_init(P, par, x0[b], u[b])
+            ev = oracle.evaluate(P, x0[b], u[b], l0, 1)
+            inn = both(oracle.nearest_pd(ev['Q'], par.reg, par.eig_floor), ev['q'], ev['G'], ev['g'], tol=1e-7)
+            seen_rho_update += inn['rho'] != 0.1
+    assert seen_rho_update >= 1        # (the adaptive-rho branch was exercised)
+
+
+def test_cpp_oracle_with_osqp_follows_the_numpy_loop(oracle, games):
+    """The C++ oracle with qp_method = 1 (its OSQP restatement inside solve(), incl. "an infeasible QP ends the solve") against the
+    numpy loop with the numpy restatement, the stand-in for the reference's own iterates: same status, iterations and QP solves on
+    well-conditioned scenarios, iterates to 1e-6 (both polish; the differences are the two LSQR implementations at tolerance 1e-6)."""
+    import copy
+    from dgsqp_amd.montecarlo import sample_scenarios
+    from oracle import pyref
+    g, P, par0 = games['kb_chicane_N15']
+    par = copy.copy(par0)
+    par.qp_method = 1
+    x0, u_tm = sample_scenarios(g, 4, seed=3)
+    u = agent_major(u_tm)
+    ref = oracle.solve_batch(P, par, x0, u, nthreads=4)
+    code = {'conv_abs_tol': 0, 'conv_rel_tol': 1, 'max_it': 2, 'diverged': 3, 'exception': 4}
+    for b in range(4):
+        s = pyref.PyRef(P, par, qp='osqp').solve(x0[b], u[b])
+        assert (code[s['msg']], s['num_iters'], s['qp_solves']) == (ref['status'][b], ref['num_iters'][b], ref['qp_solves'][b]), b
+        assert np.abs(s['u'] - ref['u'][b]).max() < 1e-6 * max(1.0, np.abs(ref['u'][b]).max()), b
+
+
 def test_v2_restatement_invariants(oracle):
     """Oracle restatement of DG-SQP v2 (DGSQP_v2.py:322-720).  With the parameters of the reference's study
     (comparison_study_barc/globals.py:27-55) the regularisation has to decay from 100 before the steps grow: ~350 iterations, all

@@ -14,7 +14,8 @@ elif which.startswith('kb'):  # reg as in the scripts: curve.py:161 reg=0, chica
     game = kinematic_racing_game('curve' if which == 'kbcurve' else 'chicane', N=N, reg=0.0 if which == 'kbcurve' else 1e-3)
 else:
     game = dynamic_racing_game(N=N, rk4_substeps=M)
-s = DGSQP(*game.solver_args(), print_method=None)
+import os
+s = DGSQP(*game.solver_args(), print_method=None, qp_method=os.environ.get('DGSQP_QP_METHOD') or None)
 t = time.time(); x0, uws = sample_scenarios(game, B, seed=1); print('sample', time.time() - t)
 for rep in range(2):
     t = time.time(); res = s.solve_batch(x0, uws); dt = time.time() - t
@@ -23,9 +24,9 @@ for rep in range(2):
 import ctypes, os
 lib = s._lib
 if hasattr(lib, 'dgsqp_prof_read'):
-    buf = (ctypes.c_ulonglong * 128)()
-    nph = lib.dgsqp_prof_read(buf, 128)
-    names = ['rollout', 'deriv1', 'deriv2', 'chains', 'dp', 'jacobi', 'pform', 'qp', 'merit', 'lsqr', 'qtmul', 'gi_adds/drops', 'wgtotal', 'wgmax(clk,wall100MHz)', 'q_scan', 'q_y', 'q_dir', 'q_step', 'q_upd', 'q_refine', 'q_warm', 'w_build', 'w_mult', 'w_x', 'e_tri', 'e_bis', 'e_vec', 'e_back', 'e_kneg', 'c_nprev', 'c_mbuild', 'c_mwarm', 'c_mfinal', 'c_pruned_trials', 'h_inj', 'h_costate', 'h_contract', 'h_rows']
+    buf = (ctypes.c_ulonglong * 256)()
+    nph = lib.dgsqp_prof_read(buf, 256)
+    names = ['rollout', 'deriv1', 'deriv2', 'chains', 'dp', 'jacobi', 'pform', 'qp', 'merit', 'lsqr', 'qtmul', 'gi_adds/drops', 'wgtotal', 'wgmax(clk,wall100MHz)', 'q_scan', 'q_y', 'q_dir', 'q_step', 'q_upd', 'q_refine', 'q_warm', 'w_build', 'w_mult', 'w_x', 'e_tri', 'e_bis', 'e_vec', 'e_back', 'e_kneg', 'c_nprev', 'c_mbuild', 'c_mwarm', 'c_mfinal', 'c_pruned_trials', 'h_inj', 'h_costate', 'h_contract', 'h_rows', 'osqp_scale', 'osqp_w', 'osqp_kinv', 'osqp_admm', 'osqp_iters(count)', 'osqp_check', 'osqp_pol_inv', 'osqp_pol_rows', 'osqp_pol_solve', 'osqp_nact(count)']
     tot = sum(buf[2 * i] for i in range(nph))
     for i in range(nph):
         if buf[2 * i + 1]:

@@ -1,7 +1,10 @@
 """Build container: the numpy restatement of the reference loop with the restated OSQP (oracle/pyref.py, oracle/osqp_restate.py)
 on the first B sampled scenarios of a game, next to the C++ oracle (exact active-set QP) with the literal and the floored
 _nearestPD.  Writes tests/golden/pyref_osqp_<game>.npz (the statistical yardstick of tests/test_gpu.py) and prints the table
-kept under profiles/.   usage: ref_stats.py <game> <B> [nproc]"""
+kept under profiles/.   usage: ref_stats.py <game> <B> [nproc]
+       ref_stats.py <game> <B> <nproc> --stable K   adds to the committed file the mask `stable` of the scenarios whose (status, iterations,
+           QP solves) the numpy loop ITSELF reproduces from inputs perturbed by 1e-13 relative (K re-runs), after checking that an
+           unperturbed re-run reproduces the stored results (OMP_NUM_THREADS = 1: the run is deterministic)"""
 import os, sys, pathlib, time, copy
 for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
     os.environ.setdefault(_v, "1")
@@ -24,11 +27,15 @@ CODE = {'conv_abs_tol': 0, 'conv_rel_tol': 1, 'max_it': 2, 'diverged': 3, 'excep
 
 
 def one(args):
-    name, b = args
+    name, b = args[:2]
     g = GAMES[name][0]()
     P, par = build_problem(*g.solver_args()), build_params(g.params, eig_floor=1e-10)
     x0, uws = mc.sample_scenarios(g, B_, seed=GAMES[name][1])
     u = np.concatenate([uws[:, :, 2 * a:2 * a + 2].reshape(B_, -1) for a in range(uws.shape[2] // 2)], axis=1)
+    if len(args) > 2 and args[2]:          # perturbed re-run k: inputs x (1 + 1e-13 N(0, 1))
+        rng = np.random.default_rng(1000 * args[2] + b)
+        x0 = x0 * (1 + 1e-13 * rng.standard_normal(x0.shape))
+        u = u * (1 + 1e-13 * rng.standard_normal(u.shape))
     r = pyref.PyRef(P, par, qp='osqp')
     try:
         with np.errstate(all='ignore'):
@@ -46,9 +53,34 @@ def stats(tag, st, it, qp):
     return f'{tag:58s} converged {conv.mean():6.3f}  max_it {np.mean(st == 2):5.3f}  qp_fail/exception {np.mean(st == 4):5.3f}  mean iters (conv) {it[conv].mean() if conv.any() else float("nan"):6.2f}  mean QPs {qp.mean():6.2f}'
 
 
+def stability(name, nproc, K):
+    path = ROOT / 'tests' / 'golden' / f'pyref_osqp_{name}.npz'
+    gold = dict(np.load(path))
+    cf0 = np.stack([gold['status'], gold['num_iters'], gold['qp_solves']], axis=1)
+    stable = np.ones(len(cf0), bool)
+    t = time.time()
+    with mp.Pool(nproc, initializer=lambda: globals().__setitem__('B_', B_)) as pool:
+        for k in range(K + 1):
+            out = pool.map(one, [(name, b, k) for b in range(B_)], chunksize=1)
+            cf = np.array([[o[0], o[1], o[2]] for o in out], np.int32)
+            same = (cf == cf0).all(axis=1)
+            if k == 0:
+                print(f'# {name}: unperturbed re-run reproduces the committed results on {same.sum()}/{len(same)} scenarios')
+                assert same.all(), np.nonzero(~same)[0]
+            else:
+                stable &= same
+                print(f'# {name}: perturbed re-run {k}: same path on {same.mean():.3f}; stable so far {stable.mean():.3f} ({time.time() - t:.0f} s)', flush=True)
+    gold['stable'] = stable
+    np.savez_compressed(path, **gold)
+    print(f'{name}: the numpy loop + restated OSQP reproduces itself under 1e-13 input perturbations ({K} re-runs) on {stable.sum()}/{len(stable)} = {stable.mean():.3f} of the scenarios')
+
+
 if __name__ == '__main__':
     name, B_ = sys.argv[1], int(sys.argv[2])
     nproc = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+    if '--stable' in sys.argv:
+        stability(name, nproc, int(sys.argv[sys.argv.index('--stable') + 1]))
+        sys.exit(0)
     g = GAMES[name][0]()
     x0, uws = mc.sample_scenarios(g, B_, seed=GAMES[name][1])
     u = np.concatenate([uws[:, :, 2 * a:2 * a + 2].reshape(B_, -1) for a in range(uws.shape[2] // 2)], axis=1)
