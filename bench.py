@@ -10,7 +10,7 @@ steps solve DIFFERENT batches (own seed each, (pipeline + 1) x group distinct on
 launch solves the staged batches of a group from a shared ticket queue (dgsqp_launch_staged_group; own buffers per batch, results
 bit-identical to separate launches), `--pipeline` launches in flight.  The timed region is exactly K steps between two fences
 (library stream synchronisation + RCCL barrier), max over ranks.  Scenarios shard over the ranks with no data-path collective
-(--scaling weak: fixed batch per GPU; strong: fixed total batch); the only exchange is ONE ncclAllGather of the 64-byte
+(--scaling weak: fixed batch per GPU; strong: fixed total batch); the only exchange is ONE ncclAllGather of the 88-byte
 per-scenario record, issued by the HIP library (dgsqp_gather_stats).  No PyTorch: the launcher only provides RANK / LOCAL_RANK /
 WORLD_SIZE.  Rank 0 prints ONE JSON line; next to `value` (K pipelined steps) it carries `value_single_launch` (strictly one
 launch at a time -- the only figure in which a launch has the GPU to itself, and where roofline.kernel_ms comes from) and
@@ -157,6 +157,9 @@ def main():
     ap.add_argument('--coop', choices=('auto', 'off'), default='auto',
                     help='cooperative line search (dgsqp_set_cooperative): auto = in the LAST launch of the timed region and in launches that run alone -- idle '
                          'workgroups evaluate line-search trials of the scenarios still solving; results are bit-identical; off = never')
+    ap.add_argument('--qp', choices=('active_set', 'osqp'), default='active_set',
+                    help="how _solve_qp is computed (dgsqp_params_t.qp_method): 'active_set' = the exact KKT point (dual active-set method + polish), "
+                         "'osqp' = OSQP's own ADMM + polish arithmetic as the reference runs it (csrc/dgsqp_osqp.h); the cpu_baseline uses the same method")
     ap.add_argument('--reg', type=float, default=None, help='DGSQPParams.reg (default: the value of the workload)')
     ap.add_argument('--eig-floor', type=float, default=None, help='_nearestPD floor (default: the literal 1e-10, DGSQP.py:1293)')
     ap.add_argument('--snap-active-bounds', action='store_true', help='implementation knob, see include/dgsqp.h (default: literal)')
@@ -179,7 +182,7 @@ def main():
 
     game = make_game(args.workload, args.reg)
     mk = lambda: DGSQP(*game.solver_args(), print_method=None, device=local_rank, eig_floor=args.eig_floor,
-                       snap_active_bounds=args.snap_active_bounds)
+                       snap_active_bounds=args.snap_active_bounds, qp_method=args.qp)
     P = max(1, args.pipeline)
     if args.group <= 0:
         args.group = args.steps if args.steps <= 24 else 12
@@ -348,7 +351,7 @@ def main():
         traffic, flop_per_solve, traffic_src = None, None, None
         try:
             import glob
-            for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r03_pmc_*.json'))):      # this round's kernels only
+            for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r0[34]_pmc_*.json'))):      # this round's kernels only
                 pm = json.load(open(f))
                 if pm.get('workload') == args.workload and pm.get('batch_per_gpu') == B:
                     if 'traffic_bytes_per_launch' in pm:
@@ -356,8 +359,14 @@ def main():
                     flop_per_solve = pm.get('fp64_flop_per_solve_upper_bound', flop_per_solve)
         except Exception:
             pass
-        bytes_per_launch = algorithmic_bytes_per_solve(d) * B
-        achieved = bytes_per_launch / (kms * 1e-3) / 1e9
+        # the dominant kernel's launches of the TIMED region: every launch solves `batches_per_launch` staged batches of B scenarios
+        # (the last one possibly fewer); HIP events on the launch's own stream (dgsqp_wait -> dgsqp_timing_t.kernel_ms)
+        gsz = max(1, min(args.group, n_batches))
+        timed_ms = float(np.mean(kernel_ms_pipe))
+        solves_per_timed_launch = B * args.steps / max(1, len(kernel_ms_pipe))
+        bytes_per_launch = algorithmic_bytes_per_solve(d) * solves_per_timed_launch
+        achieved = bytes_per_launch / (timed_ms * 1e-3) / 1e9
+        achieved_single = algorithmic_bytes_per_solve(d) * B / (kms * 1e-3) / 1e9
         summ = summarize(stats)
         line = {
             'metric': 'Monte-Carlo scenarios/sec (SQP solves/sec), 2-agent N=25' if args.workload.startswith(('dyn_curve_N25', 'kb_curve_N25', 'kb_chicane_N25'))
@@ -366,11 +375,12 @@ def main():
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': args.workload, 'description': WORKLOADS[args.workload]['desc'], 'batch_per_gpu': B, 'batch_total': B_total,
                        'n': int(d.n), 'n_c': int(d.n_c), 'parallelism': f'scenario-sharded x{world}',
+                       'shard_mode': 'contiguous (weak: every rank samples its own batch_per_gpu scenarios)' if args.scaling == 'weak' else 'contiguous ranges of one batch (sharding.shard_range)',
                        'sampler': {'circuit': 'scripts/DGSQP_comp_monte_carlo.py:365-382, PID warm start',
                                    'merge': 'scripts/DGSQP_merge_monte_carlo.py:421-480, zero warm start'}.get(
                                        game.sampler, 'scripts/DGSQP_ALGAMES_monte_carlo_curve.py:384-467, PID warm start') + ' (seed 1 + rank + 1000 * batch)',
                        'distinct_batches': n_batches, 'batches_per_launch': max(1, args.group), 'layout': {0: 'lds', 1: 'big', 2: 'xl'}[int(d.layout)],
-                       'launches_in_flight': P, 'batches_in_flight': P * max(1, args.group), 'cooperative_line_search': args.coop, 'reg': float(game.params.reg), 'eig_floor': float(solver._cparams.eig_floor),
+                       'launches_in_flight': P, 'batches_in_flight': P * max(1, args.group), 'cooperative_line_search': args.coop, 'qp_method': args.qp, 'reg': float(game.params.reg), 'eig_floor': float(solver._cparams.eig_floor),
                        'snap_active_bounds': int(solver._cparams.snap_active_bounds)},
             'elapsed_s_per_rank': elapsed_per_rank,        # each rank's own time for its K steps: load imbalance between the shards shows here
             'value_single_launch': single['value'] if single else None,
@@ -383,9 +393,15 @@ def main():
             # The path is ALU/LDS-bound (state lives in LDS for the whole solve); the HBM figure is reported as the
             # contract asks and is expected to be a tiny fraction of peak.
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
-                         'traffic': traffic, 'traffic_source': traffic_src, 'kernel': 'dg_solve_kernel', 'kernel_ms': kms,
-                         'kernel_ms_source': 'HIP events, launches one at a time' if single else 'HIP events, overlapping launches',
-                         'algorithmic_bytes_per_solve': algorithmic_bytes_per_solve(d)},
+                         # PMC bytes (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc passes over one-batch launches) scaled to the solves of a timed launch
+                         'traffic': traffic * solves_per_timed_launch / B if traffic is not None else None, 'traffic_source': traffic_src,
+                         'kernel': 'dg_solve_kernel', 'kernel_ms': timed_ms,
+                         'kernel_ms_source': f'HIP events on the launch streams, mean over the {len(kernel_ms_pipe)} launch(es) of the timed region',
+                         'launches_timed': len(kernel_ms_pipe), 'solves_per_launch': solves_per_timed_launch,
+                         'algorithmic_bytes_per_solve': algorithmic_bytes_per_solve(d), 'algorithmic_bytes_per_launch': bytes_per_launch,
+                         # the same kernel launched one batch at a time (what the rocprof kernel-trace of profiles/ and the PMC passes measure)
+                         'single_launch': {'kernel_ms': kms, 'solves_per_launch': B, 'achieved': achieved_single, 'frac': achieved_single / 8000.0, 'traffic': traffic,
+                                           'source': 'HIP events, launches one at a time' if single else 'HIP events, overlapping launches'}},
         }
         if flop_per_solve is not None:
             # second, honest roof of this path: vector fp64 issue (256 CUs x 4 SIMDs x 32 lanes x 2 flop x 2.4 GHz = 78.6 TF/s).
@@ -397,20 +413,30 @@ def main():
             from oracle import oracle            # checker/baseline only: the CPU restatement, NOT CasADi+OSQP
             oracle.build()
             cores = os.cpu_count() or 1
-            # a THROUGHPUT over at least as many scenarios as hardware threads, handed out dynamically (not the time of the slowest one); plus one core alone
-            ns = min(args.cpu_sample if args.cpu_sample != 64 else max(64, cores), B)       # default: one scenario per hardware thread (bounded: 15-30 s)
+            # A THROUGHPUT, not the time of the slowest scenario: every thread gets at least 8 scenarios handed out dynamically (default: the
+            # whole first batch over min(cores, B / 8) threads), every scenario's own wall-clock time on its thread is recorded, and
+            # `value` = threads / mean seconds per scenario -- what those threads sustain over a long Monte-Carlo run.  `value_wall` is the
+            # sample over its wall time, idle tail behind the slowest scenario (tens of seconds for one that never converges) included.
+            ns = min(args.cpu_sample if args.cpu_sample != 64 else B, B)
+            nth = max(1, min(cores, ns // 8))
             x0, u_am = batches[0]
             t1 = time.perf_counter()
-            oracle.solve_batch(solver._problem, solver._cparams, x0[:ns], u_am[:ns], nthreads=min(cores, ns))
+            ob = oracle.solve_batch(solver._problem, solver._cparams, x0[:ns], u_am[:ns], nthreads=nth, timed=True)
             dt = time.perf_counter() - t1
             n1 = min(4, ns)
             t1 = time.perf_counter()
             oracle.solve_batch(solver._problem, solver._cparams, x0[:n1], u_am[:n1], nthreads=1)
             dt1 = time.perf_counter() - t1
-            line['cpu_baseline'] = {'value': ns / dt, 'unit': 'scenarios/s', 'cores': min(cores, ns), 'kind': 'port',
-                                    'value_one_core': n1 / dt1,
-                                    'sample': f'first {ns} scenarios of batch 0 over {min(cores, ns)} threads (dynamic hand-out), {dt:.1f} s; first {n1} on one core, {dt1:.1f} s; '
-                                              f'oracle/dgsqp_oracle.cpp (dense literal restatement, not CasADi+OSQP)'}
+            sec = ob['seconds']
+            line['cpu_baseline'] = {'value': nth / float(sec.mean()), 'unit': 'scenarios/s', 'cores': nth, 'kind': 'port',
+                                    'value_wall': ns / dt, 'value_one_core': n1 / dt1, 'scenarios_per_thread': ns / nth,
+                                    'seconds_per_scenario': {'mean': float(sec.mean()), 'median': float(np.median(sec)), 'max': float(sec.max())},
+                                    'sample': f'first {ns} scenarios of batch 0 over {nth} of {cores} hardware threads, dynamic hand-out, {ns / nth:.0f} per thread, {dt:.1f} s wall '
+                                              f'(mean {sec.mean():.2f} s, slowest {sec.max():.1f} s per scenario); value = threads / mean seconds per scenario; first {n1} alone on one core: {dt1:.1f} s; '
+                                              f'oracle/dgsqp_oracle.cpp (dense literal restatement, QP: ' + ('exact active set' if args.qp == 'active_set' else 'restated OSQP, oracle/osqp.hpp') + '; not CasADi+OSQP)'}
+        elif world > 1:
+            line['cpu_baseline'] = None
+            line['cpu_baseline_note'] = 'timed on rank 0 of the 1-GPU run only (bench.py --gpus 1)'
         print(json.dumps(line), flush=True)
     comm.close()
 

@@ -80,7 +80,7 @@ class PidT(C.Structure):
 
 class StatRecordT(C.Structure):
     _fields_ = [('status', C.c_int32), ('iters', C.c_int32), ('qp_solves', C.c_int32), ('rank', C.c_int32),
-                ('p_feas', C.c_double), ('comp', C.c_double), ('stat', C.c_double), ('cost', C.c_double * 3)]
+                ('p_feas', C.c_double), ('comp', C.c_double), ('stat', C.c_double), ('cost', C.c_double * MAX_AGENTS)]
 
 
 class DimsT(C.Structure):

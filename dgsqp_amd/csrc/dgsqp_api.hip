@@ -382,14 +382,21 @@ static int park_for_launch(dgsqp_solver* h, bool coop, int grid, int64_t total, 
   size_t cap = (size_t)((double)total * (frac > 0.0 && frac <= 1.0 ? frac : 0.25) + 1.0);
   DgParkPool& pool = g_park[h->device & 63];      // (g_reg_mutex is held by the launch functions)
   if (pool.owner && pool.owner != h && pool.owner->in_flight && pool.owner->launch_gen == pool.owner_gen) return DGSQP_OK;   // busy: no deferral
-  if (pool.slots == 0 || pool.slot_doubles < slot) {
+  // The pool holds what this launch may defer (a quarter of its scenarios) and grows geometrically when a larger launch comes along; its
+  // size is bounded by DGSQP_DEFER_POOL_BYTES (default 16 GiB; 0 switches deferral off).  It is only ever re-allocated while no launch uses it.
+  size_t limit_bytes = (size_t)16 << 30;
+  { const char* e = getenv("DGSQP_DEFER_POOL_BYTES"); if (e) limit_bytes = (size_t)strtoull(e, nullptr, 10); }
+  const size_t max_slots = limit_bytes / (slot * sizeof(double));
+  if (cap > max_slots) cap = max_slots;
+  if (cap < 1) return DGSQP_OK;
+  if (pool.slots < cap || pool.slot_doubles < slot) {
+    size_t slots = pool.slot_doubles == slot ? 2 * pool.slots : 0;
+    if (slots < cap) slots = cap;
+    if (slots < 64) slots = 64;
+    if (slots > max_slots) slots = max_slots;
     if (pool.entries) (void)hipFree(pool.entries);
     if (pool.store) (void)hipFree(pool.store);
     pool = DgParkPool();
-    size_t slots = 4096;
-    const size_t max_slots = (size_t)(16ull << 30) / (slot * sizeof(double));
-    if (slots > max_slots) slots = max_slots;
-    if (slots < 1) return DGSQP_OK;
     HIPCHK(h, hipMalloc((void**)&pool.entries, sizeof(DgParkEntry) * slots));
     if (hipMalloc((void**)&pool.store, sizeof(double) * slot * slots) != hipSuccess) {      // no room: solve without deferral
       (void)hipGetLastError();
@@ -743,7 +750,7 @@ int dgsqp_coop_stats(dgsqp_handle_t h, uint64_t* out4 /* six values */) {
   { const int rc = wait_idle(h); if (rc) return rc; }
   DgCoop hdr;
   HIPCHK(h, hipMemcpy(&hdr, h->d_coop, sizeof(DgCoop) - sizeof(DgCoopJob), hipMemcpyDeviceToHost));
-  out4[0] = hdr.helped; out4[1] = hdr.timeouts; out4[2] = hdr.finished; out4[3] = hdr.idle;
+  out4[0] = hdr.helped; out4[1] = hdr.helper_regs; out4[2] = hdr.finished; out4[3] = hdr.idle;
   out4[4] = hdr.used; out4[5] = hdr.mismatches;
   return DGSQP_OK;
 }

@@ -1,6 +1,6 @@
 // Library-owned RCCL communicator: one process per GPU, the Monte-Carlo batch shards with no
-// data-path collective; the ONE exchange per batch is an all-gather of a fixed 64-byte record per scenario
-// {status, iterations, QP solves, rank, p_feas, comp, stat, cost[0..2]} over xGMI, plus a barrier and a max-reduction for the
+// data-path collective; the ONE exchange per batch is an all-gather of a fixed 88-byte record per scenario
+// {status, iterations, QP solves, rank, p_feas, comp, stat, cost[0..5]} over xGMI, plus a barrier and a max-reduction for the
 // benchmark's timing.  RCCL is loaded at run time (dlopen) so that the library also loads on hosts without it; nothing here
 // needs PyTorch.  Included by dgsqp_api.hip after struct dgsqp_solver.
 #pragma once
@@ -64,10 +64,10 @@ __global__ void dg_pack_stats_kernel(int64_t B, int64_t Bpad, int M, int rank, c
   if (b < B) {
     r.status = status[b]; r.iters = iters[b]; r.qp_solves = qps[b];
     r.p_feas = cond[3 * b]; r.comp = cond[3 * b + 1]; r.stat = cond[3 * b + 2];
-    for (int a = 0; a < 3; a++) r.cost[a] = a < M ? cost[b * M + a] : 0.0;
+    for (int a = 0; a < DGSQP_MAX_AGENTS; a++) r.cost[a] = a < M ? cost[b * M + a] : 0.0;
   } else {
     r.status = -1; r.iters = 0; r.qp_solves = 0; r.p_feas = r.comp = r.stat = 0.0;
-    r.cost[0] = r.cost[1] = r.cost[2] = 0.0;
+    for (int a = 0; a < DGSQP_MAX_AGENTS; a++) r.cost[a] = 0.0;
   }
   out[b] = r;
 }

@@ -109,10 +109,10 @@ struct DgCoopJob {
 };
 struct DgCoop {
   unsigned int idle;              // helper workgroups currently polling
-  unsigned int timeouts;          // owner waits that gave up (diagnostic: must stay 0)
+  unsigned int helper_regs;       // times a workgroup entered the helper loop (diagnostic)
   unsigned long long finished;    // scenarios completed by this launch
   unsigned int open;              // job slots currently open: the one word idle helpers poll
-  unsigned int pad0_;
+  unsigned int active_helpers;    // workgroups evaluating trials right now (at most Ctx.coop_helpers; the others sleep)
   unsigned long long helped;      // trials evaluated by helpers (diagnostic)
   unsigned int pad1_;
   unsigned int mismatches;        // verify mode: helper values whose bits differ from the owner's own evaluation (must stay 0)

@@ -1157,8 +1157,15 @@ __device__ __noinline__ int dev_coop_help(Ctx& c) {
   // The first `coop_helpers` workgroups to run out of scenarios help; the others only wait for the launch to end: a failing line search
   // has at most 48 trials on offer, and 250 workgroups evaluating trials nobody will need keep the whole chip under load -- its clock
   // sags and the scenarios still solving, serial chains all of them, run slower than in a plain launch's quiet tail.
-  const unsigned int rank = (unsigned int)dev_bcast_u64(TID == 0 ? (unsigned long long)__hip_atomic_fetch_add(&co->idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull);
+  // `active_helpers` counts the workgroups evaluating trials right now: a helper that leaves to resume a deferred scenario gives its place
+  // back, one that returns takes a place only if there is one (`idle` counts every workgroup in here, active or asleep)
+  const unsigned int rank = (unsigned int)dev_bcast_u64(TID == 0 ? (unsigned long long)__hip_atomic_fetch_add(&co->active_helpers, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull);
   const bool passive = (int)rank >= c.coop_helpers;
+  if (TID == 0) {
+    if (passive) __hip_atomic_fetch_sub(&co->active_helpers, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&co->idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&co->helper_regs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   int start = (2 * (int)blockIdx.x + 2) % njobs;
   unsigned long long spins = 0;
   int ret = 0;
@@ -1244,7 +1251,10 @@ __device__ __noinline__ int dev_coop_help(Ctx& c) {
     dev_coop_trial(c, job, j);
     if (TID == 0) __hip_atomic_fetch_sub(&job->active, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (TID == 0) __hip_atomic_fetch_sub(&co->idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (TID == 0) {
+    __hip_atomic_fetch_sub(&co->idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!passive) __hip_atomic_fetch_sub(&co->active_helpers, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   __syncthreads();
   return ret;
 }

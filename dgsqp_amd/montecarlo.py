@@ -41,6 +41,7 @@ class Game:
     obs_d: float
     name: str = ''
     sampler: str = 'first_segment'      # 'first_segment' (chicane.py/curve.py/agents.py) or 'circuit' (comp.py)
+    second_car_ahead: bool = False      # the sampler also rejects placements with car 2 behind car 1 (ablation.py:387)
 
     def solver_args(self):
         return (self.joint_model, self.costs, self.agent_constraints, self.shared_constraints, self.bounds, self.params)
@@ -92,6 +93,31 @@ def kinematic_racing_game(track_kind='chicane', theta_deg=45, N=25, reg=1e-3, M=
                 [InputRateLimits((10.0, steer_rate), (-10.0, -steer_rate)) for _ in range(M)],
                 CollisionAvoidance([r] * M), _bounds(half_width, M), params, track, half_width, 2 * r,
                 name=f'kb_{track_kind}_N{N}')
+
+
+def ablation_racing_game(N=25, nonmono_ls=True, merit_function='stat_l1', theta_deg=90) -> Game:
+    """The game of the ablation study, scripts/DGSQP_monte_carlo_ablation.py: curve track with a 90 degree turn (:145-153), horizons
+    15 / 20 / 25 (:140), steering-rate limit pi (:101-102, :115-116), radii 0.2 (:134-135), car 2 with blocking weight 1, obstacle
+    weight 5 and the competition weights swapped (:123-131), reg 1e-3; the study switches ``nonmono_ls`` and ``merit_function``
+    ('stat_l1' with the watchdog: :166-180, 'stat' without: :183-197).  Its sampler also rejects car 2 behind car 1 (:387)."""
+    dt, half_width, r, M = 0.1, 1.0, 0.2, 2
+    track = _track('curve', theta_deg, half_width)
+    cfg = lambda: KinematicBicycleConfig(dt=dt, model_name='kinematic_bicycle_cl', noise=False,
+                                         discretization_method='euler', wheel_dist_front=0.13, wheel_dist_rear=0.13,
+                                         drag_coefficient=0.1, slip_coefficient=0.1, code_gen=False)
+    models = [CasadiKinematicBicycleCombined(0, cfg(), track=track) for _ in range(M)]
+    joint = CasadiDecoupledMultiAgentDynamicsModel(0, models, MultiAgentModelConfig(
+        dt=dt, discretization_method='euler', use_mx=True, code_gen=False, verbose=True, compute_hessians=True))
+    params = DGSQPParams(solver_name='sqgames_all' if nonmono_ls else 'sqgames_none', dt=dt, N=N, reg=1e-3, nonmono_ls=nonmono_ls,
+                         merit_function=merit_function, line_search_iters=50, sqp_iters=50, p_tol=1e-3, d_tol=1e-3, beta=0.01, tau=0.5,
+                         verbose=False)
+    costs = [RacingCost(input_weight=(1.0, 1.0), input_rate_weight=(1.0, 1.0), comp_weights=(10.0, 5.0), comp_type='atan',
+                        blocking_weight=0, obs_weight=0, obs_r=0.3),
+             RacingCost(input_weight=(1.0, 1.0), input_rate_weight=(1.0, 1.0), comp_weights=(5.0, 10.0), comp_type='atan',
+                        blocking_weight=1, obs_weight=5, obs_r=0.3)]
+    return Game(joint, costs, [InputRateLimits((10.0, np.pi), (-10.0, -np.pi)) for _ in range(M)],
+                CollisionAvoidance([r] * M), _bounds(half_width, M), params, track, half_width, 2 * r,
+                name=f'ablation_N{N}_{"nms" if nonmono_ls else "ls"}_{merit_function}', second_car_ahead=True)
 
 
 def dynamic_racing_game(track_kind='curve', theta_deg=45, N=25, reg=1e-3, rk4_substeps=10, game_def='exact_dynamic', solver='v1') -> Game:
@@ -348,6 +374,8 @@ def sample_scenarios(game: Game, B: int, seed: int = 1, max_rounds: int = 200, s
         ey2 = ey1 + 1.2 * obs_d * np.sin(d)
         v2 = rng.random(n) + 2
         ok = (s2 >= 0) & (np.abs(ey2) <= hw)
+        if game.second_car_ahead:
+            ok &= s2 >= s1
         s1, ey1, v1, s2, ey2, v2 = (a[ok] for a in (s1, ey1, v1, s2, ey2, v2))
         q0 = []
         for mdl, s, ey, v in ((models[0], s1, ey1, v1), (models[1], s2, ey2, v2)):

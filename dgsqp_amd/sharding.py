@@ -1,6 +1,6 @@
 """Multi-GPU plumbing: the Monte-Carlo batch shards embarrassingly (every scenario is an independent
 ``solve()``, reference DGSQP/solvers/DGSQP.py:302-310), one process per GPU, no collective on the data
-path; the only exchange is ONE all-gather of a fixed 64-byte per-scenario record for the convergence
+path; the only exchange is ONE all-gather of a fixed 88-byte per-scenario record for the convergence
 statistics -- ``ncclAllGather`` over xGMI issued by the HIP library itself (``dgsqp_gather_stats``,
 include/dgsqp.h; RCCL communicator owned by the solver handle).  No PyTorch anywhere: ranks find each
 other through the environment a launcher sets (RANK / LOCAL_RANK / WORLD_SIZE, e.g. ``torch.distributed.run``
@@ -18,8 +18,8 @@ from . import _ffi
 
 STATS_FIELDS = ('status', 'num_iters', 'qp_solves', 'p_feas', 'comp', 'stat')
 RECORD_DTYPE = np.dtype([('status', np.int32), ('iters', np.int32), ('qp_solves', np.int32), ('rank', np.int32),
-                         ('p_feas', np.float64), ('comp', np.float64), ('stat', np.float64), ('cost', np.float64, (3,))])
-assert RECORD_DTYPE.itemsize == 64 == C.sizeof(_ffi.StatRecordT)
+                         ('p_feas', np.float64), ('comp', np.float64), ('stat', np.float64), ('cost', np.float64, (_ffi.MAX_AGENTS,))])
+assert RECORD_DTYPE.itemsize == 88 == C.sizeof(_ffi.StatRecordT)
 
 
 def shard_range(B: int, rank: int, world: int):
@@ -64,13 +64,13 @@ def pack_stats(res: dict) -> np.ndarray:
 
 
 def records_from_results(res: dict, rank: int = 0) -> np.ndarray:
-    """Host-side construction of the 64-byte records (what ``dg_pack_stats_kernel`` builds on the device)."""
+    """Host-side construction of the 88-byte records (what ``dg_pack_stats_kernel`` builds on the device)."""
     B = len(res['status'])
     rec = np.zeros(B, RECORD_DTYPE)
     rec['status'], rec['iters'], rec['qp_solves'], rec['rank'] = res['status'], res['num_iters'], res['qp_solves'], rank
     rec['p_feas'], rec['comp'], rec['stat'] = res['cond'][:, 0], res['cond'][:, 1], res['cond'][:, 2]
     if 'cost' in res:
-        m = min(3, res['cost'].shape[1])
+        m = min(_ffi.MAX_AGENTS, res['cost'].shape[1])
         rec['cost'][:, :m] = res['cost'][:, :m]
     return rec
 
@@ -87,6 +87,13 @@ def stats_from_records(rec: np.ndarray) -> np.ndarray:
     """Gathered records (rank order, padding rows status -1) -> [B_total, 6] float64 table ``summarize`` takes."""
     rec = rec[rec['status'] >= 0]
     return np.column_stack([rec['status'], rec['iters'], rec['qp_solves'], rec['p_feas'], rec['comp'], rec['stat']]).astype(np.float64)
+
+
+def costs_from_records(rec: np.ndarray, M: int) -> np.ndarray:
+    """Gathered records -> [B_total, M] costs of every agent (``f_J``, DGSQP.py:492), padding rows dropped."""
+    if not 1 <= M <= _ffi.MAX_AGENTS:
+        raise ValueError(f'M must be in 1..{_ffi.MAX_AGENTS}')
+    return np.ascontiguousarray(rec[rec['status'] >= 0]['cost'][:, :M])
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -199,7 +206,7 @@ class Communicator:
         return v
 
     def gather_stats(self, B_pad: int) -> np.ndarray:
-        """ONE ncclAllGather of the 64-byte records of the handle's last solve; returns the [world * B_pad] record array."""
+        """ONE ncclAllGather of the 88-byte records of the handle's last solve; returns the [world * B_pad] record array."""
         out = np.zeros(self.world * B_pad, RECORD_DTYPE)
         self._check(self._lib.dgsqp_gather_stats(self._h, int(B_pad), out.ctypes.data_as(C.c_void_p)))
         return out

@@ -264,9 +264,14 @@ def solve_batches(solvers, batches) -> list:
         staged.append(B)
     t0 = time.time()
     arr = (C.c_void_p * len(solvers))(*[s._h for s in solvers])
-    lib.dgsqp_set_cooperative(solvers[0]._h, 2)        # the caller waits for this launch: idle workgroups help with its line searches
+    # the caller waits for this launch, so a leader in the default mode 1 ("synchronous calls only") runs it cooperatively: idle
+    # workgroups help with its line searches.  An explicit set_cooperative(0) / (2) of the leader is honoured and left as it is.
+    mode = getattr(solvers[0], '_coop_mode', 1)
+    if mode == 1:
+        lib.dgsqp_set_cooperative(solvers[0]._h, 2)
     rc = lib.dgsqp_launch_staged_group(arr, len(solvers))
-    lib.dgsqp_set_cooperative(solvers[0]._h, 1)
+    if mode == 1:
+        lib.dgsqp_set_cooperative(solvers[0]._h, 1)
     if rc != 0:
         raise RuntimeError('dgsqp_launch_staged_group failed: ' + lib.dgsqp_last_error(solvers[0]._h).decode())
     tm = _ffi.TimingT()
@@ -497,13 +502,14 @@ class DGSQP(AbstractSolver):
         launch.  Results are bit-identical in every mode; only the time a launch spends behind its slowest scenario changes."""
         if self._lib.dgsqp_set_cooperative(self._h, int(mode)) != 0:
             raise ValueError(f'bad cooperative mode {mode}')
+        self._coop_mode = int(mode)
 
     def coop_stats(self) -> dict:
-        """Counters of the last cooperative launch: trials evaluated by helper workgroups, owner waits that gave up (must be 0)."""
+        """Counters of the last cooperative launch (include/dgsqp.h: dgsqp_coop_stats)."""
         out = (C.c_uint64 * 6)()
         if self._lib.dgsqp_coop_stats(self._h, out) != 0:
             raise RuntimeError(self._lib.dgsqp_last_error(self._h).decode())
-        return dict(helped=int(out[0]), timeouts=int(out[1]), finished=int(out[2]), idle=int(out[3]), used=int(out[4]), mismatches=int(out[5]))
+        return dict(helped=int(out[0]), helper_registrations=int(out[1]), finished=int(out[2]), idle=int(out[3]), used=int(out[4]), mismatches=int(out[5]))
 
     def set_deferral(self, min_iters: int = 8, factor: float = 2.0):
         """Deferral of long scenarios in cooperative launches (include/dgsqp.h: dgsqp_set_deferral): a scenario still iterating after

@@ -234,12 +234,12 @@ typedef struct {
   int32_t grid, block;
 } dgsqp_timing_t;
 
-/* Fixed 64-byte per-scenario record of the ONE collective of a sharded Monte-Carlo batch: what the
-   convergence statistics need (process_data_curve.py:44-53).  cost holds the first three agents' costs. */
+/* Fixed 88-byte per-scenario record of the ONE collective of a sharded Monte-Carlo batch: what the
+   convergence statistics need (process_data_curve.py:44-53).  cost holds every agent's cost (DGSQP_MAX_AGENTS slots). */
 typedef struct {
   int32_t status, iters, qp_solves, rank;
   double p_feas, comp, stat;
-  double cost[3];
+  double cost[DGSQP_MAX_AGENTS];   /* f_J of every agent (DGSQP.py:492); zeros beyond M */
 } dgsqp_stat_record_t;
 
 typedef struct dgsqp_solver* dgsqp_handle_t;
@@ -311,8 +311,8 @@ int dgsqp_launch_staged_group(const dgsqp_handle_t* hs, int count);
    (dgsqp_solve_batch, dgsqp_solve_staged -- nothing else is waiting for the compute units); 2: every launch of this handle, also
    the asynchronous ones -- for the LAST launch of a pipeline.  The leader's setting governs a grouped launch. */
 int dgsqp_set_cooperative(dgsqp_handle_t h, int mode);
-/* Diagnostic: counters of the handle's last cooperative launch -- out6 = {trials evaluated by helpers, owner waits that gave up
-   (must be 0), scenarios finished, helpers still registered (0 after the launch), helper values the owners consumed, helper values
+/* Diagnostic: counters of the handle's last cooperative launch -- out6 = {trials evaluated by helpers, times a workgroup entered
+   the helper loop (at most coop_helpers of them evaluate trials at any moment, the others sleep), scenarios finished, helpers still registered (0 after the launch), helper values the owners consumed, helper values
    whose bits differed from the owner's own evaluation (verify mode, environment DGSQP_COOP_VERIFY=1; must be 0)}. */
 int dgsqp_coop_stats(dgsqp_handle_t h, uint64_t* out6);
 /* Deferral of long scenarios (cooperative launches; scheduling only, results are bit-identical).  Nothing in a scenario's inputs
@@ -322,8 +322,11 @@ int dgsqp_coop_stats(dgsqp_handle_t h, uint64_t* out6);
    is empty, the scenarios that have cost the most so far first.  The long solves of a launch's last batches thereby run while the
    chip still has other work.  Defaults: min_iters 8, factor 2.0; min_iters 0 switches it off.  Never applied with a wall-clock
    limit (dgsqp_params_t.time_limit >= 0), to DG-SQP v2, while logs are recorded, or in non-cooperative launches.  The slots
-   (LDS image + scratch image per scenario, 4,096 of them or what 16 GB hold) are one pool per device, allocated at the first
-   deferring launch; a cooperative launch that finds the pool in use by another launch in flight simply does not defer.  Nothing is
+   (LDS image + scratch image per scenario: 0.65 MB for the 2-agent N = 25 games, up to 4 MB for the XL layouts) are one pool per
+   device: sized for what the launch may defer (a quarter of its scenarios; 257 slots = 0.17 GB for a 1,024-scenario batch, 3.4 GB for
+   a group of 20), grown geometrically by later, larger launches, never beyond DGSQP_DEFER_POOL_BYTES (environment; default 16 GiB,
+   0 = no deferral), kept until the process's last handle is destroyed; a cooperative launch that finds the pool in use by another
+   launch in flight simply does not defer.  Nothing is
    deferred before 32 scenarios of the launch have finished nor when fewer than two rounds of fresh scenarios remain. */
 int dgsqp_set_deferral(dgsqp_handle_t h, int32_t min_iters, double factor);
 /* Diagnostic: out2 = {scenarios deferred, scenarios resumed} of the handle's last cooperative launch (equal after the launch). */
@@ -431,7 +434,7 @@ int dgsqp_synchronize(dgsqp_handle_t h);
  * Multi-GPU (one process per GPU, scenarios sharded, no data-path collective): the library owns the RCCL communicator.
  *   dgsqp_comm_unique_id   rank 0: 128-byte ncclUniqueId to hand to the other ranks (file, socket, environment ...)
  *   dgsqp_comm_init        every rank: ncclCommInitRank on the handle's device (collective call)
- *   dgsqp_gather_stats     the ONE collective per batch: ncclAllGather over xGMI of the 64-byte records of the handle's last solve.
+ *   dgsqp_gather_stats     the ONE collective per batch: ncclAllGather over xGMI of the 88-byte records of the handle's last solve.
  *                          B_pad = the largest shard (shards may differ by one scenario); out[world * B_pad] in rank order, padding
  *                          rows carry status -1.  Every rank receives all records.
  *   dgsqp_comm_barrier, dgsqp_comm_allreduce_max   fences / max-over-ranks of small host vectors for benchmark timing

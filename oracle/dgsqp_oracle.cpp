@@ -1774,15 +1774,22 @@ int oracle_solve_trace(const dgsqp_problem_t* P, const dgsqp_params_t* par, cons
 }
 
 // DGSQP.solve() for B scenarios on `nthreads` host threads
+// bench.py's cpu_baseline: wall-clock seconds every scenario of the next oracle_solve_batch call took on its thread (null: off)
+static double* g_scenario_seconds = nullptr;
+void oracle_set_scenario_seconds(double* buf) { g_scenario_seconds = buf; }
+
 int oracle_solve_batch(const dgsqp_problem_t* P, const dgsqp_params_t* par, int64_t B, const double* x0, const double* u_ws,
                        double* u_out, double* l_out, double* x_out, int32_t* status, int32_t* iters, int32_t* qp_solves,
                        double* cond, double* cost, double* l_init, int literal, int nthreads) {
   Layout L = make_layout(*P);
+  double* const secs = g_scenario_seconds;
   std::atomic<int64_t> next{0};       // dynamic hand-out: iteration counts vary 1..50+, a static partition would time the unluckiest thread
   auto work = [&](int64_t, int64_t) {
     for (int64_t b = next++; b < B; b = next++) {
       SolveOut o;
+      const auto t_scn = std::chrono::steady_clock::now();
       solve_any(*P, *par, L, x0 + b * L.nq, u_ws + b * L.n, literal, o);
+      if (secs) secs[b] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_scn).count();
       if (u_out) std::copy(o.u.begin(), o.u.end(), u_out + b * L.n);
       if (l_out) std::copy(o.l.begin(), o.l.end(), l_out + b * L.nc);
       if (x_out) std::copy(o.x.begin(), o.x.end(), x_out + b * (int64_t)(L.N + 1) * L.nq);

@@ -152,18 +152,23 @@ def merit(P, par, Q, q, G, g, l, s, du, dl, mu):
     return phi.value, dphi.value, mu_out.value
 
 
-def solve_batch(P, par, x0, u_ws, literal=0, nthreads=1):
-    """u_ws agent-major [B, n]."""
+def solve_batch(P, par, x0, u_ws, literal=0, nthreads=1, timed=False):
+    """u_ws agent-major [B, n].  ``timed``: also returns ``seconds`` [B], the wall-clock time each scenario took on its thread."""
     d = dims(P)
     x0 = np.ascontiguousarray(x0, float)
     u_ws = np.ascontiguousarray(u_ws, float)
     B = x0.shape[0]
+    secs = np.zeros(B) if timed else None
+    lib().oracle_set_scenario_seconds(_d(secs))
     out = dict(u=np.zeros((B, d['n'])), l=np.zeros((B, d['nc'])), x=np.zeros((B, d['N'] + 1, d['nq'])),
                status=np.zeros(B, np.int32), num_iters=np.zeros(B, np.int32), qp_solves=np.zeros(B, np.int32),
                cond=np.zeros((B, 3)), cost=np.zeros((B, d['M'])), l_init=np.zeros((B, d['nc'])))
     lib().oracle_solve_batch(C.byref(P), C.byref(par), C.c_int64(B), _d(x0), _d(u_ws), _d(out['u']), _d(out['l']), _d(out['x']),
                              _i(out['status']), _i(out['num_iters']), _i(out['qp_solves']), _d(out['cond']), _d(out['cost']),
                              _d(out['l_init']), C.c_int(literal), C.c_int(nthreads))
+    lib().oracle_set_scenario_seconds(None)
+    if timed:
+        out['seconds'] = secs
     return out
 
 

@@ -31,10 +31,12 @@ def agent_major(u_tm):
 @pytest.fixture(scope='session')
 def games():
     """Small set of games used across tests: name -> (Game, ProblemT, ParamsT)."""
-    from dgsqp_amd.montecarlo import barc_racing_game, kinematic_racing_game, dynamic_racing_game, merge_game
+    from dgsqp_amd.montecarlo import ablation_racing_game, barc_racing_game, kinematic_racing_game, dynamic_racing_game, merge_game
     from dgsqp_amd.solver import build_problem, build_params
     out = {}
-    for name, g in (('kb_chicane_N15', kinematic_racing_game('chicane', N=15)),
+    ablation = tuple((f'ablation_N{N}_{"nms" if nm else "ls"}_{mf}', ablation_racing_game(N=N, nonmono_ls=nm, merit_function=mf))
+                     for N in (15, 25) for nm in (True, False) for mf in ('stat_l1', 'stat'))      # DGSQP_monte_carlo_ablation.py:166-197
+    for name, g in ablation + (('kb_chicane_N15', kinematic_racing_game('chicane', N=15)),
                     ('kb_chicane_N25', kinematic_racing_game('chicane', N=25)),
                     ('kb_curve_N10', kinematic_racing_game('curve', N=10)),
                     ('dyn_curve_N15', dynamic_racing_game(N=15, rk4_substeps=4, game_def='curve')),

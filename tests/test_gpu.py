@@ -89,11 +89,17 @@ def test_qp_parity_and_kkt(oracle, games, solvers, name):
         assert np.abs(lh * (o['G'] @ d + o['g'])).max() < 1e-10 * scale
 
 
-@pytest.mark.parametrize('name', ['kb_chicane_N15', 'kb_curve_N10', 'dyn_curve_N15', 'dyn_curve_N25', 'kb_barc2_N15', 'merge_N8'])
+ABLATION = [f'ablation_N{N}_{nm}_{mf}' for N in (15, 25) for nm in ('nms', 'ls') for mf in ('stat_l1', 'stat')]
+
+
+@pytest.mark.parametrize('name', ['kb_chicane_N15', 'kb_curve_N10', 'dyn_curve_N15', 'dyn_curve_N25', 'kb_barc2_N15', 'merge_N8'] + ABLATION)
 def test_solve_matches_golden_fixtures(solvers, name):
     """Committed oracle solutions (tools/make_golden.py, literal parameters): identical flags / iteration / QP counts on the
     scenarios the oracle itself reproduces under 1e-13 input perturbations (the fixture's ``stable`` mask), iterates of the
-    identical ones within 1e-5 relative (north_star); forks on the unstable rest are printed, not hidden."""
+    identical ones within 1e-5 relative (north_star); forks on the unstable rest are printed, not hidden.
+    ``ablation_N*``: the reference's ablation study (scripts/DGSQP_monte_carlo_ablation.py:166-197, theta = 90 degrees, car 2 with
+    blocking and soft-obstacle costs) in all four combinations nonmono_ls x merit_function ('nms' = watchdog, 'ls' = plain
+    backtracking line search, the DGSQPParams default), 32 scenarios each at N = 15 and N = 25."""
     gold = np.load(GOLD / f'{name}.npz')
     s = solvers[name]
     res = s.solve_batch(gold['x0'], gold['u_ws'])
@@ -265,11 +271,15 @@ def test_event_trace_parity_with_osqp(oracle, games):
     assert identical >= B - 1, identical
 
 
-def test_event_trace_parity(oracle, games, solvers):
+@pytest.mark.parametrize('name', ['kb_chicane_N15', 'ablation_N15_ls_stat', 'ablation_N15_ls_stat_l1', 'ablation_N15_nms_stat'])
+def test_event_trace_parity(oracle, games, solvers, name):
     """Event-by-event comparison of the SQP state machine (convergence measures, mu, merit values, every
-    watchdog / line-search trial): same event codes in the same order, values within 1e-5 relative."""
+    watchdog / line-search trial): same event codes in the same order, values within 1e-5 relative.  The ablation games run the
+    other three combinations of nonmono_ls x merit_function (plain _line_search_3 instead of the watchdog; merit 'stat' without the
+    l1 term and with mu = 0).  Without the watchdog a failing line search halves alpha down to 2^-50, where the Armijo test compares
+    merits that agree to 13 digits -- decided by rounding in the reference as well: such scenarios fail the oracle's own 1e-13
+    perturbation test and are exempt (at most 3 of the 12)."""
     from dgsqp_amd.montecarlo import sample_scenarios
-    name = 'kb_chicane_N15'
     g, P, par = games[name]
     s = solvers[name]
     B = 12
@@ -280,15 +290,17 @@ def test_event_trace_parity(oracle, games, solvers):
         traces = s.fetch_trace(B)
     finally:
         s.set_trace(0)
-    identical = 0
+    ref = oracle.solve_batch(P, tight_lsqr(par), x0, agent_major(u_tm), nthreads=B)
+    stable = stable_mask(oracle, P, tight_lsqr(par), x0, agent_major(u_tm), ref)
+    identical = np.zeros(B, bool)
     for b in range(B):
         to = oracle.solve_trace(P, tight_lsqr(par), x0[b], agent_major(u_tm)[b])
         tg = traces[b]
         if len(to) == len(tg) and np.array_equal(to[:, 0], tg[:, 0]):
             big = np.abs(to[:, 1]) > 1e-6
-            if np.all(np.abs(tg[big, 1] - to[big, 1]) <= 1e-5 * np.abs(to[big, 1])):
-                identical += 1
-    assert identical >= B - 1, identical
+            identical[b] = np.all(np.abs(tg[big, 1] - to[big, 1]) <= 1e-5 * np.abs(to[big, 1]))
+    print(name, 'event traces identical', identical.sum(), 'of', B, '; oracle-stable', stable.sum(), '; identical among stable', identical[stable].sum())
+    assert stable.sum() >= B - 3 and identical[stable].sum() >= stable.sum() - 1, (identical, stable)
 
 
 def test_full_size_properties(games):
@@ -841,7 +853,7 @@ def test_cooperative_line_search_is_bit_identical(games):
         for r in (res, chk):
             for k in ('status', 'num_iters', 'qp_solves', 'u', 'l', 'x', 'cond', 'cost'):
                 assert np.array_equal(r[k], ref[k], equal_nan=True), (name, k)      # (NaN iterates of qp_fail / diverged runs are outputs too)
-        assert st['timeouts'] == 0 and st['idle'] == 0 and st['finished'] == B and st['helped'] > 0 and st['used'] > 0, st
+        assert st['helper_registrations'] > 0 and st['idle'] == 0 and st['finished'] == B and st['helped'] > 0 and st['used'] > 0, st
         assert st_chk['mismatches'] == 0 and st_chk['used'] > 0, st_chk
 
 
@@ -1233,7 +1245,7 @@ def test_single_precision_boundary(games, solvers):
 
 def test_rccl_gather_single_rank(games):
     """The library-owned RCCL communicator (dgsqp_comm_init / dgsqp_gather_stats, include/dgsqp.h) on one rank: ncclAllGather of the
-    64-byte records of the last solve, padding rows, barrier and max-reduction -- no PyTorch involved."""
+    88-byte records of the last solve, padding rows, barrier and max-reduction -- no PyTorch involved."""
     from dgsqp_amd.montecarlo import sample_scenarios
     from dgsqp_amd.sharding import Communicator, stats_from_records, pack_stats
     from dgsqp_amd.solver import DGSQP
@@ -1306,12 +1318,14 @@ def test_bench_line_contract():
                 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'value_single_launch', 'value_host_inclusive'):
         assert key in d, key
     assert 0 < d['value_host_inclusive'] and 0 < d['value_single_launch'] <= 1.5 * d['value']
-    assert d['config']['distinct_batches'] >= 2 and d['roofline']['kernel_ms_source'].endswith('one at a time')
+    assert d['config']['distinct_batches'] >= 2 and d['roofline']['single_launch']['source'].endswith('one at a time')
+    assert 'timed region' in d['roofline']['kernel_ms_source'] and d['roofline']['launches_timed'] >= 1
+    assert abs(d['roofline']['solves_per_launch'] * d['roofline']['launches_timed'] - 64 * 3) < 1e-9 and d['config']['qp_method'] == 'active_set'
     assert d['unit'] == 'scenarios/s' and d['n_gpus'] == 1 and d['steps'] == 3 and d['scaling'] == 'weak' and d['dtype'] == 'f64'
     assert d['config']['workload'] == 'kb_curve_N25' and d['config']['batch_per_gpu'] == 64
     assert d['config']['launches_in_flight'] == 2 and d['config']['batches_per_launch'] >= 1      # (steps are issued in grouped launches)
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-15 and r['kernel_ms'] > 0
     c = d['cpu_baseline']
-    assert c['kind'] == 'port' and c['value'] > 0 and c['cores'] >= 1
+    assert c['kind'] == 'port' and c['value'] > 0 and c['cores'] >= 1 and c['value_wall'] > 0 and c['seconds_per_scenario']['max'] >= c['seconds_per_scenario']['mean'] > 0
     assert abs(d['value'] - 64 * 3 / (d['ms_per_step'] * 3e-3)) < 1e-6 * d['value']

@@ -254,12 +254,35 @@ import bench
 bench.spawn_ranks(int(sys.argv[1]), [{str(ROOT)!r}, sys.argv[2]], script={str(stub)!r}, timeout=120.0)
 ''')
     env = dict(os.environ, TMPDIR=str(tmp_path))
-    ok = subprocess.run([sys.executable, str(driver), '3', 'ok'], env=env, capture_output=True, text=True, timeout=300)
-    assert ok.returncode == 0 and '"stub": "ok", "world": 3' in ok.stdout, ok.stdout + ok.stderr
-    assert not list(tmp_path.glob('dgsqp_rccl_*.id')), 'rendezvous file left behind'
+    for world in (3, 8):          # 8: the node the scaling run uses (one rank per GPU)
+        ok = subprocess.run([sys.executable, str(driver), str(world), 'ok'], env=env, capture_output=True, text=True, timeout=300)
+        assert ok.returncode == 0 and f'"stub": "ok", "world": {world}' in ok.stdout, ok.stdout + ok.stderr
+        assert not list(tmp_path.glob('dgsqp_rccl_*.id')), 'rendezvous file left behind'
     t0 = time.time()
     bad = subprocess.run([sys.executable, str(driver), '2', 'fail'], env=env, capture_output=True, text=True, timeout=300)
     assert bad.returncode == 7 and time.time() - t0 < 45, (bad.returncode, bad.stderr[-500:])
+
+
+def test_stat_record_carries_every_agents_cost():
+    """The record of the ONE collective (dgsqp_stat_record_t, 88 bytes) has a cost slot for every agent the library supports: the
+    6-car merge (BASELINE configs[4]) keeps all six costs through pack -> pad -> gather -> unpack; struct and numpy dtype agree."""
+    import ctypes
+    from dgsqp_amd import _ffi
+    from dgsqp_amd.sharding import RECORD_DTYPE, costs_from_records, pad_records, records_from_results, stats_from_records
+    assert ctypes.sizeof(_ffi.StatRecordT) == RECORD_DTYPE.itemsize == 88 and RECORD_DTYPE['cost'].shape == (_ffi.MAX_AGENTS,) == (6,)
+    for f in _ffi.StatRecordT._fields_:
+        assert getattr(_ffi.StatRecordT, f[0]).offset == RECORD_DTYPE.fields[f[0]][1], f[0]
+    rng = np.random.default_rng(0)
+    B, M = 5, 6
+    res = dict(status=np.array([0, 1, 2, 4, 0], np.int32), num_iters=np.arange(B, dtype=np.int32), qp_solves=np.arange(B, dtype=np.int32) + 1,
+               cond=rng.random((B, 3)), cost=rng.standard_normal((B, M)))
+    world = np.concatenate([pad_records(records_from_results({k: v[:3] for k, v in res.items()}, rank=0), 3),
+                            pad_records(records_from_results({k: v[3:] for k, v in res.items()}, rank=1), 3)])
+    assert len(world) == 6 and (world['status'] == -1).sum() == 1
+    assert np.array_equal(costs_from_records(world, M), res['cost'])
+    assert np.array_equal(stats_from_records(world)[:, 0], res['status'])
+    with pytest.raises(ValueError):
+        costs_from_records(world, 7)
 
 
 def test_rendezvous_ignores_a_stale_file(tmp_path):
@@ -322,7 +345,7 @@ dist.destroy_process_group()
 
 def test_two_process_gloo_shard_and_gather(tmp_path):
     """world_size=2: contiguous sharding (uneven: 3 + 2), the file rendezvous of the ncclUniqueId, and ONE equal-count all-gather
-    of the padded 64-byte records == the single-process result.  gloo is the transport in this CPU test only; on the GPU the
+    of the padded 88-byte records == the single-process result.  gloo is the transport in this CPU test only; on the GPU the
     same payload goes through the library's ncclAllGather (tests/test_gpu.py::test_rccl_gather_single_rank)."""
     script = tmp_path / 'worker.py'
     script.write_text(_GLOO_WORKER)

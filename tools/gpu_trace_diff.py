@@ -1,5 +1,5 @@
 """Development aid: first diverging SQP event between device and oracle (run on the GPU box).
-usage: gpu_trace_diff.py <kbcurve0|kbchicane0|barc2> [B] [N]"""
+usage: gpu_trace_diff.py <kbcurve0|kbchicane0|barc2|ablation_<nms|ls>_<stat_l1|stat>> [B] [N]      (environment: DGSQP_SEED)"""
 import os, sys, pathlib
 import numpy as np
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
@@ -11,7 +11,7 @@ from dgsqp_amd.solver import DGSQP, build_problem, build_params
 kind = sys.argv[1]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 25
-g = mc.kinematic_racing_game('curve', N=N, M=3) if kind == 'agents3' else mc.merge_game(N=N) if kind == 'merge' else (mc.barc_racing_game(N=N, M=2) if kind == 'barc2' else mc.kinematic_racing_game('curve' if kind == 'kbcurve0' else 'chicane', N=N, reg=0.0))
+g = mc.ablation_racing_game(N=N, nonmono_ls=kind.split('_')[1] == 'nms', merit_function=kind.split('_', 2)[2]) if kind.startswith('ablation') else mc.kinematic_racing_game('curve', N=N, M=3) if kind == 'agents3' else mc.merge_game(N=N) if kind == 'merge' else (mc.barc_racing_game(N=N, M=2) if kind == 'barc2' else mc.kinematic_racing_game('curve' if kind == 'kbcurve0' else 'chicane', N=N, reg=0.0))
 M = g.joint_model.n_a
 
 
@@ -24,11 +24,8 @@ def tight(par):
 
 
 P, par = build_problem(*g.solver_args()), tight(build_params(g.params))
-orig = sv.build_params
-sv.build_params = lambda p: tight(orig(p))
-s = DGSQP(*g.solver_args(), print_method=None)
-sv.build_params = orig
-x0, u_tm = mc.sample_scenarios(g, B, seed=0 if kind == 'barc2' else 1)
+s = DGSQP(*g.solver_args(), print_method=None, lsqr_tol=1e-13, qp_warm_start=not os.environ.get('DGSQP_NO_WARM'))
+x0, u_tm = mc.sample_scenarios(g, B, seed=int(os.environ.get('DGSQP_SEED', 0 if kind == 'barc2' else 1)))
 u = np.ascontiguousarray(u_tm.reshape(B, N, M, 2).transpose(0, 2, 1, 3).reshape(B, -1))
 s.set_trace(8000)
 res = s.solve_batch(x0, u_tm)

@@ -36,7 +36,7 @@ def param_defaults():
 
 def solve_fixtures(only=None):
     import copy
-    from dgsqp_amd.montecarlo import (barc_racing_game, kinematic_racing_game, dynamic_racing_game, merge_game,
+    from dgsqp_amd.montecarlo import (ablation_racing_game, barc_racing_game, kinematic_racing_game, dynamic_racing_game, merge_game,
                                       sample_scenarios)
     from dgsqp_amd.solver import build_problem, build_params
     from oracle import oracle
@@ -45,7 +45,10 @@ def solve_fixtures(only=None):
                                 ('dyn_curve_N15', dynamic_racing_game(N=15, rk4_substeps=4, game_def='curve'), 16, 13),
                                 ('dyn_curve_N25', dynamic_racing_game(N=25, rk4_substeps=10), 64, 1),     # BASELINE configs[1]
                                 ('kb_barc2_N15', barc_racing_game(N=15, M=2), 32, 0),        # reg = 0 (comp.py:169)
-                                ('merge_N8', merge_game(N=8), 16, 1)):                       # reg = 0 (merge.py:182)
+                                ('merge_N8', merge_game(N=8), 16, 1)) + tuple(                # reg = 0 (merge.py:182)
+            # the ablation study (scripts/DGSQP_monte_carlo_ablation.py:166-197): nonmono_ls x merit_function at theta = 90 degrees
+            (f'ablation_N{N}_{"nms" if nm else "ls"}_{mf}', ablation_racing_game(N=N, nonmono_ls=nm, merit_function=mf), 32, 1)
+            for N in (15, 25) for nm in (True, False) for mf in ('stat_l1', 'stat')):
         if only and name not in only:
             continue
         P = build_problem(*game.solver_args())
