@@ -414,11 +414,13 @@ def main():
             oracle.build()
             cores = os.cpu_count() or 1
             # A THROUGHPUT, not the time of the slowest scenario: every thread gets at least 8 scenarios handed out dynamically (default: the
-            # whole first batch over min(cores, B / 8) threads), every scenario's own wall-clock time on its thread is recorded, and
+            # first 512 scenarios of the first batch over 64 threads), every scenario's own wall-clock time on its thread is recorded, and
             # `value` = threads / mean seconds per scenario -- what those threads sustain over a long Monte-Carlo run.  `value_wall` is the
             # sample over its wall time, idle tail behind the slowest scenario (tens of seconds for one that never converges) included.
-            ns = min(args.cpu_sample if args.cpu_sample != 64 else B, B)
-            nth = max(1, min(cores, ns // 8))
+            # (default: 8 scenarios for each of up to 64 threads -- 512 scenarios, 20-40 s; more threads only add contention in the dense oracle:
+            # 128 threads on the 256-thread host took 6.4 s per scenario against 0.5 s for one alone, profiles/r04_*)
+            ns = min(args.cpu_sample if args.cpu_sample != 64 else 8 * min(cores, 64), B)
+            nth = max(1, min(cores, 64, ns // 8))
             x0, u_am = batches[0]
             t1 = time.perf_counter()
             ob = oracle.solve_batch(solver._problem, solver._cparams, x0[:ns], u_am[:ns], nthreads=nth, timed=True)

@@ -72,7 +72,8 @@ struct DgLds {
   int o_du, o_lhat;
   int a_z, a_y, a_E, a_dy, a_w;  // qp_method = OSQP (dgsqp_osqp.h): the ADMM's n_c-vectors z, y, E (row scaling), delta y, a work vector -- inside the
                                  // slot of the active-set factor T (p_R), which only the polish needs
-  int a_sw;                      // pivot-column buffers of the Gauss-Jordan sweep (2 (NH RPT + 4) doubles): the QP's partial-sum slot where that is large enough
+  int a_tab;                     // ... followed by the per-QP index tables of the transposed product G' w (dgsqp_osqp.h: osqp_build_tables)
+  int a_sw;                      // pivot-column buffers of the Gauss-Jordan sweep (4 (NH RPT + 4) doubles): the ADMM's delta-y / work vectors where they are large enough
   int a_tail;                    // ... and five n-vectors of the polish at the end of that slot (T keeps room for DgProb.osqp_namax active rows)
   int x_el;  // XL layout with xl_el: packed lower triangle of the QP's elimination M = L~ D L~^T (overlaps the QP outputs and c_R, dead until J is built)
   int c_R;   // classical QP: the first DgProb.c_rcap columns of the triangular factor R, packed column-major (phase-multiplexed with e_xs2)
@@ -212,10 +213,11 @@ static inline std::string dg_build_layout(DgProb& D) {
     int tslot = D.classic_qp ? npk : dg_tcol(n);   // (the dual method's inverse factor T: padded columns, dg_tcol)
     const int ncp = (nc + 1) & ~1, np = (n + 1) & ~1;
     if (D.osqp) tslot = dg_tcol(D.osqp_nacap < n ? D.osqp_nacap : n) + (D.osqp_nacap < n ? 5 * np : 0);
-    if (D.osqp && tslot < 5 * ncp + 5 * np) tslot = 5 * ncp + 5 * np;
+    const int tabsz = 2 * n + (n + 8) / 4 + (D.ngd + 2) / 2 + 2;       // 8 int16 per column, n + 1 uint16 column starts, one uint32 per gradient entry
+    if (D.osqp && tslot < 5 * ncp + tabsz + 5 * np) tslot = 5 * ncp + tabsz + 5 * np;
     L.p_R = D.big == 2 ? -1 : take(tslot);
     if (D.osqp) {
-      L.a_z = L.p_R; L.a_y = L.a_z + ncp; L.a_E = L.a_y + ncp; L.a_dy = L.a_E + ncp; L.a_w = L.a_dy + ncp;
+      L.a_z = L.p_R; L.a_y = L.a_z + ncp; L.a_E = L.a_y + ncp; L.a_dy = L.a_E + ncp; L.a_w = L.a_dy + ncp; L.a_tab = L.a_w + ncp;
       L.a_tail = L.p_R + ((tslot - 5 * np) & ~1);
       int na = 0;
       while (na < n && dg_tcol(na + 1) <= L.a_tail - L.p_R) na++;
@@ -230,8 +232,9 @@ static inline std::string dg_build_layout(DgProb& D) {
   }
   L.p_yd2 = take(nd); L.p_yslot = take((n + 2) / 2 + 1); L.p_yfree = take((n + 2) / 2 + 1); L.p_dpart = take(D.ntask); L.p_act = take(nc / 8 + 2); L.p_part = take(DG_NH * n);
   if (D.osqp) {
-    const int need = 2 * (DG_NH * rpt + 4);
-    L.a_sw = DG_NH * n >= need ? L.p_part : take(need);
+    // (the ADMM's delta-y and work vectors are free whenever a matrix is inverted: before the loop, after a check, in the polish)
+    const int need = 4 * (DG_NH * rpt + 4);
+    L.a_sw = 2 * ((nc + 1) & ~1) >= need ? L.a_dy : take(need);
   }
   L.p_xu = L.p_rd;     // unconstrained minimiser of the QP, x = x_u - Y lam at every point of the dual method (the slot the reciprocal diagonal of the Cholesky factor had)
   const int qp_end = o;
@@ -446,6 +449,7 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   D.t2_doubles = t2;
   D.osqp = par.qp_method == DGSQP_QP_OSQP ? 1 : 0;
   D.osqp_nacap = D.n;
+  if (D.osqp && (D.ngd >= 65536 || D.ndense >= 65536)) return "qp_method OSQP: the packed gradients exceed the 16-bit offsets of its index tables";
   D.big = D.n > 128 ? 2 : 0;   // XL layout: every matrix of the PSD / QP phases in the global scratch, generic (slow) kernels
   D.xl_noblock = getenv("DGSQP_XL_NOBLOCK") ? 1 : 0;
   if (D.big == 2 && D.n <= 176 && !getenv("DGSQP_XL_NOPACK")) { D.xl_pack = 1; D.gd_global = 1; }       // (tried first; dg_build_layout falls back when the arena overflows)

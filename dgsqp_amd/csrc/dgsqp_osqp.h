@@ -213,18 +213,18 @@ __device__ inline void osqp_build_w(const DgProb& D, const OsqpPtrs& o) {
   __syncthreads();
 }
 
-// Explicit inverse of the SPD matrix  sM dI M dI + sW W + diag(dg)  (dI = diag(di), di == nullptr: identity) into the packed-P slot
-// (LDS, or the scratch in the big layout): register-resident Gauss-Jordan sweep (spd_sweep_regs).  Returns false when a pivot was not
-// positive / finite (the matrix is not numerically SPD).  tws: 2 (NH RPT + 4) doubles of LDS.
+// Explicit inverse of the SPD matrix  sM dI M dI + sW W + diag(dg)  (dI = diag(di), di == nullptr: identity) by the register-resident
+// Gauss-Jordan sweep (spd_sweep_regs): on return Br holds MINUS the inverse, thread (jc = TID & 127, hf = TID >> 7) its column jc at
+// rows hf + NH r.  With `store` the inverse also goes to the packed-P slot (LDS, or the scratch in the big layout) for dev_p_mul.
+// Returns false when a pivot was not positive / finite (the matrix is not numerically SPD).  tws: 4 (NH RPT + 4) doubles of LDS.
 template <int RPT>
-__device__ __noinline__ bool dev_osqp_inverse_t(const Ctx& c, cgptr M, cgptr W, clptr di, clptr dg, double sM, double sW, lptr tws) {
+__device__ __forceinline__ bool osqp_inverse_regs(const Ctx& c, cgptr M, cgptr W, clptr di, clptr dg, double sM, double sW, lptr tws, double (&Br)[RPT], bool store) {
   const DgProb& D = dg_prob;
   const int n = D.n;
   constexpr int NH = DG_NH;
   const int jc = TID & 127, hf = TID >> 7;
   const bool colok = jc < n;
   __syncthreads();
-  double Br[RPT];
 #pragma unroll
   for (int r = 0; r < RPT; r++) {
     const int i = hf + NH * r;
@@ -239,33 +239,24 @@ __device__ __noinline__ bool dev_osqp_inverse_t(const Ctx& c, cgptr M, cgptr W, 
   __syncthreads();
   spd_sweep_regs<RPT>(Br, tws, n);
   int bad = 0;
-  if (D.big) {
-    gptr Pp = c.ws + D.ws_P;
 #pragma unroll
-    for (int r = 0; r < RPT; r++) {
-      const int i = hf + NH * r;
-      if (colok && i < n && i >= jc) Pp[i * (i + 1) / 2 + jc] = -Br[r];
-      if (colok && i == jc && !(-Br[r] > 0.0 && -Br[r] < 1e300)) bad = 1;
-    }
-    __threadfence_block();
-  } else {
-    lptr Pp = LP(D.L.g_Bp);
+  for (int r = 0; r < RPT; r++) {
+    const int i = hf + NH * r;
+    if (colok && i == jc && !(-Br[r] > 0.0 && -Br[r] < 1e300)) bad = 1;
+  }
+  if (store) {
+    if (D.big) {
+      gptr Pp = c.ws + D.ws_P;
 #pragma unroll
-    for (int r = 0; r < RPT; r++) {
-      const int i = hf + NH * r;
-      if (colok && i < n && i >= jc) Pp[i * (i + 1) / 2 + jc] = -Br[r];
-      if (colok && i == jc && !(-Br[r] > 0.0 && -Br[r] < 1e300)) bad = 1;
+      for (int r = 0; r < RPT; r++) { const int i = hf + NH * r; if (colok && i < n && i >= jc) Pp[i * (i + 1) / 2 + jc] = -Br[r]; }
+      __threadfence_block();
+    } else {
+      lptr Pp = LP(D.L.g_Bp);
+#pragma unroll
+      for (int r = 0; r < RPT; r++) { const int i = hf + NH * r; if (colok && i < n && i >= jc) Pp[i * (i + 1) / 2 + jc] = -Br[r]; }
     }
   }
   return !__syncthreads_or(bad);
-}
-__device__ inline bool dev_osqp_inverse(const Ctx& c, const OsqpPtrs& o, clptr di, clptr dg, double sM, double sW) {
-  const int n = dg_prob.n;
-  lptr tws = LP(dg_prob.L.a_sw);
-  if (n <= 32) return dev_osqp_inverse_t<32 / DG_NH>(c, o.M, o.W, di, dg, sM, sW, tws);
-  if (n <= 64) return dev_osqp_inverse_t<64 / DG_NH>(c, o.M, o.W, di, dg, sM, sW, tws);
-  if (n <= 100) return dev_osqp_inverse_t<100 / DG_NH>(c, o.M, o.W, di, dg, sM, sW, tws);
-  return dev_osqp_inverse_t<128 / DG_NH>(c, o.M, o.W, di, dg, sM, sW, tws);
 }
 
 // out_r = E_r (G (D v))_r for every G row.  Leaves D v in o.tmp and its dense dots in o.ddx.
@@ -301,26 +292,66 @@ __device__ inline void osqp_at_active(const DgProb& D, clptr gd, const lds_i_t* 
   __syncthreads();
 }
 
+
+// ---- the ADMM iteration's own products.  Per QP (the T slot is free during the ADMM) three index tables are built from the static
+// structure of G: for every column the six box / rate rows that touch it, and the list of (dense gradient, entry) pairs covering it --
+// the packed gradients transposed by index.  G' w is then one pass with four lanes per column over independent, unrollable loads; the
+// generic gt_mul (row / gradient tables looked up per column, row indices from constant memory) took 14 of an iteration's 29 kcycles.
+struct OsqpTabs {
+  const __attribute__((address_space(3))) short* colrows;            // [n][8]: r_in_ub, r_in_lb, r_rate_ub, r_rate_lb, r_rate_ub(t+1), r_rate_lb(t+1), -, -   (-1: none)
+  __attribute__((address_space(3))) unsigned short* cstart;          // [n + 1]
+  __attribute__((address_space(3))) unsigned int* pairT;             // [ngd]: (dense gradient << 16) | offset of the entry inside the packed gradients ... offsets < 65536
+};
+__device__ inline OsqpTabs osqp_tabs() {
+  const DgProb& D = dg_prob;
+  lptr base = LP(D.L.a_tab);
+  OsqpTabs t;
+  t.colrows = (const __attribute__((address_space(3))) short*)base;
+  t.cstart = (__attribute__((address_space(3))) unsigned short*)(base + 2 * D.n);
+  t.pairT = (__attribute__((address_space(3))) unsigned int*)(base + 2 * D.n + (D.n + 8) / 4);
+  return t;
+}
+__device__ inline void osqp_build_tables(const DgProb& D, const OsqpTabs& T) {
+  const int n = D.n;
+  __attribute__((address_space(3))) short* cr = (__attribute__((address_space(3))) short*)T.colrows;
+  __syncthreads();
+  for (int col = TID; col < n; col += NT) {
+    const int a = col / (D.N * DGSQP_NUA), rem = col % (D.N * DGSQP_NUA), t = rem / DGSQP_NUA, j = rem % DGSQP_NUA;
+    cr[8 * col + 0] = D.r_in_ub[a][t][j]; cr[8 * col + 1] = D.r_in_lb[a][t][j];
+    cr[8 * col + 2] = D.r_rate_ub[a][t][j]; cr[8 * col + 3] = D.r_rate_lb[a][t][j];
+    cr[8 * col + 4] = t + 1 < D.N ? D.r_rate_ub[a][t + 1][j] : (short)-1; cr[8 * col + 5] = t + 1 < D.N ? D.r_rate_lb[a][t + 1][j] : (short)-1;
+    cr[8 * col + 6] = -1; cr[8 * col + 7] = -1;
+    int cnt = 0;
+    for (int d = D.stage_dense0[t + 1]; d < D.ndense; d++) { const DgDense dd = ld_dense(d); cnt += (dd.a == a) || (dd.kind == 1 && dd.b == a); }
+    T.cstart[col + 1] = (unsigned short)cnt;
+  }
+  __syncthreads();
+  if (TID == 0) { unsigned int s = 0; T.cstart[0] = 0; for (int col = 0; col < n; col++) { s += T.cstart[col + 1]; T.cstart[col + 1] = (unsigned short)s; } }
+  __syncthreads();
+  for (int col = TID; col < n; col += NT) {
+    const int a = col / (D.N * DGSQP_NUA), rem = col % (D.N * DGSQP_NUA), t = rem / DGSQP_NUA, j = rem % DGSQP_NUA;
+    int k = T.cstart[col];
+    for (int d = D.stage_dense0[t + 1]; d < D.ndense; d++) {
+      const DgDense dd = ld_dense(d);
+      if (dd.a == a) T.pairT[k++] = ((unsigned int)d << 16) | (unsigned int)(dd.off + t * DGSQP_NUA + j);
+      else if (dd.kind == 1 && dd.b == a) T.pairT[k++] = ((unsigned int)d << 16) | (unsigned int)(dd.off + 2 * dd.k + t * DGSQP_NUA + j);
+    }
+  }
+  __syncthreads();
+}
 // ------------------------------------------------------------------------------------------------
 // _solve_qp core with OSQP's arithmetic.  In: M (scratch, ws_xM), q, g, packed G.  Out: du (L.o_du), lhat (L.o_lhat).
 // Returns 0 when OSQP hands back a point (solved, solved inaccurate, or the iteration limit: the reference continues from whatever
 // OSQP returns), 1 when it reports primal / dual infeasibility or non-finite data, or when the point is not finite (a NaN step:
 // DGSQP.py:566-585 raises).
 // ------------------------------------------------------------------------------------------------
-__device__ __noinline__ int dev_qp_osqp(const Ctx& c) {
+// Setup of one OSQP call (no registers shared with the ADMM loop: its own function keeps that loop's register allocation clean):
+// finite-data check, Ruiz equilibration (section 5.1; OSQP scale_data(): 10 passes) into o.Dv / o.EI / o.E, W = Gs' Gs, the index tables.
+// Returns the cost scaling c, or a NaN when the data is not finite.
+__device__ __noinline__ double osqp_setup(const Ctx& c) {
   const DgProb& D = dg_prob;
-  const DgLds& L = D.L;
-  lptr lds = LP(0);
   const int n = D.n, nc = D.nc;
   const OsqpPtrs o = osqp_ptrs(c);
-  lptr du = lds + L.o_du, lhat = lds + L.o_lhat;
-  const int lane = TID & 63;
-  const bool w0 = TID < 64;
-  const double sigma = 1e-6, alpha = 1.6, eps_abs = 1e-3, eps_rel = 1e-3, eps_inf = 1e-4, delta = 1e-6;
-  const int max_iter = 4000, check_every = 25;
-  __syncthreads();
-  PROF_BEGIN(pt_qp);
-  if (TID == 0) { o.scal[DG_QP_NPREV] = 0.0; o.scal[DG_XVALID] = 0.0; }
   // ---- data must be finite (the conic plugin returns NaN otherwise)
   {
     int bad = 0;
@@ -328,11 +359,7 @@ __device__ __noinline__ int dev_qp_osqp(const Ctx& c) {
     for (int j = TID; j < n; j += NT) bad |= !(__builtin_fabs(o.q[j]) < INFINITY);
     for (int r = TID; r < nc; r += NT) bad |= (o.g[r] != o.g[r]);
     for (int p = TID; p < D.ngd; p += NT) bad |= !(__builtin_fabs(o.gd[p]) < INFINITY);
-    if (__syncthreads_or(bad)) {
-      if (TID == 0) { o.scal[DG_OSQP_INFO] = OSQP_NAN_DATA; o.scal[DG_OSQP_INFO + 1] = 0; o.scal[DG_OSQP_INFO + 2] = 0; }
-      __syncthreads();
-      return 1;
-    }
+    if (__syncthreads_or(bad)) return __builtin_nan("");
   }
   // ---- Ruiz equilibration (section 5.1; OSQP scale_data()): 10 passes
   PROF_BEGIN(po1);
@@ -370,175 +397,32 @@ __device__ __noinline__ int dev_qp_osqp(const Ctx& c) {
     qn = qn < OSQP_MIN_SCALING ? 1.0 : fmin(qn, OSQP_MAX_SCALING);
     cc *= 1.0 / fmax(ct, qn);
   }
-  const double cinv = 1.0 / cc;
   PROF_END(PH_O_SCALE, po1);
-  // ---- W = Gs' Gs (once), K(rho) and its inverse
+  // ---- W = Gs' Gs (once per call)
   PROF_BEGIN(po2);
   osqp_build_w(D, o);
   PROF_END(PH_O_W, po2);
-  double rho = 0.1;
-  int rho_updates = 0;
-  auto rho_I = [&](int j, double r) { return o.EI[j] * OSQP_INFTY > OSQP_INFTY * OSQP_MIN_SCALING ? OSQP_RHO_MIN : r; };   // "loose" row: both bounds beyond 1e26 after scaling
-  auto build_kinv = [&](double r) -> bool {
-    __syncthreads();
-    for (int j = TID; j < n; j += NT) { const double aI = o.EI[j] * o.Dv[j]; o.tmp[j] = sigma + rho_I(j, r) * aI * aI; }
-    __syncthreads();
-    PROF_BEGIN(po3);
-    const bool okk = dev_osqp_inverse(c, o, o.Dv, o.tmp, cc, r);
-    PROF_END(PH_O_KINV, po3);
-    return okk;
-  };
-  bool spd = build_kinv(rho);
-  for (int j = TID; j < n; j += NT) { o.x[j] = 0.0; o.dx[j] = 0.0; }
-  for (int r = TID; r < nc; r += NT) { o.z[r] = 0.0; o.y[r] = 0.0; o.dy[r] = 0.0; }
-  __syncthreads();
-  // The G rows have  l = -inf -> -1e30 E_r,  u = E_r min(-g_r, 1e30):  never equalities (rho_vec = rho on all of them), never "loose"
-  // unless -g_r >= 1e26 / E_r (then OSQP gives the row rho_min; not reproduced: no game produces such a row)
-  int status = OSQP_MAX_ITER, iters = 0;
-  double pri_res = INFINITY, dua_res = INFINITY;
-  bool stopped = !spd;
-  if (!spd) status = OSQP_NAN_DATA;
-  auto residual_vectors = [&]() {       // Ax (G rows) -> w, Px -> rhs, A'y -> xt
-    osqp_gs_mul(o, o.x, o.w);
-    osqp_m_pass<false>(o.M, n, o.tmp, o.part, o.rhs);               // (o.tmp = D x after osqp_gs_mul)
-    for (int j = TID; j < n; j += NT) o.rhs[j] *= cc * o.Dv[j];
-    __syncthreads();
-    osqp_gst_mul(c, o, o.y, o.dy, o.xt);                            // (dy is free here: its last use was the infeasibility test)
-  };
-  double eps_p = 0, eps_d = 0, ad_pr = 0, ad_dr = 0;
-  auto residuals = [&]() {
-    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, u[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int r = TID; r < nc; r += NT) {
-      const double ei = 1.0 / o.E[r], ax = o.w[r], zz = o.z[r];
-      v[0] = fmax(v[0], __builtin_fabs(ei * (ax - zz))); v[1] = fmax(v[1], __builtin_fabs(ei * zz)); v[2] = fmax(v[2], __builtin_fabs(ei * ax));
-      v[3] = fmax(v[3], __builtin_fabs(ax - zz)); v[4] = fmax(v[4], __builtin_fabs(zz)); v[5] = fmax(v[5], __builtin_fabs(ax));
-    }
-    for (int j = TID; j < n; j += NT) {
-      const double di = 1.0 / o.Dv[j], px = o.rhs[j], aty = o.xt[j], qs = cc * o.Dv[j] * o.q[j];
-      v[6] = fmax(v[6], __builtin_fabs(o.Dv[j] * o.x[j]));                    // identity rows: |z / E| = |Ax / E| = |D x|
-      v[7] = fmax(v[7], __builtin_fabs(o.EI[j] * o.Dv[j] * o.x[j]));          // ... and |z| = |Ax| scaled
-      u[0] = fmax(u[0], __builtin_fabs(di * (px + qs + aty))); u[1] = fmax(u[1], __builtin_fabs(di * qs)); u[2] = fmax(u[2], __builtin_fabs(di * aty));
-      u[3] = fmax(u[3], __builtin_fabs(di * px)); u[4] = fmax(u[4], __builtin_fabs(px + qs + aty)); u[5] = fmax(u[5], __builtin_fabs(qs));
-      u[6] = fmax(u[6], __builtin_fabs(aty)); u[7] = fmax(u[7], __builtin_fabs(px));
-    }
-    block_max8(v, o.red);
-    block_max8(u, o.red);
-    pri_res = v[0];
-    dua_res = cinv * u[0];
-    eps_p = eps_abs + eps_rel * fmax(fmax(v[1], v[6]), fmax(v[2], v[6]));
-    eps_d = eps_abs + eps_rel * cinv * fmax(u[1], fmax(u[2], u[3]));
-    ad_pr = v[3] / (fmax(fmax(v[4], v[7]), fmax(v[5], v[7])) + 1e-10);
-    ad_dr = u[4] / (fmax(u[5], fmax(u[6], u[7])) + 1e-10);
-  };
-  PROF_BEGIN(po4);
-  for (int it = 1; !stopped && it <= max_iter; it++) {
-    iters = it;
-    // (1) right-hand side and the reduced solve
-    for (int r = TID; r < nc; r += NT) o.w[r] = o.E[r] * (rho * o.z[r] - o.y[r]);
-    gt_mul(c, o.w, o.tmp);
-    for (int j = TID; j < n; j += NT) {
-      const double dj = o.Dv[j], aI = o.EI[j] * dj, xj = o.x[j];
-      o.rhs[j] = sigma * xj - cc * dj * o.q[j] + dj * o.tmp[j] + aI * rho_I(j, rho) * (aI * xj);
-    }
-    dev_p_mul(c, o.rhs, o.xt, 1.0);
-    // (2) zt = As xt, relaxation, projection, dual update
-    osqp_gs_mul(o, o.xt, o.w);
-    for (int r = TID; r < nc; r += NT) {
-      const double er = o.E[r], zp = o.z[r], yr = o.y[r];
-      const double zr = alpha * o.w[r] + (1.0 - alpha) * zp;
-      const double us = er * fmin(-o.g[r], OSQP_INFTY), ls = -OSQP_INFTY * er;
-      const double zn = fmin(fmax(zr + yr / rho, ls), us);
-      const double dyr = rho * (zr - zn);
-      o.z[r] = zn; o.dy[r] = dyr; o.y[r] = yr + dyr;
-    }
-    for (int j = TID; j < n; j += NT) { const double xp = o.x[j], xn = alpha * o.xt[j] + (1.0 - alpha) * xp; o.x[j] = xn; o.dx[j] = xn - xp; }
-    __syncthreads();
-    if (it % check_every != 0) continue;
-    // ---- termination (section 3.4) every 25 iterations; the same products serve the rho adaptation (section 5.2)
-    PROF_BEGIN(po5);
-    // primal infeasibility certificate (uses delta y, which the residual products overwrite)
-    bool pinf = false;
-    {
-      double nrm = 0, lhs = 0;
-      for (int r = TID; r < nc; r += NT) {
-        const double er = o.E[r], us = er * fmin(-o.g[r], OSQP_INFTY), ls = -OSQP_INFTY * er;
-        const bool inf_u = us > OSQP_INFTY * OSQP_MIN_SCALING, inf_l = ls < -OSQP_INFTY * OSQP_MIN_SCALING;
-        double v = o.dy[r];
-        v = (inf_u && inf_l) ? 0.0 : (inf_u ? fmin(v, 0.0) : (inf_l ? fmax(v, 0.0) : v));
-        o.w[r] = v;
-        nrm = fmax(nrm, __builtin_fabs(er * v));
-        if (!inf_u) lhs += us * fmax(v, 0.0);
-        if (!inf_l) lhs += ls * fmin(v, 0.0);
-      }
-      nrm = block_max(nrm, o.red);
-      lhs = block_sum(lhs, o.red);
-      if (nrm > 1.0 / OSQP_INFTY && lhs < -eps_inf * nrm) {
-        osqp_gst_mul(c, o, o.w, o.w, o.xt);                          // As' dy; the test divides by D again
-        double mx = 0;
-        for (int j = TID; j < n; j += NT) mx = fmax(mx, __builtin_fabs(o.xt[j] / o.Dv[j]));
-        mx = block_max(mx, o.red);
-        pinf = mx < eps_inf * nrm;
-      }
-    }
-    residual_vectors();
-    residuals();
-    PROF_END(PH_O_CHECK, po5);
-    if (pri_res <= eps_p && dua_res <= eps_d) { status = OSQP_SOLVED; break; }
-    if (pinf) { status = OSQP_PRIMAL_INFEASIBLE; break; }
-    {
-      // dual infeasibility certificate
-      double nrm = 0, qdx = 0;
-      for (int j = TID; j < n; j += NT) { nrm = fmax(nrm, __builtin_fabs(o.Dv[j] * o.dx[j])); qdx += cc * o.Dv[j] * o.q[j] * o.dx[j]; }
-      nrm = block_max(nrm, o.red);
-      qdx = block_sum(qdx, o.red);
-      bool dinf = false;
-      if (nrm > 1.0 / OSQP_INFTY && qdx < -cc * eps_inf * nrm) {
-        osqp_gs_mul(o, o.dx, o.w);                                   // w = As dx; o.tmp = D dx
-        osqp_m_pass<false>(o.M, n, o.tmp, o.part, o.rhs);
-        double mx = 0;
-        for (int j = TID; j < n; j += NT) mx = fmax(mx, __builtin_fabs(cc * o.rhs[j]));      // |Dinv (Ps dx)| = |c M D dx|
-        mx = block_max(mx, o.red);
-        if (mx < cc * eps_inf * nrm) {
-          int viol = 0;
-          for (int r = TID; r < nc; r += NT) {
-            const double er = o.E[r], us = er * fmin(-o.g[r], OSQP_INFTY), ls = -OSQP_INFTY * er, adx = o.w[r] / er;
-            const bool ok_u = us > OSQP_INFTY * OSQP_MIN_SCALING || adx < eps_inf * nrm;
-            const bool ok_l = ls < -OSQP_INFTY * OSQP_MIN_SCALING || adx > -eps_inf * nrm;
-            viol |= !(ok_u && ok_l);
-          }
-          for (int j = TID; j < n; j += NT) {
-            const bool inf_b = o.EI[j] * OSQP_INFTY > OSQP_INFTY * OSQP_MIN_SCALING;
-            const double adx = o.Dv[j] * o.dx[j];
-            viol |= !((inf_b || adx < eps_inf * nrm) && (inf_b || adx > -eps_inf * nrm));
-          }
-          dinf = !__syncthreads_or(viol);
-        }
-      }
-      if (dinf) { status = OSQP_DUAL_INFEASIBLE; break; }
-    }
-    // rho adaptation (interval fixed at 25)
-    {
-      const double rho_new = fmin(fmax(rho * sqrt(ad_pr / (ad_dr + 1e-10)), OSQP_RHO_MIN), OSQP_RHO_MAX);
-      if (rho_new > rho * 5.0 || rho_new < rho / 5.0) {
-        rho = rho_new;
-        rho_updates++;
-        if (!build_kinv(rho)) { status = OSQP_NAN_DATA; break; }
-      }
-    }
-  }
-  PROF_END(PH_O_ADMM, po4);
-  PROF_COUNT(PH_O_ITERS, iters);
-  if (status == OSQP_MAX_ITER) {      // iteration limit: OSQP re-checks with 10x the tolerances ("solved inaccurate")
-    residual_vectors();
-    residuals();
-    if (pri_res <= 10.0 * eps_p && dua_res <= 10.0 * eps_d) status = OSQP_SOLVED_INACCURATE;
-  }
-  __syncthreads();
-  // ---- the ADMM iterate, unscaled, is the answer unless the polish improves on it
-  for (int j = TID; j < n; j += NT) du[j] = o.Dv[j] * o.x[j];
-  for (int r = TID; r < nc; r += NT) lhat[r] = cinv * o.E[r] * o.y[r];
+  osqp_build_tables(D, osqp_tabs());
+  return cc;
+}
+
+// Polish (section 4) of the ADMM point held in o.z / o.y (scaled), in unscaled variables (see the header).  On acceptance du / lhat are
+// overwritten with the polished point.  Returns 1 accepted, -1 rejected (or not attempted: more active rows than the T slot holds, a
+// pivot that was not positive); *na_out = active rows.
+template <int RPT>
+__device__ __noinline__ int osqp_polish(const Ctx& c, double cc, double pri_res, double dua_res, int* na_out) {
+  const DgProb& D = dg_prob;
+  const DgLds& L = D.L;
+  lptr lds = LP(0);
+  const int n = D.n, nc = D.nc;
+  const OsqpPtrs o = osqp_ptrs(c);
+  lptr du = lds + L.o_du, lhat = lds + L.o_lhat;
+  const int lane = TID & 63;
+  const bool w0 = TID < 64;
+  const double delta = 1e-6, cinv = 1.0 / cc;
   int polished = 0, na = 0;
-  if (status == OSQP_SOLVED) {
+  double Kr[RPT];
+  {
     // ---- polish (section 4).  Active rows in row order:  upper  (u - z) < y,  lower  (z - l) < -y  (l = -1e30 E: never)
     const QpPtrs q = qp_ptrs(c);
     lptr xs = lds + L.a_tail, nu = xs + ((n + 1) & ~1), e1 = nu + ((n + 1) & ~1), e2 = e1 + ((n + 1) & ~1), regd = e2 + ((n + 1) & ~1);
@@ -568,7 +452,7 @@ __device__ __noinline__ int dev_qp_osqp(const Ctx& c) {
       for (int j = TID; j < n; j += NT) o.tmp[j] = delta / (o.Dv[j] * o.Dv[j]);
       __syncthreads();
       PROF_BEGIN(po6);
-      ok = dev_osqp_inverse(c, o, nullptr, o.tmp, cc, 0.0);
+      ok = osqp_inverse_regs<RPT>(c, o.M, o.W, nullptr, o.tmp, cc, 0.0, LP(L.a_sw), Kr, true);
       PROF_END(PH_O_PINV, po6);
     }
     PROF_COUNT(PH_O_NACT, na);
@@ -666,6 +550,340 @@ __device__ __noinline__ int dev_qp_osqp(const Ctx& c) {
     } else polished = -1;
     PROF_END(PH_O_PSOLVE, po8);
   }
+  *na_out = na;
+  return polished;
+}
+
+// out_i = sum_j P_ij t_j for the packed symmetric P (LDS, or the scratch in the big layout): dev_p_mul_t without its leading barrier; the
+// caller supplies the final phase (what to do with row i's sum)
+template <class PT, class F>
+__device__ inline void osqp_pmul_fused(PT Pp, clptr t, lptr part, int n, F&& fin) {
+  constexpr int NSEG = NT / 128;
+  const int i = TID & 127, sg = TID >> 7;
+  if (i < n) {
+    const int len = (n + NSEG - 1) / NSEG;
+    const int j0 = sg * len, j1 = (j0 + len < n) ? j0 + len : n;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    const int split = (i + 1 < j1) ? ((i + 1 > j0) ? i + 1 : j0) : j1;
+    const PT row = Pp + i * (i + 1) / 2;
+    int j = j0;
+    for (; j + 3 < split; j += 4) { a0 += row[j] * t[j]; a1 += row[j + 1] * t[j + 1]; a2 += row[j + 2] * t[j + 2]; a3 += row[j + 3] * t[j + 3]; }
+    for (; j < split; j++) a0 += row[j] * t[j];
+    for (; j + 3 < j1; j += 4) {
+      a0 += Pp[j * (j + 1) / 2 + i] * t[j]; a1 += Pp[(j + 1) * (j + 2) / 2 + i] * t[j + 1];
+      a2 += Pp[(j + 2) * (j + 3) / 2 + i] * t[j + 2]; a3 += Pp[(j + 3) * (j + 4) / 2 + i] * t[j + 3];
+    }
+    for (; j < j1; j++) a0 += Pp[j * (j + 1) / 2 + i] * t[j];
+    part[sg * n + i] = (a0 + a1) + (a2 + a3);
+  }
+  __syncthreads();
+  if (TID < n) {
+    double s = 0;
+#pragma unroll
+    for (int g = 0; g < NSEG; g++) s += part[g * n + TID];
+    fin(TID, s);
+  }
+  __syncthreads();
+}
+
+#define DG_OSQP_CHK 40    // scal slots 40..46: what osqp_check hands back -- pri_res, dua_res, eps_pri, eps_dua, the two ratios of the rho rule, flags (1 primal, 2 dual infeasible)
+__device__ inline double osqp_rho_I(const OsqpPtrs& o, int j, double rho) { return o.EI[j] * OSQP_INFTY > OSQP_INFTY * OSQP_MIN_SCALING ? OSQP_RHO_MIN : rho; }   // "loose" identity row: both bounds beyond 1e26 after scaling
+
+// K(rho)^-1 = (Ps + sigma I + rho_I (E_I D)^2 + rho W)^-1 into the packed-P slot.  Its own function (as are the iteration, the check and
+// the polish below): each piece gets a register allocation of its own -- inlined into one function the sweep's 150 live registers
+// pushed the iteration's addresses into scratch, a memory round trip per barrier phase.
+template <int RPT>
+__device__ __noinline__ bool osqp_build_kinv(const Ctx& c, double rho, double cc) {
+  const DgProb& D = dg_prob;
+  const OsqpPtrs o = osqp_ptrs(c);
+  __syncthreads();
+  for (int j = TID; j < D.n; j += NT) { const double aI = o.EI[j] * o.Dv[j]; o.tmp[j] = 1e-6 + osqp_rho_I(o, j, rho) * aI * aI; }
+  __syncthreads();
+  PROF_BEGIN(po3);
+  double Br[RPT];
+  const bool ok = osqp_inverse_regs<RPT>(c, o.M, o.W, o.Dv, o.tmp, cc, rho, LP(D.L.a_sw), Br, true);
+  PROF_END(PH_O_KINV, po3);
+  return ok;
+}
+
+// One ADMM iteration (Algorithm 1 with relaxation alpha = 1.6) on the state in LDS: x, z, y, w = E (rho z - y); leaves delta x, delta y.
+__device__ __noinline__ void osqp_iterate(const Ctx& c, double rho, double cc) {
+  const DgProb& D = dg_prob;
+  const int n = D.n, nc = D.nc;
+  const OsqpPtrs o = osqp_ptrs(c);
+  const OsqpTabs tabs = osqp_tabs();
+  const double sigma = 1e-6, alpha = 1.6, irho = 1.0 / rho;
+  auto rho_I = [&](int j, double r) { return osqp_rho_I(o, j, r); };
+    // One ADMM iteration in six barrier phases.  Carried between iterations: w = E (rho z - y)  (rebuilt after a check, which uses w).
+    // (1) yd_d = w[r+] - w[r-]: what every dense gradient contributes to G' w
+    PROF_BEGIN(pa1);
+    for (int d = TID; d < D.ndense; d += NT) {
+      const DgDense dd = ld_dense(d);
+      o.yd[d] = (dd.r_pos >= 0 ? o.w[dd.r_pos] : 0.0) - (dd.r_neg >= 0 ? o.w[dd.r_neg] : 0.0);
+    }
+    __syncthreads();
+    // (2) rhs = sigma x - qs + D G' w + a_I rho_I (a_I x): four lanes per column over the transposed index table
+    for (int it4 = TID; it4 < 4 * n; it4 += NT) {
+      const int col = it4 >> 2, part = it4 & 3;
+      double s0 = 0, s1 = 0;
+      if (part == 0) {
+        const __attribute__((address_space(3))) short* cr = tabs.colrows + 8 * col;
+        const int r0 = cr[0], r1 = cr[1], r2 = cr[2], r3 = cr[3], r4 = cr[4], r5 = cr[5];
+        const double w0 = o.w[r0 >= 0 ? r0 : 0], w1 = o.w[r1 >= 0 ? r1 : 0], w2 = o.w[r2 >= 0 ? r2 : 0], w3 = o.w[r3 >= 0 ? r3 : 0], w4 = o.w[r4 >= 0 ? r4 : 0], w5 = o.w[r5 >= 0 ? r5 : 0];
+        s0 = ((r0 >= 0 ? w0 : 0.0) - (r1 >= 0 ? w1 : 0.0)) + ((r2 >= 0 ? w2 : 0.0) - (r3 >= 0 ? w3 : 0.0));
+        s1 = (r5 >= 0 ? w5 : 0.0) - (r4 >= 0 ? w4 : 0.0);
+      }
+      const int k1 = tabs.cstart[col + 1];
+      int k = tabs.cstart[col] + part;
+      for (; k + 4 < k1; k += 8) {
+        const unsigned int pa = tabs.pairT[k], pb = tabs.pairT[k + 4];
+        const double ga = o.gd[pa & 0xffffu], ya = o.yd[pa >> 16], gb = o.gd[pb & 0xffffu], yb = o.yd[pb >> 16];
+        s0 = __builtin_fma(ya, ga, s0); s1 = __builtin_fma(yb, gb, s1);
+      }
+      if (k < k1) { const unsigned int pa = tabs.pairT[k]; s0 = __builtin_fma(o.yd[pa >> 16], o.gd[pa & 0xffffu], s0); }
+      double sm = s0 + s1;
+      sm += dpp_f64<0xB1>(sm);
+      sm += dpp_f64<0x4E>(sm);
+      if (part == 0) {
+        const double dj = o.Dv[col], aI = o.EI[col] * dj, xj = o.x[col];
+        o.rhs[col] = sigma * xj - cc * dj * o.q[col] + dj * sm + aI * rho_I(col, rho) * (aI * xj);
+      }
+    }
+    __syncthreads();
+    PROF_END(PH_O_GT, pa1);
+    // (3, 4) xt = K^-1 rhs; relaxation of x; tmp = D xt for the product with G
+    PROF_BEGIN(pa2);
+    {
+      auto fin = [&](int i, double xt) {
+        const double xp = o.x[i], xn = alpha * xt + (1.0 - alpha) * xp;
+        o.x[i] = xn; o.dx[i] = xn - xp; o.tmp[i] = o.Dv[i] * xt;
+      };
+      if (D.big) osqp_pmul_fused<cgptr>(c.ws + D.ws_P, o.rhs, o.part, n, fin);
+      else osqp_pmul_fused<clptr>(LP(D.L.g_Bp), o.rhs, o.part, n, fin);
+    }
+    PROF_END(PH_O_PMUL, pa2);
+    // (5) chunk sums of the dense gradients' dots with D xt
+    PROF_BEGIN(pa3);
+    for (int t = TID; t < D.ntask; t += NT) {
+      const DgTask T = ld_task(t);
+      clptr p = o.gd + T.p0;
+      clptr wv = o.tmp + T.v0;
+      double pv[DG_CHUNK], wq[DG_CHUNK];
+#pragma unroll
+      for (int i = 0; i < DG_CHUNK; i++) { pv[i] = p[i]; wq[i] = wv[i]; }
+      double sa[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < DG_CHUNK; i++) sa[i & 3] += i < T.len ? pv[i] * wq[i] : 0.0;
+      o.dpart[t] = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+    }
+    __syncthreads();
+    PROF_END(PH_O_GS, pa3);
+    // (6) zt = E G (D xt) row by row, relaxation, projection onto [l, u], dual update, next iteration's w
+    PROF_BEGIN(pa4);
+    for (int r = TID; r < nc; r += NT) {
+      const DgRow R = ld_row(r);
+      double zt;
+      if (R.dense >= 0) {
+        const DgDense dd = ld_dense(R.dense);
+        const int ts = dd.t0lo + 256 * dd.t0hi;
+        double sd = 0;
+        for (int i = 0; i < dd.nt; i++) sd += o.dpart[ts + i];
+        zt = (double)R.sgn * sd;
+      } else {
+        const bool rate = R.type == DG_R_RATE_UB || R.type == DG_R_RATE_LB, pos = R.type == DG_R_IN_UB || R.type == DG_R_RATE_UB;
+        const int c1 = am_col(D, R.a, R.k, R.idx);
+        const bool has0 = rate && R.k > 0;
+        const double v1 = o.tmp[c1], v0 = o.tmp[has0 ? c1 - DGSQP_NUA : c1];
+        zt = (pos ? 1.0 : -1.0) * v1 + (has0 ? (pos ? -1.0 : 1.0) : 0.0) * v0;
+      }
+      const double er = o.E[r], zp = o.z[r], yr = o.y[r];
+      const double zr = alpha * (er * zt) + (1.0 - alpha) * zp;
+      const double us = er * fmin(-o.g[r], OSQP_INFTY), ls = -OSQP_INFTY * er;
+      const double zn = fmin(fmax(__builtin_fma(yr, irho, zr), ls), us);        // (y / rho as a multiplication by 1 / rho: a 20-instruction IEEE division per row otherwise)
+      const double dyr = rho * (zr - zn), yn = yr + dyr;
+      o.z[r] = zn; o.dy[r] = dyr; o.y[r] = yn;
+      o.w[r] = er * (rho * zn - yn);
+    }
+    __syncthreads();
+    PROF_END(PH_O_UPD, pa4);
+}
+
+// The termination tests of a check iteration (section 3.4) and the ratios of the rho rule (5.2); results in scal[DG_OSQP_CHK ..].
+__device__ __noinline__ void osqp_check(const Ctx& c, double cc) {
+  const DgProb& D = dg_prob;
+  const int n = D.n, nc = D.nc;
+  const OsqpPtrs o = osqp_ptrs(c);
+  const double eps_abs = 1e-3, eps_rel = 1e-3, eps_inf = 1e-4, cinv = 1.0 / cc;
+  PROF_BEGIN(po5);
+    // primal infeasibility certificate (uses delta y, which the residual products overwrite)
+    bool pinf = false;
+    {
+      double nrm = 0, lhs = 0;
+      for (int r = TID; r < nc; r += NT) {
+        const double er = o.E[r], us = er * fmin(-o.g[r], OSQP_INFTY), ls = -OSQP_INFTY * er;
+        const bool inf_u = us > OSQP_INFTY * OSQP_MIN_SCALING, inf_l = ls < -OSQP_INFTY * OSQP_MIN_SCALING;
+        double v = o.dy[r];
+        v = (inf_u && inf_l) ? 0.0 : (inf_u ? fmin(v, 0.0) : (inf_l ? fmax(v, 0.0) : v));
+        o.w[r] = v;
+        nrm = fmax(nrm, __builtin_fabs(er * v));
+        if (!inf_u) lhs += us * fmax(v, 0.0);
+        if (!inf_l) lhs += ls * fmin(v, 0.0);
+      }
+      nrm = block_max(nrm, o.red);
+      lhs = block_sum(lhs, o.red);
+      if (nrm > 1.0 / OSQP_INFTY && lhs < -eps_inf * nrm) {
+        osqp_gst_mul(c, o, o.w, o.w, o.xt);                          // As' dy; the test divides by D again
+        double mx = 0;
+        for (int j = TID; j < n; j += NT) mx = fmax(mx, __builtin_fabs(o.xt[j] / o.Dv[j]));
+        mx = block_max(mx, o.red);
+        pinf = mx < eps_inf * nrm;
+      }
+    }
+    // Ax (G rows) -> w, Px -> rhs, A'y -> xt
+    osqp_gs_mul(o, o.x, o.w);
+    osqp_m_pass<false>(o.M, n, o.tmp, o.part, o.rhs);               // (o.tmp = D x after osqp_gs_mul)
+    for (int j = TID; j < n; j += NT) o.rhs[j] *= cc * o.Dv[j];
+    __syncthreads();
+    osqp_gst_mul(c, o, o.y, o.dy, o.xt);                            // (dy is free here: its last use was the infeasibility test)
+    double pri_res, dua_res, eps_p, eps_d, ad_pr, ad_dr;
+    {
+      double v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, u[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int r = TID; r < nc; r += NT) {
+        const double ei = 1.0 / o.E[r], ax = o.w[r], zz = o.z[r];
+        v[0] = fmax(v[0], __builtin_fabs(ei * (ax - zz))); v[1] = fmax(v[1], __builtin_fabs(ei * zz)); v[2] = fmax(v[2], __builtin_fabs(ei * ax));
+        v[3] = fmax(v[3], __builtin_fabs(ax - zz)); v[4] = fmax(v[4], __builtin_fabs(zz)); v[5] = fmax(v[5], __builtin_fabs(ax));
+      }
+      for (int j = TID; j < n; j += NT) {
+        const double di = 1.0 / o.Dv[j], px = o.rhs[j], aty = o.xt[j], qs = cc * o.Dv[j] * o.q[j];
+        v[6] = fmax(v[6], __builtin_fabs(o.Dv[j] * o.x[j]));                    // identity rows: |z / E| = |Ax / E| = |D x|
+        v[7] = fmax(v[7], __builtin_fabs(o.EI[j] * o.Dv[j] * o.x[j]));          // ... and |z| = |Ax| scaled
+        u[0] = fmax(u[0], __builtin_fabs(di * (px + qs + aty))); u[1] = fmax(u[1], __builtin_fabs(di * qs)); u[2] = fmax(u[2], __builtin_fabs(di * aty));
+        u[3] = fmax(u[3], __builtin_fabs(di * px)); u[4] = fmax(u[4], __builtin_fabs(px + qs + aty)); u[5] = fmax(u[5], __builtin_fabs(qs));
+        u[6] = fmax(u[6], __builtin_fabs(aty)); u[7] = fmax(u[7], __builtin_fabs(px));
+      }
+      block_max8(v, o.red);
+      block_max8(u, o.red);
+      pri_res = v[0];
+      dua_res = cinv * u[0];
+      eps_p = eps_abs + eps_rel * fmax(fmax(v[1], v[6]), fmax(v[2], v[6]));
+      eps_d = eps_abs + eps_rel * cinv * fmax(u[1], fmax(u[2], u[3]));
+      ad_pr = v[3] / (fmax(fmax(v[4], v[7]), fmax(v[5], v[7])) + 1e-10);
+      ad_dr = u[4] / (fmax(u[5], fmax(u[6], u[7])) + 1e-10);
+    }
+    bool dinf = false;
+    if (!(pri_res <= eps_p && dua_res <= eps_d) && !pinf)
+    {
+      // dual infeasibility certificate
+      double nrm = 0, qdx = 0;
+      for (int j = TID; j < n; j += NT) { nrm = fmax(nrm, __builtin_fabs(o.Dv[j] * o.dx[j])); qdx += cc * o.Dv[j] * o.q[j] * o.dx[j]; }
+      nrm = block_max(nrm, o.red);
+      qdx = block_sum(qdx, o.red);
+      if (nrm > 1.0 / OSQP_INFTY && qdx < -cc * eps_inf * nrm) {
+        osqp_gs_mul(o, o.dx, o.w);                                   // w = As dx; o.tmp = D dx
+        osqp_m_pass<false>(o.M, n, o.tmp, o.part, o.rhs);
+        double mx = 0;
+        for (int j = TID; j < n; j += NT) mx = fmax(mx, __builtin_fabs(cc * o.rhs[j]));      // |Dinv (Ps dx)| = |c M D dx|
+        mx = block_max(mx, o.red);
+        if (mx < cc * eps_inf * nrm) {
+          int viol = 0;
+          for (int r = TID; r < nc; r += NT) {
+            const double er = o.E[r], us = er * fmin(-o.g[r], OSQP_INFTY), ls = -OSQP_INFTY * er, adx = o.w[r] / er;
+            const bool ok_u = us > OSQP_INFTY * OSQP_MIN_SCALING || adx < eps_inf * nrm;
+            const bool ok_l = ls < -OSQP_INFTY * OSQP_MIN_SCALING || adx > -eps_inf * nrm;
+            viol |= !(ok_u && ok_l);
+          }
+          for (int j = TID; j < n; j += NT) {
+            const bool inf_b = o.EI[j] * OSQP_INFTY > OSQP_INFTY * OSQP_MIN_SCALING;
+            const double adx = o.Dv[j] * o.dx[j];
+            viol |= !((inf_b || adx < eps_inf * nrm) && (inf_b || adx > -eps_inf * nrm));
+          }
+          dinf = !__syncthreads_or(viol);
+        }
+      }
+    }
+    __syncthreads();
+    if (TID == 0) {
+      o.scal[DG_OSQP_CHK] = pri_res; o.scal[DG_OSQP_CHK + 1] = dua_res; o.scal[DG_OSQP_CHK + 2] = eps_p; o.scal[DG_OSQP_CHK + 3] = eps_d;
+      o.scal[DG_OSQP_CHK + 4] = ad_pr; o.scal[DG_OSQP_CHK + 5] = ad_dr; o.scal[DG_OSQP_CHK + 6] = (pinf ? 1.0 : 0.0) + (dinf ? 2.0 : 0.0);
+    }
+    __syncthreads();
+    PROF_END(PH_O_CHECK, po5);
+}
+
+template <int RPT>
+__device__ __noinline__ int dev_qp_osqp_t(const Ctx& c) {
+  const DgProb& D = dg_prob;
+  const DgLds& L = D.L;
+  lptr lds = LP(0);
+  const int n = D.n, nc = D.nc;
+  const OsqpPtrs o = osqp_ptrs(c);
+  lptr du = lds + L.o_du, lhat = lds + L.o_lhat;
+  const int max_iter = 4000, check_every = 25;
+  __syncthreads();
+  PROF_BEGIN(pt_qp);
+  if (TID == 0) { o.scal[DG_QP_NPREV] = 0.0; o.scal[DG_XVALID] = 0.0; }
+  // ---- setup: finite data, Ruiz equilibration, W = Gs' Gs, index tables
+  const double cc = osqp_setup(c);
+  if (cc != cc) {        // non-finite data: the conic plugin returns NaN
+    if (TID == 0) { o.scal[DG_OSQP_INFO] = OSQP_NAN_DATA; o.scal[DG_OSQP_INFO + 1] = 0; o.scal[DG_OSQP_INFO + 2] = 0; }
+    __syncthreads();
+    return 1;
+  }
+  const double cinv = 1.0 / cc;
+  double rho = 0.1;
+  int rho_updates = 0;
+  for (int j = TID; j < n; j += NT) { o.x[j] = 0.0; o.dx[j] = 0.0; }
+  for (int r = TID; r < nc; r += NT) { o.z[r] = 0.0; o.y[r] = 0.0; o.dy[r] = 0.0; o.w[r] = 0.0; }
+  __syncthreads();
+  // The G rows have  l = -inf -> -1e30 E_r,  u = E_r min(-g_r, 1e30):  never equalities (rho_vec = rho on all of them), never "loose"
+  // unless -g_r >= 1e26 / E_r (then OSQP gives the row rho_min; not reproduced: no game produces such a row)
+  int status = OSQP_MAX_ITER, iters = 0;
+  double pri_res = INFINITY, dua_res = INFINITY, eps_p = 0, eps_d = 0;
+  bool need_kinv = true;
+  PROF_BEGIN(po4);
+  static_assert(4000 % 25 == 0, "the iteration limit falls on a termination check");
+  for (int it = 1; it <= max_iter; it++) {
+    if (need_kinv) {      // first iteration, or rho was changed by the previous check
+      need_kinv = false;
+      if (!osqp_build_kinv<RPT>(c, rho, cc)) { status = OSQP_NAN_DATA; break; }
+      // (the sweep's column buffers lie over delta y and w)
+      for (int r = TID; r < nc; r += NT) { o.dy[r] = 0.0; o.w[r] = o.E[r] * (rho * o.z[r] - o.y[r]); }
+      __syncthreads();
+    }
+    iters = it;
+    osqp_iterate(c, rho, cc);
+    if (it % check_every != 0) continue;
+    // ---- termination (section 3.4) every 25 iterations; the same products serve the rho adaptation (section 5.2)
+    osqp_check(c, cc);
+    pri_res = o.scal[DG_OSQP_CHK]; dua_res = o.scal[DG_OSQP_CHK + 1]; eps_p = o.scal[DG_OSQP_CHK + 2]; eps_d = o.scal[DG_OSQP_CHK + 3];
+    const double ad_pr = o.scal[DG_OSQP_CHK + 4], ad_dr = o.scal[DG_OSQP_CHK + 5];
+    const int flags = (int)o.scal[DG_OSQP_CHK + 6];
+    if (pri_res <= eps_p && dua_res <= eps_d) { status = OSQP_SOLVED; break; }
+    if (flags & 1) { status = OSQP_PRIMAL_INFEASIBLE; break; }
+    if (flags & 2) { status = OSQP_DUAL_INFEASIBLE; break; }
+    // rho adaptation (interval fixed at 25)
+    {
+      const double rho_new = fmin(fmax(rho * sqrt(ad_pr / (ad_dr + 1e-10)), OSQP_RHO_MIN), OSQP_RHO_MAX);
+      if (rho_new > rho * 5.0 || rho_new < rho / 5.0) {
+        rho = rho_new;
+        rho_updates++;
+        need_kinv = true;
+      }
+    }
+    // (the check used w; the next iteration needs w = E (rho z - y), with the rho just chosen)
+    for (int r = TID; r < nc; r += NT) o.w[r] = o.E[r] * (rho * o.z[r] - o.y[r]);
+    __syncthreads();
+  }
+  PROF_END(PH_O_ADMM, po4);
+  PROF_COUNT(PH_O_ITERS, iters);
+  // iteration limit: OSQP re-checks with 10x the tolerances ("solved inaccurate"); iteration 4000 is a check iteration, its residuals are at hand
+  if (status == OSQP_MAX_ITER && iters == max_iter && pri_res <= 10.0 * eps_p && dua_res <= 10.0 * eps_d) status = OSQP_SOLVED_INACCURATE;
+  __syncthreads();
+  // ---- the ADMM iterate, unscaled, is the answer unless the polish improves on it
+  for (int j = TID; j < n; j += NT) du[j] = o.Dv[j] * o.x[j];
+  for (int r = TID; r < nc; r += NT) lhat[r] = cinv * o.E[r] * o.y[r];
+  int polished = 0, na = 0;
+  if (status == OSQP_SOLVED) polished = osqp_polish<RPT>(c, cc, pri_res, dua_res, &na);
   __syncthreads();
   if (TID == 0) {
     o.scal[DG_OSQP_INFO] = (double)status; o.scal[DG_OSQP_INFO + 1] = (double)iters; o.scal[DG_OSQP_INFO + 2] = (double)polished; o.scal[DG_OSQP_INFO + 3] = rho;
@@ -678,4 +896,11 @@ __device__ __noinline__ int dev_qp_osqp(const Ctx& c) {
   nonfinite = __syncthreads_or(nonfinite);
   PROF_END(PH_QP, pt_qp);
   return (nonfinite || status == OSQP_PRIMAL_INFEASIBLE || status == OSQP_DUAL_INFEASIBLE || status == OSQP_NAN_DATA) ? 1 : 0;
+}
+__device__ inline int dev_qp_osqp(const Ctx& c) {
+  const int n = dg_prob.n;
+  if (n <= 32) return dev_qp_osqp_t<32 / DG_NH>(c);
+  if (n <= 64) return dev_qp_osqp_t<64 / DG_NH>(c);
+  if (n <= 100) return dev_qp_osqp_t<100 / DG_NH>(c);
+  return dev_qp_osqp_t<128 / DG_NH>(c);
 }

@@ -145,48 +145,98 @@ __device__ inline void twisted_eigvec(double dA, double dB, double eA, double eB
   zA *= nr; zB *= nr;
 }
 // Symmetric Gauss-Jordan sweep of an SPD matrix held in registers (thread (jc = TID & 127, hf = TID >> 7) owns column jc, rows
-// hf + NH r): after all n pivots the slice holds -A^-1 (SPD => no pivoting).  tws: 2 (NH RPT + 4) doubles of LDS for the
-// published pivot column (double buffered).  One barrier per pivot.
+// hf + NH r): after all n pivots the slice holds -A^-1 (SPD => no pivoting).  TWO pivots per barrier: with the columns k and k + 1 of
+// the current matrix published, the sweep of pivot k followed by the sweep of pivot k + 1 is
+//   d1 = a_kk,  r1_j = a_kj / d1,  c'_i = a_i,k+1 - a_ik r1_{k+1}  (column k + 1 after the first sweep),  d2 = c'_{k+1},  r2_j = c'_j / d2,
+//   a_ij <- a_ij - a_ik r1_j - c'_i r2_j                                                  (i, j outside {k, k + 1})
+//   column k: a_ik / d1 - c'_i r2_k,   column k + 1: c'_i / d2,   row k: r1_j - r1_{k+1} r2_j,   row k + 1: r2_j,
+//   [k][k] = -1/d1 - r1_{k+1} r2_k,   [k][k+1] = [k+1][k] = r2_k = r1_{k+1} / d2,   [k+1][k+1] = -1/d2
+// -- every thread derives the scalars itself from the two published columns, so a step is one round of LDS reads, two multiply-adds per
+// entry and one barrier (the one-pivot version paid the read latency and the barrier per pivot: 2.5 kcycles each, 100 of them).
+// tws: 4 (NH RPT + 4) doubles of LDS (two column pairs, double buffered).
 template <int RPT>
 __device__ __forceinline__ void spd_sweep_regs(double (&Br)[RPT], lptr tws, int n) {
-  constexpr int NH = DG_NH;
+  constexpr int NH = DG_NH, CS = NH * RPT + 4;
   const int jc = TID & 127, hf = TID >> 7;
   const bool colok = jc < n;
-  lptr colA = tws, colB = tws + (NH * RPT + 4);  // pivot column, double buffered; padding rows stay zero
-  for (int i = TID; i < 2 * (NH * RPT + 4); i += NT) colA[i] = 0.0;
+  for (int i = TID; i < 4 * CS; i += NT) tws[i] = 0.0;    // padding rows stay zero
   __syncthreads();
-  if (jc == 0) {
+  if (jc < 2) {
 #pragma unroll
-    for (int r = 0; r < RPT; r++) colA[hf + NH * r] = Br[r];
+    for (int r = 0; r < RPT; r++) tws[jc * CS + hf + NH * r] = Br[r];
   }
   __syncthreads();
-  for (int k = 0; k < n; k++) {
-    clptr colk = (k & 1) ? colB : colA;
-    lptr coln = (k & 1) ? colA : colB;
+  int k = 0;
+  for (; k + 1 < n; k += 2) {
+    clptr c1 = tws + ((k >> 1) & 1) * 2 * CS, c2 = c1 + CS;
+    lptr nx = tws + (((k >> 1) + 1) & 1) * 2 * CS;
+    const double d1 = c1[k], a12 = c1[k + 1], a22 = c2[k + 1];
+    const double ck = colok ? c1[jc] : 0.0, ck1 = colok ? c2[jc] : 0.0;
+    const double id1 = fast_rcp(d1);
+    const double r1k1 = a12 * id1;
+    const double id2 = fast_rcp(__builtin_fma(-a12, r1k1, a22));
+    const double r2k = r1k1 * id2;
+    const double r1 = ck * id1;
+    const double r2 = __builtin_fma(-ck, r1k1, ck1) * id2;
+    // the update in two halves of the rows: half as many column entries live at a time (the slice itself fills a third of the registers)
+    constexpr int RH = (RPT + 1) / 2;
+#pragma unroll
+    for (int h0 = 0; h0 < RPT; h0 += RH) {
+      double ci1[RH], ci2[RH];
+#pragma unroll
+      for (int r = 0; r < RH; r++) { const int rr = h0 + r < RPT ? h0 + r : RPT - 1; ci1[r] = c1[hf + NH * rr]; ci2[r] = c2[hf + NH * rr]; }
+#pragma unroll
+      for (int r = 0; r < RH; r++) ci2[r] = __builtin_fma(-ci1[r], r1k1, ci2[r]);        // c'_i (rows k, k + 1 are overwritten below)
+      if (jc != k && jc != k + 1) {
+#pragma unroll
+        for (int r = 0; r < RH; r++) if (h0 + r < RPT) Br[h0 + r] = __builtin_fma(-ci2[r], r2, __builtin_fma(-ci1[r], r1, Br[h0 + r]));
+      } else if (jc == k) {
+#pragma unroll
+        for (int r = 0; r < RH; r++) if (h0 + r < RPT) Br[h0 + r] = __builtin_fma(-ci2[r], r2k, ci1[r] * id1);
+      } else {
+#pragma unroll
+        for (int r = 0; r < RH; r++) if (h0 + r < RPT) Br[h0 + r] = ci2[r] * id2;
+      }
+    }
+    if (hf == (k & (NH - 1))) {            // row k: one register (index k / NH, wave-uniform) of these threads
+      const int rs = k / NH;
+      const double v = jc == k ? __builtin_fma(-r1k1, r2k, -id1) : (jc == k + 1 ? r2k : __builtin_fma(-r1k1, r2, r1));
+#pragma unroll
+      for (int r = 0; r < RPT; r++) Br[r] = (r == rs) ? v : Br[r];
+    }
+    if (hf == ((k + 1) & (NH - 1))) {      // row k + 1
+      const int rs = (k + 1) / NH;
+      const double v = jc == k ? r2k : (jc == k + 1 ? -id2 : r2);
+#pragma unroll
+      for (int r = 0; r < RPT; r++) Br[r] = (r == rs) ? v : Br[r];
+    }
+    if (jc == k + 2 || jc == k + 3) {      // the next pair of pivot columns is final as soon as this update is done
+      lptr dst = nx + (jc - k - 2) * CS;
+#pragma unroll
+      for (int r = 0; r < RPT; r++) dst[hf + NH * r] = Br[r];
+    }
+    __syncthreads();
+  }
+  if (k < n) {                             // odd n: the last pivot alone (its column is the first of the current pair)
+    clptr colk = tws + ((k >> 1) & 1) * 2 * CS;
     const double dinv = fast_rcp(colk[k]);
     const double rj = colok ? colk[jc] * dinv : 0.0;
     const bool pc = jc == k;
-    const double rowv = pc ? -dinv : rj;   // new row k:  a_kj/d, pivot -1/d
-    // Straight-line update (selects on registers only, every LDS read unconditional so they can be batched):
-    //   general  a_ij - a_ik a_kj/d ;  column k  a_ik/d ;  row k  a_kj/d ;  pivot -1/d
     double ci[RPT];
 #pragma unroll
     for (int r = 0; r < RPT; r++) ci[r] = colk[hf + NH * r];
     if (!pc) {
 #pragma unroll
-      for (int r = 0; r < RPT; r++) Br[r] = fma(-ci[r], rj, Br[r]);      // general entry
+      for (int r = 0; r < RPT; r++) Br[r] = fma(-ci[r], rj, Br[r]);
     } else {
 #pragma unroll
-      for (int r = 0; r < RPT; r++) Br[r] = ci[r] * dinv;                // pivot column (4 threads per step)
+      for (int r = 0; r < RPT; r++) Br[r] = ci[r] * dinv;
     }
-    if (hf == (k & (NH - 1))) {      // pivot row: one register (index k / NH, wave-uniform) of these threads
+    if (hf == (k & (NH - 1))) {
       const int rs = k / NH;
+      const double rowv = pc ? -dinv : rj;
 #pragma unroll
       for (int r = 0; r < RPT; r++) Br[r] = (r == rs) ? rowv : Br[r];
-    }
-    if (jc == k + 1) {   // the next pivot column is final as soon as this update is done
-#pragma unroll
-      for (int r = 0; r < RPT; r++) coln[hf + NH * r] = Br[r];
     }
     __syncthreads();
   }
