@@ -23,12 +23,14 @@ for name in names:
         res = s.solve_batch(ref['x0'], ref['u_ws'])
         dt = time.time() - t
         st = np.where(res['status'] == 4, 4, res['status'])
-        ident = (st == ref['status']) & (res['num_iters'] == ref['num_iters']) & (res['qp_solves'] == ref['qp_solves'])
+        ident = ((st == ref['status']) & (res['num_iters'] == ref['num_iters']) & (res['qp_solves'] == ref['qp_solves'])) | ((st == 4) & (ref['status'] == 4))   # (a solve that raises in the reference has no counts)
+        stable = ref['stable']
+        rest = ident[~stable].mean() if (~stable).any() else float('nan')
         cd, cr = res['status'] <= 1, ref['status'] <= 1
         idc = ident & cd & cr
         err = np.array([np.abs(res['u'][b] - ref['u'][b]).max() / max(1.0, np.abs(ref['u'][b]).max()) for b in np.nonzero(idc)[0]])
         errl = np.array([np.abs(res['l'][b] - ref['l'][b]).max() / max(1.0, np.abs(ref['l'][b]).max()) for b in np.nonzero(idc)[0]])
-        print(f'{name:16s} qp_method {method:10s}: {len(st)} scenarios in {dt:6.2f} s | identical (status, iters, QPs) {ident.mean():.3f} | same converged flag {np.mean(cd == cr):.3f} | '
+        print(f'{name:16s} qp_method {method:10s}: {len(st)} scenarios in {dt:6.2f} s | identical (status, iters, QPs) {ident.mean():.3f}, on the {int(stable.sum())} scenarios the numpy loop itself reproduces under 1e-13 perturbations {ident[stable].mean():.3f}, on the other {int((~stable).sum())} {rest:.3f} | same converged flag {np.mean(cd == cr):.3f} | '
               f'converged device {cd.mean():.3f} numpy+OSQP {cr.mean():.3f} | mean iters (commonly converged) {res["num_iters"][cd & cr].mean():.2f} vs {ref["num_iters"][cd & cr].mean():.2f} | '
               f'identical converged: u median {np.median(err) if len(err) else float("nan"):.1e} max {err.max() if len(err) else float("nan"):.1e} (> 1e-5: {int((err > 1e-5).sum())}), '
               f'l max {errl.max() if len(errl) else float("nan"):.1e}', flush=True)
