@@ -891,10 +891,9 @@ __device__ __noinline__ void dev_costates(const Ctx& c, clptr lm) {
   lptr Dxs = lds + L.e_Dxs;   // [a][k][nq]   d/dx_k of (stage cost a + sum_r l_r c_r)
   lptr Kc = lds + L.e_K;      // [a][k][b][5] columns (block a) of the state Hessian: Kxx, Kxy, Kyy on positions, k_ey, k_s
   // ---- 0. first / second state derivatives of every agent's stage Lagrangian
-  for (int it = TID; it < M * (N + 1); it += NT) {
-    const int a = it / (N + 1), k = it % (N + 1);
-    double Dx[DGSQP_MAX_AGENTS * DGSQP_MAX_NQA];
-    double Kl[DGSQP_MAX_AGENTS * 5];
+  // (accumulated IN PLACE in their destinations -- every (agent, stage) belongs to one thread: as run-time indexed local arrays the two
+  // vectors lived in scratch memory, 57 scratch accesses inside the loops of a function every line-search trial calls)
+  auto stage = [&](int a, int k, lptr Dx, auto Kl) {
     for (int i = 0; i < nq; i++) Dx[i] = 0.0;
     for (int i = 0; i < M * 5; i++) Kl[i] = 0.0;
     clptr xk = x + k * nq;
@@ -966,9 +965,11 @@ __device__ __noinline__ void dev_costates(const Ctx& c, clptr lm) {
         Dx[ip] += lr * (hi ? ln.n_hi[0] : ln.n_lo[0]); Dx[ip + 1] += lr * (hi ? ln.n_hi[1] : ln.n_lo[1]);
       } else Dx[D.qoff[R.a] + R.idx] -= lr;
     }
-    for (int i = 0; i < nq; i++) Dxs[(a * (N + 1) + k) * nq + i] = Dx[i];
-    if (D.tab_const) { gptr Kg = c.ws + D.ws_K; for (int i = 0; i < M * 5; i++) Kg[(a * (N + 1) + k) * M * 5 + i] = Kl[i]; }
-    else for (int i = 0; i < M * 5; i++) Kc[(a * (N + 1) + k) * M * 5 + i] = Kl[i];
+  };
+  for (int it = TID; it < M * (N + 1); it += NT) {
+    const int a = it / (N + 1), k = it % (N + 1);
+    if (D.tab_const) stage(a, k, Dxs + (a * (N + 1) + k) * nq, (gptr)(c.ws + D.ws_K) + (a * (N + 1) + k) * M * 5);
+    else stage(a, k, Dxs + (a * (N + 1) + k) * nq, Kc + (a * (N + 1) + k) * M * 5);
   }
   if (D.tab_const) __threadfence_block();
   __syncthreads();

@@ -1,12 +1,16 @@
-"""Development aid: time solve_batch for a config on the GPU box."""
+"""Development aid: time solve_batch for a config on the GPU box (with the -DDG_PROF library: per-phase cycle counters).
+usage: gpu_time.py <dyn|kbcurve|kbchicane|agents3|kbcurve50|any workload name of bench.py> <N> <B> [rk4 substeps]   (environment: DGSQP_QP_METHOD)"""
 import sys, time, pathlib
 import numpy as np
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+import os
 from dgsqp_amd.montecarlo import kinematic_racing_game, dynamic_racing_game, sample_scenarios
 from dgsqp_amd.solver import DGSQP
 which, N, B = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 M = int(sys.argv[4]) if len(sys.argv) > 4 else 10
-if which == 'agents3':      # XL layout: scripts/DGSQP_monte_carlo_agents.py at M=3, N=25
+if which in __import__('bench').WORKLOADS:      # a bench.py workload by name (N is the workload's own)
+    game = __import__('bench').make_game(which)
+elif which == 'agents3':      # XL layout: scripts/DGSQP_monte_carlo_agents.py at M=3, N=25
     game = kinematic_racing_game('curve', N=N, M=3)
 elif which == 'kbcurve50':    # XL layout at n = 200 (BASELINE configs[3]'s size on the curve track)
     game = kinematic_racing_game('curve', N=N)
