@@ -59,6 +59,8 @@ def sampler_kind(game) -> int:
 def sampler_spec(game, seed: int) -> SamplerT:
     """The C-ABI description of the game's sampler (include/dgsqp.h: dgsqp_sampler_t)."""
     from .montecarlo import _MERGE_X_NOM
+    if getattr(game, 'second_car_ahead', False):
+        raise ValueError("the device sampler has no 'car 2 ahead of car 1' rule (DGSQP_monte_carlo_ablation.py:387): sample this game on the host (montecarlo.sample_scenarios)")
     S = SamplerT()
     S.kind, S.seed = sampler_kind(game), int(seed)
     S.half_width, S.obs_d = float(game.half_width), float(game.obs_d)
