@@ -985,12 +985,14 @@ def test_three_agents_on_the_barc_circuit(oracle, N, B):
         assert e < (2e-4 if N == 25 else 1e-5), b
 
 
-@pytest.mark.parametrize('kind', ['dyn', 'kb', 'kb_sum_obj'])
+@pytest.mark.parametrize('kind', ['dyn', 'kb', 'kb_sum_obj', 'kb_osqp'])
 def test_dgsqp_v2_matches_oracle(oracle, kind):
     """DG-SQP v2 (DGSQP_v2.py:322-720 -- d-steps / m-steps with checkpoints, decaying regularisation,
     merit memory, merit without the complementarity term) on the device against the oracle's restatement: the dynamic-bicycle game
     with the parameters of the reference's study (comparison_study_barc/globals.py) and a kinematic game with the default
-    DGSQPV2Params; event logs identical event by event, flags / iteration / QP counts identical, iterates within 1e-5."""
+    DGSQPV2Params; event logs identical event by event, flags / iteration / QP counts identical, iterates within 1e-5.
+    ``kb_osqp``: the kinematic game with OSQP's own arithmetic behind v2's _solve_qp (qp_method='osqp' on both sides; the
+    regularisation v2 decays enters the projected Hessian OSQP is handed), six scenarios."""
     import copy
     from dgsqp_amd import montecarlo as mc
     from dgsqp_amd.solver import build_problem, build_params
@@ -1004,10 +1006,11 @@ def test_dgsqp_v2_matches_oracle(oracle, kind):
         if kind == 'kb_sum_obj':                              # merit 'sum_obj_l1' (DGSQP_v2.py:1161-1164): device = costate sweep, oracle = dense Du_x
             g.params.merit_function = 'sum_obj_l1'
     g.params.time_limit = None
-    P, par = build_problem(*g.solver_args()), build_params(g.params, lsqr_tol=1e-13)
-    assert par.variant == 1 and par.rel_tol_req == 10
-    s = DGSQPv2(*g.solver_args(), print_method=None, lsqr_tol=1e-13)
-    B = 10
+    qpm = 'osqp' if kind == 'kb_osqp' else None
+    P, par = build_problem(*g.solver_args()), build_params(g.params, lsqr_tol=1e-13, qp_method=qpm)
+    assert par.variant == 1 and par.rel_tol_req == 10 and par.qp_method == (1 if qpm else 0)
+    s = DGSQPv2(*g.solver_args(), print_method=None, lsqr_tol=1e-13, qp_method=qpm)
+    B = 6 if qpm else 10
     x0, u_tm = mc.sample_scenarios(g, B, seed=2)
     u = agent_major(u_tm)
     s.set_trace(20000)
