@@ -831,7 +831,9 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
       xl_jt_mul<MP>(J, js, n, S, 0, n, np, dv, part);
     }
   };
-  auto drop = [&](int l) {   // remove the active constraint at position l, restore R upper triangular (rotations also on J)
+  // `rot` (optional): a vector c = J^T w held in LDS; the rotations that act on the columns of J act on its entries l .. iq the same
+  // way, so it follows J without another pass over it (one pass over J per dropped row in the warm start's clean-up and in the main loop)
+  auto drop = [&](int l, lptr rot = nullptr) {   // remove the active constraint at position l, restore R upper triangular (rotations also on J)
     if (TID == 0) q.act[q.alist[l]] = 0;
     __syncthreads();
     // R loses column l: new column j = old column j + 1 (rows 0..j+1, upper Hessenberg from column l on).  Rows above l are copied
@@ -876,6 +878,15 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
       }
     }
     __syncthreads();
+    if (rot && TID == NT - 1) {      // (a thread that owns no row of J for n < NT)
+      double carry = rot[l];
+      for (int k = l; k < iq; k++) {
+        const double cc = gc[k], s2 = gs[k], jb = rot[k + 1];
+        rot[k] = cc * carry + s2 * jb;
+        carry = -s2 * carry + cc * jb;
+      }
+      rot[iq] = carry;
+    }
     // the same rotations on the columns of J: every thread carries its own row through the whole sequence
     for (int i = TID; i < n; i += NT) {
       MP Ji = J + (int64_t)i * js;
@@ -1071,9 +1082,8 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
       { double bv; int bi; block_argmin(umin, kmin, red, bv, bi); umin = bv; kmin = bi; }
       umax = block_max(umax, red);
       if (!(umin < -1e-10 * (1.0 + umax))) break;
-      // drop the row with the most negative multiplier; J's rotations change c = J^T q as well: recompute it
-      drop(kmin);
-      xl_jt_mul<MP>(J, js, n, S, 0, n, lds + L.q, dv, part);
+      // drop the row with the most negative multiplier; J's rotations act on c = J^T q as well
+      drop(kmin, dv);
     }
     // x = J1 y1 - J2 c2 ; multipliers clipped at 0 (rounding)
     for (int k = TID; k < n; k += NT) np[k] = k < iq ? zv[k] : -dv[k];
@@ -1097,13 +1107,18 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
     double sp = row_slack(ip);
     PROF_END(PH_Q_DIR, px4a);
     int st = -1;          // -1 running, 0 constraint added, 1 infeasible, 2 iteration limit
-    bool have_d = true;   // dv = J^T n_p is current (row_products); after a drop J has changed
+    bool have_d = true;   // dv = J^T n_p is current (row_products); a drop rotates it along with J
+    bool have_z = false;  // zv = J2 d2 of the previous inner step is still valid up to the one column a drop moved into J2
     for (int inner = 0; inner < 10 * (n + nc) && st < 0; inner++) {
       // step 2a: d = J^T np ; z = J2 d2 ; r = R^-1 d1
       PROF_BEGIN(px4);
       if (!have_d) xl_jt_mul<MP>(J, js, n, S, 0, n, np, dv, part);
       have_d = false;
-      xl_j_mul<MP>(J, js, n, S, iq, n, dv, zv, part);
+      // z = J2 d2: one pass over J -- except right after a drop, where J2 has only gained the column iq and d2 the entry d[iq]
+      // (the rotations of the drop touch the columns l .. iq, none of the old J2): z += d[iq] J[:, iq]
+      if (have_z) { for (int i = TID; i < n; i += NT) zv[i] += dv[iq] * J[(int64_t)i * js + iq]; __syncthreads(); }
+      else xl_j_mul<MP>(J, js, n, S, iq, n, dv, zv, part);
+      have_z = false;
       if (TID < 64) xl_wave_backsub(R, iq, dv, rv);
       __syncthreads();
       PROF_END(PH_Q_DIR, px4);
@@ -1120,7 +1135,8 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
         for (int k = TID; k < iq; k += NT) uu[k] -= t * rv[k];
         if (TID == 0) uu[iq] += t;
         __syncthreads();
-        drop(lidx);
+        drop(lidx, dv);         // (d = J^T n_p follows the rotations)
+        have_d = true; have_z = true;
         continue;
       }
       for (int i = TID; i < n; i += NT) x[i] += t * zv[i];
@@ -1132,7 +1148,8 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
         absorb(ip, true, znp);
         st = 0;
       } else {          // partial step: drop the blocking constraint, recompute the slack of ip
-        drop(lidx);
+        drop(lidx, dv);
+        have_d = true; have_z = true;
         sp = row_slack(ip);
       }
       PROF_END(PH_Q_UPD, px5);
