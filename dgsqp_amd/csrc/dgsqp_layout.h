@@ -38,7 +38,8 @@ struct DgDense {    // one distinct dense gradient: d x^a_k[idx] / du   or the o
 
 // Dot products with the dense gradients are cut into chunks of <= DG_CHUNK contiguous entries (one lane each, all loads
 // issued together): gd[p0 .. p0+len) . v[v0 .. v0+len)
-#define DG_XL_KMAX 64     // XL layout: negative eigenvalues the tridiagonal _nearestPD handles (beyond: one-sided Jacobi, ~5x slower)
+#define DG_XL_KMAX DG_NVARMAX   // XL layout: negative eigenvalues the tridiagonal _nearestPD handles (all of them; it was 64 until round 4, and the
+                                 // one-sided Jacobi sweeps beyond cost ~200 Mcycles per call at n = 200: one F1 scenario with > 64 spent 27 Gcycles there)
 #define DG_CHUNK 16
 // Storage of the dual method's inverse Cholesky factor T (upper triangular, dgsqp_solve.h: qpt_solve): column j = 8a + b holds its
 // rows 0..j followed by zeros up to row 8(a + 1) - 1, plus one unused entry; it starts at dg_tcol(j).  The zeros make groups of eight
@@ -97,6 +98,7 @@ struct DgProb {
                     // gradients move to the scratch to make room (gd_global)
   int xl_el;        // XL layout: the elimination that builds J = L^-T runs on a packed lower triangle in LDS (L.x_el) and J is written to
                     // the scratch once, instead of n passes over the L2-resident J
+  int xl_blk;       // XL layout: the elimination that builds J = L^-T runs 16 pivots per pass (xl_eliminate_blocked; multipliers in LDS at L.x_el)
   int xl_noblock;   // (development knob, environment DGSQP_XL_NOBLOCK: the XL warm start re-absorbs its rows one at a time)
   int tab_const;    // the row / dense-gradient / task tables are read from this constant block instead of LDS copies, the compact
                     // state-Hessian columns (e_K) live in the global scratch (ws_K) and the stage gradients share the costates'
@@ -145,7 +147,7 @@ static inline std::string dg_build_layout(DgProb& D) {
   D.ws_H = D.ws_base + 2 * D.n + 2 * D.nc + 16;
   D.ws_tang = D.ws_H + (int64_t)D.M * D.N * D.M * (DG_MAXEFF * DG_MAXEFF);
   D.ws_Y = D.ws_tang + (int64_t)(D.N + 1) * DGSQP_MAX_NQA * D.n;   // y_j = P a_j of the QP's active rows
-  D.ws_P = D.ws_Y + (int64_t)D.n * D.n;                              // big layout: packed P, packed reflectors;
+  D.ws_P = (D.ws_Y + (int64_t)D.n * D.n + 1) & ~(int64_t)1;           // big layout: packed P, packed reflectors (16-byte aligned: the XL kernels read pairs);
   const int64_t matsz = D.big == 2 ? (int64_t)D.n * D.n : (D.big ? (int64_t)D.n * (D.n + 1) / 2 : 0);   // XL: three full matrices
   D.ws_V = D.ws_P + matsz;
   D.ws_R = D.ws_V + matsz;
@@ -290,6 +292,8 @@ static inline std::string dg_build_layout(DgProb& D) {
   L.x_el = (qp_end + 1) & ~1;
   D.xl_el = D.big == 2 && D.xl_pack && L.x_el + npk + 2 <= DG_LDS_LIMIT / 8 && !getenv("DGSQP_XL_NOEL");
   if (D.xl_el && L.x_el + npk + 2 > tot) tot = L.x_el + npk + 2;       // (the triangle is part of the arena whatever R gets)
+  D.xl_blk = D.big == 2 && !D.xl_el && n >= 128 && L.x_el + 16 * n + 2 <= DG_LDS_LIMIT / 8 && !getenv("DGSQP_XL_NOBLKEL");
+  if (D.xl_blk && L.x_el + 16 * n + 2 > tot) tot = L.x_el + 16 * n + 2;
   L.c_R = (out_end + 1) & ~1;
   D.c_rcap = 0;
   if (D.classic_qp) {
@@ -311,6 +315,9 @@ static inline std::string dg_build_layout(DgProb& D) {
     snprintf(buf, sizeof buf, "problem needs %ld B of LDS per scenario (limit %d): n=%d n_c=%d", (long)tot * 8, DG_LDS_LIMIT, n, nc);
     return buf;
   }
+  if (getenv("DGSQP_LAYOUT_DEBUG"))
+    fprintf(stderr, "dgsqp layout: n=%d nc=%d big=%d pack=%d scr=%d g_tw=%d eig_end=%d qp_end=%d out_end=%d x_el=%d c_R=%d rcap=%d total=%d (limit %d doubles)\n",
+            n, nc, D.big, D.xl_pack, L.scr, L.g_tw, eig_end, qp_end, out_end, L.x_el, L.c_R, D.c_rcap, tot, DG_LDS_LIMIT / 8);
   return "";
 }
 

@@ -28,6 +28,58 @@ __device__ inline XlSplit xl_split(int n) {
   return S;
 }
 
+// ---- rank-16 update of a matrix in the L2 scratch on the matrix cores:  C[i][j] += sum_{kk < 16} a_of(kk, i) * b_of(kk, j)  over the
+// 16 x 16 tiles tile_of(t) = (ti, tj), t < ntile (tile index t covers rows / columns 16 t .. 16 t + 15; elements outside n x n are neither read nor written).
+// v_mfma_f64_16x16x4_f64: lane l holds A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15] and the results C[(l >> 4) + 4 r][l & 15],
+// r = 0 .. 3 -- every register of a tile is four 128-byte row segments.  The operands come from LDS one value per lane and MFMA
+// (the VALU form of this update needs 16 broadcast LDS reads per ROW of 64 results: the LDS pipe, not the ALU, bounds it);
+// four tiles per wavefront and pass keep 16 L2 round trips in flight.  Same fp64 FMAs as the VALU form, in the MFMA's order.
+typedef double xl_v4d __attribute__((ext_vector_type(4)));
+// General form: result(i, j) = c_of(i, j) + sum_{kk < 16 nk16} a_of(kk, i) b_of(kk, j), handed to s_of(i, j, value).
+template <class FT, class FA, class FB, class FC, class FS>
+__device__ __forceinline__ void xl_mfma_tiles(int n, int ntile, int nk16, FT tile_of, FA a_of, FB b_of, FC c_of, FS s_of) {
+  const int lane = TID & 63, wave = TID >> 6, li = lane & 15, h = lane >> 4;
+  constexpr int U = 4;
+  for (int t0 = wave * U; t0 < ntile; t0 += (NT / 64) * U) {
+    xl_v4d acc[U];
+    int row0[U], col[U], rowa[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int t = t0 + u < ntile ? t0 + u : ntile - 1;      // (a short last pass repeats its last tile's loads; nothing is stored)
+      int ti, tj;
+      tile_of(t, ti, tj);
+      row0[u] = 16 * ti + h; col[u] = 16 * tj + li; rowa[u] = 16 * ti + li;
+#pragma unroll
+      for (int r = 0; r < 4; r++) { const int row = row0[u] + 4 * r; acc[u][r] = (row < n && col[u] < n) ? c_of(row, col[u]) : 0.0; }
+    }
+    for (int kc = 0; kc < nk16; kc++) {
+      double av[U][4], bv[U][4];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) { av[u][q] = a_of(16 * kc + 4 * q + h, rowa[u]); bv[u][q] = b_of(16 * kc + 4 * q + h, col[u]); }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][q], bv[u][q], acc[u], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (t0 + u < ntile) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const int row = row0[u] + 4 * r; if (row < n && col[u] < n) s_of(row, col[u], acc[u][r]); }
+      }
+    }
+  }
+}
+template <class FT, class FA, class FB>
+__device__ __forceinline__ void xl_mfma_rank16(gptr C, int ldc, int n, int ntile, FT tile_of, FA a_of, FB b_of) {
+  xl_mfma_tiles(n, ntile, 1, tile_of, a_of, b_of, [&](int i, int j) { return C[(int64_t)i * ldc + j]; },
+                [&](int i, int j, double v) { C[(int64_t)i * ldc + j] = v; });
+}
+
 // ---- _nearestPD through the tridiagonal form (the same algorithm as the fast layouts, written generically):
 //   Householder tridiagonalisation of B (block-wide, B and the reflectors in the L2 scratch), Sturm-count multisection
 //   for the NEGATIVE eigenvalues only, eigenvectors by twisted factorisation (one wavefront each), modified Gram-Schmidt,
@@ -35,6 +87,7 @@ __device__ inline XlSplit xl_split(int n) {
 // Returns false (nothing written) when there are more than XL_KMAX negative eigenvalues: the Jacobi path takes over.
 #define XL_KMAX DG_XL_KMAX
 #define XL_RCH 16      // Givens rotations applied to a row of J per pass
+#define XL_PB 8        // columns per panel of the blocked tridiagonalisation (matrix in the L2 scratch)
 #define XL_SEG 8       // 16-column segments of a row of J one thread updates per pass (loads first, stores after)
 __device__ __noinline__ bool dev_xl_psd_tri(const Ctx& c, gptr Qpd) {
   const DgProb& D = dg_prob;
@@ -138,12 +191,35 @@ __device__ __noinline__ bool dev_xl_psd_tri(const Ctx& c, gptr Qpd) {
     const int i = e / n, k = e % n;
     Bm[e] = 0.5 * (Qg[(int64_t)i * n + k] + Qg[(int64_t)k * n + i]);
   }
+  // ---- Householder tridiagonalisation, BLOCKED (the matrix lives in the L2 scratch: n = 200 .. 320).  The plain reduction reads the
+  // trailing block for the product B v and reads + writes it again for the rank-2 update, every column: three L2 passes per column,
+  // 14 of the 95 Mcycles of a QP iteration at n = 300.  Here the updates of XL_PB columns are held back as a panel (V, W: 2 XL_PB
+  // columns in LDS; LAPACK's dlatrd scheme): column k is read with the panel's corrections applied on the fly, the product uses the
+  // matrix of the panel's start plus two thin products with the panel, and the trailing block is read + written ONCE per panel
+  // (B -= V W^T + W V^T) -- 1 + 2 / XL_PB passes per column.  Same arithmetic as the plain reduction up to the order of the sums.
+  constexpr int PB = XL_PB;
+  static_assert(PB == NT / 64, "one wavefront per panel column in the thin products");
+  lptr Pl = strips + 6 * n;             // panel, column-major: V_c at c n, W_c at (PB + c) n; rows <= (column's index) stay zero
+  for (int e = TID; e < 2 * PB * n; e += NT) Pl[e] = 0.0;
   XSYNC();
-  // ---- Householder tridiagonalisation
+  // product B0 v: thread (g2, ip) owns the column PAIR (2 ip, 2 ip + 1) -- 16-byte loads, n / 2 lanes per row, so that NT / (n / 2)
+  // groups share the rows (3 at n = 300 where one column per thread leaves 212 threads idle and 19 dependent round trips per column)
+  const bool pairs = !(n & 1) && !((uintptr_t)Bm & 15);
+  const int np2 = ((n >> 1) + 31) & ~31;
+  const int G2 = pairs ? (NT / np2 < 6 ? NT / np2 : 6) : S.G, g2 = pairs ? TID / np2 : S.g, ip2 = TID - g2 * np2;
+  int pc = 0;                           // columns in the panel
   for (int k = 0; k + 2 < n; k++) {
-    const int m = n - k - 1;
+    // (1) column k of the UPDATED matrix below the diagonal (= row k right of it: both triangles are kept)
+    double vk[PB], wk[PB];
+#pragma unroll
+    for (int cc = 0; cc < PB; cc++) { vk[cc] = cc < pc ? Pl[cc * n + k] : 0.0; wk[cc] = cc < pc ? Pl[(PB + cc) * n + k] : 0.0; }
     double s2 = 0;
-    for (int i = k + 1 + TID; i < n; i += NT) { const double x = Bm[(int64_t)i * n + k]; vv[i] = x; s2 += x * x; }
+    for (int i = k + 1 + TID; i < n; i += NT) {
+      double x = Bm[(int64_t)k * n + i];
+#pragma unroll
+      for (int cc = 0; cc < PB; cc++) if (cc < pc) x -= Pl[cc * n + i] * wk[cc] + Pl[(PB + cc) * n + i] * vk[cc];
+      vv[i] = x; s2 += x * x;
+    }
     const double nrm2 = block_sum(s2, red);
     const double x0 = vv[k + 1];
     const double tail2 = nrm2 - x0 * x0;
@@ -151,17 +227,48 @@ __device__ __noinline__ bool dev_xl_psd_tri(const Ctx& c, gptr Qpd) {
     if (!(tail2 > 0.0)) { alpha = x0; beta = 0.0; }
     else { alpha = x0 >= 0 ? -sqrt(nrm2) : sqrt(nrm2); const double v0 = x0 - alpha; beta = 2.0 / (tail2 + v0 * v0); }
     __syncthreads();
-    if (TID == 0) { dv[k] = Bm[(int64_t)k * n + k]; ev[k] = alpha; tau[k] = beta; if (beta != 0.0) vv[k + 1] = x0 - alpha; }
+    if (TID == 0) {
+      double dk = Bm[(int64_t)k * n + k];
+#pragma unroll
+      for (int cc = 0; cc < PB; cc++) dk -= 2.0 * vk[cc] * wk[cc];
+      dv[k] = dk; ev[k] = alpha; tau[k] = beta;
+      if (beta != 0.0) vv[k + 1] = x0 - alpha;
+    }
     __syncthreads();
     for (int i = k + 1 + TID; i < n; i += NT) Vr[(int64_t)k * n + i] = vv[i];
     if (beta != 0.0) {
-      // p = beta B v (B symmetric: column i is read along rows, coalesced over i); thread (g, i) sums the g-th part of the rows
-      if (S.g < S.G && S.i > k && S.i < n) {
+      // (2) B0 v with the matrix as it stood at the panel's start (B symmetric: column i is read along rows, coalesced over i) ...
+      if (pairs) {
+        if (g2 < G2 && 2 * ip2 + 1 > k && 2 * ip2 < n) {
+          const int len = n - k - 1, ja = k + 1 + (g2 * len) / G2, jb = k + 1 + ((g2 + 1) * len) / G2;
+          const double2* pb = (const double2*)(Bm + (int64_t)ja * n + 2 * ip2);
+          const int rs2 = n >> 1;
+          double a0 = 0, a1 = 0, c0 = 0, c1 = 0;
+          int j = ja;
+          for (; j + 15 < jb; j += 16, pb += 16 * rs2) {          // sixteen L2 round trips in flight
+            double2 b[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) b[u] = pb[u * rs2];
+#pragma unroll
+            for (int u = 0; u < 16; u += 2) {
+              const double v0 = vv[j + u], v1 = vv[j + u + 1];
+              a0 += b[u].x * v0; c0 += b[u].y * v0; a1 += b[u + 1].x * v1; c1 += b[u + 1].y * v1;
+            }
+          }
+          for (; j + 3 < jb; j += 4, pb += 4 * rs2) {
+            const double2 b0 = pb[0], b1 = pb[rs2], b2 = pb[2 * rs2], b3 = pb[3 * rs2];
+            a0 += b0.x * vv[j]; c0 += b0.y * vv[j]; a1 += b1.x * vv[j + 1]; c1 += b1.y * vv[j + 1];
+            a0 += b2.x * vv[j + 2]; c0 += b2.y * vv[j + 2]; a1 += b3.x * vv[j + 3]; c1 += b3.y * vv[j + 3];
+          }
+          for (; j < jb; j++, pb += rs2) { const double2 b0 = pb[0]; a0 += b0.x * vv[j]; c0 += b0.y * vv[j]; }
+          part[g2 * n + 2 * ip2] = a0 + a1; part[g2 * n + 2 * ip2 + 1] = c0 + c1;      // (column k itself may ride along: never read)
+        }
+      } else if (S.g < S.G && S.i > k && S.i < n) {
         const int len = n - k - 1, ja = k + 1 + (S.g * len) / S.G, jb = k + 1 + ((S.g + 1) * len) / S.G;
         cgptr pb = Bm + (int64_t)ja * n + S.i;
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         int j = ja;
-        for (; j + 15 < jb; j += 16, pb += 16 * n) {          // sixteen L2 round trips in flight
+        for (; j + 15 < jb; j += 16, pb += 16 * n) {
           double b[16];
 #pragma unroll
           for (int u = 0; u < 16; u++) b[u] = pb[u * n];
@@ -175,42 +282,45 @@ __device__ __noinline__ bool dev_xl_psd_tri(const Ctx& c, gptr Qpd) {
         for (; j < jb; j++, pb += n) a0 += pb[0] * vv[j];
         part[S.g * n + S.i] = (a0 + a1) + (a2 + a3);
       }
+      // (3) ... and the panel's thin products W^T v and V^T v, one panel column per wavefront, while the loads above are in flight
+      if (wave < pc) {
+        double sw = 0, sv = 0;
+        for (int i = k + 1 + lane; i < n; i += 64) { const double vi = vv[i]; sw += Pl[(PB + wave) * n + i] * vi; sv += Pl[wave * n + i] * vi; }
+        sw = wave_sum(sw); sv = wave_sum(sv);
+        if (lane == 0) { e2[wave] = sw; e2[PB + wave] = sv; }
+      }
       __syncthreads();
+      // (4) p = beta (B0 v - V (W^T v) - W (V^T v)),  w = p - (beta / 2) (p . v) v;  v and w join the panel
       double pvsum = 0;
       for (int i = k + 1 + TID; i < n; i += NT) {
         double a = part[i];
-        for (int g = 1; g < S.G; g++) a += part[g * n + i];
-        const double p = beta * a;
-        pv[i] = p; pvsum += p * vv[i];
+        for (int g = 1; g < G2; g++) a += part[g * n + i];
+#pragma unroll
+        for (int cc = 0; cc < PB; cc++) if (cc < pc) a -= Pl[cc * n + i] * e2[cc] + Pl[(PB + cc) * n + i] * e2[PB + cc];
+        const double pq = beta * a;
+        pv[i] = pq; pvsum += pq * vv[i];
       }
       const double K = 0.5 * beta * block_sum(pvsum, red);
-      for (int i = k + 1 + TID; i < n; i += NT) pv[i] -= K * vv[i];       // w
-      __syncthreads();
-      // B -= v w^T + w v^T on the trailing block: thread (g, j) owns column j of the rows k + 1 + g, k + 1 + g + G, ...
-      if (S.g < S.G && S.i > k && S.i < n) {
-        const int j = S.i, G = S.G;
-        const double vj = vv[j], wj = pv[j];
-        int i = k + 1 + S.g;
-        gptr pb = Bm + (int64_t)i * n + j;
-        const int64_t rs = (int64_t)G * n;
-        for (; i + 15 * G < n; i += 16 * G, pb += 16 * rs) {      // sixteen rows per pass: their L2 round trips overlap
-          double b[16];
-#pragma unroll
-          for (int u = 0; u < 16; u++) b[u] = pb[u * rs];
-#pragma unroll
-          for (int u = 0; u < 16; u++) pb[u * rs] = b[u] - (vv[i + u * G] * wj + pv[i + u * G] * vj);
-        }
-        for (; i + 3 * G < n; i += 4 * G, pb += 4 * rs) {
-          double b[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) b[u] = pb[u * rs];
-#pragma unroll
-          for (int u = 0; u < 4; u++) pb[u * rs] = b[u] - (vv[i + u * G] * wj + pv[i + u * G] * vj);
-        }
-        for (; i < n; i += G, pb += rs) pb[0] = pb[0] - (vv[i] * wj + pv[i] * vj);
+      for (int i = k + 1 + TID; i < n; i += NT) {
+        const double w = pv[i] - K * vv[i];
+        Pl[pc * n + i] = vv[i]; Pl[(PB + pc) * n + i] = w;
       }
     }
-    XSYNC();
+    pc++;
+    __syncthreads();
+    if (pc == PB || k + 3 >= n) {
+      // (5) B -= V W^T + W V^T on the trailing block (rows and columns > k), a rank-16 product on the matrix cores.  Tiles start at the
+      // 16-row boundary at or below k + 1: the rows and columns <= k they touch are dead (read for the last time inside this panel)
+      const int t_lo = (k + 1) >> 4, t_hi = (n + 15) >> 4;
+      const int TT = t_hi - t_lo;
+      xl_mfma_rank16(Bm, n, n, TT * TT, [&](int t, int& ti, int& tj) { ti = t_lo + t / TT; tj = t_lo + t % TT; },
+                     [&](int kk, int i) { return i < n ? -Pl[kk * n + i] : 0.0; },
+                     [&](int kk, int j) { return j < n ? Pl[((kk + PB) & (2 * PB - 1)) * n + j] : 0.0; });
+      XSYNC();
+      for (int e = TID; e < 2 * PB * n; e += NT) Pl[e] = 0.0;
+      pc = 0;
+      __syncthreads();
+    }
   }
   if (TID == 0) {
     dv[n - 2] = Bm[(int64_t)(n - 2) * n + n - 2]; dv[n - 1] = Bm[(int64_t)(n - 1) * n + n - 1];
@@ -320,13 +430,15 @@ __device__ __noinline__ bool dev_xl_psd_tri(const Ctx& c, gptr Qpd) {
   XSYNC();
   // ---- M = B + sum_j (floor - lambda_j) v_j v_j^T + reg I
   const double reg = dev_reg();
-  for (int e = TID; e < n * n; e += NT) {
-    const int i = e / n, k = e % n;
-    double a = 0.5 * (Qg[(int64_t)i * n + k] + Qg[(int64_t)k * n + i]);
-    for (int j = 0; j < kneg; j++) a += (D.eig_floor - lamv[j]) * Z[(int64_t)j * n + i] * Z[(int64_t)j * n + k];
-    if (i == k) a += reg;
-    Mx[e] = a;
-    if (Qpd) Qpd[e] = a;
+  // (a rank-kneg product: on the matrix cores, 16 eigenvectors per pass over a tile's operands)
+  {
+    const int T = (n + 15) >> 4;
+    const double fl = D.eig_floor;
+    xl_mfma_tiles(n, T * T, (kneg + 15) >> 4, [&](int t, int& ti, int& tj) { ti = t / T; tj = t - ti * T; },
+                  [&](int kk, int i) { return (kk < kneg && i < n) ? (fl - lamv[kk]) * Z[(int64_t)kk * n + i] : 0.0; },
+                  [&](int kk, int j) { return (kk < kneg && j < n) ? Z[(int64_t)kk * n + j] : 0.0; },
+                  [&](int i, int k) { return 0.5 * (Qg[(int64_t)i * n + k] + Qg[(int64_t)k * n + i]) + (i == k ? reg : 0.0); },
+                  [&](int i, int k, double v) { Mx[(int64_t)i * n + k] = v; if (Qpd) Qpd[(int64_t)i * n + k] = v; });
   }
   XSYNC();
   PROF_END(PH_JACOBI, pt_t);
@@ -647,6 +759,125 @@ __device__ inline void xl_j_mul(MP J, int js, int n, const XlSplit& S, int k0, i
   }
 }
 
+
+// ---- J = L^-T, first part: the elimination M = L~ D L~^T with X = L~^-1 accumulated in place (lower triangle of J, d on the diagonal),
+// BLOCKED for the matrix in the L2 scratch.  The column-by-column form below reads and writes the whole active region once per pivot
+// (15 of the 56 Mcycles of a QP at n = 300); here 16 pivots form a panel:
+//   (a) the 16 x 16 diagonal block is factored by one wavefront (rows on lanes, pivots exchanged by v_readlane);
+//   (b) every row below the panel computes its 16 multipliers from its own 16 entries (no barrier: the pivot rows are the block's);
+//   (c) the panel's own rows complete their part of X by a forward substitution per column (16 values in registers);
+//   (d) ONE pass over the rows below the panel applies all 16 pivots, a rank-16 product on the matrix cores:
+//       X[i][k] -= sum_c m[i][c] X[j0 + c][k]  (k < j0),   S[i][k] -= sum_c m[i][c] (m[k][c] d_c)  (j0 + 16 <= k <= i),
+//       and X[i][j0 + c] = -(m_i Xpp)[c] with Xpp the inverse of the block's unit factor.
+// Same eliminations as the column-by-column form (the sums over a panel's pivots are taken in the MFMA's order).
+// LDS: the multipliers (16 columns of n) at `Mm`, two 16 x 16 tables at `tab`, 16 pivots + reciprocals + a flag at `sm`.
+__device__ __noinline__ bool xl_eliminate_blocked(gptr J, const int js, const int n, lptr Mm, lptr tab, lptr sm) {
+  const int lane = TID & 63, wave = TID >> 6;
+  lptr Lm = tab, Xp = tab + 256, dd = sm, dinv = sm + 16, flag = sm + 32;
+  const int T = (n + 15) >> 4;
+  if (TID == 0) flag[0] = 0.0;
+  for (int j0 = 0; j0 < n; j0 += 16) {
+    const int pb = n - j0 < 16 ? n - j0 : 16, jt = j0 >> 4;
+    __syncthreads();
+    // (a) diagonal block
+    if (wave == 0) {
+      const int r = lane & 15;
+      double a[16];
+#pragma unroll
+      for (int cc = 0; cc < 16; cc++) a[cc] = (r < pb && cc <= r) ? J[(int64_t)(j0 + r) * js + j0 + cc] : 0.0;
+      bool okp = true;
+#pragma unroll
+      for (int cc = 0; cc < 16; cc++) {
+        const double dcc = lane_bcast(a[cc], cc);
+        const bool live = cc < pb;
+        if (live && !(dcc > 0.0)) okp = false;
+        const double inv = (live && dcc > 0.0) ? 1.0 / dcc : 0.0;
+        const double m = r > cc ? a[cc] * inv : 0.0;
+#pragma unroll
+        for (int c2 = cc + 1; c2 < 16; c2++) {
+          const double piv = lane_bcast(a[cc], c2);        // (row c2, column cc) = L[c2][cc] d_cc
+          if (r >= c2) a[c2] -= m * piv;
+        }
+        if (lane < 16) {
+          Lm[r * 16 + cc] = m;
+          if (r == cc) { dd[cc] = live ? dcc : 0.0; dinv[cc] = inv; if (live) J[(int64_t)(j0 + r) * js + j0 + cc] = dcc; }
+        }
+      }
+      if (!okp && lane == 0) flag[0] = 1.0;
+    }
+    __syncthreads();
+    if (flag[0] != 0.0) return true;
+    // (b) multipliers of the rows below the panel (thread = row)
+    const int i = j0 + 16 + TID;
+    const bool below = i < n;
+    double m[16];
+    if (below) {
+      double a[16];
+#pragma unroll
+      for (int cc = 0; cc < 16; cc++) a[cc] = J[(int64_t)i * js + j0 + cc];
+#pragma unroll
+      for (int cc = 0; cc < 16; cc++) {
+        m[cc] = a[cc] * dinv[cc];
+#pragma unroll
+        for (int c2 = cc + 1; c2 < 16; c2++) a[c2] -= a[cc] * Lm[c2 * 16 + cc];       // a[cc] = m d_cc: the unnormalised entry
+        Mm[cc * n + i] = m[cc];
+      }
+    }
+    // (c) X of the panel's rows: columns k < j0 (forward substitution on what previous panels left) and the block itself (on the identity)
+    if (TID < j0 + pb) {
+      const int k = TID, kc = k - j0;
+      double x[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) x[r] = kc < 0 ? (r < pb ? J[(int64_t)(j0 + r) * js + k] : 0.0) : (r == kc ? 1.0 : 0.0);
+#pragma unroll
+      for (int r = 1; r < 16; r++) {
+        double sacc = x[r];
+#pragma unroll
+        for (int cc = 0; cc < r; cc++) sacc -= Lm[r * 16 + cc] * x[cc];
+        x[r] = sacc;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        if (r < pb && r > kc) J[(int64_t)(j0 + r) * js + k] = x[r];
+        if (kc >= 0) Xp[r * 16 + kc] = x[r];
+      }
+    } else if (TID < j0 + 16) {           // (a short last panel: the columns it does not have)
+      const int kc = TID - j0;
+#pragma unroll
+      for (int r = 0; r < 16; r++) Xp[r * 16 + kc] = 0.0;
+    }
+    XSYNC();
+    if (pb < 16 || j0 + 16 >= n) break;       // nothing below the last panel
+    // (d) the panel's own columns of the rows below:  X[i][j0 + c] = -(m[c] + sum_{c' > c} m[c'] Xpp[c'][c])
+    if (below) {
+#pragma unroll
+      for (int cc = 0; cc < 16; cc++) {
+        double sacc = m[cc];
+#pragma unroll
+        for (int c2 = cc + 1; c2 < 16; c2++) sacc += m[c2] * Xp[c2 * 16 + cc];
+        J[(int64_t)i * js + j0 + cc] = -sacc;
+      }
+    }
+    // ... and everything else of those rows on the matrix cores: tile row ti > jt has the tile columns [0, jt) and (jt, ti]
+    {
+      const int base = (jt + 1) * jt / 2, ntile = T * (T - 1) / 2 - base;
+      xl_mfma_rank16(J, js, n, ntile,
+                     [&](int t, int& ti, int& tj) {
+                       const int g = t + base;
+                       int rr = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)g)) * 0.5f);
+                       while (rr * (rr - 1) / 2 > g) rr--;
+                       while ((rr + 1) * rr / 2 <= g) rr++;
+                       const int cidx = g - rr * (rr - 1) / 2;
+                       ti = rr; tj = cidx < jt ? cidx : cidx + 1;
+                     },
+                     [&](int kk, int ii) { return ii < n ? -Mm[kk * n + ii] : 0.0; },
+                     [&](int kk, int jj) { return jj < j0 ? J[(int64_t)(j0 + kk) * js + jj] : (jj < n ? Mm[kk * n + jj] * dd[kk] : 0.0); });
+    }
+    XSYNC();
+  }
+  return false;
+}
+
 template <class MP>
 __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
   const DgProb& D = dg_prob;
@@ -729,6 +960,22 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
 #ifdef DG_PROF
   long long pa_ = 0, pb_ = 0, pc_ = 0;
 #endif
+  bool blocked_el = false;
+  if constexpr (!xl_mp<MP>::lds) {
+    if (D.xl_blk) {        // 16 pivots per pass over the matrix, the pass on the matrix cores (xl_eliminate_blocked)
+#ifdef DG_PROF
+      const long long p0_ = clock64();
+#endif
+      bad = xl_eliminate_blocked(J, js, n, lds + L.x_el, part, tv);
+      blocked_el = true;
+      for (int r = TID; r < nc; r += NT) lhat[r] = 0.0;      // (the multipliers' slot overlaps the QP outputs)
+      __syncthreads();
+#ifdef DG_PROF
+      pb_ += clock64() - p0_;
+#endif
+    }
+  }
+  if (!blocked_el)
   for (int j = 0; j < n; j++) {
 #ifdef DG_PROF
     long long p0_ = clock64();
