@@ -678,21 +678,61 @@ __device__ inline void xl_wave_fwdsub_t(const XlR& R, int iq, clptr b, lptr out)
     }
   }
 }
-__device__ inline void xl_wave_backsub(const XlR& R, int iq, clptr b, lptr out) {
+// (own functions: see xl_jt_mul_pairs)
+__device__ __noinline__ void xl_wave_backsub(const XlR& R, int iq, clptr b, lptr out) {
   if (iq <= 64) xl_wave_backsub_t<1, 8>(R, iq, b, out);
   else if (iq <= 128) xl_wave_backsub_t<2, 8>(R, iq, b, out);
   else if (iq <= 256) xl_wave_backsub_t<4, 4>(R, iq, b, out);
   else xl_wave_backsub_t<5, 4>(R, iq, b, out);
 }
-__device__ inline void xl_wave_fwdsub(const XlR& R, int iq, clptr b, lptr out) {
+__device__ __noinline__ void xl_wave_fwdsub(const XlR& R, int iq, clptr b, lptr out) {
   if (iq <= 64) xl_wave_fwdsub_t<1, 8>(R, iq, b, out);
   else if (iq <= 128) xl_wave_fwdsub_t<2, 8>(R, iq, b, out);
   else if (iq <= 256) xl_wave_fwdsub_t<4, 4>(R, iq, b, out);
   else xl_wave_fwdsub_t<5, 4>(R, iq, b, out);
 }
 // out[i] = sum_{k0 <= k < k1} J[k][i] v[k]   (J^T v restricted to rows k0..k1-1): consecutive threads read consecutive addresses
+// J^T v for a matrix in the scratch (own function: inside the QP's body the register allocation of these loops changed with every
+// unrelated edit -- 63 k or 126 k cycles per step direction).  Thread (g, ip) owns the column PAIR (2 ip, 2 ip + 1) and the g-th part
+// of the rows -- 16-byte loads, sixteen L2 round trips in flight.  One column per thread and eight in flight is 38 dependent round
+// trips at n = 300, where n / 2 lanes per row leave room for three row groups: 6.  Needs an even n and row stride and a 16-byte
+// aligned matrix (the caller checks).
+__device__ __noinline__ void xl_jt_mul_pairs(cgptr J, int js, int n, int k0, int k1, clptr v, lptr out, lptr part) {
+  const int np2 = ((n >> 1) + 31) & ~31;
+  const int G2 = NT / np2 < DG_NH ? NT / np2 : DG_NH, g2 = TID / np2, ip2 = TID - g2 * np2;
+  if (g2 < G2 && 2 * ip2 < n) {
+    const int len = k1 - k0, ka = k0 + (g2 * len) / G2, kb = k0 + ((g2 + 1) * len) / G2;
+    const double2* pb = (const double2*)(J + (int64_t)ka * js + 2 * ip2);
+    const int rs2 = js >> 1;
+    double a0 = 0, a1 = 0, c0 = 0, c1 = 0;
+    int k = ka;
+    for (; k + 15 < kb; k += 16, pb += 16 * rs2) {
+      double2 b[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) b[u] = pb[u * rs2];
+#pragma unroll
+      for (int u = 0; u < 16; u += 2) {
+        const double v0 = v[k + u], v1 = v[k + u + 1];
+        a0 += b[u].x * v0; c0 += b[u].y * v0; a1 += b[u + 1].x * v1; c1 += b[u + 1].y * v1;
+      }
+    }
+    for (; k + 3 < kb; k += 4, pb += 4 * rs2) {
+      const double2 b0 = pb[0], b1 = pb[rs2], b2 = pb[2 * rs2], b3 = pb[3 * rs2];
+      a0 += b0.x * v[k]; c0 += b0.y * v[k]; a1 += b1.x * v[k + 1]; c1 += b1.y * v[k + 1];
+      a0 += b2.x * v[k + 2]; c0 += b2.y * v[k + 2]; a1 += b3.x * v[k + 3]; c1 += b3.y * v[k + 3];
+    }
+    for (; k < kb; k++, pb += rs2) { const double2 b0 = pb[0]; a0 += b0.x * v[k]; c0 += b0.y * v[k]; }
+    part[g2 * n + 2 * ip2] = a0 + a1; part[g2 * n + 2 * ip2 + 1] = c0 + c1;
+  }
+  __syncthreads();
+  if (TID < n) { double sacc = part[TID]; for (int g = 1; g < G2; g++) sacc += part[g * n + TID]; out[TID] = sacc; }
+  __syncthreads();
+}
 template <class MP>
 __device__ inline void xl_jt_mul(MP J, int js, int n, const XlSplit& S, int k0, int k1, clptr v, lptr out, lptr part) {
+  if constexpr (!xl_mp<MP>::lds) {
+    if (!(n & 1) && !(js & 1) && !((uintptr_t)J & 15)) { xl_jt_mul_pairs(J, js, n, k0, k1, v, out, part); return; }
+  }
   if (S.g < S.G && S.i < n) {
     const int len = k1 - k0, ka = k0 + (S.g * len) / S.G, kb = k0 + ((S.g + 1) * len) / S.G;
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
@@ -710,6 +750,29 @@ __device__ inline void xl_jt_mul(MP J, int js, int n, const XlSplit& S, int k0, 
   __syncthreads();
   if (TID < n) { double s = part[TID]; for (int g = 1; g < S.G; g++) s += part[g * n + TID]; out[TID] = s; }
   __syncthreads();
+}
+// J v (columns k0 .. k1 - 1) for a matrix in the scratch: one wavefront per row, lanes along the row (own function, see xl_jt_mul_pairs)
+__device__ __noinline__ void xl_j_mul_rows(cgptr J, int js, int n, int k0, int k1, clptr v, lptr out) {
+  const int lane = TID & 63;
+  // eight rows per wavefront and pass, every load of the pass (8 rows x up to 5 chunks of 64 columns, n <= 320) issued before the
+  // first use: one L2 round trip per pass instead of one per chunk
+  constexpr int RP = 8;
+  for (int i0 = (TID >> 6) * RP; i0 < n; i0 += (NT / 64) * RP) {
+    double a[RP][XL_NV], vk[XL_NV];
+#pragma unroll
+    for (int cidx = 0; cidx < XL_NV; cidx++) {
+      const int k = k0 + lane + 64 * cidx;
+      const bool on = k < k1;
+      vk[cidx] = on ? v[k] : 0.0;
+#pragma unroll
+      for (int r = 0; r < RP; r++) a[r][cidx] = (on && i0 + r < n) ? J[(int64_t)(i0 + r) * js + k] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < RP; r++) {
+      const double t = wave_sum(((a[r][0] * vk[0] + a[r][1] * vk[1]) + (a[r][2] * vk[2] + a[r][3] * vk[3])) + a[r][4] * vk[4]);
+      if (lane == 0 && i0 + r < n) out[i0 + r] = t;
+    }
+  }
 }
 // out[i] = sum_{k0 <= k < k1} J[i][k] v[k]   (J v restricted to columns k0..k1-1).  LDS: the odd row stride keeps the row-per-thread
 // reads conflict-free.  Scratch: one wavefront per row, lanes along the row.
@@ -729,36 +792,53 @@ __device__ inline void xl_j_mul(MP J, int js, int n, const XlSplit& S, int k0, i
     if (TID < n) { double s = part[TID]; for (int g = 1; g < S.G; g++) s += part[g * n + TID]; out[TID] = s; }
     __syncthreads();
   } else {
-    const int lane = TID & 63;
-    // four rows per wavefront and pass, every load of the pass (4 rows x up to 4 chunks of 64 columns, n <= 256) issued before the
-    // first use: one L2 round trip per pass instead of one per chunk.  Columns beyond 256 (n <= 320) ride in a fifth chunk.
-    for (int i0 = (TID >> 6) * 4; i0 < n; i0 += (NT / 64) * 4) {
-      double a[4][4], vk[4];
-#pragma unroll
-      for (int cidx = 0; cidx < 4; cidx++) {
-        const int k = k0 + lane + 64 * cidx;
-        const bool on = k < k1;
-        vk[cidx] = on ? v[k] : 0.0;
-#pragma unroll
-        for (int r = 0; r < 4; r++) a[r][cidx] = (on && i0 + r < n) ? J[(int64_t)(i0 + r) * js + k] : 0.0;
-      }
-      double s[4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) s[r] = (a[r][0] * vk[0] + a[r][1] * vk[1]) + (a[r][2] * vk[2] + a[r][3] * vk[3]);
-      if (k1 - k0 > 256) {       // uniform
-        const int k = k0 + lane + 256;
-        const bool on = k < k1;
-        const double v5 = on ? v[k] : 0.0;
-#pragma unroll
-        for (int r = 0; r < 4; r++) s[r] += ((on && i0 + r < n) ? J[(int64_t)(i0 + r) * js + k] : 0.0) * v5;
-      }
-#pragma unroll
-      for (int r = 0; r < 4; r++) { const double t = wave_sum(s[r]); if (lane == 0 && i0 + r < n) out[i0 + r] = t; }
-    }
+    xl_j_mul_rows(J, js, n, k0, k1, v, out);
     __syncthreads();
   }
 }
 
+
+// Warm start, step (C): J <- J H_t0 ... H_{t1-1} for a matrix in the scratch, four rows per wavefront and pass (their L2 round trips
+// overlap; the reflectors come from LDS: reflector t is column refc[t] of Dl, zero above entry t, scale betas[t]).
+__device__ __noinline__ void xl_reflect_rows(gptr J, int js, int n, int t0, int t1, clptr betas, clptr refc, clptr Dl) {
+  const int lane = TID & 63, wave = TID >> 6;
+  constexpr int RP = 4;
+  for (int i0 = wave * RP; i0 < n; i0 += (NT / 64) * RP) {
+    double r[RP][XL_NV];
+#pragma unroll
+    for (int rr = 0; rr < RP; rr++) {
+#pragma unroll
+      for (int h = 0; h < XL_NV; h++) { const int k = lane + 64 * h; r[rr][h] = (k < n && i0 + rr < n) ? J[(int64_t)(i0 + rr) * js + k] : 0.0; }
+    }
+    for (int t = t0; t < t1; t++) {
+      const double bt = betas[t];
+      if (bt == 0.0) continue;
+      clptr v = Dl + (int)refc[t] * n;
+      double vk[XL_NV], ds[RP];
+#pragma unroll
+      for (int rr = 0; rr < RP; rr++) ds[rr] = 0.0;
+#pragma unroll
+      for (int h = 0; h < XL_NV; h++) {
+        const int k = lane + 64 * h;
+        vk[h] = (k >= t && k < n) ? v[k] : 0.0;
+#pragma unroll
+        for (int rr = 0; rr < RP; rr++) ds[rr] += r[rr][h] * vk[h];
+      }
+#pragma unroll
+      for (int rr = 0; rr < RP; rr++) ds[rr] = bt * wave_sum(ds[rr]);
+#pragma unroll
+      for (int rr = 0; rr < RP; rr++) {
+#pragma unroll
+        for (int h = 0; h < XL_NV; h++) r[rr][h] -= ds[rr] * vk[h];
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < RP; rr++) {
+#pragma unroll
+      for (int h = 0; h < XL_NV; h++) { const int k = lane + 64 * h; if (k < n && i0 + rr < n) J[(int64_t)(i0 + rr) * js + k] = r[rr][h]; }
+    }
+  }
+}
 
 // ---- J = L^-T, first part: the elimination M = L~ D L~^T with X = L~^-1 accumulated in place (lower triangle of J, d on the diagonal),
 // BLOCKED for the matrix in the L2 scratch.  The column-by-column form below reads and writes the whole active region once per pivot
@@ -1171,7 +1251,34 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
       for (int i = TID; i < n; i += NT) zv[i] = beta * (zv[i] - delta * J[i * js + iq]);
       if (TID == 0) dv[iq] = v0;
       __syncthreads();
-      if (S.g < S.G && S.i + iq < n) {     // thread (g, k): column k >= iq of the rows g, g + G, ...
+      bool paired = false;
+      if constexpr (!xl_mp<MP>::lds) {
+        // scratch: thread (g, ip) owns the column PAIR (kb + 2 ip, + 1), kb = iq rounded down to even, of the rows g, g + G2, ... --
+        // 16-byte loads and stores, n / 2 lanes per row and so three row groups at n = 300, where one column per thread (below)
+        // walks all 300 rows alone: 38 dependent L2 round trips per added row against 13.  (A pair that straddles iq rewrites
+        // column iq - 1 with its own value: v = 0 there.)
+        if (!(n & 1) && !(js & 1) && !((uintptr_t)J & 15)) {
+          paired = true;
+          const int np2 = ((n >> 1) + 31) & ~31;
+          const int G2 = NT / np2, g2 = TID / np2, ip2 = TID - g2 * np2, kb = iq & ~1, k = kb + 2 * ip2;
+          if (g2 < G2 && k < n) {
+            const double vk0 = k >= iq ? dv[k] : 0.0, vk1 = dv[k + 1];
+            int i = g2;
+            double2* pj = (double2*)(J + (int64_t)i * js + k);
+            const int rs2 = G2 * (js >> 1);
+            clptr pw = zv + i;
+            for (; i + 7 * G2 < n; i += 8 * G2, pj += 8 * rs2, pw += 8 * G2) {
+              double2 a[8];
+#pragma unroll
+              for (int u = 0; u < 8; u++) a[u] = pj[u * rs2];
+#pragma unroll
+              for (int u = 0; u < 8; u++) { const double w = pw[u * G2]; a[u].x -= w * vk0; a[u].y -= w * vk1; pj[u * rs2] = a[u]; }
+            }
+            for (; i < n; i += G2, pj += rs2, pw += G2) { double2 a0 = pj[0]; const double w = pw[0]; a0.x -= w * vk0; a0.y -= w * vk1; pj[0] = a0; }
+          }
+        }
+      }
+      if (!paired && S.g < S.G && S.i + iq < n) {     // thread (g, k): column k >= iq of the rows g, g + G, ...
         const int k = S.i + iq, G = S.G, rs = G * js;
         const double vk = dv[k];
         int i = S.g;
@@ -1214,18 +1321,20 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
     int jp0 = 0;
     if constexpr (!xl_mp<MP>::lds) {
       // Blocked form (J in the scratch).  Re-absorbing the guessed rows one at a time costs three L2 passes over J per row (J^T n_p, the
-      // step direction, the reflection): 1.7 of the 8 Mcycles of a QP iteration at n = 150.  The reflections only depend on
-      // D = J^T N_W, so: (A) D for the first mb rows into LDS (a row of J for a box / rate row, one product for a dense row), (B)
-      // Householder QR of D there, column by column with the dependence test of the sequential path -- R and the reflectors --,
-      // (C) ONE pass over J applying the reflectors to every row (one wavefront per row, reflectors from LDS).  Same arithmetic
-      // as the loop below up to the order of the sums; rows beyond the LDS capacity go through that loop afterwards.
-      const int mcap = (L.o_du - L.x_el) / n;
-      const int mb = nprev < mcap ? nprev : mcap;
-      if (mb >= 4 && !D.xl_noblock) {
+      // step direction, the reflection): 84 k cycles per row at n = 300, 10 of the 55 Mcycles of a QP iteration there.  The reflections
+      // only depend on D = J^T N_W, so, mcap rows at a time (as many columns of D as fit between the end of the QP scratch and the LDS
+      // columns of R: the QP outputs in between are dead until the start has its x): (A) D for the block's rows into LDS (a row of J
+      // for a box / rate row, one product for a dense row), (B) Householder QR of D there, column by column with the dependence test
+      // of the sequential path -- R and the reflectors --, (C) ONE pass over J applying the block's reflectors to every row
+      // (xl_reflect_rows).  Same arithmetic as the loop below up to the order of the sums; a remainder of fewer than four rows goes
+      // through that loop.  (Until round 4 only the first block was taken: 5 rows at n = 300.)
+      const int mcap = (L.c_R - L.x_el) / n;
+      while (mcap >= 4 && nprev - jp0 >= 4 && iq < n && !D.xl_noblock) {
+        const int mb = nprev - jp0 < mcap ? nprev - jp0 : mcap, iq0 = iq;
         lptr Dl = lds + L.x_el, betas = zv, refc = rv, npn = acc;
         const int lane = TID & 63, wave = TID >> 6;
         for (int j = 0; j < mb; j++) {                    // (A) dense rows, one product each
-          const int p = q.prev[j];
+          const int p = q.prev[jp0 + j];
           if (ld_row(p).dense < 0) continue;              // uniform
           row_products(p);
           double sn = 0;
@@ -1236,7 +1345,7 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
         __syncthreads();
         for (int e = TID; e < mb * n; e += NT) {          // (A) box / rate rows: d = -+ (row c1 of J - row c1 - 2)
           const int j = e / n, i = e - j * n;
-          const DgRow Rw = ld_row(q.prev[j]);
+          const DgRow Rw = ld_row(q.prev[jp0 + j]);
           if (Rw.dense >= 0) continue;
           const int c1 = am_col(D, Rw.a, Rw.k, Rw.idx);
           const bool has0 = (Rw.type == DG_R_RATE_UB || Rw.type == DG_R_RATE_LB) && Rw.k > 0;
@@ -1260,7 +1369,7 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
           __syncthreads();
           for (int i = TID; i < iq; i += NT) R.set(i, iq, d[i]);
           if (TID == 0) {
-            const int p = q.prev[j];
+            const int p = q.prev[jp0 + j];
             R.set(iq, iq, delta); q.act[p] = 1; q.alist[iq] = p; uu[iq] = 0.0;
             if (beta != 0.0) d[iq] = v0;
             betas[iq] = beta; refc[iq] = (double)j;
@@ -1277,30 +1386,14 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
           iq++;
           __syncthreads();
         }
-        const int iqb = iq;
-        for (int i = wave; i < n; i += NT / 64) {          // (C) J <- J H_0 ... H_{iqb-1}, row by row
-          MP Ji = J + (int64_t)i * js;
-          double r[XL_NV];
-#pragma unroll
-          for (int h = 0; h < XL_NV; h++) { const int k = lane + 64 * h; r[h] = k < n ? Ji[k] : 0.0; }
-          for (int t = 0; t < iqb; t++) {
-            const double bt = betas[t];
-            if (bt == 0.0) continue;
-            clptr v = Dl + (int)refc[t] * n;
-            double vk[XL_NV], ds = 0;
-#pragma unroll
-            for (int h = 0; h < XL_NV; h++) { const int k = lane + 64 * h; vk[h] = (k >= t && k < n) ? v[k] : 0.0; ds += r[h] * vk[h]; }
-            ds = bt * wave_sum(ds);
-#pragma unroll
-            for (int h = 0; h < XL_NV; h++) r[h] -= ds * vk[h];
-          }
-#pragma unroll
-          for (int h = 0; h < XL_NV; h++) { const int k = lane + 64 * h; if (k < n) Ji[k] = r[h]; }
-        }
+        xl_reflect_rows(J, js, n, iq0, iq, betas, refc, Dl);          // (C) J <- J H_iq0 ... H_{iq-1}
         XSYNC();
-        jp0 = mb;
+        jp0 += mb;
       }
     }
+    PROF_END(PH_O_GT, pxw);
+    PROF_COUNT(PH_O_NACT, nprev);
+    PROF_BEGIN(pxs);
     for (int jp = jp0; jp < nprev && iq < n; jp++) {
       const int p = q.prev[jp];
       row_products(p);
@@ -1312,6 +1405,9 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
       __syncthreads();
       absorb(p, false, s_d2);
     }
+    PROF_END(PH_O_PMUL, pxs);
+    PROF_BEGIN(pxf);
+    int ndrop_ = 0;
     // c = J^T q  (dv)
     xl_jt_mul<MP>(J, js, n, S, 0, n, lds + L.q, dv, part);
     for (int guard = 0; guard <= n && iq > 0; guard++) {
@@ -1330,13 +1426,16 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
       umax = block_max(umax, red);
       if (!(umin < -1e-10 * (1.0 + umax))) break;
       // drop the row with the most negative multiplier; J's rotations act on c = J^T q as well
-      drop(kmin, dv);
+      drop(kmin, dv); ndrop_++;
     }
+    PROF_END(PH_O_GS, pxf);
+    PROF_COUNT(PH_O_UPD, ndrop_);
     // x = J1 y1 - J2 c2 ; multipliers clipped at 0 (rounding)
     for (int k = TID; k < n; k += NT) np[k] = k < iq ? zv[k] : -dv[k];
     __syncthreads();
     xl_j_mul<MP>(J, js, n, S, 0, n, np, x, part);
     for (int k = TID; k < iq; k += NT) uu[k] = fmax(uu[k], 0.0);
+    for (int r = TID; r < nc; r += NT) lhat[r] = 0.0;          // (the blocks of D reach over the QP outputs)
     __syncthreads();
     PROF_END(PH_Q_WARM, pxw);
   }
