@@ -7,7 +7,7 @@
 // (2020): Algorithm 1 (ADMM), 3.4 (termination, infeasibility certificates), 4 (polish), 5.1 (Ruiz equilibration), 5.2 (rho) --
 // with the OSQP 0.6 defaults (rho 0.1, sigma 1e-6, alpha 1.6, eps_abs = eps_rel 1e-3, eps_prim_inf = eps_dual_inf 1e-4, max_iter 4000,
 // scaling 10, adaptive rho with tolerance 5, check_termination 25, polish delta 1e-6 with 3 refinement steps), exactly as
-// oracle/osqp_restate.py (numpy) and oracle/osqp.hpp (C++) do; the parity tests compare this kernel with those.  The conic plugin poses
+// the test infrastructure's two CPU restatements (numpy: osqp_restate, C++: osqp.hpp) do; the parity tests compare this kernel with those.  The conic plugin poses
 // the problem with identity rows for the (absent) variable bounds ABOVE the G rows:  l <= [I; G] x <= u,  l = -inf, u = [inf; -g].
 // Stated deviations (shared with the two CPU restatements): adaptive-rho interval fixed at 25 iterations (OSQP derives it from the
 // wall-clock time of its first factorisation), every call starts from rho = 0.1 (inside CasADi's plugin the adapted rho persists).
