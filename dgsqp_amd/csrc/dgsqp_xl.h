@@ -208,6 +208,12 @@ __device__ __noinline__ bool dev_xl_psd_tri(const Ctx& c, gptr Qpd) {
   const int np2 = ((n >> 1) + 31) & ~31;
   const int G2 = pairs ? (NT / np2 < 6 ? NT / np2 : 6) : S.G, g2 = pairs ? TID / np2 : S.g, ip2 = TID - g2 * np2;
   int pc = 0;                           // columns in the panel
+#ifdef DG_PROF
+  long long tq1 = 0, tq2 = 0, tq3 = 0, tq4 = 0, tqc = clock64();
+#define TRI_T(acc) do { const long long now_ = clock64(); acc += now_ - tqc; tqc = now_; } while (0)
+#else
+#define TRI_T(acc) do {} while (0)
+#endif
   for (int k = 0; k + 2 < n; k++) {
     // (1) column k of the UPDATED matrix below the diagonal (= row k right of it: both triangles are kept)
     double vk[PB], wk[PB];
@@ -236,6 +242,7 @@ __device__ __noinline__ bool dev_xl_psd_tri(const Ctx& c, gptr Qpd) {
     }
     __syncthreads();
     for (int i = k + 1 + TID; i < n; i += NT) Vr[(int64_t)k * n + i] = vv[i];
+    TRI_T(tq1);
     if (beta != 0.0) {
       // (2) B0 v with the matrix as it stood at the panel's start (B symmetric: column i is read along rows, coalesced over i) ...
       if (pairs) {
@@ -290,6 +297,7 @@ __device__ __noinline__ bool dev_xl_psd_tri(const Ctx& c, gptr Qpd) {
         if (lane == 0) { e2[wave] = sw; e2[PB + wave] = sv; }
       }
       __syncthreads();
+      TRI_T(tq2);
       // (4) p = beta (B0 v - V (W^T v) - W (V^T v)),  w = p - (beta / 2) (p . v) v;  v and w join the panel
       double pvsum = 0;
       for (int i = k + 1 + TID; i < n; i += NT) {
@@ -308,6 +316,7 @@ __device__ __noinline__ bool dev_xl_psd_tri(const Ctx& c, gptr Qpd) {
     }
     pc++;
     __syncthreads();
+    TRI_T(tq3);
     if (pc == PB || k + 3 >= n) {
       // (5) B -= V W^T + W V^T on the trailing block (rows and columns > k), a rank-16 product on the matrix cores.  Tiles start at the
       // 16-row boundary at or below k + 1: the rows and columns <= k they touch are dead (read for the last time inside this panel)
@@ -320,8 +329,10 @@ __device__ __noinline__ bool dev_xl_psd_tri(const Ctx& c, gptr Qpd) {
       for (int e = TID; e < 2 * PB * n; e += NT) Pl[e] = 0.0;
       pc = 0;
       __syncthreads();
+      TRI_T(tq4);
     }
   }
+  PROF_COUNT(PH_T_COL, tq1); PROF_COUNT(PH_T_MV, tq2); PROF_COUNT(PH_T_W, tq3); PROF_COUNT(PH_T_UPD, tq4);
   if (TID == 0) {
     dv[n - 2] = Bm[(int64_t)(n - 2) * n + n - 2]; dv[n - 1] = Bm[(int64_t)(n - 1) * n + n - 1];
     ev[n - 2] = Bm[(int64_t)(n - 1) * n + n - 2]; ev[n - 1] = 0.0; tau[n - 2] = 0.0; tau[n - 1] = 0.0;
@@ -1391,8 +1402,8 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
         jp0 += mb;
       }
     }
-    PROF_END(PH_O_GT, pxw);
-    PROF_COUNT(PH_O_NACT, nprev);
+    PROF_END(PH_QW_BLK, pxw);
+    PROF_COUNT(PH_QW_NPREV, nprev);
     PROF_BEGIN(pxs);
     for (int jp = jp0; jp < nprev && iq < n; jp++) {
       const int p = q.prev[jp];
@@ -1405,7 +1416,7 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
       __syncthreads();
       absorb(p, false, s_d2);
     }
-    PROF_END(PH_O_PMUL, pxs);
+    PROF_END(PH_QW_SEQ, pxs);
     PROF_BEGIN(pxf);
     int ndrop_ = 0;
     // c = J^T q  (dv)
@@ -1428,8 +1439,8 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
       // drop the row with the most negative multiplier; J's rotations act on c = J^T q as well
       drop(kmin, dv); ndrop_++;
     }
-    PROF_END(PH_O_GS, pxf);
-    PROF_COUNT(PH_O_UPD, ndrop_);
+    PROF_END(PH_QW_FIN, pxf);
+    PROF_COUNT(PH_QW_DROPS, ndrop_);
     // x = J1 y1 - J2 c2 ; multipliers clipped at 0 (rounding)
     for (int k = TID; k < n; k += NT) np[k] = k < iq ? zv[k] : -dv[k];
     __syncthreads();

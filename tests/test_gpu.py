@@ -1141,6 +1141,35 @@ def test_xl_layout_long_horizon_n200(oracle):
         assert rel(res['u'][b], ref['u'][b]) < 1e-6 and rel(res['l'][b], ref['l'][b]) < 1e-5
 
 
+@pytest.mark.parametrize('kind', ['merge6', 'kb_curve_N50'])
+def test_xl_nearest_pd_with_many_negative_eigenvalues(oracle, kind):
+    """_nearestPD (DGSQP.py:601-626) of the XL layout when MOST of the curvature is negative: with multipliers 100 x the usual size the
+    game Hessian of the six-car merge has ~100 negative eigenvalues of 300, the N = 50 race ~90 of 200.  Until round 4 the tridiagonal
+    path handled 64 and left the rest to one-sided Jacobi sweeps; now every count goes through the blocked Householder reduction,
+    multisection, twisted factorisation, Gram-Schmidt and the rank-k correction on the matrix cores.  Checked against the oracle's
+    Jacobi eigh: the projected Hessian to 1e-10 of |Q|, its smallest eigenvalue at the floor."""
+    from dgsqp_amd.montecarlo import kinematic_racing_game, merge_game, sample_scenarios
+    from dgsqp_amd.solver import DGSQP, build_problem, build_params
+    g = merge_game(N=25, M=6) if kind == 'merge6' else kinematic_racing_game('curve', N=50)
+    P, par = build_problem(*g.solver_args()), tight_lsqr(build_params(g.params))
+    s = DGSQP(*g.solver_args(), print_method=None, lsqr_tol=1e-13)
+    assert s.dims.layout == 2
+    B = 3
+    x0, u_tm = sample_scenarios(g, B, seed=3)
+    rng = np.random.default_rng(5)
+    u = agent_major(u_tm) + 0.05 * rng.standard_normal((B, s.n))
+    l = 100.0 * np.maximum(0, rng.standard_normal((B, s.n_c_total)))
+    qp = s.qp_batch(x0, u, l)
+    for b in range(B):
+        o = oracle.evaluate(P, x0[b], u[b], l[b], 1)
+        w = np.linalg.eigvalsh(0.5 * (o['Q'] + o['Q'].T))
+        assert (w < 0).sum() > 64, (b, (w < 0).sum())
+        Qpd = oracle.nearest_pd(o['Q'], par.reg, par.eig_floor)
+        assert np.abs(qp['Qpd'][b] - Qpd).max() < 1e-10 * np.abs(o['Q']).max(), (b, np.abs(qp['Qpd'][b] - Qpd).max(), np.abs(o['Q']).max())
+        wd = np.linalg.eigvalsh(0.5 * (qp['Qpd'][b] + qp['Qpd'][b].T))
+        assert wd.min() > -1e-9 * np.abs(w).max(), (b, wd.min())
+
+
 def test_time_limit_status(oracle, games):
     """DGSQPParams.time_limit (DGSQP.py:470): checked at the end of every SQP iteration; with a limit of 0.1 microseconds every
     scenario that is not finished after its first iteration ends with 'time_limit' -- on the device and on the oracle alike."""

@@ -53,6 +53,10 @@ d['sq_wave_cycle_shares'] = {'waiting (SQ_WAIT_ANY)': t['SQ_WAIT_ANY'] / wc, 'is
 json.dump(d, open(sys.argv[1], 'w'), indent=1)
 PY
 done
+if [ -d $G/pmc_fetch_merge6_N25 ]; then
+  for tag in fetch write; do cp $(ls -t $G/pmc_${tag}_merge6_N25/*/*_counter_collection.csv | head -1) $D/${P}_pmc_${tag}_merge6_N25.csv; done
+  python3 $R/tools/pmc_summary.py $D/${P}_pmc_fetch_merge6_N25.csv $D/${P}_pmc_write_merge6_N25.csv merge6_N25 256 $D/${P}_pmc_merge6_N25.json > /dev/null
+fi
 python3 - $D $P <<'PY'
 import json, sys, glob, os
 D, P = sys.argv[1], sys.argv[2]

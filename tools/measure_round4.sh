@@ -76,5 +76,12 @@ for w in dyn_curve_N25 kb_curve_N25; do
     sed -i "/^pmc_${tag}_$w /d" $O/steps.txt; echo "pmc_${tag}_$w $?" >> $O/steps.txt
   done
 done
+# the XL layout keeps its matrices in the L2 / MALL scratch: HBM-side traffic of one launch of 256 six-car merges (n = 300)
+w=merge6_N25
+for pass in "fetch FETCH_SIZE" "write WRITE_SIZE"; do
+  set -- $pass; tag=$1; shift
+  rocprofv3 --pmc "$@" --output-format csv -d $O/pmc_${tag}_$w -- python3 $R/bench.py --workload $w --batch 256 --steps 2 --warmup 0 --group 1 --pipeline 1 --coop off --single-steps 0 --host-steps 0 --cpu-sample 0 > $O/pmc_${tag}_$w.json 2> $O/pmc_${tag}_$w.err
+  sed -i "/^pmc_${tag}_$w /d" $O/steps.txt; echo "pmc_${tag}_$w $?" >> $O/steps.txt
+done
 fi
 cat $O/steps.txt
