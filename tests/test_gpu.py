@@ -1141,6 +1141,39 @@ def test_xl_layout_long_horizon_n200(oracle):
         assert rel(res['u'][b], ref['u'][b]) < 1e-6 and rel(res['l'][b], ref['l'][b]) < 1e-5
 
 
+@pytest.mark.parametrize('M,N', [(3, 30), (5, 25), (2, 64)])
+def test_xl_sizes_between_the_configs(oracle, M, N):
+    """XL sizes the BASELINE configs do not name: n = 180 (last elimination panel of 4 pivots, last tridiagonalisation panel of 2
+    columns), n = 250 (panel of 10; five agents), n = 256 (a multiple of the panel width: no short panel; N = 64 is the horizon limit).
+    _nearestPD and the QP against the oracle on the linearisation of perturbed start points, then whole solves."""
+    from dgsqp_amd.montecarlo import kinematic_racing_game, sample_scenarios
+    from dgsqp_amd.solver import DGSQP, build_problem, build_params
+    g = kinematic_racing_game('curve', N=N, M=M)
+    P, par = build_problem(*g.solver_args()), tight_lsqr(build_params(g.params))
+    s = DGSQP(*g.solver_args(), print_method=None, lsqr_tol=1e-13)
+    assert s.n == 2 * N * M and s.dims.layout == 2
+    B = 4
+    x0, u_tm = sample_scenarios(g, B, seed=4)
+    u = agent_major(u_tm)
+    l0 = np.array([oracle.dual_init(P, par, x0[b], u[b]) for b in range(2)])
+    qp = s.qp_batch(x0[:2], u[:2], l0)
+    for b in range(2):
+        o = oracle.evaluate(P, x0[b], u[b], l0[b], 1)
+        Qpd = oracle.nearest_pd(o['Q'], par.reg, par.eig_floor)
+        du, lam, flag = oracle.qp(Qpd, o['q'], o['G'], o['g'])
+        assert np.abs(qp['Qpd'][b] - Qpd).max() < 1e-10 * np.abs(o['Q']).max(), (b, np.abs(qp['Qpd'][b] - Qpd).max())
+        assert qp['flag'][b] == flag, (b, qp['flag'][b], flag)
+        if flag == 0:
+            assert rel(qp['du'][b], du) < 1e-6 and np.array_equal(qp['lhat'][b] > 1e-9, lam > 1e-9), (b, rel(qp['du'][b], du))
+    res = s.solve_batch(x0, u_tm)
+    ref = oracle.solve_batch(P, par, x0, u, nthreads=B)
+    same = (res['status'] == ref['status']) & (res['num_iters'] == ref['num_iters']) & (res['qp_solves'] == ref['qp_solves'])
+    print(f'xl n={s.n}: identical {same.sum()}/{B}; status device {res["status"]} oracle {ref["status"]}; iterations {res["num_iters"]} {ref["num_iters"]}')
+    assert same.sum() >= B - 1, (res['status'], ref['status'], res['num_iters'], ref['num_iters'])
+    for b in np.where(same & (ref['status'] <= 1))[0]:
+        assert rel(res['u'][b], ref['u'][b]) < 1e-5, (b, rel(res['u'][b], ref['u'][b]))
+
+
 @pytest.mark.parametrize('kind', ['merge6', 'kb_curve_N50'])
 def test_xl_nearest_pd_with_many_negative_eigenvalues(oracle, kind):
     """_nearestPD (DGSQP.py:601-626) of the XL layout when MOST of the curvature is negative: with multipliers 100 x the usual size the
