@@ -88,8 +88,9 @@ dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restric
 #endif
     bool deferred = false;
     int its = 0;
-    if (dg_prob.par.variant == DGSQP_VARIANT_V2) dev_solve_v2(c, (cgptr)u_ws + b * dg_prob.n, b, O);
-    else deferred = dev_solve(c, (cgptr)u_ws + b * dg_prob.n, b, O, resume, (long long)tk, c.park.entries ? dev_bcast_u64(TID == 0 ? wall_clock64() : 0ull) : 0ull, &its);
+    const unsigned long long ticks0 = c.park.entries ? dev_bcast_u64(TID == 0 ? wall_clock64() : 0ull) : 0ull;
+    if (dg_prob.par.variant == DGSQP_VARIANT_V2) deferred = dev_solve_v2(c, (cgptr)u_ws + b * dg_prob.n, b, O, resume, (long long)tk, ticks0, &its);
+    else deferred = dev_solve(c, (cgptr)u_ws + b * dg_prob.n, b, O, resume, (long long)tk, ticks0, &its);
     if (resume && TID == 0) {
       DgParkEntry* e = &c.park.entries[resume - c.park.entries];
       e->t_done = wall_clock64() - AT_LOAD(&coop->t_first); e->final_its = its; e->final_qps = O.qp_solves ? O.qp_solves[b] : 0;
@@ -365,7 +366,7 @@ static bool coop_for_launch(dgsqp_solver* h, int grid) {
 }
 // Deferral of long scenarios for the cooperative launch about to be enqueued on h's stream (DgPark, dgsqp_device.h): a quarter of
 // the launch's scenarios may be deferred at a time (bounded by 16 GB of slots).  Off for launches that give every scenario its own
-// workgroup, for DG-SQP v2 and while logs are recorded.  (development knobs: DGSQP_DEFER = 0 switches it off, DGSQP_DEFER_MIN_IT,
+// workgroup and while logs are recorded (DG-SQP v2 is deferred like v1 since round 4).  (development knobs: DGSQP_DEFER = 0 switches it off, DGSQP_DEFER_MIN_IT,
 // DGSQP_DEFER_FACTOR override dgsqp_set_deferral.)
 static int park_for_launch(dgsqp_solver* h, bool coop, int grid, int64_t total, DgPark* out) {
   memset(out, 0, sizeof(*out));
@@ -375,7 +376,7 @@ static int park_for_launch(dgsqp_solver* h, bool coop, int grid, int64_t total, 
   { const char* e = getenv("DGSQP_DEFER"); if (e && atoi(e) == 0) min_it = 0; }
   { const char* e = getenv("DGSQP_DEFER_MIN_IT"); if (e) min_it = atoi(e); }
   { const char* e = getenv("DGSQP_DEFER_FACTOR"); if (e) factor = atof(e); }
-  if (!coop || min_it <= 0 || total <= (int64_t)grid || h->hp.par.variant == DGSQP_VARIANT_V2 || h->trace_cap > 0 || h->itlog_cap > 0) return DGSQP_OK;
+  if (!coop || min_it <= 0 || total <= (int64_t)grid || h->trace_cap > 0 || h->itlog_cap > 0) return DGSQP_OK;
   const size_t slot = (size_t)h->hp.L.total + (size_t)h->hp.ws_doubles;
   double frac = 0.25;
   { const char* e = getenv("DGSQP_DEFER_CAP_FRAC"); if (e) frac = atof(e); }

@@ -140,6 +140,8 @@ struct DgParkEntry {
   unsigned long long t_park, t_resume, t_done;   // diagnostic (dgsqp_deferral_log): 100 MHz ticks since the launch's first ticket
   int final_its, final_qps;
   double cond[3];                 // convergence measures of its last iteration before it was set aside (diagnostic)
+  double xd[6];                   // DG-SQP v2's further loop variables: reg, delta, both at the checkpoint, 100 MHz ticks spent solving so far
+  int xi[6];                      // ... m-step count, checkpoint counter / index, merit-memory ring (entries, head)
 };
 struct DgPark {
   DgParkEntry* entries;           // null: no deferral

@@ -1670,7 +1670,8 @@ __device__ inline long long dev_park_reserve(const Ctx& c, int sqp_it) {
   return (long long)dev_bcast_u64((unsigned long long)r);
 }
 // the scenario's state -- LDS arena, workgroup scratch, loop variables -- into slot idx
-__device__ __noinline__ void dev_park_store(const Ctx& c, unsigned int idx, int sqp_it, int rel_tol_its, int total_qp, long long ticket, unsigned long long key, const double* cond) {
+__device__ __noinline__ void dev_park_store(const Ctx& c, unsigned int idx, int sqp_it, int rel_tol_its, int total_qp, long long ticket, unsigned long long key, const double* cond,
+                                            const double* xd = nullptr, const int* xi = nullptr) {
   const DgProb& D = dg_prob;
   double* slot = c.park.store + (size_t)idx * c.park.slot_doubles;
   __syncthreads();
@@ -1696,6 +1697,8 @@ __device__ __noinline__ void dev_park_store(const Ctx& c, unsigned int idx, int 
     e->sqp_it = sqp_it; e->rel_tol_its = rel_tol_its; e->total_qp = total_qp; e->ticket = ticket; e->key = key;
     e->t_park = wall_clock64() - AT_LOAD(&c.coop->t_first);
     for (int i = 0; i < 3; i++) e->cond[i] = cond[i];
+    if (xd) for (int i = 0; i < 6; i++) e->xd[i] = xd[i];
+    if (xi) for (int i = 0; i < 6; i++) e->xi[i] = xi[i];
     __threadfence();
     __hip_atomic_store(&e->state, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(&c.coop->park_avail, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);

@@ -92,7 +92,10 @@ __device__ inline double v2_line_search(const Ctx& c, double mu, double phi_b, d
   return phi1;
 }
 
-__device__ inline void dev_solve_v2(const Ctx& c, cgptr u_ws, int64_t b, const SolveOutPtrs& O) {
+// Returns true when the scenario was DEFERRED (dev_solve's contract; round 4: v2's loop variables travel in DgParkEntry.xd / .xi, its
+// iteration records, merit memory and previous iterate are part of the stored scratch / LDS image).
+__device__ inline bool dev_solve_v2(const Ctx& c, cgptr u_ws, int64_t b, const SolveOutPtrs& O, const DgParkEntry* resume = nullptr,
+                                    long long ticket = 0, unsigned long long ticks0 = 0ull, int* iters_out = nullptr) {
   const DgProb& D = dg_prob;
   const DgLds& L = D.L;
   lptr lds = LP(0);
@@ -102,18 +105,21 @@ __device__ inline void dev_solve_v2(const Ctx& c, cgptr u_ws, int64_t b, const S
   gptr rec_ckpt = c.ws + D.ws_v2, rec_last = rec_ckpt + v2_rec_doubles(D), rec_cur = rec_last + v2_rec_doubles(D);
   gptr im1 = rec_cur + v2_rec_doubles(D);          // u_im1 [n], l_im1 [nc]
   __syncthreads();
-  if (TID == 0) { sc[DG_XVALID] = 0.0; sc[DG_QP_NPREV] = 0.0; sc[DG_REG] = par.reg; sc[DG_ITREC] = 0.0; }
-  for (int i = TID; i < n; i += NT) lds[L.u + i] = u_ws[i];
-  for (int r = TID; r < nc; r += NT) lds[L.l + r] = 0.0;
-  __syncthreads();
   const bool timed = par.time_limit >= 0.0;
-  const double t_start = timed ? dev_block_clock() : 0.0;
-  // dual warm start and the first entry of the merit memory (DGSQP_v2.py:333-343)
-  dev_evaluate(c, lds + L.u, 0.0, nullptr, false);
-  const double obj0 = par.merit_function == DGSQP_MERIT_SUM_OBJ_L1 ? dev_v2_sum_obj(c, false) : 0.0;      // (the dual start reuses the EVAL scratch)
-  dev_dual_init(c);
-  dev_log_iterate(c);
-  dev_stat_vector(c, lds + L.l, lds + L.d);
+  double t_start = 0.0, obj0 = 0.0;
+  if (!resume) {
+    if (TID == 0) { sc[DG_XVALID] = 0.0; sc[DG_QP_NPREV] = 0.0; sc[DG_REG] = par.reg; sc[DG_ITREC] = 0.0; }
+    for (int i = TID; i < n; i += NT) lds[L.u + i] = u_ws[i];
+    for (int r = TID; r < nc; r += NT) lds[L.l + r] = 0.0;
+    __syncthreads();
+    t_start = timed ? dev_block_clock() : 0.0;
+    // dual warm start and the first entry of the merit memory (DGSQP_v2.py:333-343)
+    dev_evaluate(c, lds + L.u, 0.0, nullptr, false);
+    obj0 = par.merit_function == DGSQP_MERIT_SUM_OBJ_L1 ? dev_v2_sum_obj(c, false) : 0.0;      // (the dual start reuses the EVAL scratch)
+    dev_dual_init(c);
+    dev_log_iterate(c);
+    dev_stat_vector(c, lds + L.l, lds + L.d);
+  }
   int mem_n = 0, mem_head = 0;                       // ring: entries sc[DG_V2_MEM0 + (mem_head + k) % size], k < mem_n
   const int mem_size = par.nms_memory_size < 1 ? 1 : (par.nms_memory_size > 16 ? 16 : par.nms_memory_size);
   auto mem_append = [&](double v) {
@@ -123,18 +129,24 @@ __device__ inline void dev_solve_v2(const Ctx& c, cgptr u_ws, int64_t b, const S
     __syncthreads();
   };
   auto mem_max = [&]() { double m = -INFINITY; for (int k = 0; k < mem_n; k++) m = fmax(m, sc[DG_V2_MEM0 + (mem_head + k) % mem_size]); return m; };
-  {
+  if (!resume) {
     double dd = 0, vio = 0;
     for (int i = TID; i < n; i += NT) dd += lds[L.d + i] * lds[L.d + i];
     for (int r = TID; r < nc; r += NT) vio += fmax(lds[L.g + r], 0.0);
     dd = block_sum(dd, lds + L.red); vio = block_sum(vio, lds + L.red);
     mem_append((par.merit_function == DGSQP_MERIT_SUM_OBJ_L1 ? obj0 : 0.5 * dd) + vio);      // nms_initial_reference_factor = 1 (DGSQP_v2.py:213)
+    for (int i = TID; i < n; i += NT) im1[i] = lds[L.u + i];
+    for (int r = TID; r < nc; r += NT) im1[n + r] = lds[L.l + r];
   }
-  for (int i = TID; i < n; i += NT) im1[i] = lds[L.u + i];
-  for (int r = TID; r < nc; r += NT) im1[n + r] = lds[L.l + r];
   double reg = par.reg, delta = 0.0, ckpt_delta = 0.0, ckpt_reg = reg;
   int ckpt_counter = 0, ckpt_index = 0;
   int sqp_it = 0, m_step_it = 0, rel_tol_its = 0, total_qp = 0, status = DGSQP_MAX_IT;
+  if (resume) {
+    sqp_it = resume->sqp_it; rel_tol_its = resume->rel_tol_its; total_qp = resume->total_qp;
+    reg = resume->xd[0]; delta = resume->xd[1]; ckpt_delta = resume->xd[2]; ckpt_reg = resume->xd[3];
+    m_step_it = resume->xi[0]; ckpt_counter = resume->xi[1]; ckpt_index = resume->xi[2]; mem_n = resume->xi[3]; mem_head = resume->xi[4];
+    if (timed) t_start = dev_block_clock() - resume->xd[4];      // the time it spent set aside does not count towards time_limit
+  }
   bool finished = false;
   double cond[3] = {0, 0, 0};
   while (true) {
@@ -253,7 +265,22 @@ __device__ inline void dev_solve_v2(const Ctx& c, cgptr u_ws, int64_t b, const S
     v2_rec_copy(c, rec_last, rec_cur);
     if (ckpt_index == sqp_it) v2_rec_copy(c, rec_ckpt, rec_cur);
     sqp_it++;
+    // deferral of long scenarios (dev_solve): set aside here, resumed at the top of the loop.  Unlike v1, also with a wall-clock limit (the
+    // v2 study always sets one, 600 s: comparison_study_barc/globals.py:40): the entry carries the time spent solving so far
+    if (!resume && !finished) {
+      const long long slot = dev_park_reserve(c, sqp_it);
+      if (slot >= 0) {
+        const unsigned long long now = dev_bcast_u64(TID == 0 ? wall_clock64() : 0ull);
+        const double sm = cond[2] == cond[2] ? fmin(cond[2], 1e30) : 1e30;
+        const unsigned long long key = (unsigned long long)((double)(now - ticks0) * (1.0 + 2.0 * log10(1.0 + sm)));
+        const double xd[6] = {reg, delta, ckpt_delta, ckpt_reg, timed ? dev_block_clock() - t_start : 0.0, 0.0};
+        const int xi[6] = {m_step_it, ckpt_counter, ckpt_index, mem_n, mem_head, 0};
+        dev_park_store(c, (unsigned int)slot, sqp_it, rel_tol_its, total_qp, ticket, key, cond, xd, xi);
+        return true;
+      }
+    }
   }
+  if (iters_out) *iters_out = sqp_it;
   // outputs
   __syncthreads();
   lds_d* ue = lds + L.e_ue;
@@ -269,4 +296,5 @@ __device__ inline void dev_solve_v2(const Ctx& c, cgptr u_ws, int64_t b, const S
     if (O.cond) for (int i = 0; i < 3; i++) O.cond[b * 3 + i] = cond[i];
   }
   __syncthreads();
+  return false;
 }

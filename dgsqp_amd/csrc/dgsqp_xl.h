@@ -950,6 +950,7 @@ __device__ __noinline__ bool xl_eliminate_blocked(gptr J, const int js, const in
       }
     }
     // ... and everything else of those rows on the matrix cores: tile row ti > jt has the tile columns [0, jt) and (jt, ti]
+    // (the tile loop as a function of its own and the multipliers read back from LDS were tried: 2.05 -> 2.5 Mcycles at n = 300)
     {
       const int base = (jt + 1) * jt / 2, ntile = T * (T - 1) / 2 - base;
       xl_mfma_rank16(J, js, n, ntile,
@@ -1171,7 +1172,7 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
   };
   // `rot` (optional): a vector c = J^T w held in LDS; the rotations that act on the columns of J act on its entries l .. iq the same
   // way, so it follows J without another pass over it (one pass over J per dropped row in the warm start's clean-up and in the main loop)
-  auto drop = [&](int l, lptr rot = nullptr) {   // remove the active constraint at position l, restore R upper triangular (rotations also on J)
+  auto drop = [&](int l, lptr rot = nullptr, lptr rot2 = nullptr) {   // remove the active constraint at position l, restore R upper triangular (rotations also on J)
     if (TID == 0) q.act[q.alist[l]] = 0;
     __syncthreads();
     // R loses column l: new column j = old column j + 1 (rows 0..j+1, upper Hessenberg from column l on).  Rows above l are copied
@@ -1216,14 +1217,15 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
       }
     }
     __syncthreads();
-    if (rot && TID == NT - 1) {      // (a thread that owns no row of J for n < NT)
-      double carry = rot[l];
+    if ((rot && TID == NT - 1) || (rot2 && TID == NT - 2)) {      // (threads that own no row of J for n < NT - 1)
+      lptr rv_ = TID == NT - 1 ? rot : rot2;
+      double carry = rv_[l];
       for (int k = l; k < iq; k++) {
-        const double cc = gc[k], s2 = gs[k], jb = rot[k + 1];
-        rot[k] = cc * carry + s2 * jb;
+        const double cc = gc[k], s2 = gs[k], jb = rv_[k + 1];
+        rv_[k] = cc * carry + s2 * jb;
         carry = -s2 * carry + cc * jb;
       }
-      rot[iq] = carry;
+      rv_[iq] = carry;
     }
     // the same rotations on the columns of J: every thread carries its own row through the whole sequence
     for (int i = TID; i < n; i += NT) {
@@ -1421,12 +1423,14 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
     int ndrop_ = 0;
     // c = J^T q  (dv)
     xl_jt_mul<MP>(J, js, n, S, 0, n, lds + L.q, dv, part);
+    // forward substitution R^T y1 = g_W once: a dropped row's rotations G turn R into [R'; 0] and y1 into the leading part of G y1
+    // (R'^T (G y1) = g_W' column by column), so y1 follows the rotations like c = J^T q does -- one triangular solve per drop, not two
+    for (int k = TID; k < n; k += NT) { acc[k] = k < iq ? q.g[q.alist[k]] : 0.0; zv[k] = 0.0; }
+    __syncthreads();
+    if (iq > 0 && TID < 64) xl_wave_fwdsub(R, iq, acc, zv);
+    __syncthreads();
     for (int guard = 0; guard <= n && iq > 0; guard++) {
-      // forward substitution R^T y1 = g_W, then back substitution R u = y1 + c1 (wavefront 0)
-      for (int k = TID; k < iq; k += NT) acc[k] = q.g[q.alist[k]];
-      __syncthreads();
-      if (TID < 64) xl_wave_fwdsub(R, iq, acc, zv);
-      __syncthreads();
+      // back substitution R u = y1 + c1 (wavefront 0)
       for (int k = TID; k < iq; k += NT) acc[k] = zv[k] + dv[k];
       __syncthreads();
       if (TID < 64) xl_wave_backsub(R, iq, acc, uu);
@@ -1437,7 +1441,7 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
       umax = block_max(umax, red);
       if (!(umin < -1e-10 * (1.0 + umax))) break;
       // drop the row with the most negative multiplier; J's rotations act on c = J^T q as well
-      drop(kmin, dv); ndrop_++;
+      drop(kmin, dv, zv); ndrop_++;
     }
     PROF_END(PH_QW_FIN, pxf);
     PROF_COUNT(PH_QW_DROPS, ndrop_);

@@ -905,6 +905,35 @@ def test_deferral_of_long_scenarios_is_bit_identical(games):
         solvers[0].set_deferral(8, 2.0)
 
 
+def test_deferral_of_long_v2_scenarios_is_bit_identical():
+    """The same for DG-SQP v2 (round 4): its loop carries more state -- decaying reg, trust radius, both at the checkpoint, m-step and
+    checkpoint counters, the merit-memory ring -- which travels in the deferral entry; the iteration records and the previous iterate
+    are part of the stored scratch image.  Outputs equal the plain launch bit for bit; every deferred scenario was resumed."""
+    from dgsqp_amd.montecarlo import dynamic_racing_game, sample_scenarios
+    from dgsqp_amd.solver import DGSQP, solve_batches
+    keys = ('status', 'num_iters', 'qp_solves', 'u', 'l', 'x', 'cond', 'cost')
+    g = dynamic_racing_game(N=15, rk4_substeps=4, game_def='curve', solver='v2')
+    B, G = 512, 4        # (nothing is deferred unless two more rounds of fresh scenarios wait behind the 256 workgroups)
+    solvers = [DGSQP(*g.solver_args(), print_method=None) for _ in range(G)]
+    batches = [sample_scenarios(g, B, seed=21 + i) for i in range(G)]
+    ref = []
+    for s, (x0, u) in zip(solvers, batches):
+        s.set_cooperative(0)
+        ref.append(s.solve_batch(x0, u))
+        s.set_cooperative(1)
+    for min_it, factor in ((8, 2.0), (4, 0.5)):
+        solvers[0].set_deferral(min_it, factor)
+        res = solve_batches(solvers, batches)
+        st = solvers[0].deferral_stats()
+        print('v2 deferral', (min_it, factor), st, 'kernel ms', res[0]['kernel_ms'], 'plain launches', [round(r['kernel_ms'], 1) for r in ref],
+              'iterations mean / max', ref[0]['num_iters'].mean(), ref[0]['num_iters'].max())
+        for r, r0 in zip(res, ref):
+            for k in keys:
+                assert np.array_equal(r[k], r0[k], equal_nan=True), (min_it, factor, k)
+        assert st['deferred'] == st['resumed'] and (st['deferred'] > 0 or min_it > 4), st
+    solvers[0].set_deferral(8, 2.0)
+
+
 def test_six_agent_merge_n300(oracle):
     """BASELINE configs[4]'s game at its own size: six cars on the highway merge (DGSQP_merge_monte_carlo.py:66-74, 253-261, 316-342
     generalised to six cars), N = 25: n = 300 decision variables, 36 / 63 / 39 rows per stage = 1,587 rows, 837 distinct dense

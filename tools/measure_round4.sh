@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 measurement artefacts -> gpurun_out/round4/ (copied into profiles/ by tools/collect_profiles4.sh).  Every step's exit code is
 # recorded in $O/steps.txt; collect_profiles4.sh refuses to copy the output of a step that failed.  PART=1|2|3 runs a third of it (the
-# whole set takes ~25 GPU-minutes).
+# whole set takes ~45 GPU-minutes); PART=5 = the XL bench lines of part 1 alone.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/round4
 PART=${PART:-123}
@@ -27,6 +27,9 @@ step bench_dyn_curve_N25_osqp_steady $O/bench_dyn_curve_N25_qp_osqp_steps120.jso
 step bench_kb_curve_N25 $O/bench_kb_curve_N25.json python bench.py --workload kb_curve_N25
 for w in kb_chicane_N25 kb_barc2_N15 merge_N20; do step bench_$w $O/bench_$w.json python bench.py --workload $w --cpu-sample 0; done
 for w in kb_curve_N25 kb_chicane_N25 kb_barc2_N15 merge_N20; do step bench_${w}_osqp $O/bench_${w}_qp_osqp.json python bench.py --workload $w --qp osqp --cpu-sample 0 --steps 24; done
+fi
+if [[ $PART == *1* || $PART == *5* ]]; then
+# ---- the XL games (PART=5: these lines alone, after a change that only touches dgsqp_xl.h)
 step bench_kb_curve3_N25 $O/bench_kb_curve3_N25.json python bench.py --workload kb_curve3_N25 --steps 48 --cpu-sample 0
 step bench_kb_barc3_N25 $O/bench_kb_barc3_N25_B512.json python bench.py --workload kb_barc3_N25 --batch 512 --steps 16 --single-steps 0 --host-steps 0 --cpu-sample 0
 step bench_kb_f1_N50 $O/bench_kb_f1_N50_B256.json python bench.py --workload kb_f1_N50 --batch 256 --steps 16 --single-steps 0 --host-steps 0 --cpu-sample 0
