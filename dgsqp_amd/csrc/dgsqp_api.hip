@@ -169,7 +169,7 @@ dg_qp_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__
   dev_load_tables();
   // The saved active set is deliberately NOT cleared between the scenarios one workgroup handles: with more scenarios
   // than workgroups every QP after the first is warm-started from an unrelated problem's active set (tests use this).
-  if (TID == 0) dg_lds[L.scal + DG_QP_NPREV] = 0.0;
+  if (TID == 0) { dg_lds[L.scal + DG_QP_NPREV] = 0.0; dg_lds[L.scal + DG_PSD_PD] = 0.0; }
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     c.x0 = (cgptr)x0 + b * dg_prob.nq;
     __syncthreads();

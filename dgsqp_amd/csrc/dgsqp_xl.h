@@ -347,6 +347,7 @@ __device__ __noinline__ bool dev_xl_psd_tri(const Ctx& c, gptr Qpd) {
   const double pivmin = fmax(1e-300, 1e-290 * tnorm * tnorm);
   __syncthreads();
   const int kneg = sturm_count(dv, e2, n, 0.0, pivmin);      // every thread, same result
+  PROF_COUNT(PH_E_KNEG, kneg); PROF_COUNT(PH_PD_TRY, kneg == 0 ? 1 : 0);
   if (kneg > XL_KMAX) return false;
   PROF_BEGIN(pe1);
   for (int j = wave; j < kneg; j += NT / 64) {

@@ -30,7 +30,7 @@ lib = s._lib
 if hasattr(lib, 'dgsqp_prof_read'):
     buf = (ctypes.c_ulonglong * 256)()
     nph = lib.dgsqp_prof_read(buf, 256)
-    names = ['rollout', 'deriv1', 'deriv2', 'chains', 'dp', 'jacobi', 'pform', 'qp', 'merit', 'lsqr', 'qtmul', 'gi_adds/drops', 'wgtotal', 'wgmax(clk,wall100MHz)', 'q_scan', 'q_y', 'q_dir', 'q_step', 'q_upd', 'q_refine', 'q_warm', 'w_build', 'w_mult', 'w_x', 'e_tri', 'e_bis', 'e_vec', 'e_back', 'e_kneg', 'c_nprev', 'c_mbuild', 'c_mwarm', 'c_mfinal', 'c_pruned_trials', 'h_inj', 'h_costate', 'h_contract', 'h_rows', 'osqp_scale', 'osqp_w', 'osqp_kinv', 'osqp_admm', 'osqp_iters(count)', 'osqp_check', 'osqp_pol_inv', 'osqp_pol_rows', 'osqp_pol_solve', 'osqp_nact(count)', 'osqp_it_gt', 'osqp_it_pmul', 'osqp_it_gs', 'osqp_it_upd', 'tri_column', 'tri_product', 'tri_w', 'tri_update', 'qwarm_blocks', 'qwarm_rows', 'qwarm_final', 'qwarm_nprev(count)', 'qwarm_drops(count)']
+    names = ['rollout', 'deriv1', 'deriv2', 'chains', 'dp', 'jacobi', 'pform', 'qp', 'merit', 'lsqr', 'qtmul', 'gi_adds/drops', 'wgtotal', 'wgmax(clk,wall100MHz)', 'q_scan', 'q_y', 'q_dir', 'q_step', 'q_upd', 'q_refine', 'q_warm', 'w_build', 'w_mult', 'w_x', 'e_tri', 'e_bis', 'e_vec', 'e_back', 'e_kneg', 'c_nprev', 'c_mbuild', 'c_mwarm', 'c_mfinal', 'c_pruned_trials', 'h_inj', 'h_costate', 'h_contract', 'h_rows', 'osqp_scale', 'osqp_w', 'osqp_kinv', 'osqp_admm', 'osqp_iters(count)', 'osqp_check', 'osqp_pol_inv', 'osqp_pol_rows', 'osqp_pol_solve', 'osqp_nact(count)', 'osqp_it_gt', 'osqp_it_pmul', 'osqp_it_gs', 'osqp_it_upd', 'tri_column', 'tri_product', 'tri_w', 'tri_update', 'qwarm_blocks', 'qwarm_rows', 'qwarm_final', 'qwarm_nprev(count)', 'qwarm_drops(count)', 'psd_pd(LDS: shortcut tried / hit rate; XL: calls / share without a negative eigenvalue)']
     tot = sum(buf[2 * i] for i in range(nph))
     for i in range(nph):
         if buf[2 * i + 1]:
