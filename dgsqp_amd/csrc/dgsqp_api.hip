@@ -234,6 +234,7 @@ struct dgsqp_solver {
   size_t park_last_cap = 0;           // deferral of long scenarios: slots the handle's last launch could use (0: it did not defer)
   int defer_min_it = 8;               // 0: off
   double defer_factor = 2.0;
+  bool defer_requested = false;       // dgsqp_set_deferral was called (DG-SQP v2 is only deferred on request)
   dgsqp_comm_state* comm = nullptr;   // RCCL communicator + record buffers (dgsqp_comm.h), owned by the handle
   std::string err;
 };
@@ -366,7 +367,7 @@ static bool coop_for_launch(dgsqp_solver* h, int grid) {
 }
 // Deferral of long scenarios for the cooperative launch about to be enqueued on h's stream (DgPark, dgsqp_device.h): a quarter of
 // the launch's scenarios may be deferred at a time (bounded by 16 GB of slots).  Off for launches that give every scenario its own
-// workgroup and while logs are recorded (DG-SQP v2 is deferred like v1 since round 4).  (development knobs: DGSQP_DEFER = 0 switches it off, DGSQP_DEFER_MIN_IT,
+// workgroup and while logs are recorded; DG-SQP v2 only after an explicit dgsqp_set_deferral (round 4).  (development knobs: DGSQP_DEFER = 0 switches it off, DGSQP_DEFER_MIN_IT,
 // DGSQP_DEFER_FACTOR override dgsqp_set_deferral.)
 static int park_for_launch(dgsqp_solver* h, bool coop, int grid, int64_t total, DgPark* out) {
   memset(out, 0, sizeof(*out));
@@ -377,6 +378,10 @@ static int park_for_launch(dgsqp_solver* h, bool coop, int grid, int64_t total, 
   { const char* e = getenv("DGSQP_DEFER_MIN_IT"); if (e) min_it = atoi(e); }
   { const char* e = getenv("DGSQP_DEFER_FACTOR"); if (e) factor = atof(e); }
   if (!coop || min_it <= 0 || total <= (int64_t)grid || h->trace_cap > 0 || h->itlog_cap > 0) return DGSQP_OK;
+  // DG-SQP v2: only when the caller asked for it (dgsqp_set_deferral).  Nearly every v2 scenario runs ~375 iterations and a few run
+  // thousands: setting those aside delays exactly the solves that decide the launch's length (48 batches of 512 as 8 x 3 launches:
+  // 409 scen/s without, 367 with; as one launch 404 / 411).
+  if (h->hp.par.variant == DGSQP_VARIANT_V2 && !h->defer_requested) return DGSQP_OK;
   const size_t slot = (size_t)h->hp.L.total + (size_t)h->hp.ws_doubles;
   double frac = 0.25;
   { const char* e = getenv("DGSQP_DEFER_CAP_FRAC"); if (e) frac = atof(e); }
@@ -711,6 +716,7 @@ int dgsqp_set_deferral(dgsqp_handle_t h, int min_iters, double factor) {
   if (!h || min_iters < 0 || !(factor >= 0.0) || factor > 1000.0) return DGSQP_E_ARG;
   h->defer_min_it = min_iters;
   h->defer_factor = factor;
+  h->defer_requested = true;
   return DGSQP_OK;
 }
 

@@ -322,7 +322,8 @@ int dgsqp_coop_stats(dgsqp_handle_t h, uint64_t* out6);
    is empty, the scenarios that have cost the most so far first.  The long solves of a launch's last batches thereby run while the
    chip still has other work.  Defaults: min_iters 8, factor 2.0; min_iters 0 switches it off.  Never applied while logs are recorded or in
    non-cooperative launches; DG-SQP v1 solves with a wall-clock limit (dgsqp_params_t.time_limit >= 0) are never deferred either.
-   DG-SQP v2 solves are (its study always sets a limit, 600 s): the time a scenario spends set aside does not count towards it.  The slots
+   DG-SQP v2 solves can be deferred too, but only after an explicit dgsqp_set_deferral (measured: it does not pay for v2's length
+   distribution); its study always sets a limit (600 s): the time a scenario spends set aside does not count towards it.  The slots
    (LDS image + scratch image per scenario: 0.65 MB for the 2-agent N = 25 games, up to 4 MB for the XL layouts) are one pool per
    device: sized for what the launch may defer (a quarter of its scenarios; 257 slots = 0.17 GB for a 1,024-scenario batch, 3.4 GB for
    a group of 20), grown geometrically by later, larger launches, never beyond DGSQP_DEFER_POOL_BYTES (environment; default 16 GiB,
