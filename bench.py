@@ -209,6 +209,10 @@ def main():
     for hh, (x0, u_am) in zip(handles, batches):
         assert lib.dgsqp_stage_inputs(hh, B, _ffi.dptr(x0), _ffi.dptr(u_am)) == 0, lib.dgsqp_last_error(hh)
 
+    # the deferral pool of the largest cooperative launch of the timed region (all `group` batches in one launch), sized before the warm-up:
+    # left to the launch itself, growing it from the warm-up's single batches is a hipFree + hipMalloc of gigabytes inside the timed region
+    if args.coop == 'auto':
+        lib.dgsqp_reserve_deferral(handles[0], B * max(1, min(args.group, n_batches, args.steps)))
     tm = _ffi.TimingT()
     for w in range(args.warmup):
         hh = handles[w % n_batches]

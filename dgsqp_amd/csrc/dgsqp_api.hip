@@ -720,6 +720,16 @@ int dgsqp_set_deferral(dgsqp_handle_t h, int min_iters, double factor) {
   return DGSQP_OK;
 }
 
+int dgsqp_reserve_deferral(dgsqp_handle_t h, int64_t scenarios) {
+  if (!h || scenarios < 1) return DGSQP_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  std::lock_guard<std::mutex> lk(g_reg_mutex);
+  DgPark unused;
+  const int rc = park_for_launch(h, true, h->max_grid, scenarios, &unused);      // (sizes the device's pool exactly as that launch would)
+  h->park_last_cap = 0;
+  return rc;
+}
+
 int dgsqp_deferral_stats(dgsqp_handle_t h, uint64_t* out2) {
   if (!h || !out2 || !h->d_coop) return DGSQP_E_ARG;
   HIPCHK(h, hipSetDevice(h->device));

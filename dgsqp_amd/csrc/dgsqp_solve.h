@@ -288,8 +288,43 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd, boo
   //          tested first: the pivots of a symmetric elimination of B (the Gauss-Jordan sweep of step 5, stopped at the first non-positive
   //          pivot) are all positive exactly when no eigenvalue is <= 0.  Then M = B + reg I as step 4a forms it from the same
   //          numbers -- identical results, without steps 2 and 3.  A failed test costs at most one sweep (0.2 Mcycles).
-  bool pd_fast = false;
-  if (scal[DG_PSD_PD] == 1.0) {       // block-uniform
+  bool pd_fast = false, have_P = false;
+  const double reg0 = dev_reg();
+  if (scal[DG_PSD_PD] == 1.0 && want_inverse && reg0 > 0.0 && !Qpd) {
+    // ... and cheaper still when P = M^-1 is wanted anyway: sweep M = B + reg I itself (pivots checked: M is positive definite) and
+    // bound its inverse, lambda_max(M^-1) <= ||M^-1||_inf.  If that is below 1 / reg, lambda_min(M) > reg, i.e. B has no eigenvalue
+    // <= 0: the sweep's result IS the P of the full path (same M, same sweep) -- one sweep instead of a test sweep plus that one.
+    // On configs[1] every call the shortcut takes is certified this way (||M^-1||_inf ~ 1.2 against 1 / reg = 1,000).
+#pragma unroll
+    for (int r = 0; r < RPT; r++) if (colok && hf + NH * r == jc) Br[r] += reg0;
+    bool okm = spd_sweep_regs<RPT, true>(Br, tws, n);
+    __syncthreads();
+    if (okm) {        // block-uniform
+      double cs = 0;
+#pragma unroll
+      for (int r = 0; r < RPT; r++) { const int i = hf + NH * r; if (colok && i < n) cs += fabs(Br[r]); }
+      Z[hf * 128 + jc] = cs;           // (the eigenvector area is free: NH x 128 partial column sums of the symmetric inverse)
+      __syncthreads();
+      double tot = 0.0;
+      if (TID < 128) {
+#pragma unroll
+        for (int h = 0; h < NH; h++) tot += Z[h * 128 + TID];
+        if (TID >= n) tot = 0.0;
+      }
+      const double nrm = block_max(tot, red);
+      okm = nrm < 0.999 / reg0;
+    }
+    if (okm) { pd_fast = true; have_P = true; }
+    else {
+#pragma unroll
+      for (int r = 0; r < RPT; r++) {
+        const int i = hf + NH * r;
+        Br[r] = (colok && i < n) ? 0.5 * (Qg[(int64_t)i * n + jc] + Qg[(int64_t)jc * n + i]) : 0.0;
+      }
+    }
+    PROF_COUNT(PH_T_COL, okm ? 1 : 0);
+  }
+  if (!have_P && scal[DG_PSD_PD] == 1.0) {       // block-uniform
     pd_fast = spd_sweep_regs<RPT, true>(Br, tws, n);
     __syncthreads();
     if (!pd_fast) {
@@ -431,16 +466,18 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd, boo
   __syncthreads();
   if (TID == 0) scal[DG_PSD_PD] = kneg == 0 ? 1.0 : 0.0;
   // ---- 4a. M = B + reg I (this thread's slice, back into Br); the negative part is corrected batch by batch
-  const double reg = dev_reg();
+  const double reg = reg0;
+  if (!have_P) {
 #pragma unroll
-  for (int r = 0; r < RPT; r++) {
-    const int i = hf + NH * r;
-    double a = 0.0;
-    if (colok && i < n) {
-      a = 0.5 * (Qg[(int64_t)i * n + jc] + Qg[(int64_t)jc * n + i]);
-      if (i == jc) a += reg;
+    for (int r = 0; r < RPT; r++) {
+      const int i = hf + NH * r;
+      double a = 0.0;
+      if (colok && i < n) {
+        a = 0.5 * (Qg[(int64_t)i * n + jc] + Qg[(int64_t)jc * n + i]);
+        if (i == jc) a += reg;
+      }
+      Br[r] = a;
     }
-    Br[r] = a;
   }
   for (int j0 = 0; j0 < kneg; j0 += PSD_KMAX) {
     const int kb = kneg - j0 < PSD_KMAX ? kneg - j0 : PSD_KMAX;
@@ -542,8 +579,8 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd, boo
   PROF_END(PH_JACOBI, pt_t);
   if (!want_inverse) return true;      // the classical QP works on M itself (written to Qpd above): no explicit inverse
   PROF_BEGIN(pt_s);
-  // ---- 5. symmetric Gauss-Jordan sweep in registers: after all pivots the slice holds -M^-1
-  spd_sweep_regs<RPT>(Br, tws, n);
+  // ---- 5. symmetric Gauss-Jordan sweep in registers: after all pivots the slice holds -M^-1 (the certified shortcut already has it)
+  if (!have_P) spd_sweep_regs<RPT>(Br, tws, n);
   if (big) {
     gptr Pp = c.ws + D.ws_P;
 #pragma unroll

@@ -331,6 +331,10 @@ int dgsqp_coop_stats(dgsqp_handle_t h, uint64_t* out6);
    launch in flight simply does not defer.  Nothing is
    deferred before 32 scenarios of the launch have finished nor when fewer than two rounds of fresh scenarios remain. */
 int dgsqp_set_deferral(dgsqp_handle_t h, int32_t min_iters, double factor);
+/* Sizes the device's deferral pool now for a cooperative launch of `scenarios` scenarios of h's game (what that launch would do itself
+   on entry: a hipFree + hipMalloc of up to several GB when the pool has to grow -- 1 to 100 ms that a caller may not want inside a
+   timed or latency-critical region).  Nothing in the reference. */
+int dgsqp_reserve_deferral(dgsqp_handle_t h, int64_t scenarios);
 /* Diagnostic: out2 = {scenarios deferred, scenarios resumed} of the handle's last cooperative launch (equal after the launch). */
 int dgsqp_deferral_stats(dgsqp_handle_t h, uint64_t* out2);
 /* Diagnostic: one row of 11 values per deferred scenario of the handle's last cooperative launch, at most cap_rows rows --

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 measurement artefacts -> gpurun_out/round4/ (copied into profiles/ by tools/collect_profiles4.sh).  Every step's exit code is
 # recorded in $O/steps.txt; collect_profiles4.sh refuses to copy the output of a step that failed.  PART=1|2|3 runs a third of it (the
-# whole set takes ~45 GPU-minutes); PART=5 = the XL bench lines of part 1 alone.
+# whole set takes ~45 GPU-minutes); PART=5 = the XL bench lines of part 1 alone, 7 = its other lines, 6 = the LDS-path phase files.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/round4
 PART=${PART:-123}
@@ -18,8 +18,8 @@ step() {   # step <name> <outfile> <command...>: run, record the exit code next 
   return 0
 }
 nproc > $O/nproc.txt
-if [[ $PART == *1* ]]; then
-# ---- bench lines.  The first one is the driver's own command; --qp osqp = the reference's own QP arithmetic
+if [[ $PART == *1* || $PART == *7* ]]; then
+# ---- bench lines (PART=7: the LDS / big-layout lines alone).  The first one is the driver's own command; --qp osqp = the reference's own QP arithmetic
 step bench_dyn_curve_N25_driver $O/bench_dyn_curve_N25_driver_steps20_warmup5.json python bench.py --gpus 1 --steps 20 --warmup 5
 step bench_dyn_curve_N25_default $O/bench_dyn_curve_N25.json python bench.py --cpu-sample 0
 step bench_dyn_curve_N25_osqp $O/bench_dyn_curve_N25_qp_osqp.json python bench.py --gpus 1 --steps 20 --warmup 5 --qp osqp
@@ -59,6 +59,15 @@ if [ -f dgsqp_amd/csrc/libdgsqp_hip_prof.so ]; then
   unset DGSQP_HIP_LIB
 else
   echo "prof_library_missing 1" >> $O/steps.txt
+fi
+fi
+if [[ $PART == *6* ]]; then      # the phase cycles of the LDS-path workloads alone (after a change that does not touch the XL kernels)
+if [ -f dgsqp_amd/csrc/libdgsqp_hip_prof.so ]; then
+  export DGSQP_HIP_LIB=$R/dgsqp_amd/csrc/libdgsqp_hip_prof.so
+  step phase_dyn $O/phase_cycles_dyn_curve_N25_B1024.txt python tools/gpu_time.py dyn 25 1024
+  DGSQP_QP_METHOD=osqp step phase_dyn_osqp $O/phase_cycles_dyn_curve_N25_B1024_qp_osqp.txt python tools/gpu_time.py dyn 25 1024
+  step phase_kb $O/phase_cycles_kb_curve_N25_B1024.txt python tools/gpu_time.py kbcurve 25 1024
+  unset DGSQP_HIP_LIB
 fi
 fi
 if [[ $PART == *3* ]]; then
