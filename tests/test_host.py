@@ -473,3 +473,19 @@ def test_layout_plan_of_the_supported_games():
     for g in (merge_game(N=27, M=6), kinematic_racing_game('curve', N=41, M=4)):      # n = 324, 328 > 320
         with pytest.raises(ValueError, match='not supported yet|LDS'):
             plan(build_problem(*g.solver_args()), build_params(g.params))
+
+
+def test_blocked_elimination_scheme_matches_the_column_form():
+    """The panel scheme of the XL layout's elimination (csrc/dgsqp_xl.h: xl_eliminate_blocked -- 16 pivots per pass, rank-16 update of the
+    tiles below, garbage above the diagonal) restated in numpy against the column-by-column form it replaces: sizes with a short last
+    panel, a full one, and a single panel.  (The device kernel itself is held to the oracle by the -m gpu tests.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('xl_proto', ROOT / 'tools' / 'xl_blocked_elimination_proto.py')
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rng = np.random.default_rng(3)
+    for n in (12, 44, 48):
+        A = rng.standard_normal((n, n))
+        M = A @ A.T + n * np.eye(n)
+        a, b = m.column_form(M), m.blocked(M, rng)
+        assert np.abs(np.tril(a) - np.tril(b)).max() < 1e-11 * np.abs(a).max(), n
