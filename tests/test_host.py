@@ -489,3 +489,65 @@ def test_blocked_elimination_scheme_matches_the_column_form():
         M = A @ A.T + n * np.eye(n)
         a, b = m.column_form(M), m.blocked(M, rng)
         assert np.abs(np.tril(a) - np.tril(b)).max() < 1e-11 * np.abs(a).max(), n
+
+
+IN_SCOPE_MODULES = ('DGSQP.solvers.DGSQP', 'DGSQP.solvers.DGSQP_v2', 'DGSQP.solvers.PID', 'DGSQP.solvers.solver_types', 'DGSQP.types',
+                    'DGSQP.dynamics.dynamics_models', 'DGSQP.dynamics.model_types', 'DGSQP.tracks.track_lib')
+OUT_OF_SCOPE_NAMES = {'IBRParams', 'ALGAMESParams', 'CALTVMPCParams', 'PATHMCPParams',                     # parameters of solvers SURVEY section 2 leaves out
+                      'CasadiKinematicBicycleProgressAugmented', 'CasadiDynamicBicycleProgressAugmented', 'CasadiDynamicCLBicycle',
+                      'CasadiKinematicUnicycleCombined', 'load_tum_raceline', 'load_mpclab_raceline'}
+
+
+def test_reference_module_paths_resolve_to_this_package():
+    """the scripts' import block (scripts/DGSQP_ALGAMES_monte_carlo_curve.py:5-15, minus IBR / ALGAMES /
+    casadi, which are out of scope) works unchanged against this repo, and the names are this package's.  Run in a fresh
+    interpreter: other tests import the REFERENCE's DGSQP package from /root/reference under the same name."""
+    block = '''
+from DGSQP.solvers.DGSQP import DGSQP
+from DGSQP.solvers.PID import PIDLaneFollower
+from DGSQP.solvers.solver_types import DGSQPParams, PIDParams
+from DGSQP.types import VehicleState, VehicleActuation, Position, ParametricPose, OrientationEuler, BodyLinearVelocity, BodyAngularVelocity
+from DGSQP.dynamics.dynamics_models import CasadiKinematicBicycleCombined, CasadiDecoupledMultiAgentDynamicsModel
+from DGSQP.dynamics.model_types import KinematicBicycleConfig, MultiAgentModelConfig
+from DGSQP.tracks.track_lib import *
+import dgsqp_amd, dgsqp_amd.solver, dgsqp_amd.tracks, dgsqp_amd.pid
+assert DGSQP is dgsqp_amd.solver.DGSQP and PIDLaneFollower is dgsqp_amd.pid.PIDLaneFollower
+assert DGSQPParams is dgsqp_amd.DGSQPParams and VehicleState is dgsqp_amd.VehicleState
+assert CurveTrack is dgsqp_amd.tracks.CurveTrack and get_track is dgsqp_amd.tracks.get_track
+from DGSQP.solvers.DGSQP_v2 import DGSQP as DGSQPv2
+from DGSQP.solvers.solver_types import DGSQPV2Params
+import dgsqp_amd.solver_v2
+assert DGSQPv2 is dgsqp_amd.solver_v2.DGSQP
+# what the curve script builds before it defines its CasADi cost functions (curve.py:140-172)
+track = CurveTrack(enter_straight_length=1, curve_length=8, curve_swept_angle=3.141592653589793 / 4, exit_straight_length=5, width=2.0, slack=0.8)
+cfg = KinematicBicycleConfig(dt=0.1, model_name='kinematic_bicycle_cl', noise=False, discretization_method='euler', code_gen=False)
+car = CasadiKinematicBicycleCombined(0.0, cfg, track=track)
+joint = CasadiDecoupledMultiAgentDynamicsModel(0.0, [car, car], MultiAgentModelConfig(dt=0.1, code_gen=False))
+assert (joint.n_q, joint.n_u) == (12, 4)
+p = DGSQPParams(dt=0.1, N=25, nonmono_ls=True, reg=0.0, beta=0.01)
+print('ok')
+'''
+    out = subprocess.run([sys.executable, '-c', block], cwd='/tmp', env=dict(os.environ, PYTHONPATH=str(ROOT)), capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-2000:]
+
+
+@pytest.mark.skipif(not pathlib.Path('/root/reference/scripts').exists(), reason='reference tree only exists in the build container')
+def test_every_in_scope_import_of_the_reference_scripts_resolves():
+    """Every ``from DGSQP.<in-scope module> import a, b, c`` line of the reference's scripts resolves against the alias package,
+    except the names that belong to components SURVEY.md section 2 leaves out (listed above, each must really be absent)."""
+    pat = re.compile(r'^from (DGSQP[\w.]*) import (.+)$')
+    wanted = {}
+    for f in sorted(pathlib.Path('/root/reference/scripts').rglob('*.py')):
+        for line in f.read_text().splitlines():
+            m = pat.match(line.strip())
+            if m and m.group(1) in IN_SCOPE_MODULES and m.group(2).strip() != '*':
+                for nm in m.group(2).split(','):
+                    wanted.setdefault(m.group(1), set()).add(nm.split(' as ')[0].strip())
+    assert len(wanted) >= 7
+    code = 'import importlib, json, sys\nw = json.loads(sys.argv[1])\nmissing = [m + "." + n for m in w for n in w[m] if not hasattr(importlib.import_module(m), n)]\nprint(json.dumps(missing))'
+    import json
+    out = subprocess.run([sys.executable, '-c', code, json.dumps({k: sorted(v) for k, v in wanted.items()})], cwd='/tmp',
+                         env=dict(os.environ, PYTHONPATH=str(ROOT)), capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    missing = {m.rsplit('.', 1)[1] for m in json.loads(out.stdout)}
+    assert missing <= OUT_OF_SCOPE_NAMES, missing - OUT_OF_SCOPE_NAMES

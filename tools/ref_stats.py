@@ -22,7 +22,11 @@ GAMES = {'dyn_curve_N25': (lambda: mc.dynamic_racing_game(N=25, rk4_substeps=10)
          'kb_chicane_N25': (lambda: mc.kinematic_racing_game('chicane', N=25), 1),
          'kb_chicane_N15': (lambda: mc.kinematic_racing_game('chicane', N=15), 1),
          'kb_barc2_N15': (lambda: mc.barc_racing_game(N=15, M=2), 0),
-         'merge_N20': (lambda: mc.merge_game(N=20), 1)}
+         'merge_N20': (lambda: mc.merge_game(N=20), 1),
+         # BASELINE configs[2], [3], [4] at their own sizes (round 5: the yardstick for the XL layouts)
+         'kb_barc3_N25': (lambda: mc.barc_racing_game(N=25, M=3), 0),
+         'kb_f1_N50': (lambda: mc.f1_racing_game(N=50), 0),
+         'merge6_N25': (lambda: mc.merge_game(N=25, M=6), 1)}
 CODE = {'conv_abs_tol': 0, 'conv_rel_tol': 1, 'max_it': 2, 'diverged': 3, 'exception': 4}
 
 
