@@ -724,9 +724,16 @@ int dgsqp_reserve_deferral(dgsqp_handle_t h, int64_t scenarios) {
   if (!h || scenarios < 1) return DGSQP_E_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   std::lock_guard<std::mutex> lk(g_reg_mutex);
+  { const int rcw = wait_idle(h); if (rcw) return rcw; }
+  DgParkPool& pool = g_park[h->device & 63];
+  dgsqp_solver* const owner = pool.owner;
+  const unsigned long long owner_gen = pool.owner_gen;
   DgPark unused;
   const int rc = park_for_launch(h, true, h->max_grid, scenarios, &unused);      // (sizes the device's pool exactly as that launch would)
   h->park_last_cap = 0;
+  // no launch follows: the pool must not look taken by this handle's NEXT launch (a plain one would make other handles' cooperative
+  // launches find it "busy" and run without deferral).  A re-allocation reset the owner anyway; otherwise put back what was there.
+  if (g_park[h->device & 63].owner == h) { g_park[h->device & 63].owner = owner == h ? nullptr : owner; g_park[h->device & 63].owner_gen = owner == h ? 0 : owner_gen; }
   return rc;
 }
 

@@ -34,7 +34,7 @@
 #define OSQP_MAX_SCALING 1e4
 #define OSQP_RHO_MIN 1e-6
 #define OSQP_RHO_MAX 1e6
-enum { OSQP_SOLVED = 1, OSQP_SOLVED_INACCURATE = 2, OSQP_MAX_ITER = -2, OSQP_PRIMAL_INFEASIBLE = -3, OSQP_DUAL_INFEASIBLE = -4, OSQP_NAN_DATA = -10 };
+enum { OSQP_SOLVED = 1, OSQP_SOLVED_INACCURATE = 2, OSQP_PRIMAL_INFEASIBLE_INACCURATE = 3, OSQP_DUAL_INFEASIBLE_INACCURATE = 4, OSQP_MAX_ITER = -2, OSQP_PRIMAL_INFEASIBLE = -3, OSQP_DUAL_INFEASIBLE = -4, OSQP_NAN_DATA = -10 };
 
 __device__ inline double osqp_limit(double v) { v = v < OSQP_MIN_SCALING ? 1.0 : v; return fmin(v, OSQP_MAX_SCALING); }
 
@@ -709,14 +709,16 @@ __device__ __noinline__ void osqp_iterate(const Ctx& c, double rho, double cc) {
 }
 
 // The termination tests of a check iteration (section 3.4) and the ratios of the rho rule (5.2); results in scal[DG_OSQP_CHK ..].
-__device__ __noinline__ void osqp_check(const Ctx& c, double cc) {
+// `approx`: the check at the iteration limit -- OSQP then repeats check_termination with every tolerance times ten
+// (check_termination(work, approximate = 1)); the infeasibility certificates at 10 x eps_inf come out of the same products: flags 4, 8.
+__device__ __noinline__ void osqp_check(const Ctx& c, double cc, bool approx) {
   const DgProb& D = dg_prob;
   const int n = D.n, nc = D.nc;
   const OsqpPtrs o = osqp_ptrs(c);
   const double eps_abs = 1e-3, eps_rel = 1e-3, eps_inf = 1e-4, cinv = 1.0 / cc;
   PROF_BEGIN(po5);
     // primal infeasibility certificate (uses delta y, which the residual products overwrite)
-    bool pinf = false;
+    bool pinf = false, pinf10 = false, dinf10 = false;
     {
       double nrm = 0, lhs = 0;
       for (int r = TID; r < nc; r += NT) {
@@ -737,6 +739,7 @@ __device__ __noinline__ void osqp_check(const Ctx& c, double cc) {
         for (int j = TID; j < n; j += NT) mx = fmax(mx, __builtin_fabs(o.xt[j] / o.Dv[j]));
         mx = block_max(mx, o.red);
         pinf = mx < eps_inf * nrm;
+        pinf10 = approx && lhs < -10.0 * eps_inf * nrm && mx < 10.0 * eps_inf * nrm;
       }
     }
     // Ax (G rows) -> w, Px -> rhs, A'y -> xt
@@ -799,12 +802,28 @@ __device__ __noinline__ void osqp_check(const Ctx& c, double cc) {
           }
           dinf = !__syncthreads_or(viol);
         }
+        if (approx && qdx < -cc * 10.0 * eps_inf * nrm && mx < cc * 10.0 * eps_inf * nrm) {      // block-uniform
+          const double e10 = 10.0 * eps_inf;
+          int viol = 0;
+          for (int r = TID; r < nc; r += NT) {
+            const double er = o.E[r], us = er * fmin(-o.g[r], OSQP_INFTY), ls = -OSQP_INFTY * er, adx = o.w[r] / er;
+            const bool ok_u = us > OSQP_INFTY * OSQP_MIN_SCALING || adx < e10 * nrm;
+            const bool ok_l = ls < -OSQP_INFTY * OSQP_MIN_SCALING || adx > -e10 * nrm;
+            viol |= !(ok_u && ok_l);
+          }
+          for (int j = TID; j < n; j += NT) {
+            const bool inf_b = o.EI[j] * OSQP_INFTY > OSQP_INFTY * OSQP_MIN_SCALING;
+            const double adx = o.Dv[j] * o.dx[j];
+            viol |= !((inf_b || adx < e10 * nrm) && (inf_b || adx > -e10 * nrm));
+          }
+          dinf10 = !__syncthreads_or(viol);
+        }
       }
     }
     __syncthreads();
     if (TID == 0) {
       o.scal[DG_OSQP_CHK] = pri_res; o.scal[DG_OSQP_CHK + 1] = dua_res; o.scal[DG_OSQP_CHK + 2] = eps_p; o.scal[DG_OSQP_CHK + 3] = eps_d;
-      o.scal[DG_OSQP_CHK + 4] = ad_pr; o.scal[DG_OSQP_CHK + 5] = ad_dr; o.scal[DG_OSQP_CHK + 6] = (pinf ? 1.0 : 0.0) + (dinf ? 2.0 : 0.0);
+      o.scal[DG_OSQP_CHK + 4] = ad_pr; o.scal[DG_OSQP_CHK + 5] = ad_dr; o.scal[DG_OSQP_CHK + 6] = (pinf ? 1.0 : 0.0) + (dinf ? 2.0 : 0.0) + (pinf10 ? 4.0 : 0.0) + (dinf10 ? 8.0 : 0.0);
     }
     __syncthreads();
     PROF_END(PH_O_CHECK, po5);
@@ -837,7 +856,7 @@ __device__ __noinline__ int dev_qp_osqp_t(const Ctx& c) {
   __syncthreads();
   // The G rows have  l = -inf -> -1e30 E_r,  u = E_r min(-g_r, 1e30):  never equalities (rho_vec = rho on all of them), never "loose"
   // unless -g_r >= 1e26 / E_r (then OSQP gives the row rho_min; not reproduced: no game produces such a row)
-  int status = OSQP_MAX_ITER, iters = 0;
+  int status = OSQP_MAX_ITER, iters = 0, approx_flags = 0;
   double pri_res = INFINITY, dua_res = INFINITY, eps_p = 0, eps_d = 0;
   bool need_kinv = true;
   PROF_BEGIN(po4);
@@ -854,13 +873,14 @@ __device__ __noinline__ int dev_qp_osqp_t(const Ctx& c) {
     osqp_iterate(c, rho, cc);
     if (it % check_every != 0) continue;
     // ---- termination (section 3.4) every 25 iterations; the same products serve the rho adaptation (section 5.2)
-    osqp_check(c, cc);
+    osqp_check(c, cc, it == max_iter);
     pri_res = o.scal[DG_OSQP_CHK]; dua_res = o.scal[DG_OSQP_CHK + 1]; eps_p = o.scal[DG_OSQP_CHK + 2]; eps_d = o.scal[DG_OSQP_CHK + 3];
     const double ad_pr = o.scal[DG_OSQP_CHK + 4], ad_dr = o.scal[DG_OSQP_CHK + 5];
     const int flags = (int)o.scal[DG_OSQP_CHK + 6];
     if (pri_res <= eps_p && dua_res <= eps_d) { status = OSQP_SOLVED; break; }
     if (flags & 1) { status = OSQP_PRIMAL_INFEASIBLE; break; }
     if (flags & 2) { status = OSQP_DUAL_INFEASIBLE; break; }
+    approx_flags = flags;
     // rho adaptation (interval fixed at 25)
     {
       const double rho_new = fmin(fmax(rho * sqrt(ad_pr / (ad_dr + 1e-10)), OSQP_RHO_MIN), OSQP_RHO_MAX);
@@ -877,7 +897,13 @@ __device__ __noinline__ int dev_qp_osqp_t(const Ctx& c) {
   PROF_END(PH_O_ADMM, po4);
   PROF_COUNT(PH_O_ITERS, iters);
   // iteration limit: OSQP re-checks with 10x the tolerances ("solved inaccurate"); iteration 4000 is a check iteration, its residuals are at hand
-  if (status == OSQP_MAX_ITER && iters == max_iter && pri_res <= 10.0 * eps_p && dua_res <= 10.0 * eps_d) status = OSQP_SOLVED_INACCURATE;
+  // ... and the two infeasibility certificates with 10x their tolerance, in OSQP's order (flags 4, 8 of the last check): an "inaccurate"
+  // infeasibility verdict returns NaN like an accurate one (osqp's store_solution), i.e. the failing flag here
+  if (status == OSQP_MAX_ITER && iters == max_iter) {
+    if (pri_res <= 10.0 * eps_p && dua_res <= 10.0 * eps_d) status = OSQP_SOLVED_INACCURATE;
+    else if (approx_flags & 4) status = OSQP_PRIMAL_INFEASIBLE_INACCURATE;
+    else if (approx_flags & 8) status = OSQP_DUAL_INFEASIBLE_INACCURATE;
+  }
   __syncthreads();
   // ---- the ADMM iterate, unscaled, is the answer unless the polish improves on it
   for (int j = TID; j < n; j += NT) du[j] = o.Dv[j] * o.x[j];
@@ -895,7 +921,8 @@ __device__ __noinline__ int dev_qp_osqp_t(const Ctx& c) {
   for (int r = TID; r < nc; r += NT) nonfinite |= !(__builtin_fabs(lhat[r]) < INFINITY);
   nonfinite = __syncthreads_or(nonfinite);
   PROF_END(PH_QP, pt_qp);
-  return (nonfinite || status == OSQP_PRIMAL_INFEASIBLE || status == OSQP_DUAL_INFEASIBLE || status == OSQP_NAN_DATA) ? 1 : 0;
+  return (nonfinite || status == OSQP_PRIMAL_INFEASIBLE || status == OSQP_DUAL_INFEASIBLE || status == OSQP_PRIMAL_INFEASIBLE_INACCURATE ||
+          status == OSQP_DUAL_INFEASIBLE_INACCURATE || status == OSQP_NAN_DATA) ? 1 : 0;
 }
 __device__ inline int dev_qp_osqp(const Ctx& c) {
   const int n = dg_prob.n;

@@ -287,8 +287,9 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd, boo
   //          none -- after 0.5 Mcycles of tridiagonalisation.  When the scenario's PREVIOUS call found none either, the inertia is
   //          tested first: the pivots of a symmetric elimination of B (the Gauss-Jordan sweep of step 5, stopped at the first non-positive
   //          pivot) are all positive exactly when no eigenvalue is <= 0.  Then M = B + reg I as step 4a forms it from the same
-  //          numbers -- identical results, without steps 2 and 3.  A failed test costs at most one sweep (0.2 Mcycles).
-  bool pd_fast = false, have_P = false;
+  //          numbers -- identical results, without steps 2 and 3.  A failed test costs one sweep (0.2 Mcycles), two when the certified
+  //          sweep of M passes its pivots but misses the norm bound and the inertia sweep of B then fails.
+  bool pd_fast = false, have_P = false, m_pivot_failed = false;
   const double reg0 = dev_reg();
   if (scal[DG_PSD_PD] == 1.0 && want_inverse && reg0 > 0.0 && !Qpd) {
     // ... and cheaper still when P = M^-1 is wanted anyway: sweep M = B + reg I itself (pivots checked: M is positive definite) and
@@ -299,6 +300,7 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd, boo
     for (int r = 0; r < RPT; r++) if (colok && hf + NH * r == jc) Br[r] += reg0;
     bool okm = spd_sweep_regs<RPT, true>(Br, tws, n);
     __syncthreads();
+    m_pivot_failed = !okm;        // M = B + reg I is not positive definite => neither is B: the inertia sweep below would fail too
     if (okm) {        // block-uniform
       double cs = 0;
 #pragma unroll
@@ -324,7 +326,7 @@ __device__ __noinline__ bool dev_psd_inverse_tridiag(const Ctx& c, gptr Qpd, boo
     }
     PROF_COUNT(PH_T_COL, okm ? 1 : 0);
   }
-  if (!have_P && scal[DG_PSD_PD] == 1.0) {       // block-uniform
+  if (!have_P && !m_pivot_failed && scal[DG_PSD_PD] == 1.0) {       // block-uniform (only the NORM bound can have failed above: B may still be positive definite)
     pd_fast = spd_sweep_regs<RPT, true>(Br, tws, n);
     __syncthreads();
     if (!pd_fast) {

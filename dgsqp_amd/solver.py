@@ -12,6 +12,7 @@ from __future__ import annotations
 import copy
 import ctypes as C
 import time
+import warnings
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -154,6 +155,9 @@ def build_problem(joint_dynamics: CasadiDecoupledMultiAgentDynamicsModel,
 QP_METHODS = {'active_set': 0, 'osqp': 1}
 
 
+_WARNED_OSQP_DEFAULT = False
+
+
 def resolve_qp_method(params, qp_method: Optional[str]) -> int:
     """How ``_solve_qp`` (DGSQP.py:232-266) is computed on the device -- ``dgsqp_params_t.qp_method``.
 
@@ -163,9 +167,15 @@ def resolve_qp_method(params, qp_method: Optional[str]) -> int:
     (csrc/dgsqp_osqp.h).  ``qp_method=None`` picks by ``params.qp_solver``: the exact solvers map to 'active_set'; 'osqp' maps to
     'active_set' as well -- the KKT point OSQP's polish aims at, the faster kernels -- unless the caller opts into
     ``qp_method='osqp'`` to follow the reference's own iterates."""
+    if params.qp_solver not in ('osqp', 'qrqp', 'qpoases', 'cplex'):         # whatever qp_method says: the reference would run another algorithm
+        raise ValueError(f'Unsupported QP solver {params.qp_solver}')           # (superscs: a conic splitting solver, not restated)
     if qp_method is None:
-        if params.qp_solver not in ('osqp', 'qrqp', 'qpoases', 'cplex'):
-            raise ValueError(f'Unsupported QP solver {params.qp_solver}')       # (superscs: a conic splitting solver, not restated)
+        global _WARNED_OSQP_DEFAULT
+        if params.qp_solver == 'osqp' and not _WARNED_OSQP_DEFAULT:
+            _WARNED_OSQP_DEFAULT = True
+            warnings.warn("DGSQPParams.qp_solver='osqp' is solved with the exact active-set QP (the KKT point OSQP's polish aims at); its iterates "
+                          "differ from OSQP's by 1e-3..1e-6 per QP.  Pass qp_method='osqp' to DGSQP(...) for OSQP's own ADMM + polish arithmetic, "
+                          "or qp_method='active_set' to silence this note.", stacklevel=3)
         return QP_METHODS['active_set']
     if qp_method not in QP_METHODS:
         raise ValueError(f'qp_method must be one of {sorted(QP_METHODS)}')

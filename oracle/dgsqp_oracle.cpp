@@ -1188,7 +1188,7 @@ static bool solve_qp(const Ctx& c, const Lin& k, vec& du, vec& lhat) {
     bool finite = true;
     for (double e : du) finite = finite && std::isfinite(e);
     for (double e : lhat) finite = finite && std::isfinite(e);
-    return finite && !(info.status == osqp_restate::PRIMAL_INFEASIBLE || info.status == osqp_restate::DUAL_INFEASIBLE || info.status == osqp_restate::NAN_DATA);
+    return finite && !(info.status == osqp_restate::PRIMAL_INFEASIBLE || info.status == osqp_restate::DUAL_INFEASIBLE || info.status == osqp_restate::PRIMAL_INFEASIBLE_INACCURATE || info.status == osqp_restate::DUAL_INFEASIBLE_INACCURATE || info.status == osqp_restate::NAN_DATA);
   }
   if (qp_gi(c.L.n, c.L.nc, Qpd.data(), k.q.data(), k.G.data(), k.g.data(), du.data(), lhat.data()) != 0) return false;
   // NOT in the reference, default off (par.snap_active_bounds = 0).  The exact minimiser sits ON its active input bounds;
@@ -1444,7 +1444,7 @@ static bool v2_solve_qp(const Ctx& c, const Lin& k, double reg, vec& du, vec& lh
     bool finite = true;
     for (double e : du) finite = finite && std::isfinite(e);
     for (double e : lhat) finite = finite && std::isfinite(e);
-    return finite && !(info.status == osqp_restate::PRIMAL_INFEASIBLE || info.status == osqp_restate::DUAL_INFEASIBLE || info.status == osqp_restate::NAN_DATA);
+    return finite && !(info.status == osqp_restate::PRIMAL_INFEASIBLE || info.status == osqp_restate::DUAL_INFEASIBLE || info.status == osqp_restate::PRIMAL_INFEASIBLE_INACCURATE || info.status == osqp_restate::DUAL_INFEASIBLE_INACCURATE || info.status == osqp_restate::NAN_DATA);
   }
   return qp_gi(c.L.n, c.L.nc, Qpd.data(), k.q.data(), k.G.data(), k.g.data(), du.data(), lhat.data()) == 0;
 }

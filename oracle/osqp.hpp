@@ -26,7 +26,7 @@ typedef std::vector<double> vec;
 
 static const double OSQP_INFTY = 1e30, MIN_SCALING = 1e-4, MAX_SCALING = 1e4;
 static const double RHO_MIN = 1e-6, RHO_MAX = 1e6, RHO_TOL = 1e-4, RHO_EQ_OVER_RHO_INEQ = 1e3;
-enum { SOLVED = 1, SOLVED_INACCURATE = 2, MAX_ITER = -2, PRIMAL_INFEASIBLE = -3, DUAL_INFEASIBLE = -4, NAN_DATA = -10 };
+enum { SOLVED = 1, SOLVED_INACCURATE = 2, PRIMAL_INFEASIBLE_INACCURATE = 3, DUAL_INFEASIBLE_INACCURATE = 4, MAX_ITER = -2, PRIMAL_INFEASIBLE = -3, DUAL_INFEASIBLE = -4, NAN_DATA = -10 };
 
 struct Settings {
   double rho = 0.1, sigma = 1e-6, alpha = 1.6, eps_abs = 1e-3, eps_rel = 1e-3, eps_prim_inf = 1e-4, eps_dual_inf = 1e-4;
@@ -244,7 +244,11 @@ static Info solve(int n, int m, const double* Pin, const double* qin, const doub
     it = S.max_iter;
     residuals();
     // OSQP re-checks with 10x tolerances at the iteration limit ("inaccurate" statuses)
-    status = (pri_res <= 10 * eps_p && dua_res <= 10 * eps_d) ? SOLVED_INACCURATE : MAX_ITER;
+    // (check_termination(work, approximate = 1): residual tolerances AND both infeasibility tolerances times ten, same order)
+    if (pri_res <= 10 * eps_p && dua_res <= 10 * eps_d) status = SOLVED_INACCURATE;
+    else if (primal_infeasible(10 * S.eps_prim_inf)) status = PRIMAL_INFEASIBLE_INACCURATE;
+    else if (dual_infeasible(10 * S.eps_dual_inf)) status = DUAL_INFEASIBLE_INACCURATE;
+    else status = MAX_ITER;
   }
 
   int polished = 0;
@@ -302,7 +306,7 @@ static Info solve(int n, int m, const double* Pin, const double* qin, const doub
     }
   }
   const double qnan = std::numeric_limits<double>::quiet_NaN();
-  if (status == PRIMAL_INFEASIBLE || status == DUAL_INFEASIBLE) {
+  if (status == PRIMAL_INFEASIBLE || status == DUAL_INFEASIBLE || status == PRIMAL_INFEASIBLE_INACCURATE || status == DUAL_INFEASIBLE_INACCURATE) {
     for (int j = 0; j < n; j++) xout[j] = qnan;         // OSQP stores NaN when there is no solution
     for (int r = 0; r < m; r++) yout[r] = qnan;
   } else {

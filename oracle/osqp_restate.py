@@ -37,6 +37,7 @@ MIN_SCALING, MAX_SCALING = 1e-4, 1e4
 RHO_MIN, RHO_MAX, RHO_TOL, RHO_EQ_OVER_RHO_INEQ = 1e-6, 1e6, 1e-4, 1e3
 
 SOLVED, SOLVED_INACCURATE, MAX_ITER, PRIMAL_INFEASIBLE, DUAL_INFEASIBLE = 1, 2, -2, -3, -4
+PRIMAL_INFEASIBLE_INACCURATE, DUAL_INFEASIBLE_INACCURATE = 3, 4
 
 
 def _limit(v):
@@ -178,8 +179,13 @@ def solve(P, q, A, l, u, *, rho=0.1, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_re
     else:
         pri_res, dua_res, eps_p, eps_d, *_ = residuals()
         # OSQP re-checks with 10x tolerances at the iteration limit ("inaccurate" statuses)
+        # (check_termination(work, approximate = 1): residual tolerances AND both infeasibility tolerances times ten, same order)
         if pri_res <= 10 * eps_p and dua_res <= 10 * eps_d:
             status = SOLVED_INACCURATE
+        elif primal_infeasible(10 * eps_prim_inf):
+            status = PRIMAL_INFEASIBLE_INACCURATE
+        elif dual_infeasible(10 * eps_dual_inf):
+            status = DUAL_INFEASIBLE_INACCURATE
         else:
             status = MAX_ITER
 
@@ -220,7 +226,7 @@ def solve(P, q, A, l, u, *, rho=0.1, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_re
         except (sla.LinAlgError, ValueError):
             polished = -1
 
-    if status in (PRIMAL_INFEASIBLE, DUAL_INFEASIBLE):
+    if status in (PRIMAL_INFEASIBLE, DUAL_INFEASIBLE, PRIMAL_INFEASIBLE_INACCURATE, DUAL_INFEASIBLE_INACCURATE):
         xo, yo = np.full(n, np.nan), np.full(m, np.nan)       # OSQP stores NaN when there is no solution
     else:
         xo, yo = D * x, cinv * E * y

@@ -88,3 +88,61 @@ def assert_control_flow_parity(res, ref, stable, tag='', min_stable_same=0.95, m
     assert same[stable].mean() >= min_stable_same, msg
     assert abs(np.mean(res['status'] <= 1) - np.mean(ref['status'] <= 1)) <= max_conv_gap + 1.0 / len(same), msg
     return same
+
+
+def sympy_one_stage_game(kind, method):
+    """A ONE-STAGE (N = 1) two-car race on the curve track whose vehicles are the ones of tests/golden/sympy_fd_<kind>.npz (the
+    reference's config defaults), with the racing cost of chicane.py:223-277 (atan competition term) and the obstacle row.
+    Returns (game, kat).  With N = 1 the game's Hessian is a closed formula in B = fBd and F = fFd (``sympy_one_stage_Q``)."""
+    from dgsqp_amd.dynamics import (CasadiDecoupledMultiAgentDynamicsModel, CasadiDynamicBicycleCombined, CasadiKinematicBicycleCombined,
+                                    DynamicBicycleConfig, KinematicBicycleConfig, MultiAgentModelConfig)
+    from dgsqp_amd.game import CollisionAvoidance, InputRateLimits, RacingCost
+    from dgsqp_amd.montecarlo import Game, _bounds, _track
+    from dgsqp_amd.solver_types import DGSQPParams
+    kat = np.load(ROOT / 'tests' / 'golden' / f'sympy_fd_{kind}.npz')
+    M_sub = int(kat[f'{method}_M'])
+    track = _track('curve', 45, 1.0)
+    if kind == 'kin':
+        mk = lambda: CasadiKinematicBicycleCombined(0, KinematicBicycleConfig(dt=0.1, discretization_method=method, M=M_sub, code_gen=False), track=track)
+    else:
+        mk = lambda: CasadiDynamicBicycleCombined(0, DynamicBicycleConfig(dt=0.1, discretization_method=method, M=M_sub, code_gen=False), track=track)
+    joint = CasadiDecoupledMultiAgentDynamicsModel(0, [mk(), mk()], MultiAgentModelConfig(dt=0.1, discretization_method=method, M=M_sub, code_gen=False))
+    params = DGSQPParams(dt=0.1, N=1, reg=1e-3, nonmono_ls=True, beta=0.01)
+    g = Game(joint, [RacingCost(comp_weights=(10.0, 5.0)) for _ in range(2)], [InputRateLimits((10.0, 4.5), (-10.0, -4.5)) for _ in range(2)],
+             CollisionAvoidance([0.2, 0.2]), _bounds(1.0, 2), params, track, 1.0, 0.4, name=f'sympy_{kind}_{method}')
+    return g, kat
+
+
+def sympy_one_stage_Q(kat, method, k1, k2, l_obs, nqa, s_idx, w_in=(1.0, 1.0), w_rate=(1.0, 1.0), w_prog=10.0, w_comp=5.0):
+    """Q of the one-stage game at x0 = (point k1, point k2) of the KAT file, u = the points' inputs, multiplier ``l_obs`` on the
+    obstacle row, from sympy's EXACT tensors:  rows a of  Duu J^a + B^T (D2 phi^a) B + sum_i (D phi^a)_i F_i  (DGSQP.py:678-727 with N = 1),
+    phi^a(x_1) = -w_p s_a + w_c atan(s_b - s_a) + l_obs ((r_1 + r_2)^2 - |p_1 - p_2|^2)."""
+    nq = 2 * nqa
+    x1 = np.concatenate([kat[f'{method}_fd'][k1], kat[f'{method}_fd'][k2]])
+    B = np.zeros((nq, 4))
+    F = np.zeros((nq, 4, 4))
+    for a, k in enumerate((k1, k2)):
+        B[a * nqa:(a + 1) * nqa, 2 * a:2 * a + 2] = kat[f'{method}_jac'][k][:, nqa:]
+        F[a * nqa:(a + 1) * nqa, 2 * a:2 * a + 2, 2 * a:2 * a + 2] = kat[f'{method}_hes'][k][:, nqa:, nqa:]
+    Q = np.zeros((4, 4))
+    for a in range(2):
+        b = 1 - a
+        sa, sb = a * nqa + s_idx, b * nqa + s_idx
+        d = x1[sb] - x1[sa]
+        g1, g2 = 1.0 / (1.0 + d * d), -2.0 * d / (1.0 + d * d) ** 2          # atan', atan''
+        dphi = np.zeros(nq)
+        d2phi = np.zeros((nq, nq))
+        dphi[sa] += -w_prog - w_comp * g1
+        dphi[sb] += w_comp * g1
+        d2phi[sa, sa] += w_comp * g2; d2phi[sb, sb] += w_comp * g2
+        d2phi[sa, sb] -= w_comp * g2; d2phi[sb, sa] -= w_comp * g2
+        for c in range(2):                                                     # obstacle row: positions are states 0, 1 of each car
+            i, j = c, nqa + c
+            dphi[i] += l_obs * (-2.0) * (x1[i] - x1[j]); dphi[j] += l_obs * 2.0 * (x1[i] - x1[j])
+            d2phi[i, i] += -2.0 * l_obs; d2phi[j, j] += -2.0 * l_obs
+            d2phi[i, j] += 2.0 * l_obs; d2phi[j, i] += 2.0 * l_obs
+        H = B.T @ d2phi @ B + np.einsum('i,ijk->jk', dphi, F)
+        for c in range(2):
+            H[2 * a + c, 2 * a + c] += w_in[c] + w_rate[c]
+        Q[2 * a:2 * a + 2] = H[2 * a:2 * a + 2]
+    return Q

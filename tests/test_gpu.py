@@ -381,6 +381,145 @@ def test_edge_cases_and_reference_surface(games, oracle):
     assert s.get_prediction()[0].x is not None and info2['msg'] in ('conv_abs_tol', 'conv_rel_tol', 'max_it', 'diverged', 'qp_fail')
 
 
+@pytest.mark.parametrize('kind,method', [('kin', 'euler'), ('kin', 'rk4'), ('dyn', 'euler'), ('dyn', 'rk4')])
+def test_one_stage_game_hessian_from_sympy_tensors(kind, method):
+    """SURVEY.md section 8c, KAT (1) on the DEVICE: Q of dgsqp_evaluate_batch on a one-stage two-car race against the closed
+    formula in sympy's exact dynamics tensors (tools/make_sympy_kats.py -> tests/golden/sympy_fd_*.npz; conftest.sympy_one_stage_Q),
+    1e-11 relative; the rollout's x_1 against sympy's f_d to 1e-13.  No oracle in this test: device vs exact symbolic derivatives."""
+    from conftest import sympy_one_stage_game, sympy_one_stage_Q
+    from dgsqp_amd.solver import DGSQP
+    g, kat = sympy_one_stage_game(kind, method)
+    s = DGSQP(*g.solver_args(), print_method=None)
+    nqa = g.joint_model.dynamics_models[0].n_q
+    s_idx = g.joint_model.dynamics_models[0].s_idx
+    pts = kat['points']
+    pairs = ((0, 1), (2, 3), (3, 0), (1, 2))
+    x0 = np.array([np.concatenate([pts[k1][:nqa], pts[k2][:nqa]]) for k1, k2 in pairs])
+    u = np.array([np.concatenate([pts[k1][nqa:], pts[k2][nqa:]]) for k1, k2 in pairs])
+    obs = 16                                              # rows: 2 x (4 rate + 4 input box) at k = 0, then the obstacle row of k = 1
+    assert s.n_c_total == 21
+    l = np.zeros((len(pairs), s.n_c_total))
+    l[:, obs] = 0.7
+    ev = s.evaluate_batch(x0, u, l)
+    for b, (k1, k2) in enumerate(pairs):
+        want = sympy_one_stage_Q(kat, method, k1, k2, 0.7, nqa, s_idx)
+        assert np.abs(ev['Q'][b] - want).max() < 1e-11 * np.abs(want).max(), (kind, method, b)
+        x1 = np.concatenate([kat[f'{method}_fd'][k1], kat[f'{method}_fd'][k2]])
+        np.testing.assert_allclose(ev['x'][b].reshape(2, -1)[1], x1, rtol=1e-13, atol=1e-14)
+
+
+def _plant_rk4(model, q, u, substeps=10):
+    """The plant of the receding-horizon tests: fixed-step rk4 of the model's own f_c over dt (the same function advances the
+    device loop and the oracle loop; the reference's simulator integrates the same f_c adaptively, dynamics_models.py:161-186)."""
+    q = np.asarray(q, float)
+    h = model.dt / substeps
+    for _ in range(substeps):
+        k1 = model.fc(q, u); k2 = model.fc(q + h / 2 * k1, u); k3 = model.fc(q + h / 2 * k2, u); k4 = model.fc(q + h * k3, u)
+        q = q + h / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+    return q
+
+
+@pytest.mark.parametrize('name', ['kb_curve_N10', 'dyn_curve_N15'])
+def test_step_receding_horizon_matches_the_oracle_loop(oracle, games, name):
+    """DGSQP.step (DGSQP.py:283-297), five receding-horizon steps per scenario: solve -> apply u_pred[0] -> plant -> shifted warm
+    start u_ws <- [u_pred[1:]; u_pred[-1]] (skipped on 'diverged' / 'qp_fail').  The device's step() is compared step by step with
+    a loop written here around the ORACLE's solve: identical (msg, iterations) at every step, applied inputs and shifted warm
+    starts within 1e-5 relative (north_star's bound on iterates), the applied input written into the VehicleStates
+    (qu2state(states, None, u_pred[0])), and every VehiclePrediction field against the formulas of dynamics_models.py:1127-1150
+    (kinematic: psidot = v L_r sin(atan(tan(delta) L_f / (L_f + L_r))) with the last entry repeated, v_tran = psidot L_r) and
+    :2596-2615 (dynamic: the eight state columns)."""
+    from dgsqp_amd.montecarlo import sample_scenarios
+    from dgsqp_amd.solver import DGSQP
+    from dgsqp_amd._ffi import STATUS_MSG as MSG
+    from dgsqp_amd.types import VehicleState
+    g, P, par = games[name]
+    par = tight_lsqr(par)
+    s = DGSQP(*g.solver_args(), print_method=None, lsqr_tol=1e-13)
+    models = g.joint_model.dynamics_models
+    x0s, u_tms = sample_scenarios(g, 3, seed=31)
+    nq = [m.n_q for m in models]
+    for b in range(3):
+        # --- device loop through the reference surface
+        states = [VehicleState(t=0.0) for _ in models]
+        g.joint_model.qu2state(states, x0s[b], None)
+        s.set_warm_start(u_tms[b])
+        # --- oracle loop
+        x_o, uws_o = x0s[b].copy(), agent_major(u_tms[b][None])[0]
+        for k in range(5):
+            x_d = g.joint_model.state2q(states)
+            info = s.step(states)
+            ref = oracle.solve_batch(P, par, x_o[None], uws_o[None], nthreads=1)
+            msg_o = MSG[int(ref['status'][0])]
+            assert (info['msg'], info['num_iters']) == (msg_o, int(ref['num_iters'][0])), (name, b, k, info['msg'], info['num_iters'], msg_o, int(ref['num_iters'][0]))
+            u_am = ref['u'][0]
+            u_tm_o = np.concatenate([u_am[a * s.N * 2:(a + 1) * s.N * 2].reshape(s.N, 2) for a in range(s.M)], axis=1)
+            assert rel(s.u_pred, u_tm_o) < 1e-5, (name, b, k)
+            if msg_o not in ('diverged', 'qp_fail'):
+                uws_o = agent_major(np.vstack((u_tm_o[1:], u_tm_o[-1]))[None])[0]
+            assert rel(s.u_ws, uws_o) < 1e-5, (name, b, k)
+            if info['msg'] not in ('diverged', 'qp_fail'):      # the shift itself, exactly (DGSQP.py:293-295)
+                assert np.array_equal(s.u_ws, agent_major(np.vstack((s.u_pred[1:], s.u_pred[-1]))[None])[0])
+            assert np.array_equal(s.u_prev, s.u_pred[0])
+            # applied input in the states, prediction messages
+            preds = s.get_prediction()
+            qi = 0
+            for a, (m, st, pr) in enumerate(zip(models, states, preds)):
+                assert (st.u.u_a, st.u.u_steer) == (s.u_pred[0, 2 * a], s.u_pred[0, 2 * a + 1])
+                q, u = s.q_pred[:, qi:qi + m.n_q], s.u_pred[:, 2 * a:2 * a + 2]
+                assert pr.t == states[0].t
+                assert np.array_equal(np.array(pr.u_a), u[:, 0]) and np.array_equal(np.array(pr.u_steer), u[:, 1])
+                if m.n_q == 6:
+                    for fld, col in (('x', 0), ('y', 1), ('v_long', 2), ('e_psi', 3), ('s', 4), ('x_tran', 5)):
+                        assert np.array_equal(np.array(getattr(pr, fld)), q[:, col]), fld
+                    psidot = q[:-1, 2] * m.L_r * np.sin(np.arctan(np.tan(u[:, 1]) * m.L_f / (m.L_f + m.L_r)))
+                    psidot = np.append(psidot, psidot[-1])
+                    np.testing.assert_allclose(np.array(pr.psidot), psidot, rtol=0, atol=1e-15)
+                    np.testing.assert_allclose(np.array(pr.v_tran), psidot * m.L_r, rtol=0, atol=1e-15)
+                else:
+                    for fld, col in (('x', 0), ('y', 1), ('v_long', 2), ('v_tran', 3), ('psidot', 4), ('e_psi', 5), ('s', 6), ('x_tran', 7)):
+                        assert np.array_equal(np.array(getattr(pr, fld)), q[:, col]), fld
+                assert len(pr.x) == s.N + 1 and len(pr.u_a) == s.N
+                qi += m.n_q
+            # q_pred[0] is the state the solve started from; q_pred follows the rollout of u_pred (oracle's x)
+            assert np.array_equal(s.q_pred[0], x_d)
+            assert rel(s.q_pred, ref['x'][0].reshape(s.N + 1, s.n_q)) < 1e-5
+            # --- the plant, same function for both loops; each loop applies ITS OWN first input
+            qi = 0
+            x_next_d, x_next_o = [], []
+            for a, m in enumerate(models):
+                x_next_d.append(_plant_rk4(m, x_d[qi:qi + m.n_q], s.u_pred[0, 2 * a:2 * a + 2]))
+                x_next_o.append(_plant_rk4(m, x_o[qi:qi + m.n_q], u_tm_o[0, 2 * a:2 * a + 2]))
+                qi += m.n_q
+            x_o = np.concatenate(x_next_o)
+            g.joint_model.qu2state(states, np.concatenate(x_next_d), None)
+            for st in states:
+                st.t += g.joint_model.dt
+            assert rel(g.joint_model.state2q(states), x_o) < 1e-5
+
+
+def test_step_keeps_the_warm_start_after_a_failed_qp(oracle, games):
+    """DGSQP.py:293: after 'qp_fail' (or 'diverged') step() does NOT shift the warm start.  Car 2 placed 1 m outside the track
+    boundary: the linearised bound rows cannot be met within the input box -> the first QP is infeasible, on the oracle alike."""
+    from dgsqp_amd.montecarlo import sample_scenarios
+    from dgsqp_amd.solver import DGSQP
+    from dgsqp_amd._ffi import STATUS_MSG as MSG
+    from dgsqp_amd.types import VehicleState
+    g, P, par = games['kb_curve_N10']
+    s = DGSQP(*g.solver_args(), print_method=None, lsqr_tol=1e-13)
+    x0, u_tm = sample_scenarios(g, 1, seed=31)
+    x0 = x0[0].copy()
+    x0[11] = g.half_width + 1.0                       # e_y of car 2
+    states = [VehicleState(t=0.0), VehicleState(t=0.0)]
+    g.joint_model.qu2state(states, x0, None)
+    s.set_warm_start(u_tm[0])
+    before = s.u_ws.copy()
+    info = s.step(states)
+    ref = oracle.solve_batch(P, tight_lsqr(par), x0[None], agent_major(u_tm), nthreads=1)
+    assert info['msg'] == MSG[int(ref['status'][0])] == 'qp_fail' and info['status'] is False
+    assert np.array_equal(s.u_ws, before)
+    assert (states[0].u.u_a, states[1].u.u_steer) == (s.u_pred[0, 0], s.u_pred[0, 3])      # the input is still written (DGSQP.py:286)
+
+
 def test_statistical_parity_at_default_lsqr_tolerance(oracle, games):
     """With scipy's default LSQR tolerance (the reference's setting) the dual start of two correct implementations
     differs by ~1e-4, so individual paths may fork; the Monte-Carlo statistics the reference reports

@@ -551,3 +551,21 @@ def test_every_in_scope_import_of_the_reference_scripts_resolves():
     assert out.returncode == 0, out.stderr[-2000:]
     missing = {m.rsplit('.', 1)[1] for m in json.loads(out.stdout)}
     assert missing <= OUT_OF_SCOPE_NAMES, missing - OUT_OF_SCOPE_NAMES
+
+
+def test_qp_solver_is_validated_whatever_qp_method_says():
+    """DGSQP.py:183-201 hands params.qp_solver to ca.conic: a solver that is not restated must not be accepted silently because
+    the caller also named a qp_method; the default mapping of 'osqp' to the exact QP is announced once."""
+    import warnings
+    from dgsqp_amd import solver as sv
+    from dgsqp_amd.solver_types import DGSQPParams
+    for qm in (None, 'active_set', 'osqp'):
+        with pytest.raises(ValueError):
+            sv.resolve_qp_method(DGSQPParams(qp_solver='superscs'), qm)
+    assert sv.resolve_qp_method(DGSQPParams(qp_solver='qrqp'), 'osqp') == sv.QP_METHODS['osqp']
+    sv._WARNED_OSQP_DEFAULT = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        assert sv.resolve_qp_method(DGSQPParams(), None) == sv.QP_METHODS['active_set']
+        assert sv.resolve_qp_method(DGSQPParams(), None) == sv.QP_METHODS['active_set']
+    assert len(w) == 1 and "qp_method='osqp'" in str(w[0].message)

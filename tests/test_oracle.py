@@ -491,3 +491,101 @@ def test_spline_track_game_derivatives(oracle):
             Qfd[:, i] = ((ep['q'] + ep['G'].T @ l) - (em['q'] + em['G'].T @ l)) / (2 * h)
         assert np.abs(Gfd - ev['G']).max() < 1e-6 * max(1.0, np.abs(ev['G']).max())
         assert np.abs(Qfd - ev['Q']).max() < 1e-6 * max(1.0, np.abs(ev['Q']).max())
+
+
+SYMPY_FIELDS = {'wheel_dist_front': 'L_f', 'wheel_dist_rear': 'L_r', 'mass': 'mass', 'yaw_inertia': 'I_z', 'gravity': 'gravity',
+                'drag_coefficient': 'c_dr', 'damping_coefficient': 'c_da', 'slip_coefficient': 'c_s', 'rolling_resistance': 'c_r',
+                'rolling_resistance_exponent': 'p_r', 'pacejka_b_front': 'pac_Bf', 'pacejka_b_rear': 'pac_Br', 'pacejka_c_front': 'pac_Cf',
+                'pacejka_c_rear': 'pac_Cr', 'pacejka_d_front': 'pac_Df', 'pacejka_d_rear': 'pac_Dr'}
+
+
+def sympy_kat_problem(games, kind):
+    """The problem record whose agent 0 is the vehicle of tests/golden/sympy_fd_<kind>.npz (the REFERENCE's config defaults,
+    model_types.py) on the curve track's arc; returns (P, kat)."""
+    import copy
+    kat = np.load(GOLD / f'sympy_fd_{kind}.npz')
+    g, P, _ = games[{'kin': 'kb_curve_N10', 'dyn': 'dyn_curve_N15', 'uni': 'merge_N8'}[kind]]
+    P = copy.deepcopy(P)
+    A = P.agents[0]
+    for name, fld in SYMPY_FIELDS.items():
+        if 'param_' + name in kat.files:
+            setattr(A, fld, float(kat['param_' + name]))
+    if kind == 'dyn':
+        assert str(kat['param_tire_model']) == 'pacejka'
+        A.tire_model, A.simple_slip = 0, int(bool(kat['param_simple_slip']))
+        A.drive_wheels = 0 if str(kat['param_drive_wheels']) == 'all' else 1
+    return P, kat
+
+
+@pytest.mark.parametrize('kind', ['uni', 'kin', 'dyn'])
+def test_dynamics_tensors_against_sympy(oracle, games, kind):
+    """SURVEY.md section 8c, KAT (1): f_d, [fAd fBd] and [fEd fGd; fGd^T fFd] (dynamics_models.py:128-144) of the oracle's jet
+    arithmetic against EXACT symbolic derivatives -- f_c transcribed into sympy from dynamics_models.py:331-339 / :1046-1070 /
+    :2013-2062 by tools/make_sympy_kats.py, independently of oracle/, with the reference's own config defaults; euler and rk4.
+    1e-12 relative to the largest entry of each tensor (finite differences pin the same tensors to 1e-6 only)."""
+    P, kat = sympy_kat_problem(games, kind)
+    if kind != 'uni':            # the KAT's track is the arc of the curve track (c, s0, psi0 stored): the oracle's tables must say the same
+        c, s0, psi0 = kat['track']
+        for s in (3.0, 5.5):
+            cc, tt, _ = oracle.track(P, s)
+            assert cc == pytest.approx(c, rel=1e-15) and tt == pytest.approx(psi0 + c * (s - s0), rel=1e-14)
+    nq = kat['points'].shape[1] - 2
+    for tag, integ in (('euler', 0), ('rk4', 1)):
+        P.integrator, P.substeps = integ, int(kat[f'{tag}_M'])
+        assert P.dt == float(kat['dt'])
+        for k, z in enumerate(kat['points']):
+            dq, qn, J, H = oracle.dynamics(P, 0, z[:nq], z[nq:])
+            for got, want, what in ((qn, kat[f'{tag}_fd'][k], 'fd'), (J, kat[f'{tag}_jac'][k], 'jac'), (H, kat[f'{tag}_hes'][k], 'hes')):
+                err = np.abs(got - want).max() / max(1e-300, np.abs(want).max())
+                assert err < 1e-12, (kind, tag, k, what, err)
+
+
+@pytest.mark.parametrize('kind,method', [('kin', 'euler'), ('kin', 'rk4'), ('dyn', 'euler'), ('dyn', 'rk4')])
+def test_one_stage_game_hessian_from_sympy_tensors(oracle, kind, method):
+    """f_Q (DGSQP.py:678-727, :828-877) on a one-stage race: rows a of Duu J^a + B^T (D2 phi^a) B + sum_i (D phi^a)_i F_i with
+    sympy's exact B = fBd, F = fFd (conftest.sympy_one_stage_Q) against the oracle's Q, multiplier 0.7 on the obstacle row."""
+    from conftest import sympy_one_stage_game, sympy_one_stage_Q
+    from dgsqp_amd.solver import build_problem
+    g, kat = sympy_one_stage_game(kind, method)
+    P = build_problem(*g.solver_args())
+    nqa = g.joint_model.dynamics_models[0].n_q
+    s_idx = g.joint_model.dynamics_models[0].s_idx
+    rows = oracle.rows(P)
+    obs = int(np.nonzero(rows[:, 0] == 0)[0][0])
+    pts = kat['points']
+    for k1, k2 in ((0, 1), (2, 3), (3, 0)):
+        x0 = np.concatenate([pts[k1][:nqa], pts[k2][:nqa]])
+        u = np.concatenate([pts[k1][nqa:], pts[k2][nqa:]])
+        l = np.zeros(len(rows))
+        l[obs] = 0.7
+        ev = oracle.evaluate(P, x0, u, l, 1)
+        want = sympy_one_stage_Q(kat, method, k1, k2, 0.7, nqa, s_idx)
+        assert np.abs(ev['Q'] - want).max() < 1e-12 * np.abs(want).max(), (kind, method, k1, k2)
+        np.testing.assert_allclose(ev['x'].reshape(2, -1)[1], np.concatenate([kat[f'{method}_fd'][k1], kat[f'{method}_fd'][k2]]), rtol=1e-13, atol=1e-14)
+
+
+@pytest.mark.parametrize('name', ['kb_barc3_N25', 'kb_f1_N50'])
+def test_infeasible_verdicts_are_backed_by_an_lp(oracle, name):
+    """The active-set QP (shared by oracle and device) ends 88 % / 30 % of the configs[2] / configs[3] solves with 'qp_fail'.  Its
+    verdict is checked here against an algorithm that shares nothing with it: the LP  min t s.t. G du - t <= -g  (HiGHS) on QPs
+    harvested from those games by tools/qp_infeasibility_lp.py (the numpy loop's iterates; up to 12 QPs the active-set method
+    called infeasible + first QPs it solved).  t* > 0 <=> no du meets the linearised constraints, whatever the Hessian; the
+    reference's OSQP would return 'primal infeasible' and a NaN step there (DGSQP.py:186 error_on_fail=False)."""
+    import scipy.optimize
+    path = GOLD / f'qp_infeasible_{name}.npz'
+    if not path.exists():
+        pytest.skip('fixture not generated')
+    d = np.load(path)
+    assert d['infeasible'].sum() >= 1
+    for G, g, t_gold, bad in zip(d['G'], d['g'], d['t'], d['infeasible']):
+        nc, n = G.shape
+        A = np.hstack([G, -np.ones((nc, 1))])
+        c = np.zeros(n + 1); c[-1] = 1.0
+        r = scipy.optimize.linprog(c, A_ub=A, b_ub=-g, bounds=[(None, None)] * n + [(-1.0, None)], method='highs')
+        assert r.status == 0 and r.x[-1] == pytest.approx(t_gold, abs=1e-7)
+        assert (r.x[-1] > 1e-6) == bool(bad), (r.x[-1], bad)          # the verdict of the active-set method == the LP's
+        # ... and the oracle's QP routine itself on this G, g (feasibility does not depend on the objective: identity Hessian)
+        du, lam, flag = oracle.qp(np.eye(n), np.zeros(n), G, g)
+        assert (flag != 0) == bool(bad)
+        if not bad:
+            assert (G @ du + g).max() < 1e-8
