@@ -84,6 +84,42 @@ def algorithmic_bytes_per_solve(d):
     return 8 * (d.n_q + d.n + d.n + d.n_c + (d.N + 1) * d.n_q + 3 + d.M) + 12
 
 
+FC_COST = {0: 1.0, 1: 3.0, 2: 0.3}          # jet cost of f_c relative to the kinematic bicycle's (dynamic bicycle: 314 instructions against ~100; unicycle ~30)
+STAGES = {0: 1, 1: 4, 2: 3, 3: 2}           # f_c evaluations per substep: euler, rk4, rk3, rk2 (dynamics_models.py:88-125)
+K_ADMM = 250                                # ADMM iterations per OSQP call in the flop model (measured mean on configs[1]: 270, profiles/r04_phase_cycles_*_qp_osqp.txt)
+
+
+def algorithmic_flops_per_solve(d, P, mean_qp_solves, qp_method):
+    """SURVEY.md section 8(d), the compute roof: per QP solve  F_eval + F_eig + F_qp  with
+        F_eval = M [N 6 n_q^3 + 2 n_q n_u N^2 n_q] + N C_AD,   C_AD = M x 3,000 x (f_c cost relative to the kinematic bicycle) x (f_c evaluations per step)
+        F_eig  = 9 n^3
+        F_qp   = 2 n^2 n_act + n^3 / 3 + k_admm (4 n n_dense + 2 n^2),   n_act = n / 4 active rows; k_admm = 0 for the exact active-set QP, 250 for OSQP
+    times the mean number of QP solves per scenario (every QP solve follows one evaluation with Hessian; the Hessian-free trial
+    evaluations of the line searches are not counted).  The survey's constants are ranges (C_AD 2-4 k, F_qp 1e7-1e8 at n = 100); the
+    ones used are stated here so that anybody can recompute the figure from the JSON line."""
+    M, N, n_q, n_u, n = int(d.M), int(d.N), int(d.n_q), int(d.n_u), int(d.n)
+    n_dense = int(d.n_dense)
+    model = int(P.agents[0].model)
+    stages = STAGES[int(P.integrator)] * (int(P.substeps) if int(P.integrator) != 0 else 1)
+    c_ad = M * 3000.0 * FC_COST[model] * stages
+    f_eval = M * (N * 6.0 * n_q ** 3 + 2.0 * n_q * n_u * N ** 2 * n_q) + N * c_ad
+    f_eig = 9.0 * n ** 3
+    f_qp = 2.0 * n ** 2 * (n / 4.0) + n ** 3 / 3.0 + (K_ADMM * (4.0 * n * n_dense + 2.0 * n ** 2) if qp_method == 'osqp' else 0.0)
+    return dict(per_qp_solve=dict(F_eval=f_eval, F_eig=f_eig, F_qp=f_qp), qp_solves_per_scenario=mean_qp_solves,
+                flop_per_solve=mean_qp_solves * (f_eval + f_eig + f_qp))
+
+
+def source_fingerprint():
+    """sha256 over the kernel sources: a PMC summary under profiles/ is only used for the kernels it was collected on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'dgsqp_amd', 'csrc', '*.h')) + glob.glob(os.path.join(ROOT, 'dgsqp_amd', 'csrc', '*.hip')) + [os.path.join(ROOT, 'include', 'dgsqp.h')]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()
+
+
 def spawn_ranks(n, argv, script=None, timeout=3600.0):
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (nothing in this process has
     touched the GPU), relay rank 0's JSON line, exit with the worst return code.  Every spawn has its own rendezvous file (port +
@@ -137,7 +173,7 @@ def spawn_ranks(n, argv, script=None, timeout=3600.0):
     sys.exit(worst if worst else (1 if failed else 0))
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=120, help='timed steps; the default is long enough (about 15 s) for the drain of the last launches -- one slowest scenario, ~0.7 s -- to weigh a few percent')
@@ -163,18 +199,15 @@ def main():
     ap.add_argument('--reg', type=float, default=None, help='DGSQPParams.reg (default: the value of the workload)')
     ap.add_argument('--eig-floor', type=float, default=None, help='_nearestPD floor (default: the literal 1e-10, DGSQP.py:1293)')
     ap.add_argument('--snap-active-bounds', action='store_true', help='implementation knob, see include/dgsqp.h (default: literal)')
-    args = ap.parse_args()
+    ap.add_argument('--extras', choices=('auto', 'off'), default='auto',
+                    help="auto: the default invocation (configs[1], exact QP, one GPU) also times, in the same run and into the same JSON line "
+                         "(key 'workloads'), --qp osqp on configs[1] and BASELINE configs[2], [3], [4] at the batch sizes BASELINE.json names; off: only the workload asked for")
+    return ap.parse_args(argv)
 
-    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
-        spawn_ranks(args.gpus, sys.argv[1:])
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('DGSQP_BENCH_DEVICE', os.environ.get('LOCAL_RANK', '0')))      # (the override lets a 1-GPU box rehearse the multi-rank path)
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    if args.gpus != world:
-        sys.stderr.write(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus} '
-                         f'or run `python bench.py --gpus {args.gpus}` without a launcher\n')
-        sys.exit(2)
 
+def run_workload(args, rank, local_rank, world):
+    """One workload through the contract's timed region (plus the one-at-a-time, host-inclusive and cpu_baseline legs the flags ask
+    for); returns the JSON record on rank 0, None elsewhere.  Every handle it creates is destroyed before it returns."""
     from dgsqp_amd import _ffi
     from dgsqp_amd.montecarlo import sample_scenarios
     from dgsqp_amd.sharding import Communicator, padded_shard_size, shard_range, stats_from_records, summarize
@@ -212,7 +245,7 @@ def main():
     # the deferral pool of the largest cooperative launch of the timed region (all `group` batches in one launch), sized before the warm-up:
     # left to the launch itself, growing it from the warm-up's single batches is a hipFree + hipMalloc of gigabytes inside the timed region
     if args.coop == 'auto':
-        lib.dgsqp_reserve_deferral(handles[0], B * max(1, min(args.group, n_batches, args.steps)))
+        assert lib.dgsqp_reserve_deferral(handles[0], B * max(1, min(args.group, n_batches, args.steps))) == 0, lib.dgsqp_last_error(handles[0])
     tm = _ffi.TimingT()
     for w in range(args.warmup):
         hh = handles[w % n_batches]
@@ -352,17 +385,24 @@ def main():
     if rank == 0:
         # HBM traffic comes from PMC counters collected in separate rocprofv3 --pmc passes (gpurun refuses mixed runs) and summarised
         # under profiles/; so does the fp64 instruction mix (SQ counters) behind the vector-ALU figure.  Latest matching file wins.
-        traffic, flop_per_solve, traffic_src = None, None, None
+        # A summary is used only when it was collected on THESE kernel sources (its `source_sha256`, written by tools/pmc_summary.py, equals
+        # the fingerprint of dgsqp_amd/csrc now) and on this QP method; otherwise traffic is null and the line says which file was refused.
+        traffic, flop_per_solve, traffic_src, traffic_note, sq_shares = None, None, None, None, None
         try:
             import glob
-            for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r0[34]_pmc_*.json'))):      # this round's kernels only
+            fp = source_fingerprint()
+            for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r0[5-9]_pmc_*.json'))):
                 pm = json.load(open(f))
-                if pm.get('workload') == args.workload and pm.get('batch_per_gpu') == B:
+                if pm.get('workload') == args.workload and pm.get('batch_per_gpu') == B and pm.get('qp_method', 'active_set') == args.qp:
+                    if pm.get('source_sha256') != fp:
+                        traffic_note = f'{os.path.relpath(f, ROOT)} refused: collected on other kernel sources (stale)'
+                        continue
                     if 'traffic_bytes_per_launch' in pm:
-                        traffic, traffic_src = pm['traffic_bytes_per_launch'], os.path.relpath(f, ROOT)
+                        traffic, traffic_src, traffic_note = pm['traffic_bytes_per_launch'], os.path.relpath(f, ROOT), None
                     flop_per_solve = pm.get('fp64_flop_per_solve_upper_bound', flop_per_solve)
-        except Exception:
-            pass
+                    sq_shares = pm.get('sq_wave_cycle_shares', sq_shares)
+        except Exception as e:
+            traffic_note = f'PMC summaries unreadable: {e}'
         # the dominant kernel's launches of the TIMED region: every launch solves `batches_per_launch` staged batches of B scenarios
         # (the last one possibly fewer); HIP events on the launch's own stream (dgsqp_wait -> dgsqp_timing_t.kernel_ms)
         gsz = max(1, min(args.group, n_batches))
@@ -372,6 +412,7 @@ def main():
         achieved = bytes_per_launch / (timed_ms * 1e-3) / 1e9
         achieved_single = algorithmic_bytes_per_solve(d) * B / (kms * 1e-3) / 1e9
         summ = summarize(stats)
+        flops = algorithmic_flops_per_solve(d, solver._problem, float(summ['mean_qp_solves_all']), args.qp)
         line = {
             'metric': 'Monte-Carlo scenarios/sec (SQP solves/sec), 2-agent N=25' if args.workload.startswith(('dyn_curve_N25', 'kb_curve_N25', 'kb_chicane_N25'))
                       else 'Monte-Carlo scenarios/sec (SQP solves/sec)', 'value': value, 'unit': 'scenarios/s',
@@ -386,7 +427,7 @@ def main():
                        'distinct_batches': n_batches, 'batches_per_launch': max(1, args.group), 'layout': {0: 'lds', 1: 'big', 2: 'xl'}[int(d.layout)],
                        'launches_in_flight': P, 'batches_in_flight': P * max(1, args.group), 'cooperative_line_search': args.coop, 'qp_method': args.qp, 'reg': float(game.params.reg), 'eig_floor': float(solver._cparams.eig_floor),
                        'snap_active_bounds': int(solver._cparams.snap_active_bounds)},
-            'elapsed_s_per_rank': elapsed_per_rank,        # each rank's own time for its K steps: load imbalance between the shards shows here
+            'elapsed_s': elapsed, 'elapsed_s_per_rank': elapsed_per_rank,        # each rank's own time for its K steps: load imbalance between the shards shows here
             'value_single_launch': single['value'] if single else None,
             'value_host_inclusive': host['value'] if host else None,
             'value_host_inclusive_grouped': host['grouped']['value'] if host else None,      # H2D + one launch + D2H of `batches_per_launch` batches
@@ -394,11 +435,19 @@ def main():
             'mean_iters': summ['mean_iters_converged'], 'mean_iters_all': summ['mean_iters_all'],
             'mean_qp_solves': summ['mean_qp_solves_all'], 'converged_fraction': summ['converged'],
             'status_fractions': {k: summ[k] for k in ('conv_abs_tol', 'conv_rel_tol', 'max_it', 'diverged', 'qp_fail')},
-            # The path is ALU/LDS-bound (state lives in LDS for the whole solve); the HBM figure is reported as the
-            # contract asks and is expected to be a tiny fraction of peak.
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
+            # The governing roof is the fp64 VECTOR ALU (per-scenario state lives in LDS for the whole solve, the path is
+            # small dense linear algebra + Taylor arithmetic): achieved = ALGORITHMIC flops of the launch (section 8d's formula, constants in
+            # algorithmic_flops_per_solve, terms in `flop_model`) / its HIP-event duration, against 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
+            # = 78.6 TFLOP/s.  The HBM figure the contract also asks for is kept under `hbm`: a tiny fraction of peak by construction.
+            'roofline': {'bound': 'valu_fp64', 'achieved': flops['flop_per_solve'] * solves_per_timed_launch / (timed_ms * 1e-3) / 1e12, 'peak': 78.6, 'unit': 'TFLOP/s',
+                         'frac': flops['flop_per_solve'] * solves_per_timed_launch / (timed_ms * 1e-3) / 1e12 / 78.6,
+                         'flop_model': flops,
+                         # executed fp64 flops from the SQ_INSTS_VALU_*_F64 pass (an upper bound: masked lanes count in full), when a summary of these kernels exists
+                         'frac_executed_upper_bound': (flop_per_solve * solves_per_timed_launch / (timed_ms * 1e-3) / 1e12 / 78.6) if flop_per_solve is not None else None,
+                         'executed_flop_per_solve_upper_bound': flop_per_solve, 'sq_wave_cycle_shares': sq_shares,
+                         'hbm': {'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0},
                          # PMC bytes (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc passes over one-batch launches) scaled to the solves of a timed launch
-                         'traffic': traffic * solves_per_timed_launch / B if traffic is not None else None, 'traffic_source': traffic_src,
+                         'traffic': traffic * solves_per_timed_launch / B if traffic is not None else None, 'traffic_source': traffic_src, 'traffic_note': traffic_note,
                          'kernel': 'dg_solve_kernel', 'kernel_ms': timed_ms,
                          'kernel_ms_source': f'HIP events on the launch streams, mean over the {len(kernel_ms_pipe)} launch(es) of the timed region',
                          'launches_timed': len(kernel_ms_pipe), 'solves_per_launch': solves_per_timed_launch,
@@ -407,12 +456,6 @@ def main():
                          'single_launch': {'kernel_ms': kms, 'solves_per_launch': B, 'achieved': achieved_single, 'frac': achieved_single / 8000.0, 'traffic': traffic,
                                            'source': 'HIP events, launches one at a time' if single else 'HIP events, overlapping launches'}},
         }
-        if flop_per_solve is not None:
-            # second, honest roof of this path: vector fp64 issue (256 CUs x 4 SIMDs x 32 lanes x 2 flop x 2.4 GHz = 78.6 TF/s).
-            # flop per solve from the offline SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 pass (an upper bound: masked lanes count)
-            line['valu_fp64'] = {'achieved_upper_bound': flop_per_solve * value / world / 1e12, 'peak': 78.6, 'unit': 'TFLOP/s',
-                                 'frac_upper_bound': flop_per_solve * value / world / 1e12 / 78.6,
-                                 'flop_per_solve_upper_bound': flop_per_solve}
         if world == 1 and args.cpu_sample > 0:
             from oracle import oracle            # checker/baseline only: the CPU restatement, NOT CasADi+OSQP
             oracle.build()
@@ -443,8 +486,65 @@ def main():
         elif world > 1:
             line['cpu_baseline'] = None
             line['cpu_baseline_note'] = 'timed on rank 0 of the 1-GPU run only (bench.py --gpus 1)'
-        print(json.dumps(line), flush=True)
+    else:
+        line = None
     comm.close()
+    del comm, handles, solver
+    while solvers:
+        solvers.pop()           # DGSQP.__del__ -> dgsqp_destroy: device buffers, streams and the deferral pool's claim go with the handle
+    import gc
+    gc.collect()
+    return line
+
+
+# The other claims of DESIGN.md / BASELINE.md, timed by the same run as the headline (default invocation at one GPU only): the reference's own
+# QP arithmetic on configs[1], and BASELINE configs[2], [3], [4] at the batch sizes BASELINE.json names -- ONE cooperative launch of the
+# whole batch each (the XL games' tails need that many scenarios behind them); kb_curve3_N25 is the solvable three-car game of
+# configs[2]'s size (DGSQP_monte_carlo_agents.py) next to the circuit game, 95 % of whose solves end in an LP-certified infeasible QP.
+EXTRA_LEGS = (
+    dict(tag='configs[1] --qp osqp', workload='dyn_curve_N25', qp='osqp'),
+    dict(tag='configs[2] B=4096', workload='kb_barc3_N25', batch=4096, steps=1, warmup=0, pipeline=1, batches=1, group=1),
+    dict(tag='configs[2] size, solvable game, B=4096', workload='kb_curve3_N25', batch=4096, steps=1, warmup=0, pipeline=1, batches=1, group=1),
+    dict(tag='configs[3] B=16384', workload='kb_f1_N50', batch=16384, steps=1, warmup=0, pipeline=1, batches=1, group=1),
+    dict(tag='configs[4] B=65536', workload='merge6_N25', batch=65536, steps=1, warmup=0, pipeline=1, batches=1, group=1),
+)
+RECORD_KEYS = ('value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'config', 'mean_iters', 'mean_iters_all', 'mean_qp_solves', 'converged_fraction',
+               'status_fractions', 'roofline', 'value_single_launch', 'value_host_inclusive', 'value_host_inclusive_grouped', 'elapsed_s')
+
+
+def main():
+    args = parse_args()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus, sys.argv[1:])
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('DGSQP_BENCH_DEVICE', os.environ.get('LOCAL_RANK', '0')))      # (the override lets a 1-GPU box rehearse the multi-rank path)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus != world:
+        sys.stderr.write(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus} '
+                         f'or run `python bench.py --gpus {args.gpus}` without a launcher\n')
+        sys.exit(2)
+    line = run_workload(args, rank, local_rank, world)
+    if rank == 0:
+        extras = (args.extras == 'auto' and world == 1 and args.workload == 'dyn_curve_N25' and args.qp == 'active_set' and args.scaling == 'weak'
+                  and args.batch == 1024 and args.reg is None and args.eig_floor is None)
+        if extras:
+            import copy
+            records = [dict({k: line.get(k) for k in RECORD_KEYS}, tag='configs[1] (the headline)')]
+            for leg in EXTRA_LEGS:
+                a = copy.copy(args)
+                a.single_steps, a.host_steps, a.cpu_sample, a.group = 0, 0, 0, 0
+                tag = leg['tag']
+                for k, v in leg.items():
+                    if k != 'tag':
+                        setattr(a, k, v)
+                t0 = time.perf_counter()
+                try:
+                    rec = run_workload(a, rank, local_rank, world)
+                    records.append(dict({k: rec.get(k) for k in RECORD_KEYS}, tag=tag, wall_s_incl_setup=time.perf_counter() - t0))
+                except Exception as e:           # a leg that fails must not take the headline down with it: say so in the line
+                    records.append(dict(tag=tag, error=f'{type(e).__name__}: {e}'))
+            line['workloads'] = records
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == '__main__':

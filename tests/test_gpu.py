@@ -1584,7 +1584,17 @@ def test_bench_line_contract():
     assert d['config']['workload'] == 'kb_curve_N25' and d['config']['batch_per_gpu'] == 64
     assert d['config']['launches_in_flight'] == 2 and d['config']['batches_per_launch'] >= 1      # (steps are issued in grouped launches)
     r = d['roofline']
-    assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-15 and r['kernel_ms'] > 0
+    # the governing roof: fp64 vector ALU, ALGORITHMIC flops of SURVEY.md section 8(d) (terms in the line) over the HIP-event duration
+    assert r['bound'] == 'valu_fp64' and r['peak'] == 78.6 and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-15 and r['kernel_ms'] > 0
+    fm = r['flop_model']
+    assert abs(fm['flop_per_solve'] - fm['qp_solves_per_scenario'] * sum(fm['per_qp_solve'].values())) < 1e-6 * fm['flop_per_solve']
+    assert abs(r['achieved'] - fm['flop_per_solve'] * r['solves_per_launch'] / (r['kernel_ms'] * 1e-3) / 1e12) < 1e-9 * r['achieved']
+    assert fm['per_qp_solve']['F_eig'] == 9.0 * 100 ** 3
+    # ... and the HBM figure the contract names, secondary
+    h = r['hbm']
+    assert h['peak'] == 8000.0 and h['unit'] == 'GB/s' and abs(h['frac'] - h['achieved'] / h['peak']) < 1e-15
+    assert abs(h['achieved'] - r['algorithmic_bytes_per_launch'] / (r['kernel_ms'] * 1e-3) / 1e9) < 1e-9 * h['achieved']
+    assert 'workloads' not in d                      # the other configs ride only on the default invocation
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['value'] > 0 and c['cores'] >= 1 and c['value_wall'] > 0 and c['seconds_per_scenario']['max'] >= c['seconds_per_scenario']['mean'] > 0
     assert abs(d['value'] - 64 * 3 / (d['ms_per_step'] * 3e-3)) < 1e-6 * d['value']
