@@ -5,7 +5,7 @@ import sys
 
 HERE = pathlib.Path(__file__).resolve().parent
 SRC = HERE / 'dgsqp_api.hip'
-DEPS = [SRC, HERE / 'dgsqp_comm.h', HERE / 'dgsqp_layout.h', HERE / 'dgsqp_device.h', HERE / 'dgsqp_eval.h', HERE / 'dgsqp_solve.h', HERE / 'dgsqp_qp.h', HERE / 'dgsqp_osqp.h', HERE / 'dgsqp_sampler.h', HERE / 'dgsqp_pid.h', HERE / 'dgsqp_xl.h', HERE / 'dgsqp_solve_v2.h',
+DEPS = [SRC, HERE / 'dgsqp_comm.h', HERE / 'dgsqp_layout.h', HERE / 'dgsqp_device.h', HERE / 'dgsqp_eval.h', HERE / 'dgsqp_solve.h', HERE / 'dgsqp_qp.h', HERE / 'dgsqp_osqp.h', HERE / 'dgsqp_osqp_xl.h', HERE / 'dgsqp_sampler.h', HERE / 'dgsqp_pid.h', HERE / 'dgsqp_xl.h', HERE / 'dgsqp_solve_v2.h',
         HERE.parent.parent / 'include' / 'dgsqp.h']
 OUT = HERE / 'libdgsqp_hip.so'
 

@@ -14,6 +14,7 @@
 
 #include "dgsqp_solve.h"
 #include "dgsqp_xl.h"
+#include "dgsqp_osqp_xl.h"
 #include "dgsqp_solve_v2.h"
 
 

@@ -76,6 +76,10 @@ struct DgLds {
   int a_tab;                     // ... followed by the per-QP index tables of the transposed product G' w (dgsqp_osqp.h: osqp_build_tables)
   int a_sw;                      // pivot-column buffers of the Gauss-Jordan sweep (4 (NH RPT + 4) doubles): the ADMM's delta-y / work vectors where they are large enough
   int a_tail;                    // ... and five n-vectors of the polish at the end of that slot (T keeps room for DgProb.osqp_namax active rows)
+  // qp_method = OSQP on the XL layout (dgsqp_osqp_xl.h): z; the slot of w (>= max(n_c, 4 n): the polish's vectors) followed by the dense-dot partials
+  // (>= n_c: a work vector of the checks) -- together >= 16 n + 2, the multipliers of the blocked elimination; seven n-vectors of stride ox_np;
+  // partial sums of the matrix products (>= 512: the elimination's tables); the polish's active rows
+  int ox_z, ox_w, ox_dpart, ox_yd2, ox_nv, ox_np, ox_part, ox_alist;
   int x_el;  // XL layout with xl_el: packed lower triangle of the QP's elimination M = L~ D L~^T (overlaps the QP outputs and c_R, dead until J is built)
   int c_R;   // classical QP: the first DgProb.c_rcap columns of the triangular factor R, packed column-major (phase-multiplexed with e_xs2)
   // LSQR scratch (s_yd2 / s_dpart: the dense-dot scratch of the dual start -- the QP's p_yd2 / p_dpart except in the
@@ -120,6 +124,7 @@ struct DgProb {
   int t2off[DGSQP_MAX_AGENTS];              // offset (doubles) of agent block in the Taylor tensor workspace
   int t2k[DGSQP_MAX_AGENTS];                // per-stage stride of that block = nqa*ndir
   int64_t t2_doubles;
+  int64_t wsx_Y, wsx_S, wsx_E, wsx_dy;   // OSQP on the XL layout: the polish's Y and Schur complement (n x n each), row scaling and delta y (n_c)
   int64_t ws_t2, ws_q, ws_base, ws_H, ws_tang, ws_Y, ws_P, ws_V, ws_R, ws_Vp, ws_xM, ws_xJ, ws_xR, ws_bfgs, ws_gd, ws_v2, ws_K, ws_doubles; // global workspace layout (doubles): Taylor tensor, raw Q, watchdog backups,
                                                              // costate-contracted dynamics Hessians, tangent trajectories
   DgRow rows[DG_NCMAX];
@@ -158,7 +163,13 @@ static inline std::string dg_build_layout(DgProb& D) {
                  (D.par.variant == DGSQP_VARIANT_V2 && D.eig_floor < 1e-8);      // v2: reg decays towards 0 during a solve (dgsqp_solve_v2.h)
   // OSQP: ADMM adds sigma = 1e-6 and the polish delta = 1e-6 to the projected Hessian, so its explicit inverses are well conditioned
   // whatever reg is; it needs the projected Hessian M itself (n x n, row-major) in the scratch; W = Gs^T Gs borrows the Y slot
-  if (D.osqp) { D.classic_qp = 0; D.ws_xM = D.ws_doubles; D.ws_xJ = D.ws_xR = D.ws_xM; D.ws_doubles = D.ws_xM + (int64_t)D.n * D.n; }
+  if (D.osqp && D.big == 2) {      // dgsqp_osqp_xl.h: M where dev_xl_psd leaves it (ws_R), the factor of K / Hu in ws_P, W in ws_V, plus the polish's two matrices
+    D.classic_qp = 0; D.ws_xM = D.ws_R; D.ws_xJ = D.ws_P; D.ws_xR = D.ws_V;
+    const int64_t ncp = (D.nc + 1) & ~1, nvp = ncp > D.n ? ncp : D.n;
+    D.wsx_Y = (D.ws_doubles + 1) & ~(int64_t)1; D.wsx_S = D.wsx_Y + (int64_t)D.n * D.n; D.wsx_E = D.wsx_S + (int64_t)D.n * D.n; D.wsx_dy = D.wsx_E + nvp;
+    D.ws_doubles = D.wsx_dy + nvp;
+  }
+  else if (D.osqp) { D.classic_qp = 0; D.ws_xM = D.ws_doubles; D.ws_xJ = D.ws_xR = D.ws_xM; D.ws_doubles = D.ws_xM + (int64_t)D.n * D.n; }
   else if (D.big == 2) { D.ws_xM = D.ws_R; D.ws_xJ = D.ws_P; D.ws_xR = D.ws_V; }
   else if (D.classic_qp) { D.ws_xM = D.ws_doubles; D.ws_xJ = D.ws_xM + (int64_t)D.n * D.n; D.ws_xR = D.ws_xJ + (int64_t)D.n * D.n; D.ws_doubles = D.ws_xR + (int64_t)D.n * D.n; }
   // hessian_approximation = 'bfgs': u of the previous iteration and d(u_prev, l) (2 n), the Hessian used at the top of the
@@ -214,11 +225,12 @@ static inline std::string dg_build_layout(DgProb& D) {
   {
     int tslot = D.classic_qp ? npk : dg_tcol(n);   // (the dual method's inverse factor T: padded columns, dg_tcol)
     const int ncp = (nc + 1) & ~1, np = (n + 1) & ~1;
-    if (D.osqp) tslot = dg_tcol(D.osqp_nacap < n ? D.osqp_nacap : n) + (D.osqp_nacap < n ? 5 * np : 0);
+    const bool osqp_lds = D.osqp && D.big != 2;     // (the XL layout's OSQP places its own vectors below: ox_*)
+    if (osqp_lds) tslot = dg_tcol(D.osqp_nacap < n ? D.osqp_nacap : n) + (D.osqp_nacap < n ? 5 * np : 0);
     const int tabsz = 2 * n + (n + 8) / 4 + (D.ngd + 2) / 2 + 2;       // 8 int16 per column, n + 1 uint16 column starts, one uint32 per gradient entry
-    if (D.osqp && tslot < 5 * ncp + tabsz + 5 * np) tslot = 5 * ncp + tabsz + 5 * np;
+    if (osqp_lds && tslot < 5 * ncp + tabsz + 5 * np) tslot = 5 * ncp + tabsz + 5 * np;
     L.p_R = D.big == 2 ? -1 : take(tslot);
-    if (D.osqp) {
+    if (osqp_lds) {
       L.a_z = L.p_R; L.a_y = L.a_z + ncp; L.a_E = L.a_y + ncp; L.a_dy = L.a_E + ncp; L.a_w = L.a_dy + ncp; L.a_tab = L.a_w + ncp;
       L.a_tail = L.p_R + ((tslot - 5 * np) & ~1);
       int na = 0;
@@ -233,7 +245,7 @@ static inline std::string dg_build_layout(DgProb& D) {
     if (o < L.scr + lsqr_size) o = L.scr + lsqr_size;
   }
   L.p_yd2 = take(nd); L.p_yslot = take((n + 2) / 2 + 1); L.p_yfree = take((n + 2) / 2 + 1); L.p_dpart = take(D.ntask); L.p_act = take(nc / 8 + 2); L.p_part = take(DG_NH * n);
-  if (D.osqp) {
+  if (D.osqp && D.big != 2) {
     // (the ADMM's delta-y and work vectors are free whenever a matrix is inverted: before the loop, after a check, in the polish)
     const int need = 4 * (DG_NH * rpt + 4);
     L.a_sw = 2 * ((nc + 1) & ~1) >= need ? L.a_dy : take(need);
@@ -304,6 +316,38 @@ static inline std::string dg_build_layout(DgProb& D) {
     D.c_rcap = cap;
     if (L.c_R + cap * (cap + 1) / 2 > tot) tot = L.c_R + cap * (cap + 1) / 2;
   }
+  if (D.osqp && D.big == 2) {
+    // OSQP on the XL layout: its vectors go where the QP scratch of the active-set kernels and the (dead) evaluation arrays are -- below
+    // the QP outputs (which hold x and y) -- and, what does not fit there, above them (trial trajectories / columns of R: dead or unused)
+    const int ncp = (nc + 1) & ~1, np = (n + 1) & ~1;
+    const int wslot = ncp > 4 * np ? ncp : 4 * np;
+    int dslot = ((D.ntask + 1) & ~1) + ((nd + 1) & ~1) + 2;
+    if (dslot < ncp) dslot = ncp;
+    int r1 = wslot + dslot;
+    if (r1 < 16 * n + 2) r1 = 16 * n + 2;
+    int a = L.scr, b = (out_end + 1) & ~1;
+    const int aend = L.o_du, bend = DG_LDS_LIMIT / 8;
+    bool fits = true;
+    auto place = [&](int cnt) -> int {
+      cnt = (cnt + 1) & ~1;
+      if (a + cnt <= aend) { const int r = a; a += cnt; return r; }
+      if (b + cnt <= bend) { const int r = b; b += cnt; return r; }
+      fits = false;
+      return L.scr;
+    };
+    L.ox_w = place(r1); L.ox_dpart = L.ox_w + wslot; L.ox_yd2 = L.ox_dpart + ((D.ntask + 1) & ~1);
+    L.ox_z = place(ncp);
+    L.ox_np = np; L.ox_nv = place(7 * np);
+    L.ox_part = place(DG_NH * n > 512 ? DG_NH * n : 512);
+    L.ox_alist = place((n + 2) / 2 + 1);
+    if (!fits) {
+      if (!D.tab_const) { D.tab_const = 1; return dg_build_layout(D); }      // the tables out of LDS first
+      char buf[200];
+      snprintf(buf, sizeof buf, "qp_method OSQP: n=%d n_c=%d does not fit the LDS arena next to the problem's vectors (XL layout)", n, nc);
+      return buf;
+    }
+    if (b > tot) tot = b;
+  }
   L.total = tot;
   if ((long)tot * 8 > DG_LDS_LIMIT && !D.big) { D.big = 1; return dg_build_layout(D); }   // (n > 128 starts at big = 2)
   if ((long)tot * 8 > DG_LDS_LIMIT && D.osqp && D.big == 1 && D.osqp_nacap > 24) { D.osqp_nacap -= 8; return dg_build_layout(D); }   // OSQP: a smaller T slot (polish of fewer active rows)
@@ -337,7 +381,6 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   if (par.merit_function == DGSQP_MERIT_SUM_OBJ_L1 && par.variant != DGSQP_VARIANT_V2) return "merit function sum_obj_l1 belongs to DG-SQP v2";
   if (P.N * P.M * DGSQP_NUA > DG_NVARMAX) return "more than 320 decision variables are not supported yet";
   if (par.qp_method != DGSQP_QP_ACTIVE_SET && par.qp_method != DGSQP_QP_OSQP) return "unknown qp_method";
-  if (par.qp_method == DGSQP_QP_OSQP && P.N * P.M * DGSQP_NUA > 128) return "qp_method OSQP supports up to 128 decision variables (the XL layout has no ADMM kernels yet)";
   if (P.n_segs < 1 || P.n_segs > DGSQP_MAX_SEGS) return "bad track table";
   D.M = P.M; D.N = P.N; D.nq = 0; D.nu = P.M * DGSQP_NUA;
   int t2 = 0;

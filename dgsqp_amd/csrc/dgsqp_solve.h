@@ -848,6 +848,7 @@ __device__ inline void qpt_drop(lptr T, lds_i_t* alist, lds_i_t* yslot, lptr lam
 #include "dgsqp_osqp.h"
 __device__ void dev_xl_psd(const Ctx& c, gptr Qpd);   // XL layout (n > 128), dgsqp_xl.h
 __device__ int dev_xl_qp(const Ctx& c);
+__device__ int dev_qp_osqp_xl(const Ctx& c);          // ... with OSQP's arithmetic, dgsqp_osqp_xl.h
 
 // ------------------------------------------------------------------------------------------------
 // dual initialisation  l = max(0, -lsqr(G G^T, G q))   (DGSQP.py:320-327).
@@ -1519,6 +1520,7 @@ __device__ inline int dev_linearize_and_qp(const Ctx& c, bool do_qp, double* con
   }
   if (!do_qp) return 0;
   dev_qt_mul(c);
+  if (dg_prob.osqp && dg_prob.big == 2) { dev_xl_psd(c, Qpd); return dev_qp_osqp_xl(c); }   // n > 128: dgsqp_osqp_xl.h
   if (dg_prob.osqp) {          // OSQP's arithmetic (dgsqp_osqp.h) on the projected Hessian M itself
     dev_psd_inverse(c, c.ws + dg_prob.ws_xM, false);
     if (Qpd) { for (int e = TID; e < dg_prob.n * dg_prob.n; e += NT) Qpd[e] = (c.ws + dg_prob.ws_xM)[e]; }
@@ -1915,7 +1917,8 @@ __device__ inline bool dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
     if (cond[0] < D.par.p_tol && cond[1] < D.par.d_tol && cond[2] < D.par.d_tol) { dev_tr(c, 40, 0.0); dev_log_iterate(c); status = DGSQP_CONV_ABS_TOL; break; }
     dev_qt_mul(c);
     int flag;
-    if (D.osqp) { dev_psd_inverse(c, c.ws + D.ws_xM, false); flag = dev_qp_osqp(c); }
+    if (D.osqp && D.big == 2) { dev_xl_psd(c, nullptr); flag = dev_qp_osqp_xl(c); }
+    else if (D.osqp) { dev_psd_inverse(c, c.ws + D.ws_xM, false); flag = dev_qp_osqp(c); }
     else if (D.big == 2) { dev_xl_psd(c, nullptr); flag = dev_xl_qp(c); }   // n > 128: dgsqp_xl.h
     else if (D.classic_qp) { dev_psd_inverse(c, c.ws + D.ws_xM, false); flag = dev_xl_qp(c); }
     else { dev_psd_inverse(c, nullptr); flag = dev_qp(c); }

@@ -47,6 +47,7 @@ __device__ inline void v2_merit_vector(const Ctx& c) {
 __device__ inline int v2_qp(const Ctx& c) {
   const DgProb& D = dg_prob;
   v2_merit_vector(c);
+  if (D.osqp && D.big == 2) { dev_xl_psd(c, nullptr); return dev_qp_osqp_xl(c); }
   if (D.osqp) { dev_psd_inverse(c, c.ws + D.ws_xM, false); return dev_qp_osqp(c); }
   if (D.big == 2) { dev_xl_psd(c, nullptr); return dev_xl_qp(c); }
   // the explicit-inverse kernels need eig_floor + reg >= 1e-8 (dgsqp_layout.h); reg decays towards 0 during a v2 solve

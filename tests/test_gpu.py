@@ -388,6 +388,8 @@ def test_one_stage_game_hessian_from_sympy_tensors(kind, method):
     1e-11 relative; the rollout's x_1 against sympy's f_d to 1e-13.  No oracle in this test: device vs exact symbolic derivatives."""
     from conftest import sympy_one_stage_game, sympy_one_stage_Q
     from dgsqp_amd.solver import DGSQP
+    if method == 'rk4' and 'rk4_M' not in np.load(GOLD / f'sympy_fd_{kind}.npz').files:
+        pytest.skip('tests/golden/sympy_fd_dyn.npz holds the euler step only (tools/make_sympy_kats.py dyn: rk4 takes about an hour of sympy)')
     g, kat = sympy_one_stage_game(kind, method)
     s = DGSQP(*g.solver_args(), print_method=None)
     nqa = g.joint_model.dynamics_models[0].n_q

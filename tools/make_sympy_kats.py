@@ -177,7 +177,7 @@ def main(kinds):
             out[f'{tag}_M'] = M
             out[f'{tag}_fd'], out[f'{tag}_jac'], out[f'{tag}_hes'] = F, J, H
             print(f'{kind} {tag} M={M}: {len(flat)} expressions, {time.time() - t:.0f} s, max |H| {np.abs(H).max():.3g}', flush=True)
-        np.savez_compressed(GOLD / f'sympy_fd_{kind}.npz', **out)
+            np.savez_compressed(GOLD / f'sympy_fd_{kind}.npz', **out)      # (after every integrator: the Pacejka model's rk4 takes an hour)
 
 
 if __name__ == '__main__':
