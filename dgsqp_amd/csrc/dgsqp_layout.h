@@ -124,7 +124,7 @@ struct DgProb {
   int t2off[DGSQP_MAX_AGENTS];              // offset (doubles) of agent block in the Taylor tensor workspace
   int t2k[DGSQP_MAX_AGENTS];                // per-stage stride of that block = nqa*ndir
   int64_t t2_doubles;
-  int64_t wsx_Y, wsx_S, wsx_E, wsx_dy;   // OSQP on the XL layout: the polish's Y and Schur complement (n x n each), row scaling and delta y (n_c)
+  int64_t wsx_Y, wsx_S, wsx_E, wsx_dy, wsx_tab;   // OSQP on the XL layout: the polish's Y and Schur complement (n x n each), row scaling and delta y (n_c), the transposed index table of G' w
   int64_t ws_t2, ws_q, ws_base, ws_H, ws_tang, ws_Y, ws_P, ws_V, ws_R, ws_Vp, ws_xM, ws_xJ, ws_xR, ws_bfgs, ws_gd, ws_v2, ws_K, ws_doubles; // global workspace layout (doubles): Taylor tensor, raw Q, watchdog backups,
                                                              // costate-contracted dynamics Hessians, tangent trajectories
   DgRow rows[DG_NCMAX];
@@ -167,7 +167,8 @@ static inline std::string dg_build_layout(DgProb& D) {
     D.classic_qp = 0; D.ws_xM = D.ws_R; D.ws_xJ = D.ws_P; D.ws_xR = D.ws_V;
     const int64_t ncp = (D.nc + 1) & ~1, nvp = ncp > D.n ? ncp : D.n;
     D.wsx_Y = (D.ws_doubles + 1) & ~(int64_t)1; D.wsx_S = D.wsx_Y + (int64_t)D.n * D.n; D.wsx_E = D.wsx_S + (int64_t)D.n * D.n; D.wsx_dy = D.wsx_E + nvp;
-    D.ws_doubles = D.wsx_dy + nvp;
+    D.wsx_tab = D.wsx_dy + nvp;          // uint32: n + 2 column starts, one entry per packed gradient element
+    D.ws_doubles = D.wsx_tab + ((int64_t)D.ngd + D.n + 6) / 2 + 2;
   }
   else if (D.osqp) { D.classic_qp = 0; D.ws_xM = D.ws_doubles; D.ws_xJ = D.ws_xR = D.ws_xM; D.ws_doubles = D.ws_xM + (int64_t)D.n * D.n; }
   else if (D.big == 2) { D.ws_xM = D.ws_R; D.ws_xJ = D.ws_P; D.ws_xR = D.ws_V; }
@@ -499,7 +500,8 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   D.t2_doubles = t2;
   D.osqp = par.qp_method == DGSQP_QP_OSQP ? 1 : 0;
   D.osqp_nacap = D.n;
-  if (D.osqp && (D.ngd >= 65536 || D.ndense >= 65536)) return "qp_method OSQP: the packed gradients exceed the 16-bit offsets of its index tables";
+  if (D.osqp && D.n <= 128 && (D.ngd >= 65536 || D.ndense >= 65536)) return "qp_method OSQP: the packed gradients exceed the 16-bit offsets of its index tables";
+  if (D.osqp && D.n > 128 && D.ngd >= (1 << 22)) return "qp_method OSQP: the packed gradients exceed the 22-bit offsets of the XL layout's index table";
   D.big = D.n > 128 ? 2 : 0;   // XL layout: every matrix of the PSD / QP phases in the global scratch, generic (slow) kernels
   D.xl_noblock = getenv("DGSQP_XL_NOBLOCK") ? 1 : 0;
   if (D.big == 2 && D.n <= 176 && !getenv("DGSQP_XL_NOPACK")) { D.xl_pack = 1; D.gd_global = 1; }       // (tried first; dg_build_layout falls back when the arena overflows)

@@ -180,12 +180,96 @@ __device__ inline void ox_gs_mul(const OxPtrs& o, GP gd, clptr v, lptr out) {
   for (int r = TID; r < D.nc; r += NT) out[r] = o.E[r] * qpw_row_dot(D, ld_row(r), o.tmp, o.ddx);
   __syncthreads();
 }
-// out = D G' (E w): E w goes to the LDS vector sc (may be w itself), then the generic transposed product
-__device__ inline void ox_gst_mul(const Ctx& c, const OxPtrs& o, clptr w, lptr sc, lptr out) {
+// ---- G' w through a transposed index table.  The generic gt_mul looks every dense gradient up per column (837 table entries per column
+// at n = 300, most of them not covering it: 0.3 Mcycles per product, half of an ADMM iteration).  Per QP the covering (gradient, entry)
+// pairs of every column are listed once in the workgroup's scratch -- the packed gradients transposed by index, as the LDS path does in
+// LDS (osqp_build_tables) -- and a product is one pass of four lanes per column over independent loads.
+typedef __attribute__((address_space(1))) unsigned int glb_u32;
+struct OxTabs { const glb_u32* cstart; const glb_u32* pairT; };      // cstart[n + 1]; pairT[k] = (gradient << 22) | offset inside the packed gradients
+__device__ inline OxTabs ox_tabs(const Ctx& c) {
+  const DgProb& D = dg_prob;
+  OxTabs T;
+  T.cstart = (const glb_u32*)(c.ws + D.wsx_tab);
+  T.pairT = T.cstart + ((D.n + 2) & ~1);
+  return T;
+}
+__device__ __noinline__ void ox_build_tables(const Ctx& c, const OxPtrs& o) {
+  const DgProb& D = dg_prob;
+  const int n = D.n;
+  glb_u32* cs = (glb_u32*)(c.ws + D.wsx_tab);
+  glb_u32* pt = cs + ((n + 2) & ~1);
+  __syncthreads();
+  for (int col = TID; col < n; col += NT) {
+    const int a = col / (D.N * DGSQP_NUA), rem = col % (D.N * DGSQP_NUA), t = rem / DGSQP_NUA;
+    int cnt = 0;
+    for (int d = D.stage_dense0[t + 1]; d < D.ndense; d++) { const DgDense dd = ld_dense(d); cnt += (dd.a == a) || (dd.kind == 1 && dd.b == a); }
+    o.tmp[col] = (double)cnt;
+  }
+  __syncthreads();
+  if (TID == 0) { double sacc = 0; for (int col = 0; col < n; col++) { const double cn = o.tmp[col]; o.tmp[col] = sacc; sacc += cn; } o.tmp[n] = sacc; }     // (n + 1 entries: tmp is followed by dx, dead here)
+  __syncthreads();
+  for (int col = TID; col <= n; col += NT) cs[col] = (unsigned int)o.tmp[col];
+  for (int col = TID; col < n; col += NT) {
+    const int a = col / (D.N * DGSQP_NUA), rem = col % (D.N * DGSQP_NUA), t = rem / DGSQP_NUA, j = rem % DGSQP_NUA;
+    int k = (int)o.tmp[col];
+    for (int d = D.stage_dense0[t + 1]; d < D.ndense; d++) {
+      const DgDense dd = ld_dense(d);
+      if (dd.a == a) pt[k++] = ((unsigned int)d << 22) | (unsigned int)(dd.off + t * DGSQP_NUA + j);
+      else if (dd.kind == 1 && dd.b == a) pt[k++] = ((unsigned int)d << 22) | (unsigned int)(dd.off + 2 * dd.k + t * DGSQP_NUA + j);
+    }
+  }
+  XSYNC();
+}
+// out = G' w  (w: an n_c-vector in LDS that already carries the row scaling)
+template <class GP>
+__device__ inline void ox_gt_mul(const Ctx& c, const OxPtrs& o, GP gd, clptr w, lptr out) {
+  const DgProb& D = dg_prob;
+  const int n = D.n;
+  const OxTabs T = ox_tabs(c);
+  lptr yd = o.ddx;
+  __syncthreads();
+  for (int d = TID; d < D.ndense; d += NT) {
+    const DgDense dd = ld_dense(d);
+    yd[d] = (dd.r_pos >= 0 ? w[dd.r_pos] : 0.0) - (dd.r_neg >= 0 ? w[dd.r_neg] : 0.0);
+  }
+  __syncthreads();
+  for (int it4 = TID; it4 < 4 * n; it4 += NT) {
+    const int col = it4 >> 2, part = it4 & 3;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (part == 0) {
+      const int a = col / (D.N * DGSQP_NUA), rem = col % (D.N * DGSQP_NUA), t = rem / DGSQP_NUA, j = rem % DGSQP_NUA;
+      int r;
+      if ((r = D.r_in_ub[a][t][j]) >= 0) s0 += w[r];
+      if ((r = D.r_in_lb[a][t][j]) >= 0) s0 -= w[r];
+      if ((r = D.r_rate_ub[a][t][j]) >= 0) s1 += w[r];
+      if ((r = D.r_rate_lb[a][t][j]) >= 0) s1 -= w[r];
+      if (t + 1 < D.N) {
+        if ((r = D.r_rate_ub[a][t + 1][j]) >= 0) s2 -= w[r];
+        if ((r = D.r_rate_lb[a][t + 1][j]) >= 0) s2 += w[r];
+      }
+    }
+    const int k1 = (int)T.cstart[col + 1];
+    int k = (int)T.cstart[col] + part;
+    for (; k + 12 < k1; k += 16) {
+      const unsigned int pa = T.pairT[k], pb = T.pairT[k + 4], pc = T.pairT[k + 8], pd = T.pairT[k + 12];
+      const double ga = gd[pa & 0x3fffffu], gb = gd[pb & 0x3fffffu], gc = gd[pc & 0x3fffffu], gg = gd[pd & 0x3fffffu];
+      s0 = __builtin_fma(yd[pa >> 22], ga, s0); s1 = __builtin_fma(yd[pb >> 22], gb, s1); s2 = __builtin_fma(yd[pc >> 22], gc, s2); s3 = __builtin_fma(yd[pd >> 22], gg, s3);
+    }
+    for (; k < k1; k += 4) { const unsigned int pa = T.pairT[k]; s0 = __builtin_fma(yd[pa >> 22], gd[pa & 0x3fffffu], s0); }
+    double sm = (s0 + s1) + (s2 + s3);
+    sm += dpp_f64<0xB1>(sm);
+    sm += dpp_f64<0x4E>(sm);
+    if (part == 0) out[col] = sm;
+  }
+  __syncthreads();
+}
+// out = D G' (E w): E w goes to the LDS vector sc (may be w itself), then the transposed product
+template <class GP>
+__device__ inline void ox_gst_mul(const Ctx& c, const OxPtrs& o, GP gd, clptr w, lptr sc, lptr out) {
   const DgProb& D = dg_prob;
   __syncthreads();
   for (int r = TID; r < D.nc; r += NT) sc[r] = o.E[r] * w[r];
-  gt_mul(c, sc, out);
+  ox_gt_mul<GP>(c, o, gd, sc, out);
   for (int j = TID; j < D.n; j += NT) out[j] *= o.Dv[j];
   __syncthreads();
 }
@@ -277,6 +361,7 @@ __device__ __noinline__ double ox_setup(const Ctx& c, GP gd) {
   PROF_BEGIN(po2);
   ox_build_w<GP>(D, o, gd);
   PROF_END(PH_O_W, po2);
+  ox_build_tables(c, o);
   return cc;
 }
 
@@ -307,7 +392,7 @@ __device__ __noinline__ void ox_iterate(const Ctx& c, GP gd, double rho, double 
   const OxPtrs o = ox_ptrs(c);
   const double sigma = 1e-6, alpha = 1.6, irho = 1.0 / rho;
   PROF_BEGIN(pa1);
-  gt_mul(c, o.w, o.xt);                                  // G' w   (w already carries E)
+  ox_gt_mul<GP>(c, o, gd, o.w, o.xt);                     // G' w   (w already carries E)
   for (int j = TID; j < n; j += NT) {
     const double dj = o.Dv[j], aI = o.EI[j] * dj, xj = o.x[j];
     o.rhs[j] = sigma * xj - cc * dj * o.q[j] + dj * o.xt[j] + aI * ox_rho_I(o, j, rho) * (aI * xj);
@@ -365,7 +450,7 @@ __device__ __noinline__ void ox_check(const Ctx& c, GP gd, double cc, bool appro
     nrm = block_max(nrm, o.red);
     lhs = block_sum(lhs, o.red);
     if (nrm > 1.0 / OSQP_INFTY && lhs < -eps_inf * nrm) {
-      ox_gst_mul(c, o, o.w, o.w, o.xt);
+      ox_gst_mul<GP>(c, o, gd, o.w, o.w, o.xt);
       double mx = 0;
       for (int j = TID; j < n; j += NT) mx = fmax(mx, __builtin_fabs(o.xt[j] / o.Dv[j]));
       mx = block_max(mx, o.red);
@@ -378,7 +463,7 @@ __device__ __noinline__ void ox_check(const Ctx& c, GP gd, double cc, bool appro
   ox_m_pass<false>(o.M, n, o.tmp, o.part, o.rhs);                  // (o.tmp = D x after ox_gs_mul)
   for (int j = TID; j < n; j += NT) o.rhs[j] *= cc * o.Dv[j];
   __syncthreads();
-  ox_gst_mul(c, o, o.y, o.dpart, o.xt);                           // (E y into the slot behind w -- at least n_c doubles, dgsqp_layout.h: the dense-dot partials, rebuilt by every product)
+  ox_gst_mul<GP>(c, o, gd, o.y, o.dpart, o.xt);                           // (E y into the slot behind w -- at least n_c doubles, dgsqp_layout.h: the dense-dot partials, rebuilt by every product)
   double pri_res, dua_res, eps_p, eps_d, ad_pr, ad_dr;
   {
     double v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, u[8] = {0, 0, 0, 0, 0, 0, 0, 0};
