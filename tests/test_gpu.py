@@ -291,6 +291,14 @@ def test_xl_convergence_statistics_against_the_restated_osqp_loop(name):
     print(name, 'converged device (exact QP)', cd.mean(), 'restated-OSQP loop', cr.mean(), 'same flag', np.mean(cd == cr),
           'mean iters (commonly converged)', res['num_iters'][both].mean() if both.any() else None, ref['num_iters'][both].mean() if both.any() else None,
           'qp_fail / exception', np.mean(res['status'] == 4), np.mean(ref['status'] == 4))
+    if name == 'merge6_N25':
+        # The one config where the two QPs do NOT give the same statistics: at reg = 0 (eigenvalues floored at 1e-10) the restated OSQP
+        # stops at its 4,000-iteration limit in 83 % of its calls (tools/ref_stats.py: 2,401 of 2,896 calls not 'solved') and the SQP
+        # continues from unconverged ADMM iterates -- 81 % converged after 14.4 iterations and 45 QPs per solve; the exact QP converges on
+        # 98 % after 7.9.  The exact QP is held to "not worse"; the device's OSQP arithmetic is held to the yardstick itself in
+        # test_xl_osqp_solves_follow_the_numpy_loop_with_the_restated_osqp.
+        assert cd.mean() >= cr.mean() - 0.05 and cd.mean() >= 0.95
+        return
     assert abs(cd.mean() - cr.mean()) <= 0.05 + 1.0 / len(cd)
     assert np.mean(cd == cr) >= 0.90
     if both.sum() >= 16:
