@@ -124,7 +124,7 @@ struct DgProb {
   int t2off[DGSQP_MAX_AGENTS];              // offset (doubles) of agent block in the Taylor tensor workspace
   int t2k[DGSQP_MAX_AGENTS];                // per-stage stride of that block = nqa*ndir
   int64_t t2_doubles;
-  int64_t wsx_Y, wsx_S, wsx_E, wsx_dy, wsx_tab;   // OSQP on the XL layout: the polish's Y and Schur complement (n x n each), row scaling and delta y (n_c), the transposed index table of G' w
+  int64_t wsx_Y, wsx_S, wsx_E, wsx_dy, wsx_tab, wsx_gdT;   // OSQP on the XL layout: the polish's Y and Schur complement (n x n each), row scaling and delta y (n_c), the transposed index table of G' w
   int64_t ws_t2, ws_q, ws_base, ws_H, ws_tang, ws_Y, ws_P, ws_V, ws_R, ws_Vp, ws_xM, ws_xJ, ws_xR, ws_bfgs, ws_gd, ws_v2, ws_K, ws_doubles; // global workspace layout (doubles): Taylor tensor, raw Q, watchdog backups,
                                                              // costate-contracted dynamics Hessians, tangent trajectories
   DgRow rows[DG_NCMAX];
@@ -168,7 +168,8 @@ static inline std::string dg_build_layout(DgProb& D) {
     const int64_t ncp = (D.nc + 1) & ~1, nvp = ncp > D.n ? ncp : D.n;
     D.wsx_Y = (D.ws_doubles + 1) & ~(int64_t)1; D.wsx_S = D.wsx_Y + (int64_t)D.n * D.n; D.wsx_E = D.wsx_S + (int64_t)D.n * D.n; D.wsx_dy = D.wsx_E + nvp;
     D.wsx_tab = D.wsx_dy + nvp;          // uint32: n + 2 column starts, one entry per packed gradient element
-    D.ws_doubles = D.wsx_tab + ((int64_t)D.ngd + D.n + 6) / 2 + 2;
+    D.wsx_gdT = D.wsx_tab + ((int64_t)D.ngd + D.n + 6) / 2 + 2;      // the packed gradients' values in the table's (transposed) order
+    D.ws_doubles = D.wsx_gdT + D.ngd + 2;
   }
   else if (D.osqp) { D.classic_qp = 0; D.ws_xM = D.ws_doubles; D.ws_xJ = D.ws_xR = D.ws_xM; D.ws_doubles = D.ws_xM + (int64_t)D.n * D.n; }
   else if (D.big == 2) { D.ws_xM = D.ws_R; D.ws_xJ = D.ws_P; D.ws_xR = D.ws_V; }

@@ -185,15 +185,18 @@ __device__ inline void ox_gs_mul(const OxPtrs& o, GP gd, clptr v, lptr out) {
 // pairs of every column are listed once in the workgroup's scratch -- the packed gradients transposed by index, as the LDS path does in
 // LDS (osqp_build_tables) -- and a product is one pass of four lanes per column over independent loads.
 typedef __attribute__((address_space(1))) unsigned int glb_u32;
-struct OxTabs { const glb_u32* cstart; const glb_u32* pairT; };      // cstart[n + 1]; pairT[k] = (gradient << 22) | offset inside the packed gradients
+struct OxTabs { const glb_u32* cstart; const glb_u32* pairT; cgptr gdT; };      // cstart[n + 1]; pairT[k] = (gradient << 22) | offset inside the packed gradients;
+                                                                                // gdT[k]: that entry's VALUE -- the packed gradients transposed, streamed instead of gathered
 __device__ inline OxTabs ox_tabs(const Ctx& c) {
   const DgProb& D = dg_prob;
   OxTabs T;
   T.cstart = (const glb_u32*)(c.ws + D.wsx_tab);
   T.pairT = T.cstart + ((D.n + 2) & ~1);
+  T.gdT = c.ws + D.wsx_gdT;
   return T;
 }
-__device__ __noinline__ void ox_build_tables(const Ctx& c, const OxPtrs& o) {
+template <class GP>
+__device__ __noinline__ void ox_build_tables(const Ctx& c, const OxPtrs& o, GP gd) {
   const DgProb& D = dg_prob;
   const int n = D.n;
   glb_u32* cs = (glb_u32*)(c.ws + D.wsx_tab);
@@ -218,6 +221,10 @@ __device__ __noinline__ void ox_build_tables(const Ctx& c, const OxPtrs& o) {
       else if (dd.kind == 1 && dd.b == a) pt[k++] = ((unsigned int)d << 22) | (unsigned int)(dd.off + 2 * dd.k + t * DGSQP_NUA + j);
     }
   }
+  XSYNC();
+  gptr gT = c.ws + D.wsx_gdT;
+  const int tot = (int)o.tmp[n];
+  for (int k = TID; k < tot; k += NT) gT[k] = gd[pt[k] & 0x3fffffu];
   XSYNC();
 }
 // out = G' w  (w: an n_c-vector in LDS that already carries the row scaling)
@@ -252,10 +259,10 @@ __device__ inline void ox_gt_mul(const Ctx& c, const OxPtrs& o, GP gd, clptr w, 
     int k = (int)T.cstart[col] + part;
     for (; k + 12 < k1; k += 16) {
       const unsigned int pa = T.pairT[k], pb = T.pairT[k + 4], pc = T.pairT[k + 8], pd = T.pairT[k + 12];
-      const double ga = gd[pa & 0x3fffffu], gb = gd[pb & 0x3fffffu], gc = gd[pc & 0x3fffffu], gg = gd[pd & 0x3fffffu];
+      const double ga = T.gdT[k], gb = T.gdT[k + 4], gc = T.gdT[k + 8], gg = T.gdT[k + 12];
       s0 = __builtin_fma(yd[pa >> 22], ga, s0); s1 = __builtin_fma(yd[pb >> 22], gb, s1); s2 = __builtin_fma(yd[pc >> 22], gc, s2); s3 = __builtin_fma(yd[pd >> 22], gg, s3);
     }
-    for (; k < k1; k += 4) { const unsigned int pa = T.pairT[k]; s0 = __builtin_fma(yd[pa >> 22], gd[pa & 0x3fffffu], s0); }
+    for (; k < k1; k += 4) { const unsigned int pa = T.pairT[k]; s0 = __builtin_fma(yd[pa >> 22], T.gdT[k], s0); }
     double sm = (s0 + s1) + (s2 + s3);
     sm += dpp_f64<0xB1>(sm);
     sm += dpp_f64<0x4E>(sm);
@@ -302,6 +309,45 @@ __device__ inline void ox_solve(cgptr J, int m, clptr v, lptr t, lptr out, lptr 
   const XlSplit S = xl_split(m);
   xl_jt_mul<cgptr>(J, m, m, S, 0, m, v, t, part);
   xl_j_mul<cgptr>(J, m, m, S, 0, m, t, out, part);
+}
+
+// A^-1 = J J' (full, symmetric, row-major m x m) from the factor J = L^-T, on the matrix cores: tile (ti, tj <= ti) of the result is the
+// sum over 16-column chunks k >= 16 ti of J[i][k] J[j][k] (J is upper triangular: earlier chunks are zero and skipped), mirrored on
+// store.  An ADMM iteration then needs ONE pass over an n x n matrix (ox_m_pass) instead of two over J -- the product is bound by the
+// bytes it streams from L2 / Infinity Cache (two thirds of an iteration at n = 300 otherwise).
+__device__ inline void ox_inverse_from_factor(cgptr J, gptr Ainv, int m) {
+  const int lane = TID & 63, wave = TID >> 6, li = lane & 15, h = lane >> 4;
+  const int T = (m + 15) >> 4, ntile = T * (T + 1) / 2;
+  __syncthreads();
+  for (int t = wave; t < ntile; t += NT / 64) {
+    int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while (ti * (ti + 1) / 2 > t) ti--;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+    const int tj = t - ti * (ti + 1) / 2;
+    const int rowa = 16 * ti + li, rowb = 16 * tj + li;       // A operand: row of the result tile; B operand: its column
+    xl_v4d acc = {0.0, 0.0, 0.0, 0.0};
+    for (int kc = ti; kc < T; kc += 2) {                       // two chunks per pass: eight loads per operand in flight
+      double av[8], bv[8];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int kk = 16 * (kc + u) + 4 * q + h;
+          const bool on = kc + u < T && kk < m;
+          av[4 * u + q] = (on && rowa < m) ? J[(int64_t)rowa * m + kk] : 0.0;
+          bv[4 * u + q] = (on && rowb < m) ? J[(int64_t)rowb * m + kk] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = 16 * ti + h + 4 * r, col = 16 * tj + li;
+      if (row < m && col < m) { Ainv[(int64_t)row * m + col] = acc[r]; if (ti != tj) Ainv[(int64_t)col * m + row] = acc[r]; }
+    }
+  }
+  XSYNC();
 }
 
 __device__ inline double ox_rho_I(const OxPtrs& o, int j, double rho) { return o.EI[j] * OSQP_INFTY > OSQP_INFTY * OSQP_MIN_SCALING ? OSQP_RHO_MIN : rho; }
@@ -361,7 +407,7 @@ __device__ __noinline__ double ox_setup(const Ctx& c, GP gd) {
   PROF_BEGIN(po2);
   ox_build_w<GP>(D, o, gd);
   PROF_END(PH_O_W, po2);
-  ox_build_tables(c, o);
+  ox_build_tables<GP>(c, o, gd);
   return cc;
 }
 
@@ -380,6 +426,7 @@ __device__ __noinline__ bool ox_build_k(const Ctx& c, double rho, double cc) {
     if (i == k) a += o.tmp[i];
     return a;
   });
+  if (ok) ox_inverse_from_factor(o.J, o.S, n);        // K^-1 itself, in the slot of the polish's Schur complement (unused until then)
   PROF_END(PH_O_KINV, po3);
   return ok;
 }
@@ -400,7 +447,7 @@ __device__ __noinline__ void ox_iterate(const Ctx& c, GP gd, double rho, double 
   __syncthreads();
   PROF_END(PH_O_GT, pa1);
   PROF_BEGIN(pa2);
-  ox_solve(o.J, n, o.rhs, o.tv, o.xt, o.part);            // xt = K^-1 rhs
+  ox_m_pass<false>(o.S, n, o.rhs, o.part, o.xt);          // xt = K^-1 rhs (explicit inverse: one pass over n x n)
   for (int i = TID; i < n; i += NT) {
     const double xt = o.xt[i], xp = o.x[i], xn = alpha * xt + (1.0 - alpha) * xp;
     o.x[i] = xn; o.dx[i] = xn - xp; o.tmp[i] = o.Dv[i] * xt;
