@@ -507,6 +507,11 @@ EXTRA_LEGS = (
     dict(tag='configs[2] size, solvable game, B=4096', workload='kb_curve3_N25', batch=4096, steps=1, warmup=0, pipeline=1, batches=1, group=1),
     dict(tag='configs[3] B=16384', workload='kb_f1_N50', batch=16384, steps=1, warmup=0, pipeline=1, batches=1, group=1),
     dict(tag='configs[4] B=65536', workload='merge6_N25', batch=65536, steps=1, warmup=0, pipeline=1, batches=1, group=1),
+    # ... and the same games with OSQP's own arithmetic (csrc/dgsqp_osqp_xl.h, round 5) at REDUCED batch sizes: at reg = 0 the restated OSQP
+    # runs into its 4,000-iteration limit on most QPs of the merge (3,400 ADMM iterations per QP on average), a solve costs 30 x the exact QP's
+    dict(tag='configs[2] --qp osqp, B=4096', workload='kb_barc3_N25', qp='osqp', batch=4096, steps=1, warmup=0, pipeline=1, batches=1, group=1),
+    dict(tag='configs[3] --qp osqp, reduced batch B=2048', workload='kb_f1_N50', qp='osqp', batch=2048, steps=1, warmup=0, pipeline=1, batches=1, group=1),
+    dict(tag='configs[4] --qp osqp, reduced batch B=2048', workload='merge6_N25', qp='osqp', batch=2048, steps=1, warmup=0, pipeline=1, batches=1, group=1),
 )
 RECORD_KEYS = ('value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'config', 'mean_iters', 'mean_iters_all', 'mean_qp_solves', 'converged_fraction',
                'status_fractions', 'roofline', 'value_single_launch', 'value_host_inclusive', 'value_host_inclusive_grouped', 'elapsed_s')

@@ -498,6 +498,75 @@ def _sample_scenarios_circuit(game: Game, B: int, seed: int, max_rounds: int):
 
 
 def _sample_scenarios_merge(game: Game, B: int, seed: int):
+    """Vectorised form of ``_sample_scenarios_merge_scalar`` (same draws in the same order from the same generator, the same rk3
+    arithmetic on arrays, the first B accepted candidates): 65,536 six-car scenarios in a second instead of two minutes."""
+    rng = np.random.default_rng(seed)
+    N = game.params.N
+    models = game.joint_model.dynamics_models
+    M = len(models)
+    radii = list(game.shared_constraints.radii)
+    mw, mp, th = 0.3, 1.5, np.pi / 12
+    x5, x7 = mp, mp + mw / np.sin(th)
+    out, have = [], 0
+    while have < B:
+        K = max(256, 2 * (B - have))
+        r = rng.random((K, M, 4))                       # candidate k, car i: the four draws of the scalar sampler, in its order
+        q = np.zeros((K, M, 4))
+        for i in range(M):
+            x_nom = _MERGE_X_NOM[i]
+            if i % 3 != 2:
+                q[:, i, 0] = x_nom + 0.5 * r[:, i, 0] - 0.25
+                q[:, i, 1] = 0.15 + 0.1 * r[:, i, 1] - 0.05
+                q[:, i, 2] = 0.3 * (1 + 0.06 * r[:, i, 2] - 0.03)
+                q[:, i, 3] = (5 * r[:, i, 3] - 2.5) * np.pi / 180
+            else:
+                y_nom = -((x7 + x5) / 2 - x_nom) * np.tan(th)
+                s_rand, ey_rand = 0.5 * r[:, i, 0] - 0.25, 0.1 * r[:, i, 1] - 0.05
+                q[:, i, 0] = x_nom + s_rand * np.cos(th) - ey_rand * np.sin(th)
+                q[:, i, 1] = y_nom + s_rand * np.sin(th) + ey_rand * np.cos(th)
+                q[:, i, 2] = 0.3 * (1 + 0.06 * r[:, i, 2] - 0.03)
+                q[:, i, 3] = np.pi / 12 + (5 * r[:, i, 3] - 2.5) * np.pi / 180
+        traj = []
+        for a, mdl in enumerate(models):
+            qa = np.zeros((K, 4)) if (M == 3 and a == 2) else q[:, a, :].copy()
+            pts = [qa[:, :2].copy()]
+            for _ in range(N):
+                qa = _unicycle_fd_zero_input(mdl, qa)
+                pts.append(qa[:, :2].copy())
+            traj.append(np.stack(pts, axis=1))           # [K, N + 1, 2]
+        hit = np.zeros(K, bool)
+        for i in range(M):
+            for j in range(i + 1, M):
+                hit |= (np.linalg.norm(traj[i] - traj[j], axis=2) < radii[i] + radii[j]).any(axis=1)
+        acc = q[~hit].reshape(-1, 4 * M)
+        out.append(acc)
+        have += len(acc)
+    return np.ascontiguousarray(np.concatenate(out)[:B]), np.zeros((B, N, 2 * M))
+
+
+def _unicycle_fd_zero_input(mdl, q):
+    """``CasadiKinematicUnicycle.fd`` (dynamics_models.py:88-125, rk3 :200-211) on rows of states with u = 0 -- the same expressions
+    evaluated on arrays, so that a row equals the scalar ``mdl.fd(q_row, 0)`` bit for bit."""
+    meth, h = mdl.model_config.discretization_method, mdl.dt / mdl.M
+
+    def fc(z):
+        return np.stack([z[:, 2] * np.cos(z[:, 3]), z[:, 2] * np.sin(z[:, 3]), np.zeros(len(z)) / mdl.m, np.zeros(len(z))], axis=1)
+    if meth == 'euler':
+        return q + mdl.dt * fc(q)
+    for _ in range(mdl.M):
+        if meth == 'rk4':
+            a1 = fc(q); a2 = fc(q + h / 2 * a1); a3 = fc(q + h / 2 * a2); a4 = fc(q + h * a3)
+            q = q + h * (a1 + 2 * a2 + 2 * a3 + a4) / 6
+        elif meth == 'rk3':
+            a1 = h * fc(q); a2 = h * fc(q + a1 / 2); a3 = h * fc(q - a1 + 2 * a2)
+            q = q + (a1 + 4 * a2 + a3) / 6
+        else:
+            a1 = fc(q); a2 = fc(q + h * a1)
+            q = q + h * (a1 + a2) / 2
+    return q
+
+
+def _sample_scenarios_merge_scalar(game: Game, B: int, seed: int):
     """Sampler of scripts/DGSQP_merge_monte_carlo.py:421-480 (seed 1 there): cars on the straight lane around their nominal
     x, every third car on the ramp; zero warm start; rejection if the zero-input trajectories collide.  For the script's
     three cars its quirk is reproduced -- car 3's check trajectory is left at the origin (``car2_q_ws[0]`` is assigned

@@ -569,3 +569,14 @@ def test_qp_solver_is_validated_whatever_qp_method_says():
         assert sv.resolve_qp_method(DGSQPParams(), None) == sv.QP_METHODS['active_set']
         assert sv.resolve_qp_method(DGSQPParams(), None) == sv.QP_METHODS['active_set']
     assert len(w) == 1 and "qp_method='osqp'" in str(w[0].message)
+
+
+def test_vectorised_merge_sampler_equals_the_scalar_one():
+    """scripts/DGSQP_merge_monte_carlo.py:421-480 restated per scenario (``_sample_scenarios_merge_scalar``: sequential draws, the
+    script's car-3 quirk) and its vectorised form used by ``sample_scenarios``: the same accepted scenarios, bit for bit."""
+    import dgsqp_amd.montecarlo as mc
+    for M, N in ((3, 20), (6, 25)):
+        g = mc.merge_game(N=N, M=M)
+        a, ua = mc._sample_scenarios_merge(g, 150, 1)
+        b, ub = mc._sample_scenarios_merge_scalar(g, 150, 1)
+        assert np.array_equal(a, b) and np.array_equal(ua, ub) and a.shape == (150, 4 * M)
