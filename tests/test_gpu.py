@@ -382,6 +382,14 @@ def test_xl_osqp_solves_follow_the_numpy_loop_with_the_restated_osqp(name):
     print(f'{name}: qp_method osqp (XL layout) vs numpy loop + restated OSQP: identical {same.mean():.3f} of all, {same[stable].mean():.3f} of the {stable.sum()} numpy-stable scenarios; '
           f'converged {cd.mean():.3f} vs {cr.mean():.3f}; same flag {np.mean(cd == cr):.3f}; iterates of the identical converged: median {np.median(err) if len(err) else float("nan"):.1e}, '
           f'above 1e-5: {int((err > 1e-5).sum())} of {len(err)}')
+    if name == 'kb_f1_N50':
+        # The chaotic game: the numpy loop reproduces ITSELF under 1e-13 input perturbations on 9 of its 64 scenarios (14 %;
+        # profiles/r05_pyref_osqp_stability.txt).  Path identity is demanded on those (one fork allowed); beyond them only the statistics:
+        # converged fraction within 12 points (two binomial standard deviations at 64 scenarios), mean iterations of the converged within 25 %.
+        assert stable.sum() >= 5 and same[stable].sum() >= stable.sum() - 1
+        assert abs(cd.mean() - cr.mean()) <= 0.12
+        assert abs(res['num_iters'][cd].mean() - ref['num_iters'][cr].mean()) <= 0.25 * ref['num_iters'][cr].mean()
+        return
     assert same[stable].mean() >= 0.95 or ('stable' not in ref.files and same.mean() >= 0.80)
     assert same.mean() >= 0.80
     assert abs(cd.mean() - cr.mean()) <= 0.05 + 1.0 / len(cd) and np.mean(cd == cr) >= 0.90
