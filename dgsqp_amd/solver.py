@@ -583,13 +583,14 @@ class DGSQP(AbstractSolver):
             raise RuntimeError(f'dgsqp_evaluate_batch failed ({rc}): {self._lib.dgsqp_last_error(self._h).decode()}')
         return out
 
-    def qp_batch(self, x0, u, l):
-        """One ``_solve_qp`` (DGSQP.py:232-266) per row at the linearisation point (u, l)."""
+    def qp_batch(self, x0, u, l, want_Qpd=True):
+        """One ``_solve_qp`` (DGSQP.py:232-266) per row at the linearisation point (u, l).  ``want_Qpd=False`` leaves the projected
+        Hessian on the device -- the path the solve itself takes (the certified ``_nearestPD`` shortcut only runs then)."""
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         u = np.ascontiguousarray(u, dtype=np.float64)
         l = np.ascontiguousarray(l, dtype=np.float64)
         B = x0.shape[0]
-        out = dict(du=np.empty((B, self.n)), lhat=np.empty((B, self.n_c_total)), Qpd=np.empty((B, self.n, self.n)),
+        out = dict(du=np.empty((B, self.n)), lhat=np.empty((B, self.n_c_total)), Qpd=np.empty((B, self.n, self.n)) if want_Qpd else None,
                    flag=np.empty(B, np.int32), info=np.zeros((B, 8)))
         rc = self._lib.dgsqp_qp_batch_info(self._h, B, _ffi.dptr(x0), _ffi.dptr(u), _ffi.dptr(l), _ffi.dptr(out['du']),
                                            _ffi.dptr(out['lhat']), _ffi.dptr(out['Qpd']), _ffi.iptr(out['flag']), _ffi.dptr(out['info']))
