@@ -429,6 +429,47 @@ def test_event_trace_parity_with_osqp(oracle, games):
     assert identical >= B - 1, identical
 
 
+def test_xl_event_trace_parity_with_osqp(oracle):
+    """The same on the XL layout (csrc/dgsqp_osqp_xl.h): the solvable three-car game of configs[2]'s size (n = 150, 825 rows), event
+    by event against the C++ oracle with its OSQP, converged LSQR dual start; eight scenarios: the same SEQUENCE of events (iterations, QP
+    solves, watchdog steps, line-search trials) on at least seven (measured: 8 of 8), the largest deviation of an event value below 1e-3 in the median
+    (measured: 5e-5; up to 7e-2 on single events such as a mu computed from a violation sum near zero) -- the 1e-9
+    differences of two polished QP answers grow along a solve of 20 iterations (the LDS-path games keep 1e-5), the decisions do not change."""
+    from concurrent.futures import ThreadPoolExecutor
+    from dgsqp_amd import montecarlo as mc
+    from dgsqp_amd.solver import DGSQP, build_problem, build_params
+    g = mc.kinematic_racing_game('curve', N=25, M=3)
+    P, par = build_problem(*g.solver_args()), tight_lsqr(build_params(g.params, qp_method='osqp'))
+    s = DGSQP(*g.solver_args(), print_method=None, lsqr_tol=1e-13, qp_method='osqp')
+    assert s.dims.layout == 2
+    B = 8
+    x0, u_tm = mc.sample_scenarios(g, B, seed=23)
+    u = s._to_agent_major(u_tm)
+    s.set_trace(20000)
+    try:
+        res = s.solve_batch(x0, u_tm)
+        traces = s.fetch_trace(B)
+    finally:
+        s.set_trace(0)
+    with ThreadPoolExecutor(8) as ex:
+        ref = list(ex.map(lambda b: oracle.solve_trace(P, par, x0[b], u[b], max_pairs=20000), range(B)))
+    same_flow, tight, worst = 0, 0, []
+    for b in range(B):
+        to, tg = ref[b], traces[b]
+        if len(to) != len(tg) or not np.array_equal(to[:, 0], tg[:, 0]):
+            worst.append(None)
+            continue
+        same_flow += 1                       # the same sequence of events: iterations, QP solves, watchdog steps, line-search trials
+        big = np.abs(to[:, 1]) > 1e-6
+        dev = float(np.max(np.abs(tg[big, 1] - to[big, 1]) / np.abs(to[big, 1]))) if big.any() else 0.0
+        worst.append(dev)
+        tight += dev <= 1e-5
+    print(f'XL layout, qp_method osqp: identical event sequences on {same_flow}/{B} scenarios, values within 1e-5 throughout on {tight}; largest relative '
+          f'deviation of an event value per scenario: {[None if w is None else float(f"{w:.1e}") for w in worst]}; status {res["status"].tolist()}')
+    assert same_flow >= B - 1
+    assert np.median([w for w in worst if w is not None]) < 1e-3
+
+
 @pytest.mark.parametrize('name', ['kb_chicane_N15', 'ablation_N15_ls_stat', 'ablation_N15_ls_stat_l1', 'ablation_N15_nms_stat'])
 def test_event_trace_parity(oracle, games, solvers, name):
     """Event-by-event comparison of the SQP state machine (convergence measures, mu, merit values, every
