@@ -1576,6 +1576,37 @@ def test_xl_sizes_between_the_configs(oracle, M, N):
         assert rel(res['u'][b], ref['u'][b]) < 1e-5, (b, rel(res['u'][b], ref['u'][b]))
 
 
+@pytest.mark.parametrize('M,N', [(3, 30), (5, 25), (2, 64), (4, 17)])
+def test_xl_osqp_sizes_between_the_configs(oracle, M, N):
+    """qp_method='osqp' on XL sizes the BASELINE configs do not name -- n = 180, 250, 256 (a multiple of the elimination's panel width) and
+    136 (the smallest panel remainder, 8; four agents): the LDS placement of dgsqp_layout.h (ox_*) and the short last panels of the blocked
+    elimination, three QPs each against oracle/osqp.hpp: same status, ADMM iterations, polish verdict, rho, active rows; x, lambda to 1e-6."""
+    from concurrent.futures import ThreadPoolExecutor
+    from dgsqp_amd.montecarlo import kinematic_racing_game, sample_scenarios
+    from dgsqp_amd.solver import DGSQP, build_problem, build_params
+    g = kinematic_racing_game('curve', N=N, M=M)
+    P, par = build_problem(*g.solver_args()), build_params(g.params, qp_method='osqp')
+    s = DGSQP(*g.solver_args(), print_method=None, qp_method='osqp')
+    assert s.n == 2 * N * M and s.dims.layout == 2
+    B = 3
+    x0, u_tm = sample_scenarios(g, B, seed=4)
+    u = s._to_agent_major(u_tm)
+    l0 = np.array([oracle.dual_init(P, par, x0[b], u[b]) for b in range(B)])
+    qp = s.qp_batch(x0, u, l0)
+
+    def cpu(b):
+        ev = oracle.evaluate(P, x0[b], u[b], l0[b], 1)
+        return oracle.osqp(oracle.nearest_pd(ev['Q'], par.reg, par.eig_floor), ev['q'], ev['G'], ev['g'])
+    with ThreadPoolExecutor(B) as ex:
+        refs = list(ex.map(cpu, range(B)))
+    for b, (xo, lo, io) in enumerate(refs):
+        inf = qp['info'][b]
+        assert (int(inf[0]), int(inf[1]), int(inf[2]), int(inf[5])) == (io['status'], io['iters'], io['polished'], io['n_active']), (b, inf[:6], io)
+        assert abs(inf[3] - io['rho']) <= 1e-6 * io['rho']
+        if io['status'] not in (-3, -4, -10, 3, 4):
+            assert np.abs(qp['du'][b] - xo).max() < 1e-6 * max(1.0, np.abs(xo).max()) and np.abs(qp['lhat'][b] - lo).max() < 1e-6 * max(1.0, np.abs(lo).max())
+
+
 @pytest.mark.parametrize('kind', ['merge6', 'kb_curve_N50'])
 def test_xl_nearest_pd_with_many_negative_eigenvalues(oracle, kind):
     """_nearestPD (DGSQP.py:601-626) of the XL layout when MOST of the curvature is negative: with multipliers 100 x the usual size the
