@@ -133,7 +133,7 @@ dg_evaluate_kernel(const DgProb* __restrict__ D, int64_t B, const double* __rest
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     c.x0 = (cgptr)x0 + b * dg_prob.nq;
     __syncthreads();
-    if (TID == 0) { dg_lds[L.scal + DG_XVALID] = 0.0; dg_lds[L.scal + DG_REG] = dg_prob.par.reg; }
+    if (TID == 0) { dg_lds[L.scal + DG_XVALID] = 0.0; dg_lds[L.scal + DG_REG] = dg_prob.par.reg; dg_lds[L.scal + DG_OSQP_RHO] = 0.1; }
     for (int i = TID; i < n; i += NT) dg_lds[L.u + i] = u[b * n + i];
     for (int r = TID; r < nc; r += NT) dg_lds[L.l + r] = l ? l[b * nc + r] : 0.0;
     __syncthreads();
@@ -174,7 +174,7 @@ dg_qp_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     c.x0 = (cgptr)x0 + b * dg_prob.nq;
     __syncthreads();
-    if (TID == 0) { dg_lds[L.scal + DG_XVALID] = 0.0; dg_lds[L.scal + DG_REG] = dg_prob.par.reg; }
+    if (TID == 0) { dg_lds[L.scal + DG_XVALID] = 0.0; dg_lds[L.scal + DG_REG] = dg_prob.par.reg; dg_lds[L.scal + DG_OSQP_RHO] = 0.1; }
     for (int i = TID; i < n; i += NT) dg_lds[L.u + i] = u[b * n + i];
     for (int r = TID; r < nc; r += NT) dg_lds[L.l + r] = l[b * nc + r];
     __syncthreads();

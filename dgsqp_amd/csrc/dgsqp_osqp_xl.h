@@ -763,7 +763,7 @@ __device__ __noinline__ int dev_qp_osqp_xl_t(const Ctx& c, GP gd) {
     return 1;
   }
   const double cinv = 1.0 / cc;
-  double rho = 0.1;
+  double rho = D.par.osqp_rho_carry ? o.scal[DG_OSQP_RHO] : 0.1;      // (carried from the scenario's previous call: include/dgsqp.h)
   int rho_updates = 0;
   for (int j = TID; j < n; j += NT) { o.x[j] = 0.0; o.dx[j] = 0.0; }
   for (int r = TID; r < nc; r += NT) { o.z[r] = 0.0; o.y[r] = 0.0; o.dy[r] = 0.0; o.w[r] = 0.0; }
@@ -816,6 +816,7 @@ __device__ __noinline__ int dev_qp_osqp_xl_t(const Ctx& c, GP gd) {
   __syncthreads();
   if (TID == 0) {
     o.scal[DG_OSQP_INFO] = (double)status; o.scal[DG_OSQP_INFO + 1] = (double)iters; o.scal[DG_OSQP_INFO + 2] = (double)polished; o.scal[DG_OSQP_INFO + 3] = rho;
+    if (D.par.osqp_rho_carry) o.scal[DG_OSQP_RHO] = rho;
     o.scal[DG_OSQP_INFO + 4] = (double)rho_updates; o.scal[DG_OSQP_INFO + 5] = (double)na; o.scal[DG_OSQP_INFO + 6] = pri_res; o.scal[DG_OSQP_INFO + 7] = dua_res;
   }
   int nonfinite = 0;

@@ -1874,7 +1874,7 @@ __device__ inline bool dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
   double t_start = 0.0;
   int sqp_it = 0, rel_tol_its = 0, status = DGSQP_MAX_IT, total_qp = 0;
   if (!resume) {
-    if (TID == 0) { lds[L.scal + DG_XVALID] = 0.0; lds[L.scal + DG_QP_NPREV] = 0.0; lds[L.scal + DG_REG] = D.par.reg; lds[L.scal + DG_PSD_PD] = 0.0; }
+    if (TID == 0) { lds[L.scal + DG_XVALID] = 0.0; lds[L.scal + DG_QP_NPREV] = 0.0; lds[L.scal + DG_REG] = D.par.reg; lds[L.scal + DG_PSD_PD] = 0.0; lds[L.scal + DG_OSQP_RHO] = 0.1; }
     for (int i = TID; i < n; i += NT) lds[L.u + i] = u_ws[i];
     for (int r = TID; r < nc; r += NT) lds[L.l + r] = 0.0;
     __syncthreads();

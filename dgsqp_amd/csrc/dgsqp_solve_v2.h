@@ -109,7 +109,7 @@ __device__ inline bool dev_solve_v2(const Ctx& c, cgptr u_ws, int64_t b, const S
   const bool timed = par.time_limit >= 0.0;
   double t_start = 0.0, obj0 = 0.0;
   if (!resume) {
-    if (TID == 0) { sc[DG_XVALID] = 0.0; sc[DG_QP_NPREV] = 0.0; sc[DG_REG] = par.reg; sc[DG_ITREC] = 0.0; sc[DG_PSD_PD] = 0.0; }
+    if (TID == 0) { sc[DG_XVALID] = 0.0; sc[DG_QP_NPREV] = 0.0; sc[DG_REG] = par.reg; sc[DG_ITREC] = 0.0; sc[DG_PSD_PD] = 0.0; sc[DG_OSQP_RHO] = 0.1; }
     for (int i = TID; i < n; i += NT) lds[L.u + i] = u_ws[i];
     for (int r = TID; r < nc; r += NT) lds[L.l + r] = 0.0;
     __syncthreads();

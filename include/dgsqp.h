@@ -198,9 +198,13 @@ typedef struct {
                                         polish succeeds.  DGSQP_QP_OSQP (1): OSQP's own arithmetic as the reference runs it through CasADi's
                                         conic plugin (DGSQP.py:183-201, :246-249): Ruiz equilibration, ADMM to eps 1e-3, adaptive rho, polish
                                         accepted on residuals alone -- the iterate the reference's loop actually continues from (1e-3 .. 1e-6
-                                        off the exact KKT point, occasionally negative multipliers); n <= 128.  A primal / dual infeasible
-                                        QP ends the solve with DGSQP_QP_FAIL wherever it occurs (the reference's NaN step raises in _get_mu
-                                        one iteration later, DGSQP.py:566-585) */
+                                        off the exact KKT point, occasionally negative multipliers); every size up to 320 unknowns.  A primal /
+                                        dual infeasible QP ends the solve with DGSQP_QP_FAIL wherever it occurs (the reference's NaN step raises
+                                        in _get_mu one iteration later, DGSQP.py:566-585) */
+  int32_t osqp_rho_carry;            /* qp_method = DGSQP_QP_OSQP only.  0 (default): every OSQP call starts at rho = 0.1, as the CPU restatements
+                                        the parity tests compare with do.  1: a call starts from the rho the previous call of the same solve()
+                                        ended with -- inside CasADi's conic plugin the OSQP workspace persists and keeps its adapted rho
+                                        (SURVEY.md parity hazard 7); the first call of a solve starts at 0.1 */
   double reg_decay;                  /* reg <- reg * reg_decay after every m-step / line-search step */
   double delta_decay;                /* gamma: d-step radius decay */
   double merit_decrease;             /* sigma */

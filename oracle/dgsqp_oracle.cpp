@@ -1162,6 +1162,7 @@ struct Ctx {
   const double* x0;
   int literal;
   vec* trace;  // optional event log (code, value) pairs, compared event-by-event with the device trace
+  mutable double osqp_rho = 0.1;  // par.osqp_rho_carry: the rho the previous OSQP call of this solve ended with (CasADi's plugin keeps its workspace)
   mutable bool qp_dead = false;   // qp_method = DGSQP_QP_OSQP: a QP inside the watchdog was primal / dual infeasible.  The reference carries the
                                   // NaN step on and raises in _get_mu at the next iteration (DGSQP.py:566-585): the solve ends with DGSQP_QP_FAIL
 };
@@ -1182,7 +1183,10 @@ static bool solve_qp(const Ctx& c, const Lin& k, vec& du, vec& lhat) {
   if (c.par.qp_method == DGSQP_QP_OSQP) {   // OSQP's own arithmetic (oracle/osqp.hpp): uba = -g, NaN answer when infeasible
     vec uba(c.L.nc);
     for (int r = 0; r < c.L.nc; r++) uba[r] = -k.g[r];
-    const osqp_restate::Info info = osqp_restate::conic(c.L.n, c.L.nc, Qpd.data(), k.q.data(), k.G.data(), uba.data(), du.data(), lhat.data());
+    osqp_restate::Settings S;
+    if (c.par.osqp_rho_carry) S.rho = c.osqp_rho;
+    const osqp_restate::Info info = osqp_restate::conic(c.L.n, c.L.nc, Qpd.data(), k.q.data(), k.G.data(), uba.data(), du.data(), lhat.data(), S);
+    if (c.par.osqp_rho_carry && std::isfinite(info.rho)) c.osqp_rho = info.rho;
     // a non-finite answer -- the NaNs OSQP stores for an infeasible QP, or an ADMM run that overflowed before its iteration limit --
     // is a NaN step: _get_mu raises on it (DGSQP.py:566-585)
     bool finite = true;
@@ -1438,7 +1442,10 @@ static bool v2_solve_qp(const Ctx& c, const Lin& k, double reg, vec& du, vec& lh
   if (c.par.qp_method == DGSQP_QP_OSQP) {
     vec uba(c.L.nc);
     for (int r = 0; r < c.L.nc; r++) uba[r] = -k.g[r];
-    const osqp_restate::Info info = osqp_restate::conic(c.L.n, c.L.nc, Qpd.data(), k.q.data(), k.G.data(), uba.data(), du.data(), lhat.data());
+    osqp_restate::Settings S;
+    if (c.par.osqp_rho_carry) S.rho = c.osqp_rho;
+    const osqp_restate::Info info = osqp_restate::conic(c.L.n, c.L.nc, Qpd.data(), k.q.data(), k.G.data(), uba.data(), du.data(), lhat.data(), S);
+    if (c.par.osqp_rho_carry && std::isfinite(info.rho)) c.osqp_rho = info.rho;
     // a non-finite answer -- the NaNs OSQP stores for an infeasible QP, or an ADMM run that overflowed before its iteration limit --
     // is a NaN step: _get_mu raises on it (DGSQP.py:566-585)
     bool finite = true;

@@ -54,7 +54,12 @@ class PyRef:
         if self.par.reg > 0:
             Q = Q + self.par.reg * np.eye(Q.shape[0])
         if self.qp_kind == 'osqp':
-            du, lhat, info = osqp_restate.conic(Q, q, G, -g, **self.qp_opts)
+            opts = dict(self.qp_opts)
+            if getattr(self.par, 'osqp_rho_carry', 0):        # the previous call's adapted rho (CasADi's conic plugin keeps its OSQP workspace)
+                opts['rho'] = self.osqp_rho
+            du, lhat, info = osqp_restate.conic(Q, q, G, -g, **opts)
+            if getattr(self.par, 'osqp_rho_carry', 0) and np.isfinite(info['rho']):
+                self.osqp_rho = float(info['rho'])
             self.qp_log.append((info['status'], info['iters'], info['polished']))
             return du, lhat
         if self.qp_kind == 'gi':           # the C++ oracle's Goldfarb-Idnani (exact minimiser); infeasible -> NaN like OSQP
@@ -182,6 +187,7 @@ class PyRef:
     def solve(self, x0, u_ws, trace=False, lsqr_kw=None):
         """u_ws agent-major [n].  Returns dict(u, l, status(bool), msg, num_iters, qp_solves, cond, l_init)."""
         self.x0 = np.ascontiguousarray(x0, float)
+        self.osqp_rho = 0.1
         self.trace = [] if trace else None
         par = self.par
         u = np.array(u_ws, float)

@@ -429,6 +429,34 @@ def test_event_trace_parity_with_osqp(oracle, games):
     assert identical >= B - 1, identical
 
 
+@pytest.mark.parametrize('kind', ['kb_chicane_N15', 'curve3_N25_xl'])
+def test_osqp_rho_carry_matches_the_oracle(oracle, games, kind):
+    """dgsqp_params_t.osqp_rho_carry (opt-in): an OSQP call starts from the rho the scenario's previous call ended with -- what OSQP does
+    inside CasADi's persistent conic plugin (SURVEY.md parity hazard 7) -- on the device (both OSQP kernels) and in the C++ oracle: identical
+    (status, iterations, QP solves) with a converged LSQR start, iterates of the converged ones to 1e-5; and the option is not a no-op."""
+    import copy
+    from dgsqp_amd import montecarlo as mc
+    from dgsqp_amd.solver import DGSQP, build_problem, build_params
+    g = games['kb_chicane_N15'][0] if kind == 'kb_chicane_N15' else mc.kinematic_racing_game('curve', N=25, M=3)
+    B = 12 if kind == 'kb_chicane_N15' else 6
+    P = build_problem(*g.solver_args())
+    par = tight_lsqr(build_params(g.params, qp_method='osqp', osqp_rho_carry=True))
+    assert par.osqp_rho_carry == 1
+    x0, u_tm = mc.sample_scenarios(g, B, seed=23)
+    s = DGSQP(*g.solver_args(), print_method=None, lsqr_tol=1e-13, qp_method='osqp', osqp_rho_carry=True)
+    res = s.solve_batch(x0, u_tm)
+    u = s._to_agent_major(u_tm)
+    ref = oracle.solve_batch(P, par, x0, u, nthreads=min(B, 8))
+    same = (res['status'] == ref['status']) & (res['num_iters'] == ref['num_iters']) & (res['qp_solves'] == ref['qp_solves'])
+    base = DGSQP(*g.solver_args(), print_method=None, lsqr_tol=1e-13, qp_method='osqp').solve_batch(x0, u_tm)
+    changed = (base['num_iters'] != res['num_iters']) | (base['qp_solves'] != res['qp_solves']) | (np.abs(base['u'] - res['u']).max(axis=1) > 1e-9)
+    print(f'{kind}: rho carried between the OSQP calls of a solve: device = oracle on {same.sum()}/{B} scenarios; differs from the restart-at-0.1 run on {changed.sum()}')
+    assert same.sum() >= B - 1
+    for b in np.nonzero(same & (ref['status'] <= 1))[0]:
+        assert rel(res['u'][b], ref['u'][b]) < 1e-5
+    assert changed.any()
+
+
 def test_xl_event_trace_parity_with_osqp(oracle):
     """The same on the XL layout (csrc/dgsqp_osqp_xl.h): the solvable three-car game of configs[2]'s size (n = 150, 825 rows), event
     by event against the C++ oracle with its OSQP, converged LSQR dual start; eight scenarios: the same SEQUENCE of events (iterations, QP
