@@ -1,7 +1,8 @@
 """What if OSQP keeps its adapted rho from call to call?  Inside CasADi's conic plugin the OSQP workspace persists (SURVEY.md parity
 hazard 7), the restatement (oracle/osqp_restate.py) starts every call at rho = 0.1.  On the six-car merge (reg = 0) that decides how many
 QPs run into the 4,000-iteration limit.  This study runs the numpy loop (oracle/pyref.py) on the first B scenarios of a game twice: as
-committed, and with the rho a call ended with handed to the next call of the same solve.
+committed, and with the rho a call ended with handed to the next call of the same solve (dgsqp_params_t.osqp_rho_carry; the device and the
+C++ oracle implement the same option, profiles/r05_osqp_rho_carry.txt holds the GPU measurement).
     usage: python tools/osqp_rho_carry_study.py <game of tools/ref_stats.py> <B> [nproc] [--carry-only]   (the restart-at-0.1 pass is what
     tests/golden/pyref_osqp_<game>.npz holds for the same first scenarios)"""
 import os, sys, pathlib
@@ -19,28 +20,14 @@ from oracle import oracle, pyref, osqp_restate
 from ref_stats import GAMES, CODE
 
 
-class CarryRho(pyref.PyRef):
-    rho = 0.1
-    iters = 0
-
-    def solve_qp(self, Q, q, G, g):
-        Q = self.nearest_pd(Q)
-        if self.par.reg > 0:
-            Q = Q + self.par.reg * np.eye(Q.shape[0])
-        du, lhat, info = osqp_restate.conic(Q, q, G, -g, rho=self.rho)
-        self.qp_log.append((info['status'], info['iters'], info['polished']))
-        if np.isfinite(info['rho']):
-            self.rho = float(info['rho'])
-        return du, lhat
-
-
 def one(args):
     name, b, B, carry = args
     g = GAMES[name][0]()
     P, par = build_problem(*g.solver_args()), build_params(g.params, eig_floor=1e-10)
     x0, uws = mc.sample_scenarios(g, B, seed=GAMES[name][1])
     u = np.concatenate([uws[:, :, 2 * a:2 * a + 2].reshape(B, -1) for a in range(uws.shape[2] // 2)], axis=1)
-    r = CarryRho(P, par, qp='osqp') if carry else pyref.PyRef(P, par, qp='osqp')
+    par.osqp_rho_carry = 1 if carry else 0          # (oracle/pyref.py hands the previous call's rho to the next one)
+    r = pyref.PyRef(P, par, qp='osqp')
     try:
         with np.errstate(all='ignore'):
             s = r.solve(x0[b], u[b])
