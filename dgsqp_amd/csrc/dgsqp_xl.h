@@ -786,6 +786,30 @@ __device__ __noinline__ void xl_j_mul_rows(cgptr J, int js, int n, int k0, int k
     }
   }
 }
+// The same product by the wavefronts 1 .. 7 only: wavefront 0 returns at once and is free for the triangular solve r = R^-1 d1 of the same
+// inner step (independent data: d1 / R against d2 / J) -- the two used to run one after the other, 20 k + 20 k cycles of the 60 k of a step
+// direction at n = 300.  Same rows, same sums as xl_j_mul_rows: results are bit-identical.
+__device__ __noinline__ void xl_j_mul_rows_but_wave0(cgptr J, int js, int n, int k0, int k1, clptr v, lptr out) {
+  const int lane = TID & 63, wave = TID >> 6;
+  if (wave == 0) return;
+  constexpr int RP = 8;
+  for (int i0 = (wave - 1) * RP; i0 < n; i0 += (NT / 64 - 1) * RP) {
+    double a[RP][XL_NV], vk[XL_NV];
+#pragma unroll
+    for (int cidx = 0; cidx < XL_NV; cidx++) {
+      const int k = k0 + lane + 64 * cidx;
+      const bool on = k < k1;
+      vk[cidx] = on ? v[k] : 0.0;
+#pragma unroll
+      for (int r = 0; r < RP; r++) a[r][cidx] = (on && i0 + r < n) ? J[(int64_t)(i0 + r) * js + k] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < RP; r++) {
+      const double t = wave_sum(((a[r][0] * vk[0] + a[r][1] * vk[1]) + (a[r][2] * vk[2] + a[r][3] * vk[3])) + a[r][4] * vk[4]);
+      if (lane == 0 && i0 + r < n) out[i0 + r] = t;
+    }
+  }
+}
 // out[i] = sum_{k0 <= k < k1} J[i][k] v[k]   (J v restricted to columns k0..k1-1).  LDS: the odd row stride keeps the row-per-thread
 // reads conflict-free.  Scratch: one wavefront per row, lanes along the row.
 template <class MP>
@@ -1478,10 +1502,19 @@ __device__ __noinline__ int dev_xl_qp_t(const Ctx& c, MP J, const int js) {
       have_d = false;
       // z = J2 d2: one pass over J -- except right after a drop, where J2 has only gained the column iq and d2 the entry d[iq]
       // (the rotations of the drop touch the columns l .. iq, none of the old J2): z += d[iq] J[:, iq]
-      if (have_z) { for (int i = TID; i < n; i += NT) zv[i] += dv[iq] * J[(int64_t)i * js + iq]; __syncthreads(); }
-      else xl_j_mul<MP>(J, js, n, S, iq, n, dv, zv, part);
+      if (have_z) {
+        for (int i = TID; i < n; i += NT) zv[i] += dv[iq] * J[(int64_t)i * js + iq];
+        __syncthreads();
+        if (TID < 64) xl_wave_backsub(R, iq, dv, rv);
+      } else if constexpr (!xl_mp<MP>::lds) {
+        // matrix in the scratch: wavefront 0 solves r = R^-1 d1 while the other seven form z = J2 d2
+        if (TID < 64) xl_wave_backsub(R, iq, dv, rv);
+        xl_j_mul_rows_but_wave0(J, js, n, iq, n, dv, zv);
+      } else {
+        xl_j_mul<MP>(J, js, n, S, iq, n, dv, zv, part);
+        if (TID < 64) xl_wave_backsub(R, iq, dv, rv);
+      }
       have_z = false;
-      if (TID < 64) xl_wave_backsub(R, iq, dv, rv);
       __syncthreads();
       PROF_END(PH_Q_DIR, px4);
       // step 2b: step lengths
