@@ -1473,6 +1473,33 @@ def test_dgsqp_v2_matches_oracle(oracle, kind):
     assert info['num_iters'] == int(res['num_iters'][0]) and np.array_equal(info['primal_sol'], res['u'][0])
 
 
+def test_dgsqp_v2_on_the_xl_layout_with_osqp(oracle):
+    """DG-SQP v2 with OSQP's arithmetic on the XL layout (v2_qp -> dev_xl_psd + dev_qp_osqp_xl with v2's decaying regularisation): the
+    three-car curve game (n = 150), the iteration limit cut to 12 so that the CPU side stays short; flags, iteration and QP counts
+    against the oracle's v2 + OSQP."""
+    from dgsqp_amd import montecarlo as mc
+    from dgsqp_amd.solver import build_problem, build_params
+    from dgsqp_amd.solver_types import DGSQPV2Params
+    from dgsqp_amd.solver_v2 import DGSQP as DGSQPv2
+    g = mc.kinematic_racing_game('curve', N=25, M=3)
+    g.params = DGSQPV2Params(dt=0.1, N=25, sqp_iters=12)
+    g.params.time_limit = None
+    P, par = build_problem(*g.solver_args()), build_params(g.params, lsqr_tol=1e-13, qp_method='osqp')
+    assert par.variant == 1 and par.qp_method == 1
+    s = DGSQPv2(*g.solver_args(), print_method=None, lsqr_tol=1e-13, qp_method='osqp')
+    assert s.dims.layout == 2
+    B = 4
+    x0, u_tm = mc.sample_scenarios(g, B, seed=2)
+    u = s._to_agent_major(u_tm)
+    res = s.solve_batch(x0, u_tm)
+    ref = oracle.solve_batch(P, par, x0, u, nthreads=B)
+    same = (res['status'] == ref['status']) & (res['num_iters'] == ref['num_iters']) & (res['qp_solves'] == ref['qp_solves'])
+    print(f'v2 + OSQP on the XL layout: identical {same.sum()}/{B}; device {res["status"].tolist()} {res["num_iters"].tolist()} {res["qp_solves"].tolist()} oracle {ref["status"].tolist()} {ref["num_iters"].tolist()} {ref["qp_solves"].tolist()}')
+    assert same.sum() >= B - 1
+    for b in np.nonzero(same)[0]:
+        assert rel(res['u'][b], ref['u'][b]) < 1e-5
+
+
 @pytest.mark.parametrize('model,N,B', [('kinematic', 12, 16), ('dynamic', 8, 8), ('kinematic', 50, 64)])
 def test_f1_spline_track_game(oracle, model, N, B):
     """BASELINE configs[3]'s game: two cars on the F1 track, a cubic-spline centre line (CasadiBSplineTrack,
