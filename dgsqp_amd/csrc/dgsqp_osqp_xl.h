@@ -123,51 +123,15 @@ __device__ inline void ox_gt_absmax(const DgProb& D, GP gd, cgptr E, lptr yd, lp
   }
   __syncthreads();
 }
+// W = Gs' Gs = D G' E^2 G D into the scratch, column by column through the transposed table (ox_build_tables, below): column j's
+// (gradient, value) pairs are scattered into an LDS vector indexed by gradient -- weighted with the E^2 of the rows sharing the gradient --,
+// then every row i >= j gathers its own pairs against it (four lanes per row, independent loads).  Box rows add to the diagonal, rate
+// rows to the diagonal and the (t, t - 1) entries.  (The first version visited every gradient of the later stages per ENTRY through the
+// constant-memory table: 47 Mcycles per QP at n = 300, a tenth of the QP; this one takes 2.)
+struct OxTabs;
+__device__ inline OxTabs ox_tabs(const Ctx& c);
 template <class GP>
-__device__ inline double ox_dense_entry(const DgDense dd, GP gd, int a, int t, int j) {
-  if (t >= dd.k) return 0.0;
-  if (dd.a == a) return gd[dd.off + t * DGSQP_NUA + j];
-  if (dd.kind == 1 && dd.b == a) return gd[dd.off + 2 * dd.k + t * DGSQP_NUA + j];
-  return 0.0;
-}
-// W = Gs' Gs = D G' E^2 G D (osqp_build_w of dgsqp_osqp.h with E and W in the scratch)
-template <class GP>
-__device__ inline void ox_build_w(const DgProb& D, const OxPtrs& o, GP gd) {
-  const int n = D.n;
-  __syncthreads();
-  for (int d = TID; d < D.ndense; d += NT) {
-    const DgDense dd = ld_dense(d);
-    const double ep = dd.r_pos >= 0 ? o.E[dd.r_pos] : 0.0, en = dd.r_neg >= 0 ? o.E[dd.r_neg] : 0.0;
-    o.yd2[d] = ep * ep + en * en;
-  }
-  __syncthreads();
-  for (int e = TID; e < n * n; e += NT) {
-    const int i = e / n, j = e - i * n;
-    if (j > i) continue;
-    const int ai = i / (D.N * DGSQP_NUA), ri = i % (D.N * DGSQP_NUA), ti = ri / DGSQP_NUA, ji = ri % DGSQP_NUA;
-    const int aj = j / (D.N * DGSQP_NUA), rj = j % (D.N * DGSQP_NUA), tj = rj / DGSQP_NUA, jj = rj % DGSQP_NUA;
-    double s = 0;
-    for (int d = D.stage_dense0[(ti > tj ? ti : tj) + 1]; d < D.ndense; d++) {
-      const DgDense dd = ld_dense(d);
-      const double gi = ox_dense_entry<GP>(dd, gd, ai, ti, ji);
-      if (gi == 0.0) continue;
-      s = __builtin_fma(o.yd2[d] * gi, ox_dense_entry<GP>(dd, gd, aj, tj, jj), s);
-    }
-    if (ai == aj && ji == jj) {
-      auto e2 = [&](int r) { const double ev = r >= 0 ? o.E[r] : 0.0; return ev * ev; };
-      if (ti == tj) {
-        s += e2(D.r_in_ub[ai][ti][ji]) + e2(D.r_in_lb[ai][ti][ji]) + e2(D.r_rate_ub[ai][ti][ji]) + e2(D.r_rate_lb[ai][ti][ji]);
-        if (ti + 1 < D.N) s += e2(D.r_rate_ub[ai][ti + 1][ji]) + e2(D.r_rate_lb[ai][ti + 1][ji]);
-      } else if (ti - tj == 1) {
-        s -= e2(D.r_rate_ub[ai][ti][ji]) + e2(D.r_rate_lb[ai][ti][ji]);
-      }
-    }
-    s *= o.Dv[i] * o.Dv[j];
-    o.W[(int64_t)i * n + j] = s;
-    o.W[(int64_t)j * n + i] = s;
-  }
-  XSYNC();
-}
+__device__ __noinline__ void ox_build_w(const Ctx& c, const OxPtrs& o, GP gd);
 
 // out_r = E_r (G (D v))_r for every G row; leaves D v in o.tmp and its dense dots in o.ddx
 template <class GP>
@@ -269,6 +233,60 @@ __device__ inline void ox_gt_mul(const Ctx& c, const OxPtrs& o, GP gd, clptr w, 
     if (part == 0) out[col] = sm;
   }
   __syncthreads();
+}
+template <class GP>
+__device__ __noinline__ void ox_build_w(const Ctx& c, const OxPtrs& o, GP gd) {
+  const DgProb& D = dg_prob;
+  const int n = D.n, nd = D.ndense;
+  const OxTabs T = ox_tabs(c);
+  lptr colj = o.w, wt = o.yd2;          // (w's slot holds n_c >= ndense doubles; the ADMM has not started)
+  __syncthreads();
+  for (int d = TID; d < nd; d += NT) {
+    const DgDense dd = ld_dense(d);
+    const double ep = dd.r_pos >= 0 ? o.E[dd.r_pos] : 0.0, en = dd.r_neg >= 0 ? o.E[dd.r_neg] : 0.0;
+    wt[d] = ep * ep + en * en;
+  }
+  __syncthreads();
+  auto e2 = [&](int r) { const double ev = r >= 0 ? o.E[r] : 0.0; return ev * ev; };
+  for (int j = 0; j < n; j++) {
+    for (int d = TID; d < nd; d += NT) colj[d] = 0.0;
+    __syncthreads();
+    for (int k = (int)T.cstart[j] + TID; k < (int)T.cstart[j + 1]; k += NT) { const unsigned int d = T.pairT[k] >> 22; colj[d] = wt[d] * T.gdT[k]; }
+    __syncthreads();
+    const int aj = j / (D.N * DGSQP_NUA), rj = j % (D.N * DGSQP_NUA), tj = rj / DGSQP_NUA, jj = rj % DGSQP_NUA;
+    const double dj = o.Dv[j];
+    for (int it4 = TID; it4 < 4 * (n - j); it4 += NT) {
+      const int i = j + (it4 >> 2), part = it4 & 3;
+      const int k1 = (int)T.cstart[i + 1];
+      int k = (int)T.cstart[i] + part;
+      double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+      for (; k + 12 < k1; k += 16) {
+        const unsigned int pa = T.pairT[k], pb = T.pairT[k + 4], pc = T.pairT[k + 8], pd = T.pairT[k + 12];
+        const double ga = T.gdT[k], gb = T.gdT[k + 4], gc = T.gdT[k + 8], gg = T.gdT[k + 12];
+        s0 = __builtin_fma(ga, colj[pa >> 22], s0); s1 = __builtin_fma(gb, colj[pb >> 22], s1); s2 = __builtin_fma(gc, colj[pc >> 22], s2); s3 = __builtin_fma(gg, colj[pd >> 22], s3);
+      }
+      for (; k < k1; k += 4) s0 = __builtin_fma(T.gdT[k], colj[T.pairT[k] >> 22], s0);
+      double sm = (s0 + s1) + (s2 + s3);
+      sm += dpp_f64<0xB1>(sm);
+      sm += dpp_f64<0x4E>(sm);
+      if (part == 0) {
+        const int ai = i / (D.N * DGSQP_NUA), ri = i % (D.N * DGSQP_NUA), ti = ri / DGSQP_NUA, ji = ri % DGSQP_NUA;
+        if (ai == aj && ji == jj) {
+          if (ti == tj) {
+            sm += e2(D.r_in_ub[ai][ti][ji]) + e2(D.r_in_lb[ai][ti][ji]) + e2(D.r_rate_ub[ai][ti][ji]) + e2(D.r_rate_lb[ai][ti][ji]);
+            if (ti + 1 < D.N) sm += e2(D.r_rate_ub[ai][ti + 1][ji]) + e2(D.r_rate_lb[ai][ti + 1][ji]);
+          } else if (ti - tj == 1) {
+            sm -= e2(D.r_rate_ub[ai][ti][ji]) + e2(D.r_rate_lb[ai][ti][ji]);
+          }
+        }
+        sm *= o.Dv[i] * dj;
+        o.W[(int64_t)i * n + j] = sm;
+        o.W[(int64_t)j * n + i] = sm;
+      }
+    }
+    __syncthreads();
+  }
+  XSYNC();
 }
 // out = D G' (E w): E w goes to the LDS vector sc (may be w itself), then the transposed product
 template <class GP>
@@ -404,10 +422,10 @@ __device__ __noinline__ double ox_setup(const Ctx& c, GP gd) {
     cc *= 1.0 / fmax(ct, qn);
   }
   PROF_END(PH_O_SCALE, po1);
-  PROF_BEGIN(po2);
-  ox_build_w<GP>(D, o, gd);
-  PROF_END(PH_O_W, po2);
   ox_build_tables<GP>(c, o, gd);
+  PROF_BEGIN(po2);
+  ox_build_w<GP>(c, o, gd);
+  PROF_END(PH_O_W, po2);
   return cc;
 }
 
