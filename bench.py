@@ -109,14 +109,20 @@ def algorithmic_flops_per_solve(d, P, mean_qp_solves, qp_method):
                 flop_per_solve=mean_qp_solves * (f_eval + f_eig + f_qp))
 
 
-def source_fingerprint():
-    """sha256 over the kernel sources: a PMC summary under profiles/ is only used for the kernels it was collected on."""
+def source_fingerprint(root=None):
+    """sha256 over the kernel sources WITHOUT their comments and white space: a PMC summary under profiles/ is only used for the kernels it
+    was collected on (editing a comment does not invalidate it; touching a statement does)."""
     import glob
     import hashlib
+    import re
+    root = root or ROOT
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, 'dgsqp_amd', 'csrc', '*.h')) + glob.glob(os.path.join(ROOT, 'dgsqp_amd', 'csrc', '*.hip')) + [os.path.join(ROOT, 'include', 'dgsqp.h')]):
+    for f in sorted(glob.glob(os.path.join(root, 'dgsqp_amd', 'csrc', '*.h')) + glob.glob(os.path.join(root, 'dgsqp_amd', 'csrc', '*.hip')) + [os.path.join(root, 'include', 'dgsqp.h')]):
+        text = open(f, encoding='utf-8', errors='replace').read()
+        text = re.sub(r'/\*.*?\*/', ' ', text, flags=re.S)
+        text = re.sub(r'//[^\n]*', ' ', text)
         h.update(os.path.basename(f).encode())
-        h.update(open(f, 'rb').read())
+        h.update(' '.join(text.split()).encode())
     return h.hexdigest()
 
 

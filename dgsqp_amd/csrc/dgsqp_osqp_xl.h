@@ -3,14 +3,20 @@
 //
 // Same algorithm, same algebra as dgsqp_osqp.h (Ruiz equilibration carried as D, E_I, E, c; the reduced ADMM system
 // K xt = sigma x - qs + As' (rho z - y), K = Ps + sigma I + rho_I (E_I D)^2 + rho W, W = Gs' Gs; identity rows not stored; polish in unscaled
-// variables in range-space form) -- what changes is where the matrices live and how K is inverted.  The n x n matrices (M, W, the
-// factor of K, the polish's Y and Schur complement) sit in the workgroup's L2 scratch; K^-1 v = J (J' v) with J = L^-T from the blocked
-// elimination of dgsqp_xl.h (xl_eliminate_blocked: 16 pivots per pass on the matrix cores) instead of the register-resident explicit
-// inverse; the products with G use the generic structured kernels (gt_mul, qp_dense_dots) that also serve the dual start -- the per-QP
-// index tables of the LDS path do not fit next to 1,587-row vectors.  LDS holds x, y (in the QP's output slots), z, w and seven
-// n-vectors; the row scaling E and delta y live in the scratch (coalesced row loops).  The polish builds Y = Ju' A_W' row by row (a box or
-// rate row is a row of Ju), the Schur complement S = Y' Y + delta E^-2, factors it with the same elimination and runs the three
-// refinement steps of OSQP against the unregularised residual; a polish with more active rows than variables is reported unsuccessful.
+// variables in range-space form) -- what changes is where the data lives and how K is inverted:
+//   * the n x n matrices (M, W, the factor J of K / Hu, K^-1, the polish's Y and Schur complement) sit in the workgroup's L2 scratch.  K is
+//     factored by the blocked elimination of dgsqp_xl.h (xl_eliminate_blocked: 16 pivots per pass on the matrix cores) and K^-1 = J J' is
+//     then formed EXPLICITLY, again on the matrix cores (ox_inverse_from_factor): an ADMM iteration streams one n x n matrix, not two;
+//   * the packed constraint gradients are transposed once per QP into the scratch (ox_build_tables: per column the list of (gradient,
+//     entry) pairs and the entries' values in that order): G' w is one pass of four lanes per column over streamed values, and W = G' E^2 G
+//     is built column by column from the same table -- the per-QP index tables of the LDS path, which do not fit next to 1,587-row vectors;
+//   * LDS holds x, y (in the QP's output slots), z, w and seven n-vectors; the row scaling E and delta y live in the scratch (coalesced row
+//     loops); the slot of w later holds the polish's vectors and, with the dense-dot partials behind it, the elimination's multipliers;
+//   * the polish builds Y = Ju' A_W' row by row (a box or rate row is a row of Ju), the Schur complement S = Y Y' + delta E^-2, factors it
+//     with the same elimination and runs OSQP's three refinement steps against the unregularised residual; a polish with more active rows
+//     than variables is reported unsuccessful.
+// Checked QP by QP against oracle/osqp.hpp (tests/test_gpu.py::test_xl_device_osqp_matches_the_cpu_restatement, ::test_xl_osqp_sizes_
+// between_the_configs: same status, ADMM iteration count, rho, polish verdict and active rows on 60 of 60 QPs).
 #pragma once
 
 struct OxPtrs {
