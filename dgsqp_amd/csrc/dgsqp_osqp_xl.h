@@ -15,7 +15,7 @@
 //   * the polish builds Y = Ju' A_W' row by row (a box or rate row is a row of Ju), the Schur complement S = Y Y' + delta E^-2, factors it
 //     with the same elimination and runs OSQP's three refinement steps against the unregularised residual; a polish with more active rows
 //     than variables is reported unsuccessful.
-// Checked QP by QP against oracle/osqp.hpp (tests/test_gpu.py::test_xl_device_osqp_matches_the_cpu_restatement, ::test_xl_osqp_sizes_
+// Checked QP by QP against the test infrastructure's C++ restatement of OSQP (osqp.hpp; tests/test_gpu.py::test_xl_device_osqp_matches_the_cpu_restatement, ::test_xl_osqp_sizes_
 // between_the_configs: same status, ADMM iteration count, rho, polish verdict and active rows on 60 of 60 QPs).
 #pragma once
 
