@@ -580,3 +580,39 @@ def test_vectorised_merge_sampler_equals_the_scalar_one():
         a, ua = mc._sample_scenarios_merge(g, 150, 1)
         b, ub = mc._sample_scenarios_merge_scalar(g, 150, 1)
         assert np.array_equal(a, b) and np.array_equal(ua, ub) and a.shape == (150, 4 * M)
+
+
+def test_bench_flop_model_fingerprint_and_extra_legs(tmp_path, games):
+    """bench.py pieces that need no GPU: SURVEY section 8(d)'s flop formula evaluated on configs[1]'s dimensions (the terms the JSON line
+    carries), the source fingerprint that guards stale PMC summaries (comments and white space do not count, statements do), and the extra
+    workloads of the default invocation (every one names a known workload; the configs' batch sizes are BASELINE.json's)."""
+    import json
+    import shutil
+    import types
+    sys.path.insert(0, str(ROOT))
+    import bench
+    g, P, par = games['dyn_curve_N25']
+    d = types.SimpleNamespace(M=2, N=25, n_q=16, n_u=4, n=100, n_dense=75)
+    fm = bench.algorithmic_flops_per_solve(d, P, 10.0, 'active_set')
+    t = fm['per_qp_solve']
+    assert t['F_eig'] == 9e6 and t['F_eval'] == 2 * (25 * 6 * 16 ** 3 + 2 * 16 * 4 * 625 * 16) + 25 * (2 * 3000.0 * 3.0 * 40)      # rk4, M = 10: 40 f_c per step
+    assert t['F_qp'] == 2 * 100 ** 2 * 25 + 100 ** 3 / 3 and fm['flop_per_solve'] == 10.0 * sum(t.values())
+    assert bench.algorithmic_flops_per_solve(d, P, 10.0, 'osqp')['per_qp_solve']['F_qp'] > t['F_qp']
+    # fingerprint
+    root = tmp_path / 'copy'
+    (root / 'dgsqp_amd').mkdir(parents=True)
+    shutil.copytree(ROOT / 'dgsqp_amd' / 'csrc', root / 'dgsqp_amd' / 'csrc', ignore=shutil.ignore_patterns('*.so', '__pycache__'))
+    shutil.copytree(ROOT / 'include', root / 'include')
+    assert bench.source_fingerprint(str(root)) == bench.source_fingerprint()
+    f = root / 'dgsqp_amd' / 'csrc' / 'dgsqp_qp.h'
+    f.write_text('// a new comment\n' + f.read_text().replace('\n', '\n   ', 3))
+    assert bench.source_fingerprint(str(root)) == bench.source_fingerprint()
+    f.write_text(f.read_text() + '\nstatic int dg_extra_statement = 1;\n')
+    assert bench.source_fingerprint(str(root)) != bench.source_fingerprint()
+    # extra legs
+    names = json.loads((ROOT / 'BASELINE.json').read_text())['configs']
+    assert len(names) == 5
+    legs = {leg['tag']: leg for leg in bench.EXTRA_LEGS}
+    assert all(leg['workload'] in bench.WORKLOADS for leg in bench.EXTRA_LEGS)
+    assert (legs['configs[2] B=4096']['batch'], legs['configs[3] B=16384']['batch'], legs['configs[4] B=65536']['batch']) == (4096, 16384, 65536)
+    assert 'batch=4096' in names[2] and 'batch=16384' in names[3] and 'batch=65536' in names[4]
