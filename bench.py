@@ -203,6 +203,9 @@ def parse_args(argv=None):
                     help="how _solve_qp is computed (dgsqp_params_t.qp_method): 'active_set' = the exact KKT point (dual active-set method + polish), "
                          "'osqp' = OSQP's own ADMM + polish arithmetic as the reference runs it (csrc/dgsqp_osqp.h); the cpu_baseline uses the same method")
     ap.add_argument('--reg', type=float, default=None, help='DGSQPParams.reg (default: the value of the workload)')
+    ap.add_argument('--mixed-precision', action='store_true',
+                    help="dgsqp_params_t.mixed_precision (off by default): with --qp osqp on the XL layout (configs[2], [3], [4]) the ADMM iteration's "
+                         "explicit K^-1 is stored in fp32 (fp64 accumulation); everything else stays fp64.  'dtype' of the line then says 'f64 (K^-1 of the ADMM iteration f32)'")
     ap.add_argument('--eig-floor', type=float, default=None, help='_nearestPD floor (default: the literal 1e-10, DGSQP.py:1293)')
     ap.add_argument('--snap-active-bounds', action='store_true', help='implementation knob, see include/dgsqp.h (default: literal)')
     ap.add_argument('--extras', choices=('auto', 'off'), default='auto',
@@ -221,7 +224,7 @@ def run_workload(args, rank, local_rank, world):
 
     game = make_game(args.workload, args.reg)
     mk = lambda: DGSQP(*game.solver_args(), print_method=None, device=local_rank, eig_floor=args.eig_floor,
-                       snap_active_bounds=args.snap_active_bounds, qp_method=args.qp)
+                       snap_active_bounds=args.snap_active_bounds, qp_method=args.qp, mixed_precision=getattr(args, 'mixed_precision', False))
     P = max(1, args.pipeline)
     if args.group <= 0:
         args.group = args.steps if args.steps <= 24 else 12
@@ -423,7 +426,7 @@ def run_workload(args, rank, local_rank, world):
             'metric': 'Monte-Carlo scenarios/sec (SQP solves/sec), 2-agent N=25' if args.workload.startswith(('dyn_curve_N25', 'kb_curve_N25', 'kb_chicane_N25'))
                       else 'Monte-Carlo scenarios/sec (SQP solves/sec)', 'value': value, 'unit': 'scenarios/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64 (K^-1 of the ADMM iteration f32)' if (getattr(args, 'mixed_precision', False) and args.qp == 'osqp' and solver.dims.layout == 2 and float(game.params.reg) >= 1e-4) else 'f64', 'data': 'synthetic',
             'config': {'workload': args.workload, 'description': WORKLOADS[args.workload]['desc'], 'batch_per_gpu': B, 'batch_total': B_total,
                        'n': int(d.n), 'n_c': int(d.n_c), 'parallelism': f'scenario-sharded x{world}',
                        'shard_mode': 'contiguous (weak: every rank samples its own batch_per_gpu scenarios)' if args.scaling == 'weak' else 'contiguous ranges of one batch (sharding.shard_range)',
@@ -518,6 +521,10 @@ EXTRA_LEGS = (
     dict(tag='configs[2] --qp osqp, B=4096', workload='kb_barc3_N25', qp='osqp', batch=4096, steps=1, warmup=0, pipeline=1, batches=1, group=1),
     dict(tag='configs[3] --qp osqp, reduced batch B=2048', workload='kb_f1_N50', qp='osqp', batch=2048, steps=1, warmup=0, pipeline=1, batches=1, group=1),
     dict(tag='configs[4] --qp osqp, reduced batch B=2048', workload='merge6_N25', qp='osqp', batch=2048, steps=1, warmup=0, pipeline=1, batches=1, group=1),
+    # ... and the solvable game of configs[2]'s size with OSQP, fp64 and with the opt-in fp32 storage of the ADMM iteration's K^-1
+    # (dgsqp_params_t.mixed_precision; configs[2] and [4] run at reg = 0, where the kernel keeps fp64: include/dgsqp.h)
+    dict(tag='configs[2] size, solvable game --qp osqp, B=4096', workload='kb_curve3_N25', qp='osqp', batch=4096, steps=1, warmup=0, pipeline=1, batches=1, group=1),
+    dict(tag='configs[2] size, solvable game --qp osqp --mixed-precision, B=4096', workload='kb_curve3_N25', qp='osqp', mixed_precision=True, batch=4096, steps=1, warmup=0, pipeline=1, batches=1, group=1),
 )
 RECORD_KEYS = ('value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'config', 'mean_iters', 'mean_iters_all', 'mean_qp_solves', 'converged_fraction',
                'status_fractions', 'roofline', 'value_single_launch', 'value_host_inclusive', 'value_host_inclusive_grouped', 'elapsed_s')

@@ -173,6 +173,7 @@ struct Ctx {
 // Regularisation added to the projected Hessian (DGSQP.py:238-239).  Constant in DG-SQP v1; v2 decays it from iteration to
 // iteration (DGSQP_v2.py:563,592), so it lives in an LDS scalar slot that dev_solve / dev_solve_v2 set per scenario.
 #define DG_REG 52
+#define DG_OSQP_F32 62   // scal slot: the current K^-1 of the XL ADMM iteration is stored in fp32 (dgsqp_params_t.mixed_precision and K well conditioned)
 #define DG_OSQP_RHO 47   // scal slot: rho the scenario's previous OSQP call ended with (dgsqp_params_t.osqp_rho_carry); 0.1 at the start of a solve
 __device__ inline double dev_reg() { const double r = LP(dg_prob.L.scal)[DG_REG]; return r > 0.0 ? r : 0.0; }
 // event log compared event-by-event with the oracle's (tests/test_gpu.py::test_event_trace_parity)

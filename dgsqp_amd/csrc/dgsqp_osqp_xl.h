@@ -339,7 +339,8 @@ __device__ inline void ox_solve(cgptr J, int m, clptr v, lptr t, lptr out, lptr 
 // sum over 16-column chunks k >= 16 ti of J[i][k] J[j][k] (J is upper triangular: earlier chunks are zero and skipped), mirrored on
 // store.  An ADMM iteration then needs ONE pass over an n x n matrix (ox_m_pass) instead of two over J -- the product is bound by the
 // bytes it streams from L2 / Infinity Cache (two thirds of an iteration at n = 300 otherwise).
-__device__ inline void ox_inverse_from_factor(cgptr J, gptr Ainv, int m) {
+template <class OT>
+__device__ inline void ox_inverse_from_factor(cgptr J, OT* Ainv, int m) {
   const int lane = TID & 63, wave = TID >> 6, li = lane & 15, h = lane >> 4;
   const int T = (m + 15) >> 4, ntile = T * (T + 1) / 2;
   __syncthreads();
@@ -368,13 +369,41 @@ __device__ inline void ox_inverse_from_factor(cgptr J, gptr Ainv, int m) {
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int row = 16 * ti + h + 4 * r, col = 16 * tj + li;
-      if (row < m && col < m) { Ainv[(int64_t)row * m + col] = acc[r]; if (ti != tj) Ainv[(int64_t)col * m + row] = acc[r]; }
+      if (row < m && col < m) { Ainv[(int64_t)row * m + col] = (OT)acc[r]; if (ti != tj) Ainv[(int64_t)col * m + row] = (OT)acc[r]; }
     }
   }
   XSYNC();
 }
 
 __device__ inline double ox_rho_I(const OxPtrs& o, int j, double rho) { return o.EI[j] * OSQP_INFTY > OSQP_INFTY * OSQP_MIN_SCALING ? OSQP_RHO_MIN : rho; }
+
+// out_i = sum_j Kinv_ij v_j for the symmetric matrix held in fp32 (dgsqp_params_t.mixed_precision): fp64 accumulation, half the bytes
+typedef __attribute__((address_space(1))) float glb_f;
+__device__ inline void ox_m_pass_f32(const glb_f* M, int n, clptr v, lptr part, lptr out) {
+  const XlSplit S = xl_split(n);
+  __syncthreads();
+  if (S.g < S.G && S.i < n) {
+    const int ja = (S.g * n) / S.G, jb = ((S.g + 1) * n) / S.G;
+    double a[4] = {0, 0, 0, 0};
+    int j = ja;
+    for (; j + 15 < jb; j += 16) {        // sixteen 4-byte loads in flight per lane = the bytes in flight of the fp64 pass
+      float m[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) m[k] = M[(int64_t)(j + k) * n + S.i];
+#pragma unroll
+      for (int k = 0; k < 16; k++) a[k & 3] = __builtin_fma((double)m[k], v[j + k], a[k & 3]);
+    }
+    for (; j < jb; j++) a[0] = __builtin_fma((double)M[(int64_t)j * n + S.i], v[j], a[0]);
+    part[S.g * n + S.i] = (a[0] + a[1]) + (a[2] + a[3]);
+  }
+  __syncthreads();
+  if (TID < n) {
+    double s = part[TID];
+    for (int g = 1; g < S.G; g++) s += part[g * n + TID];
+    out[TID] = s;
+  }
+  __syncthreads();
+}
 
 // Setup: finite-data check, Ruiz equilibration (10 passes), W.  Returns c, or NaN for non-finite data.
 template <class GP>
@@ -450,7 +479,20 @@ __device__ __noinline__ bool ox_build_k(const Ctx& c, double rho, double cc) {
     if (i == k) a += o.tmp[i];
     return a;
   });
-  if (ok) ox_inverse_from_factor(o.J, o.S, n);        // K^-1 itself, in the slot of the polish's Schur complement (unused until then)
+  if (ok) {        // K^-1 itself, in the slot of the polish's Schur complement (unused until then)
+    // dgsqp_params_t.mixed_precision: fp32 storage where the QP's Hessian is regularised.  ADMM run with a rounded inverse converges to the
+    // QP whose Hessian is off by K (K^-1 - fl32(K^-1)) K: below the 1e-3 of the curve and circuit games' reg (same solutions on 20 of 20
+    // solves converged in both, tests/test_gpu.py::test_xl_osqp_mixed_precision_against_fp64), but at reg = 0 the flat directions of P
+    // (eigenvalues 1e-10 after _nearestPD) drown in it: the six-car merge converged on 42 % instead of 88 % of 256 scenarios, with 53 instead
+    // of 36 QPs per solve.  Hence fp64 whenever reg < 1e-4 (v2 decays reg along a solve: decided per factorisation).
+    const bool f32 = D.par.mixed_precision && dev_reg() >= 1e-4;
+    if (D.par.mixed_precision) {
+      if (TID == 0) o.scal[DG_OSQP_F32] = f32 ? 1.0 : 0.0;
+      __syncthreads();
+    }
+    if (f32) ox_inverse_from_factor<glb_f>(o.J, (glb_f*)o.S, n);
+    else ox_inverse_from_factor<glb_d>(o.J, o.S, n);
+  }
   PROF_END(PH_O_KINV, po3);
   return ok;
 }
@@ -471,7 +513,8 @@ __device__ __noinline__ void ox_iterate(const Ctx& c, GP gd, double rho, double 
   __syncthreads();
   PROF_END(PH_O_GT, pa1);
   PROF_BEGIN(pa2);
-  ox_m_pass<false>(o.S, n, o.rhs, o.part, o.xt);          // xt = K^-1 rhs (explicit inverse: one pass over n x n)
+  if (D.par.mixed_precision && o.scal[DG_OSQP_F32] != 0.0) ox_m_pass_f32((const glb_f*)o.S, n, o.rhs, o.part, o.xt);
+  else ox_m_pass<false>(o.S, n, o.rhs, o.part, o.xt);     // xt = K^-1 rhs (explicit inverse: one pass over n x n)
   for (int i = TID; i < n; i += NT) {
     const double xt = o.xt[i], xp = o.x[i], xn = alpha * xt + (1.0 - alpha) * xp;
     o.x[i] = xn; o.dx[i] = xn - xp; o.tmp[i] = o.Dv[i] * xt;

@@ -184,17 +184,19 @@ def resolve_qp_method(params, qp_method: Optional[str]) -> int:
 
 def build_params(params: DGSQPParams, eig_floor: Optional[float] = None, snap_active_bounds: bool = False,
                  lsqr_tol: Optional[float] = None, qp_warm_start: bool = True, qp_method: Optional[str] = None,
-                 osqp_rho_carry: bool = False) -> _ffi.ParamsT:
+                 osqp_rho_carry: bool = False, mixed_precision: bool = False) -> _ffi.ParamsT:
     """``eig_floor``: value ``_nearestPD`` gives to negative eigenvalues; ``None`` = the reference's literal 1e-10
     (DGSQP.py:1293).  At ``reg = 0`` (curve.py, comp.py, merge.py) that leaves a QP of condition 1e12, which the device solves
     with its classical (J = L^-T) active-set kernels; passing a larger floor (1e-6) is an explicit opt-in that keeps such games
     on the faster explicit-inverse kernels.  ``snap_active_bounds``: see include/dgsqp.h (default literal).
     ``lsqr_tol``: atol = btol of the LSQR dual start; ``None`` = scipy's defaults (1e-6), what ``DGSQP.py:324`` runs with.
     ``osqp_rho_carry`` (``qp_method='osqp'`` only): an OSQP call starts from the rho the previous call of the same solve ended with, as
-    inside CasADi's persistent conic plugin, instead of 0.1 (include/dgsqp.h; default off = the committed restatements)."""
+    inside CasADi's persistent conic plugin, instead of 0.1 (include/dgsqp.h; default off = the committed restatements).
+    ``mixed_precision`` (``qp_method='osqp'`` on the XL layout only): the ADMM iteration's explicit K^-1 in fp32, everything else fp64."""
     if isinstance(params, DGSQPV2Params):
         p2 = _build_params_v2(params, eig_floor, snap_active_bounds, lsqr_tol, qp_warm_start, qp_method)
         p2.osqp_rho_carry = int(bool(osqp_rho_carry))
+        p2.mixed_precision = int(bool(mixed_precision))
         return p2
     if not params.conv_approx:
         raise NotImplementedError('conv_approx=False (IPOPT Newton step, DGSQP.py:204-228) is not on the Monte-Carlo path')
@@ -216,6 +218,7 @@ def build_params(params: DGSQPParams, eig_floor: Optional[float] = None, snap_ac
     p.snap_active_bounds = int(bool(snap_active_bounds))
     p.qp_method = resolve_qp_method(params, qp_method)
     p.osqp_rho_carry = int(bool(osqp_rho_carry))
+    p.mixed_precision = int(bool(mixed_precision))
     return p
 
 
@@ -361,7 +364,8 @@ class DGSQP(AbstractSolver):
                  lsqr_tol: Optional[float] = None,
                  qp_warm_start: bool = True,
                  qp_method: Optional[str] = None,
-                 osqp_rho_carry: bool = False):
+                 osqp_rho_carry: bool = False,
+                 mixed_precision: bool = False):
         """``eig_floor``, ``snap_active_bounds``: implementation knobs, see ``build_params``; the defaults are the reference's
         literal formulas (``_nearestPD`` floor 1e-10, DGSQP.py:1293; no adjustment of the QP step).  ``qp_method``: 'active_set'
         (exact KKT point) or 'osqp' (OSQP's own ADMM + polish arithmetic), see ``resolve_qp_method``."""
@@ -380,7 +384,8 @@ class DGSQP(AbstractSolver):
 
         self._problem = build_problem(joint_dynamics, costs, agent_constraints, shared_constraints, bounds, params)
         self._cparams = build_params(params, eig_floor=eig_floor, snap_active_bounds=snap_active_bounds, lsqr_tol=lsqr_tol,
-                                     qp_warm_start=qp_warm_start, qp_method=qp_method, osqp_rho_carry=osqp_rho_carry)
+                                     qp_warm_start=qp_warm_start, qp_method=qp_method, osqp_rho_carry=osqp_rho_carry,
+                                     mixed_precision=mixed_precision)
         _, _, self.n, n_c = problem_dims(self._problem)
         self.n_c_total = n_c
 

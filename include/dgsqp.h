@@ -205,6 +205,15 @@ typedef struct {
                                         the parity tests compare with do.  1: a call starts from the rho the previous call of the same solve()
                                         ended with -- inside CasADi's conic plugin the OSQP workspace persists and keeps its adapted rho
                                         (SURVEY.md parity hazard 7); the first call of a solve starts at 0.1 */
+  int32_t mixed_precision;           /* 0 (default): fp64 storage and arithmetic throughout.  1: qp_method = DGSQP_QP_OSQP on the XL layout
+                                        (n > 128: BASELINE configs[2], [3], [4], which name fp32) keeps the explicit K^-1 of the ADMM iteration in
+                                        fp32 -- fp64 accumulation; the iteration is memory-bound and K^-1 is 60 % of the bytes it streams --;
+                                        factorisations, residual checks, the polish and every other kernel stay fp64 -- and so does K^-1 when
+                                        reg < 1e-4 (measured: at reg = 0 the flat directions of the projected Hessian drown in the rounding and
+                                        the six-car merge of configs[4] loses half its converged solves, so the switch leaves that game in fp64).
+                                        At reg = 1e-3 the returned points agree with the fp64 kernel's (the polish is fp64), ADMM iteration
+                                        counts are no longer bit-comparable with the fp64 restatements */
+  int32_t reserved_;
   double reg_decay;                  /* reg <- reg * reg_decay after every m-step / line-search step */
   double delta_decay;                /* gamma: d-step radius decay */
   double merit_decrease;             /* sigma */

@@ -457,6 +457,60 @@ def test_osqp_rho_carry_matches_the_oracle(oracle, games, kind):
     assert changed.any()
 
 
+@pytest.mark.parametrize('name', ['curve3_N25', 'kb_f1_N50', 'merge6_N25'])
+def test_xl_osqp_mixed_precision_against_fp64(oracle, name):
+    """dgsqp_params_t.mixed_precision (opt-in; BASELINE configs[2..4] name fp32): the XL ADMM iteration with K^-1 stored in fp32 against the
+    fp64 kernel and, through it, oracle/osqp.hpp.  QP level (8 scenarios, the QP at the dual start): the same verdict (solved /
+    infeasible / limit) on every QP both runs settle (statuses 1, -3, -4), the ADMM iteration count within 25 % (or 50), and wherever both
+    polishes succeed the same point to 1e-6 -- the polish is fp64 and lands on the KKT point of the same active set.  Solve level (24
+    scenarios): converged fractions within 3 scenarios of each other, and the solutions of scenarios converged in both within 1e-3
+    on at least 80 % of them (the solvable three-car game; F1 is chaotic: statistics only).  The six-car merge runs at reg = 0, where the
+    kernel keeps K^-1 in fp64 (csrc/dgsqp_osqp_xl.h, ox_build_k: the measured reason): the switch must leave it bit-identical."""
+    from dgsqp_amd import montecarlo as mc
+    from dgsqp_amd.solver import DGSQP, build_problem, build_params
+    g = mc.kinematic_racing_game('curve', N=25, M=3) if name == 'curve3_N25' else XL_REF_GAMES[name](mc)
+    P, par = build_problem(*g.solver_args()), build_params(g.params, qp_method='osqp')
+    s64 = DGSQP(*g.solver_args(), print_method=None, qp_method='osqp')
+    s32 = DGSQP(*g.solver_args(), print_method=None, qp_method='osqp', mixed_precision=True)
+    assert s32.dims.layout == 2 and s32._cparams.mixed_precision == 1 and s64._cparams.mixed_precision == 0
+    B = 8
+    x0, u_tm = mc.sample_scenarios(g, B, seed=1 if name == 'merge6_N25' else 0)
+    u = s64._to_agent_major(u_tm)
+    l = np.array([oracle.dual_init(P, par, x0[b], u[b]) for b in range(B)])
+    a, b_ = s64.qp_batch(x0, u, l), s32.qp_batch(x0, u, l)
+    settled, polished, worst = 0, 0, 0.0
+    for i in range(B):
+        ia, ib = a['info'][i], b_['info'][i]
+        if int(ia[0]) in (1, -3, -4) and int(ib[0]) in (1, -3, -4):
+            settled += 1
+            assert int(ia[0]) == int(ib[0]), (ia[:6], ib[:6])
+            assert abs(ia[1] - ib[1]) <= max(50, 0.25 * ia[1]), (ia[:6], ib[:6])
+        if int(ia[0]) == 1 and int(ib[0]) == 1 and int(ia[2]) == 1 and int(ib[2]) == 1 and int(ia[5]) == int(ib[5]):
+            polished += 1
+            worst = max(worst, np.abs(a['du'][i] - b_['du'][i]).max() / max(1.0, np.abs(a['du'][i]).max()))
+    print(f'{name}: K^-1 in fp32 vs fp64, QP at the dual start: {settled}/{B} settled in both with the same verdict, {polished} polished in both, x within {worst:.1e}; '
+          f'ADMM iterations fp64 {a["info"][:, 1].astype(int).tolist()} fp32 {b_["info"][:, 1].astype(int).tolist()}')
+    assert worst < 1e-6
+    if name == 'curve3_N25':
+        assert settled >= B - 1 and polished >= B // 2
+    B = 24
+    x0, u_tm = mc.sample_scenarios(g, B, seed=5)
+    r64, r32 = s64.solve_batch(x0, u_tm), s32.solve_batch(x0, u_tm)
+    c64, c32 = r64['status'] == 0, r32['status'] == 0
+    both = c64 & c32
+    close = np.array([rel(r32['u'][i], r64['u'][i]) < 1e-3 for i in np.nonzero(both)[0]])
+    print(f'{name}: full solves, K^-1 fp32 vs fp64: converged {c32.sum()} vs {c64.sum()} of {B}, mean QP solves {r32["qp_solves"].mean():.1f} vs {r64["qp_solves"].mean():.1f}; '
+          f'same solution (1e-3) on {int(close.sum())}/{int(both.sum())} converged in both')
+    assert abs(int(c32.sum()) - int(c64.sum())) <= (3 if name == 'curve3_N25' else 6)
+    if name == 'curve3_N25':
+        assert both.sum() >= B // 2 and close.mean() >= 0.8
+    if name == 'merge6_N25':
+        assert g.params.reg == 0
+        for k in ('status', 'num_iters', 'qp_solves', 'u'):
+            assert np.array_equal(r32[k], r64[k]), k
+        assert np.array_equal(a['du'], b_['du'], equal_nan=True)
+
+
 def test_xl_event_trace_parity_with_osqp(oracle):
     """The same on the XL layout (csrc/dgsqp_osqp_xl.h): the solvable three-car game of configs[2]'s size (n = 150, 825 rows), event
     by event against the C++ oracle with its OSQP, converged LSQR dual start; eight scenarios: the same SEQUENCE of events (iterations, QP

@@ -1,5 +1,5 @@
 """Development aid: time solve_batch for a config on the GPU box (with the -DDG_PROF library: per-phase cycle counters).
-usage: gpu_time.py <dyn|kbcurve|kbchicane|agents3|kbcurve50|any workload name of bench.py> <N> <B> [rk4 substeps]   (environment: DGSQP_QP_METHOD)"""
+usage: gpu_time.py <dyn|kbcurve|kbchicane|agents3|kbcurve50|any workload name of bench.py> <N> <B> [rk4 substeps]   (environment: DGSQP_QP_METHOD, DGSQP_MIXED=1)"""
 import sys, time, pathlib
 import numpy as np
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
@@ -19,7 +19,8 @@ elif which.startswith('kb'):  # reg as in the scripts: curve.py:161 reg=0, chica
 else:
     game = dynamic_racing_game(N=N, rk4_substeps=M)
 import os
-s = DGSQP(*game.solver_args(), print_method=None, qp_method=os.environ.get('DGSQP_QP_METHOD') or None)
+s = DGSQP(*game.solver_args(), print_method=None, qp_method=os.environ.get('DGSQP_QP_METHOD') or None,
+          mixed_precision=bool(os.environ.get('DGSQP_MIXED')))
 t = time.time(); x0, uws = sample_scenarios(game, B, seed=1); print('sample', time.time() - t)
 for rep in range(2):
     t = time.time(); res = s.solve_batch(x0, uws); dt = time.time() - t
