@@ -535,7 +535,7 @@ def main():
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         spawn_ranks(args.gpus, sys.argv[1:])
     rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('DGSQP_BENCH_DEVICE', os.environ.get('LOCAL_RANK', '0')))      # (the override lets a 1-GPU box rehearse the multi-rank path)
+    local_rank = int(os.environ.get('DGSQP_BENCH_DEVICE', os.environ.get('LOCAL_RANK', '0')))      # (the override lets a 1-GPU box rehearse spawn + rendezvous of the multi-rank path -- up to ncclCommInitRank, which refuses two ranks on one device)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus != world:
         sys.stderr.write(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus} '
