@@ -208,6 +208,8 @@ def parse_args(argv=None):
                          "explicit K^-1 is stored in fp32 (fp64 accumulation); everything else stays fp64.  'dtype' of the line then says 'f64 (K^-1 of the ADMM iteration f32)'")
     ap.add_argument('--eig-floor', type=float, default=None, help='_nearestPD floor (default: the literal 1e-10, DGSQP.py:1293)')
     ap.add_argument('--snap-active-bounds', action='store_true', help='implementation knob, see include/dgsqp.h (default: literal)')
+    ap.add_argument('--extras-budget', type=float, default=420.0,
+                    help='seconds since the start of the process after which no further extra leg is started (the legs left out are named in the line); the full set takes about five minutes on an MI355X')
     ap.add_argument('--extras', choices=('auto', 'off'), default='auto',
                     help="auto: the default invocation (configs[1], exact QP, one GPU) also times, in the same run and into the same JSON line "
                          "(key 'workloads'), --qp osqp on configs[1] and BASELINE configs[2], [3], [4] at the batch sizes BASELINE.json names; off: only the workload asked for")
@@ -519,8 +521,8 @@ EXTRA_LEGS = (
     # ... and the same games with OSQP's own arithmetic (csrc/dgsqp_osqp_xl.h, round 5) at REDUCED batch sizes: at reg = 0 the restated OSQP
     # runs into its 4,000-iteration limit on most QPs of the merge (3,400 ADMM iterations per QP on average), a solve costs 30 x the exact QP's
     dict(tag='configs[2] --qp osqp, B=4096', workload='kb_barc3_N25', qp='osqp', batch=4096, steps=1, warmup=0, pipeline=1, batches=1, group=1),
-    dict(tag='configs[3] --qp osqp, reduced batch B=2048', workload='kb_f1_N50', qp='osqp', batch=2048, steps=1, warmup=0, pipeline=1, batches=1, group=1),
-    dict(tag='configs[4] --qp osqp, reduced batch B=2048', workload='merge6_N25', qp='osqp', batch=2048, steps=1, warmup=0, pipeline=1, batches=1, group=1),
+    dict(tag='configs[3] --qp osqp, reduced batch B=1024', workload='kb_f1_N50', qp='osqp', batch=1024, steps=1, warmup=0, pipeline=1, batches=1, group=1),
+    dict(tag='configs[4] --qp osqp, reduced batch B=1024', workload='merge6_N25', qp='osqp', batch=1024, steps=1, warmup=0, pipeline=1, batches=1, group=1),
     # ... and the solvable game of configs[2]'s size with OSQP, fp64 and with the opt-in fp32 storage of the ADMM iteration's K^-1
     # (dgsqp_params_t.mixed_precision; configs[2] and [4] run at reg = 0, where the kernel keeps fp64: include/dgsqp.h)
     dict(tag='configs[2] size, solvable game --qp osqp, B=4096', workload='kb_curve3_N25', qp='osqp', batch=4096, steps=1, warmup=0, pipeline=1, batches=1, group=1),
@@ -528,6 +530,9 @@ EXTRA_LEGS = (
 )
 RECORD_KEYS = ('value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'config', 'mean_iters', 'mean_iters_all', 'mean_qp_solves', 'converged_fraction',
                'status_fractions', 'roofline', 'value_single_launch', 'value_host_inclusive', 'value_host_inclusive_grouped', 'elapsed_s')
+
+
+T_START = time.perf_counter()
 
 
 def main():
@@ -552,6 +557,9 @@ def main():
                 a = copy.copy(args)
                 a.single_steps, a.host_steps, a.cpu_sample, a.group = 0, 0, 0, 0
                 tag = leg['tag']
+                if time.perf_counter() - T_START > args.extras_budget:
+                    records.append(dict(tag=tag, skipped=f'not started: {time.perf_counter() - T_START:.0f} s into the run, --extras-budget {args.extras_budget:.0f} s'))
+                    continue
                 for k, v in leg.items():
                     if k != 'tag':
                         setattr(a, k, v)

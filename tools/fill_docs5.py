@@ -25,8 +25,8 @@ lab = {'configs[1] (the headline)': ('**configs[1]** 2-agent dynamic bicycle cur
        'configs[3] B=16384': ('**configs[3]** 2-car F1 track N=50 (n = 200), reg 1e-3', 'XL, exact QP'),
        'configs[4] B=65536': ('**configs[4]** 6-car merge N=25 (n = 300, 1,587 rows), reg 0', 'XL, exact QP'),
        'configs[2] --qp osqp, B=4096': ('configs[2], `--qp osqp`', 'XL, OSQP'),
-       'configs[3] --qp osqp, reduced batch B=2048': ('configs[3], `--qp osqp`, reduced batch', 'XL, OSQP'),
-       'configs[4] --qp osqp, reduced batch B=2048': ('configs[4], `--qp osqp`, reduced batch', 'XL, OSQP'),
+       'configs[3] --qp osqp, reduced batch B=1024': ('configs[3], `--qp osqp`, reduced batch', 'XL, OSQP'),
+       'configs[4] --qp osqp, reduced batch B=1024': ('configs[4], `--qp osqp`, reduced batch', 'XL, OSQP'),
        'configs[2] size, solvable game --qp osqp, B=4096': ("the solvable game of configs[2]'s size, `--qp osqp`", 'XL, OSQP'),
        'configs[2] size, solvable game --qp osqp --mixed-precision, B=4096': ("same, `--mixed-precision` (`K⁻¹` of the ADMM iteration in fp32; §1)", 'XL, OSQP, fp32 operand')}
 for tag, (label, layout) in lab.items():
@@ -71,9 +71,9 @@ def baseline_table():
             add("2'. same — OSQP", "the solvable three-car game, `qp_method='osqp'`", '4,096', 'configs[2] size, solvable game --qp osqp, B=4096', 'event sequences identical to the oracle with its OSQP on 8 of 8 scenarios'),
             add("2'. same — OSQP, `--mixed-precision`", "same; the ADMM iteration's `K⁻¹` stored in fp32 (`dgsqp_params_t.mixed_precision`, opt-in)", '4,096', 'configs[2] size, solvable game --qp osqp --mixed-precision, B=4096', 'the mixed-precision line (DESIGN.md §1): same solutions on 20 of 20 solves converged in both; configs[2] and [4] run at `reg = 0`, where the kernel keeps fp64'),
             add('3. 2-agent F1 N=50, B=16384', '`f1_racing_game(N=50)`: cubic-spline track on the device (n = 200, 1,050 rows, XL layout)', '16,384 in one cooperative launch', 'configs[3] B=16384', 'converged 49 % here, 53 % C++ oracle, 52 % numpy + OSQP loop (64 scenarios); chaotic game: only statistics are comparable (DESIGN.md §2); fp64, one GPU'),
-            add('3. same — OSQP', "same game, `qp_method='osqp'`", '2,048 (reduced)', 'configs[3] --qp osqp, reduced batch B=2048', '1,150 ADMM iterations per QP'),
+            add('3. same — OSQP', "same game, `qp_method='osqp'`", '1,024 (reduced)', 'configs[3] --qp osqp, reduced batch B=1024', '1,150 ADMM iterations per QP'),
             add('4. 6-agent merge N=25, B=65536', '`merge_game(N=25, M=6)`: n = 300, 1,587 rows, 837 dense gradients (XL layout, tables in constant memory)', '65,536 in one cooperative launch', 'configs[4] B=65536', '32/32 solves identical to the oracle; fp64, one GPU (the config names fp32 and 8 GPUs)'),
-            add('4. same — OSQP', "same game, `qp_method='osqp'`", '2,048 (reduced)', 'configs[4] --qp osqp, reduced batch B=2048', 'identical paths to the numpy + OSQP loop on 62 of 64 scenarios, converged 81.2 % on both; 3,400 ADMM iterations per QP at `reg = 0`')]
+            add('4. same — OSQP', "same game, `qp_method='osqp'`", '1,024 (reduced)', 'configs[4] --qp osqp, reduced batch B=1024', 'identical paths to the numpy + OSQP loop on 62 of 64 scenarios, converged 81.2 % on both; 3,400 ADMM iterations per QP at `reg = 0`')]
     return '\n'.join(rows)
 
 
