@@ -631,6 +631,29 @@ __device__ __noinline__ void osqp_iterate_block(const Ctx& c, double rho, double
     const double v = D.big ? (c.ws + D.ws_P)[idx] : LP(D.L.g_Bp)[idx];
     pr[k] = valid ? v : 0.0;
   }
+  // ... and the packed gradient entries it multiplies in every iteration: the 16 values of its first dense-dot task (phase 5) and the
+  // first GTR (value, gradient index) pairs of its quarter of a column of G' (phase 2) -- both orders of the same numbers
+  constexpr int GTR = 14;
+  const bool task0 = TID < D.ntask;
+  const DgTask T0 = task0 ? ld_task(TID) : DgTask{0, 0, 0, 0};
+  double pv0[DG_CHUNK];
+#pragma unroll
+  for (int i = 0; i < DG_CHUNK; i++) pv0[i] = (task0 && i < T0.len) ? o.gd[T0.p0 + i] : 0.0;
+  const bool gcol = TID < 4 * n;
+  const int gk0 = gcol ? tabs.cstart[TID >> 2] + (TID & 3) : 0, gk1 = gcol ? tabs.cstart[(TID >> 2) + 1] : 0;
+  double gtv[GTR];
+  int gti[GTR];
+#pragma unroll
+  for (int m = 0; m < GTR; m++) {
+    const int k = gk0 + 4 * m;
+    const bool valid = k < gk1;
+    const unsigned int pa = valid ? tabs.pairT[k] : 0u;
+    gtv[m] = valid ? o.gd[pa & 0xffffu] : 0.0;
+    gti[m] = valid ? (int)(pa >> 16) : 0;
+  }
+  int gcnt = gcol && gk1 > gk0 ? (gk1 - gk0 + 3) / 4 : 0;               // pairs of this lane held in registers ...
+  gcnt = gcnt < GTR ? gcnt : GTR;
+  const int gwave = (int)wave_max((double)gcnt);                          // ... and the most any lane of the wavefront holds (uniform loop bound)
   for (int rep = 0; rep < count; rep++) {
     // One ADMM iteration in six barrier phases.  Carried between iterations: w = E (rho z - y)  (rebuilt after a check, which uses w).
     // (1) yd_d = w[r+] - w[r-]: what every dense gradient contributes to G' w
@@ -653,6 +676,12 @@ __device__ __noinline__ void osqp_iterate_block(const Ctx& c, double rho, double
       }
       const int k1 = tabs.cstart[col + 1];
       int k = tabs.cstart[col] + part;
+      if (it4 == TID) {        // this thread's own column quarter: values and indices from registers (zeros beyond its end)
+#pragma unroll
+        for (int m = 0; m < GTR; m += 2)
+          if (m < gwave) { s0 = __builtin_fma(o.yd[gti[m]], gtv[m], s0); s1 = __builtin_fma(o.yd[gti[m + 1]], gtv[m + 1], s1); }
+        k += 4 * GTR;
+      }
       for (; k + 4 < k1; k += 8) {
         const unsigned int pa = tabs.pairT[k], pb = tabs.pairT[k + 4];
         const double ga = o.gd[pa & 0xffffu], ya = o.yd[pa >> 16], gb = o.gd[pb & 0xffffu], yb = o.yd[pb >> 16];
@@ -692,7 +721,17 @@ __device__ __noinline__ void osqp_iterate_block(const Ctx& c, double rho, double
     PROF_END(PH_O_PMUL, pa2);
     // (5) chunk sums of the dense gradients' dots with D xt
     PROF_BEGIN(pa3);
-    for (int t = TID; t < D.ntask; t += NT) {
+    if (task0) {           // the thread's first task: gradient values from registers
+      clptr wv = o.tmp + T0.v0;
+      double wq[DG_CHUNK];
+#pragma unroll
+      for (int i = 0; i < DG_CHUNK; i++) wq[i] = wv[i];
+      double sa[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < DG_CHUNK; i++) sa[i & 3] += i < T0.len ? pv0[i] * wq[i] : 0.0;
+      o.dpart[TID] = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+    }
+    for (int t = TID + NT; t < D.ntask; t += NT) {
       const DgTask T = ld_task(t);
       clptr p = o.gd + T.p0;
       clptr wv = o.tmp + T.v0;
