@@ -497,46 +497,153 @@ __device__ __noinline__ bool ox_build_k(const Ctx& c, double rho, double cc) {
   return ok;
 }
 
-// One ADMM iteration (Algorithm 1, alpha = 1.6): x, z, y, w = E (rho z - y) in LDS; leaves delta x (LDS) and delta y (scratch)
+// `count` ADMM iterations (Algorithm 1, alpha = 1.6): x, z, y, w = E (rho z - y) in LDS; leaves delta x (LDS) and delta y (scratch) of the
+// last one.  The iterations between two termination checks run inside ONE call: every thread keeps the first OX_RC values of its slice of
+// K^-1 (column TID of its row group: n / G values, G = 3, 2, 1 at n = 150, 200, 300) in registers across them -- the iteration is bound by
+// the bytes it streams, and K^-1 is most of them: all but 2 of 50 values at n = 150, half of them at n = 200, a sixth at n = 300.  Same
+// products in the same order as ox_m_pass / ox_m_pass_f32 (the register prefix covers whole groups of the unrolled loop): bit-identical.
+#define OX_RC 48
 template <class GP>
-__device__ __noinline__ void ox_iterate(const Ctx& c, GP gd, double rho, double cc) {
+__device__ __noinline__ void ox_iterate_block(const Ctx& c, GP gd, double rho, double cc, int count) {
   const DgProb& D = dg_prob;
   const int n = D.n, nc = D.nc;
   const OxPtrs o = ox_ptrs(c);
   const double sigma = 1e-6, alpha = 1.6, irho = 1.0 / rho;
-  PROF_BEGIN(pa1);
-  ox_gt_mul<GP>(c, o, gd, o.w, o.xt);                     // G' w   (w already carries E)
-  for (int j = TID; j < n; j += NT) {
-    const double dj = o.Dv[j], aI = o.EI[j] * dj, xj = o.x[j];
-    o.rhs[j] = sigma * xj - cc * dj * o.q[j] + dj * o.xt[j] + aI * ox_rho_I(o, j, rho) * (aI * xj);
+  const bool f32 = D.par.mixed_precision && o.scal[DG_OSQP_F32] != 0.0;
+  const XlSplit S = xl_split(n);
+  const bool act = S.g < S.G && S.i < n;
+  const int ja = act ? (S.g * n) / S.G : 0, jb = act ? ((S.g + 1) * n) / S.G : 0;
+  const bool regs = n / S.G >= OX_RC;                      // (block-uniform: every row group then holds at least OX_RC rows)
+  double kc[OX_RC];
+#pragma unroll
+  for (int k = 0; k < OX_RC; k++) {
+    const bool valid = regs && act;                        // ja + k < jb by the line above
+    const int64_t idx = valid ? (int64_t)(ja + k) * n + S.i : 0;
+    kc[k] = valid ? (f32 ? (double)((const glb_f*)o.S)[idx] : o.S[idx]) : 0.0;
   }
-  __syncthreads();
-  PROF_END(PH_O_GT, pa1);
-  PROF_BEGIN(pa2);
-  if (D.par.mixed_precision && o.scal[DG_OSQP_F32] != 0.0) ox_m_pass_f32((const glb_f*)o.S, n, o.rhs, o.part, o.xt);
-  else ox_m_pass<false>(o.S, n, o.rhs, o.part, o.xt);     // xt = K^-1 rhs (explicit inverse: one pass over n x n)
-  for (int i = TID; i < n; i += NT) {
-    const double xt = o.xt[i], xp = o.x[i], xn = alpha * xt + (1.0 - alpha) * xp;
-    o.x[i] = xn; o.dx[i] = xn - xp; o.tmp[i] = o.Dv[i] * xt;
+  // ... and the six box / rate rows of the columns it sums in G' w (a table walk through DgProb per column and iteration otherwise)
+  constexpr int GR = (4 * DG_NVARMAX + NT - 1) / NT;      // rounds of (column, quarter) tasks
+  const OxTabs T = ox_tabs(c);
+  int rr[GR][6];
+#pragma unroll
+  for (int g = 0; g < GR; g++) {
+    const int it4 = TID + g * NT, col = it4 >> 2;
+    const bool lead = it4 < 4 * n && (it4 & 3) == 0;
+    const int a = lead ? col / (D.N * DGSQP_NUA) : 0, rem = lead ? col % (D.N * DGSQP_NUA) : 0, t = rem / DGSQP_NUA, j = rem % DGSQP_NUA;
+    const bool nxt = lead && t + 1 < D.N;
+    rr[g][0] = lead ? D.r_in_ub[a][t][j] : -1; rr[g][1] = lead ? D.r_in_lb[a][t][j] : -1;
+    rr[g][2] = lead ? D.r_rate_ub[a][t][j] : -1; rr[g][3] = lead ? D.r_rate_lb[a][t][j] : -1;
+    rr[g][4] = nxt ? D.r_rate_ub[a][nxt ? t + 1 : t][j] : -1; rr[g][5] = nxt ? D.r_rate_lb[a][nxt ? t + 1 : t][j] : -1;
   }
-  __syncthreads();
-  PROF_END(PH_O_PMUL, pa2);
-  PROF_BEGIN(pa3);
-  qp_dense_dots<GP>(D, gd, o.tmp, o.dpart, o.ddx);
-  PROF_END(PH_O_GS, pa3);
-  PROF_BEGIN(pa4);
-  for (int r = TID; r < nc; r += NT) {
-    const double zt = qpw_row_dot(D, ld_row(r), o.tmp, o.ddx);
-    const double er = o.E[r], zp = o.z[r], yr = o.y[r];
-    const double zr = alpha * (er * zt) + (1.0 - alpha) * zp;
-    const double us = er * fmin(-o.g[r], OSQP_INFTY), ls = -OSQP_INFTY * er;
-    const double zn = fmin(fmax(__builtin_fma(yr, irho, zr), ls), us);
-    const double dyr = rho * (zr - zn), yn = yr + dyr;
-    o.z[r] = zn; o.dy[r] = dyr; o.y[r] = yn;
-    o.w[r] = er * (rho * zn - yn);
+  for (int rep = 0; rep < count; rep++) {
+    PROF_BEGIN(pa1);
+    {                                                       // G' w as ox_gt_mul forms it (w already carries E), the row indices from registers
+      lptr yd = o.ddx;
+      clptr w = o.w;
+      __syncthreads();
+      for (int d = TID; d < D.ndense; d += NT) {
+        const DgDense dd = ld_dense(d);
+        yd[d] = (dd.r_pos >= 0 ? w[dd.r_pos] : 0.0) - (dd.r_neg >= 0 ? w[dd.r_neg] : 0.0);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int g = 0; g < GR; g++) {
+        const int it4 = TID + g * NT;
+        if (it4 < 4 * n) {
+          const int col = it4 >> 2, part = it4 & 3;
+          double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+          if (rr[g][0] >= 0) s0 += w[rr[g][0]];
+          if (rr[g][1] >= 0) s0 -= w[rr[g][1]];
+          if (rr[g][2] >= 0) s1 += w[rr[g][2]];
+          if (rr[g][3] >= 0) s1 -= w[rr[g][3]];
+          if (rr[g][4] >= 0) s2 -= w[rr[g][4]];
+          if (rr[g][5] >= 0) s2 += w[rr[g][5]];
+          const int k1 = (int)T.cstart[col + 1];
+          int k = (int)T.cstart[col] + part;
+          for (; k + 12 < k1; k += 16) {
+            const unsigned int pa = T.pairT[k], pb = T.pairT[k + 4], pc = T.pairT[k + 8], pd = T.pairT[k + 12];
+            const double ga = T.gdT[k], gb = T.gdT[k + 4], gc = T.gdT[k + 8], gg = T.gdT[k + 12];
+            s0 = __builtin_fma(yd[pa >> 22], ga, s0); s1 = __builtin_fma(yd[pb >> 22], gb, s1); s2 = __builtin_fma(yd[pc >> 22], gc, s2); s3 = __builtin_fma(yd[pd >> 22], gg, s3);
+          }
+          for (; k < k1; k += 4) { const unsigned int pa = T.pairT[k]; s0 = __builtin_fma(yd[pa >> 22], T.gdT[k], s0); }
+          double sm = (s0 + s1) + (s2 + s3);
+          sm += dpp_f64<0xB1>(sm);
+          sm += dpp_f64<0x4E>(sm);
+          if (part == 0) o.xt[col] = sm;
+        }
+      }
+      __syncthreads();
+    }
+    for (int j = TID; j < n; j += NT) {
+      const double dj = o.Dv[j], aI = o.EI[j] * dj, xj = o.x[j];
+      o.rhs[j] = sigma * xj - cc * dj * o.q[j] + dj * o.xt[j] + aI * ox_rho_I(o, j, rho) * (aI * xj);
+    }
+    __syncthreads();
+    PROF_END(PH_O_GT, pa1);
+    PROF_BEGIN(pa2);
+    if (!regs) {
+      if (f32) ox_m_pass_f32((const glb_f*)o.S, n, o.rhs, o.part, o.xt);
+      else ox_m_pass<false>(o.S, n, o.rhs, o.part, o.xt);     // xt = K^-1 rhs (explicit inverse: one pass over n x n)
+    } else {
+      if (act) {
+        double a[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < OX_RC; k++) a[k & 3] = __builtin_fma(kc[k], o.rhs[ja + k], a[k & 3]);
+        int j = ja + OX_RC;
+        if (f32) {
+          const glb_f* M = (const glb_f*)o.S;
+          for (; j + 15 < jb; j += 16) {
+            float m[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) m[k] = M[(int64_t)(j + k) * n + S.i];
+#pragma unroll
+            for (int k = 0; k < 16; k++) a[k & 3] = __builtin_fma((double)m[k], o.rhs[j + k], a[k & 3]);
+          }
+          for (; j < jb; j++) a[0] = __builtin_fma((double)M[(int64_t)j * n + S.i], o.rhs[j], a[0]);
+        } else {
+          cgptr M = o.S;
+          for (; j + 7 < jb; j += 8) {
+            double m[8], t[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { m[k] = M[(int64_t)(j + k) * n + S.i]; t[k] = o.rhs[j + k]; }
+#pragma unroll
+            for (int k = 0; k < 8; k++) a[k & 3] = __builtin_fma(m[k], t[k], a[k & 3]);
+          }
+          for (; j < jb; j++) a[0] = __builtin_fma(M[(int64_t)j * n + S.i], o.rhs[j], a[0]);
+        }
+        o.part[S.g * n + S.i] = (a[0] + a[1]) + (a[2] + a[3]);
+      }
+      __syncthreads();
+      if (TID < n) {
+        double sm = o.part[TID];
+        for (int g = 1; g < S.G; g++) sm += o.part[g * n + TID];
+        o.xt[TID] = sm;
+      }
+      __syncthreads();
+    }
+    for (int i = TID; i < n; i += NT) {
+      const double xt = o.xt[i], xp = o.x[i], xn = alpha * xt + (1.0 - alpha) * xp;
+      o.x[i] = xn; o.dx[i] = xn - xp; o.tmp[i] = o.Dv[i] * xt;
+    }
+    __syncthreads();
+    PROF_END(PH_O_PMUL, pa2);
+    PROF_BEGIN(pa3);
+    qp_dense_dots<GP>(D, gd, o.tmp, o.dpart, o.ddx);
+    PROF_END(PH_O_GS, pa3);
+    PROF_BEGIN(pa4);
+    for (int r = TID; r < nc; r += NT) {
+      const double zt = qpw_row_dot(D, ld_row(r), o.tmp, o.ddx);
+      const double er = o.E[r], zp = o.z[r], yr = o.y[r];
+      const double zr = alpha * (er * zt) + (1.0 - alpha) * zp;
+      const double us = er * fmin(-o.g[r], OSQP_INFTY), ls = -OSQP_INFTY * er;
+      const double zn = fmin(fmax(__builtin_fma(yr, irho, zr), ls), us);
+      const double dyr = rho * (zr - zn), yn = yr + dyr;
+      o.z[r] = zn; o.dy[r] = dyr; o.y[r] = yn;
+      o.w[r] = er * (rho * zn - yn);
+    }
+    XSYNC();
+    PROF_END(PH_O_UPD, pa4);
   }
-  XSYNC();
-  PROF_END(PH_O_UPD, pa4);
 }
 
 // Termination tests of a check iteration and the ratios of the rho rule (osqp_check of dgsqp_osqp.h; delta y is read from the scratch and
@@ -839,7 +946,7 @@ __device__ __noinline__ int dev_qp_osqp_xl_t(const Ctx& c, GP gd) {
   double pri_res = INFINITY, dua_res = INFINITY, eps_p = 0, eps_d = 0;
   bool need_k = true;
   PROF_BEGIN(po4);
-  for (int it = 1; it <= max_iter; it++) {
+  for (int it = check_every; it <= max_iter; it += check_every) {       // one block of iterations, then a termination check
     if (need_k) {
       need_k = false;
       if (!ox_build_k(c, rho, cc)) { status = OSQP_NAN_DATA; break; }
@@ -847,9 +954,8 @@ __device__ __noinline__ int dev_qp_osqp_xl_t(const Ctx& c, GP gd) {
       for (int r = TID; r < nc; r += NT) o.w[r] = o.E[r] * (rho * o.z[r] - o.y[r]);
       __syncthreads();
     }
+    ox_iterate_block<GP>(c, gd, rho, cc, check_every);
     iters = it;
-    ox_iterate<GP>(c, gd, rho, cc);
-    if (it % check_every != 0) continue;
     ox_check<GP>(c, gd, cc, it == max_iter);
     pri_res = o.scal[DG_OSQP_CHK]; dua_res = o.scal[DG_OSQP_CHK + 1]; eps_p = o.scal[DG_OSQP_CHK + 2]; eps_d = o.scal[DG_OSQP_CHK + 3];
     const double ad_pr = o.scal[DG_OSQP_CHK + 4], ad_dr = o.scal[DG_OSQP_CHK + 5];
