@@ -27,8 +27,10 @@ step bench_kb_curve_N25 $O/bench_kb_curve_N25.json python bench.py --workload kb
 # OSQP's arithmetic on the XL layout (round 5): configs[2], [3], [4] with qp_method = osqp
 step bench_barc3_osqp $O/bench_kb_barc3_N25_B4096_qp_osqp.json python bench.py --workload kb_barc3_N25 --qp osqp --batch 4096 --steps 1 --warmup 0 --pipeline 1 --batches 1 --single-steps 0 --host-steps 0 --cpu-sample 0
 step bench_curve3_osqp $O/bench_kb_curve3_N25_B4096_qp_osqp.json python bench.py --workload kb_curve3_N25 --qp osqp --batch 4096 --steps 1 --warmup 0 --pipeline 1 --batches 1 --single-steps 0 --host-steps 0 --cpu-sample 0
+step bench_curve3_osqp_mixed $O/bench_kb_curve3_N25_B4096_qp_osqp_mixed.json python bench.py --workload kb_curve3_N25 --qp osqp --mixed-precision --batch 4096 --steps 1 --warmup 0 --pipeline 1 --batches 1 --single-steps 0 --host-steps 0 --cpu-sample 0
+step bench_f1_osqp_mixed $O/bench_kb_f1_N50_B4096_qp_osqp_mixed.json python bench.py --workload kb_f1_N50 --qp osqp --mixed-precision --batch 4096 --steps 1 --warmup 0 --pipeline 1 --batches 1 --single-steps 0 --host-steps 0 --cpu-sample 0
 step bench_f1_osqp $O/bench_kb_f1_N50_B4096_qp_osqp.json python bench.py --workload kb_f1_N50 --qp osqp --batch 4096 --steps 1 --warmup 0 --pipeline 1 --batches 1 --single-steps 0 --host-steps 0 --cpu-sample 0
-step bench_merge6_osqp $O/bench_merge6_N25_B8192_qp_osqp.json python bench.py --workload merge6_N25 --qp osqp --batch 8192 --steps 1 --warmup 0 --pipeline 1 --batches 1 --single-steps 0 --host-steps 0 --cpu-sample 0
+step bench_merge6_osqp $O/bench_merge6_N25_B4096_qp_osqp.json python bench.py --workload merge6_N25 --qp osqp --batch 4096 --steps 1 --warmup 0 --pipeline 1 --batches 1 --single-steps 0 --host-steps 0 --cpu-sample 0
 fi
 if [[ $PART == *2* ]]; then
 step gpu_tests $O/gpu_tests_full.txt python -m pytest tests -m gpu -q -s
