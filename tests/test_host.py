@@ -616,3 +616,45 @@ def test_bench_flop_model_fingerprint_and_extra_legs(tmp_path, games):
     assert all(leg['workload'] in bench.WORKLOADS for leg in bench.EXTRA_LEGS)
     assert (legs['configs[2] B=4096']['batch'], legs['configs[3] B=16384']['batch'], legs['configs[4] B=65536']['batch']) == (4096, 16384, 65536)
     assert 'batch=4096' in names[2] and 'batch=16384' in names[3] and 'batch=65536' in names[4]
+
+
+def test_bench_extra_legs_respect_the_wall_budget(monkeypatch, capsys):
+    """bench.py's default invocation: ONE JSON line whose `workloads` holds a record per extra leg; a leg that fails is reported in the
+    line, legs that would start after --extras-budget seconds are named as skipped -- neither takes the headline down (no GPU needed:
+    run_workload is replaced by a stub)."""
+    import json
+    sys.path.insert(0, str(ROOT))
+    import bench
+    calls = []
+
+    def stub(args, rank, local_rank, world):
+        calls.append((args.workload, args.qp, args.batch, getattr(args, 'mixed_precision', False)))
+        if args.workload == 'kb_f1_N50' and args.qp == 'active_set':
+            raise RuntimeError('stub failure')
+        return {k: None for k in bench.RECORD_KEYS} | {'value': float(len(calls)), 'metric': 'm', 'unit': 'scenarios/s'}
+    monkeypatch.setattr(bench, 'run_workload', stub)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '1', '--steps', '20', '--warmup', '5'])
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        monkeypatch.delenv(k, raising=False)
+    bench.main()
+    out = [ln for ln in capsys.readouterr().out.splitlines() if ln.strip()]
+    assert len(out) == 1                                    # the contract: one JSON line
+    line = json.loads(out[0])
+    tags = [w['tag'] for w in line['workloads']]
+    assert tags == ['configs[1] (the headline)'] + [leg['tag'] for leg in bench.EXTRA_LEGS]
+    assert calls[0] == ('dyn_curve_N25', 'active_set', 1024, False) and len(calls) == 1 + len(bench.EXTRA_LEGS)
+    failed = [w for w in line['workloads'] if 'error' in w]
+    assert len(failed) == 1 and failed[0]['tag'] == 'configs[3] B=16384' and 'stub failure' in failed[0]['error']
+    assert any(c[3] for c in calls)                         # the mixed-precision leg reaches run_workload with its switch on
+    # past the budget: every leg is named, none is started
+    calls.clear()
+    monkeypatch.setattr(bench, 'T_START', bench.T_START - 1e6)
+    bench.main()
+    line = json.loads([ln for ln in capsys.readouterr().out.splitlines() if ln.strip()][-1])
+    assert len(calls) == 1 and all('skipped' in w for w in line['workloads'][1:]) and line['value'] == 1.0
+    # a non-default invocation times only what it was asked for
+    calls.clear()
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--qp', 'osqp'])
+    bench.main()
+    line = json.loads([ln for ln in capsys.readouterr().out.splitlines() if ln.strip()][-1])
+    assert len(calls) == 1 and 'workloads' not in line
