@@ -44,6 +44,9 @@ WORKLOADS = {
     # the reference's own Monte-Carlo experiment (scripts/DGSQP_ALGAMES_monte_carlo_curve.py), kinematic bicycle
     'kb_curve_N25': dict(desc='2-agent kinematic-bicycle (euler) curve track, N=25, reg=0 (curve.py:161), fp64', kind='kb', track='curve', N=25, reg=0.0),
     'kb_chicane_N25': dict(desc='2-agent kinematic-bicycle (euler) chicane track, N=25, reg=1e-3 (chicane.py:164), fp64', kind='kb', track='chicane', N=25, reg=1e-3),
+    # n = 60 games whose arena fits HALF a CU's LDS: the measurement behind row N1 (two 256-thread workgroups per CU, tools/n1_two_per_cu.py)
+    'kb_chicane_N15': dict(desc='2-agent kinematic-bicycle (euler) chicane track, N=15, reg=1e-3 (BASELINE configs[0] game), fp64', kind='kb', track='chicane', N=15, reg=1e-3),
+    'dyn_curve_N15': dict(desc='2-agent dynamic-bicycle (Pacejka, rk4 M=10) curve track, N=15, game of exact_dynamic_game_dynamic.py, fp64', kind='dyn', track='curve', N=15, reg=1e-3),
     # other Monte-Carlo scripts of the reference at their own sizes (not BASELINE's metric; for the DESIGN.md table)
     'kb_barc2_N15': dict(desc='2-agent kinematic-bicycle race on the L_track_barc circuit, N=15, reg=0 (DGSQP_comp_monte_carlo.py), fp64', kind='barc', M=2, N=15, reg=0.0),
     'kb_barc3_N25': dict(desc='3-agent kinematic-bicycle race on the L_track_barc circuit, N=25, reg=0 (BASELINE configs[2] game), XL layout, fp64', kind='barc', M=3, N=25, reg=0.0),
@@ -208,17 +211,42 @@ def parse_args(argv=None):
                          "explicit K^-1 is stored in fp32 (fp64 accumulation); everything else stays fp64.  'dtype' of the line then says 'f64 (K^-1 of the ADMM iteration f32)'")
     ap.add_argument('--eig-floor', type=float, default=None, help='_nearestPD floor (default: the literal 1e-10, DGSQP.py:1293)')
     ap.add_argument('--snap-active-bounds', action='store_true', help='implementation knob, see include/dgsqp.h (default: literal)')
-    ap.add_argument('--extras-budget', type=float, default=420.0,
-                    help='seconds since the start of the process after which no further extra leg is started (the legs left out are named in the line); the full set takes about five minutes on an MI355X')
+    ap.add_argument('--extras-budget', type=float, default=270.0,
+                    help='seconds since the start of the process by which the extra legs must be over: a leg gets min(its own timeout, what is left), and none is started with less than 15 s left (the legs left out are named in the line)')
+    ap.add_argument('--line', choices=('compact', 'full'), default='compact',
+                    help='compact: the ONE stdout line holds the contract keys, config, roofline, cpu_baseline and the headline figures in under 4 KB (full records: bench_workloads.json); '
+                         'full: the complete record of this workload (what the extra legs, run as child processes, hand back)')
     ap.add_argument('--extras', choices=('auto', 'off'), default='auto',
-                    help="auto: the default invocation (configs[1], exact QP, one GPU) also times, in the same run and into the same JSON line "
-                         "(key 'workloads'), --qp osqp on configs[1] and BASELINE configs[2], [3], [4] at the batch sizes BASELINE.json names; off: only the workload asked for")
+                    help="auto: the default invocation (configs[1], exact QP, one GPU) also times, in the same run, --qp osqp on configs[1] and BASELINE configs[2], [3], [4] "
+                         "at the batch sizes BASELINE.json names -- each leg in a child process with a timeout, full records in bench_workloads.json, a four-column summary "
+                         "in the line (key 'workloads'); off: only the workload asked for")
     return ap.parse_args(argv)
 
 
 def run_workload(args, rank, local_rank, world):
     """One workload through the contract's timed region (plus the one-at-a-time, host-inclusive and cpu_baseline legs the flags ask
-    for); returns the JSON record on rank 0, None elsewhere.  Every handle it creates is destroyed before it returns."""
+    for); returns the JSON record on rank 0, None elsewhere.  Every handle it creates is destroyed before it returns -- also when
+    it raises (device buffers, streams, the communicator and the deferral pool's claim go with the handles)."""
+    held = {'solvers': [], 'comm': None}
+    ok = False
+    try:
+        line = _run_workload(args, rank, local_rank, world, held)
+        ok = True
+        return line
+    finally:
+        if held['comm'] is not None and (ok or world == 1):       # (a failing rank of several must not wait in close()'s barrier for peers that may be gone)
+            try:
+                held['comm'].close()
+            except Exception:
+                pass
+            held['comm'] = None
+        while held['solvers']:
+            held['solvers'].pop()           # DGSQP.__del__ -> dgsqp_destroy
+        import gc
+        gc.collect()
+
+
+def _run_workload(args, rank, local_rank, world, held):
     from dgsqp_amd import _ffi
     from dgsqp_amd.montecarlo import sample_scenarios
     from dgsqp_amd.sharding import Communicator, padded_shard_size, shard_range, stats_from_records, summarize
@@ -231,11 +259,13 @@ def run_workload(args, rank, local_rank, world):
     if args.group <= 0:
         args.group = args.steps if args.steps <= 24 else 12
     n_batches = args.batches if args.batches > 0 else max(P, min(max(3 * P, (P + 1) * max(1, args.group)), args.steps))     # distinct batches = handles; steps cycle through them
-    solvers = [mk() for _ in range(n_batches)]
+    solvers = held['solvers']
+    for _ in range(n_batches):
+        solvers.append(mk())
     solver = solvers[0]
     d = solver.dims
     lib = solver._lib
-    comm = Communicator(solver, rank, world)          # RCCL communicator owned by handle 0 (world = 1: no peer needed)
+    comm = held['comm'] = Communicator(solver, rank, world)          # RCCL communicator owned by handle 0 (world = 1: no peer needed)
     if args.scaling == 'weak':
         B_total, (lo, hi) = args.batch * world, (rank * args.batch, (rank + 1) * args.batch)
     else:
@@ -490,6 +520,7 @@ def run_workload(args, rank, local_rank, world):
             sec = ob['seconds']
             line['cpu_baseline'] = {'value': nth / float(sec.mean()), 'unit': 'scenarios/s', 'cores': nth, 'kind': 'port',
                                     'value_wall': ns / dt, 'value_one_core': n1 / dt1, 'scenarios_per_thread': ns / nth,
+                                    'sample_short': f'first {ns} scenarios of batch 0, {nth} of {cores} threads, {dt:.0f} s wall; value = threads / mean s per scenario; C++ restatement, not CasADi+OSQP',
                                     'seconds_per_scenario': {'mean': float(sec.mean()), 'median': float(np.median(sec)), 'max': float(sec.max())},
                                     'sample': f'first {ns} scenarios of batch 0 over {nth} of {cores} hardware threads, dynamic hand-out, {ns / nth:.0f} per thread, {dt:.1f} s wall '
                                               f'(mean {sec.mean():.2f} s, slowest {sec.max():.1f} s per scenario); value = threads / mean seconds per scenario; first {n1} alone on one core: {dt1:.1f} s; '
@@ -499,12 +530,7 @@ def run_workload(args, rank, local_rank, world):
             line['cpu_baseline_note'] = 'timed on rank 0 of the 1-GPU run only (bench.py --gpus 1)'
     else:
         line = None
-    comm.close()
-    del comm, handles, solver
-    while solvers:
-        solvers.pop()           # DGSQP.__del__ -> dgsqp_destroy: device buffers, streams and the deferral pool's claim go with the handle
-    import gc
-    gc.collect()
+    del comm, handles, solver, solvers
     return line
 
 
@@ -512,27 +538,103 @@ def run_workload(args, rank, local_rank, world):
 # QP arithmetic on configs[1], and BASELINE configs[2], [3], [4] at the batch sizes BASELINE.json names -- ONE cooperative launch of the
 # whole batch each (the XL games' tails need that many scenarios behind them); kb_curve3_N25 is the solvable three-car game of
 # configs[2]'s size (DGSQP_monte_carlo_agents.py) next to the circuit game, 95 % of whose solves end in an LP-certified infeasible QP.
+# Every leg runs in a FRESH CHILD PROCESS with its own timeout (run_leg), after the parent has measured the headline and destroyed its
+# handles; the full records go to the side file bench_workloads.json, the ONE line on stdout stays under 4 KB.
+_ONE = dict(steps=1, warmup=0, pipeline=1, batches=1, group=1)
 EXTRA_LEGS = (
-    dict(tag='configs[1] --qp osqp', workload='dyn_curve_N25', qp='osqp'),
-    dict(tag='configs[2] B=4096', workload='kb_barc3_N25', batch=4096, steps=1, warmup=0, pipeline=1, batches=1, group=1),
-    dict(tag='configs[2] size, solvable game, B=4096', workload='kb_curve3_N25', batch=4096, steps=1, warmup=0, pipeline=1, batches=1, group=1),
-    dict(tag='configs[3] B=16384', workload='kb_f1_N50', batch=16384, steps=1, warmup=0, pipeline=1, batches=1, group=1),
-    dict(tag='configs[4] B=65536', workload='merge6_N25', batch=65536, steps=1, warmup=0, pipeline=1, batches=1, group=1),
+    dict(tag='configs[1] --qp osqp', workload='dyn_curve_N25', qp='osqp', timeout=90),
+    dict(tag='configs[4] B=65536', workload='merge6_N25', batch=65536, timeout=120, **_ONE),
+    dict(tag='configs[3] B=16384', workload='kb_f1_N50', batch=16384, timeout=90, **_ONE),
+    dict(tag='configs[2] B=4096', workload='kb_barc3_N25', batch=4096, timeout=60, **_ONE),
+    dict(tag='configs[2] size, solvable game, B=4096', workload='kb_curve3_N25', batch=4096, timeout=60, **_ONE),
     # ... and the same games with OSQP's own arithmetic (csrc/dgsqp_osqp_xl.h, round 5) at REDUCED batch sizes: at reg = 0 the restated OSQP
     # runs into its 4,000-iteration limit on most QPs of the merge (3,400 ADMM iterations per QP on average), a solve costs 30 x the exact QP's
-    dict(tag='configs[2] --qp osqp, B=4096', workload='kb_barc3_N25', qp='osqp', batch=4096, steps=1, warmup=0, pipeline=1, batches=1, group=1),
-    dict(tag='configs[3] --qp osqp, reduced batch B=1024', workload='kb_f1_N50', qp='osqp', batch=1024, steps=1, warmup=0, pipeline=1, batches=1, group=1),
-    dict(tag='configs[4] --qp osqp, reduced batch B=1024', workload='merge6_N25', qp='osqp', batch=1024, steps=1, warmup=0, pipeline=1, batches=1, group=1),
-    # ... and the solvable game of configs[2]'s size with OSQP, fp64 and with the opt-in fp32 storage of the ADMM iteration's K^-1
+    dict(tag='configs[2] size, solvable game --qp osqp, B=4096', workload='kb_curve3_N25', qp='osqp', batch=4096, timeout=60, **_ONE),
+    dict(tag='configs[3] --qp osqp, reduced batch B=1024', workload='kb_f1_N50', qp='osqp', batch=1024, timeout=60, **_ONE),
+    dict(tag='configs[4] --qp osqp, reduced batch B=1024', workload='merge6_N25', qp='osqp', batch=1024, timeout=120, **_ONE),
+    dict(tag='configs[2] --qp osqp, B=4096', workload='kb_barc3_N25', qp='osqp', batch=4096, timeout=60, **_ONE),
+    # ... and the solvable game of configs[2]'s size with the opt-in fp32 storage of the ADMM iteration's K^-1
     # (dgsqp_params_t.mixed_precision; configs[2] and [4] run at reg = 0, where the kernel keeps fp64: include/dgsqp.h)
-    dict(tag='configs[2] size, solvable game --qp osqp, B=4096', workload='kb_curve3_N25', qp='osqp', batch=4096, steps=1, warmup=0, pipeline=1, batches=1, group=1),
-    dict(tag='configs[2] size, solvable game --qp osqp --mixed-precision, B=4096', workload='kb_curve3_N25', qp='osqp', mixed_precision=True, batch=4096, steps=1, warmup=0, pipeline=1, batches=1, group=1),
+    dict(tag='configs[2] size, solvable game --qp osqp --mixed-precision, B=4096', workload='kb_curve3_N25', qp='osqp', mixed_precision=True, batch=4096, timeout=60, **_ONE),
 )
 RECORD_KEYS = ('value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'config', 'mean_iters', 'mean_iters_all', 'mean_qp_solves', 'converged_fraction',
                'status_fractions', 'roofline', 'value_single_launch', 'value_host_inclusive', 'value_host_inclusive_grouped', 'elapsed_s')
+SIDECAR = os.path.join(ROOT, 'bench_workloads.json')
+LINE_LIMIT = 4096           # bytes of the ONE stdout line (the driver keeps an 8 KB tail of the run's output)
 
 
 T_START = time.perf_counter()
+
+
+def run_leg(leg, args, timeout):
+    """One extra leg as a fresh child process (never an exec: this process has initialised the GPU): `bench.py --workload ... --extras off
+    --line full`, no one-at-a-time / host / cpu legs.  Returns the child's full record; raises on a non-zero exit, a timeout (the child and
+    only the child is killed) or an unparseable line."""
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--workload', leg['workload'], '--qp', leg.get('qp', 'active_set'),
+           '--steps', str(leg.get('steps', args.steps)), '--warmup', str(leg.get('warmup', args.warmup)), '--batch', str(leg.get('batch', args.batch)),
+           '--pipeline', str(leg.get('pipeline', args.pipeline)), '--batches', str(leg.get('batches', 0)), '--group', str(leg.get('group', 0)),
+           '--coop', args.coop, '--single-steps', '0', '--host-steps', '0', '--cpu-sample', '0', '--extras', 'off', '--line', 'full']
+    if leg.get('mixed_precision'):
+        cmd.append('--mixed-precision')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    if out.returncode != 0:
+        raise RuntimeError(f'exit code {out.returncode}: {out.stderr.strip()[-300:]}')
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    if not lines:
+        raise RuntimeError('the child printed no JSON line')
+    return json.loads(lines[-1])
+
+
+def _sig(x, digits=5):
+    return float(f'{x:.{digits}g}') if isinstance(x, float) else x
+
+
+def compact_line(line, records=None, sidecar=None):
+    """The ONE stdout line: the contract's keys, `config`, `roofline` and `cpu_baseline` trimmed to their numbers, the other throughput
+    figures of the headline, and -- default invocation -- a summary [tag, scenarios/s, converged fraction, roofline.frac] per extra leg.
+    Everything else (flop model terms, single-launch detail, status fractions, the legs' full records) is in the side file."""
+    c, r = line['config'], line['roofline']
+    out = {k: line[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data')}
+    out['config'] = {k: c[k] for k in ('workload', 'batch_per_gpu', 'batch_total', 'n', 'n_c', 'parallelism', 'layout', 'qp_method', 'reg', 'distinct_batches',
+                                       'batches_per_launch', 'launches_in_flight', 'cooperative_line_search') if k in c}
+    out['roofline'] = {'bound': r['bound'], 'achieved': _sig(r['achieved']), 'peak': r['peak'], 'unit': r['unit'], 'frac': _sig(r['frac']),
+                       'frac_is': 'algorithmic flops (SURVEY 8d model) / HIP-event time / peak', 'frac_executed_upper_bound': _sig(r.get('frac_executed_upper_bound')),
+                       'traffic': r.get('traffic'), 'kernel': r['kernel'], 'kernel_ms': _sig(r['kernel_ms'], 7), 'launches_timed': r.get('launches_timed'),
+                       'solves_per_launch': r.get('solves_per_launch'), 'hbm': {k: _sig(v) for k, v in r['hbm'].items()}}
+    if r.get('traffic_note'):
+        out['roofline']['traffic_note'] = r['traffic_note'][:120]
+    cb = line.get('cpu_baseline')
+    if cb:
+        out['cpu_baseline'] = {'value': _sig(cb['value']), 'unit': cb['unit'], 'cores': cb['cores'], 'kind': cb['kind'], 'sample': cb.get('sample_short', ''),
+                               'value_wall': _sig(cb.get('value_wall')), 'value_one_core': _sig(cb.get('value_one_core'))}
+    elif 'cpu_baseline' in line:
+        out['cpu_baseline'] = None
+        out['cpu_baseline_note'] = line.get('cpu_baseline_note')
+    for k in ('value_single_launch', 'value_host_inclusive', 'value_host_inclusive_grouped', 'mean_iters', 'mean_iters_all', 'mean_qp_solves', 'converged_fraction', 'elapsed_s'):
+        out[k] = _sig(line.get(k), 6)
+    if line.get('elapsed_s_per_rank') and line['n_gpus'] > 1:
+        out['elapsed_s_per_rank'] = [_sig(x) for x in line['elapsed_s_per_rank']]
+    if records is not None:
+        osqp = [w for w in records if w.get('tag') == 'configs[1] --qp osqp' and 'value' in w]
+        out['value_qp_osqp'] = _sig(osqp[0]['value'], 6) if osqp else None
+        out['workloads'] = [[w['tag'], _sig(w.get('value')), _sig(w.get('converged_fraction')), _sig((w.get('roofline') or {}).get('frac'))] if 'value' in w
+                            else [w['tag'], None, (w.get('error') or w.get('skipped') or '')[:60], None] for w in records]
+        out['workloads_columns'] = ['tag', 'scenarios/s', 'converged_fraction | why missing', 'roofline.frac']
+    if sidecar:
+        out['sidecar'] = os.path.relpath(sidecar, ROOT)
+    return out
+
+
+def write_sidecar(path, headline, records):
+    try:
+        tmp = path + '.tmp'
+        with open(tmp, 'w') as f:
+            json.dump({'headline': headline, 'workloads': records}, f, indent=1)
+        os.replace(tmp, path)
+        return path
+    except OSError:
+        return None
 
 
 def main():
@@ -547,30 +649,42 @@ def main():
                          f'or run `python bench.py --gpus {args.gpus}` without a launcher\n')
         sys.exit(2)
     line = run_workload(args, rank, local_rank, world)
-    if rank == 0:
-        extras = (args.extras == 'auto' and world == 1 and args.workload == 'dyn_curve_N25' and args.qp == 'active_set' and args.scaling == 'weak'
-                  and args.batch == 1024 and args.reg is None and args.eig_floor is None)
-        if extras:
-            import copy
-            records = [dict({k: line.get(k) for k in RECORD_KEYS}, tag='configs[1] (the headline)')]
-            for leg in EXTRA_LEGS:
-                a = copy.copy(args)
-                a.single_steps, a.host_steps, a.cpu_sample, a.group = 0, 0, 0, 0
-                tag = leg['tag']
-                if time.perf_counter() - T_START > args.extras_budget:
-                    records.append(dict(tag=tag, skipped=f'not started: {time.perf_counter() - T_START:.0f} s into the run, --extras-budget {args.extras_budget:.0f} s'))
-                    continue
-                for k, v in leg.items():
-                    if k != 'tag':
-                        setattr(a, k, v)
-                t0 = time.perf_counter()
-                try:
-                    rec = run_workload(a, rank, local_rank, world)
-                    records.append(dict({k: rec.get(k) for k in RECORD_KEYS}, tag=tag, wall_s_incl_setup=time.perf_counter() - t0))
-                except Exception as e:           # a leg that fails must not take the headline down with it: say so in the line
-                    records.append(dict(tag=tag, error=f'{type(e).__name__}: {e}'))
-            line['workloads'] = records
+    if rank != 0:
+        return
+    if args.line == 'full':
         print(json.dumps(line), flush=True)
+        return
+    extras = (args.extras == 'auto' and world == 1 and args.workload == 'dyn_curve_N25' and args.qp == 'active_set' and args.scaling == 'weak'
+              and args.batch == 1024 and args.reg is None and args.eig_floor is None)
+    records, sidecar = None, None
+    if extras:
+        # the headline is measured and safe in the side file before any leg starts; its handles are destroyed (run_workload)
+        records = [dict({k: line.get(k) for k in RECORD_KEYS}, tag='configs[1] (the headline)')]
+        sidecar = write_sidecar(SIDECAR, line, records)
+        for leg in EXTRA_LEGS:
+            tag = leg['tag']
+            left = args.extras_budget - (time.perf_counter() - T_START)
+            if left < 15.0:
+                records.append(dict(tag=tag, skipped=f'not started: {time.perf_counter() - T_START:.0f} s into the run, --extras-budget {args.extras_budget:.0f} s'))
+                continue
+            t0 = time.perf_counter()
+            try:
+                rec = run_leg(leg, args, min(float(leg.get('timeout', 90)), left))
+                records.append(dict({k: rec.get(k) for k in RECORD_KEYS}, tag=tag, wall_s_incl_setup=time.perf_counter() - t0))
+            except subprocess.TimeoutExpired as e:
+                records.append(dict(tag=tag, error=f'timeout after {e.timeout:.0f} s (child killed)'))
+            except Exception as e:           # a leg that fails must not take the headline down with it: say so in the line
+                records.append(dict(tag=tag, error=f'{type(e).__name__}: {e}'))
+            sidecar = write_sidecar(SIDECAR, line, records)
+    out = compact_line(line, records, sidecar)
+    text = json.dumps(out, separators=(',', ':'))
+    if len(text) > LINE_LIMIT:              # never again a line the driver cannot keep: shed the optional parts, most verbose first
+        for k in ('workloads_columns', 'elapsed_s_per_rank', 'workloads'):
+            out.pop(k, None)
+            text = json.dumps(out, separators=(',', ':'))
+            if len(text) <= LINE_LIMIT:
+                break
+    print(text, flush=True)
 
 
 if __name__ == '__main__':

@@ -27,7 +27,7 @@ struct DgBatch { const double* x0; const double* u_ws; SolveOutPtrs O; };
 // ------------------------------------------------------------------------------------------------
 // Persistent solve kernel: each workgroup pulls scenarios from a device-wide ticket counter, so that
 // scenarios with long SQP runs (iteration counts vary 1..50+) do not serialise a static partition.
-__global__ void __launch_bounds__(DG_BLOCK)
+__global__ void __launch_bounds__(DG_BLOCK, 2)
 dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__ x0, const double* __restrict__ u_ws,
                 SolveOutPtrs O, double* __restrict__ ws_all, unsigned long long* __restrict__ ticket,
                 double* __restrict__ trace, int trace_cap, unsigned int* __restrict__ drained,
@@ -119,7 +119,7 @@ dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restric
 #include "dgsqp_sampler.h"
 
 // Test hook: one _evaluate(hessian=True) (+ dual init) per scenario, results expanded to dense arrays.
-__global__ void __launch_bounds__(DG_BLOCK)
+__global__ void __launch_bounds__(DG_BLOCK, 2)
 dg_evaluate_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__ x0, const double* __restrict__ u,
                    const double* __restrict__ l, double* q, double* g, double* G, double* Q, double* x, double* l0,
                    double* __restrict__ ws_all) {
@@ -158,7 +158,7 @@ dg_evaluate_kernel(const DgProb* __restrict__ D, int64_t B, const double* __rest
 }
 
 // Test hook: _solve_qp at the linearisation point (u, l).
-__global__ void __launch_bounds__(DG_BLOCK)
+__global__ void __launch_bounds__(DG_BLOCK, 2)
 dg_qp_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restrict__ x0, const double* __restrict__ u,
              const double* __restrict__ l, double* du, double* lhat, double* Qpd, int32_t* flag, double* info8, double* __restrict__ ws_all) {
   Ctx c;
@@ -462,6 +462,12 @@ int dgsqp_create(const dgsqp_problem_t* prob, const dgsqp_params_t* par, int dev
     g_create_err = msg;
     delete h;
     return build_error_code(msg);
+  }
+  if (DG_BLOCK != 512 && (h->hp.big || h->hp.classic_qp || h->hp.osqp)) {
+    // the -DDG_BLOCK=256 build (two workgroups per CU, row N1): LDS-resident explicit-inverse layout with the active-set QP only
+    g_create_err = "too large: this build (DG_BLOCK = 256, two workgroups per CU) holds the LDS-resident explicit-inverse layout with the active-set QP only";
+    delete h;
+    return DGSQP_E_TOO_LARGE;
   }
   auto fail = [&](const std::string& m) { g_create_err = m; dgsqp_destroy(h); return DGSQP_E_DEVICE; };
   int ndev = 0;

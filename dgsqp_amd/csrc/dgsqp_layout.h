@@ -14,11 +14,15 @@
 #define DG_MAXEFF 8       // effective variables of one agent's dynamics (dyn bicycle: 6 states + 2 inputs)
 #define DG_MAXDIR 36      // MAXEFF*(MAXEFF+1)/2 Taylor directions
 #ifndef DG_BLOCK
-#define DG_PSD_KMAX 16   // negative eigenpairs handled per batch (two per wavefront)
 #define DG_BLOCK 512      // threads per scenario workgroup (8 wavefronts = 2 per SIMD, to hide LDS latency)
 #endif
+// -DDG_BLOCK=256 (row N1, "two scenarios per CU"): 4 wavefronts = 1 per SIMD per workgroup and HALF the arena, so that two workgroups
+// share a CU and one scenario's latency-bound phases overlap the other's issue-bound ones.  That build holds the LDS-resident
+// explicit-inverse layout only (dgsqp_create refuses big / XL / classical-QP games: their register tilings assume 8 wavefronts).
+#define DG_WG_PER_CU (512 / DG_BLOCK)
+#define DG_PSD_KMAX (2 * (DG_BLOCK / 64))   // negative eigenpairs handled per batch (two per wavefront)
 #define DG_NH (DG_BLOCK / 128)  // row-groups of the register-resident matrix slices (thread = column x row-group)
-#define DG_LDS_LIMIT (163840 - 512)   // 160 KB per CU minus the kernel's static LDS (256 B)
+#define DG_LDS_LIMIT ((163840 - 512) / DG_WG_PER_CU)   // 160 KB per CU minus the kernel's static LDS (256 B per workgroup)
 
 enum { DG_R_OBS = 0, DG_R_RATE_UB, DG_R_RATE_LB, DG_R_IN_UB, DG_R_IN_LB, DG_R_ST_UB, DG_R_ST_LB, DG_R_LANE };
 

@@ -13,7 +13,7 @@
 #define DG_XL_BASIS 49   // scal slot: the saved eigenvector basis of the Jacobi _nearestPD is valid (XL layout)
 #define XL_NV 5      // registers per lane for one column (n <= 320 = DG_NVARMAX)
 #define XL_MAXP 20   // pairs of one tournament round per wavefront (160 pairs / 8 wavefronts)
-static_assert(64 * XL_NV >= DG_NVARMAX && XL_MAXP * (DG_BLOCK / 64) * 2 >= DG_NVARMAX, "XL kernels: register tiling must cover DG_NVARMAX columns");
+static_assert(DG_BLOCK != 512 || (64 * XL_NV >= DG_NVARMAX && XL_MAXP * (DG_BLOCK / 64) * 2 >= DG_NVARMAX), "XL kernels: register tiling must cover DG_NVARMAX columns");
 #ifndef XL_GRP
 #define XL_GRP 4     // ... handled four at a time (their four columns each stay in registers)
 #endif
@@ -198,7 +198,7 @@ __device__ __noinline__ bool dev_xl_psd_tri(const Ctx& c, gptr Qpd) {
   // matrix of the panel's start plus two thin products with the panel, and the trailing block is read + written ONCE per panel
   // (B -= V W^T + W V^T) -- 1 + 2 / XL_PB passes per column.  Same arithmetic as the plain reduction up to the order of the sums.
   constexpr int PB = XL_PB;
-  static_assert(PB == NT / 64, "one wavefront per panel column in the thin products");
+  static_assert(NT != 512 || PB == NT / 64, "one wavefront per panel column in the thin products");
   lptr Pl = strips + 6 * n;             // panel, column-major: V_c at c n, W_c at (PB + c) n; rows <= (column's index) stay zero
   for (int e = TID; e < 2 * PB * n; e += NT) Pl[e] = 0.0;
   XSYNC();

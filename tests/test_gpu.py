@@ -1935,14 +1935,15 @@ def test_monte_carlo_example_script(tmp_path):
 
 
 def test_bench_line_contract():
-    """bench.py prints ONE JSON line with the contract's keys, the roofline object and the CPU baseline (tiny batch)."""
+    """bench.py prints ONE JSON line with the contract's keys, the roofline object and the CPU baseline (tiny batch): the full record
+    (`--line full`, what the extra legs' child processes hand back) and the compact default line of less than 4 KB."""
     import json
     import pathlib
     import subprocess
     import sys
     root = pathlib.Path(__file__).resolve().parent.parent
     out = subprocess.run([sys.executable, str(root / 'bench.py'), '--workload', 'kb_curve_N25', '--batch', '64', '--steps', '3',
-                          '--warmup', '1', '--cpu-sample', '2', '--pipeline', '2'], capture_output=True, text=True, timeout=600, cwd=str(root))
+                          '--warmup', '1', '--cpu-sample', '2', '--pipeline', '2', '--line', 'full'], capture_output=True, text=True, timeout=600, cwd=str(root))
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1
@@ -1972,3 +1973,16 @@ def test_bench_line_contract():
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['value'] > 0 and c['cores'] >= 1 and c['value_wall'] > 0 and c['seconds_per_scenario']['max'] >= c['seconds_per_scenario']['mean'] > 0
     assert abs(d['value'] - 64 * 3 / (d['ms_per_step'] * 3e-3)) < 1e-6 * d['value']
+    # the default (compact) line of the same workload: everything the contract names, in less than 4 KB, and nothing else on stdout
+    out = subprocess.run([sys.executable, str(root / 'bench.py'), '--workload', 'kb_curve_N25', '--batch', '64', '--steps', '3',
+                          '--warmup', '1', '--cpu-sample', '2', '--pipeline', '2', '--single-steps', '1', '--host-steps', '1'], capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    c = json.loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'value_single_launch', 'value_host_inclusive', 'value_host_inclusive_grouped'):
+        assert key in c, key
+    assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'kernel_ms', 'hbm'} <= set(c['roofline']) and abs(c['roofline']['frac'] - c['roofline']['achieved'] / 78.6) < 1e-4 * c['roofline']['frac']
+    assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(c['cpu_baseline']) and c['cpu_baseline']['kind'] == 'port' and c['steps'] == 3 and c['config']['workload'] == 'kb_curve_N25'
+    assert 'workloads' not in c and abs(c['value'] - 64 * 3 / (c['ms_per_step'] * 3e-3)) < 1e-6 * c['value']

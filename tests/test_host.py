@@ -618,43 +618,116 @@ def test_bench_flop_model_fingerprint_and_extra_legs(tmp_path, games):
     assert 'batch=4096' in names[2] and 'batch=16384' in names[3] and 'batch=65536' in names[4]
 
 
-def test_bench_extra_legs_respect_the_wall_budget(monkeypatch, capsys):
-    """bench.py's default invocation: ONE JSON line whose `workloads` holds a record per extra leg; a leg that fails is reported in the
-    line, legs that would start after --extras-budget seconds are named as skipped -- neither takes the headline down (no GPU needed:
-    run_workload is replaced by a stub)."""
+def test_bench_extra_legs_respect_the_wall_budget(monkeypatch, capsys, tmp_path):
+    """bench.py's default invocation: ONE stdout line of less than 4 KB (the driver keeps an 8 KB tail: round 5's 30 KB line came back
+    unparsed) with the contract's keys, roofline, cpu_baseline and a four-column summary per extra leg; the legs run as CHILD PROCESSES
+    with a timeout each (run_leg) after the headline is safe in the side file; a leg that fails or times out is reported in the line, legs
+    that would start after --extras-budget seconds are named as skipped -- none takes the headline down (no GPU needed: run_workload and
+    run_leg are replaced by stubs that return records as large as the real ones)."""
     import json
+    import subprocess
     sys.path.insert(0, str(ROOT))
     import bench
-    calls = []
+    calls, legs_run = [], []
+    big = {'flop_model': {'per_qp_solve': {'F_eval': 1.0, 'F_eig': 2.0, 'F_qp': 3.0}, 'pad': 'x' * 1500}, 'single_launch': {'pad': 'y' * 800}}
+
+    def record(value):
+        return {'metric': 'Monte-Carlo scenarios/sec (SQP solves/sec), 2-agent N=25', 'value': value, 'unit': 'scenarios/s', 'n_gpus': 1, 'steps': 20, 'warmup': 5,
+                'ms_per_step': 1.234567891234, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+                'config': {'workload': 'dyn_curve_N25', 'description': 'd' * 300, 'batch_per_gpu': 1024, 'batch_total': 1024, 'n': 100, 'n_c': 325, 'parallelism': 'scenario-sharded x1',
+                           'layout': 'lds', 'qp_method': 'active_set', 'reg': 1e-3, 'distinct_batches': 20, 'batches_per_launch': 20, 'launches_in_flight': 5,
+                           'cooperative_line_search': 'auto', 'sampler': 's' * 200},
+                'roofline': dict(big, bound='valu_fp64', achieved=3.9123456789, peak=78.6, unit='TFLOP/s', frac=0.0497753, frac_executed_upper_bound=0.17, traffic=1.2e12,
+                                 traffic_note=None, kernel='dg_solve_kernel', kernel_ms=1743.9123456, launches_timed=1, solves_per_launch=20480.0,
+                                 hbm={'achieved': 0.09, 'peak': 8000.0, 'unit': 'GB/s', 'frac': 1.1e-5}),
+                'cpu_baseline': {'value': 25.3, 'unit': 'scenarios/s', 'cores': 64, 'kind': 'port', 'sample': 'z' * 400, 'sample_short': 'first 512 scenarios', 'value_wall': 11.6, 'value_one_core': 1.8},
+                'value_single_launch': 1858.0, 'value_host_inclusive': 1674.0, 'value_host_inclusive_grouped': 11608.0, 'mean_iters': 5.6, 'mean_iters_all': 6.5,
+                'mean_qp_solves': 10.5, 'converged_fraction': 0.94, 'status_fractions': {'conv_abs_tol': 0.9}, 'elapsed_s': 1.74, 'elapsed_s_per_rank': [1.74]}
 
     def stub(args, rank, local_rank, world):
-        calls.append((args.workload, args.qp, args.batch, getattr(args, 'mixed_precision', False)))
-        if args.workload == 'kb_f1_N50' and args.qp == 'active_set':
+        calls.append((args.workload, args.qp, args.batch))
+        return record(11757.123456789)
+
+    def leg_stub(leg, args, timeout):
+        legs_run.append((leg['tag'], timeout))
+        assert json.load(open(bench.SIDECAR))['headline']['value'] == 11757.123456789      # the headline is on disk before any leg starts
+        if leg['workload'] == 'kb_f1_N50' and leg.get('qp') is None:
             raise RuntimeError('stub failure')
-        return {k: None for k in bench.RECORD_KEYS} | {'value': float(len(calls)), 'metric': 'm', 'unit': 'scenarios/s'}
+        if leg['workload'] == 'merge6_N25' and leg.get('qp') == 'osqp':
+            raise subprocess.TimeoutExpired(['bench.py'], timeout)
+        return record(float(len(legs_run)))
     monkeypatch.setattr(bench, 'run_workload', stub)
+    monkeypatch.setattr(bench, 'run_leg', leg_stub)
+    monkeypatch.setattr(bench, 'SIDECAR', str(tmp_path / 'bench_workloads.json'))
     monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '1', '--steps', '20', '--warmup', '5'])
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
         monkeypatch.delenv(k, raising=False)
     bench.main()
     out = [ln for ln in capsys.readouterr().out.splitlines() if ln.strip()]
-    assert len(out) == 1                                    # the contract: one JSON line
+    assert len(out) == 1 and len(out[0]) < 4096             # the contract: one JSON line, and one the driver's tail can hold
     line = json.loads(out[0])
-    tags = [w['tag'] for w in line['workloads']]
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',
+                'roofline', 'cpu_baseline', 'value_single_launch', 'value_host_inclusive', 'value_host_inclusive_grouped', 'value_qp_osqp', 'workloads'):
+        assert key in line, key
+    assert line['value'] == 11757.123456789 and line['config']['workload'] == 'dyn_curve_N25' and 'description' not in line['config']
+    assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'kernel_ms', 'hbm', 'frac_executed_upper_bound'} <= set(line['roofline']) and 'flop_model' not in line['roofline']
+    assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(line['cpu_baseline']) and len(line['cpu_baseline']['sample']) < 200
+    tags = [w[0] for w in line['workloads']]
     assert tags == ['configs[1] (the headline)'] + [leg['tag'] for leg in bench.EXTRA_LEGS]
-    assert calls[0] == ('dyn_curve_N25', 'active_set', 1024, False) and len(calls) == 1 + len(bench.EXTRA_LEGS)
-    failed = [w for w in line['workloads'] if 'error' in w]
-    assert len(failed) == 1 and failed[0]['tag'] == 'configs[3] B=16384' and 'stub failure' in failed[0]['error']
-    assert any(c[3] for c in calls)                         # the mixed-precision leg reaches run_workload with its switch on
+    assert calls == [('dyn_curve_N25', 'active_set', 1024)] and [t for t, _ in legs_run] == [leg['tag'] for leg in bench.EXTRA_LEGS]
+    assert all(0 < to <= leg['timeout'] for (_, to), leg in zip(legs_run, bench.EXTRA_LEGS))          # every leg has its own timeout
+    assert line['value_qp_osqp'] == 1.0                     # (the first leg: --qp osqp on configs[1])
+    failed = {w[0]: w[2] for w in line['workloads'] if w[1] is None}
+    assert 'stub failure' in failed['configs[3] B=16384'] and 'timeout' in failed['configs[4] --qp osqp, reduced batch B=1024'] and len(failed) == 2
+    side = json.load(open(bench.SIDECAR))                   # the full records: headline with its flop model, one record per leg
+    assert side['headline']['roofline']['flop_model']['pad'] and len(side['workloads']) == 1 + len(bench.EXTRA_LEGS)
+    assert sum('error' in w for w in side['workloads']) == 2 and line['sidecar'].endswith('bench_workloads.json')
     # past the budget: every leg is named, none is started
-    calls.clear()
+    calls.clear(), legs_run.clear()
     monkeypatch.setattr(bench, 'T_START', bench.T_START - 1e6)
     bench.main()
-    line = json.loads([ln for ln in capsys.readouterr().out.splitlines() if ln.strip()][-1])
-    assert len(calls) == 1 and all('skipped' in w for w in line['workloads'][1:]) and line['value'] == 1.0
-    # a non-default invocation times only what it was asked for
+    out = [ln for ln in capsys.readouterr().out.splitlines() if ln.strip()]
+    line = json.loads(out[-1])
+    assert len(out) == 1 and len(out[0]) < 4096
+    assert len(calls) == 1 and not legs_run and all(w[1] is None and 'not started' in w[2] for w in line['workloads'][1:]) and line['value'] == 11757.123456789
+    monkeypatch.setattr(bench, 'T_START', bench.T_START + 1e6)
+    # a non-default invocation times only what it was asked for; `--line full` (what a leg's child prints) is the whole record
     calls.clear()
     monkeypatch.setattr(sys, 'argv', ['bench.py', '--qp', 'osqp'])
     bench.main()
-    line = json.loads([ln for ln in capsys.readouterr().out.splitlines() if ln.strip()][-1])
-    assert len(calls) == 1 and 'workloads' not in line
+    out = [ln for ln in capsys.readouterr().out.splitlines() if ln.strip()]
+    line = json.loads(out[-1])
+    assert len(calls) == 1 and 'workloads' not in line and not legs_run and len(out) == 1 and len(out[0]) < 4096
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--workload', 'merge6_N25', '--extras', 'off', '--line', 'full'])
+    bench.main()
+    line = json.loads(capsys.readouterr().out.splitlines()[-1])
+    assert line['roofline']['flop_model']['pad'] and 'status_fractions' in line
+
+
+def test_bench_leg_child_process_is_killed_at_its_timeout(monkeypatch, tmp_path):
+    """run_leg starts `bench.py` as a child (never an exec) and a child that hangs costs its own record: subprocess.TimeoutExpired after the
+    leg's timeout, the child gone; a child that fails raises with its stderr (stand-in scripts, no GPU)."""
+    import subprocess
+    import types
+    sys.path.insert(0, str(ROOT))
+    import bench
+    args = types.SimpleNamespace(steps=1, warmup=0, batch=8, pipeline=1, coop='auto')
+    hang = tmp_path / 'hang.py'
+    hang.write_text('import sys, time\nopen(sys.argv[0] + ".args", "w").write(" ".join(sys.argv[1:]))\ntime.sleep(600)\n')
+    monkeypatch.setattr(bench, '__file__', str(hang))
+    t0 = time.time()
+    with pytest.raises(subprocess.TimeoutExpired):
+        bench.run_leg(dict(tag='t', workload='merge6_N25', qp='osqp', batch=64, mixed_precision=True), args, 1.5)
+    assert time.time() - t0 < 30
+    sent = (tmp_path / 'hang.py.args').read_text()
+    assert '--workload merge6_N25' in sent and '--qp osqp' in sent and '--batch 64' in sent and '--extras off' in sent and '--line full' in sent and '--mixed-precision' in sent
+    assert '--cpu-sample 0' in sent and '--single-steps 0' in sent and '--host-steps 0' in sent
+    bad = tmp_path / 'bad.py'
+    bad.write_text('import sys\nsys.stderr.write("boom")\nsys.exit(3)\n')
+    monkeypatch.setattr(bench, '__file__', str(bad))
+    with pytest.raises(RuntimeError, match='exit code 3.*boom'):
+        bench.run_leg(dict(tag='t', workload='merge6_N25'), args, 30)
+    good = tmp_path / 'good.py'
+    good.write_text('print("noise")\nprint(\'{"value": 7.0}\')\n')
+    monkeypatch.setattr(bench, '__file__', str(good))
+    assert bench.run_leg(dict(tag='t', workload='merge6_N25'), args, 30) == {'value': 7.0}
