@@ -98,6 +98,10 @@ dg_solve_kernel(const DgProb* __restrict__ D, int64_t B, const double* __restric
     }
     if (coop && !deferred && TID == 0) {
       __threadfence();
+      if (!resume && c.park.entries) {
+        __hip_atomic_fetch_add(&coop->done_ticks, wall_clock64() - ticks0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&coop->done_fresh, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       __hip_atomic_fetch_add(&coop->done_iters, (unsigned long long)its, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_add(&coop->finished, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -375,6 +379,13 @@ static int park_for_launch(dgsqp_solver* h, bool coop, int grid, int64_t total, 
   h->park_last_cap = 0;
   int min_it = h->defer_min_it;
   double factor = h->defer_factor;
+  // qp_method OSQP on the LDS path: what a scenario costs is set by its ADMM iterations, not by its SQP iterations -- "twice the mean
+  // iteration count" sets aside scenarios that are not long, and their state copies and late resumes cost more than the tail they
+  // save (20 batches of configs[1] in one launch, profiles/r06_osqp_deferral_sweep.txt: 4,410 scen/s at factor 2, 4,914 without deferral,
+  // 5,337 at factor 4, 5,108 at 6; the exact QP has its optimum at 2: 11,739 against 11,105 at 3 and 10,129 without)
+  if (h->hp.osqp && h->hp.big != 2 && !h->defer_requested) factor = 4.0;
+  int time_mode = 0;
+  { const char* e = getenv("DGSQP_DEFER_TIME"); if (e) time_mode = atoi(e) != 0; }
   { const char* e = getenv("DGSQP_DEFER"); if (e && atoi(e) == 0) min_it = 0; }
   { const char* e = getenv("DGSQP_DEFER_MIN_IT"); if (e) min_it = atoi(e); }
   { const char* e = getenv("DGSQP_DEFER_FACTOR"); if (e) factor = atof(e); }
@@ -418,6 +429,7 @@ static int park_for_launch(dgsqp_solver* h, bool coop, int grid, int64_t total, 
   h->park_last_cap = cap;
   out->entries = pool.entries; out->store = pool.store; out->cap = (unsigned int)cap;
   out->min_it = min_it; out->factor_x16 = (int)(factor * 16.0 + 0.5); out->slot_doubles = slot;
+  out->time_mode = time_mode;
   return DGSQP_OK;
 }
 static int grid_for(dgsqp_solver* h, int64_t B) {
@@ -463,9 +475,9 @@ int dgsqp_create(const dgsqp_problem_t* prob, const dgsqp_params_t* par, int dev
     delete h;
     return build_error_code(msg);
   }
-  if (DG_BLOCK != 512 && (h->hp.big || h->hp.classic_qp || h->hp.osqp)) {
-    // the -DDG_BLOCK=256 build (two workgroups per CU, row N1): LDS-resident explicit-inverse layout with the active-set QP only
-    g_create_err = "too large: this build (DG_BLOCK = 256, two workgroups per CU) holds the LDS-resident explicit-inverse layout with the active-set QP only";
+  if (DG_BLOCK != 512 && (h->hp.big == 2 || h->hp.classic_qp || h->hp.osqp)) {
+    // the -DDG_BLOCK=256 build (two workgroups per CU, row N1): explicit-inverse layouts (n <= 128) with the active-set QP only
+    g_create_err = "too large: this build (DG_BLOCK = 256, two workgroups per CU) holds the LDS-resident and big explicit-inverse layouts with the active-set QP only";
     delete h;
     return DGSQP_E_TOO_LARGE;
   }

@@ -123,6 +123,8 @@ struct DgCoop {
   unsigned long long done_iters;  // SQP iterations of the scenarios finished so far (their mean sets the deferral threshold)
   unsigned long long park_resumed;   // (diagnostic)
   unsigned long long t_first;     // 100 MHz counter when the launch's first workgroup started (diagnostic time base)
+  unsigned long long done_ticks;  // 100 MHz ticks the scenarios finished WITHOUT a deferral took, and how many those are: their mean is the
+  unsigned long long done_fresh;  // deferral threshold in time mode (DgPark.time_mode: qp_method OSQP, where a scenario's cost is its ADMM iterations)
   DgCoopJob jobs[1];              // 2 per workgroup of the grid (double buffered)
 };
 // Deferral of long scenarios (scheduling only; cooperative launches).  A launch cannot end before its slowest scenario, and nothing in a
@@ -149,7 +151,7 @@ struct DgPark {
   unsigned int cap;
   int min_it;                     // never defer before this many iterations ...
   int factor_x16;                 // ... nor before factor x mean iterations of the finished scenarios (fixed point, 1/16)
-  int pad_;
+  int time_mode;                  // 1: ... x mean TIME of the scenarios finished without a deferral instead (100 MHz ticks)
   unsigned long long slot_doubles;
 };
 

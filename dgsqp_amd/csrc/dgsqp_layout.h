@@ -128,6 +128,8 @@ struct DgProb {
   int t2off[DGSQP_MAX_AGENTS];              // offset (doubles) of agent block in the Taylor tensor workspace
   int t2k[DGSQP_MAX_AGENTS];                // per-stage stride of that block = nqa*ndir
   int64_t t2_doubles;
+  int ox_nya, ox_ngi;   // OSQP on the XL layout, wave-interleaved G' table (dgsqp_osqp_xl.h: ox_build_tables): entries of the per-agent multiplier lists; padded entries of the table
+  int64_t wsx_gdI, wsx_tabI;   // ... its values, and its index part (group starts, per-agent list starts, the lists)
   int64_t wsx_Y, wsx_S, wsx_E, wsx_dy, wsx_tab, wsx_gdT;   // OSQP on the XL layout: the polish's Y and Schur complement (n x n each), row scaling and delta y (n_c), the transposed index table of G' w
   int64_t ws_t2, ws_q, ws_base, ws_H, ws_tang, ws_Y, ws_P, ws_V, ws_R, ws_Vp, ws_xM, ws_xJ, ws_xR, ws_bfgs, ws_gd, ws_v2, ws_K, ws_doubles; // global workspace layout (doubles): Taylor tensor, raw Q, watchdog backups,
                                                              // costate-contracted dynamics Hessians, tangent trajectories
@@ -174,6 +176,31 @@ static inline std::string dg_build_layout(DgProb& D) {
     D.wsx_tab = D.wsx_dy + nvp;          // uint32: n + 2 column starts, one entry per packed gradient element
     D.wsx_gdT = D.wsx_tab + ((int64_t)D.ngd + D.n + 6) / 2 + 2;      // the packed gradients' values in the table's (transposed) order
     D.ws_doubles = D.wsx_gdT + D.ngd + 2;
+    // the same values once more in WAVE-INTERLEAVED order for the ADMM iteration's G' w (ox_iterate_block): task (column, quarter) = lane
+    // it4 & 63 of group it4 >> 6 (16 neighbouring columns); entry m of that lane at gstart[group] + 64 m + lane, every group padded to its
+    // longest quarter column (a multiple of four entries) -- one 512-byte run per wavefront load instead of 16 cache lines.  The multipliers
+    // come from per-agent lists (agent a: its covering gradients in table order), so the hot loop reads no index at all.
+    {
+      int nya = 0;
+      for (int d = 0; d < D.ndense; d++) nya += D.dense[d].kind == 1 ? 2 : 1;
+      D.ox_nya = nya;
+      const int NG = (4 * D.n + 63) / 64;
+      int tot = 0;
+      for (int G = 0; G < NG; G++) {
+        int mx = 0;
+        for (int col = 16 * G; col < 16 * G + 16 && col < D.n; col++) {
+          const int a = col / (D.N * DGSQP_NUA), t = (col % (D.N * DGSQP_NUA)) / DGSQP_NUA;
+          int cnt = 0;
+          for (int d = D.stage_dense0[t + 1]; d < D.ndense; d++) cnt += (D.dense[d].a == a) || (D.dense[d].kind == 1 && D.dense[d].b == a);
+          if (cnt > mx) mx = cnt;
+        }
+        tot += 64 * ((((mx + 3) / 4) + 3) & ~3);
+      }
+      D.ox_ngi = tot;
+      D.wsx_tabI = (D.ws_doubles + 1) & ~(int64_t)1;                     // uint32: NG + 1 group starts, M + 1 list starts, nya list entries
+      D.wsx_gdI = D.wsx_tabI + (NG + 1 + DGSQP_MAX_AGENTS + 1 + nya + 3) / 2 + 2;
+      D.ws_doubles = D.wsx_gdI + tot + 2;
+    }
   }
   else if (D.osqp) { D.classic_qp = 0; D.ws_xM = D.ws_doubles; D.ws_xJ = D.ws_xR = D.ws_xM; D.ws_doubles = D.ws_xM + (int64_t)D.n * D.n; }
   else if (D.big == 2) { D.ws_xM = D.ws_R; D.ws_xJ = D.ws_P; D.ws_xR = D.ws_V; }
@@ -327,7 +354,8 @@ static inline std::string dg_build_layout(DgProb& D) {
     // the QP outputs (which hold x and y) -- and, what does not fit there, above them (trial trajectories / columns of R: dead or unused)
     const int ncp = (nc + 1) & ~1, np = (n + 1) & ~1;
     const int wslot = ncp > 4 * np ? ncp : 4 * np;
-    int dslot = ((D.ntask + 1) & ~1) + ((nd + 1) & ~1) + 2;
+    const int dp_len = D.ntask > D.ox_nya ? D.ntask : D.ox_nya;       // (the dense-dot partials; between two products the slot holds the per-agent multiplier lists of G' w)
+    int dslot = ((dp_len + 1) & ~1) + ((nd + 1) & ~1) + 2;
     if (dslot < ncp) dslot = ncp;
     int r1 = wslot + dslot;
     if (r1 < 16 * n + 2) r1 = 16 * n + 2;
@@ -341,7 +369,7 @@ static inline std::string dg_build_layout(DgProb& D) {
       fits = false;
       return L.scr;
     };
-    L.ox_w = place(r1); L.ox_dpart = L.ox_w + wslot; L.ox_yd2 = L.ox_dpart + ((D.ntask + 1) & ~1);
+    L.ox_w = place(r1); L.ox_dpart = L.ox_w + wslot; L.ox_yd2 = L.ox_dpart + ((dp_len + 1) & ~1);
     L.ox_z = place(ncp);
     L.ox_np = np; L.ox_nv = place(7 * np);
     L.ox_part = place(DG_NH * n > 512 ? DG_NH * n : 512);
@@ -356,6 +384,7 @@ static inline std::string dg_build_layout(DgProb& D) {
   }
   L.total = tot;
   if ((long)tot * 8 > DG_LDS_LIMIT && !D.big) { D.big = 1; return dg_build_layout(D); }   // (n > 128 starts at big = 2)
+  if ((long)tot * 8 > DG_LDS_LIMIT && D.big == 1 && DG_WG_PER_CU > 1 && !D.osqp && !D.gd_global) { D.gd_global = 1; return dg_build_layout(D); }   // half-arena build: the packed gradients to the scratch as well
   if ((long)tot * 8 > DG_LDS_LIMIT && D.osqp && D.big == 1 && D.osqp_nacap > 24) { D.osqp_nacap -= 8; return dg_build_layout(D); }   // OSQP: a smaller T slot (polish of fewer active rows)
   if ((long)tot * 8 > DG_LDS_LIMIT && D.big == 2 && D.xl_pack) { D.xl_pack = 0; D.gd_global = 0; return dg_build_layout(D); }   // no room for the packed matrix: the plain XL layout
   if ((long)tot * 8 > DG_LDS_LIMIT && D.big == 2 && !D.gd_global) { D.gd_global = 1; return dg_build_layout(D); }
@@ -509,6 +538,8 @@ static inline std::string dg_build(const dgsqp_problem_t& P, const dgsqp_params_
   if (D.osqp && D.n > 128 && D.ngd >= (1 << 22)) return "qp_method OSQP: the packed gradients exceed the 22-bit offsets of the XL layout's index table";
   D.big = D.n > 128 ? 2 : 0;   // XL layout: every matrix of the PSD / QP phases in the global scratch, generic (slow) kernels
   D.xl_noblock = getenv("DGSQP_XL_NOBLOCK") ? 1 : 0;
+  if (D.big == 0 && getenv("DGSQP_FORCE_BIG")) D.big = 1;                      // (development knobs: the big layout / the gradients in the scratch for a game that would fit without)
+  if (D.big == 1 && !D.osqp && getenv("DGSQP_FORCE_GD_GLOBAL")) D.gd_global = 1;
   if (D.big == 2 && D.n <= 176 && !getenv("DGSQP_XL_NOPACK")) { D.xl_pack = 1; D.gd_global = 1; }       // (tried first; dg_build_layout falls back when the arena overflows)
   return dg_build_layout(D);
 }

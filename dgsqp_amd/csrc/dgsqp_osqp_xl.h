@@ -165,6 +165,22 @@ __device__ inline OxTabs ox_tabs(const Ctx& c) {
   T.gdT = c.ws + D.wsx_gdT;
   return T;
 }
+// The same values in WAVE-INTERLEAVED order, for the ADMM iteration (ox_iterate_block).  Task it4 = 4 col + quarter is lane it4 & 63 of
+// group it4 >> 6 (sixteen neighbouring columns: eight stages of one agent, nearly equal lengths); entry m of a lane -- the column's entry
+// quarter + 4 m -- sits at gstart[group] + 64 m + lane, the group padded with zeros to its longest quarter column rounded up to four
+// entries: a wavefront load reads ONE 512-byte run where the column-major table gave it 16 cache lines.  The multiplier of entry e of
+// column (a, t, j) is element (ybase[a] + cnt_a - cnt_col + e) of the per-agent lists ylist (agent a's covering gradients in table
+// order: a column covers the LAST cnt_col of them) -- gathered once per iteration into LDS, so the loop reads values only, no index.
+struct OxTabI { const glb_u32* gstart; const glb_u32* ybase; const glb_u32* ylist; cgptr gdI; };
+__device__ inline OxTabI ox_tabi(const Ctx& c) {
+  const DgProb& D = dg_prob;
+  OxTabI T;
+  T.gstart = (const glb_u32*)(c.ws + D.wsx_tabI);
+  T.ybase = T.gstart + ((4 * D.n + 63) / 64 + 1);
+  T.ylist = T.ybase + (DGSQP_MAX_AGENTS + 1);
+  T.gdI = c.ws + D.wsx_gdI;
+  return T;
+}
 template <class GP>
 __device__ __noinline__ void ox_build_tables(const Ctx& c, const OxPtrs& o, GP gd) {
   const DgProb& D = dg_prob;
@@ -195,6 +211,41 @@ __device__ __noinline__ void ox_build_tables(const Ctx& c, const OxPtrs& o, GP g
   gptr gT = c.ws + D.wsx_gdT;
   const int tot = (int)o.tmp[n];
   for (int k = TID; k < tot; k += NT) gT[k] = gd[pt[k] & 0x3fffffu];
+  XSYNC();
+  // ---- the wave-interleaved copy (OxTabI)
+  const int NG = (4 * n + 63) / 64;
+  glb_u32* gs = (glb_u32*)(c.ws + D.wsx_tabI);
+  glb_u32* yb = gs + (NG + 1);
+  glb_u32* yl = yb + (DGSQP_MAX_AGENTS + 1);
+  if (TID == 0) {
+    unsigned int acc = 0;
+    for (int G = 0; G < NG; G++) {
+      int mx = 0;
+      for (int col = 16 * G; col < 16 * G + 16 && col < n; col++) { const int cn = (int)(cs[col + 1] - cs[col]); mx = cn > mx ? cn : mx; }
+      gs[G] = acc;
+      acc += 64u * (unsigned int)((((mx + 3) >> 2) + 3) & ~3);
+    }
+    gs[NG] = acc;
+  }
+  if (TID == 64) {        // per-agent lists: the gradients covering agent a, in table (= increasing gradient) order
+    unsigned int acc = 0;
+    for (int a = 0; a < D.M; a++) {
+      yb[a] = acc;
+      for (int d = 0; d < D.ndense; d++) { const DgDense dd = ld_dense(d); if (dd.a == a || (dd.kind == 1 && dd.b == a)) yl[acc++] = (unsigned int)d; }
+    }
+    for (int a = D.M; a <= DGSQP_MAX_AGENTS; a++) yb[a] = acc;
+  }
+  XSYNC();
+  gptr gI = c.ws + D.wsx_gdI;
+  for (int G = 0; G < NG; G++) {
+    const int base = (int)gs[G], len = ((int)gs[G + 1] - base) >> 6;
+    for (int e = TID; e < 64 * len; e += NT) {
+      const int m = e >> 6, it4 = 64 * G + (e & 63), col = it4 >> 2, idx = (it4 & 3) + 4 * m;
+      double v = 0.0;
+      if (col < n) { const int k0 = (int)cs[col], cn = (int)cs[col + 1] - k0; if (idx < cn) v = gT[k0 + idx]; }
+      gI[base + e] = v;
+    }
+  }
   XSYNC();
 }
 // out = G' w  (w: an n_c-vector in LDS that already carries the row scaling)
@@ -535,22 +586,41 @@ __device__ __noinline__ void ox_iterate_block(const Ctx& c, GP gd, double rho, d
     rr[g][2] = lead ? D.r_rate_ub[a][t][j] : -1; rr[g][3] = lead ? D.r_rate_lb[a][t][j] : -1;
     rr[g][4] = nxt ? D.r_rate_ub[a][nxt ? t + 1 : t][j] : -1; rr[g][5] = nxt ? D.r_rate_lb[a][nxt ? t + 1 : t][j] : -1;
   }
+  // ... and, per (column, quarter) task, where its run of the wave-interleaved table starts, how long the group's runs are, how many
+  // entries are its own and where its multipliers start in the per-agent lists; per thread, the gradients whose multipliers it gathers
+  const OxTabI TI = ox_tabi(c);
+  const int NGI = (4 * n + 63) / 64;
+  int gbase[GR], glen[GR], gcnt[GR], gyo[GR];
+#pragma unroll
+  for (int g = 0; g < GR; g++) {
+    const int it4 = TID + g * NT, G = it4 >> 6, col = it4 >> 2, part = it4 & 3;
+    const bool in = G < NGI, has = col < n;
+    gbase[g] = in ? (int)TI.gstart[G] : 0;
+    glen[g] = in ? ((int)TI.gstart[G + 1] - gbase[g]) >> 6 : 0;
+    const int cn = has ? (int)(T.cstart[col + 1] - T.cstart[col]) : 0;
+    gcnt[g] = cn > part ? (cn - part + 3) >> 2 : 0;
+    const int a = has ? col / (D.N * DGSQP_NUA) : 0;
+    gyo[g] = has ? (int)TI.ybase[a + 1] - cn + part : 0;      // ybase[a] + cnt_a - cnt_col + quarter
+  }
+  constexpr int YR = (2 * DG_NDMAX + NT - 1) / NT;
+  int yld[YR];
+#pragma unroll
+  for (int g = 0; g < YR; g++) yld[g] = TID + g * NT < D.ox_nya ? (int)TI.ylist[TID + g * NT] : -1;
   for (int rep = 0; rep < count; rep++) {
     PROF_BEGIN(pa1);
-    {                                                       // G' w as ox_gt_mul forms it (w already carries E), the row indices from registers
-      lptr yd = o.ddx;
+    {                                                       // G' w as ox_gt_mul forms it (w already carries E), the row indices from registers,
+      lptr ya = o.dpart;                                    // the gradient values from the wave-interleaved table (same entries, same order of the sums)
       clptr w = o.w;
       __syncthreads();
-      for (int d = TID; d < D.ndense; d += NT) {
-        const DgDense dd = ld_dense(d);
-        yd[d] = (dd.r_pos >= 0 ? w[dd.r_pos] : 0.0) - (dd.r_neg >= 0 ? w[dd.r_neg] : 0.0);
+#pragma unroll
+      for (int g = 0; g < YR; g++) {
+        if (yld[g] >= 0) { const DgDense dd = ld_dense(yld[g]); ya[TID + g * NT] = (dd.r_pos >= 0 ? w[dd.r_pos] : 0.0) - (dd.r_neg >= 0 ? w[dd.r_neg] : 0.0); }
       }
       __syncthreads();
 #pragma unroll
       for (int g = 0; g < GR; g++) {
         const int it4 = TID + g * NT;
-        if (it4 < 4 * n) {
-          const int col = it4 >> 2, part = it4 & 3;
+        if (it4 < 64 * NGI) {                               // (wave-uniform: whole groups)
           double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
           if (rr[g][0] >= 0) s0 += w[rr[g][0]];
           if (rr[g][1] >= 0) s0 -= w[rr[g][1]];
@@ -558,18 +628,23 @@ __device__ __noinline__ void ox_iterate_block(const Ctx& c, GP gd, double rho, d
           if (rr[g][3] >= 0) s1 -= w[rr[g][3]];
           if (rr[g][4] >= 0) s2 -= w[rr[g][4]];
           if (rr[g][5] >= 0) s2 += w[rr[g][5]];
-          const int k1 = (int)T.cstart[col + 1];
-          int k = (int)T.cstart[col] + part;
-          for (; k + 12 < k1; k += 16) {
-            const unsigned int pa = T.pairT[k], pb = T.pairT[k + 4], pc = T.pairT[k + 8], pd = T.pairT[k + 12];
-            const double ga = T.gdT[k], gb = T.gdT[k + 4], gc = T.gdT[k + 8], gg = T.gdT[k + 12];
-            s0 = __builtin_fma(yd[pa >> 22], ga, s0); s1 = __builtin_fma(yd[pb >> 22], gb, s1); s2 = __builtin_fma(yd[pc >> 22], gc, s2); s3 = __builtin_fma(yd[pd >> 22], gg, s3);
+          cgptr gp = TI.gdI + gbase[g] + (it4 & 63);
+          const int cnt = gcnt[g], nfull = cnt & ~3, yo = gyo[g];
+          for (int m = 0; m < glen[g]; m += 4) {            // glen: a multiple of four; lanes past their own count add nothing
+            const double g0 = gp[64 * m], g1 = gp[64 * (m + 1)], g2 = gp[64 * (m + 2)], g3 = gp[64 * (m + 3)];
+            const double y0 = ya[m < cnt ? yo + 4 * m : 0], y1 = ya[m + 1 < cnt ? yo + 4 * (m + 1) : 0], y2 = ya[m + 2 < cnt ? yo + 4 * (m + 2) : 0], y3 = ya[m + 3 < cnt ? yo + 4 * (m + 3) : 0];
+            if (m + 3 < nfull) {                            // a full quad of this lane: the four accumulators, as the column-major loop
+              s0 = __builtin_fma(y0, g0, s0); s1 = __builtin_fma(y1, g1, s1); s2 = __builtin_fma(y2, g2, s2); s3 = __builtin_fma(y3, g3, s3);
+            } else {                                        // its last, partial quad: everything into s0, in order
+              if (m < cnt) s0 = __builtin_fma(y0, g0, s0);
+              if (m + 1 < cnt) s0 = __builtin_fma(y1, g1, s0);
+              if (m + 2 < cnt) s0 = __builtin_fma(y2, g2, s0);
+            }
           }
-          for (; k < k1; k += 4) { const unsigned int pa = T.pairT[k]; s0 = __builtin_fma(yd[pa >> 22], T.gdT[k], s0); }
           double sm = (s0 + s1) + (s2 + s3);
           sm += dpp_f64<0xB1>(sm);
           sm += dpp_f64<0x4E>(sm);
-          if (part == 0) o.xt[col] = sm;
+          if ((it4 & 3) == 0 && it4 < 4 * n) o.xt[it4 >> 2] = sm;
         }
       }
       __syncthreads();

@@ -117,6 +117,31 @@ __device__ inline QpPtrs qp_ptrs(const Ctx& c) {
   q.Y = c.ws + D.ws_Y;
   return q;
 }
+// The packed gradients live in LDS or -- DgProb.gd_global: XL layouts, and the half-arena build's n = 100 games -- in the workgroup's scratch
+__device__ inline double qp_gcoef(const DgProb& D, const QpPtrs& q, int p, int col) {
+  return q.gdG ? g_row_coef<cgptr>(D, q.gdG, p, col) : g_row_coef<clptr>(D, q.gd, p, col);
+}
+__device__ inline void qp_gd_dots(const DgProb& D, const QpPtrs& q, clptr v, lptr part, lptr out) {
+  if (q.gdG) qp_dense_dots<cgptr>(D, q.gdG, v, part, out); else qp_dense_dots<clptr>(D, q.gd, v, part, out);
+}
+// a_i . y_j and |a_i|^2 of a dense row's packed gradient (one or two agents' blocks) against a column y_j of Y
+template <class GP>
+__device__ inline void qp_dense_pair(const DgProb& D, const DgDense dd, GP gp, cgptr yj, double& dot, double& nrm2) {
+  const int len = DGSQP_NUA * dd.k;
+  double s0 = 0, s1 = 0, n0 = 0, n1 = 0;
+  for (int part = 0; part < (dd.kind == 1 ? 2 : 1); part++) {
+    cgptr yy = yj + (part == 0 ? dd.a : dd.b) * D.N * DGSQP_NUA;
+    GP gg = gp + part * len;
+    int e = 0;
+    for (; e + 1 < len; e += 2) {
+      const double g0 = gg[e], g1 = gg[e + 1];
+      s0 = __builtin_fma(g0, yy[e], s0); s1 = __builtin_fma(g1, yy[e + 1], s1);
+      n0 = __builtin_fma(g0, g0, n0); n1 = __builtin_fma(g1, g1, n1);
+    }
+    if (e < len) { const double g0 = gg[e]; s0 = __builtin_fma(g0, yy[e], s0); n0 = __builtin_fma(g0, g0, n0); }
+  }
+  dot = s0 + s1; nrm2 = n0 + n1;
+}
 // All wavefronts: a_p into tv, y = P a_p into yv (a column copy for box / rate rows), dense-gradient dots of y into ddy.
 __device__ inline void qp_row_products(const Ctx& c, const QpPtrs& q, int p) {
   const DgProb& D = dg_prob;
@@ -134,10 +159,10 @@ __device__ inline void qp_row_products(const Ctx& c, const QpPtrs& q, int p) {
     }
     __syncthreads();
   } else {
-    for (int col = TID; col < n; col += NT) q.tv[col] = g_row_coef(D, q.gd, p, col);
+    for (int col = TID; col < n; col += NT) q.tv[col] = qp_gcoef(D, q, p, col);
     dev_p_mul(c, q.tv, q.yv, 1.0);
   }
-  qp_dense_dots(D, q.gd, q.yv, q.dpart, q.ddy);
+  qp_gd_dots(D, q, q.yv, q.dpart, q.ddy);
 }
 // All wavefronts: xv = x_u - Y lam for the m active rows (slots in yslot).  Thread = element i x quarter of the columns: every
 // thread has its loads from L2 in flight together; the four partial sums meet in LDS.
@@ -175,7 +200,7 @@ __device__ inline void qp_x_from_lambda(const QpPtrs& q, int m) {
 __device__ inline int qp_scan(const QpPtrs& q, double tol) {
   const DgProb& D = dg_prob;
   const int NONE = 0x7fffffff;
-  if (q.gdG) qp_dense_dots<cgptr>(D, q.gdG, q.xv, q.dpart, q.ddx); else qp_dense_dots<clptr>(D, q.gd, q.xv, q.dpart, q.ddx);
+  qp_gd_dots(D, q, q.xv, q.dpart, q.ddx);
   double best = -tol;
   int bi = NONE;
   for (int r = TID; r < D.nc; r += NT) {
@@ -329,7 +354,7 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
       const int p = q.prev[jj];
       if (ld_row(p).dense < 0) continue;          // uniform
       __syncthreads();
-      for (int col = TID; col < n; col += NT) q.tv[col] = g_row_coef(D, q.gd, p, col);
+      for (int col = TID; col < n; col += NT) q.tv[col] = qp_gcoef(D, q, p, col);
       dev_p_mul(c, q.tv, q.yv, 1.0);
       for (int i = TID; i < n; i += NT) q.Y[(int64_t)jj * n + i] = q.yv[i];
     }
@@ -354,22 +379,9 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
         a2 = has0 ? 2.0 : 1.0;
       } else {
         const DgDense dd = ld_dense(Ri.dense);
-        const int len = DGSQP_NUA * dd.k;
-        clptr gp = q.gd + dd.off;
-        double s0 = 0, s1 = 0, n0 = 0, n1 = 0;
-        for (int part = 0; part < (dd.kind == 1 ? 2 : 1); part++) {
-          cgptr yy = yj + (part == 0 ? dd.a : dd.b) * D.N * DGSQP_NUA;
-          clptr gg = gp + part * len;
-          int e = 0;
-          for (; e + 1 < len; e += 2) {
-            const double g0 = gg[e], g1 = gg[e + 1];
-            s0 = __builtin_fma(g0, yy[e], s0); s1 = __builtin_fma(g1, yy[e + 1], s1);
-            n0 = __builtin_fma(g0, g0, n0); n1 = __builtin_fma(g1, g1, n1);
-          }
-          if (e < len) { const double g0 = gg[e]; s0 = __builtin_fma(g0, yy[e], s0); n0 = __builtin_fma(g0, g0, n0); }
-        }
-        sv = Ri.sgn * (s0 + s1);
-        a2 = n0 + n1;
+        double dot;
+        if (q.gdG) qp_dense_pair<cgptr>(D, dd, q.gdG + dd.off, yj, dot, a2); else qp_dense_pair<clptr>(D, dd, q.gd + dd.off, yj, dot, a2);
+        sv = Ri.sgn * dot;
       }
       Sb[t] = sv;
       if (i == j) q.tv[j] = a2;
@@ -425,7 +437,7 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
       }
     }
     __syncthreads();
-    qp_dense_dots(D, q.gd, q.xv, q.dpart, q.ddx);     // xv still holds the unconstrained minimiser
+    qp_gd_dots(D, q, q.xv, q.dpart, q.ddx);     // xv still holds the unconstrained minimiser
     if (w0) {
       PROF_COUNT(PH_C_NPREV, nprev); PROF_COUNT(PH_C_MBUILD, S.m);
       // Multipliers: primal active-set steps on the dual problem restricted to W (min 1/2 l'Sl - v'l, l >= 0), from the
@@ -499,7 +511,7 @@ __device__ __noinline__ int dev_qp(const Ctx& c) {
     // Iterative refinement on the active set: P is an explicit inverse, so the active rows hold to ~1e-12 only; two
     // projection steps  x <- x - Y S^-1 (A x - b),  lam <- lam + S^-1 (A x - b)  (Y = P A^T) bring them to rounding level.
     for (int pass = 0; pass < 2; pass++) {
-      qp_dense_dots(D, q.gd, q.xv, q.dpart, q.ddx);
+      qp_gd_dots(D, q, q.xv, q.dpart, q.ddx);
       if (w0 && S.m > 0) {
         const int m = S.m;
         for (int j = lane; j < m; j += 64) q.cvec[j] = q.g[q.alist[j]] + qpw_row_dot(D, ld_row(q.alist[j]), q.xv, q.ddx);

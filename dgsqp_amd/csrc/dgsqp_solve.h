@@ -1724,14 +1724,18 @@ struct SolveOutPtrs {
 };
 // ---- deferral of long scenarios (DgPark, dgsqp_device.h) ----
 // A slot for this scenario, or -1: not yet long enough, no fresh ticket left (nothing to make room for), or no slot free.  Block-uniform.
-__device__ inline long long dev_park_reserve(const Ctx& c, int sqp_it) {
+__device__ inline long long dev_park_reserve(const Ctx& c, int sqp_it, unsigned long long ticks0) {
   if (!c.park.entries || sqp_it < c.park.min_it) return -1;
   long long r = -1;
   if (TID == 0) {
     DgCoop* co = c.coop;
     const unsigned long long fin = AT_LOAD(&co->finished), di = AT_LOAD(&co->done_iters);
     // (nothing is deferred before 32 scenarios have finished: what "long" means for this game is not known yet)
-    const bool long_enough = fin >= 32ull && (unsigned long long)sqp_it * 16ull * fin >= (unsigned long long)c.park.factor_x16 * di;
+    bool long_enough = fin >= 32ull && (unsigned long long)sqp_it * 16ull * fin >= (unsigned long long)c.park.factor_x16 * di;
+    if (c.park.time_mode) {       // by time spent instead of by iterations
+      const unsigned long long fresh = AT_LOAD(&co->done_fresh), dt = AT_LOAD(&co->done_ticks);
+      long_enough = fresh >= 32ull && (wall_clock64() - ticks0) * 16ull * fresh >= (unsigned long long)c.park.factor_x16 * dt;
+    }
     // ... and only while at least two more rounds of fresh scenarios wait: setting a scenario aside just before the queue runs empty
     // only delays it (a single 1,024-scenario batch of the 3-car merge lost 14 % that way)
     if (long_enough && AT_LOAD(c.ticket) + 2ull * gridDim.x < c.coop_total) {
@@ -1962,7 +1966,7 @@ __device__ inline bool dev_solve(const Ctx& c, cgptr u_ws, int64_t b, const Solv
     if (sqp_it >= D.par.sqp_iters) { status = DGSQP_MAX_IT; break; }
     if (timed && (dev_block_clock() - t_start) * 1e-8 > D.par.time_limit) { status = DGSQP_TIME_LIMIT; break; }   // block-uniform
     if (!resume && !timed) {      // (a wall-clock limit counts the time spent waiting: such solves are never deferred)
-      const long long slot = dev_park_reserve(c, sqp_it);
+      const long long slot = dev_park_reserve(c, sqp_it, ticks0);
       if (slot >= 0) {
         const unsigned long long now = dev_bcast_u64(TID == 0 ? wall_clock64() : 0ull);
         // resume order: cost so far, weighted up for a scenario that is far from stationarity -- the ones that run to the iteration

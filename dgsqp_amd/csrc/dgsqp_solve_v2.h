@@ -269,7 +269,7 @@ __device__ inline bool dev_solve_v2(const Ctx& c, cgptr u_ws, int64_t b, const S
     // deferral of long scenarios (dev_solve): set aside here, resumed at the top of the loop.  Unlike v1, also with a wall-clock limit (the
     // v2 study always sets one, 600 s: comparison_study_barc/globals.py:40): the entry carries the time spent solving so far
     if (!resume && !finished) {
-      const long long slot = dev_park_reserve(c, sqp_it);
+      const long long slot = dev_park_reserve(c, sqp_it, ticks0);
       if (slot >= 0) {
         const unsigned long long now = dev_bcast_u64(TID == 0 ? wall_clock64() : 0ull);
         const double sm = cond[2] == cond[2] ? fmin(cond[2], 1e30) : 1e30;

@@ -114,13 +114,19 @@ def test_solve_matches_golden_fixtures(solvers, name):
             assert rel(res['cost'][b], gold['cost'][b]) < 1e-8, b
 
 
+# identical-path counts measured at the literal LSQR setting (profiles/r05_gpu_tests_parity_lines.txt); the floor of each fixture is ONE scenario below
+LITERAL_LSQR_IDENTICAL = {'kb_chicane_N15': (32, 32), 'kb_curve_N10': (32, 32), 'dyn_curve_N15': (16, 16), 'dyn_curve_N25': (56, 64), 'kb_barc2_N15': (32, 32), 'merge_N8': (16, 16)}
+
+
 @pytest.mark.parametrize('name', ['kb_chicane_N15', 'kb_curve_N10', 'dyn_curve_N15', 'dyn_curve_N25', 'kb_barc2_N15', 'merge_N8'])
 def test_identity_at_the_reference_lsqr_setting_is_tracked(oracle, games, name):
     """The strict parity tests above run with a converged LSQR dual start (lsqr_tol = 1e-13); the reference (DGSQP.py:324) and bench.py run
     scipy's default 1e-6.  This test runs the LITERAL default on both sides -- device and oracle on the scenarios of the golden fixture,
     nothing overridden -- and reports the identical-path fraction, so that the number at the reference's own setting is tracked from
-    round to round; it is held to a floor (>= 70 % of all scenarios, converged fractions within 8 points), not to the 95 % of the
-    tight-tolerance tests: at 1e-6 two correct LSQR implementations stop a Lanczos step apart on some scenarios (l0 differs by 1e-4)."""
+    round to round.  Each fixture is held to its OWN measured count minus one scenario (round 5: 100 % on five fixtures, 56/64 on
+    dyn_curve_N25 -- at 1e-6 two correct LSQR implementations stop a Lanczos step apart on some scenarios, l0 differs by 1e-4), converged
+    fractions within 2 scenarios: a regression of two scenarios anywhere fails (the global 70 % floor of round 5 would have let a
+    quarter of them go)."""
     from dgsqp_amd.solver import DGSQP
     gold = np.load(GOLD / f'{name}.npz')
     g, P, par = games[name]
@@ -133,8 +139,9 @@ def test_identity_at_the_reference_lsqr_setting_is_tracked(oracle, games, name):
     err = max([rel(res['u'][b], ref['u'][b]) for b in idc], default=0.0)
     print(f'{name} at the reference LSQR setting (1e-6): identical (status, iterations, QPs) on {same.sum()}/{len(same)} scenarios; converged device {cd.mean():.3f} '
           f'oracle {cr.mean():.3f}; largest relative iterate difference of the identical converged ones {err:.1e}')
-    assert same.mean() >= 0.70
-    assert abs(cd.mean() - cr.mean()) <= 0.08 + 1.0 / len(cd)
+    measured, total = LITERAL_LSQR_IDENTICAL[name]
+    assert len(same) == total and same.sum() >= measured - 1, (int(same.sum()), measured)
+    assert abs(int(cd.sum()) - int(cr.sum())) <= 2
     assert err < 5e-3
 
 
@@ -462,9 +469,11 @@ def test_xl_osqp_mixed_precision_against_fp64(oracle, name):
     """dgsqp_params_t.mixed_precision (opt-in; BASELINE configs[2..4] name fp32): the XL ADMM iteration with K^-1 stored in fp32 against the
     fp64 kernel and, through it, oracle/osqp.hpp.  QP level (8 scenarios, the QP at the dual start): the same verdict (solved /
     infeasible / limit) on every QP both runs settle (statuses 1, -3, -4), the ADMM iteration count within 25 % (or 50), and wherever both
-    polishes succeed the same point to 1e-6 -- the polish is fp64 and lands on the KKT point of the same active set.  Solve level (24
-    scenarios): converged fractions within 3 scenarios of each other, and the solutions of scenarios converged in both within 1e-3
-    on at least 80 % of them (the solvable three-car game; F1 is chaotic: statistics only).  The six-car merge runs at reg = 0, where the
+    polishes succeed the same point to 1e-6 -- the polish is fp64 and lands on the KKT point of the same active set.  Solve level, the
+    solvable three-car game (24 scenarios): converged counts within 3 scenarios of each other, and the solutions of scenarios converged in
+    both within 1e-3 on at least 80 % of them.  F1 is chaotic -- a 24-scenario sample once gave 2 converged against 7 (profiles/r05_mixed_precision.txt),
+    single paths do not agree and are not asserted --: the STATISTIC is held over 256 scenarios, converged fractions within 8 points
+    (measured 44.9 % vs 47.3 %) and mean QP solves within 15 %.  The six-car merge runs at reg = 0, where the
     kernel keeps K^-1 in fp64 (csrc/dgsqp_osqp_xl.h, ox_build_k: the measured reason): the switch must leave it bit-identical."""
     from dgsqp_amd import montecarlo as mc
     from dgsqp_amd.solver import DGSQP, build_problem, build_params
@@ -493,7 +502,7 @@ def test_xl_osqp_mixed_precision_against_fp64(oracle, name):
     assert worst < 1e-6
     if name == 'curve3_N25':
         assert settled >= B - 1 and polished >= B // 2
-    B = 8 if name == 'merge6_N25' else 24          # (the merge only has to come out bit-identical: eight solves show it)
+    B = {'merge6_N25': 8, 'kb_f1_N50': 256}.get(name, 24)          # (the merge only has to come out bit-identical: eight solves show it; F1: a statistic)
     x0, u_tm = mc.sample_scenarios(g, B, seed=5)
     r64, r32 = s64.solve_batch(x0, u_tm), s32.solve_batch(x0, u_tm)
     c64, c32 = r64['status'] == 0, r32['status'] == 0
@@ -501,7 +510,10 @@ def test_xl_osqp_mixed_precision_against_fp64(oracle, name):
     close = np.array([rel(r32['u'][i], r64['u'][i]) < 1e-3 for i in np.nonzero(both)[0]])
     print(f'{name}: full solves, K^-1 fp32 vs fp64: converged {c32.sum()} vs {c64.sum()} of {B}, mean QP solves {r32["qp_solves"].mean():.1f} vs {r64["qp_solves"].mean():.1f}; '
           f'same solution (1e-3) on {int(close.sum())}/{int(both.sum())} converged in both')
-    assert abs(int(c32.sum()) - int(c64.sum())) <= (3 if name == 'curve3_N25' else 6)
+    if name == 'kb_f1_N50':
+        assert abs(c32.mean() - c64.mean()) <= 0.08 and abs(r32['qp_solves'].mean() - r64['qp_solves'].mean()) <= 0.15 * r64['qp_solves'].mean()
+    else:
+        assert abs(int(c32.sum()) - int(c64.sum())) <= 3
     if name == 'curve3_N25':
         assert both.sum() >= B // 2 and close.mean() >= 0.8
     if name == 'merge6_N25':
@@ -599,6 +611,72 @@ def test_event_trace_parity(oracle, games, solvers, name):
         deep[b] = len(alphas) > 0 and alphas[-1] < 1e-9 and (k >= len(to) or to[k, 0] in (30, 31, 40, 22)) and (k >= len(tg) or tg[k, 0] in (30, 31, 40, 22))
     print(name, 'event traces identical', identical.sum(), 'of', B, '; first difference inside a line search below alpha = 1e-9:', deep.sum())
     assert (identical | deep).sum() >= B - 1 and identical.sum() >= B - 3, (identical, deep)
+
+
+def _trace_first_difference(to, tg, vtol):
+    """Index of the first event at which two SQP event logs [(code, value)] differ -- in code, or in value by more than ``vtol`` relative
+    (values below 1e-6 and the merit values of an iteration whose mu is a quotient by a rounding-size violation, p_feas < 1e-9, are
+    compared by code alone: test_event_trace_parity) -- or min(len) when one is a prefix of the other; equal logs: their length."""
+    m = min(len(to), len(tg))
+    close = (to[:m, 0] == tg[:m, 0]) & ((np.abs(to[:m, 1]) <= 1e-6) | (np.abs(tg[:m, 1] - to[:m, 1]) <= vtol * np.abs(to[:m, 1])))
+    pf = 1.0
+    noisy = np.zeros(m, bool)
+    for k in range(m):
+        if to[k, 0] == 2:
+            pf = to[k, 1]
+        elif to[k, 0] == 1:
+            pf = 1.0
+        noisy[k] = pf < 1e-9 and to[k, 0] in (11, 12, 13, 20, 21, 22, 31)
+    close |= noisy & (to[:m, 0] == tg[:m, 0])
+    return int(np.argmin(close)) if not close.all() else m
+
+
+@pytest.mark.parametrize('name', ['kb_f1_N50', 'kb_barc3_N25'])
+def test_event_trace_prefix_parity_on_the_chaotic_configs(oracle, name):
+    """BASELINE configs[3] (F1, N = 50, n = 200) and configs[2] (three cars on the BARC circuit, N = 25, n = 150) are chaotic / failing
+    games: whole-solve identity is only defined on the scenarios the oracle reproduces under 1e-13 input perturbations (39 of 64 and 39 of
+    48 in round 5), the others were compared by two loose statistics.  Here EVERY scenario is used up to the point where the oracle
+    itself stops being reproducible: the C++ oracle's event log (DGSQP.py:368-398 convergence measures, :559-585 mu, merit values, every
+    watchdog / line-search trial) is recorded from the nominal inputs and from two 1e-13-perturbed copies; the scenario's STABLE PREFIX
+    ends at the first event where a perturbed log leaves the nominal one (another code, or a value off by more than 1e-8 relative -- the
+    growth that precedes a fork); over that prefix the device's log must carry the same codes in the same order with values within
+    1e-5.  At most 1 scenario in 20 may leave its prefix early (two re-runs do not find every fragile decision: conftest.stable_mask)."""
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+    from dgsqp_amd import montecarlo as mc
+    from dgsqp_amd.solver import DGSQP, build_problem, build_params
+    g, B = (mc.f1_racing_game(N=50), 64) if name == 'kb_f1_N50' else (mc.barc_racing_game(N=25, M=3), 48)
+    P, par = build_problem(*g.solver_args()), build_params(g.params, lsqr_tol=1e-13)
+    s = DGSQP(*g.solver_args(), print_method=None, lsqr_tol=1e-13)
+    assert s.dims.layout == 2
+    x0, u_tm = mc.sample_scenarios(g, B, seed=0)
+    u = s._to_agent_major(u_tm)
+    cap = 40000
+    s.set_trace(cap)
+    try:
+        s.solve_batch(x0, u_tm)
+        dev = s.fetch_trace(B)
+    finally:
+        s.set_trace(0)
+    rng = np.random.default_rng(2024)
+    pert = [(x0 * (1 + 1e-13 * rng.standard_normal(x0.shape)), u * (1 + 1e-13 * rng.standard_normal(u.shape))) for _ in range(2)]
+    jobs = [(x0[b], u[b]) for b in range(B)] + [(px[b], pu[b]) for px, pu in pert for b in range(B)]
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 8)) as ex:          # (ctypes releases the GIL: the oracle runs on all host cores)
+        logs = list(ex.map(lambda xu: oracle.solve_trace(P, par, xu[0], xu[1], max_pairs=cap), jobs))
+    nominal, p1, p2 = logs[:B], logs[B:2 * B], logs[2 * B:]
+    prefix = np.array([min(_trace_first_difference(nominal[b], p1[b], 1e-8), _trace_first_difference(nominal[b], p2[b], 1e-8)) for b in range(B)])
+    whole = np.array([prefix[b] == len(nominal[b]) for b in range(B)])                     # the oracle reproduces the entire log
+    agree = np.array([min(_trace_first_difference(nominal[b][:prefix[b]], dev[b][:prefix[b]], 1e-5), prefix[b]) if len(dev[b]) >= prefix[b]
+                      else _trace_first_difference(nominal[b][:prefix[b]], dev[b], 1e-5) for b in range(B)])
+    ok = agree >= prefix
+    iters = np.array([int((nominal[b][:prefix[b], 0] == 1).sum()) for b in range(B)])       # SQP iterations that start inside the prefix
+    print(f'{name}: stable prefixes of {B} oracle event logs: {int(prefix.sum())} of {sum(len(t) for t in nominal)} events (median {int(np.median(prefix))}, min {int(prefix.min())}; '
+          f'{int(whole.sum())} logs stable to their end), {int(iters.sum())} SQP iterations inside them (median {int(np.median(iters))} per scenario); '
+          f'device identical over the whole prefix on {int(ok.sum())}/{B} scenarios, events compared {int(np.minimum(agree, prefix).sum())}; '
+          f'early departures (scenario, event, prefix): {[(int(b), int(agree[b]), int(prefix[b])) for b in np.nonzero(~ok)[0]]}')
+    assert prefix.min() >= 3 and np.median(iters) >= 2                   # every prefix holds at least the first convergence test; typically several iterations
+    assert ok.sum() >= B - max(1, B // 20), (agree[~ok], prefix[~ok])
+    assert ok[whole].all() or (~ok[whole]).sum() <= 1                    # where the oracle is stable to the end, so is the device (whole-solve identity)
 
 
 def test_full_size_properties(games):
@@ -1932,6 +2010,66 @@ def test_monte_carlo_example_script(tmp_path):
             assert all(np.array_equal(r['solve_info']['iter_data'][0]['u_sol'], ref['u'][b]) for b, r in enumerate(recs))
         else:       # (the mirror's initial states equal the device's to rounding of sin / cos: 1e-12)
             assert max(np.abs(r['solve_info']['iter_data'][0]['u_sol'] - ref['u'][b]).max() for b, r in enumerate(recs)) < 1e-6
+
+
+@pytest.mark.parametrize('script', ['chicane', 'comp', 'merge', 'agents', 'ablation'])
+def test_monte_carlo_example_drivers(tmp_path, script):
+    """examples/monte_carlo_{chicane,comp,merge,agents,ablation}.py -- the DG-SQP legs of scripts/DGSQP_ALGAMES_monte_carlo_chicane.py
+    (:487-511), DGSQP_comp_monte_carlo.py (:488-506), DGSQP_merge_monte_carlo.py (:505-525), DGSQP_monte_carlo_agents.py (:323-342) and
+    DGSQP_monte_carlo_ablation.py (:480-504) on the library: each writes the pickle(s) its scripts/process_data_*.py reads (file names,
+    top-level keys, one ``dict(solve_info, params, init)`` per sample with the keys of DGSQP.py:495-502), and the records are those of a
+    plain solve_batch of the same samples (grouped launches + a ragged remainder change nothing)."""
+    import pathlib
+    import pickle
+    import subprocess
+    import sys
+    from dgsqp_amd import montecarlo as mc
+    from dgsqp_amd.solver import DGSQP
+    root = pathlib.Path(__file__).resolve().parent.parent
+    out = tmp_path / 'out'
+    argv = {'chicane': ['--num-mc', '40', '--batch', '16', '--N', '10', '--out', str(out / 'data_c_45_N_10.pkl')],
+            'comp': ['--num-mc', '40', '--batch', '16', '--N', '8', '--out', str(out)],
+            'merge': ['--num-mc', '40', '--batch', '16', '--N', '8', '--out', str(out)],
+            'agents': ['--num-mc', '24', '--batch', '16', '--agents', '2', '3', '--N', '8', '--out', str(out)],
+            'ablation': ['--num-mc', '24', '--batch', '16', '--N', '10', '--out', str(out)]}[script]
+    run = subprocess.run([sys.executable, str(root / 'examples' / f'monte_carlo_{script}.py')] + argv, capture_output=True, text=True, timeout=900, cwd=str(root))
+    assert run.returncode == 0, run.stderr[-2000:]
+    load = lambda f: pickle.load(open(f, 'rb'))
+
+    def check(recs, game, n, seed):
+        assert len(recs) == n and all({'solve_info', 'params', 'init'} <= set(r) for r in recs)
+        si = recs[0]['solve_info']
+        assert {'time', 'num_iters', 'status', 'cost', 'cond', 'iter_data', 'msg', 'init'} <= set(si) and {'p_feas', 'comp', 'stat'} <= set(si['cond'])
+        assert 'qp_solves' in si['iter_data'][0] and len(recs[0]['init']) == game.joint_model.n_a and hasattr(recs[0]['init'][0].x, 'x')
+        x0, u_ws = mc.sample_scenarios(game, n, seed=seed)
+        ref = DGSQP(*game.solver_args(), print_method=None).solve_batch(x0, u_ws)
+        assert [r['solve_info']['num_iters'] for r in recs] == list(ref['num_iters'])
+        assert [r['solve_info']['status'] for r in recs] == list(ref['status'] <= 1) and [r['solve_info']['msg'] for r in recs] == list(ref['msg'])
+        assert all(np.array_equal(r['solve_info']['iter_data'][0]['u_sol'], ref['u'][b]) for b, r in enumerate(recs))
+        assert abs(recs[0]['init'][0].x.x - x0[0, 0]) < 1e-15 and recs[0]['params'].N == game.params.N
+
+    if script == 'chicane':
+        d = load(out / 'data_c_45_N_10.pkl')
+        assert {'dgsqp', 'algames', 'track', 'agent_dyn_configs', 'joint_model_config'} <= set(d)        # chicane.py:501-505
+        check(d['dgsqp'], mc.kinematic_racing_game('chicane', N=10, reg=1e-3), 40, 1)
+    elif script in ('comp', 'merge'):
+        files = sorted(out.glob('sample_*.pkl'), key=lambda f: int(f.stem.split('_')[1]))
+        assert [f.name for f in files] == [f'sample_{i + 1}.pkl' for i in range(40)]                        # comp.py:503, merge.py:521
+        ds = [load(f) for f in files]
+        assert all(('dgsqp' in d and 'env' in d) for d in ds) and (script == 'merge' or 'algames' in ds[0])
+        check([d['dgsqp'] for d in ds], mc.barc_racing_game(N=8, M=2, reg=0.0) if script == 'comp' else mc.merge_game(N=8, reg=0.0, M=3), 40, 0 if script == 'comp' else 1)
+    elif script == 'agents':
+        for M in (2, 3):
+            d = load(out / f'data_c_45_M_{M}_N_8.pkl')                                                      # agents.py:339
+            assert {'sqgames', 'track', 'agent_dyn_configs', 'joint_model_config'} <= set(d) and len(d['agent_dyn_configs']) == M
+            check(d['sqgames'], mc.kinematic_racing_game('curve', N=8, M=M, reg=1e-3), 24, 1)
+    else:
+        d = load(out / 'data_c_90_N_10.pkl')                                                                # ablation.py:501
+        assert {'sqgames_all', 'sqgames_none', 'track', 'agent_dyn_configs', 'joint_model_config'} <= set(d)
+        check(d['sqgames_all'], mc.ablation_racing_game(N=10, nonmono_ls=True, merit_function='stat_l1'), 24, 1)
+        check(d['sqgames_none'], mc.ablation_racing_game(N=10, nonmono_ls=False, merit_function='stat'), 24, 1)
+        assert d['sqgames_all'][0]['params'].nonmono_ls and not d['sqgames_none'][0]['params'].nonmono_ls
+        assert abs(d['sqgames_all'][3]['init'][1].x.y - d['sqgames_none'][3]['init'][1].x.y) == 0.0         # the same samples for both solvers
 
 
 def test_bench_line_contract():

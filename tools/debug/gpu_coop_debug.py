@@ -1,8 +1,8 @@
 """Development aid (GPU box): cooperative line search vs the plain launch on one batch -- kernel times, helper counters, and how
-the outputs differ (they must not).  usage: python tools/gpu_coop_debug.py [workload] [B] [seed]"""
+the outputs differ (they must not).  usage: python tools/debug/gpu_coop_debug.py [workload] [B] [seed]"""
 import os, sys, pathlib
 import numpy as np
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 import bench
 from dgsqp_amd.montecarlo import sample_scenarios
 from dgsqp_amd.solver import DGSQP

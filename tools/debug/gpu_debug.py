@@ -1,7 +1,7 @@
 """Development aid (runs on the GPU box): stage-by-stage comparison of the HIP path with the oracle."""
 import sys, time, pathlib
 import numpy as np
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 from dgsqp_amd.montecarlo import kinematic_racing_game, dynamic_racing_game, sample_scenarios
 from dgsqp_amd.solver import DGSQP
 from dgsqp_amd import _ffi

@@ -1,9 +1,9 @@
 """Development aid (GPU box): deferral of long scenarios (dgsqp_set_deferral) in one cooperative grouped launch of G batches --
 kernel time with and without, how many scenarios were deferred, and whether the outputs differ (they must not).
-usage: python tools/gpu_defer_debug.py [workload] [B] [G] [seed]"""
+usage: python tools/debug/gpu_defer_debug.py [workload] [B] [G] [seed]"""
 import os, sys, pathlib
 import numpy as np
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 import bench
 from dgsqp_amd.montecarlo import sample_scenarios
 from dgsqp_amd.solver import DGSQP, solve_batches

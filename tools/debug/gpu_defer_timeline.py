@@ -1,9 +1,9 @@
 """Development aid (GPU box): timeline of one cooperative grouped launch with deferral -- when the queue ran empty, when the deferred
 scenarios were resumed and finished, how well the resume order's key predicts what a scenario still costs.
-usage: python tools/gpu_defer_timeline.py [workload] [B] [G] [min_it] [factor] [seed]"""
+usage: python tools/debug/gpu_defer_timeline.py [workload] [B] [G] [min_it] [factor] [seed]"""
 import os, sys, pathlib
 import numpy as np
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 import bench
 from dgsqp_amd.montecarlo import sample_scenarios
 from dgsqp_amd.solver import DGSQP, solve_batches

@@ -3,7 +3,7 @@ oracle, and the first SQP event at which the two logs differ.
 usage: gpu_forks.py <fixture name, e.g. dyn_curve_N25> [rel tol of the event comparison, default 1e-6]"""
 import os, sys, pathlib
 import numpy as np
-ROOT = pathlib.Path(__file__).resolve().parent.parent
+ROOT = pathlib.Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tests'))
 from conftest import agent_major, tight_lsqr
 from oracle import oracle

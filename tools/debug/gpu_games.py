@@ -2,7 +2,7 @@
 usage: gpu_games.py <barc2|barc3|merge> [B] [N]"""
 import os, sys, time, pathlib
 import numpy as np
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 from oracle import oracle
 import dgsqp_amd.solver as sv
 from dgsqp_amd import montecarlo as mc

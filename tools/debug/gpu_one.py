@@ -1,7 +1,7 @@
 """Development aid: phase profile of selected scenarios of a sampled batch (prof build)."""
 import sys, time, pathlib, ctypes
 import numpy as np
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 from dgsqp_amd.montecarlo import kinematic_racing_game, dynamic_racing_game, sample_scenarios
 from dgsqp_amd.solver import DGSQP
 which, N, B = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])

@@ -1,7 +1,7 @@
 """Development aid (GPU box, -DDG_PROF build): per-phase cycles of ONE scenario of the dyn bench batch (the slowest one by default)."""
 import sys, pathlib, ctypes
 import numpy as np
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 from dgsqp_amd.montecarlo import dynamic_racing_game, sample_scenarios
 from dgsqp_amd.solver import DGSQP
 idx = int(sys.argv[1]) if len(sys.argv) > 1 else 278

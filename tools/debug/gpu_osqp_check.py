@@ -9,7 +9,7 @@ import time
 
 import numpy as np
 
-ROOT = pathlib.Path(__file__).resolve().parent.parent
+ROOT = pathlib.Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tools')); sys.path.insert(0, str(ROOT / 'tests'))
 import dgsqp_amd.montecarlo as mc  # noqa: E402
 from dgsqp_amd.solver import DGSQP, build_problem, build_params, plan  # noqa: E402

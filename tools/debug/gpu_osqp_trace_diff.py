@@ -2,7 +2,7 @@
 LSQR dual start.  usage: gpu_osqp_trace_diff.py <game of tools/ref_stats.py> [B] [first scenario]"""
 import os, sys, pathlib
 import numpy as np
-ROOT = pathlib.Path(__file__).resolve().parent.parent
+ROOT = pathlib.Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tools')); sys.path.insert(0, str(ROOT / 'tests'))
 from oracle import oracle
 from dgsqp_amd import montecarlo as mc

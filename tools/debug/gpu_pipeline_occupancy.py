@@ -2,10 +2,10 @@
 clock?  Replays bench.py's launch schedule (P launches in flight over 3P staged batches, next launch when the previous one drains) and
 reads the per-workgroup lifetime counters of the diagnostic build:
     occupancy = sum of workgroup lifetimes / (wall x CUs x clock),   clock = cycles / wall of the longest-lived workgroup.
-usage: DGSQP_HIP_LIB=dgsqp_amd/csrc/libdgsqp_hip_prof.so python tools/gpu_pipeline_occupancy.py [steps] [in_flight] [batch]"""
+usage: DGSQP_HIP_LIB=dgsqp_amd/csrc/libdgsqp_hip_prof.so python tools/debug/gpu_pipeline_occupancy.py [steps] [in_flight] [batch]"""
 import ctypes as C, sys, time, pathlib
 import numpy as np
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 from dgsqp_amd import _ffi
 from dgsqp_amd.montecarlo import dynamic_racing_game, sample_scenarios
 from dgsqp_amd.solver import DGSQP

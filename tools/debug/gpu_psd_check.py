@@ -1,7 +1,7 @@
 """Development aid: accuracy of the device _nearestPD against the oracle with many negative eigenvalues."""
 import sys, pathlib, os
 import numpy as np
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 from dgsqp_amd.montecarlo import kinematic_racing_game, dynamic_racing_game, sample_scenarios
 from dgsqp_amd.solver import DGSQP
 from oracle import oracle

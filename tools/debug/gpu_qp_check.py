@@ -2,7 +2,7 @@
 usage: gpu_qp_check.py <barc2|barc3|kbcurve|kbchicane> <reg> [B]"""
 import sys, pathlib
 import numpy as np
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 from dgsqp_amd import montecarlo as mc
 from dgsqp_amd.solver import DGSQP, build_problem, build_params
 from oracle import oracle

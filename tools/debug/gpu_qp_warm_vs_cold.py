@@ -1,7 +1,7 @@
 """Development aid (GPU box): kernel time of bench batches with and without the warm start of the active-set QP."""
 import sys, pathlib
 import numpy as np
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 import bench
 from dgsqp_amd.montecarlo import sample_scenarios
 from dgsqp_amd.solver import DGSQP

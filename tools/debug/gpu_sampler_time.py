@@ -1,7 +1,7 @@
 """Development aid: host (numpy) vs device PID warm start + collision rejection inside the scenario sampler."""
 import sys, time, pathlib
 import numpy as np
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 from dgsqp_amd.montecarlo import kinematic_racing_game, dynamic_racing_game, sample_scenarios
 from dgsqp_amd.solver import DGSQP
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096

@@ -1,8 +1,8 @@
 """Development aid (GPU box, -DDG_PROF library): per-phase cycles of single scenarios solved alone.
-usage: DGSQP_HIP_LIB=dgsqp_amd/csrc/libdgsqp_hip_prof.so python tools/gpu_scn_profile.py workload seed:index [seed:index ...]"""
+usage: DGSQP_HIP_LIB=dgsqp_amd/csrc/libdgsqp_hip_prof.so python tools/debug/gpu_scn_profile.py workload seed:index [seed:index ...]"""
 import ctypes, sys, pathlib
 import numpy as np
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 import bench
 from dgsqp_amd.montecarlo import sample_scenarios
 from dgsqp_amd.solver import DGSQP

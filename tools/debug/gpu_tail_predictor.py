@@ -2,7 +2,7 @@
 counts (+ the warm-start trajectory's closest approach) so that a cheap cost proxy for longest-first ticket order can be studied."""
 import sys, pathlib
 import numpy as np
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 import bench
 from dgsqp_amd.montecarlo import sample_scenarios
 from dgsqp_amd.solver import DGSQP

@@ -1,9 +1,9 @@
 """Development aid (GPU box, -DDG_PROF library): what is the tail of a launch made of?  Solves batch j of bench.py's own sampling,
 lists the slowest scenarios by cycles and prints the per-phase cycles of each of them solved alone.
-usage: DGSQP_HIP_LIB=dgsqp_amd/csrc/libdgsqp_hip_prof.so python tools/gpu_tail_profile.py [workload] [batch index] [top]"""
+usage: DGSQP_HIP_LIB=dgsqp_amd/csrc/libdgsqp_hip_prof.so python tools/debug/gpu_tail_profile.py [workload] [batch index] [top]"""
 import ctypes, sys, pathlib
 import numpy as np
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 import bench
 from dgsqp_amd.montecarlo import sample_scenarios
 from dgsqp_amd.solver import DGSQP

@@ -2,7 +2,7 @@
 usage: gpu_trace_diff.py <kbcurve0|kbchicane0|barc2|ablation_<nms|ls>_<stat_l1|stat>> [B] [N]      (environment: DGSQP_SEED)"""
 import os, sys, pathlib
 import numpy as np
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 from oracle import oracle
 import dgsqp_amd.solver as sv
 from dgsqp_amd import montecarlo as mc

@@ -13,7 +13,7 @@ enum { K_FMA_F64 = 0, K_FMA_F32, K_PK_FMA_F32, K_MUL_F64, K_ADD_F64, K_NKIND };
 static const char* kname[] = {"v_fma_f64", "v_fma_f32", "v_pk_fma_f32", "v_mul_f64", "v_add_f64"};
 static const double kflop[] = {2.0 * 64, 2.0 * 64, 4.0 * 64, 64.0, 64.0};      // flop per wave instruction
 
-template <int KIND, int CH, bool DEP>
+template <int KIND, int CH, bool DEP, int REP = 8>
 __global__ void __launch_bounds__(1024) rate_kernel(long long* out, int iters, double seed) {
   double a[CH];
   float f[CH];
@@ -27,7 +27,8 @@ __global__ void __launch_bounds__(1024) rate_kernel(long long* out, int iters, d
   const long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; it++) {
 #pragma unroll
-    for (int c = 0; c < CH; c++) {
+    for (int cc = 0; cc < CH * REP; cc++) {      // REP x CH instructions per trip: the loop's own scalar instructions stay below 5 % of the stream
+      const int c = cc % CH;
       const int s = DEP ? 0 : c;          // DEP: one dependent chain (latency); otherwise CH independent chains (issue rate)
       if (KIND == K_FMA_F64) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a[s]) : "v"(x), "v"(y));
       if (KIND == K_MUL_F64) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a[s]) : "v"(x));
@@ -46,7 +47,7 @@ __global__ void __launch_bounds__(1024) rate_kernel(long long* out, int iters, d
 template <int KIND, bool DEP>
 static void run(int waves_per_simd, int ncu, long long* d_out, FILE* fo) {
   constexpr int CH = 8;
-  const int iters = 100000 / CH * (DEP ? 1 : 1);
+  const int iters = 102400 / (CH * 8);
   const int block = 64 * 4 * waves_per_simd;
   const int nw = ncu * block / 64;
   hipLaunchKernelGGL((rate_kernel<KIND, CH, DEP>), dim3(ncu), dim3(block), 0, 0, d_out, iters, 1.0);   // warm-up (clocks)
@@ -56,7 +57,7 @@ static void run(int waves_per_simd, int ncu, long long* d_out, FILE* fo) {
   hipMemcpy(h.data(), d_out, sizeof(long long) * (nw + 1), hipMemcpyDeviceToHost);
   std::sort(h.begin() + 1, h.end());
   const double med = (double)h[1 + nw / 2];
-  const double ninstr = (double)iters * CH;
+  const double ninstr = (double)iters * CH * 8;
   const double cyc_per_instr_wave = med / ninstr;                       // one wave's view
   const double cyc_per_instr_simd = cyc_per_instr_wave / waves_per_simd; // the SIMD issues waves_per_simd such streams
   char line[512];
@@ -72,7 +73,7 @@ int main(int argc, char** argv) {
   if (hipGetDeviceProperties(&p, 0) != hipSuccess) { fprintf(stderr, "no HIP device\n"); return 1; }
   FILE* fo = argc > 1 ? fopen(argv[1], "w") : nullptr;
   char head[512];
-  snprintf(head, sizeof head, "%s (%s), %d CUs; one workgroup per CU, 8 chains per thread, 100,000 instructions per wave, s_memtime (shader cycles), median over wavefronts\n",
+  snprintf(head, sizeof head, "%s (%s), %d CUs; one workgroup per CU, 8 chains per thread, 64 instructions per loop trip, 102,400 instructions per wave, s_memtime (shader cycles), median over wavefronts\n",
            p.name, p.gcnArchName, p.multiProcessorCount);
   fputs(head, stdout);
   if (fo) fputs(head, fo);

@@ -34,7 +34,7 @@ np.savez(sys.argv[2], u=r['u'], l=r['l'], status=r['status'], it=r['num_iters'],
 '''
 
 
-def run(cmd, lib, timeout=900):
+def run(cmd, lib, timeout=420):
     env = dict(os.environ, DGSQP_HIP_LIB=str(lib))
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=str(ROOT))
     if out.returncode != 0:
@@ -44,7 +44,7 @@ def run(cmd, lib, timeout=900):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--workloads', nargs='+', default=['kb_chicane_N15', 'dyn_curve_N15'])
+    ap.add_argument('--workloads', nargs='+', default=['kb_chicane_N15', 'dyn_curve_N15', 'dyn_curve_N25'])
     ap.add_argument('--out', default=str(ROOT / 'profiles' / 'r06_n1_two_per_cu.txt'))
     ap.add_argument('--tmp', default='/tmp')
     args = ap.parse_args()

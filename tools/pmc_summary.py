@@ -1,7 +1,8 @@
 """Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, see MI355X_MICROARCH.md) into the JSON
-bench.py reads for roofline.traffic.  usage: pmc_summary.py <fetch_counter_csv> <write_counter_csv> <workload> <batch> <out.json> [qp_method]
-The summary records the fingerprint of the kernel sources it was collected on (bench.source_fingerprint): bench.py refuses it once
-dgsqp_amd/csrc has changed."""
+bench.py reads for roofline.traffic.  usage: pmc_summary.py <fetch_counter_csv> <write_counter_csv> <workload> <batch> <out.json> [qp_method [measured_source_sha256]]
+The summary records the fingerprint of the kernel sources it was MEASURED on -- the value tools/measure_round6.sh wrote on the GPU box
+before its passes (argument 7); a summary is refused here when that value is not the fingerprint of the present tree, and by bench.py
+once dgsqp_amd/csrc has changed.  (Without the argument the present tree's fingerprint is recorded, as rounds 4-5 did.)"""
 import csv, json, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from bench import source_fingerprint
@@ -15,11 +16,14 @@ def per_launch(path, counter):
     return tot / max(n, 1), n
 
 
+measured_sha = sys.argv[7] if len(sys.argv) > 7 else source_fingerprint()
+if measured_sha != source_fingerprint():
+    sys.exit(f'pmc_summary.py: the counters were measured on kernel sources {measured_sha[:12]}..., the tree is at {source_fingerprint()[:12]}...: refused')
 fetch_kb, nf = per_launch(sys.argv[1], 'FETCH_SIZE')
 write_kb, nw = per_launch(sys.argv[2], 'WRITE_SIZE')
 out = {
     'workload': sys.argv[3], 'batch_per_gpu': int(sys.argv[4]), 'kernel': 'dg_solve_kernel', 'qp_method': sys.argv[6] if len(sys.argv) > 6 else 'active_set',
-    'source_sha256': source_fingerprint(),
+    'source_sha256': measured_sha,
     'launches_averaged': [nf, nw],
     'FETCH_SIZE_KB': fetch_kb, 'WRITE_SIZE_KB': write_kb,
     # gfx950 (MI355X_MICROARCH.md, section HBM): FETCH_SIZE tallies 128-B requests at 64 B -- doubled before it is compared with a
