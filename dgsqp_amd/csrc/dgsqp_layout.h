@@ -4,6 +4,7 @@
 //  and the LDS arena of one scenario workgroup.
 #pragma once
 #include <stdint.h>
+#include <algorithm>
 
 #include "../../include/dgsqp.h"
 
@@ -128,6 +129,8 @@ struct DgProb {
   int t2off[DGSQP_MAX_AGENTS];              // offset (doubles) of agent block in the Taylor tensor workspace
   int t2k[DGSQP_MAX_AGENTS];                // per-stage stride of that block = nqa*ndir
   int64_t t2_doubles;
+  int16_t ox_perm[DG_NVARMAX];   // ... its task order: the columns sorted by length (longest first), sixteen to a group
+  int ox_gstart[DG_NVARMAX / 16 + 2];   // ... and where each group's runs start (entries)
   int ox_nya, ox_ngi;   // OSQP on the XL layout, wave-interleaved G' table (dgsqp_osqp_xl.h: ox_build_tables): entries of the per-agent multiplier lists; padded entries of the table
   int64_t wsx_gdI, wsx_tabI;   // ... its values, and its index part (group starts, per-agent list starts, the lists)
   int64_t wsx_Y, wsx_S, wsx_E, wsx_dy, wsx_tab, wsx_gdT;   // OSQP on the XL layout: the polish's Y and Schur complement (n x n each), row scaling and delta y (n_c), the transposed index table of G' w
@@ -176,29 +179,35 @@ static inline std::string dg_build_layout(DgProb& D) {
     D.wsx_tab = D.wsx_dy + nvp;          // uint32: n + 2 column starts, one entry per packed gradient element
     D.wsx_gdT = D.wsx_tab + ((int64_t)D.ngd + D.n + 6) / 2 + 2;      // the packed gradients' values in the table's (transposed) order
     D.ws_doubles = D.wsx_gdT + D.ngd + 2;
-    // the same values once more in WAVE-INTERLEAVED order for the ADMM iteration's G' w (ox_iterate_block): task (column, quarter) = lane
-    // it4 & 63 of group it4 >> 6 (16 neighbouring columns); entry m of that lane at gstart[group] + 64 m + lane, every group padded to its
-    // longest quarter column (a multiple of four entries) -- one 512-byte run per wavefront load instead of 16 cache lines.  The multipliers
-    // come from per-agent lists (agent a: its covering gradients in table order), so the hot loop reads no index at all.
+    // the same values once more in WAVE-INTERLEAVED order for the ADMM iteration's G' w (ox_iterate_block).  The columns are sorted by
+    // length (ox_perm; the lengths are a property of the game) and taken sixteen to a group; task (sorted column s, quarter) = lane
+    // it4 & 63 of group it4 >> 6, it4 = 4 s + quarter; entry m of that lane at ox_gstart[group] + 64 m + lane, every group padded with
+    // zeros to its longest quarter column rounded up to eight entries -- a wavefront load reads ONE 512-byte run where the column-major
+    // table gave it 16 cache lines, and eight of them are in flight per lane.  The multipliers come from per-agent lists (agent a: its
+    // covering gradients in table order), so the hot loop reads no index at all.
     {
       int nya = 0;
       for (int d = 0; d < D.ndense; d++) nya += D.dense[d].kind == 1 ? 2 : 1;
       D.ox_nya = nya;
       const int NG = (4 * D.n + 63) / 64;
+      int cnt[DG_NVARMAX];
+      for (int col = 0; col < D.n; col++) {
+        const int a = col / (D.N * DGSQP_NUA), t = (col % (D.N * DGSQP_NUA)) / DGSQP_NUA;
+        cnt[col] = 0;
+        for (int d = D.stage_dense0[t + 1]; d < D.ndense; d++) cnt[col] += (D.dense[d].a == a) || (D.dense[d].kind == 1 && D.dense[d].b == a);
+        D.ox_perm[col] = (int16_t)col;
+      }
+      std::stable_sort(D.ox_perm, D.ox_perm + D.n, [&](int16_t x, int16_t y) { return cnt[x] > cnt[y]; });
       int tot = 0;
       for (int G = 0; G < NG; G++) {
-        int mx = 0;
-        for (int col = 16 * G; col < 16 * G + 16 && col < D.n; col++) {
-          const int a = col / (D.N * DGSQP_NUA), t = (col % (D.N * DGSQP_NUA)) / DGSQP_NUA;
-          int cnt = 0;
-          for (int d = D.stage_dense0[t + 1]; d < D.ndense; d++) cnt += (D.dense[d].a == a) || (D.dense[d].kind == 1 && D.dense[d].b == a);
-          if (cnt > mx) mx = cnt;
-        }
-        tot += 64 * ((((mx + 3) / 4) + 3) & ~3);
+        const int mx = 16 * G < D.n ? cnt[D.ox_perm[16 * G]] : 0;        // (sorted: the group's first column is its longest)
+        D.ox_gstart[G] = tot;
+        tot += 64 * ((((mx + 3) / 4) + 7) & ~7);
       }
+      D.ox_gstart[NG] = tot;
       D.ox_ngi = tot;
-      D.wsx_tabI = (D.ws_doubles + 1) & ~(int64_t)1;                     // uint32: NG + 1 group starts, M + 1 list starts, nya list entries
-      D.wsx_gdI = D.wsx_tabI + (NG + 1 + DGSQP_MAX_AGENTS + 1 + nya + 3) / 2 + 2;
+      D.wsx_tabI = (D.ws_doubles + 1) & ~(int64_t)1;                     // uint32: M + 1 list starts, nya list entries
+      D.wsx_gdI = D.wsx_tabI + (DGSQP_MAX_AGENTS + 1 + nya + 3) / 2 + 2;
       D.ws_doubles = D.wsx_gdI + tot + 2;
     }
   }

@@ -165,18 +165,19 @@ __device__ inline OxTabs ox_tabs(const Ctx& c) {
   T.gdT = c.ws + D.wsx_gdT;
   return T;
 }
-// The same values in WAVE-INTERLEAVED order, for the ADMM iteration (ox_iterate_block).  Task it4 = 4 col + quarter is lane it4 & 63 of
-// group it4 >> 6 (sixteen neighbouring columns: eight stages of one agent, nearly equal lengths); entry m of a lane -- the column's entry
-// quarter + 4 m -- sits at gstart[group] + 64 m + lane, the group padded with zeros to its longest quarter column rounded up to four
-// entries: a wavefront load reads ONE 512-byte run where the column-major table gave it 16 cache lines.  The multiplier of entry e of
-// column (a, t, j) is element (ybase[a] + cnt_a - cnt_col + e) of the per-agent lists ylist (agent a's covering gradients in table
-// order: a column covers the LAST cnt_col of them) -- gathered once per iteration into LDS, so the loop reads values only, no index.
-struct OxTabI { const glb_u32* gstart; const glb_u32* ybase; const glb_u32* ylist; cgptr gdI; };
+// The same values in WAVE-INTERLEAVED order, for the ADMM iteration (ox_iterate_block).  The columns are taken in the order DgProb.ox_perm
+// (sorted by length, longest first: neighbours in that order have nearly equal lengths), sixteen to a group; task it4 = 4 s + quarter of
+// sorted column s is lane it4 & 63 of group it4 >> 6; entry m of a lane -- the column's entry quarter + 4 m -- sits at
+// ox_gstart[group] + 64 m + lane, the group padded with zeros to its longest quarter column rounded up to eight entries: a wavefront
+// load reads ONE 512-byte run where the column-major table gave it 16 cache lines, eight such loads are in flight per lane.  The
+// multiplier of entry e of column (a, t, j) is element (ybase[a] + cnt_a - cnt_col + e) of the per-agent lists ylist (agent a's covering
+// gradients in table order: a column covers the LAST cnt_col of them) -- gathered once per iteration into LDS, so the loop reads values
+// only, no index.
+struct OxTabI { const glb_u32* ybase; const glb_u32* ylist; cgptr gdI; };
 __device__ inline OxTabI ox_tabi(const Ctx& c) {
   const DgProb& D = dg_prob;
   OxTabI T;
-  T.gstart = (const glb_u32*)(c.ws + D.wsx_tabI);
-  T.ybase = T.gstart + ((4 * D.n + 63) / 64 + 1);
+  T.ybase = (const glb_u32*)(c.ws + D.wsx_tabI);
   T.ylist = T.ybase + (DGSQP_MAX_AGENTS + 1);
   T.gdI = c.ws + D.wsx_gdI;
   return T;
@@ -212,21 +213,11 @@ __device__ __noinline__ void ox_build_tables(const Ctx& c, const OxPtrs& o, GP g
   const int tot = (int)o.tmp[n];
   for (int k = TID; k < tot; k += NT) gT[k] = gd[pt[k] & 0x3fffffu];
   XSYNC();
-  // ---- the wave-interleaved copy (OxTabI)
+  // ---- the wave-interleaved copy (OxTabI): read by ox_iterate_block<GP, true>, n > 176
+  if (n <= 176) return;
   const int NG = (4 * n + 63) / 64;
-  glb_u32* gs = (glb_u32*)(c.ws + D.wsx_tabI);
-  glb_u32* yb = gs + (NG + 1);
+  glb_u32* yb = (glb_u32*)(c.ws + D.wsx_tabI);
   glb_u32* yl = yb + (DGSQP_MAX_AGENTS + 1);
-  if (TID == 0) {
-    unsigned int acc = 0;
-    for (int G = 0; G < NG; G++) {
-      int mx = 0;
-      for (int col = 16 * G; col < 16 * G + 16 && col < n; col++) { const int cn = (int)(cs[col + 1] - cs[col]); mx = cn > mx ? cn : mx; }
-      gs[G] = acc;
-      acc += 64u * (unsigned int)((((mx + 3) >> 2) + 3) & ~3);
-    }
-    gs[NG] = acc;
-  }
   if (TID == 64) {        // per-agent lists: the gradients covering agent a, in table (= increasing gradient) order
     unsigned int acc = 0;
     for (int a = 0; a < D.M; a++) {
@@ -235,14 +226,13 @@ __device__ __noinline__ void ox_build_tables(const Ctx& c, const OxPtrs& o, GP g
     }
     for (int a = D.M; a <= DGSQP_MAX_AGENTS; a++) yb[a] = acc;
   }
-  XSYNC();
   gptr gI = c.ws + D.wsx_gdI;
   for (int G = 0; G < NG; G++) {
-    const int base = (int)gs[G], len = ((int)gs[G + 1] - base) >> 6;
+    const int base = D.ox_gstart[G], len = (D.ox_gstart[G + 1] - base) >> 6;
     for (int e = TID; e < 64 * len; e += NT) {
-      const int m = e >> 6, it4 = 64 * G + (e & 63), col = it4 >> 2, idx = (it4 & 3) + 4 * m;
+      const int m = e >> 6, it4 = 64 * G + (e & 63), sc = it4 >> 2, idx = (it4 & 3) + 4 * m;
       double v = 0.0;
-      if (col < n) { const int k0 = (int)cs[col], cn = (int)cs[col + 1] - k0; if (idx < cn) v = gT[k0 + idx]; }
+      if (sc < n) { const int col = D.ox_perm[sc], k0 = (int)cs[col], cn = (int)cs[col + 1] - k0; if (idx < cn) v = gT[k0 + idx]; }
       gI[base + e] = v;
     }
   }
@@ -554,7 +544,11 @@ __device__ __noinline__ bool ox_build_k(const Ctx& c, double rho, double cc) {
 // the bytes it streams, and K^-1 is most of them: all but 2 of 50 values at n = 150, half of them at n = 200, a sixth at n = 300.  Same
 // products in the same order as ox_m_pass / ox_m_pass_f32 (the register prefix covers whole groups of the unrolled loop): bit-identical.
 #define OX_RC 48
-template <class GP>
+// IL: G' w from the wave-interleaved table (n > 176: BASELINE configs[3], [4]) or, IL = false, from the column-major one (the packed-matrix
+// layouts up to n = 176: there all but two values of each thread's K^-1 slice sit in registers, the phase is short, and the interleaved
+// loop's extra live registers cost the K^-1 product more than the table gains -- profiles/r06_xl_admm_iteration.txt).  Two instantiations,
+// two register allocations.
+template <class GP, bool IL>
 __device__ __noinline__ void ox_iterate_block(const Ctx& c, GP gd, double rho, double cc, int count) {
   const DgProb& D = dg_prob;
   const int n = D.n, nc = D.nc;
@@ -578,8 +572,9 @@ __device__ __noinline__ void ox_iterate_block(const Ctx& c, GP gd, double rho, d
   int rr[GR][6];
 #pragma unroll
   for (int g = 0; g < GR; g++) {
-    const int it4 = TID + g * NT, col = it4 >> 2;
+    const int it4 = TID + g * NT;
     const bool lead = it4 < 4 * n && (it4 & 3) == 0;
+    const int col = lead ? (IL ? (int)D.ox_perm[it4 >> 2] : it4 >> 2) : 0;           // (IL: tasks run over the columns in the wave-interleaved table's order, sorted by length)
     const int a = lead ? col / (D.N * DGSQP_NUA) : 0, rem = lead ? col % (D.N * DGSQP_NUA) : 0, t = rem / DGSQP_NUA, j = rem % DGSQP_NUA;
     const bool nxt = lead && t + 1 < D.N;
     rr[g][0] = lead ? D.r_in_ub[a][t][j] : -1; rr[g][1] = lead ? D.r_in_lb[a][t][j] : -1;
@@ -590,30 +585,35 @@ __device__ __noinline__ void ox_iterate_block(const Ctx& c, GP gd, double rho, d
   // entries are its own and where its multipliers start in the per-agent lists; per thread, the gradients whose multipliers it gathers
   const OxTabI TI = ox_tabi(c);
   const int NGI = (4 * n + 63) / 64;
-  int gbase[GR], glen[GR], gcnt[GR], gyo[GR];
+  int gbase[GR], glen[GR], gcnt[GR], gyo[GR], gcol[GR];
 #pragma unroll
   for (int g = 0; g < GR; g++) {
-    const int it4 = TID + g * NT, G = it4 >> 6, col = it4 >> 2, part = it4 & 3;
-    const bool in = G < NGI, has = col < n;
-    gbase[g] = in ? (int)TI.gstart[G] : 0;
-    glen[g] = in ? ((int)TI.gstart[G + 1] - gbase[g]) >> 6 : 0;
+    const int it4 = TID + g * NT, G = it4 >> 6, sc = it4 >> 2, part = it4 & 3;
+    const bool in = IL && G < NGI, has = IL && sc < n;
+    const int col = has ? D.ox_perm[sc] : 0;
+    gcol[g] = has && part == 0 ? col : -1;
+    gbase[g] = in ? D.ox_gstart[G] : 0;
+    glen[g] = in ? (D.ox_gstart[G + 1] - gbase[g]) >> 6 : 0;
     const int cn = has ? (int)(T.cstart[col + 1] - T.cstart[col]) : 0;
     gcnt[g] = cn > part ? (cn - part + 3) >> 2 : 0;
     const int a = has ? col / (D.N * DGSQP_NUA) : 0;
     gyo[g] = has ? (int)TI.ybase[a + 1] - cn + part : 0;      // ybase[a] + cnt_a - cnt_col + quarter
   }
+  // (measured, profiles/r06_xl_admm_iteration.txt: with the group starts as scalar loads inside the loop and the list re-read per iteration
+  // the phase is 36 kcycles at n = 300 instead of 22 k -- these few registers are worth it)
   constexpr int YR = (2 * DG_NDMAX + NT - 1) / NT;
   int yld[YR];
 #pragma unroll
-  for (int g = 0; g < YR; g++) yld[g] = TID + g * NT < D.ox_nya ? (int)TI.ylist[TID + g * NT] : -1;
+  for (int g = 0; g < YR; g++) yld[g] = IL && TID + g * NT < D.ox_nya ? (int)TI.ylist[TID + g * NT] : -1;
   for (int rep = 0; rep < count; rep++) {
     PROF_BEGIN(pa1);
+    if constexpr (IL)
     {                                                       // G' w as ox_gt_mul forms it (w already carries E), the row indices from registers,
       lptr ya = o.dpart;                                    // the gradient values from the wave-interleaved table (same entries, same order of the sums)
       clptr w = o.w;
       __syncthreads();
 #pragma unroll
-      for (int g = 0; g < YR; g++) {
+      for (int g = 0; g < YR; g++) {                        // the multipliers in per-agent list order
         if (yld[g] >= 0) { const DgDense dd = ld_dense(yld[g]); ya[TID + g * NT] = (dd.r_pos >= 0 ? w[dd.r_pos] : 0.0) - (dd.r_neg >= 0 ? w[dd.r_neg] : 0.0); }
       }
       __syncthreads();
@@ -630,21 +630,67 @@ __device__ __noinline__ void ox_iterate_block(const Ctx& c, GP gd, double rho, d
           if (rr[g][5] >= 0) s2 += w[rr[g][5]];
           cgptr gp = TI.gdI + gbase[g] + (it4 & 63);
           const int cnt = gcnt[g], nfull = cnt & ~3, yo = gyo[g];
-          for (int m = 0; m < glen[g]; m += 4) {            // glen: a multiple of four; lanes past their own count add nothing
-            const double g0 = gp[64 * m], g1 = gp[64 * (m + 1)], g2 = gp[64 * (m + 2)], g3 = gp[64 * (m + 3)];
-            const double y0 = ya[m < cnt ? yo + 4 * m : 0], y1 = ya[m + 1 < cnt ? yo + 4 * (m + 1) : 0], y2 = ya[m + 2 < cnt ? yo + 4 * (m + 2) : 0], y3 = ya[m + 3 < cnt ? yo + 4 * (m + 3) : 0];
-            if (m + 3 < nfull) {                            // a full quad of this lane: the four accumulators, as the column-major loop
-              s0 = __builtin_fma(y0, g0, s0); s1 = __builtin_fma(y1, g1, s1); s2 = __builtin_fma(y2, g2, s2); s3 = __builtin_fma(y3, g3, s3);
-            } else {                                        // its last, partial quad: everything into s0, in order
-              if (m < cnt) s0 = __builtin_fma(y0, g0, s0);
-              if (m + 1 < cnt) s0 = __builtin_fma(y1, g1, s0);
-              if (m + 2 < cnt) s0 = __builtin_fma(y2, g2, s0);
+          for (int m = 0; m < glen[g]; m += 8) {            // glen: a multiple of eight; eight 512-byte runs in flight per wavefront
+            double gv[8], yv[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) gv[j] = gp[64 * (m + j)];
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const bool v = m + j < cnt; const double y = ya[v ? yo + 4 * (m + j) : 0]; yv[j] = v ? y : 0.0; }
+            // same sums in the same order as the column-major loop: entries below nfull (whole quads of this lane) go to accumulator
+            // (entry & 3), the last one to three to s0 in order; entries past the lane's count are zero times zero
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              if ((j & 3) == 0) s0 = __builtin_fma(yv[j], gv[j], s0);
+              else {
+                const bool tl = m + j >= nfull;
+                double& sk = (j & 3) == 1 ? s1 : ((j & 3) == 2 ? s2 : s3);
+                const double r = __builtin_fma(yv[j], gv[j], tl ? s0 : sk);
+                s0 = tl ? r : s0; sk = tl ? sk : r;
+              }
             }
           }
           double sm = (s0 + s1) + (s2 + s3);
           sm += dpp_f64<0xB1>(sm);
           sm += dpp_f64<0x4E>(sm);
-          if ((it4 & 3) == 0 && it4 < 4 * n) o.xt[it4 >> 2] = sm;
+          if (gcol[g] >= 0) o.xt[gcol[g]] = sm;
+        }
+      }
+      __syncthreads();
+    }
+    else
+    {                                                       // G' w as ox_gt_mul forms it (w already carries E), the row indices from registers
+      lptr yd = o.ddx;
+      clptr w = o.w;
+      __syncthreads();
+      for (int d = TID; d < D.ndense; d += NT) {
+        const DgDense dd = ld_dense(d);
+        yd[d] = (dd.r_pos >= 0 ? w[dd.r_pos] : 0.0) - (dd.r_neg >= 0 ? w[dd.r_neg] : 0.0);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int g = 0; g < GR; g++) {
+        const int it4 = TID + g * NT;
+        if (it4 < 4 * n) {
+          const int col = it4 >> 2, part = it4 & 3;
+          double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+          if (rr[g][0] >= 0) s0 += w[rr[g][0]];
+          if (rr[g][1] >= 0) s0 -= w[rr[g][1]];
+          if (rr[g][2] >= 0) s1 += w[rr[g][2]];
+          if (rr[g][3] >= 0) s1 -= w[rr[g][3]];
+          if (rr[g][4] >= 0) s2 -= w[rr[g][4]];
+          if (rr[g][5] >= 0) s2 += w[rr[g][5]];
+          const int k1 = (int)T.cstart[col + 1];
+          int k = (int)T.cstart[col] + part;
+          for (; k + 12 < k1; k += 16) {
+            const unsigned int pa = T.pairT[k], pb = T.pairT[k + 4], pc = T.pairT[k + 8], pd = T.pairT[k + 12];
+            const double ga = T.gdT[k], gb = T.gdT[k + 4], gc = T.gdT[k + 8], gg = T.gdT[k + 12];
+            s0 = __builtin_fma(yd[pa >> 22], ga, s0); s1 = __builtin_fma(yd[pb >> 22], gb, s1); s2 = __builtin_fma(yd[pc >> 22], gc, s2); s3 = __builtin_fma(yd[pd >> 22], gg, s3);
+          }
+          for (; k < k1; k += 4) { const unsigned int pa = T.pairT[k]; s0 = __builtin_fma(yd[pa >> 22], T.gdT[k], s0); }
+          double sm = (s0 + s1) + (s2 + s3);
+          sm += dpp_f64<0xB1>(sm);
+          sm += dpp_f64<0x4E>(sm);
+          if (part == 0) o.xt[col] = sm;
         }
       }
       __syncthreads();
@@ -1029,7 +1075,7 @@ __device__ __noinline__ int dev_qp_osqp_xl_t(const Ctx& c, GP gd) {
       for (int r = TID; r < nc; r += NT) o.w[r] = o.E[r] * (rho * o.z[r] - o.y[r]);
       __syncthreads();
     }
-    ox_iterate_block<GP>(c, gd, rho, cc, check_every);
+    if (n <= 176) ox_iterate_block<GP, false>(c, gd, rho, cc, check_every); else ox_iterate_block<GP, true>(c, gd, rho, cc, check_every);
     iters = it;
     ox_check<GP>(c, gd, cc, it == max_iter);
     pri_res = o.scal[DG_OSQP_CHK]; dua_res = o.scal[DG_OSQP_CHK + 1]; eps_p = o.scal[DG_OSQP_CHK + 2]; eps_d = o.scal[DG_OSQP_CHK + 3];
