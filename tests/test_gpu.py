@@ -2038,6 +2038,61 @@ def test_monte_carlo_example_script(tmp_path):
             assert max(np.abs(r['solve_info']['iter_data'][0]['u_sol'] - ref['u'][b]).max() for b, r in enumerate(recs)) < 1e-6
 
 
+@pytest.mark.parametrize('name', ['kb_chicane_N15', 'dyn_curve_N15', 'kb_curve_N10'])
+def test_two_workgroups_per_cu_build_matches_the_golden_fixtures(name, tmp_path):
+    """Row N1: libdgsqp_hip_b256.so -- the same sources with 256-thread workgroups and half the LDS arena, TWO workgroups per CU -- on the
+    golden fixtures of the n <= 60 games, in a process of its own (DGSQP_HIP_LIB): the launch really runs 256-thread blocks on a grid
+    of two per CU, and the solves meet the same bar as the product build's (test_solve_matches_golden_fixtures: identical control flow on
+    >= 95 % of the oracle-stable scenarios, iterates within 1e-5).  A game it cannot hold (XL layout) is refused loudly."""
+    import json
+    import pathlib
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    so = root / 'dgsqp_amd' / 'csrc' / 'libdgsqp_hip_b256.so'
+    assert so.exists(), 'build it: python dgsqp_amd/csrc/build.py'
+    code = f"""
+import ctypes as C, json, sys, warnings
+import numpy as np
+warnings.simplefilter('ignore')
+sys.path.insert(0, {str(root)!r})
+from dgsqp_amd import _ffi, montecarlo as mc
+from dgsqp_amd.solver import DGSQP
+g = {{'kb_chicane_N15': lambda: mc.kinematic_racing_game('chicane', N=15), 'kb_curve_N10': lambda: mc.kinematic_racing_game('curve', N=10),
+     'dyn_curve_N15': lambda: mc.dynamic_racing_game(N=15, rk4_substeps=4, game_def='curve')}}[{name!r}]()      # (the games of conftest.games)
+s = DGSQP(*g.solver_args(), print_method=None, lsqr_tol=1e-13)
+gold = np.load({str(GOLD / (name + '.npz'))!r})
+res = s.solve_batch(gold['x0'], gold['u_ws'])
+tm = _ffi.TimingT()
+x0, u = mc.sample_scenarios(g, 2048, seed=3)
+assert s._lib.dgsqp_stage_inputs(s._h, 2048, _ffi.dptr(np.ascontiguousarray(x0)), _ffi.dptr(np.ascontiguousarray(s._to_agent_major(u)))) == 0
+assert s._lib.dgsqp_solve_staged(s._h, C.byref(tm)) == 0
+info = C.create_string_buffer(256); s._lib.dgsqp_backend_info(info, 256)
+cus = int(info.value.decode().split('CUs=')[1].split()[0])
+try:
+    DGSQP(*mc.kinematic_racing_game('curve', N=25, M=3).solver_args(), print_method=None)
+    refused = ''
+except Exception as e:
+    refused = str(e)
+np.savez({str(tmp_path / 'out.npz')!r}, **{{k: res[k] for k in ('u', 'l', 'status', 'num_iters', 'qp_solves', 'cost')}})
+print(json.dumps(dict(block=int(tm.block), grid=int(tm.grid), cus=cus, lds=int(s.dims.lds_bytes), layout=int(s.dims.layout), refused=refused)))
+"""
+    import os
+    run = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, DGSQP_HIP_LIB=str(so)), capture_output=True, text=True, timeout=900, cwd=str(root))
+    assert run.returncode == 0, run.stderr[-2000:]
+    d = json.loads(run.stdout.strip().splitlines()[-1])
+    assert d['block'] == 256 and d['grid'] == 2 * d['cus'] and d['lds'] <= (163840 - 512) // 2 and d['layout'] == 0, d
+    assert '(-4)' in d['refused'] and ('LDS' in d['refused'] or 'DG_BLOCK = 256' in d['refused']), d['refused']      # DGSQP_E_TOO_LARGE: half the arena, or a layout this build does not hold
+    gold = np.load(GOLD / f'{name}.npz')
+    res = dict(np.load(tmp_path / 'out.npz'))
+    same = assert_control_flow_parity(res, gold, gold['stable'], name + ' (two workgroups per CU)', min_stable_same=0.95, max_conv_gap=0.05)
+    assert same.mean() >= 0.85
+    for b in np.where(same & (gold['status'] <= 1))[0]:
+        assert rel(res['u'][b], gold['u'][b]) < 1e-5, b
+        if gold['status'][b] == 0:
+            assert rel(res['l'][b], gold['l'][b]) < 1e-5, b
+
+
 @pytest.mark.parametrize('script', ['chicane', 'comp', 'merge', 'agents', 'ablation'])
 def test_monte_carlo_example_drivers(tmp_path, script):
     """examples/monte_carlo_{chicane,comp,merge,agents,ablation}.py -- the DG-SQP legs of scripts/DGSQP_ALGAMES_monte_carlo_chicane.py

@@ -115,6 +115,37 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
 
 
+def test_half_arena_build_exports_and_plans():
+    """libdgsqp_hip_b256.so (-DDG_BLOCK=256: two 256-thread workgroups per CU, row N1) is built next to the product, exports the same C-ABI,
+    and plans its games against HALF the LDS arena: the n = 60 games stay LDS-resident, configs[1] (n = 100) only fits as the big layout with
+    the packed gradients in the scratch as well (measured 0.5-0.86 x the product build: profiles/r06_n1_two_per_cu.txt), an n = 100 game with
+    525 rows does not fit at all (own process each: the library is chosen at load time, DGSQP_HIP_LIB)."""
+    from dgsqp_amd import _ffi
+    from dgsqp_amd.csrc.build import OUT_B256, build
+    build()
+    assert OUT_B256.exists()
+    lib = ctypes.CDLL(str(OUT_B256))
+    for name in _ffi.EXPORTED_SYMBOLS:
+        assert hasattr(lib, name), name
+    code = ("import sys, warnings; warnings.simplefilter('ignore'); sys.path.insert(0, %r)\n"
+            "import bench\nfrom dgsqp_amd.solver import plan, build_problem, build_params\n"
+            "for w in ('kb_chicane_N15', 'dyn_curve_N15', 'dyn_curve_N25', 'kb_chicane_N25'):\n"
+            "    g = bench.make_game(w)\n"
+            "    try:\n        d = plan(build_problem(*g.solver_args()), build_params(g.params, qp_method='active_set')); print(w, d['lds_bytes'], d['layout'])\n"
+            "    except ValueError as e:\n        print(w, 'refused', 'LDS' in str(e))\n") % str(ROOT)
+    out = {}
+    for tag, so in (('b512', ROOT / 'dgsqp_amd' / 'csrc' / 'libdgsqp_hip.so'), ('b256', OUT_B256)):
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, DGSQP_HIP_LIB=str(so)), capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-1500:]
+        out[tag] = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln.strip()}
+    half = (163840 - 512) // 2
+    assert all(int(out['b512'][w][0]) <= 163840 - 512 and out['b512'][w][1] == '0' for w in out['b512'])          # the product: all four LDS-resident
+    assert int(out['b256']['kb_chicane_N15'][0]) <= half and out['b256']['kb_chicane_N15'][1] == '0'
+    assert int(out['b256']['dyn_curve_N15'][0]) <= half and out['b256']['dyn_curve_N15'][1] == '0'
+    assert int(out['b256']['dyn_curve_N25'][0]) <= half and out['b256']['dyn_curve_N25'][1] == '1'                  # big layout (+ gradients in the scratch)
+    assert out['b256']['kb_chicane_N25'] == ['refused', 'True']
+
+
 def test_struct_layouts_match_the_header():
     """ctypes mirrors and the C structs agree in size (checked by compiling a tiny C program)."""
     from dgsqp_amd import _ffi
