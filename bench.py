@@ -89,14 +89,15 @@ def algorithmic_bytes_per_solve(d):
 
 FC_COST = {0: 1.0, 1: 3.0, 2: 0.3}          # jet cost of f_c relative to the kinematic bicycle's (dynamic bicycle: 314 instructions against ~100; unicycle ~30)
 STAGES = {0: 1, 1: 4, 2: 3, 3: 2}           # f_c evaluations per substep: euler, rk4, rk3, rk2 (dynamics_models.py:88-125)
-K_ADMM = 250                                # ADMM iterations per OSQP call in the flop model (measured mean on configs[1]: 270, profiles/r04_phase_cycles_*_qp_osqp.txt)
+K_ADMM = 250                                # ADMM iterations per OSQP call in the flop model WHEN the run did not count them (the timed region's own mean, dgsqp_osqp_counters, replaces it: 270 on configs[1], 3,400 on the six-car merge at reg = 0)
 
 
-def algorithmic_flops_per_solve(d, P, mean_qp_solves, qp_method):
+def algorithmic_flops_per_solve(d, P, mean_qp_solves, qp_method, k_admm=None):
     """SURVEY.md section 8(d), the compute roof: per QP solve  F_eval + F_eig + F_qp  with
         F_eval = M [N 6 n_q^3 + 2 n_q n_u N^2 n_q] + N C_AD,   C_AD = M x 3,000 x (f_c cost relative to the kinematic bicycle) x (f_c evaluations per step)
         F_eig  = 9 n^3
-        F_qp   = 2 n^2 n_act + n^3 / 3 + k_admm (4 n n_dense + 2 n^2),   n_act = n / 4 active rows; k_admm = 0 for the exact active-set QP, 250 for OSQP
+        F_qp   = 2 n^2 n_act + n^3 / 3 + k_admm (4 n n_dense + 2 n^2),   n_act = n / 4 active rows; k_admm = 0 for the exact active-set QP; for OSQP the
+                 MEASURED mean ADMM iterations per QP of the timed region (dgsqp_osqp_counters), 250 when no count is at hand
     times the mean number of QP solves per scenario (every QP solve follows one evaluation with Hessian; the Hessian-free trial
     evaluations of the line searches are not counted).  The survey's constants are ranges (C_AD 2-4 k, F_qp 1e7-1e8 at n = 100); the
     ones used are stated here so that anybody can recompute the figure from the JSON line."""
@@ -107,8 +108,10 @@ def algorithmic_flops_per_solve(d, P, mean_qp_solves, qp_method):
     c_ad = M * 3000.0 * FC_COST[model] * stages
     f_eval = M * (N * 6.0 * n_q ** 3 + 2.0 * n_q * n_u * N ** 2 * n_q) + N * c_ad
     f_eig = 9.0 * n ** 3
-    f_qp = 2.0 * n ** 2 * (n / 4.0) + n ** 3 / 3.0 + (K_ADMM * (4.0 * n * n_dense + 2.0 * n ** 2) if qp_method == 'osqp' else 0.0)
-    return dict(per_qp_solve=dict(F_eval=f_eval, F_eig=f_eig, F_qp=f_qp), qp_solves_per_scenario=mean_qp_solves,
+    k = (K_ADMM if k_admm is None else float(k_admm)) if qp_method == 'osqp' else 0.0
+    f_qp = 2.0 * n ** 2 * (n / 4.0) + n ** 3 / 3.0 + k * (4.0 * n * n_dense + 2.0 * n ** 2)
+    return dict(per_qp_solve=dict(F_eval=f_eval, F_eig=f_eig, F_qp=f_qp), qp_solves_per_scenario=mean_qp_solves, admm_iterations_per_qp=k if qp_method == 'osqp' else None,
+                admm_iterations_source=None if qp_method != 'osqp' else ('counted over the timed region (dgsqp_osqp_counters)' if k_admm is not None else 'assumed'),
                 flop_per_solve=mean_qp_solves * (f_eval + f_eig + f_qp))
 
 
@@ -366,7 +369,15 @@ def _run_workload(args, rank, local_rank, world, held):
         return elapsed, kernel_ms, last
 
     # ---- the timed region of the contract: exactly K steps, fences on both sides, max over ranks
+    if args.qp == 'osqp':
+        fence()
+        lib.dgsqp_osqp_counters(handles[0], None, 1)          # (QP calls, ADMM iterations) of this device from here on
     elapsed, kernel_ms_pipe, last = run_steps(args.steps, P, max(1, args.group))
+    k_admm = None
+    if args.qp == 'osqp':
+        cnt = (C.c_uint64 * 2)()
+        if lib.dgsqp_osqp_counters(handles[0], cnt, 0) == 0 and cnt[0] > 0:
+            k_admm = cnt[1] / cnt[0]
     elapsed_per_rank = run_steps.per_rank
     value = B_total * args.steps / elapsed
     # the single stats gather: the records of one step (batch 0, solved by handle 0, which owns the communicator)
@@ -453,7 +464,7 @@ def _run_workload(args, rank, local_rank, world, held):
         achieved = bytes_per_launch / (timed_ms * 1e-3) / 1e9
         achieved_single = algorithmic_bytes_per_solve(d) * B / (kms * 1e-3) / 1e9
         summ = summarize(stats)
-        flops = algorithmic_flops_per_solve(d, solver._problem, float(summ['mean_qp_solves_all']), args.qp)
+        flops = algorithmic_flops_per_solve(d, solver._problem, float(summ['mean_qp_solves_all']), args.qp, k_admm)
         line = {
             'metric': 'Monte-Carlo scenarios/sec (SQP solves/sec), 2-agent N=25' if args.workload.startswith(('dyn_curve_N25', 'kb_curve_N25', 'kb_chicane_N25'))
                       else 'Monte-Carlo scenarios/sec (SQP solves/sec)', 'value': value, 'unit': 'scenarios/s',

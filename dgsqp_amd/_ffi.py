@@ -170,6 +170,8 @@ def load_library() -> C.CDLL:
     lib.dgsqp_set_cooperative.restype = C.c_int
     lib.dgsqp_coop_stats.argtypes = [H, C.POINTER(C.c_uint64)]
     lib.dgsqp_coop_stats.restype = C.c_int
+    lib.dgsqp_osqp_counters.argtypes = [H, C.POINTER(C.c_uint64), C.c_int]
+    lib.dgsqp_osqp_counters.restype = C.c_int
     lib.dgsqp_set_deferral.argtypes = [H, C.c_int32, C.c_double]
     lib.dgsqp_set_deferral.restype = C.c_int
     lib.dgsqp_reserve_deferral.argtypes = [H, C.c_int64]
@@ -204,7 +206,7 @@ EXPORTED_SYMBOLS = ['dgsqp_create', 'dgsqp_destroy', 'dgsqp_dims', 'dgsqp_plan',
                     'dgsqp_pid_warm_start_batch', 'dgsqp_launch_staged', 'dgsqp_wait', 'dgsqp_draining',
                     'dgsqp_set_iterate_log', 'dgsqp_fetch_iterate_log', 'dgsqp_synchronize', 'dgsqp_finished', 'dgsqp_launch_staged_group', 'dgsqp_solve_batch_f32', 'dgsqp_comm_unique_id', 'dgsqp_comm_init',
                     'dgsqp_comm_destroy', 'dgsqp_gather_stats', 'dgsqp_comm_barrier', 'dgsqp_comm_allreduce_max',
-                    'dgsqp_set_cooperative', 'dgsqp_coop_stats', 'dgsqp_sample_batch', 'dgsqp_set_deferral', 'dgsqp_reserve_deferral', 'dgsqp_deferral_stats', 'dgsqp_deferral_log']
+                    'dgsqp_set_cooperative', 'dgsqp_coop_stats', 'dgsqp_osqp_counters', 'dgsqp_sample_batch', 'dgsqp_set_deferral', 'dgsqp_reserve_deferral', 'dgsqp_deferral_stats', 'dgsqp_deferral_log']
 
 
 def dptr(a):

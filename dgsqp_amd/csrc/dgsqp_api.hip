@@ -798,6 +798,22 @@ int dgsqp_coop_stats(dgsqp_handle_t h, uint64_t* out4 /* six values */) {
   return DGSQP_OK;
 }
 
+int dgsqp_osqp_counters(dgsqp_handle_t h, uint64_t* out2, int reset) {
+  if (!h) return DGSQP_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  { const int rc = wait_idle(h); if (rc) return rc; }
+  if (out2) {
+    unsigned long long v[2] = {0ull, 0ull};
+    HIPCHK(h, hipMemcpyFromSymbol(v, HIP_SYMBOL(dg_osqp_count), sizeof v));
+    out2[0] = v[0]; out2[1] = v[1];
+  }
+  if (reset) {
+    const unsigned long long z[2] = {0ull, 0ull};
+    HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(dg_osqp_count), z, sizeof z));
+  }
+  return DGSQP_OK;
+}
+
 int dgsqp_fetch_results(dgsqp_handle_t h, double* u_out, double* l_out, double* x_out, int32_t* status, int32_t* iters,
                         int32_t* qp_solves, double* cond, double* cost) {
   if (!h) return DGSQP_E_ARG;

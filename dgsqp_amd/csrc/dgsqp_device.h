@@ -187,6 +187,10 @@ __device__ inline void dev_tr(const Ctx& c, int code, double v) {
   }
 }
 
+// qp_method OSQP: QP calls and ADMM iterations since the last reset (dgsqp_osqp_counters): the measured mean iteration count behind
+// bench.py's flop model (always on: two atomics per QP)
+__device__ unsigned long long dg_osqp_count[2];
+
 // Diagnostic build only (-DDG_PROF): per-phase cycle counters accumulated by thread 0 of every workgroup
 // into a global array; the production library compiles these to nothing.
 enum { PH_ROLLOUT = 0, PH_DERIV1, PH_DERIV2, PH_CHAINS, PH_DP, PH_JACOBI, PH_PFORM, PH_QP, PH_MERIT, PH_LSQR, PH_QTMUL, PH_SWEEP, PH_WGTOTAL, PH_WGMAX, PH_Q_SCAN, PH_Q_Y, PH_Q_DIR, PH_Q_STEP, PH_Q_UPD, PH_Q_REFINE, PH_Q_WARM, PH_W_BUILD, PH_W_MULT, PH_W_X, PH_E_TRI, PH_E_BIS, PH_E_VEC, PH_E_BACK, PH_E_KNEG, PH_C_NPREV, PH_C_MBUILD, PH_C_MWARM, PH_C_MFINAL, PH_C_TRIALS, PH_H_INJ, PH_H_COST, PH_H_CONTR, PH_H_ROWS, PH_O_SCALE, PH_O_W, PH_O_KINV, PH_O_ADMM, PH_O_ITERS, PH_O_CHECK, PH_O_PINV, PH_O_PROWS, PH_O_PSOLVE, PH_O_NACT, PH_O_GT, PH_O_PMUL, PH_O_GS, PH_O_UPD, PH_T_COL, PH_T_MV, PH_T_W, PH_T_UPD, PH_QW_BLK, PH_QW_SEQ, PH_QW_FIN, PH_QW_NPREV, PH_QW_DROPS, PH_PD_TRY, PH_COUNT };

@@ -981,6 +981,7 @@ __device__ __noinline__ int dev_qp_osqp_t(const Ctx& c) {
   __syncthreads();
   if (TID == 0) {
     o.scal[DG_OSQP_INFO] = (double)status; o.scal[DG_OSQP_INFO + 1] = (double)iters; o.scal[DG_OSQP_INFO + 2] = (double)polished; o.scal[DG_OSQP_INFO + 3] = rho;
+    atomicAdd(&dg_osqp_count[0], 1ULL); atomicAdd(&dg_osqp_count[1], (unsigned long long)iters);
     if (D.par.osqp_rho_carry) o.scal[DG_OSQP_RHO] = rho;
     o.scal[DG_OSQP_INFO + 4] = (double)rho_updates; o.scal[DG_OSQP_INFO + 5] = (double)na; o.scal[DG_OSQP_INFO + 6] = pri_res; o.scal[DG_OSQP_INFO + 7] = dua_res;
   }

@@ -330,6 +330,10 @@ int dgsqp_set_cooperative(dgsqp_handle_t h, int mode);
    the helper loop (at most coop_helpers of them evaluate trials at any moment, the others sleep), scenarios finished, helpers still registered (0 after the launch), helper values the owners consumed, helper values
    whose bits differed from the owner's own evaluation (verify mode, environment DGSQP_COOP_VERIFY=1; must be 0)}. */
 int dgsqp_coop_stats(dgsqp_handle_t h, uint64_t* out6);
+/* qp_method = DGSQP_QP_OSQP: {QP calls, ADMM iterations} of every solve on h's DEVICE since the last reset (waits for h's launches; callers
+   that want a clean count let the device's other handles finish first).  out2 may be NULL (reset only).  Nothing in the reference: OSQP
+   reports `info.iter` per call; this is the sum bench.py divides to price the ADMM work it measures (mean iterations per QP). */
+int dgsqp_osqp_counters(dgsqp_handle_t h, uint64_t* out2, int reset);
 /* Deferral of long scenarios (cooperative launches; scheduling only, results are bit-identical).  Nothing in a scenario's inputs
    tells how long its solve will run; its own history does.  A scenario still iterating after max(min_iters, factor x the mean
    iteration count of the launch's finished scenarios) SQP iterations is set aside while fresh scenarios remain in the queue -- its

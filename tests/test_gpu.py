@@ -437,6 +437,28 @@ def test_event_trace_parity_with_osqp(oracle, games):
 
 
 @pytest.mark.parametrize('kind', ['kb_chicane_N15', 'curve3_N25_xl'])
+def test_osqp_counters_count_the_qp_calls_of_a_solve(games, kind):
+    """dgsqp_osqp_counters: {QP calls, ADMM iterations} of the device since the last reset -- what bench.py divides to price the ADMM work of
+    its timed region (both OSQP kernels).  Every QP call of a batch is counted (= the sum of the scenarios' qp_solves, plus the calls that
+    ended a solve with qp_fail), the iterations per call lie between one check interval and the limit (25 ... 4,000), and a reset clears both."""
+    import ctypes as C
+    from dgsqp_amd import montecarlo as mc
+    from dgsqp_amd.solver import DGSQP
+    g = games['kb_chicane_N15'][0] if kind == 'kb_chicane_N15' else mc.kinematic_racing_game('curve', N=25, M=3)
+    s = DGSQP(*g.solver_args(), print_method=None, qp_method='osqp')
+    x0, u_tm = mc.sample_scenarios(g, 12 if kind == 'kb_chicane_N15' else 6, seed=23)
+    cnt = (C.c_uint64 * 2)()
+    assert s._lib.dgsqp_osqp_counters(s._h, None, 1) == 0 and s._lib.dgsqp_osqp_counters(s._h, cnt, 0) == 0 and (cnt[0], cnt[1]) == (0, 0)
+    res = s.solve_batch(x0, u_tm)
+    assert s._lib.dgsqp_osqp_counters(s._h, cnt, 1) == 0
+    calls, its = int(cnt[0]), int(cnt[1])
+    nq = int(res['qp_solves'].sum())
+    assert nq <= calls <= nq + int((res['status'] == 4).sum()) and 25 * calls <= its <= 4000 * calls, (calls, its, nq)
+    print(f'{kind}: {calls} OSQP calls, {its / calls:.0f} ADMM iterations per call')
+    assert s._lib.dgsqp_osqp_counters(s._h, cnt, 0) == 0 and (cnt[0], cnt[1]) == (0, 0)
+
+
+@pytest.mark.parametrize('kind', ['kb_chicane_N15', 'curve3_N25_xl'])
 def test_osqp_rho_carry_matches_the_oracle(oracle, games, kind):
     """dgsqp_params_t.osqp_rho_carry (opt-in): an OSQP call starts from the rho the scenario's previous call ended with -- what OSQP does
     inside CasADi's persistent conic plugin (SURVEY.md parity hazard 7) -- on the device (both OSQP kernels) and in the C++ oracle: identical

@@ -629,6 +629,10 @@ def test_bench_flop_model_fingerprint_and_extra_legs(tmp_path, games):
     assert t['F_eig'] == 9e6 and t['F_eval'] == 2 * (25 * 6 * 16 ** 3 + 2 * 16 * 4 * 625 * 16) + 25 * (2 * 3000.0 * 3.0 * 40)      # rk4, M = 10: 40 f_c per step
     assert t['F_qp'] == 2 * 100 ** 2 * 25 + 100 ** 3 / 3 and fm['flop_per_solve'] == 10.0 * sum(t.values())
     assert bench.algorithmic_flops_per_solve(d, P, 10.0, 'osqp')['per_qp_solve']['F_qp'] > t['F_qp']
+    # OSQP: the ADMM term is priced with the MEASURED mean iteration count when the run counted it (dgsqp_osqp_counters), 250 otherwise
+    fo, fm_ = bench.algorithmic_flops_per_solve(d, P, 10.0, 'osqp', 3400.0), bench.algorithmic_flops_per_solve(d, P, 10.0, 'osqp')
+    assert fo['admm_iterations_per_qp'] == 3400.0 and 'counted' in fo['admm_iterations_source'] and fm_['admm_iterations_per_qp'] == 250 and fm_['admm_iterations_source'] == 'assumed'
+    assert abs((fo['per_qp_solve']['F_qp'] - t['F_qp']) / (fm_['per_qp_solve']['F_qp'] - t['F_qp']) - 3400.0 / 250.0) < 1e-12 and fm['admm_iterations_per_qp'] is None
     # fingerprint
     root = tmp_path / 'copy'
     (root / 'dgsqp_amd').mkdir(parents=True)

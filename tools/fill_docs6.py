@@ -1,0 +1,99 @@
+"""Regenerate the measured tables of DESIGN.md section 5 and BASELINE.md section 4 (round 6) from the records under profiles/ (tools/collect_profiles6.sh
+copies them there): the driver command's compact line (r06_bench_driver_steps20_warmup5.json) and its side file with the full records of the headline
+and of every extra leg (r06_bench_workloads.json).  The DESIGN.md table sits between <!-- r06:bench begin --> / <!-- r06:bench end -->; prose is written by hand."""
+import json, pathlib
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+P = ROOT / 'profiles'
+f = lambda v: '—' if v is None else f'{v:,.0f}'
+side = json.load(open(P / 'r06_bench_workloads.json'))
+drv = dict(side['headline'], workloads=side['workloads'])        # the full headline record + one record per leg (a leg that failed / was skipped carries no 'value')
+compact = json.loads([ln for ln in open(P / 'r06_bench_driver_steps20_warmup5.json') if ln.startswith('{')][-1])
+assert abs(compact['value'] - drv['value']) < 1e-6 * drv['value'], 'side file and compact line are not from the same run'
+
+
+def row(label, layout, d, timed_by):
+    sf = d.get('status_fractions')
+    fail = f"{100 * sf['qp_fail']:.1f} % / {100 * sf['max_it']:.1f} %" if sf else '—'
+    r = d['roofline']
+    if 'flop_model' not in r:      # a compact line: the model's flops per solve from achieved TFLOP/s x launch time / solves of the launch
+        r = dict(r, flop_model={'flop_per_solve': r['achieved'] * 1e12 * r['kernel_ms'] * 1e-3 / r['solves_per_launch']})
+    return (f"| {label} | {layout} | **{f(d['value'])}** | {d['config']['batch_per_gpu']:,} x {d['steps']} | {100 * d['converged_fraction']:.1f} % | {fail} | {d['mean_iters']:.1f} / {d['mean_qp_solves']:.1f} | "
+            f"{r['flop_model']['flop_per_solve'] / 1e9:.2f} | {100 * r['frac']:.1f} % | {r['hbm']['frac']:.1e} | {timed_by} |")
+
+
+W = {w['tag']: w for w in drv['workloads'] if 'value' in w}
+rows = ['| workload (fp64) | layout / QP | scen/s (`value`) | batch x steps | converged | `qp_fail` / `max_it` | mean iters (conv.) / QPs | Gflop per solve (§8d model) | fp64 vector roof | HBM roof | timed by |',
+        '|---|---|---|---|---|---|---|---|---|---|---|']
+lab = {'configs[1] (the headline)': ('**configs[1]** 2-agent dynamic bicycle curve N=25, rk4 M=10, reg 1e-3', 'LDS, exact QP'),
+       'configs[1] --qp osqp': ("same game, **`--qp osqp`** (the reference's own QP arithmetic)", 'LDS, OSQP'),
+       'configs[2] B=4096': ('**configs[2]** 3-car BARC circuit N=25 (n = 150), reg 0', 'XL packed, exact QP'),
+       'configs[2] size, solvable game, B=4096': ('3-car curve-track race N=25 (`agents.py`, M = 3): the solvable game of configs[2]\'s size', 'XL packed, exact QP'),
+       'configs[3] B=16384': ('**configs[3]** 2-car F1 track N=50 (n = 200), reg 1e-3', 'XL, exact QP'),
+       'configs[4] B=65536': ('**configs[4]** 6-car merge N=25 (n = 300, 1,587 rows), reg 0', 'XL, exact QP'),
+       'configs[2] --qp osqp, B=4096': ('configs[2], `--qp osqp`', 'XL, OSQP'),
+       'configs[3] --qp osqp, reduced batch B=1024': ('configs[3], `--qp osqp`, reduced batch', 'XL, OSQP'),
+       'configs[4] --qp osqp, reduced batch B=1024': ('configs[4], `--qp osqp`, reduced batch', 'XL, OSQP'),
+       'configs[2] size, solvable game --qp osqp, B=4096': ("the solvable game of configs[2]'s size, `--qp osqp`", 'XL, OSQP'),
+       'configs[2] size, solvable game --qp osqp --mixed-precision, B=4096': ("same, `--mixed-precision` (`K⁻¹` of the ADMM iteration in fp32; §1)", 'XL, OSQP, fp32 operand')}
+for tag, (label, layout) in lab.items():
+    if tag in W:
+        rows.append(row(label, layout, W[tag], 'the driver\'s command (child process of the same run)' if tag != 'configs[1] (the headline)' else 'the driver\'s command'))
+    else:
+        rows.append(f'| {label} | {layout} | not in this run: ' + next((w.get('error') or w.get('skipped') or '?' for w in drv['workloads'] if w['tag'] == tag), 'no such leg') + ' | | | | | | | | |')
+for name, label, layout in (('dyn_curve_N25_steps120', 'configs[1], 120 steps (steady state: 12 batches per launch, 5 launches in flight)', 'LDS, exact QP'),
+                            ('kb_curve_N25', '2-agent KB curve N=25, reg=0 (`curve.py`), 120 steps', 'LDS, classical QP'),
+                            ('kb_curve3_N25_B4096_qp_osqp', '3-car curve-track race N=25, `--qp osqp`', 'XL packed, OSQP'),
+                            ('kb_curve3_N25_B4096_qp_osqp_mixed', 'same, `--mixed-precision`', 'XL packed, OSQP, fp32 operand'),
+                            ('kb_f1_N50_B4096_qp_osqp', 'configs[3], `--qp osqp`, B = 4,096', 'XL, OSQP'),
+                            ('kb_f1_N50_B4096_qp_osqp_mixed', 'configs[3], `--qp osqp --mixed-precision`, B = 4,096', 'XL, OSQP, fp32 operand'),
+                            ('merge6_N25_B4096_qp_osqp', 'configs[4], `--qp osqp`, B = 4,096', 'XL, OSQP')):
+    pth = P / f'r06_bench_{name}.json'
+    if pth.exists():
+        rows.append(row(label, layout, json.loads([ln for ln in open(pth) if ln.startswith('{')][-1]), '`tools/measure_round6.sh`'))
+text = '\n'.join(rows)
+path = ROOT / 'DESIGN.md'
+s = path.read_text()
+a, b = '<!-- r06:bench begin -->', '<!-- r06:bench end -->'
+assert a in s and b in s
+s = s[:s.index(a) + len(a)] + '\n' + text + '\n' + s[s.index(b):]
+path.write_text(s)
+c = drv['cpu_baseline']
+print(text)
+print('headline extras:', drv['value_single_launch'], drv['value_host_inclusive'], drv['value_host_inclusive_grouped'], c['value'], c['cores'], c['value_wall'], c['value_one_core'])
+
+
+# ---- every number from the ONE line of the driver's command
+def baseline_table():
+    d = drv
+    Wd = {w['tag']: w for w in d['workloads']}
+
+    def add(cfg, game, B, tag, note, cpu='—'):
+        w = Wd[tag]
+        if 'value' not in w:
+            return f"| {cfg} | {game} | {B} | {cpu} | not in this run ({(w.get('error') or w.get('skipped') or '')[:60]}) | | | | {note} |"
+        rf = f"{100 * w['roofline']['frac']:.1f} % / {w['roofline']['hbm']['frac']:.1e}"
+        return f"| {cfg} | {game} | {B} | {cpu} | **{f(w['value'])}** | {w['mean_iters']:.1f} | {w['converged_fraction']:.3f} | {rf} | {note} |"
+    cb = d['cpu_baseline']
+    rows = ['| config (BASELINE.json, 0-based) | game here | batch | CPU restatement scen/s | 1 GPU scen/s | mean iters (conv.) | conv. frac | fp64 vector roof (§8d flop model) / HBM roof | notes |',
+            '|---|---|---|---|---|---|---|---|---|',
+            add('1. 2-agent dyn-bicycle curve N=25, B=1024 — exact QP (the headline `value`)', "the reference's own dynamic game (`exact_dynamic_game_dynamic.py`, cost_setting 0) on the curve track, rk4 M=10, DG-SQP v1", '1,024 x 20 steps in ONE cooperative launch', 'configs[1] (the headline)',
+                f"one launch at a time {f(d['value_single_launch'])}; host-inclusive {f(d['value_host_inclusive'])} (one batch) / {f(d['value_host_inclusive_grouped'])} (the twenty batches together); device = oracle on every oracle-stable scenario of the fixture",
+                cpu=f"{cb['value']:.1f} sustained / {cb['value_wall']:.1f} wall ({cb['cores']} threads) / {cb['value_one_core']:.2f} one core"),
+            add('1. same — OSQP (`--qp osqp`)', "same game, `qp_method='osqp'` (`csrc/dgsqp_osqp.h`)", '1,024 x 20', 'configs[1] --qp osqp', 'follows the numpy loop + restated OSQP on 98.6 % of the scenarios that loop itself reproduces (`profiles/r06_osqp_vs_pyref.txt`)'),
+            add('2. 3-agent BARC track N=25, B=4096', '`barc_racing_game(N=25, M=3)` (n = 150, 825 rows, XL layout with packed LDS matrices)', '4,096 in one cooperative launch', 'configs[2] B=4096', "DG-SQP v1 fails on this game — LP-certified infeasible linearisations, 98 % of the numpy + OSQP loop's solves raise (DESIGN.md §2); fp64 (the config names fp32)"),
+            add("2'. the solvable game of that size", '3-car curve-track race (`DGSQP_monte_carlo_agents.py`, M = 3, N = 25)', '4,096', 'configs[2] size, solvable game, B=4096', 'the line to read for n = 150'),
+            add('2. same — OSQP', 'circuit game, `csrc/dgsqp_osqp_xl.h` (round 5)', '4,096', 'configs[2] --qp osqp, B=4096', 'fails like the numpy + OSQP loop (same flag on 64 of 64 scenarios)'),
+            add("2'. same — OSQP", "the solvable three-car game, `qp_method='osqp'`", '4,096', 'configs[2] size, solvable game --qp osqp, B=4096', 'event sequences identical to the oracle with its OSQP on 8 of 8 scenarios'),
+            add("2'. same — OSQP, `--mixed-precision`", "same; the ADMM iteration's `K⁻¹` stored in fp32 (`dgsqp_params_t.mixed_precision`, opt-in)", '4,096', 'configs[2] size, solvable game --qp osqp --mixed-precision, B=4096', 'the mixed-precision line (DESIGN.md §1): same solutions on 20 of 20 solves converged in both; no gain left at n = 150 since the fp64 kernel keeps 48 of a thread\'s 50 `K⁻¹` values in registers (+6 % at n = 200); configs[2] and [4] run at `reg = 0`, where the kernel keeps fp64'),
+            add('3. 2-agent F1 N=50, B=16384', '`f1_racing_game(N=50)`: cubic-spline track on the device (n = 200, 1,050 rows, XL layout)', '16,384 in one cooperative launch', 'configs[3] B=16384', 'converged 49 % here, 53 % C++ oracle, 52 % numpy + OSQP loop (64 scenarios); chaotic game: only statistics are comparable (DESIGN.md §2); fp64, one GPU'),
+            add('3. same — OSQP', "same game, `qp_method='osqp'`", '1,024 (reduced)', 'configs[3] --qp osqp, reduced batch B=1024', '1,150 ADMM iterations per QP'),
+            add('4. 6-agent merge N=25, B=65536', '`merge_game(N=25, M=6)`: n = 300, 1,587 rows, 837 dense gradients (XL layout, tables in constant memory)', '65,536 in one cooperative launch', 'configs[4] B=65536', '32/32 solves identical to the oracle; fp64, one GPU (the config names fp32 and 8 GPUs)'),
+            add('4. same — OSQP', "same game, `qp_method='osqp'`", '1,024 (reduced)', 'configs[4] --qp osqp, reduced batch B=1024', 'identical paths to the numpy + OSQP loop on 62 of 64 scenarios, converged 81.2 % on both; 3,400 ADMM iterations per QP at `reg = 0`')]
+    return '\n'.join(rows)
+
+
+pb = ROOT / 'BASELINE.md'
+sb = pb.read_text()
+i0 = sb.index('| config (BASELINE.json, 0-based) |')
+i1 = sb.index('\n\nBuilder-run, not in the driver')
+pb.write_text(sb[:i0] + baseline_table() + sb[i1:])
