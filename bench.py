@@ -214,7 +214,7 @@ def parse_args(argv=None):
                          "explicit K^-1 is stored in fp32 (fp64 accumulation); everything else stays fp64.  'dtype' of the line then says 'f64 (K^-1 of the ADMM iteration f32)'")
     ap.add_argument('--eig-floor', type=float, default=None, help='_nearestPD floor (default: the literal 1e-10, DGSQP.py:1293)')
     ap.add_argument('--snap-active-bounds', action='store_true', help='implementation knob, see include/dgsqp.h (default: literal)')
-    ap.add_argument('--extras-budget', type=float, default=270.0,
+    ap.add_argument('--extras-budget', type=float, default=300.0,
                     help='seconds since the start of the process by which the extra legs must be over: a leg gets min(its own timeout, what is left), and none is started with less than 15 s left (the legs left out are named in the line)')
     ap.add_argument('--line', choices=('compact', 'full'), default='compact',
                     help='compact: the ONE stdout line holds the contract keys, config, roofline, cpu_baseline and the headline figures in under 4 KB (full records: bench_workloads.json); '
@@ -512,14 +512,15 @@ def _run_workload(args, rank, local_rank, world, held):
             from oracle import oracle            # checker/baseline only: the CPU restatement, NOT CasADi+OSQP
             oracle.build()
             cores = os.cpu_count() or 1
-            # A THROUGHPUT, not the time of the slowest scenario: every thread gets at least 8 scenarios handed out dynamically (default: the
-            # first 512 scenarios of the first batch over 64 threads), every scenario's own wall-clock time on its thread is recorded, and
+            # A THROUGHPUT, not the time of the slowest scenario: every thread gets at least 4 scenarios handed out dynamically (default: the
+            # first 256 scenarios of the first batch over 64 threads), every scenario's own wall-clock time on its thread is recorded, and
             # `value` = threads / mean seconds per scenario -- what those threads sustain over a long Monte-Carlo run.  `value_wall` is the
             # sample over its wall time, idle tail behind the slowest scenario (tens of seconds for one that never converges) included.
-            # (default: 8 scenarios for each of up to 64 threads -- 512 scenarios, 20-40 s; more threads only add contention in the dense oracle:
+            # (default: 4 scenarios for each of up to 64 threads -- 256 scenarios, ~20 s, the contract's "10-30 s of CPU work"; round 5 took 8 per thread, 42 s;
+            # more threads only add contention in the dense oracle:
             # 128 threads on the 256-thread host took 6.4 s per scenario against 0.5 s for one alone, profiles/r04_*)
-            ns = min(args.cpu_sample if args.cpu_sample != 64 else 8 * min(cores, 64), B)
-            nth = max(1, min(cores, 64, ns // 8))
+            ns = min(args.cpu_sample if args.cpu_sample != 64 else 4 * min(cores, 64), B)
+            nth = max(1, min(cores, 64, ns // 4))
             x0, u_am = batches[0]
             t1 = time.perf_counter()
             ob = oracle.solve_batch(solver._problem, solver._cparams, x0[:ns], u_am[:ns], nthreads=nth, timed=True)
@@ -561,12 +562,10 @@ EXTRA_LEGS = (
     # ... and the same games with OSQP's own arithmetic (csrc/dgsqp_osqp_xl.h, round 5) at REDUCED batch sizes: at reg = 0 the restated OSQP
     # runs into its 4,000-iteration limit on most QPs of the merge (3,400 ADMM iterations per QP on average), a solve costs 30 x the exact QP's
     dict(tag='configs[2] size, solvable game --qp osqp, B=4096', workload='kb_curve3_N25', qp='osqp', batch=4096, timeout=60, **_ONE),
-    dict(tag='configs[3] --qp osqp, reduced batch B=1024', workload='kb_f1_N50', qp='osqp', batch=1024, timeout=60, **_ONE),
     dict(tag='configs[4] --qp osqp, reduced batch B=1024', workload='merge6_N25', qp='osqp', batch=1024, timeout=120, **_ONE),
-    dict(tag='configs[2] --qp osqp, B=4096', workload='kb_barc3_N25', qp='osqp', batch=4096, timeout=60, **_ONE),
-    # ... and the solvable game of configs[2]'s size with the opt-in fp32 storage of the ADMM iteration's K^-1
-    # (dgsqp_params_t.mixed_precision; configs[2] and [4] run at reg = 0, where the kernel keeps fp64: include/dgsqp.h)
-    dict(tag='configs[2] size, solvable game --qp osqp --mixed-precision, B=4096', workload='kb_curve3_N25', qp='osqp', mixed_precision=True, batch=4096, timeout=60, **_ONE),
+    dict(tag='configs[3] --qp osqp, reduced batch B=1024', workload='kb_f1_N50', qp='osqp', batch=1024, timeout=60, **_ONE),
+    # (the circuit game with OSQP -- 99 % of its solves fail, as the reference's would -- and the opt-in fp32 storage of the ADMM iteration's K^-1
+    # are timed by tools/measure_round6.sh, not by every default run: profiles/r06_bench_kb_barc3_N25_B4096_qp_osqp.json, ..._qp_osqp_mixed.json)
 )
 RECORD_KEYS = ('value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'config', 'mean_iters', 'mean_iters_all', 'mean_qp_solves', 'converged_fraction',
                'status_fractions', 'roofline', 'value_single_launch', 'value_host_inclusive', 'value_host_inclusive_grouped', 'elapsed_s')
