@@ -38,10 +38,11 @@ lab = {'configs[1] (the headline)': ('**configs[1]** 2-agent dynamic bicycle cur
 for tag, (label, layout) in lab.items():
     if tag in W:
         rows.append(row(label, layout, W[tag], 'the driver\'s command (child process of the same run)' if tag != 'configs[1] (the headline)' else 'the driver\'s command'))
-    else:
-        rows.append(f'| {label} | {layout} | not in this run: ' + next((w.get('error') or w.get('skipped') or '?' for w in drv['workloads'] if w['tag'] == tag), 'no such leg') + ' | | | | | | | | |')
+    elif any(w['tag'] == tag for w in drv['workloads']):       # a leg of this run that failed or was skipped: say so (legs the run does not have are left out)
+        rows.append(f'| {label} | {layout} | not in this run: ' + next((w.get('error') or w.get('skipped') or '?' for w in drv['workloads'] if w['tag'] == tag), '?') + ' | | | | | | | | |')
 for name, label, layout in (('dyn_curve_N25_steps120', 'configs[1], 120 steps (steady state: 12 batches per launch, 5 launches in flight)', 'LDS, exact QP'),
                             ('kb_curve_N25', '2-agent KB curve N=25, reg=0 (`curve.py`), 120 steps', 'LDS, classical QP'),
+                            ('kb_barc3_N25_B4096_qp_osqp', 'configs[2], `--qp osqp`', 'XL packed, OSQP'),
                             ('kb_curve3_N25_B4096_qp_osqp', '3-car curve-track race N=25, `--qp osqp`', 'XL packed, OSQP'),
                             ('kb_curve3_N25_B4096_qp_osqp_mixed', 'same, `--mixed-precision`', 'XL packed, OSQP, fp32 operand'),
                             ('kb_f1_N50_B4096_qp_osqp', 'configs[3], `--qp osqp`, B = 4,096', 'XL, OSQP'),
@@ -66,9 +67,17 @@ print('headline extras:', drv['value_single_launch'], drv['value_host_inclusive'
 def baseline_table():
     d = drv
     Wd = {w['tag']: w for w in d['workloads']}
+    # legs the default run leaves to tools/measure_round6.sh (own bench.py invocations, same box): read from their files
+    for tag, name in (('configs[2] --qp osqp, B=4096', 'kb_barc3_N25_B4096_qp_osqp'),
+                      ('configs[2] size, solvable game --qp osqp --mixed-precision, B=4096', 'kb_curve3_N25_B4096_qp_osqp_mixed')):
+        pth = P / f'r06_bench_{name}.json'
+        if tag not in Wd and pth.exists():
+            Wd[tag] = dict(json.loads([ln for ln in open(pth) if ln.startswith('{')][-1]), separate_run=True)
 
     def add(cfg, game, B, tag, note, cpu='—'):
-        w = Wd[tag]
+        w = Wd.get(tag, {'skipped': 'not measured'})
+        if w.get('separate_run'):
+            note = note + ' — own `bench.py` invocation of `tools/measure_round6.sh`, not a leg of the default run'
         if 'value' not in w:
             return f"| {cfg} | {game} | {B} | {cpu} | not in this run ({(w.get('error') or w.get('skipped') or '')[:60]}) | | | | {note} |"
         rf = f"{100 * w['roofline']['frac']:.1f} % / {w['roofline']['hbm']['frac']:.1e}"
