@@ -736,7 +736,7 @@ def test_event_trace_prefix_parity_against_the_numpy_loop(name):
     (nothing overridden: the reference's own setting) and must produce the same events over the prefix, every value the numpy loop itself
     reproduces to 1e-7 within 1e-5.  OSQP's ADMM stops at multiples of 25 iterations and its polish is accepted on a comparison of
     residuals, so a QP answer can differ by 1e-3 between two correct implementations (the numpy loop reproduces ITSELF
-    on 9 of these 64 solves); the floor is set from the measured count."""
+    on 9 of these 64 solves, and its stable prefixes hold 269 SQP iterations in all); the floor is the measured count (50 of 64) minus four."""
     from dgsqp_amd import montecarlo as mc
     from dgsqp_amd.solver import DGSQP
     fx = np.load(GOLD / f'pyref_osqp_trace_{name}.npz')
@@ -768,7 +768,7 @@ def test_event_trace_prefix_parity_against_the_numpy_loop(name):
     print(f'{name} against the numpy loop + numpy OSQP: stable prefixes hold {int(fx["prefix"].sum())} events / {its} SQP iterations ({int(fx["whole"].sum())} logs stable to their end); '
           f'device qp_method osqp, all defaults: the whole prefix on {int(ok.sum())}/{B} scenarios (+ {int(deep.sum())} leaving inside a line search below alpha = 1e-9), '
           f'{events} events followed, {checked} values compared; departures (scenario, event, prefix, kind): {departures}')
-    assert (ok | deep).sum() >= 0.6 * B
+    assert (ok | deep).sum() >= 46, departures            # measured: 50 of 64 (profiles/r06_gpu_tests_parity_lines.txt); most early departures sit at the first QP's verdict
 
 
 def test_full_size_properties(games):
