@@ -15,13 +15,13 @@ min_it = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 factor = float(sys.argv[5]) if len(sys.argv) > 5 else 2.0
 seed = int(sys.argv[6]) if len(sys.argv) > 6 else 5
 g = bench.make_game(name)
-solvers = [DGSQP(*g.solver_args(), print_method=None) for _ in range(G)]
+solvers = [DGSQP(*g.solver_args(), print_method=None, qp_method=os.environ.get('DGSQP_QP_METHOD', 'active_set')) for _ in range(G)]
 batches = [sample_scenarios(g, B, seed=seed + i) for i in range(G)]
 solvers[0].set_deferral(min_it, factor)
 for rep in range(2):
     r = solve_batches(solvers, batches)
 log = solvers[0].deferral_log()
-out_dir = pathlib.Path(__file__).resolve().parent.parent / 'gpurun_out' / 'defer'
+out_dir = pathlib.Path(__file__).resolve().parent.parent.parent / 'gpurun_out' / 'defer'
 out_dir.mkdir(parents=True, exist_ok=True)
 np.save(out_dir / f'log_{name}_{G}_{min_it}.npy', log)
 ms = lambda t: np.asarray(t) * 1e-5
