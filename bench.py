@@ -564,6 +564,9 @@ EXTRA_LEGS = (
     dict(tag='configs[2] size, solvable game --qp osqp, B=4096', workload='kb_curve3_N25', qp='osqp', batch=4096, timeout=60, **_ONE),
     dict(tag='configs[4] --qp osqp, reduced batch B=1024', workload='merge6_N25', qp='osqp', batch=1024, timeout=120, **_ONE),
     dict(tag='configs[3] --qp osqp, reduced batch B=1024', workload='kb_f1_N50', qp='osqp', batch=1024, timeout=60, **_ONE),
+    # BASELINE configs[0], the reference's own CPU-runnable case: ONE scenario of the N = 15 chicane game per launch, twenty launches one after the
+    # other -- `value` is then solves per second of a caller that solves sample by sample as the reference's scripts do (1 / value = latency)
+    dict(tag='configs[0] one scenario per launch (1 / value = latency of a solve)', workload='kb_chicane_N15', batch=1, steps=20, warmup=5, pipeline=1, batches=4, group=1, timeout=30),
     # (the circuit game with OSQP -- 99 % of its solves fail, as the reference's would -- and the opt-in fp32 storage of the ADMM iteration's K^-1
     # are timed by tools/measure_round6.sh, not by every default run: profiles/r06_bench_kb_barc3_N25_B4096_qp_osqp.json, ..._qp_osqp_mixed.json)
 )

@@ -26,6 +26,7 @@ rows = ['| workload (fp64) | layout / QP | scen/s (`value`) | batch x steps | co
         '|---|---|---|---|---|---|---|---|---|---|---|']
 lab = {'configs[1] (the headline)': ('**configs[1]** 2-agent dynamic bicycle curve N=25, rk4 M=10, reg 1e-3', 'LDS, exact QP'),
        'configs[1] --qp osqp': ("same game, **`--qp osqp`** (the reference's own QP arithmetic)", 'LDS, OSQP'),
+       'configs[0] one scenario per launch (1 / value = latency of a solve)': ('**configs[0]** 2-agent kinematic chicane N=15, ONE scenario per launch, twenty launches one after the other (`value` = solves/s of a sample-by-sample caller; 1 / value = latency)', 'LDS, exact QP'),
        'configs[2] B=4096': ('**configs[2]** 3-car BARC circuit N=25 (n = 150), reg 0', 'XL packed, exact QP'),
        'configs[2] size, solvable game, B=4096': ('3-car curve-track race N=25 (`agents.py`, M = 3): the solvable game of configs[2]\'s size', 'XL packed, exact QP'),
        'configs[3] B=16384': ('**configs[3]** 2-car F1 track N=50 (n = 200), reg 1e-3', 'XL, exact QP'),
@@ -88,6 +89,7 @@ def baseline_table():
             add('1. 2-agent dyn-bicycle curve N=25, B=1024 — exact QP (the headline `value`)', "the reference's own dynamic game (`exact_dynamic_game_dynamic.py`, cost_setting 0) on the curve track, rk4 M=10, DG-SQP v1", '1,024 x 20 steps in ONE cooperative launch', 'configs[1] (the headline)',
                 f"one launch at a time {f(d['value_single_launch'])}; host-inclusive {f(d['value_host_inclusive'])} (one batch) / {f(d['value_host_inclusive_grouped'])} (the twenty batches together); device = oracle on every oracle-stable scenario of the fixture",
                 cpu=f"{cb['value']:.1f} sustained / {cb['value_wall']:.1f} wall ({cb['cores']} threads) / {cb['value_one_core']:.2f} one core"),
+            add('0. 2-agent KB chicane N=15, single scenario', "`kinematic_racing_game('chicane', N=15)`, one scenario per launch (what a caller that solves sample by sample, as the reference's scripts do, gets)", '1 x 20 launches', 'configs[0] one scenario per launch (1 / value = latency of a solve)', '1 / value = 2.8 ms per solve, inputs resident; the C++ restatement takes 19 ms for such a solve on one host core; parity fixture `tests/golden/kb_chicane_N15.npz`, `__graft_entry__.smoke()`'),
             add('1. same — OSQP (`--qp osqp`)', "same game, `qp_method='osqp'` (`csrc/dgsqp_osqp.h`)", '1,024 x 20', 'configs[1] --qp osqp', 'follows the numpy loop + restated OSQP on 98.6 % of the scenarios that loop itself reproduces (`profiles/r06_osqp_vs_pyref.txt`)'),
             add('2. 3-agent BARC track N=25, B=4096', '`barc_racing_game(N=25, M=3)` (n = 150, 825 rows, XL layout with packed LDS matrices)', '4,096 in one cooperative launch', 'configs[2] B=4096', "DG-SQP v1 fails on this game — LP-certified infeasible linearisations, 98 % of the numpy + OSQP loop's solves raise (DESIGN.md §2); fp64 (the config names fp32)"),
             add("2'. the solvable game of that size", '3-car curve-track race (`DGSQP_monte_carlo_agents.py`, M = 3, N = 25)', '4,096', 'configs[2] size, solvable game, B=4096', 'the line to read for n = 150'),
