@@ -739,6 +739,30 @@ def test_bench_extra_legs_respect_the_wall_budget(monkeypatch, capsys, tmp_path)
     assert line['roofline']['flop_model']['pad'] and 'status_fractions' in line
 
 
+def test_bench_compact_line_of_a_multi_rank_run():
+    """What rank 0 prints when N > 1 (the driver's SCALE runs): the same compact line -- contract keys, `cpu_baseline` null with its note (timed at
+    N = 1 only), every rank's own elapsed time -- under 4 KB also at 8 ranks, no `workloads` (the extra legs ride on the 1-GPU default run)."""
+    import json
+    sys.path.insert(0, str(ROOT))
+    import bench
+    full = {'metric': 'Monte-Carlo scenarios/sec (SQP solves/sec), 2-agent N=25', 'value': 90000.123456, 'unit': 'scenarios/s', 'n_gpus': 8, 'steps': 20, 'warmup': 5, 'ms_per_step': 91.0,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'dyn_curve_N25', 'description': 'd' * 300, 'batch_per_gpu': 1024, 'batch_total': 8192, 'n': 100, 'n_c': 325, 'parallelism': 'scenario-sharded x8', 'layout': 'lds',
+                       'qp_method': 'active_set', 'reg': 1e-3, 'distinct_batches': 20, 'batches_per_launch': 20, 'launches_in_flight': 5, 'cooperative_line_search': 'auto', 'shard_mode': 'x' * 100},
+            'roofline': {'bound': 'valu_fp64', 'achieved': 30.0, 'peak': 78.6, 'unit': 'TFLOP/s', 'frac': 0.38, 'frac_executed_upper_bound': None, 'traffic': None, 'traffic_note': 'n' * 300, 'kernel': 'dg_solve_kernel',
+                         'kernel_ms': 1800.0, 'launches_timed': 1, 'solves_per_launch': 20480.0, 'hbm': {'achieved': 0.7, 'peak': 8000.0, 'unit': 'GB/s', 'frac': 9e-5}, 'flop_model': {'pad': 'z' * 2000}},
+            'cpu_baseline': None, 'cpu_baseline_note': 'timed on rank 0 of the 1-GPU run only (bench.py --gpus 1)', 'value_single_launch': 15000.0, 'value_host_inclusive': 13000.0,
+            'value_host_inclusive_grouped': 88000.0, 'mean_iters': 5.6, 'mean_iters_all': 6.5, 'mean_qp_solves': 10.5, 'converged_fraction': 0.94, 'elapsed_s': 1.82,
+            'elapsed_s_per_rank': [1.80, 1.81, 1.79, 1.82, 1.80, 1.78, 1.81, 1.80]}
+    out = bench.compact_line(full)
+    text = json.dumps(out, separators=(',', ':'))
+    assert len(text) < 4096 and out['n_gpus'] == 8 and out['cpu_baseline'] is None
+    assert out['cpu_baseline_note'].startswith('timed on rank 0') and len(out['elapsed_s_per_rank']) == 8 and 'workloads' not in out and 'value_qp_osqp' not in out
+    assert out['config']['parallelism'] == 'scenario-sharded x8' and 'flop_model' not in out['roofline'] and len(out['roofline']['traffic_note']) <= 120
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+        assert key in out, key
+
+
 def test_bench_leg_child_process_is_killed_at_its_timeout(monkeypatch, tmp_path):
     """run_leg starts `bench.py` as a child (never an exec) and a child that hangs costs its own record: subprocess.TimeoutExpired after the
     leg's timeout, the child gone; a child that fails raises with its stderr (stand-in scripts, no GPU)."""
