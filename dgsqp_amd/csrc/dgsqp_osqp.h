@@ -184,25 +184,36 @@ __device__ inline void osqp_build_w(const DgProb& D, const OsqpPtrs& o) {
     o.yd[d] = ep * ep + en * en;
   }
   __syncthreads();
-  for (int e = TID; e < n * n; e += NT) {
-    const int i = e / n, j = e - i * n;
-    if (j > i) continue;
-    const int ai = i / (D.N * DGSQP_NUA), ri = i % (D.N * DGSQP_NUA), ti = ri / DGSQP_NUA, ji = ri % DGSQP_NUA;
-    const int aj = j / (D.N * DGSQP_NUA), rj = j % (D.N * DGSQP_NUA), tj = rj / DGSQP_NUA, jj = rj % DGSQP_NUA;
+  // one thread per pair of the lower triangle, enumerated in STAGE-MAJOR column order (column c' = t M nu + a nu + j): for i' >= j' the
+  // later stage is i''s, so the gradients a pair sums over -- those of the stages after max(t_i, t_j) -- depend on i' alone and the lanes of
+  // a wavefront (consecutive pairs: mostly one i') loop over the same range.  (Round 5 walked all n^2 entries and skipped the upper half:
+  // half the lanes idle, loop lengths mixed within a wavefront -- 0.52 Mcycles per QP at n = 100.)  Same sums in the same order per pair.
+  const int NU = DGSQP_NUA, MN = D.M * NU;
+  for (int p = TID; p < n * (n + 1) / 2; p += NT) {
+    int ip = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
+    while ((ip + 1) * (ip + 2) / 2 <= p) ip++;
+    while (ip * (ip + 1) / 2 > p) ip--;
+    const int jp = p - ip * (ip + 1) / 2;                     // stage-major indices, jp <= ip
+    const int ti = ip / MN, ai = (ip - ti * MN) / NU, ji = ip % NU;
+    const int tj = jp / MN, aj = (jp - tj * MN) / NU, jj = jp % NU;
+    int i = ai * D.N * NU + ti * NU + ji, j = aj * D.N * NU + tj * NU + jj;      // agent-major columns (the decision vector's order)
+    if (j > i) { const int t_ = i; i = j; j = t_; }           // (the pair is stored at both places; the summation below is symmetric in its two entries
+    const int Ai = i / (D.N * NU), Ti = (i % (D.N * NU)) / NU, Ji = i % NU;        //  only up to the order of the two factors of a product: keep round 5's (i >= j))
+    const int Aj = j / (D.N * NU), Tj = (j % (D.N * NU)) / NU, Jj = j % NU;
     double s = 0;
-    for (int d = D.stage_dense0[(ti > tj ? ti : tj) + 1]; d < D.ndense; d++) {
+    for (int d = D.stage_dense0[(Ti > Tj ? Ti : Tj) + 1]; d < D.ndense; d++) {
       const DgDense dd = ld_dense(d);
-      const double gi = osqp_dense_entry(dd, o.gd, ai, ti, ji);
+      const double gi = osqp_dense_entry(dd, o.gd, Ai, Ti, Ji);
       if (gi == 0.0) continue;
-      s = __builtin_fma(o.yd[d] * gi, osqp_dense_entry(dd, o.gd, aj, tj, jj), s);
+      s = __builtin_fma(o.yd[d] * gi, osqp_dense_entry(dd, o.gd, Aj, Tj, Jj), s);
     }
-    if (ai == aj && ji == jj) {
+    if (Ai == Aj && Ji == Jj) {
       auto e2 = [&](int r) { const double ev = r >= 0 ? o.E[r] : 0.0; return ev * ev; };
-      if (ti == tj) {
-        s += e2(D.r_in_ub[ai][ti][ji]) + e2(D.r_in_lb[ai][ti][ji]) + e2(D.r_rate_ub[ai][ti][ji]) + e2(D.r_rate_lb[ai][ti][ji]);
-        if (ti + 1 < D.N) s += e2(D.r_rate_ub[ai][ti + 1][ji]) + e2(D.r_rate_lb[ai][ti + 1][ji]);
-      } else if (ti - tj == 1) {
-        s -= e2(D.r_rate_ub[ai][ti][ji]) + e2(D.r_rate_lb[ai][ti][ji]);     // (rate rows of stage t: +1 at t, -1 at t - 1)
+      if (Ti == Tj) {
+        s += e2(D.r_in_ub[Ai][Ti][Ji]) + e2(D.r_in_lb[Ai][Ti][Ji]) + e2(D.r_rate_ub[Ai][Ti][Ji]) + e2(D.r_rate_lb[Ai][Ti][Ji]);
+        if (Ti + 1 < D.N) s += e2(D.r_rate_ub[Ai][Ti + 1][Ji]) + e2(D.r_rate_lb[Ai][Ti + 1][Ji]);
+      } else if (Ti - Tj == 1) {
+        s -= e2(D.r_rate_ub[Ai][Ti][Ji]) + e2(D.r_rate_lb[Ai][Ti][Ji]);     // (rate rows of stage t: +1 at t, -1 at t - 1)
       }
     }
     s *= o.Dv[i] * o.Dv[j];
