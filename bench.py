@@ -212,6 +212,9 @@ def parse_args(argv=None):
     ap.add_argument('--mixed-precision', action='store_true',
                     help="dgsqp_params_t.mixed_precision (off by default): with --qp osqp on the XL layout (configs[2], [3], [4]) the ADMM iteration's "
                          "explicit K^-1 is stored in fp32 (fp64 accumulation); everything else stays fp64.  'dtype' of the line then says 'f64 (K^-1 of the ADMM iteration f32)'")
+    ap.add_argument('--wg-per-cu', type=int, choices=(1, 2), default=1,
+                    help='2: solve on libdgsqp_hip_b256.so -- 256-thread workgroups, half the LDS arena, two workgroups per CU (row N1: large batches of n <= 64 games; '
+                         'explicit-inverse layouts with the active-set QP only)')
     ap.add_argument('--eig-floor', type=float, default=None, help='_nearestPD floor (default: the literal 1e-10, DGSQP.py:1293)')
     ap.add_argument('--snap-active-bounds', action='store_true', help='implementation knob, see include/dgsqp.h (default: literal)')
     ap.add_argument('--extras-budget', type=float, default=300.0,
@@ -257,7 +260,8 @@ def _run_workload(args, rank, local_rank, world, held):
 
     game = make_game(args.workload, args.reg)
     mk = lambda: DGSQP(*game.solver_args(), print_method=None, device=local_rank, eig_floor=args.eig_floor,
-                       snap_active_bounds=args.snap_active_bounds, qp_method=args.qp, mixed_precision=getattr(args, 'mixed_precision', False))
+                       snap_active_bounds=args.snap_active_bounds, qp_method=args.qp, mixed_precision=getattr(args, 'mixed_precision', False),
+                       workgroups_per_cu=getattr(args, 'wg_per_cu', 1))
     P = max(1, args.pipeline)
     if args.group <= 0:
         args.group = args.steps if args.steps <= 24 else 12
@@ -477,7 +481,7 @@ def _run_workload(args, rank, local_rank, world, held):
                                    'merge': 'scripts/DGSQP_merge_monte_carlo.py:421-480, zero warm start'}.get(
                                        game.sampler, 'scripts/DGSQP_ALGAMES_monte_carlo_curve.py:384-467, PID warm start') + ' (seed 1 + rank + 1000 * batch)',
                        'distinct_batches': n_batches, 'batches_per_launch': max(1, args.group), 'layout': {0: 'lds', 1: 'big', 2: 'xl'}[int(d.layout)],
-                       'launches_in_flight': P, 'batches_in_flight': P * max(1, args.group), 'cooperative_line_search': args.coop, 'qp_method': args.qp, 'reg': float(game.params.reg), 'eig_floor': float(solver._cparams.eig_floor),
+                       'launches_in_flight': P, 'batches_in_flight': P * max(1, args.group), 'workgroups_per_cu': int(getattr(args, 'wg_per_cu', 1)), 'cooperative_line_search': args.coop, 'qp_method': args.qp, 'reg': float(game.params.reg), 'eig_floor': float(solver._cparams.eig_floor),
                        'snap_active_bounds': int(solver._cparams.snap_active_bounds)},
             'elapsed_s': elapsed, 'elapsed_s_per_rank': elapsed_per_rank,        # each rank's own time for its K steps: load imbalance between the shards shows here
             'value_single_launch': single['value'] if single else None,
@@ -567,6 +571,10 @@ EXTRA_LEGS = (
     # BASELINE configs[0], the reference's own CPU-runnable case: ONE scenario of the N = 15 chicane game per launch, twenty launches one after the
     # other -- `value` is then solves per second of a caller that solves sample by sample as the reference's scripts do (1 / value = latency)
     dict(tag='configs[0] one scenario per launch (1 / value = latency of a solve)', workload='kb_chicane_N15', batch=1, steps=20, warmup=5, pipeline=1, batches=4, group=1, timeout=30),
+    # ... and the same game in batches of 1,024 (twenty in one launch, like the headline) on the product build and on the two-workgroups-per-CU build
+    # (row N1: libdgsqp_hip_b256.so, DGSQP(workgroups_per_cu=2))
+    dict(tag="configs[0]'s game, B=1024 x 20, one 512-thread workgroup per CU", workload='kb_chicane_N15', timeout=30),
+    dict(tag="configs[0]'s game, B=1024 x 20, two 256-thread workgroups per CU", workload='kb_chicane_N15', wg_per_cu=2, timeout=30),
     # (the circuit game with OSQP -- 99 % of its solves fail, as the reference's would -- and the opt-in fp32 storage of the ADMM iteration's K^-1
     # are timed by tools/measure_round6.sh, not by every default run: profiles/r06_bench_kb_barc3_N25_B4096_qp_osqp.json, ..._qp_osqp_mixed.json)
 )
@@ -589,6 +597,8 @@ def run_leg(leg, args, timeout):
            '--coop', args.coop, '--single-steps', '0', '--host-steps', '0', '--cpu-sample', '0', '--extras', 'off', '--line', 'full']
     if leg.get('mixed_precision'):
         cmd.append('--mixed-precision')
+    if leg.get('wg_per_cu', 1) != 1:
+        cmd += ['--wg-per-cu', str(leg['wg_per_cu'])]
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
     if out.returncode != 0:
@@ -610,7 +620,7 @@ def compact_line(line, records=None, sidecar=None):
     c, r = line['config'], line['roofline']
     out = {k: line[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data')}
     out['config'] = {k: c[k] for k in ('workload', 'batch_per_gpu', 'batch_total', 'n', 'n_c', 'parallelism', 'layout', 'qp_method', 'reg', 'distinct_batches',
-                                       'batches_per_launch', 'launches_in_flight', 'cooperative_line_search') if k in c}
+                                       'batches_per_launch', 'launches_in_flight', 'cooperative_line_search', 'workgroups_per_cu') if k in c}
     out['roofline'] = {'bound': r['bound'], 'achieved': _sig(r['achieved']), 'peak': r['peak'], 'unit': r['unit'], 'frac': _sig(r['frac']),
                        'frac_is': 'algorithmic flops (SURVEY 8d model) / HIP-event time / peak', 'frac_executed_upper_bound': _sig(r.get('frac_executed_upper_bound')),
                        'traffic': r.get('traffic'), 'kernel': r['kernel'], 'kernel_ms': _sig(r['kernel_ms'], 7), 'launches_timed': r.get('launches_timed'),

@@ -97,21 +97,26 @@ class TimingT(C.Structure):
 _PD = C.POINTER(C.c_double)
 _PI = C.POINTER(C.c_int32)
 _LIB = None
+_LIBS = {}          # workgroups per CU -> CDLL (1: the product build; 2: libdgsqp_hip_b256.so, 256-thread workgroups and half the LDS arena)
 
 
-def library_path() -> pathlib.Path:
+def library_path(workgroups_per_cu: int = 1) -> pathlib.Path:
     env = os.environ.get('DGSQP_HIP_LIB')
     if env:
         return pathlib.Path(env)
-    return pathlib.Path(__file__).resolve().parent / 'csrc' / 'libdgsqp_hip.so'
+    name = {1: 'libdgsqp_hip.so', 2: 'libdgsqp_hip_b256.so'}[int(workgroups_per_cu)]
+    return pathlib.Path(__file__).resolve().parent / 'csrc' / name
 
 
-def load_library() -> C.CDLL:
-    """Load the HIP solver library; raise loudly if it is absent (no CPU fallback)."""
+def load_library(workgroups_per_cu: int = 1) -> C.CDLL:
+    """Load the HIP solver library; raise loudly if it is absent (no CPU fallback).  ``workgroups_per_cu=2`` loads the build with
+    256-thread workgroups, two per CU (row N1: large batches of n <= 64 games; the two libraries can live in one process)."""
     global _LIB
-    if _LIB is not None:
-        return _LIB
-    path = library_path()
+    if int(workgroups_per_cu) not in (1, 2):
+        raise ValueError('workgroups_per_cu: 1 (the product build) or 2 (libdgsqp_hip_b256.so)')
+    if int(workgroups_per_cu) in _LIBS:
+        return _LIBS[int(workgroups_per_cu)]
+    path = library_path(workgroups_per_cu)
     if not path.exists():
         raise RuntimeError(f'HIP solver library {path} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                            f'(hipcc --offload-arch=gfx950). There is no CPU fallback.')
@@ -196,7 +201,9 @@ def load_library() -> C.CDLL:
     lib.dgsqp_comm_barrier.restype = C.c_int
     lib.dgsqp_comm_allreduce_max.argtypes = [H, _PD, C.c_int]
     lib.dgsqp_comm_allreduce_max.restype = C.c_int
-    _LIB = lib
+    _LIBS[int(workgroups_per_cu)] = lib
+    if int(workgroups_per_cu) == 1:
+        _LIB = lib
     return lib
 
 

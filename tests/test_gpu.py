@@ -2159,6 +2159,33 @@ print(json.dumps(dict(block=int(tm.block), grid=int(tm.grid), cus=cus, lds=int(s
             assert rel(res['l'][b], gold['l'][b]) < 1e-5, b
 
 
+def test_workgroups_per_cu_option_in_one_process(games):
+    """DGSQP(..., workgroups_per_cu=2) runs that solver on libdgsqp_hip_b256.so while other solvers of the same process stay on the product
+    build (two libraries, two sets of kernels and constants side by side): the same scenarios through both give the same control flow and
+    the same iterates, the launches have 256- and 512-thread blocks, and a game the half-arena build cannot hold raises."""
+    import ctypes as C
+    from dgsqp_amd import _ffi, montecarlo as mc
+    from dgsqp_amd.solver import DGSQP
+    g = games['kb_chicane_N15'][0]
+    s1 = DGSQP(*g.solver_args(), print_method=None)
+    s2 = DGSQP(*g.solver_args(), print_method=None, workgroups_per_cu=2)
+    assert s1._lib is not s2._lib and s2.dims.lds_bytes <= (163840 - 512) // 2
+    x0, u = mc.sample_scenarios(g, 256, seed=11)
+    r1, r2, r1b = s1.solve_batch(x0, u), s2.solve_batch(x0, u), s1.solve_batch(x0, u)
+    same = (r1['status'] == r2['status']) & (r1['num_iters'] == r2['num_iters']) & (r1['qp_solves'] == r2['qp_solves'])
+    conv = same & (r1['status'] <= 1)
+    print(f'workgroups_per_cu 2 vs 1 in one process: identical (status, iterations, QPs) on {int(same.sum())}/256, iterates of the identical converged ones within '
+          f'{max(rel(r2["u"][b], r1["u"][b]) for b in np.nonzero(conv)[0]):.1e}')
+    assert same.sum() >= 250 and all(rel(r2['u'][b], r1['u'][b]) < 1e-5 for b in np.nonzero(conv)[0])
+    assert all(np.array_equal(r1[k], r1b[k]) for k in ('u', 'l', 'status', 'num_iters'))          # the product build's results do not depend on what the other library did in between
+    tm = _ffi.TimingT()
+    for sv, block in ((s1, 512), (s2, 256)):
+        assert sv._lib.dgsqp_stage_inputs(sv._h, 256, _ffi.dptr(np.ascontiguousarray(x0)), _ffi.dptr(np.ascontiguousarray(sv._to_agent_major(u)))) == 0
+        assert sv._lib.dgsqp_solve_staged(sv._h, C.byref(tm)) == 0 and tm.block == block
+    with pytest.raises(RuntimeError, match=r'\(-4\)'):
+        DGSQP(*games['kb_chicane_N25'][0].solver_args(), print_method=None, workgroups_per_cu=2)
+
+
 @pytest.mark.parametrize('script', ['chicane', 'comp', 'merge', 'agents', 'ablation'])
 def test_monte_carlo_example_drivers(tmp_path, script):
     """examples/monte_carlo_{chicane,comp,merge,agents,ablation}.py -- the DG-SQP legs of scripts/DGSQP_ALGAMES_monte_carlo_chicane.py

@@ -179,9 +179,16 @@ def test_solver_fails_loudly_without_gpu(games):
 def test_missing_library_is_an_error(monkeypatch, tmp_path):
     from dgsqp_amd import _ffi
     monkeypatch.setattr(_ffi, '_LIB', None)
+    monkeypatch.setattr(_ffi, '_LIBS', {})
     monkeypatch.setenv('DGSQP_HIP_LIB', str(tmp_path / 'nope.so'))
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         _ffi.load_library()
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        _ffi.load_library(2)
+    with pytest.raises(ValueError):
+        _ffi.load_library(3)
+    monkeypatch.delenv('DGSQP_HIP_LIB')
+    assert _ffi.library_path(1).name == 'libdgsqp_hip.so' and _ffi.library_path(2).name == 'libdgsqp_hip_b256.so'      # (workgroups per CU -> build)
 
 
 def test_product_never_imports_the_oracle():

@@ -27,6 +27,8 @@ rows = ['| workload (fp64) | layout / QP | scen/s (`value`) | batch x steps | co
 lab = {'configs[1] (the headline)': ('**configs[1]** 2-agent dynamic bicycle curve N=25, rk4 M=10, reg 1e-3', 'LDS, exact QP'),
        'configs[1] --qp osqp': ("same game, **`--qp osqp`** (the reference's own QP arithmetic)", 'LDS, OSQP'),
        'configs[0] one scenario per launch (1 / value = latency of a solve)': ('**configs[0]** 2-agent kinematic chicane N=15, ONE scenario per launch, twenty launches one after the other (`value` = solves/s of a sample-by-sample caller; 1 / value = latency)', 'LDS, exact QP'),
+       "configs[0]'s game, B=1024 x 20, one 512-thread workgroup per CU": ("configs[0]'s game (kinematic chicane N=15, n = 60) in batches of 1,024, the product build", 'LDS, exact QP'),
+       "configs[0]'s game, B=1024 x 20, two 256-thread workgroups per CU": ("same, **two 256-thread workgroups per CU** (row N1: `libdgsqp_hip_b256.so`, `DGSQP(workgroups_per_cu=2)`, `--wg-per-cu 2`)", 'LDS (half arena), exact QP'),
        'configs[2] B=4096': ('**configs[2]** 3-car BARC circuit N=25 (n = 150), reg 0', 'XL packed, exact QP'),
        'configs[2] size, solvable game, B=4096': ('3-car curve-track race N=25 (`agents.py`, M = 3): the solvable game of configs[2]\'s size', 'XL packed, exact QP'),
        'configs[3] B=16384': ('**configs[3]** 2-car F1 track N=50 (n = 200), reg 1e-3', 'XL, exact QP'),
